@@ -1,0 +1,298 @@
+"""TEST INFRASTRUCTURE — CPU oracle for the PraNet-V2 hot path.  NOT the product.
+
+A functional, plain-PyTorch-CPU fp32 restatement of the algorithm the reference
+runs between `optimizer.zero_grad()` and `optimizer.step()`
+(/root/reference/binary_seg/MyTrain_med.py:59-86).  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this file; the product path
+(pranet-v2_amd/) never does and raises if its HIP library is missing.
+
+Pinning: tests/test_oracle_golden.py checks every function here against vectors
+produced by the *imported reference itself* in the build container
+(tests/golden/make_golden.py -> tests/golden/*.npz).  The reference ships no tests
+or golden vectors for this path, so those generated vectors are the pin.
+
+All functions take a flat state_dict `P` (key -> tensor, reference names) and a key
+prefix, so no nn.Module of ours is involved: this file shares no code with the product.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Ctx:
+    """Mode + optional side effects (running-stat updates) of one forward."""
+
+    def __init__(self, training):
+        self.training = training
+
+
+def bn(P, name, x, ctx):
+    # nn.BatchNorm2d defaults (pranet.py:37, Res2Net_v1b.py:33): eps 1e-5, momentum 0.1,
+    # biased var for normalisation, unbiased for running_var; F.batch_norm updates P[...] in place.
+    y = F.batch_norm(x, P[name + ".running_mean"], P[name + ".running_var"], P[name + ".weight"], P[name + ".bias"],
+                     ctx.training, BN_MOMENTUM, BN_EPS)
+    if ctx.training:
+        P[name + ".num_batches_tracked"] += 1
+    return y
+
+
+def basic_conv(P, name, x, ctx, stride=1, padding=0, dilation=1):
+    # BasicConv2d.forward = bn(conv(x)), bias-free, NO ReLU  (pranet.py:40-43)
+    x = F.conv2d(x, P[name + ".conv.weight"], None, stride, padding, dilation)
+    return bn(P, name + ".bn", x, ctx)
+
+
+# --------------------------------------------------------------------------------------
+# Res2Net-50 v1b 26w x 4s  (Res2Net_v1b.py)
+# --------------------------------------------------------------------------------------
+def bottle2neck(P, p, x, ctx, stride, stage, has_down, scale=4):
+    # Res2Net_v1b.py:58-91
+    out = F.relu(bn(P, p + "bn1", F.conv2d(x, P[p + "conv1.weight"]), ctx))
+    width = out.shape[1] // scale
+    spx = torch.split(out, width, 1)
+    outs = []
+    sp = None
+    for i in range(scale - 1):
+        sp = spx[i] if (i == 0 or stage) else sp + spx[i]
+        sp = F.conv2d(sp, P[p + f"convs.{i}.weight"], None, stride, 1)
+        sp = F.relu(bn(P, p + f"bns.{i}", sp, ctx))
+        outs.append(sp)
+    if stage:
+        outs.append(F.avg_pool2d(spx[scale - 1], 3, stride, 1))        # :40, :80
+    else:
+        outs.append(spx[scale - 1])
+    out = torch.cat(outs, 1)
+    out = bn(P, p + "bn3", F.conv2d(out, P[p + "conv3.weight"]), ctx)
+    if has_down:
+        # AvgPool2d(k=stride, s=stride, ceil_mode=True, count_include_pad=False) -> 1x1 conv -> BN (:127-136)
+        r = F.avg_pool2d(x, stride, stride, 0, True, False)
+        r = bn(P, p + "downsample.2", F.conv2d(r, P[p + "downsample.1.weight"]), ctx)
+    else:
+        r = x
+    return F.relu(out + r)
+
+
+def res2net_features(P, p, x, ctx, layers=(3, 4, 6, 3)):
+    # stem + maxpool + layer1..4, as PraNet_V2.forward drives it (pranet.py:331-341)
+    x = F.relu(bn(P, p + "conv1.1", F.conv2d(x, P[p + "conv1.0.weight"], None, 2, 1), ctx))
+    x = F.relu(bn(P, p + "conv1.4", F.conv2d(x, P[p + "conv1.3.weight"], None, 1, 1), ctx))
+    x = F.conv2d(x, P[p + "conv1.6.weight"], None, 1, 1)
+    x = F.relu(bn(P, p + "bn1", x, ctx))
+    x = F.max_pool2d(x, 3, 2, 1)
+    feats = []
+    for li, nblk in enumerate(layers):
+        stride = 1 if li == 0 else 2
+        for b in range(nblk):
+            q = f"{p}layer{li + 1}.{b}."
+            x = bottle2neck(P, q, x, ctx, stride if b == 0 else 1, b == 0, b == 0)
+        feats.append(x)
+    return feats  # x1..x4
+
+
+# --------------------------------------------------------------------------------------
+# heads  (pranet.py)
+# --------------------------------------------------------------------------------------
+def rfb(P, p, x, ctx):
+    # RFB_modified.forward pranet.py:75-83
+    x0 = basic_conv(P, p + "branch0.0", x, ctx)
+    br = [x0]
+    for bi, k in ((1, 3), (2, 5), (3, 7)):
+        q = f"{p}branch{bi}."
+        y = basic_conv(P, q + "0", x, ctx)
+        y = basic_conv(P, q + "1", y, ctx, padding=(0, k // 2))
+        y = basic_conv(P, q + "2", y, ctx, padding=(k // 2, 0))
+        y = basic_conv(P, q + "3", y, ctx, padding=k, dilation=k)
+        br.append(y)
+    x_cat = basic_conv(P, p + "conv_cat", torch.cat(br, 1), ctx, padding=1)
+    return F.relu(x_cat + basic_conv(P, p + "conv_res", x, ctx))
+
+
+def up2_ac(x):
+    # nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)  (pranet.py:93)
+    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+
+
+def aggregation(P, p, x1, x2, x3, ctx, v1=False):
+    # pranet.py:109-125 (V2) / PraNet_Res2Net.py:83-98 (V1)
+    c = lambda n, t: basic_conv(P, p + n, t, ctx, padding=1)
+    x2_1 = c("conv_upsample1", up2_ac(x1)) * x2
+    x3_1 = c("conv_upsample2", up2_ac(up2_ac(x1))) * c("conv_upsample3", up2_ac(x2)) * x3
+    x2_2 = c("conv_concat2", torch.cat((x2_1, c("conv_upsample4", up2_ac(x1))), 1))
+    x3_2 = c("conv_concat3", torch.cat((x3_1, c("conv_upsample5", up2_ac(x2_2))), 1))
+    x = c("conv4", x3_2)
+    if v1:
+        return F.conv2d(x, P[p + "conv5.weight"], P[p + "conv5.bias"])
+    return (F.conv2d(x, P[p + "conv5_fg.weight"], P[p + "conv5_fg.bias"]),
+            F.conv2d(x, P[p + "conv5_bg.weight"], P[p + "conv5_bg.bias"]))
+
+
+def interp(x, scale):
+    # F.interpolate(x, scale_factor=s, mode='bilinear') -> align_corners=False, given scale used
+    return F.interpolate(x, scale_factor=scale, mode="bilinear")
+
+
+def dsra_fuse(fg, crop_fg, crop_bg, use_softmax=True):
+    # pranet.py:365-368 — bg is NOT modified
+    if use_softmax:
+        return fg + fg * F.softmax(crop_fg - crop_bg, dim=1)
+    return fg + fg * (crop_fg - crop_bg)
+
+
+def pranet_v2_forward(P, x, training, use_softmax=True, sem_downsample=1):
+    """PraNet_V2.forward (pranet.py:329-417).  Mutates BN running stats in P when training."""
+    ctx = Ctx(training)
+    x1, x2, x3, x4 = res2net_features(P, "backbone.", x, ctx)
+    x2_rfb = rfb(P, "rfb2_1.", x2, ctx)
+    x3_rfb = rfb(P, "rfb3_1.", x3, ctx)
+    x4_rfb = rfb(P, "rfb4_1.", x4, ctx)
+    ra5_fg, ra5_bg = aggregation(P, "agg1.", x4_rfb, x3_rfb, x2_rfb, ctx)
+    sd = sem_downsample
+    l5_fg, l5_bg = interp(ra5_fg, 8 / sd), interp(ra5_bg, 8 / sd)
+    # ---- DSRA3
+    c4_fg, c4_bg = interp(ra5_fg, 0.25), interp(ra5_bg, 0.25)
+    t = basic_conv(P, "ra4_conv1", x4, ctx)
+    for i in (2, 3, 4):
+        t = F.relu(basic_conv(P, f"ra4_conv{i}", t, ctx, padding=2))
+    ra4_fg = basic_conv(P, "ra4_conv5_fg", t, ctx)
+    ra4_bg = basic_conv(P, "ra4_conv5_bg", t, ctx)
+    ra4_fg = dsra_fuse(ra4_fg, c4_fg, c4_bg, use_softmax)
+    l4_fg, l4_bg = interp(ra4_fg, 32 / sd), interp(ra4_bg, 32 / sd)
+    # ---- DSRA2 / DSRA1
+    prev_fg, prev_bg = ra4_fg, ra4_bg
+    lat = {}
+    for s, xs, up in ((3, x3, 16), (2, x2, 8)):
+        c_fg, c_bg = interp(prev_fg, 2), interp(prev_bg, 2)
+        t = basic_conv(P, f"ra{s}_conv1", xs, ctx)
+        t = F.relu(basic_conv(P, f"ra{s}_conv2", t, ctx, padding=1))
+        t = F.relu(basic_conv(P, f"ra{s}_conv3", t, ctx, padding=1))
+        r_fg = basic_conv(P, f"ra{s}_conv4_fg", t, ctx, padding=1)
+        r_bg = basic_conv(P, f"ra{s}_conv4_bg", t, ctx, padding=1)
+        r_fg = dsra_fuse(r_fg, c_fg, c_bg, use_softmax)
+        lat[s] = (interp(r_fg, up / sd), interp(r_bg, up / sd))
+        prev_fg, prev_bg = r_fg, r_bg
+    return lat[2][0], lat[3][0], l4_fg, l5_fg, lat[2][1], lat[3][1], l4_bg, l5_bg
+
+
+def pranet_v1_forward(P, x, training):
+    """PraNet.forward (PraNet_Res2Net.py:130-186): reverse attention = (1 - sigmoid(crop)) gate."""
+    ctx = Ctx(training)
+    x1, x2, x3, x4 = res2net_features(P, "resnet.", x, ctx)
+    x2_rfb = rfb(P, "rfb2_1.", x2, ctx)
+    x3_rfb = rfb(P, "rfb3_1.", x3, ctx)
+    x4_rfb = rfb(P, "rfb4_1.", x4, ctx)
+    ra5 = aggregation(P, "agg1.", x4_rfb, x3_rfb, x2_rfb, ctx, v1=True)
+    l5 = interp(ra5, 8)
+    crop = interp(ra5, 0.25)
+    t = (-1 * torch.sigmoid(crop) + 1).expand(-1, 2048, -1, -1).mul(x4)
+    t = basic_conv(P, "ra4_conv1", t, ctx)
+    for i in (2, 3, 4):
+        t = F.relu(basic_conv(P, f"ra4_conv{i}", t, ctx, padding=2))
+    x = basic_conv(P, "ra4_conv5", t, ctx) + crop
+    l4 = interp(x, 32)
+    lats = {}
+    for s, xs, up in ((3, x3, 16), (2, x2, 8)):
+        crop = interp(x, 2)
+        t = (-1 * torch.sigmoid(crop) + 1).expand(-1, xs.shape[1], -1, -1).mul(xs)
+        t = basic_conv(P, f"ra{s}_conv1", t, ctx)
+        t = F.relu(basic_conv(P, f"ra{s}_conv2", t, ctx, padding=1))
+        t = F.relu(basic_conv(P, f"ra{s}_conv3", t, ctx, padding=1))
+        x = basic_conv(P, f"ra{s}_conv4", t, ctx, padding=1) + crop
+        lats[s] = interp(x, up)
+    return l5, l4, lats[3], lats[2]
+
+
+# --------------------------------------------------------------------------------------
+# loss / optimiser / eval tail
+# --------------------------------------------------------------------------------------
+def structure_loss(pred, pred_bg, mask_fg, mask_bg):
+    # MyTrain_med.py:19-38
+    weit = 1 + 5 * torch.abs(F.avg_pool2d(mask_fg, kernel_size=31, stride=1, padding=15) - mask_fg)
+    wsum = weit.sum(dim=(2, 3))
+    wbce = (weit * F.binary_cross_entropy_with_logits(pred, mask_fg, reduction="none")).sum(dim=(2, 3)) / wsum
+    wbce2 = (weit * F.binary_cross_entropy_with_logits(pred_bg, mask_bg, reduction="none")).sum(dim=(2, 3)) / wsum
+    p = torch.sigmoid(pred)
+    inter = ((p * mask_fg) * weit).sum(dim=(2, 3))
+    union = ((p + mask_fg) * weit).sum(dim=(2, 3))
+    wiou = 1 - (inter + 1) / (union - inter + 1)
+    return (wbce + wiou + 0.8 * wbce2).mean()
+
+
+def total_loss(outs, gts):
+    # MyTrain_med.py:74-82 : four (fg,bg) pairs, same masks
+    bg = 1 - gts
+    return sum(structure_loss(outs[i], outs[i + 4], gts, bg) for i in range(4))
+
+
+def params_of(P):
+    """Keys that nn.Module.parameters() would yield (everything except BN buffers)."""
+    return [k for k in P if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
+
+
+def train_step(P, opt_state, x, gts, lr=1e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8, forward=pranet_v2_forward):
+    """One MyTrain_med.py:59-86 step on CPU: fwd, 4x structure_loss, bwd, clamp(+-clip), Adam.
+
+    Mutates P (params + BN buffers) and opt_state {"step", "m", "v"}; returns (loss, outs, grads).
+    """
+    keys = params_of(P)
+    for k in keys:
+        P[k].requires_grad_(True); P[k].grad = None
+    outs = forward(P, x, True)
+    loss = total_loss(outs, gts)
+    loss.backward()
+    grads = {}
+    opt_state["step"] = opt_state.get("step", 0) + 1
+    t = opt_state["step"]
+    with torch.no_grad():
+        for k in keys:
+            g = P[k].grad
+            P[k].requires_grad_(False)
+            if g is None:
+                continue
+            g = g.clamp(-clip, clip)                           # utils/utils.py:14-17
+            grads[k] = g
+            m = opt_state.setdefault("m", {}).setdefault(k, torch.zeros_like(g))
+            v = opt_state.setdefault("v", {}).setdefault(k, torch.zeros_like(g))
+            m.mul_(betas[0]).add_(g, alpha=1 - betas[0])       # torch.optim.Adam, no wd / amsgrad
+            v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+            bc1, bc2 = 1 - betas[0] ** t, 1 - betas[1] ** t
+            denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+            P[k].addcdiv_(m, denom, value=-lr / bc1)
+            P[k].grad = None
+    return loss.detach(), [o.detach() for o in outs], grads
+
+
+def test_postprocess(outs, gt_shape):
+    # MyTest_med.py:104-111 : sum of the 4 fg maps -> bilinear to GT size -> sigmoid -> min-max -> uint8
+    res = outs[0] + outs[1] + outs[2] + outs[3]
+    res = F.interpolate(res, size=gt_shape, mode="bilinear", align_corners=False)
+    res = res.sigmoid().squeeze()
+    res = (res - res.min()) / (res.max() - res.min() + 1e-8)
+    return (res.numpy() * 255).astype("uint8")
+
+
+def mean_dice(pred_u8, gt):
+    """meanDic of eval.py:22,44-50 + eval_functions.py:131-166 (Fmeasure_calu Dice over 256 thresholds)."""
+    import numpy as np
+    pred = pred_u8.astype(np.float64) / 255.0
+    gt = gt > 0.5
+    dice = np.zeros(256)
+    thr = np.linspace(1, 0, 256)
+    for i, t in enumerate(thr):
+        lab = pred >= t if t <= 1 else np.zeros_like(gt)
+        num_rec, num_no_rec = lab.sum(), (~lab).sum()
+        lab_and = lab & gt
+        num_and, num_obj = lab_and.sum(), gt.sum()
+        if num_and == 0:
+            dice[i] = 0
+        else:
+            dice[i] = 2.0 * num_and / (num_obj + num_rec)
+    return float(dice.mean())
+
+
+def clone_sd(sd):
+    return OrderedDict((k, v.clone()) for k, v in sd.items())

@@ -1,0 +1,166 @@
+"""TEST INFRASTRUCTURE — not part of the product path.
+
+Deterministic state_dict builder shared by the golden-vector generator
+(tests/golden/make_golden.py, run in the build container next to the imported
+reference) and by the parity tests (run on the GPU box, where the reference does
+not exist).  The full PraNet-V2 state_dict is 130 MB, far too big to commit, so
+fixtures carry only (seed, key->shape manifest, expected outputs) and both sides
+regenerate the identical weights from this file.
+
+Key names / shapes restate what the reference classes register:
+  PraNet_V2            /root/reference/binary_seg/lib/pranet.py:268-325
+  RFB_modified         pranet.py:46-74      aggregation  pranet.py:86-104
+  Res2Net / Bottle2neck /root/reference/binary_seg/lib/Res2Net_v1b.py:15-56,95-146
+  PraNet (V1)          /root/reference/binary_seg/lib/PraNet_Res2Net.py:101-128
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+
+def _conv(m, name, cout, cin, kh, kw, bias=False):
+    m[name + ".weight"] = (cout, cin, kh, kw)
+    if bias:
+        m[name + ".bias"] = (cout,)
+
+
+def _bn(m, name, c):
+    m[name + ".weight"] = (c,)
+    m[name + ".bias"] = (c,)
+    m[name + ".running_mean"] = (c,)
+    m[name + ".running_var"] = (c,)
+    m[name + ".num_batches_tracked"] = ()
+
+
+def _basic(m, name, cin, cout, k):
+    kh, kw = (k, k) if isinstance(k, int) else k
+    _conv(m, name + ".conv", cout, cin, kh, kw)
+    _bn(m, name + ".bn", cout)
+
+
+def _res2net(m, p, layers=(3, 4, 6, 3), base_width=26, scale=4):
+    _conv(m, p + "conv1.0", 32, 3, 3, 3); _bn(m, p + "conv1.1", 32)
+    _conv(m, p + "conv1.3", 32, 32, 3, 3); _bn(m, p + "conv1.4", 32)
+    _conv(m, p + "conv1.6", 64, 32, 3, 3)
+    _bn(m, p + "bn1", 64)
+    inplanes = 64
+    for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), layers)):
+        stride = 1 if li == 0 else 2
+        for b in range(nblk):
+            q = f"{p}layer{li + 1}.{b}."
+            width = int(math.floor(planes * (base_width / 64.0)))
+            _conv(m, q + "conv1", width * scale, inplanes, 1, 1); _bn(m, q + "bn1", width * scale)
+            for i in range(scale - 1):
+                _conv(m, q + f"convs.{i}", width, width, 3, 3)
+            for i in range(scale - 1):
+                _bn(m, q + f"bns.{i}", width)
+            _conv(m, q + "conv3", planes * 4, width * scale, 1, 1); _bn(m, q + "bn3", planes * 4)
+            if b == 0 and (stride != 1 or inplanes != planes * 4):
+                _conv(m, q + "downsample.1", planes * 4, inplanes, 1, 1); _bn(m, q + "downsample.2", planes * 4)
+            inplanes = planes * 4
+    m[p + "fc.weight"] = (1000, 2048)
+    m[p + "fc.bias"] = (1000,)
+
+
+def _rfb(m, p, cin, c):
+    _basic(m, p + "branch0.0", cin, c, 1)
+    for bi, k in ((1, 3), (2, 5), (3, 7)):
+        q = f"{p}branch{bi}."
+        _basic(m, q + "0", cin, c, 1)
+        _basic(m, q + "1", c, c, (1, k))
+        _basic(m, q + "2", c, c, (k, 1))
+        _basic(m, q + "3", c, c, 3)
+    _basic(m, p + "conv_cat", 4 * c, c, 3)
+    _basic(m, p + "conv_res", cin, c, 1)
+
+
+def _agg(m, p, c, num_class=None):
+    for i in (1, 2, 3, 4):
+        _basic(m, p + f"conv_upsample{i}", c, c, 3)
+    _basic(m, p + "conv_upsample5", 2 * c, 2 * c, 3)
+    _basic(m, p + "conv_concat2", 2 * c, 2 * c, 3)
+    _basic(m, p + "conv_concat3", 3 * c, 3 * c, 3)
+    _basic(m, p + "conv4", 3 * c, 3 * c, 3)
+    if num_class is None:  # V1: single head
+        _conv(m, p + "conv5", 1, 3 * c, 1, 1, bias=True)
+    else:
+        _conv(m, p + "conv5_fg", num_class, 3 * c, 1, 1, bias=True)
+        _conv(m, p + "conv5_bg", num_class, 3 * c, 1, 1, bias=True)
+
+
+def manifest_pranet_v2(num_class=1, channel=32):
+    """key -> shape, in the order the reference's state_dict() yields them."""
+    m = OrderedDict()
+    _conv(m, "conv.0", 3, 1, 1, 1, bias=True); _bn(m, "conv.1", 3)
+    _res2net(m, "backbone.")
+    _rfb(m, "rfb2_1.", 512, channel); _rfb(m, "rfb3_1.", 1024, channel); _rfb(m, "rfb4_1.", 2048, channel)
+    _agg(m, "agg1.", channel, num_class)
+    _basic(m, "ra4_conv1", 2048, 256, 1)
+    for i in (2, 3, 4):
+        _basic(m, f"ra4_conv{i}", 256, 256, 5)
+    _basic(m, "ra4_conv5_fg", 256, num_class, 1); _basic(m, "ra4_conv5_bg", 256, num_class, 1)
+    for s, cin in ((3, 1024), (2, 512)):
+        _basic(m, f"ra{s}_conv1", cin, 64, 1)
+        _basic(m, f"ra{s}_conv2", 64, 64, 3); _basic(m, f"ra{s}_conv3", 64, 64, 3)
+        _basic(m, f"ra{s}_conv4_fg", 64, num_class, 3); _basic(m, f"ra{s}_conv4_bg", 64, num_class, 3)
+    return m
+
+
+def manifest_pranet_v1(channel=32):
+    m = OrderedDict()
+    _res2net(m, "resnet.")
+    _rfb(m, "rfb2_1.", 512, channel); _rfb(m, "rfb3_1.", 1024, channel); _rfb(m, "rfb4_1.", 2048, channel)
+    _agg(m, "agg1.", channel, None)
+    _basic(m, "ra4_conv1", 2048, 256, 1)
+    for i in (2, 3, 4):
+        _basic(m, f"ra4_conv{i}", 256, 256, 5)
+    _basic(m, "ra4_conv5", 256, 1, 1)
+    for s, cin in ((3, 1024), (2, 512)):
+        _basic(m, f"ra{s}_conv1", cin, 64, 1)
+        _basic(m, f"ra{s}_conv2", 64, 64, 3); _basic(m, f"ra{s}_conv3", 64, 64, 3)
+        _basic(m, f"ra{s}_conv4", 64, 1, 3)
+    return m
+
+
+def make_state_dict(manifest, seed=0):
+    """Deterministic non-trivial weights: every tensor from its own CPU generator.
+
+    conv/linear: N(0, sqrt(2/fan_in))·0.9 ; BN gamma U(0.6,1.4), beta N(0,0.1),
+    running_mean N(0,0.1), running_var U(0.6,1.4).  Values are chosen so that
+    activations stay O(1) through ~60 layers in both train and eval mode.
+    """
+    sd = OrderedDict()
+    for idx, (k, shape) in enumerate(manifest.items()):
+        g = torch.Generator(device="cpu").manual_seed(seed * 100003 + idx)
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(shape, generator=g) * 0.8 + 0.6
+        elif k.endswith("running_mean"):
+            sd[k] = torch.randn(shape, generator=g) * 0.1
+        elif len(shape) == 1 and k.endswith(".weight"):      # BN gamma
+            sd[k] = torch.rand(shape, generator=g) * 0.8 + 0.6
+        elif len(shape) == 1:                                  # biases (BN beta, conv/fc bias)
+            sd[k] = torch.randn(shape, generator=g) * 0.1
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            sd[k] = torch.randn(shape, generator=g) * (0.9 * math.sqrt(2.0 / fan_in))
+    return sd
+
+
+def synthetic_batch(n, size, seed=1234):
+    """Images N(0,1) and polyp-like masks (1-3 filled ellipses, float {0,1}) — SURVEY §8(d)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn((n, 3, size, size), generator=g)
+    yy, xx = torch.meshgrid(torch.arange(size, dtype=torch.float32), torch.arange(size, dtype=torch.float32), indexing="ij")
+    mask = torch.zeros((n, 1, size, size))
+    for i in range(n):
+        k = int(torch.randint(1, 4, (1,), generator=g))
+        for _ in range(k):
+            cy, cx = (torch.rand(2, generator=g) * 0.6 + 0.2) * size
+            ry, rx = (torch.rand(2, generator=g) * 0.16 + 0.08) * size
+            mask[i, 0][((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = 1.0
+    return x, mask

@@ -1,0 +1,151 @@
+"""Pins oracle/ (the CPU restatement) against vectors produced by the imported reference
+(tests/golden/make_golden.py).  CPU only; no HIP code involved."""
+import json, os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pranet_oracle as O
+from oracle import weights as W
+
+torch.set_num_threads(8)
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 2e-5   # oracle vs reference: same torch CPU kernels, different op order in places
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_manifest_matches_reference():
+    ref = json.load(open(os.path.join(G, "manifest.json")))
+    ours = W.manifest_pranet_v2(1)
+    assert [(k, list(v)) for k, v in ours.items()] == [(k, v) for k, v in ref["pranet_v2_k1"].items()]
+    assert len(ours) == 949
+    ours1 = W.manifest_pranet_v1()
+    assert [(k, list(v)) for k, v in ours1.items()] == [(k, v) for k, v in ref["pranet_v1"].items()]
+    sd = W.make_state_dict(ours)
+    nparam = sum(v.numel() for k, v in sd.items() if k in O.params_of(sd))
+    assert nparam == ref["n_params_v2"] == 32548842
+
+
+@pytest.mark.parametrize("tag", ["rand", "zeros", "ones"])
+def test_structure_loss(tag):
+    z = np.load(os.path.join(G, "structure_loss.npz"))
+    pred = T(z[f"{tag}_pred"]).requires_grad_(True)
+    pred_bg = T(z[f"{tag}_pred_bg"]).requires_grad_(True)
+    mask = T(z[f"{tag}_mask"])
+    loss = O.structure_loss(pred, pred_bg, mask, 1 - mask)
+    loss.backward()
+    assert abs(float(loss) - float(z[f"{tag}_loss"])) < 1e-6
+    assert (pred.grad - T(z[f"{tag}_gpred"])).abs().max() < 1e-7
+    assert (pred_bg.grad - T(z[f"{tag}_gpred_bg"])).abs().max() < 1e-7
+
+
+@pytest.mark.parametrize("sm", [True, False])
+def test_dsra_k9(sm):
+    z = np.load(os.path.join(G, "dsra_k9.npz"))
+    fg, cf, cb = (T(z[k]).requires_grad_(True) for k in ("fg", "crop_fg", "crop_bg"))
+    y = O.dsra_fuse(fg, cf, cb, sm)
+    y.backward(T(z["gout"]))
+    tag = "sm" if sm else "nosm"
+    assert (y - T(z[tag + "_y"])).abs().max() < 1e-6
+    for t, k in ((fg, "gfg"), (cf, "gcf"), (cb, "gcb")):
+        assert (t.grad - T(z[f"{tag}_{k}"])).abs().max() < 1e-6
+
+
+def _block_sd(z, prefix):
+    sd = OrderedDict()
+    for k in z.files:
+        if k.startswith(prefix):
+            name = k[len(prefix):]
+            v = T(z[k]).clone()
+            if name.endswith("running_mean"): v.zero_()
+            if name.endswith("running_var"): v.fill_(1.0)
+            if name.endswith("num_batches_tracked"): v.zero_()
+            sd[name] = v
+    return sd
+
+
+def test_blocks():
+    z = np.load(os.path.join(G, "blocks.npz"))
+    sd = _block_sd(z, "b2n_sd.")
+    y = O.bottle2neck(sd, "", T(z["b2n_x"]), O.Ctx(True), 1, False, False)
+    assert (y - T(z["b2n_y"])).abs().max() < TOL
+    for k in sd:   # running stats after one train-mode forward
+        assert (sd[k].float() - T(z["b2n_sd." + k]).float()).abs().max() < TOL, k
+    sd = _block_sd(z, "b2s_sd.")
+    y = O.bottle2neck(sd, "", T(z["b2s_x"]), O.Ctx(True), 2, True, True)
+    assert (y - T(z["b2s_y"])).abs().max() < TOL
+    for k in sd:
+        assert (sd[k].float() - T(z["b2s_sd." + k]).float()).abs().max() < TOL, k
+    sd = _block_sd(z, "rfb_sd.")
+    y = O.rfb(sd, "", T(z["rfb_x"]), O.Ctx(True))
+    assert (y - T(z["rfb_y"])).abs().max() < TOL
+    sd = _block_sd(z, "agg_sd.")
+    fg, bg = O.aggregation(sd, "", T(z["agg_x1"]), T(z["agg_x2"]), T(z["agg_x3"]), O.Ctx(True))
+    assert (fg - T(z["agg_fg"])).abs().max() < 5e-4 * max(1.0, float(T(z["agg_fg"]).abs().max()))
+    assert (bg - T(z["agg_bg"])).abs().max() < 5e-4 * max(1.0, float(T(z["agg_bg"]).abs().max()))
+
+
+@pytest.mark.parametrize("tag,full", [("96", True), ("352", False)])
+def test_model_train_steps(tag, full):
+    z = np.load(os.path.join(G, f"pranet_v2_{tag}.npz"))
+    size, n = int(z["size"]), int(z["n"])
+    P = W.make_state_dict(W.manifest_pranet_v2(1), seed=0)
+    x, mask = W.synthetic_batch(n, size, seed=1234)
+    st = {}
+    for step in (1, 2):
+        loss, outs, grads = O.train_step(P, st, x, mask)
+        s = f"s{step}."
+        assert abs(float(loss) - float(z[s + "loss"])) < 2e-4
+        for i, o in enumerate(outs):
+            ref = T(z[s + f"out{i}"])
+            got = o if full else o[:, :, ::4, ::4]
+            assert (got - ref).abs().max() < 1e-4, (step, i)
+        for k in [f[len(s + "param."):] for f in z.files if f.startswith(s + "param.")]:
+            assert (P[k].reshape(-1)[:256] - T(z[s + "param." + k])).abs().max() < 2e-6, k
+        for k in [f[len(s + "buf."):] for f in z.files if f.startswith(s + "buf.")]:
+            assert (P[k].reshape(-1)[:256] - T(z[s + "buf." + k])).abs().max() < 1e-5, k
+        if step == 1:
+            assert sorted(k for k in O.params_of(P) if k not in grads) == sorted(str(s_) for s_ in z["nograd"])
+    # eval forward + MyTest tail + Dice
+    with torch.no_grad():
+        outs = O.pranet_v2_forward(P, x[:1], False)
+    for i, o in enumerate(outs):
+        ref = T(z[f"eval.out{i}"])
+        got = o if full else o[:, :, ::4, ::4]
+        assert (got - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max())), i
+    u8 = O.test_postprocess(outs, tuple(z["eval.u8"].shape))
+    assert np.abs(u8.astype(int) - z["eval.u8"].astype(int)).max() <= 1
+    assert abs(O.mean_dice(u8, z["eval.gt"]) - float(z["eval.meanDic"])) < 1e-3
+
+
+def test_grad_probes_96():
+    z = np.load(os.path.join(G, "pranet_v2_96.npz"))
+    P = W.make_state_dict(W.manifest_pranet_v2(1), seed=0)
+    x, mask = W.synthetic_batch(2, 96, seed=1234)
+    keys = O.params_of(P)
+    for k in keys:
+        P[k].requires_grad_(True)
+    loss = O.total_loss(O.pranet_v2_forward(P, x, True), mask)
+    loss.backward()
+    for f in z.files:
+        if f.startswith("graw."):
+            k = f[5:]
+            ref = T(z[f])
+            got = P[k].grad.reshape(-1)[:256]
+            scale = max(1e-3, float(ref.abs().max()))
+            assert (got - ref).abs().max() < 2e-3 * scale, k
+            assert abs(float(P[k].grad.norm()) - float(z["grawnorm." + k])) < 2e-3 * float(z["grawnorm." + k]) + 1e-6, k
+
+
+def test_v1_forward():
+    z = np.load(os.path.join(G, "pranet_v1_96.npz"))
+    P = W.make_state_dict(W.manifest_pranet_v1(), seed=1)
+    x, _ = W.synthetic_batch(2, 96, seed=77)
+    outs = O.pranet_v1_forward(P, x, True)
+    for i, o in enumerate(outs):
+        assert (o - T(z[f"out{i}"])).abs().max() < 1e-4, i
