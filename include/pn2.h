@@ -1,0 +1,155 @@
+/* pn2.h — C ABI of libpn2_hip.so: the MI355X (gfx950) PraNet-V2 hot-path kernels.
+ *
+ * The reference (ai4colonoscopy/PraNet-V2) has no native code and no FFI: its operator API is the
+ * nn.Module surface of binary_seg/lib and the torch ops those modules dispatch.  Each entry point
+ * below replaces the torch op(s) cited next to it (file:line under /root/reference/binary_seg);
+ * pranet-v2_amd/pn2/capi.py is the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; the library never frees);
+ *   - activations are NHWC views: base pointer at the view's first channel, `ld` = elements between pixels;
+ *   - dtype: PN2_F32 (exact fp32 parity path, v_mfma_f32_16x16x4_f32) or PN2_BF16 (bf16 storage, f32 accumulate);
+ *   - every call is asynchronous on `stream` (a hipStream_t); returns 0 on success, <0 for argument
+ *     errors (-1 null pointer, -2 unsupported geometry/alignment, -3 unknown dtype), >0 = hipError_t;
+ *   - no global state; safe to call from any thread / any stream; graph-capture safe (no sync, no malloc).
+ */
+#ifndef PN2_H
+#define PN2_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN2_F32 0
+#define PN2_BF16 1
+#define PN2_CONV_STATS 1   /* emit per-channel sum / sum-of-squares partials (fused BN batch statistics) */
+#define PN2_CONV_ACCUM 2   /* out += result (gradient accumulation) */
+
+/* ---------------------------------------------------------------------------------------------- conv
+ * F.conv2d / nn.Conv2d forward and its autograd backward:
+ *   lib/Res2Net_v1b.py:32,44,49,102-108,133 ; lib/pranet.py:34-36 (BasicConv2d), :52-73 (RFB), :94-104 (aggregation),
+ *   :303-325 (DSRA stacks) ; backward via MyTrain_med.py:84 (loss.backward()).                      */
+typedef struct pn2_conv_desc {
+    int N, H, W;            /* gathered tensor (x for forward, dy for dgrad) */
+    int OH, OW;             /* produced tensor (y for forward, dx for dgrad) */
+    int Cin_p, ld_in;       /* gathered physical channels (multiple of 8) and its pixel stride */
+    int Cout, ld_out;       /* produced channels to store and pixel stride */
+    int KH, KW, stride, pad_h, pad_w, dil_h, dil_w;   /* of the FORWARD convolution */
+    int transposed;         /* 0 forward gather, 1 dgrad gather */
+    int Kp;                 /* packed-weight row length, multiple of 128 */
+    int flags;              /* PN2_CONV_* */
+} pn2_conv_desc;
+
+typedef struct pn2_wgrad_desc {
+    int N, H, W, OH, OW;    /* x spatial, dy spatial */
+    int Cin_p, ld_x;        /* x physical channels / stride */
+    int Cout_p, ld_dy;      /* dy physical channels / stride */
+    int KH, KW, stride, pad_h, pad_w, dil_h, dil_w;
+    int Rp, Kp;             /* slab rows (multiple of the co tile, normally 128) and row length (multiple of 128) */
+} pn2_wgrad_desc;
+
+typedef struct pn2_pack_desc {
+    int Cout, Cin, KH, KW;              /* logical OIHW shape */
+    int Cout_p, gw_out, gwp_out;        /* physical output channels; groups of gw logical stored in gwp slots */
+    int Cin_p, gw_in, gwp_in;
+    int Rp, Kp;                         /* packed panel rows / row length */
+    int transposed;                     /* 0: [co][tap*Cin_p+ci] (forward, wgrad slabs) ; 1: [ci][tap*Cout_p+co] (dgrad) */
+} pn2_pack_desc;
+
+int pn2_conv_tile_n(int cout);          /* N tile the forward/dgrad kernel will pick for `cout` */
+int pn2_wgrad_tile_co(int cout_p);      /* co tile of the wgrad kernel */
+int pn2_conv_stat_blocks(int m);        /* rows of the psum/psq partial buffers for m output pixels */
+int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, void* stream);
+int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream);
+int pn2_pack_weight(int dtype, const float* w_oihw, void* wp, const pn2_pack_desc* p, void* stream);
+int pn2_wgrad_reduce(const float* slab, float* gw_oihw, const pn2_pack_desc* p, int nsplit, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- batch norm
+ * nn.BatchNorm2d train/eval forward + backward (lib/pranet.py:37,41-42 ; lib/Res2Net_v1b.py:33,45,50,103,106,110,135),
+ * fused with the ReLU / residual add that follows it (Res2Net_v1b.py:63,72,88-89 ; pranet.py:82,358-360).   */
+typedef struct pn2_bn_desc {
+    int M;                  /* pixels */
+    int Cp;                 /* physical channels of the raw conv output */
+    int C, gw, gwp;         /* logical channels and group-padding map of gamma/beta/running stats */
+    float eps, momentum;
+} pn2_bn_desc;
+/* batch statistics from the conv epilogue partials -> scale/shift (physical), saved mean/invstd, running-stat update */
+int pn2_bn_finalize(const float* psum, const float* psq, int nblk, const pn2_bn_desc* d, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* eval mode: scale/shift from running statistics */
+int pn2_bn_eval_prepare(const pn2_bn_desc* d, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float* scale, float* shift, void* stream);
+/* y[m][c] = act(x[m][c]*scale[c] + shift[c] + res[m][c]) for c < Cout ; scale==NULL -> identity affine */
+int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int ld_y, int M, int Cout,
+                   const float* scale, const float* shift, const void* res, int ld_res, int relu, void* stream);
+/* backward pass 1: per-channel partials of sum(dz) and sum(dz*xhat), dz = dy*(y>0 if relu) ; dy has Cdy valid channels */
+int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
+                      int M, int Cp, const float* mean, const float* invstd, float* p1, float* p2, int nblk, void* stream);
+int pn2_bn_bwd_blocks(int M);
+/* pass 1b: dgamma/dbeta (logical, optionally accumulated) + per-channel coefficients for pass 2 */
+int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn_desc* d, const float* gamma, const float* invstd,
+                        float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);
+/* pass 2: dx = g*invstd*(dz - c1 - xhat*c2) ; optional dres (+)= dz.  coef = [gscale|c1|c2] each Cp long.
+ * coef==NULL: pure activation backward (dx = dz), used for eval-mode / affine-only layers.                */
+int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
+                     int M, int Cp, const float* mean, const float* invstd, const float* coef, void* dx, int ld_dx,
+                     void* dres, int ld_dres, int dres_accum, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- pooling
+ * nn.MaxPool2d(3,2,1) Res2Net_v1b.py:112 ; nn.AvgPool2d(3,stride,1) :40,80 ; AvgPool2d(s,s,ceil,count_include_pad=False) :131-132 */
+int pn2_maxpool3x3s2_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, unsigned char* idx, int N, int H, int W, int C, int OH, int OW, void* stream);
+int pn2_maxpool3x3s2_bwd(int dt, const void* dy, int ld_dy, const unsigned char* idx, void* dx, int ld_dx, int N, int H, int W, int C, int OH, int OW, void* stream);
+int pn2_avgpool_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int OH, int OW,
+                    int k, int stride, int pad, int count_include_pad, void* stream);
+int pn2_avgpool_bwd(int dt, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C, int OH, int OW,
+                    int k, int stride, int pad, int count_include_pad, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- resampling
+ * nn.Upsample(x2, bilinear, align_corners=True) pranet.py:93 ; F.interpolate(scale_factor=s, mode='bilinear')
+ * (align_corners=False, given scale used) pranet.py:349-354,370-376,392-398,414-415.  rh/rw = source step per output pixel. */
+int pn2_bilinear_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int OH, int OW,
+                     int align_corners, float rh, float rw, void* stream);
+int pn2_bilinear_bwd(int dt, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C, int OH, int OW,
+                     int align_corners, float rh, float rw, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- DSRA / RA
+ * V2 fusion fg + fg*softmax(crop_fg - crop_bg, dim=1) (or *(crop_fg-crop_bg)) pranet.py:365-368,385-389,407-411 ;
+ * all maps fp32 [M][K].  V1 gate (1 - sigmoid(crop)).expand(C) * x  PraNet_Res2Net.py:153-154,166-167,177-178. */
+int pn2_dsra_fuse_fwd(const float* fg, const float* crop_fg, const float* crop_bg, float* out, int M, int K, int use_softmax, void* stream);
+int pn2_dsra_fuse_bwd(const float* fg, const float* crop_fg, const float* crop_bg, const float* dout, float* dfg, float* dcrop_fg,
+                      float* dcrop_bg, int M, int K, int use_softmax, void* stream);
+int pn2_ra_gate_fwd(int dt, const void* x, int ld_x, const float* crop, void* out, int ld_out, int M, int C, void* stream);
+int pn2_ra_gate_bwd(int dt, const void* x, int ld_x, const float* crop, const void* dout, int ld_dout, void* dx, int ld_dx, int dx_accum,
+                    float* dcrop, int M, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- structure loss
+ * MyTrain_med.py:19-38 applied to the P (fg,bg) pairs of :78-82 in one pass.  preds = P fg maps then P bg maps,
+ * each [N][HW] fp32 ; mask [N][HW].  weit/wsum are `weit` is produced once per batch by pn2_loss_weights.   */
+int pn2_loss_weights(const float* mask, float* weit, int N, int H, int W, int ksize, void* stream);
+int pn2_loss_blocks(int HW);            /* row-chunks per image of the `partial` scratch: [P][N][blocks][5] floats */
+/* preds: 2P maps laid out at preds + j*map_stride (j<P: fg of pair j, j>=P: bg of pair j-P), each [N][HW] fp32.
+ * Outputs: sums [P][N][4] and wsum [N] (kept for the backward), loss [P+1] = per-pair losses then their total. */
+int pn2_structure_loss_fwd(const float* preds, long long map_stride, int P, const float* mask, const float* weit, float* partial,
+                           float* sums, float* wsum, float* loss, int N, int HW, void* stream);
+int pn2_structure_loss_bwd(const float* preds, float* dpreds, long long map_stride, int P, const float* mask, const float* weit,
+                           const float* wsum, const float* sums, float gscale, int N, int HW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- element-wise / layout */
+int pn2_binary(int dt, int op /*0 add,1 mul*/, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream);
+int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld_d, int M, int C, int accumulate, void* stream);
+int pn2_nchw_to_nhwc(int dt_out, const float* x, void* y, int ld_y, int N, int C, int HW, int Cp, void* stream);   /* pad channels zeroed */
+int pn2_bias_grad(const float* dy, int M, int K, float* db, int accumulate, void* stream);   /* db[k] = sum_m dy[m][k] (fp32 head maps) */
+
+/* ---------------------------------------------------------------------------------------------- optimiser
+ * clip_gradient (utils/utils.py:7-17: per-element clamp) + torch.optim.Adam step (MyTrain_med.py:149,85-86), one launch over
+ * the flat parameter arena.  step_ptr: device int64 step counter incremented by the kernel launch before (graph friendly). */
+int pn2_clamp_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
+                   float eps, float clip, float grad_scale, const float* bias_corr /* device [2]: 1-b1^t, 1-b2^t */, void* stream);
+int pn2_adam_tick(float* bias_corr /* [4]: bc1, bc2, b1^t, b2^t */, float beta1, float beta2, void* stream);
+
+/* MyTest_med.py:104-111 tail on device: sum of 4 maps already resized -> sigmoid -> min-max -> uint8 */
+int pn2_eval_tail(const float* res, unsigned char* out, float* minmax /* scratch [2 + 2*512] */, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,305 @@
+// pn2_bn.hip — BatchNorm2d (train / eval) fused with the ReLU and residual add that follow it.
+// Reference semantics: nn.BatchNorm2d defaults (eps 1e-5, momentum 0.1, biased variance for
+// normalisation, unbiased for running_var) at /root/reference/binary_seg/lib/pranet.py:37,41-42 and
+// /root/reference/binary_seg/lib/Res2Net_v1b.py:33,45,50,103,106,110,135; ReLU / residual at
+// Res2Net_v1b.py:63,72,88-89 and pranet.py:82,358-360.
+//
+// All of these are HBM-bound streaming kernels: 16-byte vectors along the NHWC channel axis, one pass.
+// Batch statistics arrive as per-row-block partials from the conv epilogue (pn2_conv.hip), so the
+// forward never re-reads the conv output to compute them.
+#include "pn2_common.h"
+#include "../../include/pn2.h"
+
+namespace {
+
+template <typename T, int W> struct VL {   // W == VEC: 16-byte vector ; W == 1: scalar
+    __device__ static __forceinline__ void load(const T* p, float* f) {
+        if constexpr (W == 1) f[0] = TT<T>::ld(p);
+        else TT<T>::unpack(*reinterpret_cast<const uint4*>(p), f);
+    }
+    __device__ static __forceinline__ void store(T* p, const float* f) {
+        if constexpr (W == 1) TT<T>::st(p, f[0]);
+        else *reinterpret_cast<uint4*>(p) = TT<T>::pack(f);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// reduce [nblk][Cp] partial rows: 8 channels x 32 row-lanes per block, accumulate in double
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void reduce_partials(const float* p1, const float* p2, int nblk, int Cp, int c, int rl, double& s1, double& s2) {
+    s1 = 0.0; s2 = 0.0;
+    if (c < Cp)
+        for (int r = rl; r < nblk; r += 32) { s1 += (double)p1[(size_t)r * Cp + c]; s2 += (double)p2[(size_t)r * Cp + c]; }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ psum, const float* __restrict__ psq, int nblk, pn2_bn_desc d,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                     float* scale, float* shift, float* mean_o, float* invstd_o) {
+    __shared__ double sh[2][32][8];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
+    double s1, s2;
+    reduce_partials(psum, psq, nblk, d.Cp, c, rl, s1, s2);
+    sh[0][rl][cl] = s1; sh[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl == 0 && c < d.Cp) {
+        for (int r = 1; r < 32; ++r) { s1 += sh[0][r][cl]; s2 += sh[1][r][cl]; }
+        const int lc = phys2log(c, d.gw, d.gwp, d.C);
+        if (lc < 0) { scale[c] = 0.f; shift[c] = 0.f; mean_o[c] = 0.f; invstd_o[c] = 0.f; return; }
+        const double mean = s1 / d.M;
+        double var = s2 / d.M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+        const float sc = gamma[lc] * invstd;
+        scale[c] = sc; shift[c] = beta[lc] - (float)mean * sc;
+        mean_o[c] = (float)mean; invstd_o[c] = invstd;
+        if (running_mean) {
+            const double unb = d.M > 1 ? var * ((double)d.M / (double)(d.M - 1)) : var;
+            running_mean[lc] = (1.f - d.momentum) * running_mean[lc] + d.momentum * (float)mean;
+            running_var[lc] = (1.f - d.momentum) * running_var[lc] + d.momentum * (float)unb;
+        }
+    }
+}
+
+__global__ void bn_eval_prepare_k(pn2_bn_desc d, const float* gamma, const float* beta, const float* rm, const float* rv, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.Cp) return;
+    const int lc = phys2log(c, d.gw, d.gwp, d.C);
+    if (lc < 0) { scale[c] = 0.f; shift[c] = 0.f; return; }
+    const float sc = gamma[lc] / sqrtf(rv[lc] + d.eps);
+    scale[c] = sc; shift[c] = beta[lc] - rm[lc] * sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = act(x*scale + shift + res)
+// ---------------------------------------------------------------------------------------------
+template <typename Ti, typename To, int W>
+__global__ __launch_bounds__(256) void affine_act_k(const Ti* __restrict__ x, int ld_x, To* __restrict__ y, int ld_y, int M, int C,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    const Ti* __restrict__ res, int ld_res, int relu) {
+    const int CV = C / W;
+    const size_t total = (size_t)M * CV;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / CV), c = (int)(idx - (size_t)m * CV) * W;
+        float v[W], r[W];
+        VL<Ti, W>::load(x + (size_t)m * ld_x + c, v);
+        if (res) VL<Ti, W>::load(res + (size_t)m * ld_res + c, r);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float t = v[e];
+            if (scale) t = t * scale[c + e] + shift[c + e];
+            else if (shift) t += shift[c + e];
+            if (res) t += r[e];
+            v[e] = relu ? fmaxf(t, 0.f) : t;
+        }
+        if constexpr (sizeof(Ti) == sizeof(To)) VL<To, W>::store(y + (size_t)m * ld_y + c, v);
+        else {
+#pragma unroll
+            for (int e = 0; e < W; ++e) TT<To>::st(y + (size_t)m * ld_y + c + e, v[e]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward pass 1: partial sums of dz and dz*xhat over row chunks
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename Tdy, int W>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
+                                                       const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, float* __restrict__ p1, float* __restrict__ p2,
+                                                       int rows_per_blk, int CVP) {
+    extern __shared__ __attribute__((aligned(16))) float shf[];   // [2][R][CVP*W]
+    const int CV = Cp / W;
+    const int R = 256 / CVP;
+    const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int r0 = blockIdx.x * rows_per_blk;
+    int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
+    for (int cvb = 0; cvb < CV; cvb += CVP) {
+        const int cv = cvb + cvl, c = cv * W;
+        float a1[W], a2[W], mu[W], is[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) { a1[e] = 0.f; a2[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
+        if (cv < CV) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
+            for (int m = r0 + rl; m < r1; m += R) {
+                float g[W], xv[W], yv[W];
+                if (W > 1 || c < Cdy) VL<Tdy, W>::load(dy + (size_t)m * ld_dy + c, g); else g[0] = 0.f;
+                VL<T, W>::load(x + (size_t)m * ld_x + c, xv);
+                if (y) VL<T, W>::load(y + (size_t)m * ld_y + c, yv);
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    const float dz = (y && !(yv[e] > 0.f)) ? 0.f : g[e];
+                    a1[e] += dz; a2[e] += dz * (xv[e] - mu[e]) * is[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < W; ++e) { shf[(rl * CVP + cvl) * W + e] = a1[e]; shf[((R + rl) * CVP + cvl) * W + e] = a2[e]; }
+        __syncthreads();
+        if (rl == 0 && cv < CV) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                float s1 = 0.f, s2 = 0.f;
+                for (int r = 0; r < R; ++r) { s1 += shf[(r * CVP + cvl) * W + e]; s2 += shf[((R + r) * CVP + cvl) * W + e]; }
+                p1[(size_t)blockIdx.x * Cp + c + e] = s1; p2[(size_t)blockIdx.x * Cp + c + e] = s2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ p1, const float* __restrict__ p2, int nblk, pn2_bn_desc d,
+                                                         const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                         float* dgamma, float* dbeta, int accumulate, float* coef) {
+    __shared__ double sh[2][32][8];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
+    double s1, s2;
+    reduce_partials(p1, p2, nblk, d.Cp, c, rl, s1, s2);
+    sh[0][rl][cl] = s1; sh[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl == 0 && c < d.Cp) {
+        for (int r = 1; r < 32; ++r) { s1 += sh[0][r][cl]; s2 += sh[1][r][cl]; }
+        const int lc = phys2log(c, d.gw, d.gwp, d.C);
+        if (lc < 0) { coef[c] = 0.f; coef[d.Cp + c] = 0.f; coef[2 * d.Cp + c] = 0.f; return; }
+        if (accumulate) { dbeta[lc] += (float)s1; dgamma[lc] += (float)s2; }
+        else { dbeta[lc] = (float)s1; dgamma[lc] = (float)s2; }
+        coef[c] = gamma[lc] * invstd[c];
+        coef[d.Cp + c] = (float)(s1 / d.M);
+        coef[2 * d.Cp + c] = (float)(s2 / d.M);
+    }
+}
+
+template <typename T, typename Tdy, int W>
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
+                                                      const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
+                                                      T* __restrict__ dres, int ld_dres, int dres_accum) {
+    const int CV = Cp / W;
+    const size_t total = (size_t)M * CV;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / CV), c = (int)(idx - (size_t)m * CV) * W;
+        float g[W], xv[W], yv[W], o[W], rr[W];
+        if (W > 1 || c < Cdy) VL<Tdy, W>::load(dy + (size_t)m * ld_dy + c, g); else g[0] = 0.f;
+        if (coef) VL<T, W>::load(x + (size_t)m * ld_x + c, xv);
+        if (y) VL<T, W>::load(y + (size_t)m * ld_y + c, yv);
+        if (dres && dres_accum) VL<T, W>::load(dres + (size_t)m * ld_dres + c, rr);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const float dz = (y && !(yv[e] > 0.f)) ? 0.f : g[e];
+            if (coef) {
+                const float xh = (xv[e] - mean[c + e]) * invstd[c + e];
+                o[e] = coef[c + e] * (dz - coef[Cp + c + e] - xh * coef[2 * Cp + c + e]);
+            } else o[e] = dz;
+            rr[e] = (dres && dres_accum) ? rr[e] + dz : dz;
+        }
+        VL<T, W>::store(dx + (size_t)m * ld_dx + c, o);
+        if (dres) VL<T, W>::store(dres + (size_t)m * ld_dres + c, rr);
+    }
+}
+
+inline int grid_for(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+template <typename Ti, typename To>
+int affine_dispatch(const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* scale, const float* shift, const void* res, int ld_res, int relu, hipStream_t st) {
+    constexpr int V = TT<Ti>::VEC;
+    const bool vec = sizeof(Ti) == sizeof(To) && C % V == 0 && ld_x % V == 0 && ld_y % V == 0 && (!res || ld_res % V == 0);
+    if (vec) hipLaunchKernelGGL((affine_act_k<Ti, To, V>), dim3(grid_for((size_t)M * (C / V))), dim3(256), 0, st, (const Ti*)x, ld_x, (To*)y, ld_y, M, C, scale, shift, (const Ti*)res, ld_res, relu);
+    else hipLaunchKernelGGL((affine_act_k<Ti, To, 1>), dim3(grid_for((size_t)M * C)), dim3(256), 0, st, (const Ti*)x, ld_x, (To*)y, ld_y, M, C, scale, shift, (const Ti*)res, ld_res, relu);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T, typename Tdy>
+int bwd_reduce_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, const void* x, int ld_x, int M, int Cp,
+                        const float* mean, const float* invstd, float* p1, float* p2, int nblk, hipStream_t st) {
+    constexpr int V = TT<T>::VEC;
+    const bool vec = sizeof(T) == sizeof(Tdy) && Cdy == Cp && Cp % V == 0 && ld_dy % V == 0 && ld_x % V == 0 && (!y || ld_y % V == 0);
+    const int rows = (M + nblk - 1) / nblk;
+    if (vec) {
+        int cvp = pow2ceil(Cp / V); if (cvp > 256) cvp = 256;
+        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, V>), dim3(nblk), dim3(256), 2 * 256 * V * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp);
+    } else {
+        int cvp = pow2ceil(Cp); if (cvp > 256) cvp = 256;
+        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, 1>), dim3(nblk), dim3(256), 2 * 256 * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp);
+    }
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T, typename Tdy>
+int bwd_apply_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, const void* x, int ld_x, int M, int Cp, const float* mean,
+                       const float* invstd, const float* coef, void* dx, int ld_dx, void* dres, int ld_dres, int dres_accum, hipStream_t st) {
+    constexpr int V = TT<T>::VEC;
+    const bool vec = sizeof(T) == sizeof(Tdy) && Cdy == Cp && Cp % V == 0 && ld_dy % V == 0 && ld_dx % V == 0 && (!coef || ld_x % V == 0) &&
+                     (!y || ld_y % V == 0) && (!dres || ld_dres % V == 0);
+    if (vec) hipLaunchKernelGGL((bn_bwd_apply_k<T, Tdy, V>), dim3(grid_for((size_t)M * (Cp / V))), dim3(256), 0, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum);
+    else hipLaunchKernelGGL((bn_bwd_apply_k<T, Tdy, 1>), dim3(grid_for((size_t)M * Cp)), dim3(256), 0, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pn2_bn_finalize(const float* psum, const float* psq, int nblk, const pn2_bn_desc* d, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    if (!psum || !psq || !d || !gamma || !beta || !scale || !shift || !mean || !invstd) return -1;
+    hipLaunchKernelGGL(bn_finalize_k, dim3((d->Cp + 7) / 8), dim3(256), 0, (hipStream_t)stream, psum, psq, nblk, *d, gamma, beta, running_mean, running_var, scale, shift, mean, invstd);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_bn_eval_prepare(const pn2_bn_desc* d, const float* gamma, const float* beta, const float* rm, const float* rv, float* scale, float* shift, void* stream) {
+    if (!d || !gamma || !beta || !rm || !rv || !scale || !shift) return -1;
+    hipLaunchKernelGGL(bn_eval_prepare_k, dim3((d->Cp + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, gamma, beta, rm, rv, scale, shift);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int ld_y, int M, int Cout, const float* scale, const float* shift,
+                   const void* res, int ld_res, int relu, void* stream) {
+    if (!x || !y) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt_in == PN2_BF16 && dt_out == PN2_BF16) return affine_dispatch<bf16_t, bf16_t>(x, ld_x, y, ld_y, M, Cout, scale, shift, res, ld_res, relu, st);
+    if (dt_in == PN2_BF16 && dt_out == PN2_F32) return affine_dispatch<bf16_t, float>(x, ld_x, y, ld_y, M, Cout, scale, shift, res, ld_res, relu, st);
+    if (dt_in == PN2_F32 && dt_out == PN2_F32) return affine_dispatch<float, float>(x, ld_x, y, ld_y, M, Cout, scale, shift, res, ld_res, relu, st);
+    return -3;
+}
+
+int pn2_bn_bwd_blocks(int M) { int b = (M + 63) / 64; return b > 1024 ? 1024 : (b < 1 ? 1 : b); }
+
+int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
+                      int M, int Cp, const float* mean, const float* invstd, float* p1, float* p2, int nblk, void* stream) {
+    if (!dy || !x || !mean || !invstd || !p1 || !p2) return -1;
+    if (y && dt_y != dt) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16 && dt_dy == PN2_BF16) return bwd_reduce_dispatch<bf16_t, bf16_t>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, st);
+    if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_reduce_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, st);
+    if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_reduce_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, st);
+    return -3;
+}
+
+int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn_desc* d, const float* gamma, const float* invstd,
+                        float* dgamma, float* dbeta, int accumulate, float* coef, void* stream) {
+    if (!p1 || !p2 || !d || !gamma || !invstd || !dgamma || !dbeta || !coef) return -1;
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((d->Cp + 7) / 8), dim3(256), 0, (hipStream_t)stream, p1, p2, nblk, *d, gamma, invstd, dgamma, dbeta, accumulate, coef);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
+                     int M, int Cp, const float* mean, const float* invstd, const float* coef, void* dx, int ld_dx,
+                     void* dres, int ld_dres, int dres_accum, void* stream) {
+    if (!dy || !dx) return -1;
+    if (coef && (!x || !mean || !invstd)) return -1;
+    if (y && dt_y != dt) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16 && dt_dy == PN2_BF16) return bwd_apply_dispatch<bf16_t, bf16_t>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, st);
+    if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_apply_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, st);
+    if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_apply_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, st);
+    return -3;
+}
+
+}  // extern "C"

@@ -1,0 +1,418 @@
+// pn2_spatial.hip — pooling, bilinear resampling, element-wise glue and layout conversion.
+// HBM-bound NHWC streaming kernels (16-byte channel vectors, grid-stride, no atomics: every backward
+// is written in gather form so results are deterministic).
+//
+// Reference ops replaced:
+//   nn.MaxPool2d(3,2,1)                          /root/reference/binary_seg/lib/Res2Net_v1b.py:112
+//   nn.AvgPool2d(3,stride,1)                     Res2Net_v1b.py:40,80
+//   nn.AvgPool2d(s,s,ceil_mode,count_include_pad=False)   Res2Net_v1b.py:131-132
+//   nn.Upsample(x2,bilinear,align_corners=True)  /root/reference/binary_seg/lib/pranet.py:93,111-118
+//   F.interpolate(scale_factor,bilinear)         pranet.py:349-354,370-376,392-398,414-415
+//   torch.split/cat, `sp + spx[i]`, `a * b`      Res2Net_v1b.py:65-80 ; pranet.py:111-119
+#include "pn2_common.h"
+#include "../../include/pn2.h"
+
+namespace {
+
+template <typename T, int W> struct VL {
+    __device__ static __forceinline__ void load(const T* p, float* f) {
+        if constexpr (W == 1) f[0] = TT<T>::ld(p);
+        else TT<T>::unpack(*reinterpret_cast<const uint4*>(p), f);
+    }
+    __device__ static __forceinline__ void store(T* p, const float* f) {
+        if constexpr (W == 1) TT<T>::st(p, f[0]);
+        else *reinterpret_cast<uint4*>(p) = TT<T>::pack(f);
+    }
+};
+
+inline int grid_for(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g)); }
+
+#define PIX_LOOP(total) for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (total); idx += (size_t)gridDim.x * 256)
+
+// ------------------------------------------------------------------------------------------ max pool
+template <typename T, int W>
+__global__ __launch_bounds__(256) void maxpool_fwd_k(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, unsigned char* __restrict__ arg,
+                                                     int N, int H, int Wd, int C, int OH, int OW) {
+    const int CV = C / W;
+    const size_t total = (size_t)N * OH * OW * CV;
+    PIX_LOOP(total) {
+        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int n = (int)(p / OH);
+        float best[W]; int bi[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy * 2 - 1 + r; if ((unsigned)iy >= (unsigned)H) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int ix = ox * 2 - 1 + s; if ((unsigned)ix >= (unsigned)Wd) continue;
+                float v[W];
+                VL<T, W>::load(x + ((size_t)(n * H + iy) * Wd + ix) * ld_x + cv * W, v);
+#pragma unroll
+                for (int e = 0; e < W; ++e) if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = r * 3 + s; }
+            }
+        }
+        const size_t o = (size_t)(n * OH + oy) * OW + ox;
+        VL<T, W>::store(y + o * ld_y + cv * W, best);
+#pragma unroll
+        for (int e = 0; e < W; ++e) arg[o * C + cv * W + e] = (unsigned char)bi[e];
+    }
+}
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) void maxpool_bwd_k(const T* __restrict__ dy, int ld_dy, const unsigned char* __restrict__ arg, T* __restrict__ dx, int ld_dx,
+                                                     int N, int H, int Wd, int C, int OH, int OW) {
+    const int CV = C / W;
+    const size_t total = (size_t)N * H * Wd * CV;
+    PIX_LOOP(total) {
+        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int ix = (int)(p % Wd); p /= Wd; const int iy = (int)(p % H); const int n = (int)(p / H);
+        float acc[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[e] = 0.f;
+        for (int r = 0; r < 3; ++r) {
+            const int ty = iy + 1 - r; if (ty < 0 || (ty & 1)) continue; const int oy = ty >> 1; if (oy >= OH) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int tx = ix + 1 - s; if (tx < 0 || (tx & 1)) continue; const int ox = tx >> 1; if (ox >= OW) continue;
+                const size_t o = (size_t)(n * OH + oy) * OW + ox;
+                float g[W];
+                VL<T, W>::load(dy + o * ld_dy + cv * W, g);
+#pragma unroll
+                for (int e = 0; e < W; ++e) if (arg[o * C + cv * W + e] == r * 3 + s) acc[e] += g[e];
+            }
+        }
+        VL<T, W>::store(dx + ((size_t)(n * H + iy) * Wd + ix) * ld_dx + cv * W, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ avg pool
+__device__ __forceinline__ float avg_div(int o, int k, int stride, int pad, int In, int include_pad, int& lo, int& hi) {
+    int s = o * stride - pad, e = s + k; if (e > In + pad) e = In + pad;
+    const int full = e - s;
+    lo = s < 0 ? 0 : s; hi = e > In ? In : e;
+    return (float)(include_pad ? full : (hi - lo));
+}
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) void avgpool_fwd_k(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int N, int H, int Wd, int C, int OH, int OW,
+                                                     int k, int stride, int pad, int inc) {
+    const int CV = C / W;
+    const size_t total = (size_t)N * OH * OW * CV;
+    PIX_LOOP(total) {
+        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int n = (int)(p / OH);
+        int y0, y1, x0, x1;
+        const float dh = avg_div(oy, k, stride, pad, H, inc, y0, y1), dw = avg_div(ox, k, stride, pad, Wd, inc, x0, x1);
+        float acc[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[e] = 0.f;
+        for (int iy = y0; iy < y1; ++iy)
+            for (int ix = x0; ix < x1; ++ix) {
+                float v[W];
+                VL<T, W>::load(x + ((size_t)(n * H + iy) * Wd + ix) * ld_x + cv * W, v);
+#pragma unroll
+                for (int e = 0; e < W; ++e) acc[e] += v[e];
+            }
+        const float inv = 1.f / (dh * dw);
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[e] *= inv;
+        VL<T, W>::store(y + ((size_t)(n * OH + oy) * OW + ox) * ld_y + cv * W, acc);
+    }
+}
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) void avgpool_bwd_k(const T* __restrict__ dy, int ld_dy, T* __restrict__ dx, int ld_dx, int N, int H, int Wd, int C, int OH, int OW,
+                                                     int k, int stride, int pad, int inc, int accumulate) {
+    const int CV = C / W;
+    const size_t total = (size_t)N * H * Wd * CV;
+    PIX_LOOP(total) {
+        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int ix = (int)(p % Wd); p /= Wd; const int iy = (int)(p % H); const int n = (int)(p / H);
+        float acc[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[e] = 0.f;
+        int oy0 = (iy + pad - k + stride) / stride; if (iy + pad - k + 1 < 0) oy0 = 0;
+        int ox0 = (ix + pad - k + stride) / stride; if (ix + pad - k + 1 < 0) ox0 = 0;
+        int oy1 = (iy + pad) / stride; if (oy1 >= OH) oy1 = OH - 1;
+        int ox1 = (ix + pad) / stride; if (ox1 >= OW) ox1 = OW - 1;
+        for (int oy = oy0; oy <= oy1; ++oy)
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                int a, b;
+                const float dh = avg_div(oy, k, stride, pad, H, inc, a, b);
+                if (iy < a || iy >= b) continue;
+                const float dw = avg_div(ox, k, stride, pad, Wd, inc, a, b);
+                if (ix < a || ix >= b) continue;
+                float g[W];
+                VL<T, W>::load(dy + ((size_t)(n * OH + oy) * OW + ox) * ld_dy + cv * W, g);
+                const float inv = 1.f / (dh * dw);
+#pragma unroll
+                for (int e = 0; e < W; ++e) acc[e] += g[e] * inv;
+            }
+        T* d = dx + ((size_t)(n * H + iy) * Wd + ix) * ld_dx + cv * W;
+        if (accumulate) { float o[W]; VL<T, W>::load(d, o);
+#pragma unroll
+            for (int e = 0; e < W; ++e) acc[e] += o[e]; }
+        VL<T, W>::store(d, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bilinear
+// PyTorch upsample_bilinear2d index math (area_pixel_compute_source_index):
+//   align_corners: src = r*dst ; else src = max(r*(dst+0.5)-0.5, 0) ; i0 = (int)src ; i1 = i0 + (i0 < In-1) ; l1 = src - i0.
+__device__ __forceinline__ void bl_src(int o, float r, int ac, int In, int& i0, int& i1, float& l0, float& l1) {
+    float s = ac ? r * (float)o : fmaxf(r * ((float)o + 0.5f) - 0.5f, 0.f);
+    i0 = (int)s; if (i0 > In - 1) i0 = In - 1;
+    i1 = i0 + (i0 < In - 1 ? 1 : 0);
+    l1 = s - (float)i0; l0 = 1.f - l1;
+}
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) void bilinear_fwd_k(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int N, int H, int Wd, int C, int OH, int OW,
+                                                      int ac, float rh, float rw) {
+    const int CV = C / W;
+    const size_t total = (size_t)N * OH * OW * CV;
+    PIX_LOOP(total) {
+        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int n = (int)(p / OH);
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        bl_src(oy, rh, ac, H, y0, y1, ly0, ly1); bl_src(ox, rw, ac, Wd, x0, x1, lx0, lx1);
+        const T* b = x + (size_t)n * H * Wd * ld_x + cv * W;
+        float a[W], bq[W], c[W], d[W], o[W];
+        VL<T, W>::load(b + (size_t)(y0 * Wd + x0) * ld_x, a); VL<T, W>::load(b + (size_t)(y0 * Wd + x1) * ld_x, bq);
+        VL<T, W>::load(b + (size_t)(y1 * Wd + x0) * ld_x, c); VL<T, W>::load(b + (size_t)(y1 * Wd + x1) * ld_x, d);
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bq[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
+        VL<T, W>::store(y + ((size_t)(n * OH + oy) * OW + ox) * ld_y + cv * W, o);
+    }
+}
+
+// candidate output range whose 2-tap footprint can touch input index i (monotone src): conservative +-1, exact test in loop
+__device__ __forceinline__ void bl_range(int i, float r, int ac, int On, int& lo, int& hi) {
+    float a, b;
+    if (ac) { if (r <= 0.f) { lo = 0; hi = On - 1; return; } a = ((float)i - 1.f) / r; b = ((float)i + 1.f) / r; }
+    else { a = ((float)i - 0.5f) / r - 0.5f; b = ((float)i + 1.5f) / r - 0.5f; }
+    lo = (int)floorf(a) - 1; hi = (int)ceilf(b) + 1;
+    if (lo < 0) lo = 0; if (hi > On - 1) hi = On - 1;
+}
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) void bilinear_bwd_k(const T* __restrict__ dy, int ld_dy, T* __restrict__ dx, int ld_dx, int N, int H, int Wd, int C, int OH, int OW,
+                                                      int ac, float rh, float rw, int accumulate) {
+    const int CV = C / W;
+    const size_t total = (size_t)N * H * Wd * CV;
+    PIX_LOOP(total) {
+        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int ix = (int)(p % Wd); p /= Wd; const int iy = (int)(p % H); const int n = (int)(p / H);
+        int oy0, oy1, ox0, ox1;
+        bl_range(iy, rh, ac, OH, oy0, oy1); bl_range(ix, rw, ac, OW, ox0, ox1);
+        float acc[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[e] = 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            int y0, y1; float ly0, ly1;
+            bl_src(oy, rh, ac, H, y0, y1, ly0, ly1);
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                int x0, x1; float lx0, lx1;
+                bl_src(ox, rw, ac, Wd, x0, x1, lx0, lx1);
+                const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+                if (wx == 0.f) continue;
+                float g[W];
+                VL<T, W>::load(dy + ((size_t)(n * OH + oy) * OW + ox) * ld_dy + cv * W, g);
+                const float w = wy * wx;
+#pragma unroll
+                for (int e = 0; e < W; ++e) acc[e] += w * g[e];
+            }
+        }
+        T* d = dx + ((size_t)(n * H + iy) * Wd + ix) * ld_dx + cv * W;
+        if (accumulate) { float o[W]; VL<T, W>::load(d, o);
+#pragma unroll
+            for (int e = 0; e < W; ++e) acc[e] += o[e]; }
+        VL<T, W>::store(d, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ element-wise
+template <typename T, int W>
+__global__ __launch_bounds__(256) void binary_k(int op, const T* __restrict__ a, int ld_a, const T* __restrict__ b, int ld_b, T* __restrict__ out, int ld_o,
+                                                int M, int C, int accumulate) {
+    const int CV = C / W;
+    const size_t total = (size_t)M * CV;
+    PIX_LOOP(total) {
+        const int m = (int)(idx / CV), c = (int)(idx % CV) * W;
+        float x[W], y[W], o[W];
+        VL<T, W>::load(a + (size_t)m * ld_a + c, x); VL<T, W>::load(b + (size_t)m * ld_b + c, y);
+        if (accumulate) VL<T, W>::load(out + (size_t)m * ld_o + c, o);
+#pragma unroll
+        for (int e = 0; e < W; ++e) { const float r = op == 0 ? x[e] + y[e] : x[e] * y[e]; o[e] = accumulate ? o[e] + r : r; }
+        VL<T, W>::store(out + (size_t)m * ld_o + c, o);
+    }
+}
+
+template <typename Ti, typename To, int W>
+__global__ __launch_bounds__(256) void copy_k(const Ti* __restrict__ s, int ld_s, To* __restrict__ d, int ld_d, int M, int C, int accumulate) {
+    const int CV = C / W;
+    const size_t total = (size_t)M * CV;
+    PIX_LOOP(total) {
+        const int m = (int)(idx / CV), c = (int)(idx % CV) * W;
+        float x[W];
+        VL<Ti, W>::load(s + (size_t)m * ld_s + c, x);
+        if constexpr (sizeof(Ti) == sizeof(To)) {
+            if (accumulate) { float o[W]; VL<To, W>::load(d + (size_t)m * ld_d + c, o);
+#pragma unroll
+                for (int e = 0; e < W; ++e) x[e] += o[e]; }
+            VL<To, W>::store(d + (size_t)m * ld_d + c, x);
+        } else {
+#pragma unroll
+            for (int e = 0; e < W; ++e) { To* q = d + (size_t)m * ld_d + c + e; TT<To>::st(q, accumulate ? x[e] + TT<To>::ld(q) : x[e]); }
+        }
+    }
+}
+
+template <typename To>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_k(const float* __restrict__ x, To* __restrict__ y, int ld_y, int N, int C, int HW, int Cp) {
+    const size_t total = (size_t)N * HW;
+    PIX_LOOP(total) {
+        const int n = (int)(idx / HW), p = (int)(idx % HW);
+        To* d = y + idx * ld_y;
+        for (int c = 0; c < Cp; ++c) TT<To>::st(d + c, c < C ? x[((size_t)n * C + c) * HW + p] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_k(const float* __restrict__ dy, int M, int K, float* db, int accumulate) {
+    // one block per channel k; deterministic tree reduce
+    __shared__ float sh[256];
+    const int k = blockIdx.x;
+    float s = 0.f;
+    for (int m = threadIdx.x; m < M; m += 256) s += dy[(size_t)m * K + k];
+    sh[threadIdx.x] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) db[k] = accumulate ? db[k] + sh[0] : sh[0];
+}
+
+template <typename T> bool vec_ok(int C, int a, int b = 0, int c = 0, int d = 0) {
+    constexpr int V = TT<T>::VEC;
+    return C % V == 0 && a % V == 0 && b % V == 0 && c % V == 0 && d % V == 0;
+}
+
+#define DISPATCH_T(dt, CALL)                                     \
+    if ((dt) == PN2_BF16) { using T = bf16_t; CALL }             \
+    else if ((dt) == PN2_F32) { using T = float; CALL }          \
+    else return -3;
+
+}  // namespace
+
+extern "C" {
+
+int pn2_maxpool3x3s2_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, unsigned char* idx, int N, int H, int W, int C, int OH, int OW, void* stream) {
+    if (!x || !y || !idx) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dt, {
+        if (vec_ok<T>(C, ld_x, ld_y)) hipLaunchKernelGGL((maxpool_fwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * OH * OW * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, idx, N, H, W, C, OH, OW);
+        else hipLaunchKernelGGL((maxpool_fwd_k<T, 1>), dim3(grid_for((size_t)N * OH * OW * C)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, idx, N, H, W, C, OH, OW);
+    })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_maxpool3x3s2_bwd(int dt, const void* dy, int ld_dy, const unsigned char* idx, void* dx, int ld_dx, int N, int H, int W, int C, int OH, int OW, void* stream) {
+    if (!dy || !dx || !idx) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dt, {
+        if (vec_ok<T>(C, ld_dy, ld_dx)) hipLaunchKernelGGL((maxpool_bwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * H * W * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)dy, ld_dy, idx, (T*)dx, ld_dx, N, H, W, C, OH, OW);
+        else hipLaunchKernelGGL((maxpool_bwd_k<T, 1>), dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, st, (const T*)dy, ld_dy, idx, (T*)dx, ld_dx, N, H, W, C, OH, OW);
+    })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_avgpool_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int OH, int OW, int k, int stride, int pad, int inc, void* stream) {
+    if (!x || !y) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dt, {
+        if (vec_ok<T>(C, ld_x, ld_y)) hipLaunchKernelGGL((avgpool_fwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * OH * OW * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, N, H, W, C, OH, OW, k, stride, pad, inc);
+        else hipLaunchKernelGGL((avgpool_fwd_k<T, 1>), dim3(grid_for((size_t)N * OH * OW * C)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, N, H, W, C, OH, OW, k, stride, pad, inc);
+    })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_avgpool_bwd(int dt, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C, int OH, int OW, int k, int stride, int pad, int inc, int accumulate, void* stream) {
+    if (!dy || !dx) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dt, {
+        if (vec_ok<T>(C, ld_dy, ld_dx)) hipLaunchKernelGGL((avgpool_bwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * H * W * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, k, stride, pad, inc, accumulate);
+        else hipLaunchKernelGGL((avgpool_bwd_k<T, 1>), dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, k, stride, pad, inc, accumulate);
+    })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_bilinear_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int OH, int OW, int ac, float rh, float rw, void* stream) {
+    if (!x || !y) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dt, {
+        if (vec_ok<T>(C, ld_x, ld_y)) hipLaunchKernelGGL((bilinear_fwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * OH * OW * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, N, H, W, C, OH, OW, ac, rh, rw);
+        else hipLaunchKernelGGL((bilinear_fwd_k<T, 1>), dim3(grid_for((size_t)N * OH * OW * C)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, N, H, W, C, OH, OW, ac, rh, rw);
+    })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_bilinear_bwd(int dt, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C, int OH, int OW, int ac, float rh, float rw, int accumulate, void* stream) {
+    if (!dy || !dx) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dt, {
+        if (vec_ok<T>(C, ld_dy, ld_dx)) hipLaunchKernelGGL((bilinear_bwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * H * W * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
+        else hipLaunchKernelGGL((bilinear_bwd_k<T, 1>), dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
+    })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_binary(int dt, int op, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream) {
+    if (!a || !b || !out) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dt, {
+        if (vec_ok<T>(C, ld_a, ld_b, ld_out)) hipLaunchKernelGGL((binary_k<T, TT<T>::VEC>), dim3(grid_for((size_t)M * C / TT<T>::VEC)), dim3(256), 0, st, op, (const T*)a, ld_a, (const T*)b, ld_b, (T*)out, ld_out, M, C, accumulate);
+        else hipLaunchKernelGGL((binary_k<T, 1>), dim3(grid_for((size_t)M * C)), dim3(256), 0, st, op, (const T*)a, ld_a, (const T*)b, ld_b, (T*)out, ld_out, M, C, accumulate);
+    })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld_d, int M, int C, int accumulate, void* stream) {
+    if (!src || !dst) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt_in == dt_out) {
+        DISPATCH_T(dt_in, {
+            if (vec_ok<T>(C, ld_s, ld_d)) hipLaunchKernelGGL((copy_k<T, T, TT<T>::VEC>), dim3(grid_for((size_t)M * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)src, ld_s, (T*)dst, ld_d, M, C, accumulate);
+            else hipLaunchKernelGGL((copy_k<T, T, 1>), dim3(grid_for((size_t)M * C)), dim3(256), 0, st, (const T*)src, ld_s, (T*)dst, ld_d, M, C, accumulate);
+        })
+    } else if (dt_in == PN2_F32 && dt_out == PN2_BF16)
+        hipLaunchKernelGGL((copy_k<float, bf16_t, 1>), dim3(grid_for((size_t)M * C)), dim3(256), 0, st, (const float*)src, ld_s, (bf16_t*)dst, ld_d, M, C, accumulate);
+    else if (dt_in == PN2_BF16 && dt_out == PN2_F32)
+        hipLaunchKernelGGL((copy_k<bf16_t, float, 1>), dim3(grid_for((size_t)M * C)), dim3(256), 0, st, (const bf16_t*)src, ld_s, (float*)dst, ld_d, M, C, accumulate);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_nchw_to_nhwc(int dt_out, const float* x, void* y, int ld_y, int N, int C, int HW, int Cp, void* stream) {
+    if (!x || !y) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt_out == PN2_BF16) hipLaunchKernelGGL(nchw_to_nhwc_k<bf16_t>, dim3(grid_for((size_t)N * HW)), dim3(256), 0, st, x, (bf16_t*)y, ld_y, N, C, HW, Cp);
+    else if (dt_out == PN2_F32) hipLaunchKernelGGL(nchw_to_nhwc_k<float>, dim3(grid_for((size_t)N * HW)), dim3(256), 0, st, x, (float*)y, ld_y, N, C, HW, Cp);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_bias_grad(const float* dy, int M, int K, float* db, int accumulate, void* stream) {
+    if (!dy || !db) return -1;
+    hipLaunchKernelGGL(bias_grad_k, dim3(K), dim3(256), 0, (hipStream_t)stream, dy, M, K, db, accumulate);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,371 @@
+// pn2_tail.hip — the memory-bound tail of the PraNet-V2 step: DSRA fusion, V1 reverse-attention gate,
+// the dual structure loss (forward + backward in one pass over all four supervision pairs), the fused
+// clamp+Adam update, and the MyTest_med.py eval tail.
+//
+// Reference code restated:
+//   DSRA fusion      /root/reference/binary_seg/lib/pranet.py:365-368,385-389,407-411
+//   RA gate (V1)     /root/reference/binary_seg/lib/PraNet_Res2Net.py:153-154,166-167,177-178
+//   structure_loss   /root/reference/binary_seg/MyTrain_med.py:19-38 (called 4x at :78-81)
+//   clip + Adam      /root/reference/binary_seg/utils/utils.py:7-17 ; MyTrain_med.py:85-86,149
+//   eval tail        /root/reference/binary_seg/MyTest_med.py:104-111
+#include "pn2_common.h"
+#include "../../include/pn2.h"
+
+namespace {
+
+constexpr int MAXK = 32;
+inline int grid_for(size_t total, int cap = 16384) { size_t g = (total + 255) / 256; return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g)); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------ DSRA
+__global__ __launch_bounds__(256) void dsra_fwd_k(const float* __restrict__ fg, const float* __restrict__ cf, const float* __restrict__ cb,
+                                                  float* __restrict__ out, int M, int K, int sm) {
+    for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
+        const size_t o = (size_t)m * K;
+        if (sm) {
+            float mx = -INFINITY;
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, cf[o + k] - cb[o + k]);
+            float e[MAXK], s = 0.f;
+            for (int k = 0; k < K; ++k) { e[k] = expf(cf[o + k] - cb[o + k] - mx); s += e[k]; }
+            for (int k = 0; k < K; ++k) { const float f = fg[o + k]; out[o + k] = f + f * (e[k] / s); }
+        } else
+            for (int k = 0; k < K; ++k) { const float f = fg[o + k]; out[o + k] = f + f * (cf[o + k] - cb[o + k]); }
+    }
+}
+
+__global__ __launch_bounds__(256) void dsra_bwd_k(const float* __restrict__ fg, const float* __restrict__ cf, const float* __restrict__ cb,
+                                                  const float* __restrict__ dout, float* __restrict__ dfg, float* __restrict__ dcf, float* __restrict__ dcb,
+                                                  int M, int K, int sm) {
+    for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
+        const size_t o = (size_t)m * K;
+        if (sm) {
+            float mx = -INFINITY;
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, cf[o + k] - cb[o + k]);
+            float p[MAXK], s = 0.f;
+            for (int k = 0; k < K; ++k) { p[k] = expf(cf[o + k] - cb[o + k] - mx); s += p[k]; }
+            float dot = 0.f;
+            for (int k = 0; k < K; ++k) { p[k] /= s; dot += dout[o + k] * fg[o + k] * p[k]; }
+            for (int k = 0; k < K; ++k) {
+                const float g = dout[o + k];
+                dfg[o + k] = g + g * p[k];
+                const float dd = p[k] * (g * fg[o + k] - dot);
+                dcf[o + k] = dd; dcb[o + k] = -dd;
+            }
+        } else
+            for (int k = 0; k < K; ++k) {
+                const float g = dout[o + k], d = cf[o + k] - cb[o + k];
+                dfg[o + k] = g + g * d;
+                dcf[o + k] = g * fg[o + k]; dcb[o + k] = -g * fg[o + k];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ RA gate (V1)
+template <typename T>
+__global__ __launch_bounds__(256) void ra_gate_fwd_k(const T* __restrict__ x, int ld_x, const float* __restrict__ crop, T* __restrict__ out, int ld_o, int M, int C) {
+    constexpr int V = TT<T>::VEC;
+    const int CV = C / V;
+    const size_t total = (size_t)M * CV;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / CV), c = (int)(idx % CV) * V;
+        const float gte = 1.f - sigmoidf_(crop[m]);
+        float v[V];
+        TT<T>::unpack(*reinterpret_cast<const uint4*>(x + (size_t)m * ld_x + c), v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] *= gte;
+        *reinterpret_cast<uint4*>(out + (size_t)m * ld_o + c) = TT<T>::pack(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ra_gate_bwd_k(const T* __restrict__ x, int ld_x, const float* __restrict__ crop, const T* __restrict__ dout, int ld_do,
+                                                     T* __restrict__ dx, int ld_dx, int dx_accum, float* __restrict__ dcrop, int M, int C) {
+    // one wave per pixel row: lanes sweep channel vectors, wave-reduce the dot product for dcrop
+    constexpr int V = TT<T>::VEC;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int m = blockIdx.x * 4 + wv; m < M; m += gridDim.x * 4) {
+        const float s = sigmoidf_(crop[m]), gte = 1.f - s;
+        float dot = 0.f;
+        for (int c = lane * V; c < C; c += 64 * V) {
+            float xv[V], g[V], o[V];
+            TT<T>::unpack(*reinterpret_cast<const uint4*>(x + (size_t)m * ld_x + c), xv);
+            TT<T>::unpack(*reinterpret_cast<const uint4*>(dout + (size_t)m * ld_do + c), g);
+            if (dx_accum) TT<T>::unpack(*reinterpret_cast<const uint4*>(dx + (size_t)m * ld_dx + c), o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { dot += g[e] * xv[e]; o[e] = dx_accum ? o[e] + g[e] * gte : g[e] * gte; }
+            *reinterpret_cast<uint4*>(dx + (size_t)m * ld_dx + c) = TT<T>::pack(o);
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) dcrop[m] = -s * gte * dot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ structure loss
+// weit = 1 + 5*|avgpool31x31(mask, stride 1, pad 15, count_include_pad) - mask|  (MyTrain_med.py:21)
+constexpr int LT = 32;
+__global__ __launch_bounds__(256) void loss_weights_k(const float* __restrict__ mask, float* __restrict__ weit, int H, int W, int ks) {
+    extern __shared__ float sh[];                  // tile (LT+ks-1)^2 then row sums (LT+ks-1) x LT
+    const int R = ks / 2, TS = LT + ks - 1;
+    float* tile = sh; float* hs = sh + TS * TS;
+    const int n = blockIdx.z, ty0 = blockIdx.y * LT, tx0 = blockIdx.x * LT;
+    const float* mk = mask + (size_t)n * H * W;
+    for (int i = threadIdx.x; i < TS * TS; i += 256) {
+        const int yy = ty0 - R + i / TS, xx = tx0 - R + i % TS;
+        tile[i] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? mk[(size_t)yy * W + xx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TS * LT; i += 256) {
+        const int r = i / LT, c = i % LT;
+        float s = 0.f;
+        for (int k = 0; k < ks; ++k) s += tile[r * TS + c + k];
+        hs[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LT * LT; i += 256) {
+        const int r = i / LT, c = i % LT, yy = ty0 + r, xx = tx0 + c;
+        if (yy >= H || xx >= W) continue;
+        float s = 0.f;
+        for (int k = 0; k < ks; ++k) s += hs[(r + k) * LT + c];
+        const float m = tile[(r + R) * TS + c + R];
+        weit[(size_t)n * H * W + (size_t)yy * W + xx] = 1.f + 5.f * fabsf(s / (float)(ks * ks) - m);
+    }
+}
+
+__device__ __forceinline__ float bce_logits(float x, float z) { return fmaxf(x, 0.f) - x * z + log1pf(__expf(-fabsf(x))); }
+
+// partial[p][n][blk][5] = { sum w*bce_fg, sum w*bce_bg, sum p*m*w, sum (p+m)*w, sum w }
+__global__ __launch_bounds__(256) void loss_fwd_k(const float* __restrict__ preds, long long map_stride, int P, const float* __restrict__ mask,
+                                                  const float* __restrict__ weit, float* __restrict__ partial, int N, int HW) {
+    __shared__ float sh[5][4];
+    const int p = blockIdx.z, n = blockIdx.y, nb = gridDim.x;
+    const float* xf = preds + (size_t)p * map_stride + (size_t)n * HW;
+    const float* xb = preds + (size_t)(P + p) * map_stride + (size_t)n * HW;
+    const float* mk = mask + (size_t)n * HW; const float* wt = weit + (size_t)n * HW;
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int chunk = (HW + nb - 1) / nb, i0 = blockIdx.x * chunk;
+    int i1 = i0 + chunk; if (i1 > HW) i1 = HW;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float m = mk[i], w = wt[i], f = xf[i], b = xb[i];
+        const float pr = 1.f / (1.f + expf(-f));
+        a[0] += w * bce_logits(f, m); a[1] += w * bce_logits(b, 1.f - m);
+        a[2] += pr * m * w; a[3] += (pr + m) * w; a[4] += w;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { a[j] = wave_sum(a[j]); if (lane == 0) sh[j][wv] = a[j]; }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int j = threadIdx.x;
+        partial[(((size_t)p * N + n) * nb + blockIdx.x) * 5 + j] = sh[j][0] + sh[j][1] + sh[j][2] + sh[j][3];
+    }
+}
+
+__global__ void loss_finalize_k(const float* __restrict__ partial, int P, int N, int nb, float* __restrict__ sums, float* __restrict__ wsum, float* __restrict__ loss) {
+    __shared__ float per[64 * 8];                  // per (p,n) loss term
+    const int t = threadIdx.x;
+    if (t < P * N) {
+        const int p = t / N, n = t % N;
+        double a[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < nb; ++b)
+            for (int j = 0; j < 5; ++j) a[j] += (double)partial[(((size_t)p * N + n) * nb + b) * 5 + j];
+        float* s = sums + ((size_t)p * N + n) * 4;
+        s[0] = (float)a[0]; s[1] = (float)a[1]; s[2] = (float)a[2]; s[3] = (float)a[3];
+        if (p == 0) wsum[n] = (float)a[4];
+        const float wbce = (float)(a[0] / a[4]), wbce2 = (float)(a[1] / a[4]);
+        const float wiou = 1.f - ((float)a[2] + 1.f) / ((float)a[3] - (float)a[2] + 1.f);
+        per[t] = wbce + wiou + 0.8f * wbce2;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float tot = 0.f;
+        for (int p = 0; p < P; ++p) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s += per[p * N + n];
+            loss[p] = s / (float)N; tot += loss[p];
+        }
+        loss[P] = tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_bwd_k(const float* __restrict__ preds, float* __restrict__ dpreds, long long map_stride, int P,
+                                                  const float* __restrict__ mask, const float* __restrict__ weit, const float* __restrict__ wsum,
+                                                  const float* __restrict__ sums, float gscale, int N, int HW) {
+    const int p = blockIdx.z, n = blockIdx.y;
+    const size_t of = (size_t)p * map_stride + (size_t)n * HW, ob = (size_t)(P + p) * map_stride + (size_t)n * HW;
+    const float* s = sums + ((size_t)p * N + n) * 4;
+    const float Wn = wsum[n], I = s[2], U = s[3], D = U - I + 1.f;
+    const float gs = gscale / (float)N, invW = 1.f / Wn, invD2 = 1.f / (D * D);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const float m = mask[(size_t)n * HW + i], w = weit[(size_t)n * HW + i];
+        const float f = preds[of + i], b = preds[ob + i];
+        const float pr = 1.f / (1.f + expf(-f)), pb = 1.f / (1.f + expf(-b));
+        const float dwiou = -(m * w * D - (I + 1.f) * (w - m * w)) * invD2;
+        dpreds[of + i] = gs * (w * (pr - m) * invW + dwiou * pr * (1.f - pr));
+        dpreds[ob + i] = gs * 0.8f * w * (pb - (1.f - m)) * invW;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ clamp + Adam
+__global__ void adam_tick_k(float* bc, float b1, float b2) {
+    // bc = {1-b1^t, 1-b2^t, b1^t, b2^t}; host initialises {0,0,1,1}
+    bc[2] *= b1; bc[3] *= b2; bc[0] = 1.f - bc[2]; bc[1] = 1.f - bc[3];
+}
+
+__global__ __launch_bounds__(256) void clamp_adam_k(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                                                    float lr, float b1, float b2, float eps, float clip, float gsc, const float* __restrict__ bc) {
+    const float step = lr / bc[0], rs2 = 1.f / sqrtf(bc[1]);
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i], Mv = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        float* pp = &P.x; float* gg = &G.x; float* mm = &Mv.x; float* vv = &V.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = fminf(fmaxf(gg[e] * gsc, -clip), clip);
+            gg[e] = ge;
+            mm[e] = b1 * mm[e] + (1.f - b1) * ge;
+            vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+            pp[e] -= step * mm[e] / (sqrtf(vv[e]) * rs2 + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(g)[i] = G; reinterpret_cast<float4*>(m)[i] = Mv; reinterpret_cast<float4*>(v)[i] = V;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float ge = fminf(fmaxf(g[i] * gsc, -clip), clip);
+        g[i] = ge;
+        m[i] = b1 * m[i] + (1.f - b1) * ge;
+        v[i] = b2 * v[i] + (1.f - b2) * ge * ge;
+        p[i] -= step * m[i] / (sqrtf(v[i]) * rs2 + eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ eval tail
+__global__ __launch_bounds__(256) void minmax_k(const float* __restrict__ x, long long n, float* __restrict__ part) {
+    __shared__ float smn[4], smx[4];
+    float mn = INFINITY, mx = -INFINITY;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float s = 1.f / (1.f + expf(-x[i])); mn = fminf(mn, s); mx = fmaxf(mx, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 + blockIdx.x * 2] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        part[3 + blockIdx.x * 2] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    }
+}
+__global__ void minmax_final_k(float* part, int nb) {
+    if (threadIdx.x == 0) {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int b = 0; b < nb; ++b) { mn = fminf(mn, part[2 + 2 * b]); mx = fmaxf(mx, part[3 + 2 * b]); }
+        part[0] = mn; part[1] = mx;
+    }
+}
+__global__ __launch_bounds__(256) void eval_u8_k(const float* __restrict__ x, unsigned char* __restrict__ out, const float* __restrict__ mm, long long n) {
+    const float mn = mm[0], den = mm[1] - mm[0] + 1e-8f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float s = 1.f / (1.f + expf(-x[i]));
+        out[i] = (unsigned char)(((s - mn) / den) * 255.f);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pn2_dsra_fuse_fwd(const float* fg, const float* cf, const float* cb, float* out, int M, int K, int sm, void* stream) {
+    if (!fg || !cf || !cb || !out) return -1;
+    if (K > MAXK) return -2;
+    hipLaunchKernelGGL(dsra_fwd_k, dim3(grid_for(M)), dim3(256), 0, (hipStream_t)stream, fg, cf, cb, out, M, K, sm);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+int pn2_dsra_fuse_bwd(const float* fg, const float* cf, const float* cb, const float* dout, float* dfg, float* dcf, float* dcb, int M, int K, int sm, void* stream) {
+    if (!fg || !cf || !cb || !dout || !dfg || !dcf || !dcb) return -1;
+    if (K > MAXK) return -2;
+    hipLaunchKernelGGL(dsra_bwd_k, dim3(grid_for(M)), dim3(256), 0, (hipStream_t)stream, fg, cf, cb, dout, dfg, dcf, dcb, M, K, sm);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_ra_gate_fwd(int dt, const void* x, int ld_x, const float* crop, void* out, int ld_out, int M, int C, void* stream) {
+    if (!x || !crop || !out) return -1;
+    if (C % 8 || ld_x % 8 || ld_out % 8) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16) hipLaunchKernelGGL(ra_gate_fwd_k<bf16_t>, dim3(grid_for((size_t)M * C / 8)), dim3(256), 0, st, (const bf16_t*)x, ld_x, crop, (bf16_t*)out, ld_out, M, C);
+    else if (dt == PN2_F32) hipLaunchKernelGGL(ra_gate_fwd_k<float>, dim3(grid_for((size_t)M * C / 4)), dim3(256), 0, st, (const float*)x, ld_x, crop, (float*)out, ld_out, M, C);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+int pn2_ra_gate_bwd(int dt, const void* x, int ld_x, const float* crop, const void* dout, int ld_dout, void* dx, int ld_dx, int dx_accum, float* dcrop, int M, int C, void* stream) {
+    if (!x || !crop || !dout || !dx || !dcrop) return -1;
+    if (C % 8 || ld_x % 8 || ld_dout % 8 || ld_dx % 8) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (M + 3) / 4 > 8192 ? 8192 : (M + 3) / 4;
+    if (dt == PN2_BF16) hipLaunchKernelGGL(ra_gate_bwd_k<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ld_x, crop, (const bf16_t*)dout, ld_dout, (bf16_t*)dx, ld_dx, dx_accum, dcrop, M, C);
+    else if (dt == PN2_F32) hipLaunchKernelGGL(ra_gate_bwd_k<float>, dim3(grid), dim3(256), 0, st, (const float*)x, ld_x, crop, (const float*)dout, ld_dout, (float*)dx, ld_dx, dx_accum, dcrop, M, C);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_loss_weights(const float* mask, float* weit, int N, int H, int W, int ksize, void* stream) {
+    if (!mask || !weit) return -1;
+    if (ksize < 1 || !(ksize & 1) || ksize > 63) return -2;
+    const int TS = LT + ksize - 1;
+    const size_t lds = (size_t)(TS * TS + TS * LT) * 4;
+    hipLaunchKernelGGL(loss_weights_k, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, N), dim3(256), lds, (hipStream_t)stream, mask, weit, H, W, ksize);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_loss_blocks(int HW) { int b = (HW + 4095) / 4096; return b > 64 ? 64 : (b < 1 ? 1 : b); }
+
+int pn2_structure_loss_fwd(const float* preds, long long map_stride, int P, const float* mask, const float* weit, float* partial,
+                           float* sums, float* wsum, float* loss, int N, int HW, void* stream) {
+    if (!preds || !mask || !weit || !partial || !sums || !wsum || !loss) return -1;
+    if (P * N > 512 || P > 8) return -2;
+    const int nb = pn2_loss_blocks(HW);
+    hipLaunchKernelGGL(loss_fwd_k, dim3(nb, N, P), dim3(256), 0, (hipStream_t)stream, preds, map_stride, P, mask, weit, partial, N, HW);
+    hipLaunchKernelGGL(loss_finalize_k, dim3(1), dim3(512), 0, (hipStream_t)stream, partial, P, N, nb, sums, wsum, loss);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_structure_loss_bwd(const float* preds, float* dpreds, long long map_stride, int P, const float* mask, const float* weit, const float* wsum,
+                           const float* sums, float gscale, int N, int HW, void* stream) {
+    if (!preds || !dpreds || !mask || !weit || !wsum || !sums) return -1;
+    int nb = (HW + 1023) / 1024; if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(loss_bwd_k, dim3(nb, N, P), dim3(256), 0, (hipStream_t)stream, preds, dpreds, map_stride, P, mask, weit, wsum, sums, gscale, N, HW);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_adam_tick(float* bc, float beta1, float beta2, void* stream) {
+    if (!bc) return -1;
+    hipLaunchKernelGGL(adam_tick_k, dim3(1), dim3(1), 0, (hipStream_t)stream, bc, beta1, beta2);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_clamp_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
+                   float eps, float clip, float grad_scale, const float* bias_corr, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !bias_corr) return -1;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return -2;
+    hipLaunchKernelGGL(clamp_adam_k, dim3(grid_for((size_t)(n / 4 + 1), 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, clip, grad_scale, bias_corr);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_eval_tail(const float* res, unsigned char* out, float* minmax, long long n, void* stream) {
+    if (!res || !out || !minmax) return -1;
+    const int nb = grid_for((size_t)n, 512);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(minmax_k, dim3(nb), dim3(256), 0, st, res, n, minmax);
+    hipLaunchKernelGGL(minmax_final_k, dim3(1), dim3(64), 0, st, minmax, nb);
+    hipLaunchKernelGGL(eval_u8_k, dim3(grid_for((size_t)n)), dim3(256), 0, st, res, out, minmax, n);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

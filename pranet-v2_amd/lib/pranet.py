@@ -1,0 +1,249 @@
+"""PraNet-V2 (DSRA) models on the pn2 engine — same nn.Module surface as the reference's lib/pranet.py.
+
+Class names, constructor signatures, sub-module names (hence state_dict keys) and the 8-tuple returned by
+forward() match /root/reference/binary_seg/lib/pranet.py (BasicConv2d :31-43, RFB_modified :46-83,
+aggregation :86-125, PVT_PraNet_V2 :129-263, PraNet_V2 :268-417), so MyTrain_med.py / MyTest_med.py import
+this file unchanged.  forward() runs hand-written gfx950 kernels (csrc/) through pn2.engine; the
+nn.Conv2d / nn.BatchNorm2d leaves only hold parameters.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from lib.nn import SynchronizedBatchNorm2d
+from pn2.capi import F32
+from pn2.engine import rup
+from pn2.graph import run_module
+from .Res2Net_v1b import res2net50_v1b_26w_4s
+
+BatchNorm2d = SynchronizedBatchNorm2d
+
+
+def conv3x3_bn_relu(in_planes, out_planes, stride=1):
+    "3x3 convolution + BN + relu (kept for import compatibility; nothing on the hot path calls it)"
+    return nn.Sequential(nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False),
+                         BatchNorm2d(out_planes), nn.ReLU(inplace=True))
+
+
+class BasicConv2d(nn.Module):
+    """conv -> BN, bias-free, and NO ReLU in forward (the `relu` member is unused, as in the reference :31-43)."""
+
+    def __init__(self, in_planes, out_planes, kernel_size, stride=1, padding=0, dilation=1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation, bias=False)
+        self.bn = nn.BatchNorm2d(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+
+    def _build(self, eng, x, relu=False, residual=None, out=None, head=False):
+        if head:      # K-channel fp32 head map; raw conv output keeps 8-channel padded rows
+            K = self.conv.out_channels
+            return eng.conv_bn_act(x, self.conv, self.bn, relu=relu, out_map=(K, rup(K, 8)), y_dt=F32, y_C=K)
+        return eng.conv_bn_act(x, self.conv, self.bn, relu=relu, residual=residual, out=out)
+
+    def forward(self, x):
+        return run_module(lambda e, a: [self._build(e, a)], [x], list(self.parameters()), self.training)[0]
+
+
+class RFB_modified(nn.Module):
+    def __init__(self, in_channel, out_channel):
+        super().__init__()
+        self.relu = nn.ReLU(True)
+        self.branch0 = nn.Sequential(BasicConv2d(in_channel, out_channel, 1))
+
+        def branch(k):
+            return nn.Sequential(
+                BasicConv2d(in_channel, out_channel, 1),
+                BasicConv2d(out_channel, out_channel, kernel_size=(1, k), padding=(0, k // 2)),
+                BasicConv2d(out_channel, out_channel, kernel_size=(k, 1), padding=(k // 2, 0)),
+                BasicConv2d(out_channel, out_channel, 3, padding=k, dilation=k))
+        self.branch1, self.branch2, self.branch3 = branch(3), branch(5), branch(7)
+        self.conv_cat = BasicConv2d(4 * out_channel, out_channel, 3, padding=1)
+        self.conv_res = BasicConv2d(in_channel, out_channel, 1)
+
+    def _build(self, eng, x):
+        """reference :75-83 — the four branches write straight into the channel slices of the concat buffer,
+        and relu(x_cat + conv_res(x)) is the residual epilogue of conv_cat's BN-apply pass."""
+        c = self.conv_cat.conv.out_channels
+        cat = eng.new_act(x.N, x.H, x.W, 4 * c)
+        self.branch0[0]._build(eng, x, out=cat.slice(0, c))
+        for bi, br in enumerate((self.branch1, self.branch2, self.branch3), start=1):
+            t = br[0]._build(eng, x)
+            t = br[1]._build(eng, t)
+            t = br[2]._build(eng, t)
+            br[3]._build(eng, t, out=cat.slice(bi * c, (bi + 1) * c))
+        res = self.conv_res._build(eng, x)
+        return self.conv_cat._build(eng, cat, relu=True, residual=res)
+
+    def forward(self, x):
+        return run_module(lambda e, a: [self._build(e, a)], [x], list(self.parameters()), self.training)[0]
+
+
+class aggregation(nn.Module):
+    def __init__(self, channel, num_class):
+        super().__init__()
+        self.relu = nn.ReLU(True)
+        self.upsample = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+        self.conv_upsample1 = BasicConv2d(channel, channel, 3, padding=1)
+        self.conv_upsample2 = BasicConv2d(channel, channel, 3, padding=1)
+        self.conv_upsample3 = BasicConv2d(channel, channel, 3, padding=1)
+        self.conv_upsample4 = BasicConv2d(channel, channel, 3, padding=1)
+        self.conv_upsample5 = BasicConv2d(2 * channel, 2 * channel, 3, padding=1)
+        self.conv_concat2 = BasicConv2d(2 * channel, 2 * channel, 3, padding=1)
+        self.conv_concat3 = BasicConv2d(3 * channel, 3 * channel, 3, padding=1)
+        self.conv4 = BasicConv2d(3 * channel, 3 * channel, 3, padding=1)
+        self.conv5_fg = nn.Conv2d(3 * channel, num_class, 1)
+        self.conv5_bg = nn.Conv2d(3 * channel, num_class, 1)
+
+    def _build_trunk(self, eng, x1, x2, x3):
+        """reference :109-121 up to conv4 (shared by the V1 single-head aggregation)."""
+        c = x1.C
+        up = lambda a: eng.bilinear(a, 2, align_corners=True)
+        u1 = up(x1)                                   # reference recomputes upsample(x1) three times; same values
+        cat2 = eng.new_act(x2.N, x2.H, x2.W, 2 * c)
+        eng.mul(self.conv_upsample1._build(eng, u1), x2, out=cat2.slice(0, c))                       # x2_1
+        self.conv_upsample4._build(eng, u1, out=cat2.slice(c, 2 * c))
+        cat3 = eng.new_act(x3.N, x3.H, x3.W, 3 * c)
+        t = eng.mul(self.conv_upsample2._build(eng, up(u1)), self.conv_upsample3._build(eng, up(x2)))
+        eng.mul(t, x3, out=cat3.slice(0, c))                                                         # x3_1
+        x2_2 = self.conv_concat2._build(eng, cat2)
+        self.conv_upsample5._build(eng, up(x2_2), out=cat3.slice(c, 3 * c))
+        x3_2 = self.conv_concat3._build(eng, cat3)
+        return self.conv4._build(eng, x3_2)
+
+    def _build(self, eng, x1, x2, x3):
+        x = self._build_trunk(eng, x1, x2, x3)
+        heads = []
+        for conv in (self.conv5_fg, self.conv5_bg):
+            K = conv.out_channels
+            heads.append(eng.conv_bn_act(x, conv, None, out_map=(K, rup(K, 8)), y_dt=F32, y_C=K, bias=conv.bias))
+        return heads
+
+    def forward(self, x1, x2, x3):
+        return run_module(lambda e, a, b, c: self._build(e, a, b, c), [x1, x2, x3], list(self.parameters()), self.training)
+
+
+def _dsra_tail(m, eng, x2, x3, x4, ra5_fg, ra5_bg):
+    """DSRA3/2/1 of reference :349-417 (identical in PVT_PraNet_V2 :205-263); returns the 8 lateral maps."""
+    sd = m.sem_downsample
+    up = lambda a, s: eng.bilinear(a, s)
+
+    def final(a, s, j):   # full-resolution lateral map j of the returned 8-tuple
+        OH, OW = int(math.floor(a.H * s)), int(math.floor(a.W * s))
+        return eng.bilinear(a, s, out=eng.lateral_out(j, 8, a.N, OH, OW, a.C))
+    l5_fg, l5_bg = final(ra5_fg, 8 / sd, 3), final(ra5_bg, 8 / sd, 7)
+    # ---- DSRA3
+    c_fg, c_bg = up(ra5_fg, 0.25), up(ra5_bg, 0.25)
+    t = m.ra4_conv1._build(eng, x4)
+    t = m.ra4_conv2._build(eng, t, relu=True)
+    t = m.ra4_conv3._build(eng, t, relu=True)
+    t = m.ra4_conv4._build(eng, t, relu=True)
+    f = m.ra4_conv5_fg._build(eng, t, head=True)
+    b = m.ra4_conv5_bg._build(eng, t, head=True)
+    f = eng.dsra_fuse(f, c_fg, c_bg, m.use_softmax)
+    l4_fg, l4_bg = final(f, 32 / sd, 2), final(b, 32 / sd, 6)
+    lat = {}
+    for s, xs, u in ((3, x3, 16), (2, x2, 8)):
+        c_fg, c_bg = up(f, 2), up(b, 2)
+        t = getattr(m, f"ra{s}_conv1")._build(eng, xs)
+        t = getattr(m, f"ra{s}_conv2")._build(eng, t, relu=True)
+        t = getattr(m, f"ra{s}_conv3")._build(eng, t, relu=True)
+        f = getattr(m, f"ra{s}_conv4_fg")._build(eng, t, head=True)
+        b = getattr(m, f"ra{s}_conv4_bg")._build(eng, t, head=True)
+        f = eng.dsra_fuse(f, c_fg, c_bg, m.use_softmax)
+        lat[s] = (final(f, u / sd, 3 - s), final(b, u / sd, 7 - s))
+    return [lat[2][0], lat[3][0], l4_fg, l5_fg, lat[2][1], lat[3][1], l4_bg, l5_bg]
+
+
+class PraNet_V2(nn.Module):
+    """Res2Net-50 encoder + RFBs + partial decoder + three dual-supervised reverse-attention stages."""
+
+    def __init__(self, channel=32, num_class=3, sem_downsample=1, use_softmax=True):
+        super().__init__()
+        self.idx = range(10)
+        self.num_class = num_class
+        self.sem_downsample = sem_downsample
+        self.use_softmax = use_softmax
+        self.conv = nn.Sequential(nn.Conv2d(1, 3, kernel_size=1), nn.BatchNorm2d(3), nn.ReLU(inplace=True))   # unused by forward (reference :278-282)
+        self.backbone = res2net50_v1b_26w_4s(pretrained=True)
+        self.rfb2_1 = RFB_modified(512, channel)
+        self.rfb3_1 = RFB_modified(1024, channel)
+        self.rfb4_1 = RFB_modified(2048, channel)
+        self.agg1 = aggregation(channel, self.num_class)
+        self.ra4_conv1 = BasicConv2d(2048, 256, kernel_size=1)
+        self.ra4_conv2 = BasicConv2d(256, 256, kernel_size=5, padding=2)
+        self.ra4_conv3 = BasicConv2d(256, 256, kernel_size=5, padding=2)
+        self.ra4_conv4 = BasicConv2d(256, 256, kernel_size=5, padding=2)
+        self.ra4_conv5_fg = BasicConv2d(256, num_class, kernel_size=1)
+        self.ra4_conv5_bg = BasicConv2d(256, num_class, kernel_size=1)
+        self.ra3_conv1 = BasicConv2d(1024, 64, kernel_size=1)
+        self.ra3_conv2 = BasicConv2d(64, 64, kernel_size=3, padding=1)
+        self.ra3_conv3 = BasicConv2d(64, 64, kernel_size=3, padding=1)
+        self.ra3_conv4_fg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
+        self.ra3_conv4_bg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
+        self.ra2_conv1 = BasicConv2d(512, 64, kernel_size=1)
+        self.ra2_conv2 = BasicConv2d(64, 64, kernel_size=3, padding=1)
+        self.ra2_conv3 = BasicConv2d(64, 64, kernel_size=3, padding=1)
+        self.ra2_conv4_fg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
+        self.ra2_conv4_bg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
+
+    def hot_parameters(self):
+        """Parameters that forward() touches (backbone.fc and self.conv never receive gradients — reference :329-417)."""
+        return [p for n, p in self.named_parameters() if not (n.startswith('conv.') or n.startswith('backbone.fc.'))]
+
+    def _build(self, eng, x):
+        x1, x2, x3, x4 = self.backbone._build_features(eng, x)
+        x2_rfb = self.rfb2_1._build(eng, x2)
+        x3_rfb = self.rfb3_1._build(eng, x3)
+        x4_rfb = self.rfb4_1._build(eng, x4)
+        ra5_fg, ra5_bg = self.agg1._build(eng, x4_rfb, x3_rfb, x2_rfb)
+        return _dsra_tail(self, eng, x2, x3, x4, ra5_fg, ra5_bg)
+
+    def forward(self, x, segSize=None):
+        return run_module(self._build, [x], self.hot_parameters(), self.training)
+
+
+class PVT_PraNet_V2(nn.Module):
+    """PVTv2-B2 variant (reference :129-263).  Heads are shared with PraNet_V2; the transformer encoder kernels are
+    the next row of the build plan, so construction is available but forward raises."""
+
+    def __init__(self, channel=32, num_class=3, sem_downsample=1, use_softmax=True):
+        super().__init__()
+        self.idx = range(10)
+        self.num_class = num_class
+        self.sem_downsample = sem_downsample
+        self.use_softmax = use_softmax
+        self.conv = nn.Sequential(nn.Conv2d(1, 3, kernel_size=1), nn.BatchNorm2d(3), nn.ReLU(inplace=True))
+        from lib.pvtv2 import pvt_v2_b2
+        self.backbone = pvt_v2_b2()
+        path = './models/pvt_v2_b2.pth'
+        if os.path.exists(path) or os.environ.get('PN2_NO_PRETRAINED', '0') != '1':
+            save_model = torch.load(path)
+            model_dict = self.backbone.state_dict()
+            model_dict.update({k: v for k, v in save_model.items() if k in model_dict.keys()})
+            self.backbone.load_state_dict(model_dict)
+        self.rfb2_1 = RFB_modified(128, channel)
+        self.rfb3_1 = RFB_modified(320, channel)
+        self.rfb4_1 = RFB_modified(512, channel)
+        self.agg1 = aggregation(channel, self.num_class)
+        self.ra4_conv1 = BasicConv2d(512, 256, kernel_size=1)
+        self.ra4_conv2 = BasicConv2d(256, 256, kernel_size=5, padding=2)
+        self.ra4_conv3 = BasicConv2d(256, 256, kernel_size=5, padding=2)
+        self.ra4_conv4 = BasicConv2d(256, 256, kernel_size=5, padding=2)
+        self.ra4_conv5_fg = BasicConv2d(256, num_class, kernel_size=1)
+        self.ra4_conv5_bg = BasicConv2d(256, num_class, kernel_size=1)
+        self.ra3_conv1 = BasicConv2d(320, 64, kernel_size=1)
+        self.ra3_conv2 = BasicConv2d(64, 64, kernel_size=3, padding=1)
+        self.ra3_conv3 = BasicConv2d(64, 64, kernel_size=3, padding=1)
+        self.ra3_conv4_fg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
+        self.ra3_conv4_bg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
+        self.ra2_conv1 = BasicConv2d(128, 64, kernel_size=1)
+        self.ra2_conv2 = BasicConv2d(64, 64, kernel_size=3, padding=1)
+        self.ra2_conv3 = BasicConv2d(64, 64, kernel_size=3, padding=1)
+        self.ra2_conv4_fg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
+        self.ra2_conv4_bg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
+
+    def forward(self, x, segSize=None):
+        raise NotImplementedError("PVT_PraNet_V2.forward: the PVTv2-B2 encoder kernels (LayerNorm, SR-attention, DW-conv) are the next "
+                                  "scope row (SURVEY.md §8 a11 / f2); there is no PyTorch fallback by design")

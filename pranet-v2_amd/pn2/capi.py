@@ -1,0 +1,117 @@
+"""ctypes binding of libpn2_hip.so (C ABI declared in include/pn2.h).
+
+This is the reference-side binding a maintainer would add: plain pointers and sizes, no torch
+types cross the boundary.  There is NO CPU fallback: if the shared library is missing or a call
+fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpn2_hip.so")
+
+F32, BF16 = 0, 1
+CONV_STATS, CONV_ACCUM = 1, 2
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "OH", "OW", "Cin_p", "ld_in", "Cout", "ld_out", "KH", "KW", "stride",
+                                       "pad_h", "pad_w", "dil_h", "dil_w", "transposed", "Kp", "flags")]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "OH", "OW", "Cin_p", "ld_x", "Cout_p", "ld_dy", "KH", "KW", "stride",
+                                       "pad_h", "pad_w", "dil_h", "dil_w", "Rp", "Kp")]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("Cout", "Cin", "KH", "KW", "Cout_p", "gw_out", "gwp_out", "Cin_p", "gw_in", "gwp_in",
+                                       "Rp", "Kp", "transposed")]
+
+
+class BnDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("Cp", C.c_int), ("C", C.c_int), ("gw", C.c_int), ("gwp", C.c_int),
+                ("eps", C.c_float), ("momentum", C.c_float)]
+
+
+P, I, LL, FL = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+# name -> argtypes ; every function returns int (0 = ok)
+SIGNATURES = {
+    "pn2_conv_tile_n": [I],
+    "pn2_wgrad_tile_co": [I],
+    "pn2_conv_stat_blocks": [I],
+    "pn2_conv_gemm": [I, P, P, P, P, P, C.POINTER(ConvDesc), P],
+    "pn2_conv_wgrad": [I, P, P, P, C.POINTER(WgradDesc), I, P],
+    "pn2_pack_weight": [I, P, P, C.POINTER(PackDesc), P],
+    "pn2_wgrad_reduce": [P, P, C.POINTER(PackDesc), I, I, P],
+    "pn2_bn_finalize": [P, P, I, C.POINTER(BnDesc), P, P, P, P, P, P, P, P, P],
+    "pn2_bn_eval_prepare": [C.POINTER(BnDesc), P, P, P, P, P, P, P],
+    "pn2_affine_act": [I, P, I, I, P, I, I, I, P, P, P, I, I, P],
+    "pn2_bn_bwd_reduce": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P],
+    "pn2_bn_bwd_blocks": [I],
+    "pn2_bn_bwd_finalize": [P, P, I, C.POINTER(BnDesc), P, P, P, P, I, P, P],
+    "pn2_bn_bwd_apply": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, I, I, P],
+    "pn2_maxpool3x3s2_fwd": [I, P, I, P, I, P, I, I, I, I, I, I, P],
+    "pn2_maxpool3x3s2_bwd": [I, P, I, P, P, I, I, I, I, I, I, I, P],
+    "pn2_avgpool_fwd": [I, P, I, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "pn2_avgpool_bwd": [I, P, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "pn2_bilinear_fwd": [I, P, I, P, I, I, I, I, I, I, I, I, FL, FL, P],
+    "pn2_bilinear_bwd": [I, P, I, P, I, I, I, I, I, I, I, I, FL, FL, I, P],
+    "pn2_dsra_fuse_fwd": [P, P, P, P, I, I, I, P],
+    "pn2_dsra_fuse_bwd": [P, P, P, P, P, P, P, I, I, I, P],
+    "pn2_ra_gate_fwd": [I, P, I, P, P, I, I, I, P],
+    "pn2_ra_gate_bwd": [I, P, I, P, P, I, P, I, I, P, I, I, P],
+    "pn2_loss_weights": [P, P, I, I, I, I, P],
+    "pn2_loss_blocks": [I],
+    "pn2_structure_loss_fwd": [P, LL, I, P, P, P, P, P, P, I, I, P],
+    "pn2_structure_loss_bwd": [P, P, LL, I, P, P, P, P, FL, I, I, P],
+    "pn2_binary": [I, I, P, I, P, I, P, I, I, I, I, P],
+    "pn2_copy": [I, P, I, I, P, I, I, I, I, P],
+    "pn2_nchw_to_nhwc": [I, P, P, I, I, I, I, I, P],
+    "pn2_bias_grad": [P, I, I, P, I, P],
+    "pn2_clamp_adam": [P, P, P, P, LL, FL, FL, FL, FL, FL, FL, P, P],
+    "pn2_adam_tick": [P, FL, FL, P],
+    "pn2_eval_tail": [P, P, P, LL, P],
+}
+# entry points that return a value rather than a status
+_VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_bn_bwd_blocks", "pn2_loss_blocks"}
+
+_lib = None
+WORK = {}     # profiling annotation for the next launch (algorithmic flops / tag), consumed by pn2.profile.Recorder
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C pranet-v2_amd/csrc` (or __graft_entry__.build()); "
+                           "pranet-v2_amd has no CPU / PyTorch fallback path")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export what pn2.h declares
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class _Caller:
+    """`call.pn2_xxx(...)` -> invokes the C entry point and raises RuntimeError on a non-zero status."""
+
+    def __getattr__(self, name):
+        fn = getattr(load(), name)
+        if name in _VALUE_FUNCS:
+            return fn
+
+        def checked(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise RuntimeError(f"{name} failed with status {rc}")
+        setattr(self, name, checked)
+        return checked
+
+
+call = _Caller()

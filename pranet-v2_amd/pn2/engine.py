@@ -1,0 +1,509 @@
+"""Host engine: NHWC activations, a reverse-mode tape, and the op set the PraNet models are written in.
+
+Everything here is plumbing around the C ABI (capi.py): PyTorch supplies device memory and the
+current HIP stream; every arithmetic pass over an activation is one of the gfx950 kernels in csrc/.
+There is deliberately no CPU implementation: ops raise on non-GPU tensors.
+
+Layout: activations are NHWC with *physical* channels.  A tensor whose logical channels come in
+groups of `gw` (Res2Net's 26/52-wide splits, K-channel heads) stores each group in `gwp` = gw rounded
+up to 8 slots, the pad slots holding exact zeros; weights are packed with matching zero rows/columns,
+so the arithmetic is unchanged while every pixel row stays 16-byte aligned.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import capi
+from .capi import call, F32, BF16
+
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def rup(v, m):
+    return (v + m - 1) // m * m
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Act:
+    """NHWC activation view.  t: torch tensor (N,H,W,Cp) whose last dim is contiguous; ld = pixel stride."""
+    __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0")
+
+    def __init__(self, eng, t, C_, gw=None, gwp=None, dt=None, requires_grad=True):
+        self.eng, self.t = eng, t
+        self.N, self.H, self.W = t.shape[0], t.shape[1], t.shape[2]
+        self.C = C_
+        self.gw = gw if gw is not None else t.shape[3]
+        self.gwp = gwp if gwp is not None else t.shape[3]
+        self.dt = dt if dt is not None else (F32 if t.dtype == torch.float32 else BF16)
+        self.grad, self._written, self.child_written, self.requires_grad = None, False, False, requires_grad
+        self.parent, self.c0 = None, 0
+
+    @property
+    def grad_written(self):
+        # a slice of a buffer that was written as a whole (e.g. dgrad into a concat buffer) counts as written
+        return self._written or (self.parent is not None and self.parent.grad_written)
+
+    @grad_written.setter
+    def grad_written(self, v):
+        self._written = v
+        if v and self.parent is not None:
+            self.parent.child_written = True
+
+    Cp = property(lambda s: s.t.shape[3])
+    ld = property(lambda s: s.t.stride(2))
+    M = property(lambda s: s.N * s.H * s.W)
+    ptr = property(lambda s: C.c_void_p(s.t.data_ptr()))
+
+    def slice(self, c0, c1, C_=None, gw=None, gwp=None):
+        """Channel-slice view (physical channel range); its gradient is the same slice of this grad."""
+        a = Act(self.eng, self.t[..., c0:c1], C_ if C_ is not None else c1 - c0, gw, gwp, self.dt, self.requires_grad)
+        a.parent, a.c0 = self, c0
+        return a
+
+    def grad_buf(self):
+        """Gradient storage (allocated on first use, uninitialised)."""
+        if self.grad is None:
+            if self.parent is not None:
+                self.grad = self.parent.grad_buf()[..., self.c0:self.c0 + self.Cp]
+            else:
+                self.grad = torch.empty(self.t.shape, dtype=self.t.dtype, device=self.t.device)
+        return self.grad
+
+    def grad_sink(self):
+        """-> (tensor, accumulate_flag) for a backward op that contributes to this activation's gradient."""
+        g = self.grad_buf()
+        acc = 1 if self.grad_written else 0
+        self.grad_written = True
+        return g, acc
+
+
+class ParamGrads:
+    """Where parameter gradients go.  Default: fresh fp32 tensors (autograd mode).  The trainer swaps in
+    views of its flat gradient arena so the fused clamp+Adam kernel sees one contiguous buffer."""
+
+    def __init__(self, provider=None):
+        self.provider = provider
+        self.bufs = {}
+        self.written = set()
+
+    def sink(self, p):
+        k = id(p)
+        if k not in self.bufs:
+            self.bufs[k] = self.provider(p) if self.provider else torch.empty_like(p, dtype=torch.float32)
+        acc = 1 if k in self.written else 0
+        self.written.add(k)
+        return self.bufs[k], acc
+
+    def get(self, p):
+        return self.bufs.get(id(p)) if id(p) in self.written else None
+
+
+class Engine:
+    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("pranet-v2_amd runs on MI355X only: no GPU visible and there is no CPU fallback")
+        capi.load()
+        self.dt = dtype
+        self.tdt = TORCH_DT[dtype]
+        self.training = training
+        self.need_grad = need_grad      # decided by the caller (grad mode is off inside autograd.Function.forward)
+        self.tape = []
+        self.pgrads = ParamGrads(grad_provider)
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.bn_modules = []            # for num_batches_tracked bookkeeping
+        self._lat = None                # contiguous block of the model's full-resolution output maps
+
+    # ------------------------------------------------------------------ allocation / layout
+    def empty(self, N, H, W, Cp, dt=None):
+        return torch.empty((N, H, W, Cp), dtype=TORCH_DT[self.dt if dt is None else dt], device=self.dev)
+
+    def new_act(self, N, H, W, C_, gw=None, gwp=None, dt=None, zero=False):
+        gw = C_ if gw is None else gw
+        gwp = rup(gw, 8) if gwp is None else gwp
+        Cp = (C_ + gw - 1) // gw * gwp
+        t = self.empty(N, H, W, Cp, dt)
+        if zero:
+            t.zero_()
+        return Act(self, t, C_, gw, gwp, self.dt if dt is None else dt)
+
+    def lateral_out(self, j, nmaps, N, OH, OW, K):
+        """j-th full-resolution fp32 output map, carved from one [nmaps][N][OH][OW][K] block so the fused
+        structure-loss kernels can walk all supervision pairs with a single base pointer + stride."""
+        if self._lat is None:
+            self._lat = torch.empty((nmaps, N, OH, OW, K), dtype=torch.float32, device=self.dev)
+        return Act(self, self._lat[j], K, K, K, F32)
+
+    def lateral_block(self):
+        return self._lat
+
+    def fbuf(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def from_nchw(self, x, requires_grad=False):
+        """fp32 NCHW module input -> NHWC compute dtype, channels zero-padded to a multiple of 8."""
+        if not x.is_cuda:
+            raise RuntimeError("pranet-v2_amd ops need GPU tensors (no CPU fallback)")
+        x = x.contiguous().float()
+        N, Cc, H, W = x.shape
+        a = self.new_act(N, H, W, Cc)
+        call.pn2_nchw_to_nhwc(self.dt, _p(x), a.ptr, a.ld, N, Cc, H * W, a.Cp, _stream())
+        a.requires_grad = requires_grad and self.need_grad
+        return a
+
+    def to_nchw(self, a):
+        """Module output: (N,C,H,W) fp32 tensor.  K=1 maps are returned as zero-copy views."""
+        t = a.t[..., :a.C] if a.gw == a.C or a.Cp == a.C else self._gather_logical(a)
+        if t.dtype != torch.float32:
+            t = t.float()
+        return t.permute(0, 3, 1, 2)
+
+    def _gather_logical(self, a):
+        idx = torch.tensor([(c // a.gw) * a.gwp + c % a.gw for c in range(a.C)], device=self.dev)
+        return a.t.index_select(3, idx)
+
+    def record(self, fn):
+        if self.need_grad:
+            self.tape.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+    # ------------------------------------------------------------------ weights
+    def _pack_desc(self, w, x_map, out_map, transposed):
+        Cout, Cin, KH, KW = w.shape
+        gw_in, gwp_in, Cin_p = x_map
+        gw_out, gwp_out, Cout_p = out_map
+        d = capi.PackDesc()
+        d.Cout, d.Cin, d.KH, d.KW = Cout, Cin, KH, KW
+        d.Cout_p, d.gw_out, d.gwp_out = Cout_p, gw_out, gwp_out
+        d.Cin_p, d.gw_in, d.gwp_in = Cin_p, gw_in, gwp_in
+        d.transposed = 1 if transposed else 0
+        if transposed:
+            d.Rp, d.Kp = rup(Cin_p, 128), rup(KH * KW * Cout_p, 128)
+        else:
+            d.Rp, d.Kp = rup(Cout_p, 128), rup(KH * KW * Cin_p, 128)
+        return d
+
+    def pack(self, w, x_map, out_map, transposed):
+        d = self._pack_desc(w, x_map, out_map, transposed)
+        wp = torch.empty((d.Rp, d.Kp), dtype=self.tdt, device=self.dev)
+        call.pn2_pack_weight(self.dt, _p(w), _p(wp), C.byref(d), _stream())
+        return wp, d
+
+    # ------------------------------------------------------------------ conv (+BN +ReLU +residual)
+    def conv_bn_act(self, x, conv, bn=None, relu=False, residual=None, out=None, out_map=None, y_dt=None, y_C=None, bias=None):
+        """y = act(BN(conv(x)) + residual)   — BasicConv2d / Bottle2neck pieces.
+
+        conv: nn.Conv2d (bias-free unless `bias` given), bn: nn.BatchNorm2d or None.
+        out: optional destination Act view (writes y into a slice of a concat buffer).
+        out_map: (gw, gwp) group-padded layout of the produced channels (default identity).
+        y_dt/y_C: fp32 K-channel head outputs (physical raw output stays padded to 8).
+        """
+        w = conv.weight
+        Cout, Cin, KH, KW = w.shape
+        sh, sw = conv.stride
+        assert sh == sw and conv.groups == 1
+        ph, pw = conv.padding
+        dh, dw = conv.dilation
+        assert x.C == Cin, (x.C, Cin)
+        N, H, W = x.N, x.H, x.W
+        OH = (H + 2 * ph - dh * (KH - 1) - 1) // sh + 1
+        OW = (W + 2 * pw - dw * (KW - 1) - 1) // sw + 1
+        gw_o, gwp_o = out_map if out_map is not None else (Cout, rup(Cout, 8))
+        Cout_p = (Cout + gw_o - 1) // gw_o * gwp_o
+        x_map = (x.gw, x.gwp, x.Cp)
+        o_map = (gw_o, gwp_o, Cout_p)
+        M = N * OH * OW
+        st = _stream()
+        train_bn = bn is not None and self.training
+
+        wp, pd = self.pack(w, x_map, o_map, False)
+        raw = self.empty(N, OH, OW, Cout_p)
+        cd = capi.ConvDesc()
+        cd.N, cd.H, cd.W, cd.OH, cd.OW = N, H, W, OH, OW
+        cd.Cin_p, cd.ld_in, cd.Cout, cd.ld_out = x.Cp, x.ld, Cout_p, Cout_p
+        cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = KH, KW, sh, ph, pw, dh, dw
+        cd.transposed, cd.Kp, cd.flags = 0, pd.Kp, (capi.CONV_STATS if train_bn else 0)
+        psum = psq = None
+        if train_bn:
+            nblk = call.pn2_conv_stat_blocks(M)
+            psum, psq = self.fbuf(nblk, Cout_p), self.fbuf(nblk, Cout_p)
+        flops = 2 * M * Cout * Cin * KH * KW
+        capi.WORK.update(flops=flops, tag=":fwd")
+        call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), st)
+
+        scale = shift = mean = invstd = None
+        bd = None
+        if bn is not None:
+            bd = capi.BnDesc()
+            bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, Cout_p, Cout, gw_o, gwp_o, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
+            scale, shift = self.fbuf(Cout_p), self.fbuf(Cout_p)
+            if train_bn:
+                mean, invstd = self.fbuf(Cout_p), self.fbuf(Cout_p)
+                call.pn2_bn_finalize(_p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+                                     _p(scale), _p(shift), _p(mean), _p(invstd), st)
+                self.bn_modules.append(bn)
+            else:
+                call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), st)
+        elif bias is not None:
+            shift = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
+            shift[:Cout] = bias.detach()
+
+        y_dt = self.dt if y_dt is None else y_dt
+        if out is None:
+            if y_C is not None:
+                out = Act(self, self.empty(N, OH, OW, y_C, y_dt), y_C, y_C, y_C, y_dt)
+            else:
+                out = Act(self, self.empty(N, OH, OW, Cout_p, y_dt), Cout, gw_o, gwp_o, y_dt)
+        ncopy = y_C if y_C is not None else Cout_p
+        if residual is not None:
+            assert residual.Cp == Cout_p and residual.dt == self.dt
+        call.pn2_affine_act(self.dt, _p(raw), Cout_p, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
+                            residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, 1 if relu else 0, st)
+
+        if not self.need_grad:
+            return out
+
+        def bwd():
+            st = _stream()
+            dy = out.grad_buf()
+            assert out.grad_written or out.child_written, "conv output never received a gradient"
+            draw = self.empty(N, OH, OW, Cout_p)
+            Cdy = ncopy
+            ymask = out if relu else None
+            if train_bn:
+                nb = call.pn2_bn_bwd_blocks(M)
+                p1, p2 = self.fbuf(nb, Cout_p), self.fbuf(nb, Cout_p)
+                call.pn2_bn_bwd_reduce(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
+                                       _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(p1), _p(p2), nb, st)
+                coef = self.fbuf(3 * Cout_p)
+                gg, ga = self.pgrads.sink(bn.weight)
+                gb, gba = self.pgrads.sink(bn.bias)
+                assert ga == gba
+                call.pn2_bn_bwd_finalize(_p(p1), _p(p2), nb, C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
+            else:
+                coef = None
+                if bn is not None:
+                    raise RuntimeError("backward through eval-mode BatchNorm is not supported")
+                if bias is not None:
+                    gb, gba = self.pgrads.sink(bias)
+                    call.pn2_bias_grad(_p(dy), M, Cdy, _p(gb), gba, st)
+            rg, racc = (None, 0)
+            if residual is not None and residual.requires_grad:
+                rg, racc = residual.grad_sink()
+            call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
+                                  _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
+                                  _p(rg), rg.stride(2) if rg is not None else 0, racc, st)
+            # ---- weight gradient
+            wd = capi.WgradDesc()
+            wd.N, wd.H, wd.W, wd.OH, wd.OW = N, H, W, OH, OW
+            wd.Cin_p, wd.ld_x, wd.Cout_p, wd.ld_dy = x.Cp, x.ld, Cout_p, Cout_p
+            wd.KH, wd.KW, wd.stride, wd.pad_h, wd.pad_w, wd.dil_h, wd.dil_w = KH, KW, sh, ph, pw, dh, dw
+            tco = call.pn2_wgrad_tile_co(Cout_p)
+            wd.Rp, wd.Kp = rup(Cout_p, tco), pd.Kp
+            tiles = (wd.Rp // tco) * (pd.Kp // 128)
+            steps = (M + 31) // 32
+            nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (1024 + tiles - 1) // tiles, 512))
+            slab = self.fbuf(nsplit, wd.Rp, wd.Kp)
+            capi.WORK.update(flops=flops, tag="")
+            call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
+            gwt, gwa = self.pgrads.sink(w)
+            rd = self._pack_desc(w, x_map, o_map, False)
+            rd.Rp = wd.Rp
+            call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, st)
+            # ---- data gradient
+            if x.requires_grad:
+                wt, ptd = self.pack(w, x_map, o_map, True)
+                gx, gxa = x.grad_sink()
+                dd = capi.ConvDesc()
+                dd.N, dd.H, dd.W, dd.OH, dd.OW = N, OH, OW, H, W
+                dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Cout_p, Cout_p, x.Cp, gx.stride(2)
+                dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = KH, KW, sh, ph, pw, dh, dw
+                dd.transposed, dd.Kp, dd.flags = 1, ptd.Kp, (capi.CONV_ACCUM if gxa else 0)
+                capi.WORK.update(flops=flops, tag=":dgrad")
+                call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
+
+        self.record(bwd)
+        return out
+
+    # ------------------------------------------------------------------ pooling
+    def maxpool3x3s2(self, x):
+        N, H, W = x.N, x.H, x.W
+        OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = Act(self, self.empty(N, OH, OW, x.Cp), x.C, x.gw, x.gwp, x.dt)
+        idx = torch.empty((N, OH, OW, x.Cp), dtype=torch.uint8, device=self.dev)
+        call.pn2_maxpool3x3s2_fwd(x.dt, x.ptr, x.ld, y.ptr, y.ld, _p(idx), N, H, W, x.Cp, OH, OW, _stream())
+
+        def bwd():
+            if not x.requires_grad:
+                return
+            gx, acc = x.grad_sink()
+            assert not acc
+            call.pn2_maxpool3x3s2_bwd(x.dt, _p(y.grad_buf()), y.grad_buf().stride(2), _p(idx), _p(gx), gx.stride(2), N, H, W, x.Cp, OH, OW, _stream())
+        self.record(bwd)
+        return y
+
+    def avgpool(self, x, k, stride, pad, ceil_mode=False, count_include_pad=True, out=None):
+        N, H, W = x.N, x.H, x.W
+
+        def osz(i):
+            o = (i + 2 * pad - k + (stride - 1 if ceil_mode else 0)) // stride + 1
+            if ceil_mode and (o - 1) * stride >= i + pad:
+                o -= 1
+            return o
+        OH, OW = osz(H), osz(W)
+        y = out if out is not None else Act(self, self.empty(N, OH, OW, x.Cp), x.C, x.gw, x.gwp, x.dt)
+        assert (y.H, y.W, y.Cp) == (OH, OW, x.Cp)
+        inc = 1 if count_include_pad else 0
+        call.pn2_avgpool_fwd(x.dt, x.ptr, x.ld, y.ptr, y.ld, N, H, W, x.Cp, OH, OW, k, stride, pad, inc, _stream())
+
+        def bwd():
+            if not x.requires_grad:
+                return
+            gy = y.grad_buf()
+            gx, acc = x.grad_sink()
+            call.pn2_avgpool_bwd(x.dt, _p(gy), gy.stride(2), _p(gx), gx.stride(2), N, H, W, x.Cp, OH, OW, k, stride, pad, inc, acc, _stream())
+        self.record(bwd)
+        return y
+
+    # ------------------------------------------------------------------ bilinear
+    def bilinear(self, x, scale=None, align_corners=False, out=None):
+        """F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=...) — the given scale is used
+        for the source-index map when align_corners is False (PyTorch default recompute_scale_factor=None)."""
+        N, H, W = x.N, x.H, x.W
+        OH, OW = int(math.floor(H * scale)), int(math.floor(W * scale))
+        if align_corners:
+            rh = (H - 1) / (OH - 1) if OH > 1 else 0.0
+            rw = (W - 1) / (OW - 1) if OW > 1 else 0.0
+        else:
+            rh = rw = 1.0 / scale
+        return self._resize(x, OH, OW, align_corners, rh, rw, out)
+
+    def resize_to(self, x, OH, OW, align_corners=False):
+        """F.interpolate(x, size=(OH,OW), mode='bilinear')"""
+        if align_corners:
+            rh = (x.H - 1) / (OH - 1) if OH > 1 else 0.0
+            rw = (x.W - 1) / (OW - 1) if OW > 1 else 0.0
+        else:
+            rh, rw = x.H / OH, x.W / OW
+        return self._resize(x, OH, OW, align_corners, rh, rw, None)
+
+    def _resize(self, x, OH, OW, ac, rh, rw, out):
+        N, H, W = x.N, x.H, x.W
+        y = out if out is not None else Act(self, self.empty(N, OH, OW, x.Cp, x.dt), x.C, x.gw, x.gwp, x.dt)
+        ac = 1 if ac else 0
+        call.pn2_bilinear_fwd(x.dt, x.ptr, x.ld, y.ptr, y.ld, N, H, W, x.Cp, OH, OW, ac, rh, rw, _stream())
+
+        def bwd():
+            if not x.requires_grad:
+                return
+            gy = y.grad_buf()
+            gx, acc = x.grad_sink()
+            st = _stream()
+            if OH >= 4 * H and OW >= 4 * W:
+                # separable adjoint: reduce along x first, then along y (keeps per-thread loops short)
+                tmp = self.empty(N, OH, W, x.Cp, x.dt)
+                call.pn2_bilinear_bwd(x.dt, _p(gy), gy.stride(2), _p(tmp), x.Cp, N, OH, W, x.Cp, OH, OW, ac, 1.0, rw, 0, st)
+                call.pn2_bilinear_bwd(x.dt, _p(tmp), x.Cp, _p(gx), gx.stride(2), N, H, W, x.Cp, OH, W, ac, rh, 1.0, acc, st)
+            else:
+                call.pn2_bilinear_bwd(x.dt, _p(gy), gy.stride(2), _p(gx), gx.stride(2), N, H, W, x.Cp, OH, OW, ac, rh, rw, acc, st)
+        self.record(bwd)
+        return y
+
+    # ------------------------------------------------------------------ element-wise
+    def binary(self, op, a, b, out=None):
+        """op 0: a+b ; op 1: a*b (same geometry).  Gradients flow to both operands."""
+        assert (a.N, a.H, a.W, a.Cp) == (b.N, b.H, b.W, b.Cp) and a.dt == b.dt
+        y = out if out is not None else Act(self, self.empty(a.N, a.H, a.W, a.Cp, a.dt), a.C, a.gw, a.gwp, a.dt)
+        call.pn2_binary(a.dt, op, a.ptr, a.ld, b.ptr, b.ld, y.ptr, y.ld, a.M, a.Cp, 0, _stream())
+
+        def bwd():
+            gy = y.grad_buf()
+            st = _stream()
+            for u, v in ((a, b), (b, a)):
+                if not u.requires_grad:
+                    continue
+                gu, acc = u.grad_sink()
+                if op == 0:
+                    call.pn2_copy(a.dt, _p(gy), gy.stride(2), a.dt, _p(gu), gu.stride(2), a.M, a.Cp, acc, st)
+                else:
+                    call.pn2_binary(a.dt, 1, _p(gy), gy.stride(2), v.ptr, v.ld, _p(gu), gu.stride(2), a.M, a.Cp, acc, st)
+        self.record(bwd)
+        return y
+
+    def add(self, a, b, out=None):
+        return self.binary(0, a, b, out)
+
+    def mul(self, a, b, out=None):
+        return self.binary(1, a, b, out)
+
+    def copy_into(self, src, dst):
+        call.pn2_copy(src.dt, src.ptr, src.ld, dst.dt, dst.ptr, dst.ld, src.M, src.Cp, 0, _stream())
+
+        def bwd():
+            if not src.requires_grad:
+                return
+            gd = dst.grad_buf()
+            gs, acc = src.grad_sink()
+            call.pn2_copy(dst.dt, _p(gd), gd.stride(2), src.dt, _p(gs), gs.stride(2), src.M, src.Cp, acc, _stream())
+        self.record(bwd)
+        return dst
+
+    # ------------------------------------------------------------------ DSRA / RA
+    def dsra_fuse(self, fg, crop_fg, crop_bg, use_softmax=True):
+        """fg + fg * softmax(crop_fg - crop_bg, dim=C)   (fp32 K-channel maps)"""
+        for a in (fg, crop_fg, crop_bg):
+            assert a.dt == F32 and a.ld == a.C
+        K, M = fg.C, fg.M
+        y = Act(self, self.empty(fg.N, fg.H, fg.W, K, F32), K, K, K, F32)
+        sm = 1 if use_softmax else 0
+        call.pn2_dsra_fuse_fwd(fg.ptr, crop_fg.ptr, crop_bg.ptr, y.ptr, M, K, sm, _stream())
+
+        def bwd():
+            gy = y.grad_buf()
+            gs = [a.grad_sink() for a in (fg, crop_fg, crop_bg)]
+            tmp = [self.fbuf(M, K) if acc else None for (_, acc) in gs]
+            dst = [t if t is not None else g for t, (g, _) in zip(tmp, gs)]
+            call.pn2_dsra_fuse_bwd(fg.ptr, crop_fg.ptr, crop_bg.ptr, _p(gy), _p(dst[0]), _p(dst[1]), _p(dst[2]), M, K, sm, _stream())
+            for t, (g, acc) in zip(tmp, gs):
+                if t is not None:
+                    call.pn2_copy(F32, _p(t), K, F32, _p(g), g.stride(2), M, K, 1, _stream())
+        self.record(bwd)
+        return y
+
+    def ra_gate(self, x, crop):
+        """(1 - sigmoid(crop)).expand(C) * x      (PraNet V1 reverse attention)"""
+        assert crop.dt == F32 and crop.C == 1
+        y = Act(self, self.empty(x.N, x.H, x.W, x.Cp, x.dt), x.C, x.gw, x.gwp, x.dt)
+        call.pn2_ra_gate_fwd(x.dt, x.ptr, x.ld, crop.ptr, y.ptr, y.ld, x.M, x.Cp, _stream())
+
+        def bwd():
+            gy = y.grad_buf()
+            gx, acc = x.grad_sink()
+            gc, cacc = crop.grad_sink()
+            dc = self.fbuf(x.M) if cacc else gc
+            call.pn2_ra_gate_bwd(x.dt, x.ptr, x.ld, crop.ptr, _p(gy), gy.stride(2), _p(gx), gx.stride(2), acc, _p(dc), x.M, x.Cp, _stream())
+            if cacc:
+                call.pn2_copy(F32, _p(dc), 1, F32, _p(gc), 1, x.M, 1, 1, _stream())
+        self.record(bwd)
+        return y
+
+    # ------------------------------------------------------------------ bookkeeping
+    def finish_forward(self):
+        """BatchNorm's num_batches_tracked += 1 (nn.BatchNorm2d train-mode side effect)."""
+        seen = set()
+        for bn in self.bn_modules:
+            if id(bn) not in seen and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+                seen.add(id(bn))
+        self.bn_modules = []

@@ -1,0 +1,73 @@
+"""Dual structure loss of the reference (MyTrain_med.py:19-38) as fused gfx950 kernels.
+
+`structure_loss(pred, pred_bg, mask_fg, mask_bg)` has the reference's signature; `structure_loss_multi` evaluates
+all supervision pairs of MyTrain_med.py:78-82 in one pass (the 31x31 boundary weights are computed once instead
+of four times).  The background target is 1 - mask_fg, as at every call site of the reference (:74).
+"""
+import ctypes as C
+
+import torch
+
+from .capi import call
+from .engine import _p, _stream
+
+
+def loss_forward(buf, P, mask, N, HW, H, W):
+    """buf: [2P][N][HW] fp32 contiguous logits.  Returns (loss[P+1], saved) — raw kernel driver, no autograd."""
+    dev = buf.device
+    weit = torch.empty((N, HW), dtype=torch.float32, device=dev)
+    call.pn2_loss_weights(_p(mask), _p(weit), N, H, W, 31, _stream())
+    nb = call.pn2_loss_blocks(HW)
+    partial = torch.empty((P, N, nb, 5), dtype=torch.float32, device=dev)
+    sums = torch.empty((P, N, 4), dtype=torch.float32, device=dev)
+    wsum = torch.empty((N,), dtype=torch.float32, device=dev)
+    loss = torch.empty((P + 1,), dtype=torch.float32, device=dev)
+    call.pn2_structure_loss_fwd(_p(buf), N * HW, P, _p(mask), _p(weit), _p(partial), _p(sums), _p(wsum), _p(loss), N, HW, _stream())
+    return loss, (weit, sums, wsum)
+
+
+def loss_backward(buf, dbuf, P, mask, saved, N, HW, gscale=1.0):
+    weit, sums, wsum = saved
+    call.pn2_structure_loss_bwd(_p(buf), _p(dbuf), N * HW, P, _p(mask), _p(weit), _p(wsum), _p(sums), float(gscale), N, HW, _stream())
+
+
+class _StructureLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mask, P, *preds):
+        if not mask.is_cuda:
+            raise RuntimeError("pn2.structure_loss needs GPU tensors (no CPU fallback)")
+        N, _, H, W = mask.shape
+        HW = H * W
+        buf = torch.stack([p.reshape(N, HW) for p in preds]).float().contiguous()
+        m = mask.reshape(N, HW).float().contiguous()
+        loss, saved = loss_forward(buf, P, m, N, HW, H, W)
+        ctx.save_for_backward(buf, m, *saved)
+        ctx.dims = (P, N, HW, preds[0].shape)
+        return loss[P], loss[:P]
+
+    @staticmethod
+    def backward(ctx, gtotal, gpairs):
+        buf, m, weit, sums, wsum = ctx.saved_tensors
+        P, N, HW, shape = ctx.dims
+        dbuf = torch.empty_like(buf)
+        loss_backward(buf, dbuf, P, m, (weit, sums, wsum), N, HW, 1.0)
+        g = dbuf.view(2, P, N, HW)
+        scale = torch.zeros(P, device=buf.device)
+        if gtotal is not None:
+            scale = scale + gtotal
+        if gpairs is not None:
+            scale = scale + gpairs
+        g = g * scale.view(1, P, 1, 1)
+        return (None, None, *[g[j // P, j % P].reshape(shape) for j in range(2 * P)])
+
+
+def structure_loss_multi(preds_fg, preds_bg, mask, return_pairs=False):
+    """sum_j structure_loss(preds_fg[j], preds_bg[j], mask, 1 - mask)  (MyTrain_med.py:78-82)."""
+    P = len(preds_fg)
+    total, pairs = _StructureLoss.apply(mask, P, *preds_fg, *preds_bg)
+    return (total, pairs) if return_pairs else total
+
+
+def structure_loss(pred, pred_bg, mask_fg, mask_bg=None):
+    """Reference signature (MyTrain_med.py:19).  mask_bg is taken to be 1 - mask_fg, as at its call sites."""
+    return structure_loss_multi([pred], [pred_bg], mask_fg)

@@ -1,0 +1,121 @@
+"""Live per-kernel timing for bench.py: one instrumented eager step with HIP events around every C-ABI launch.
+
+The kernels are launched on torch's current stream, so torch.cuda.Event (a hipEvent recorded on that stream) brackets
+exactly the launch it surrounds.  Work is *algorithmic*: logical conv FLOPs (2*M*Cout*Cin*KH*KW for forward, dgrad and
+wgrad alike) and minimum tensor bytes for the streaming kernels — not padded/physical counts.
+"""
+import torch
+
+from . import capi
+from .capi import F32
+
+_EL = {0: 4, 1: 2}
+
+
+def _bytes(name, a):
+    """minimum HBM bytes of one launch from its C arguments (streaming kernels only)"""
+    try:
+        if name == "pn2_affine_act":
+            dt_in, _, _, dt_out, _, _, M, C, _, _, res = a[:11]
+            return M * C * (_EL[dt_in] * (2 if res.value else 1) + _EL[dt_out])
+        if name == "pn2_bn_bwd_reduce":
+            dt, dt_dy, _, _, Cdy, y = a[0], a[1], a[2], a[3], a[4], a[5]
+            M, Cp = a[10], a[11]
+            return M * (Cdy * _EL[dt_dy] + Cp * _EL[dt] * (2 if y.value else 1))
+        if name == "pn2_bn_bwd_apply":
+            dt, dt_dy, Cdy, y, M, Cp, dres = a[0], a[1], a[4], a[5], a[10], a[11], a[17]
+            return M * (Cdy * _EL[dt_dy] + Cp * _EL[dt] * (2 + (1 if y.value else 0) + (1 if dres.value else 0)))
+        if name in ("pn2_bilinear_fwd", "pn2_bilinear_bwd", "pn2_avgpool_fwd", "pn2_avgpool_bwd"):
+            dt, N, H, W, C, OH, OW = a[0], a[5], a[6], a[7], a[8], a[9], a[10]
+            return N * C * _EL[dt] * (H * W + OH * OW)
+        if name in ("pn2_maxpool3x3s2_fwd", "pn2_maxpool3x3s2_bwd"):
+            dt, N, H, W, C, OH, OW = a[0], a[6], a[7], a[8], a[9], a[10], a[11]
+            return N * C * (_EL[dt] * (H * W + OH * OW) + OH * OW)
+        if name == "pn2_structure_loss_fwd":
+            P, N, HW = a[2], a[9], a[10]
+            return N * HW * 4 * (2 * P + 2)
+        if name == "pn2_structure_loss_bwd":
+            P, N, HW = a[3], a[9], a[10]
+            return N * HW * 4 * (4 * P + 2)
+        if name == "pn2_clamp_adam":
+            return int(a[4]) * 4 * 7
+        if name == "pn2_binary":
+            dt, M, C = a[0], a[8], a[9]
+            return M * C * _EL[dt] * 3
+        if name == "pn2_copy":
+            return a[6] * a[7] * (_EL[a[0]] + _EL[a[3]])
+        if name == "pn2_nchw_to_nhwc":
+            return a[4] * a[6] * (a[5] * 4 + a[7] * _EL[a[0]])
+    except Exception:
+        return 0
+    return 0
+
+
+class Recorder:
+    def __init__(self):
+        self.rows = []          # (name, flops, bytes, e0, e1)
+        self.saved = {}
+
+    def __enter__(self):
+        lib = capi.load()
+        for name in capi.SIGNATURES:
+            if name in capi._VALUE_FUNCS:
+                continue
+            fn = getattr(lib, name)
+
+            def wrapped(*a, _fn=fn, _name=name):
+                fl = capi.WORK.pop("flops", 0)
+                tag = capi.WORK.pop("tag", "")
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _fn(*a)
+                e1.record()
+                if rc != 0:
+                    raise RuntimeError(f"{_name} failed with status {rc}")
+                self.rows.append((_name + tag, fl, _bytes(_name, a) if not fl else 0, e0, e1))
+            self.saved[name] = capi.call.__dict__.get(name)
+            setattr(capi.call, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, old in self.saved.items():
+            if old is None:
+                capi.call.__dict__.pop(name, None)
+            else:
+                setattr(capi.call, name, old)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, by, e0, e1 in self.rows:
+            d = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0, "bytes": 0})
+            d["ms"] += e0.elapsed_time(e1); d["launches"] += 1; d["flops"] += fl; d["bytes"] += by
+        return agg
+
+
+def measure_step(trainer, x, m, dtype):
+    peak_tf = 2500.0 if dtype == "bf16" else 157.3
+    trainer.step(x, m)                       # eager warm-up (allocator, caches)
+    with Recorder() as rec:
+        trainer.step(x, m)
+    agg = rec.summary()
+    kernels = {}
+    for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        e = {"ms": round(d["ms"], 3), "launches": d["launches"]}
+        if d["flops"]:
+            e["TFLOPs"] = round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)
+        elif d["bytes"]:
+            e["GBps"] = round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)
+        kernels[name] = e
+    mf = [(n, d) for n, d in agg.items() if d["flops"]]
+    name, d = max(mf, key=lambda kv: kv[1]["ms"])
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4),
+                "traffic": None, "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
+    tail = [agg[k] for k in ("pn2_structure_loss_fwd", "pn2_structure_loss_bwd") if k in agg]
+    if tail:
+        by = sum(t["bytes"] for t in tail); ms = sum(t["ms"] for t in tail)
+        roofline["hbm_loss_tail"] = {"bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                     "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4)}
+    return {"roofline": roofline, "kernels": kernels}

@@ -1,0 +1,169 @@
+"""Training-step driver: what the reference runs between optimizer.zero_grad() and optimizer.step()
+(MyTrain_med.py:59-86) as one engine pass — forward, the 4-pair structure loss, backward, element-wise
+gradient clamp and Adam — over flat parameter / gradient / moment arenas.
+
+Data parallelism (one process per GPU): gradients are summed with RCCL all-reduce (torch.distributed backend
+"nccl") in buckets that are launched as soon as backward has produced every gradient they contain, so the
+collective overlaps the remaining backward kernels; the 1/world scaling is folded into the clamp+Adam kernel.
+BatchNorm statistics stay per replica, exactly as nn.DataParallel + nn.BatchNorm2d would do in the reference.
+"""
+import ctypes as C
+
+import torch
+
+from .capi import call, F32
+from .engine import Engine, Act, _p, _stream
+from .graph import get_compute_dtype
+from . import loss as L
+
+
+def _r4(n):
+    return (n + 3) // 4 * 4
+
+
+class Trainer:
+    def __init__(self, model, lr=1e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8, dtype=None, process_group=None, bucket_bytes=32 << 20):
+        self.model = model
+        self.lr, self.clip, self.betas, self.eps = lr, clip, betas, eps
+        self.dtype = get_compute_dtype() if dtype is None else dtype
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        hot = list(model.hot_parameters())
+        hot_ids = {id(p) for p in hot}
+        cold = [p for p in model.parameters() if id(p) not in hot_ids]
+        dev = hot[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("Trainer needs the model on the GPU (no CPU path)")
+        self.n_hot = sum(_r4(p.numel()) for p in hot)
+        n_all = self.n_hot + sum(_r4(p.numel()) for p in cold)
+        self.flat = torch.zeros(n_all, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(self.n_hot, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(self.n_hot, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.n_hot, dtype=torch.float32, device=dev)
+        self.bias_corr = torch.tensor([0.0, 0.0, 1.0, 1.0], dtype=torch.float32, device=dev)
+        self.off = {}
+        o = 0
+        for p in hot + cold:
+            n = p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
+            self.off[id(p)] = (o, n)
+            o += _r4(n)
+        self.hot = hot
+        # gradient buckets in arena order (backward completes them from the tail)
+        self.buckets = []
+        cur, start, nbytes = [], 0, 0
+        for p in hot:
+            off, n = self.off[id(p)]
+            cur.append(id(p)); nbytes += 4 * _r4(n)
+            if nbytes >= bucket_bytes:
+                self.buckets.append((start, off + _r4(n), set(cur)))
+                cur, start, nbytes = [], off + _r4(n), 0
+        if cur:
+            self.buckets.append((start, self.n_hot, set(cur)))
+        self.graph = None
+        self.last_outs = None
+
+    # ------------------------------------------------------------------ pieces
+    def _grad_view(self, p):
+        off, n = self.off[id(p)]
+        return self.gflat[off:off + n].view(p.shape)
+
+    def forward_backward(self, images, gts, reduce_hook=True):
+        """forward + loss + backward; returns loss[5] = (l2, l3, l4, l5 pair losses, total) on device."""
+        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True)
+        x = eng.from_nchw(images)
+        outs = self.model._build(eng, x)
+        eng.finish_forward()
+        N, H, W = outs[0].N, outs[0].H, outs[0].W
+        P = len(outs) // 2
+        lat = eng.lateral_block()
+        if lat is None or any(o.t.data_ptr() != lat[j].data_ptr() for j, o in enumerate(outs)):
+            lat = torch.stack([o.t for o in outs])
+        HW = H * W
+        mask = gts.reshape(N, HW).float().contiguous()
+        loss, saved = L.loss_forward(lat, P, mask, N, HW, H, W)
+        dlat = torch.empty_like(lat)
+        L.loss_backward(lat, dlat, P, mask, saved, N, HW, 1.0)
+        for j, o in enumerate(outs):
+            o.grad = dlat[j]
+            o.grad_written = True
+        works = []
+        pending = list(range(len(self.buckets)))
+        for fn in reversed(eng.tape):
+            fn()
+            if self.world > 1 and reduce_hook:
+                done = [b for b in pending if self.buckets[b][2] <= eng.pgrads.written]
+                for b in done:
+                    a, e, _ = self.buckets[b]
+                    works.append(torch.distributed.all_reduce(self.gflat[a:e], group=self.pg, async_op=True))
+                    pending.remove(b)
+        eng.tape = []
+        if self.world > 1:
+            if not reduce_hook:
+                works = [torch.distributed.all_reduce(self.gflat[a:e], group=self.pg, async_op=True) for a, e, _ in self.buckets]
+            else:
+                for b in pending:     # parameters that received no gradient this step
+                    a, e, _ = self.buckets[b]
+                    works.append(torch.distributed.all_reduce(self.gflat[a:e], group=self.pg, async_op=True))
+            for w in works:
+                w.wait()
+        self.last_outs = lat
+        return loss
+
+    def optimizer_step(self):
+        st = _stream()
+        call.pn2_adam_tick(_p(self.bias_corr), self.betas[0], self.betas[1], st)
+        call.pn2_clamp_adam(_p(self.flat), _p(self.gflat), _p(self.exp_avg), _p(self.exp_avg_sq), self.n_hot, self.lr, self.betas[0], self.betas[1],
+                            self.eps, self.clip, 1.0 / self.world, _p(self.bias_corr), st)
+
+    def step(self, images, gts):
+        """One MyTrain_med.py:59-86 iteration.  Returns the device tensor [loss5, loss4, loss3, loss2, total]."""
+        loss = self.forward_backward(images, gts)
+        self.optimizer_step()
+        return loss
+
+    # ------------------------------------------------------------------ hipGraph replay of the whole step
+    def capture(self, images, gts, warmup=3):
+        """Capture forward+loss+backward(+Adam) into hipGraphs and replay them with `replay(images, gts)`.
+        With data parallelism the gradient all-reduce stays outside the graphs (between backward and Adam)."""
+        self.s_images = images.clone()
+        self.s_gts = gts.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(self.s_images, self.s_gts)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        if self.world == 1:
+            with torch.cuda.graph(self.graph):
+                self.s_loss = self.step(self.s_images, self.s_gts)
+            self.graph_opt = None
+        else:
+            with torch.cuda.graph(self.graph):
+                self.s_loss = self.forward_backward_local(self.s_images, self.s_gts)
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt):
+                self.optimizer_step()
+        return self
+
+    def forward_backward_local(self, images, gts):
+        w, self.world = self.world, 1
+        try:
+            return self.forward_backward(images, gts)
+        finally:
+            self.world = w
+
+    def replay(self, images=None, gts=None):
+        if images is not None:
+            self.s_images.copy_(images, non_blocking=True)
+            self.s_gts.copy_(gts, non_blocking=True)
+        self.graph.replay()
+        if self.graph_opt is not None:
+            works = [torch.distributed.all_reduce(self.gflat[a:e], group=self.pg, async_op=True) for a, e, _ in self.buckets]
+            for w in works:
+                w.wait()
+            self.graph_opt.replay()
+        return self.s_loss

@@ -1,0 +1,43 @@
+"""Training helpers with the reference's names and behaviour (/root/reference/binary_seg/utils/utils.py)."""
+import numpy as np
+import torch
+
+
+def clip_gradient(optimizer, grad_clip):
+    """Per-element clamp of every gradient to [-grad_clip, grad_clip] (reference utils/utils.py:7-17)."""
+    for group in optimizer.param_groups:
+        for param in group['params']:
+            if param.grad is not None:
+                param.grad.data.clamp_(-grad_clip, grad_clip)
+
+
+def adjust_lr(optimizer, init_lr, epoch, decay_rate=0.1, decay_epoch=30):
+    """Multiplies the CURRENT lr (so decay compounds), exactly as reference utils/utils.py:20-23."""
+    decay = decay_rate ** (epoch // decay_epoch)
+    for param_group in optimizer.param_groups:
+        param_group['lr'] *= decay
+
+
+class AvgMeter(object):
+    """reference utils/utils.py:26-46: show() = mean of the last `num` recorded values."""
+
+    def __init__(self, num=40):
+        self.num = num
+        self.reset()
+
+    def reset(self):
+        self.val = 0
+        self.avg = 0
+        self.sum = 0
+        self.count = 0
+        self.losses = []
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+        self.losses.append(val)
+
+    def show(self):
+        return torch.mean(torch.stack(self.losses[np.maximum(len(self.losses) - self.num, 0):]))

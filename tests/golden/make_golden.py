@@ -194,6 +194,24 @@ def gen_model(size, n, tag, full_maps):
             out[s + "param." + k] = head(names[k])
         for k in PROBE_BUFFERS:
             out[s + "buf." + k] = head(bufs[k])
+    # The same reference classes run in float64: the well-conditioned "truth" of step 1.  Train-mode BN over small
+    # batches makes this network ill-conditioned in fp32 (the reference's own fp32 result differs from its fp64 result
+    # by ~1e-3 on the logits), so parity tests bound |ours - ref64| by a multiple of |ref32 - ref64| measured here.
+    m64 = R.pranet.PraNet_V2(num_class=1)
+    m64.load_state_dict(sd0, strict=True)
+    m64 = m64.double().train()
+    o64 = m64(x.double())
+    l64 = [R.train.structure_loss(o64[i], o64[i + 4], mask.double(), 1 - mask.double()) for i in range(4)]
+    (l64[3] + l64[2] + l64[1] + l64[0]).backward()
+    out["f64.losses"] = np.array([float(l) for l in l64])
+    n64 = dict(m64.named_parameters())
+    for i, o in enumerate(o64):
+        o = o.detach()
+        out[f"f64.out{i}"] = npy(o if full_maps else o[:, :, ::4, ::4]).astype(np.float64)
+    for k in PROBE_PARAMS:
+        out["f64.graw." + k] = head(n64[k].grad)
+        out["f64.grawnorm." + k] = npy(n64[k].grad.norm())
+    del m64, o64
     # eval-mode forward with the populated running stats + MyTest_med.py:104-111 tail
     model.eval()
     with torch.no_grad():
