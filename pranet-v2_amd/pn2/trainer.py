@@ -14,6 +14,7 @@ import torch
 from .capi import call, F32
 from .engine import Engine, Act, _p, _stream
 from .graph import get_compute_dtype
+from .dp import GradBuckets
 from . import loss as L
 
 
@@ -51,16 +52,7 @@ class Trainer:
             o += _r4(n)
         self.hot = hot
         # gradient buckets in arena order (backward completes them from the tail)
-        self.buckets = []
-        cur, start, nbytes = [], 0, 0
-        for p in hot:
-            off, n = self.off[id(p)]
-            cur.append(id(p)); nbytes += 4 * _r4(n)
-            if nbytes >= bucket_bytes:
-                self.buckets.append((start, off + _r4(n), set(cur)))
-                cur, start, nbytes = [], off + _r4(n), 0
-        if cur:
-            self.buckets.append((start, self.n_hot, set(cur)))
+        self.buckets = GradBuckets(self.gflat, [(id(p), self.off[id(p)][0], _r4(self.off[id(p)][1])) for p in hot], bucket_bytes, process_group)
         self.graph = None
         self.last_outs = None
 
@@ -88,26 +80,15 @@ class Trainer:
         for j, o in enumerate(outs):
             o.grad = dlat[j]
             o.grad_written = True
-        works = []
-        pending = list(range(len(self.buckets)))
+        if self.world > 1:
+            self.buckets.reset()
         for fn in reversed(eng.tape):
             fn()
             if self.world > 1 and reduce_hook:
-                done = [b for b in pending if self.buckets[b][2] <= eng.pgrads.written]
-                for b in done:
-                    a, e, _ = self.buckets[b]
-                    works.append(torch.distributed.all_reduce(self.gflat[a:e], group=self.pg, async_op=True))
-                    pending.remove(b)
+                self.buckets.launch_ready(eng.pgrads.written)
         eng.tape = []
         if self.world > 1:
-            if not reduce_hook:
-                works = [torch.distributed.all_reduce(self.gflat[a:e], group=self.pg, async_op=True) for a, e, _ in self.buckets]
-            else:
-                for b in pending:     # parameters that received no gradient this step
-                    a, e, _ = self.buckets[b]
-                    works.append(torch.distributed.all_reduce(self.gflat[a:e], group=self.pg, async_op=True))
-            for w in works:
-                w.wait()
+            self.buckets.finish()
         self.last_outs = lat
         return loss
 
@@ -162,8 +143,6 @@ class Trainer:
             self.s_gts.copy_(gts, non_blocking=True)
         self.graph.replay()
         if self.graph_opt is not None:
-            works = [torch.distributed.all_reduce(self.gflat[a:e], group=self.pg, async_op=True) for a, e, _ in self.buckets]
-            for w in works:
-                w.wait()
+            self.buckets.reduce_all()
             self.graph_opt.replay()
         return self.s_loss
