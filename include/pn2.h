@@ -57,11 +57,15 @@ typedef struct pn2_pack_desc {
 
 int pn2_conv_tile_n(int cout);          /* N tile the forward/dgrad kernel will pick for `cout` */
 int pn2_wgrad_tile_co(int cout_p);      /* co tile of the wgrad kernel */
-int pn2_conv_stat_blocks(int m);        /* rows of the psum/psq partial buffers for m output pixels */
+int pn2_conv_tile_m(int m, int cout, int dtype);        /* M tile (128 or 64) chosen for m output pixels x cout channels */
+int pn2_conv_stat_blocks(int m, int cout, int dtype);   /* rows of the psum/psq partial buffers = ceil(m / tile_m) */
 int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, void* stream);
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream);
 int pn2_pack_weight(int dtype, const float* w_oihw, void* wp, const pn2_pack_desc* p, void* stream);
 int pn2_wgrad_reduce(const float* slab, float* gw_oihw, const pn2_pack_desc* p, int nsplit, int accumulate, void* stream);
+/* one launch that repacks many weights (all convs of a model, forward and dgrad panels) from a DEVICE job table */
+typedef struct pn2_pack_job { const float* w; void* wp; pn2_pack_desc d; } pn2_pack_job;
+int pn2_pack_weights_multi(int dtype, const pn2_pack_job* jobs_dev, int njobs, int blocks_per_job, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- batch norm
  * nn.BatchNorm2d train/eval forward + backward (lib/pranet.py:37,41-42 ; lib/Res2Net_v1b.py:33,45,50,103,106,110,135),

@@ -28,8 +28,16 @@ template <typename T, int W> struct VL {   // W == VEC: 16-byte vector ; W == 1:
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void reduce_partials(const float* p1, const float* p2, int nblk, int Cp, int c, int rl, double& s1, double& s2) {
     s1 = 0.0; s2 = 0.0;
-    if (c < Cp)
-        for (int r = rl; r < nblk; r += 32) { s1 += (double)p1[(size_t)r * Cp + c]; s2 += (double)p2[(size_t)r * Cp + c]; }
+    if (c < Cp) {
+        int r = rl;
+        for (; r + 96 < nblk; r += 128) {        // 4 independent row loads in flight per thread
+            const float a0 = p1[(size_t)r * Cp + c], a1 = p1[(size_t)(r + 32) * Cp + c], a2 = p1[(size_t)(r + 64) * Cp + c], a3 = p1[(size_t)(r + 96) * Cp + c];
+            const float b0 = p2[(size_t)r * Cp + c], b1 = p2[(size_t)(r + 32) * Cp + c], b2 = p2[(size_t)(r + 64) * Cp + c], b3 = p2[(size_t)(r + 96) * Cp + c];
+            s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; r < nblk; r += 32) { s1 += (double)p1[(size_t)r * Cp + c]; s2 += (double)p2[(size_t)r * Cp + c]; }
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ psum, const float* __restrict__ psq, int nblk, pn2_bn_desc d,
@@ -121,15 +129,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ d
         if (cv < CV) {
 #pragma unroll
             for (int e = 0; e < W; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
-            for (int m = r0 + rl; m < r1; m += R) {
-                float g[W], xv[W], yv[W];
-                if (W > 1 || c < Cdy) VL<Tdy, W>::load(dy + (size_t)m * ld_dy + c, g); else g[0] = 0.f;
-                VL<T, W>::load(x + (size_t)m * ld_x + c, xv);
-                if (y) VL<T, W>::load(y + (size_t)m * ld_y + c, yv);
+            for (int m = r0 + rl; m < r1; m += R * 4) {
+                float g[4][W], xv[4][W], yv[4][W];
 #pragma unroll
-                for (int e = 0; e < W; ++e) {
-                    const float dz = (y && !(yv[e] > 0.f)) ? 0.f : g[e];
-                    a1[e] += dz; a2[e] += dz * (xv[e] - mu[e]) * is[e];
+                for (int u = 0; u < 4; ++u) {          // issue all loads of 4 rows before using any
+                    const int mm = m + u * R;
+                    if (mm < r1) {
+                        if (W > 1 || c < Cdy) VL<Tdy, W>::load(dy + (size_t)mm * ld_dy + c, g[u]); else g[u][0] = 0.f;
+                        VL<T, W>::load(x + (size_t)mm * ld_x + c, xv[u]);
+                        if (y) VL<T, W>::load(y + (size_t)mm * ld_y + c, yv[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (m + u * R < r1) {
+#pragma unroll
+                        for (int e = 0; e < W; ++e) {
+                            const float dz = (y && !(yv[u][e] > 0.f)) ? 0.f : g[u][e];
+                            a1[e] += dz; a2[e] += dz * (xv[u][e] - mu[e]) * is[e];
+                        }
+                    }
                 }
             }
         }
@@ -197,6 +216,120 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const Tdy* __restrict__ dy
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// row-streaming variants (16-byte vectors): a thread owns ONE channel vector and walks down the rows,
+// so the per-channel parameters live in registers instead of being re-fetched for every element, and
+// U independent row loads are in flight per thread.  256 threads = CVP channel-vectors x R row lanes.
+// ---------------------------------------------------------------------------------------------
+constexpr int RU = 4;   // rows in flight per thread
+
+template <typename T>
+__global__ __launch_bounds__(256) void affine_rows_k(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int M, int C,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const T* __restrict__ res, int ld_res, int relu, int rows_per_blk, int CVP) {
+    constexpr int V = TT<T>::VEC;
+    const int CV = C / V, R = 256 / CVP;
+    const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int r0 = blockIdx.x * rows_per_blk;
+    int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
+    for (int cv = cvl; cv < CV; cv += CVP) {
+        const int c = cv * V;
+        float sc[V], sh[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = shift ? shift[c + e] : 0.f; }
+        for (int m = r0 + rl; m < r1; m += R * RU) {
+            uint4 vx[RU], vr[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int mm = m + u * R;
+                if (mm < r1) {
+                    vx[u] = *reinterpret_cast<const uint4*>(x + (size_t)mm * ld_x + c);
+                    if (res) vr[u] = *reinterpret_cast<const uint4*>(res + (size_t)mm * ld_res + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int mm = m + u * R;
+                if (mm < r1) {
+                    float v[V], r[V];
+                    TT<T>::unpack(vx[u], v);
+                    if (res) TT<T>::unpack(vr[u], r);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        float t = v[e] * sc[e] + sh[e];
+                        if (res) t += r[e];
+                        v[e] = relu ? fmaxf(t, 0.f) : t;
+                    }
+                    *reinterpret_cast<uint4*>(y + (size_t)mm * ld_y + c) = TT<T>::pack(v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__ dy, int ld_dy, const T* __restrict__ y, int ld_y,
+                                                           const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
+                                                           T* __restrict__ dres, int ld_dres, int dres_accum, int rows_per_blk, int CVP) {
+    constexpr int V = TT<T>::VEC;
+    const int CV = Cp / V, R = 256 / CVP;
+    const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int r0 = blockIdx.x * rows_per_blk;
+    int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
+    for (int cv = cvl; cv < CV; cv += CVP) {
+        const int c = cv * V;
+        // dx = a*dz + b*(x - mu) + d  with  a = g, b = -g*c2*invstd, d = -g*c1   (g = gamma*invstd)
+        float ka[V], kb[V], kd[V], kmu[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            if (coef) {
+                const float g = coef[c + e], c1 = coef[Cp + c + e], c2 = coef[2 * Cp + c + e];
+                ka[e] = g; kb[e] = -g * c2 * invstd[c + e]; kd[e] = -g * c1; kmu[e] = mean[c + e];
+            } else { ka[e] = 1.f; kb[e] = 0.f; kd[e] = 0.f; kmu[e] = 0.f; }
+        }
+        for (int m = r0 + rl; m < r1; m += R * RU) {
+            uint4 vg[RU], vx[RU], vy[RU], vr[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int mm = m + u * R;
+                if (mm < r1) {
+                    vg[u] = *reinterpret_cast<const uint4*>(dy + (size_t)mm * ld_dy + c);
+                    if (coef) vx[u] = *reinterpret_cast<const uint4*>(x + (size_t)mm * ld_x + c);
+                    if (y) vy[u] = *reinterpret_cast<const uint4*>(y + (size_t)mm * ld_y + c);
+                    if (dres && dres_accum) vr[u] = *reinterpret_cast<const uint4*>(dres + (size_t)mm * ld_dres + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int mm = m + u * R;
+                if (mm < r1) {
+                    float g[V], xv[V], yv[V], rr[V], o[V];
+                    TT<T>::unpack(vg[u], g);
+                    if (coef) TT<T>::unpack(vx[u], xv);
+                    if (y) TT<T>::unpack(vy[u], yv);
+                    if (dres && dres_accum) TT<T>::unpack(vr[u], rr);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const float dz = (y && !(yv[e] > 0.f)) ? 0.f : g[e];
+                        o[e] = coef ? ka[e] * dz + kb[e] * (xv[e] - kmu[e]) + kd[e] : dz;
+                        rr[e] = (dres && dres_accum) ? rr[e] + dz : dz;
+                    }
+                    *reinterpret_cast<uint4*>(dx + (size_t)mm * ld_dx + c) = TT<T>::pack(o);
+                    if (dres) *reinterpret_cast<uint4*>(dres + (size_t)mm * ld_dres + c) = TT<T>::pack(rr);
+                }
+            }
+        }
+    }
+}
+
+inline void rows_geometry(int M, int CV, int& cvp, int& rows_per_blk, int& nblk) {
+    cvp = 1; while (cvp < CV && cvp < 256) cvp <<= 1;
+    const int R = 256 / cvp;
+    rows_per_blk = R * RU * 2;
+    nblk = (M + rows_per_blk - 1) / rows_per_blk;
+}
+
 inline int grid_for(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
@@ -204,6 +337,15 @@ template <typename Ti, typename To>
 int affine_dispatch(const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* scale, const float* shift, const void* res, int ld_res, int relu, hipStream_t st) {
     constexpr int V = TT<Ti>::VEC;
     const bool vec = sizeof(Ti) == sizeof(To) && C % V == 0 && ld_x % V == 0 && ld_y % V == 0 && (!res || ld_res % V == 0);
+    if constexpr (sizeof(Ti) == sizeof(To)) {
+        if (vec) {
+            int cvp, rpb, nblk;
+            rows_geometry(M, C / V, cvp, rpb, nblk);
+            hipLaunchKernelGGL((affine_rows_k<Ti>), dim3(nblk), dim3(256), 0, st, (const Ti*)x, ld_x, (Ti*)y, ld_y, M, C, scale, shift, (const Ti*)res, ld_res, relu, rpb, cvp);
+            PN2_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (vec) hipLaunchKernelGGL((affine_act_k<Ti, To, V>), dim3(grid_for((size_t)M * (C / V))), dim3(256), 0, st, (const Ti*)x, ld_x, (To*)y, ld_y, M, C, scale, shift, (const Ti*)res, ld_res, relu);
     else hipLaunchKernelGGL((affine_act_k<Ti, To, 1>), dim3(grid_for((size_t)M * C)), dim3(256), 0, st, (const Ti*)x, ld_x, (To*)y, ld_y, M, C, scale, shift, (const Ti*)res, ld_res, relu);
     PN2_CHECK_LAUNCH();
@@ -233,6 +375,15 @@ int bwd_apply_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int ld
     constexpr int V = TT<T>::VEC;
     const bool vec = sizeof(T) == sizeof(Tdy) && Cdy == Cp && Cp % V == 0 && ld_dy % V == 0 && ld_dx % V == 0 && (!coef || ld_x % V == 0) &&
                      (!y || ld_y % V == 0) && (!dres || ld_dres % V == 0);
+    if constexpr (sizeof(T) == sizeof(Tdy)) {
+        if (vec) {
+            int cvp, rpb, nblk;
+            rows_geometry(M, Cp / V, cvp, rpb, nblk);
+            hipLaunchKernelGGL((bn_bwd_apply_rows_k<T>), dim3(nblk), dim3(256), 0, st, (const T*)dy, ld_dy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, rpb, cvp);
+            PN2_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (vec) hipLaunchKernelGGL((bn_bwd_apply_k<T, Tdy, V>), dim3(grid_for((size_t)M * (Cp / V))), dim3(256), 0, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum);
     else hipLaunchKernelGGL((bn_bwd_apply_k<T, Tdy, 1>), dim3(grid_for((size_t)M * Cp)), dim3(256), 0, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum);
     PN2_CHECK_LAUNCH();

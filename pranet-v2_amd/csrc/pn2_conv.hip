@@ -19,20 +19,20 @@
 
 namespace {
 
-constexpr int BM = 128;        // output pixels per workgroup (forward / dgrad)
-constexpr int ROWB = 64;       // bytes of K per LDS row per step (32 bf16 or 16 f32)
-constexpr int RS = ROWB + 16;  // padded LDS row stride (bytes)
+constexpr int ROWB = 128;      // bytes of K per LDS row per step (64 bf16 or 32 f32): two 64-byte MFMA sub-steps
+constexpr int KSUB = ROWB / 64;
+constexpr int RS = ROWB + 16;  // padded LDS row stride (bytes): 36 banks -> the 16 rows of a fragment read hit 16 distinct 16-B slots
 
 template <typename T> struct MMA;
 template <> struct MMA<bf16_t> {
-    static constexpr int BK = 32;
+    static constexpr int BK = 32 * KSUB;
     __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
     }
 };
 template <> struct MMA<float> {
-    static constexpr int BK = 16;
-    // lane (g = lane>>4) holds k = 4g..4g+3 of this 16-deep step; MFMA j contracts {j, 4+j, 8+j, 12+j}
+    static constexpr int BK = 16 * KSUB;
+    // lane (g = lane>>4) holds k = 4g..4g+3 of this 16-deep sub-step; MFMA j contracts {j, 4+j, 8+j, 12+j}
     __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
@@ -67,14 +67,14 @@ __device__ __forceinline__ bool tap_pixel(const GatherGeom& g, int iy0, int ix0,
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad gather-GEMM
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BN, int WM, int WN, bool PW>
+template <typename T, int BM, int BN, int WM, int WN, bool PW>
 __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in, const T* __restrict__ wp, T* __restrict__ out,
                                                         float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d) {
     constexpr int VEC = TT<T>::VEC, BK = MMA<T>::BK;
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int STAGE = (BM + BN) * RS;
     constexpr int CRS = BN * (int)sizeof(T) + 16;
-    constexpr int NA = BM / 64, NB = (BN + 63) / 64;
+    constexpr int NA = BM / 32, NB = BN / 32;     // 16-byte vectors per thread per step (8 vectors per 128-byte row)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -94,11 +94,11 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
     gg.transposed = d.transposed;
 
     // ---- per-thread A rows
-    const int kv = tid & 3;
+    const int kv = tid & 7;
     int rbase[NA], riy0[NA], rix0[NA]; bool rok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + (tid >> 2) + 64 * i;
+        const int m = m0 + (tid >> 3) + 32 * i;
         rok[i] = m < M;
         const int mm = rok[i] ? m : 0;
         if (PW) { rbase[i] = mm; riy0[i] = 0; rix0[i] = 0; }
@@ -113,43 +113,51 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
     }
     int ci = kv * VEC, tap = 0;
     if (!PW) { while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; } }
-    const T* bptr = wp + (size_t)(n0 + (tid >> 2)) * d.Kp + kv * VEC;
+    const T* bptr = wp + (size_t)(n0 + (tid >> 3)) * d.Kp + kv * VEC;
 
+    // Loads are UNCONDITIONAL (out-of-range vectors read a clamped, valid address) and the zero fill is applied when the
+    // registers are written to LDS: a branch around a load makes hipcc wait for it at the join, which would serialise the
+    // global->register prefetch of step t+1 with the MFMAs of step t.
     uint4 ra[NA], rb[NB];
-    auto gload = [&](int step) {
-        if (PW) {
-            const int k = step * BK + kv * VEC;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                ra[i] = make_uint4(0, 0, 0, 0);
-                if (rok[i] && k < d.Cin_p) ra[i] = *reinterpret_cast<const uint4*>(in + (size_t)rbase[i] * d.ld_in + k);
-            }
-        } else {
-            const int r = tap / d.KW, s = tap - r * d.KW;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                ra[i] = make_uint4(0, 0, 0, 0);
-                int iy, ix;
-                if (rok[i] && tap < taps && tap_pixel(gg, riy0[i], rix0[i], r, s, iy, ix))
-                    ra[i] = *reinterpret_cast<const uint4*>(in + (size_t)(rbase[i] + iy * d.W + ix) * d.ld_in + ci);
-            }
-            ci += BK;
-            while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            if (BN >= 64 || tid < 128) rb[i] = *reinterpret_cast<const uint4*>(bptr + (size_t)(64 * i) * d.Kp + (size_t)step * BK);
-        }
-    };
-    auto lstore = [&](int stage) {
-        char* As = smem + stage * STAGE;
-        char* Bs = As + BM * RS;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(As + ((tid >> 2) + 64 * i) * RS + kv * 16) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            if (BN >= 64 || tid < 128) *reinterpret_cast<uint4*>(Bs + ((tid >> 2) + 64 * i) * RS + kv * 16) = rb[i];
-    };
+    unsigned amask = 0;
+    // (macros, not lambdas: arrays captured by reference in a lambda ended up in scratch memory)
+#define PN2_GLOAD(step_)                                                                                               \
+    do {                                                                                                               \
+        amask = 0;                                                                                                     \
+        if (PW) {                                                                                                      \
+            const int k_ = (step_) * BK + kv * VEC;                                                                    \
+            const bool kok_ = k_ < d.Cin_p;                                                                            \
+            const int kc_ = kok_ ? k_ : 0;                                                                             \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+                if (rok[i] && kok_) amask |= 1u << i;                                                                  \
+                ra[i] = *reinterpret_cast<const uint4*>(in + (size_t)rbase[i] * d.ld_in + kc_);                        \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            const int r_ = tap / d.KW, s_ = tap - r_ * d.KW;                                                           \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+                int iy_, ix_;                                                                                          \
+                const bool ok_ = rok[i] && tap < taps && tap_pixel(gg, riy0[i], rix0[i], r_, s_, iy_, ix_);            \
+                const size_t off_ = ok_ ? (size_t)(rbase[i] + iy_ * d.W + ix_) * d.ld_in + ci : 0;                     \
+                if (ok_) amask |= 1u << i;                                                                             \
+                ra[i] = *reinterpret_cast<const uint4*>(in + off_);                                                    \
+            }                                                                                                          \
+            ci += BK;                                                                                                  \
+            while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; }                                                            \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                 \
+            rb[i] = *reinterpret_cast<const uint4*>(bptr + (size_t)(32 * i) * d.Kp + (size_t)(step_) * BK);            \
+    } while (0)
+#define PN2_LSTORE(stage_)                                                                                             \
+    do {                                                                                                               \
+        char* As_ = smem + (stage_) * STAGE;                                                                           \
+        char* Bs_ = As_ + BM * RS;                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                               \
+            const uint4 v_ = (amask >> i) & 1u ? ra[i] : make_uint4(0, 0, 0, 0);                                       \
+            *reinterpret_cast<uint4*>(As_ + ((tid >> 3) + 32 * i) * RS + kv * 16) = v_;                                \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                 \
+            *reinterpret_cast<uint4*>(Bs_ + ((tid >> 3) + 32 * i) * RS + kv * 16) = rb[i];                            \
+    } while (0)
 
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -157,26 +165,33 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    lstore(0);
+    PN2_GLOAD(0);
+    PN2_LSTORE(0);
     __syncthreads();
     for (int step = 0; step < ksteps; ++step) {
         const int cur = step & 1;
-        if (step + 1 < ksteps) gload(step + 1);
+        // branch-free prefetch: the last iteration re-loads the final tile into the idle stage (never read)
+        const int nxt = step + 1 < ksteps ? step + 1 : step;
+        PN2_GLOAD(nxt);
         const char* As = smem + cur * STAGE;
         const char* Bs = As + BM * RS;
-        uint4 a[MT], b[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(As + (wm * WTM + i * 16 + l15) * RS + g * 16);
+        for (int ks = 0; ks < KSUB; ++ks) {
+            uint4 a[MT], b[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WTN + j * 16 + l15) * RS + g * 16);
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(As + (wm * WTM + i * 16 + l15) * RS + ks * 64 + g * 16);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WTN + j * 16 + l15) * RS + ks * 64 + g * 16);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], a[i], b[j]);
-        if (step + 1 < ksteps) lstore(cur ^ 1);
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], a[i], b[j]);
+        }
+        PN2_LSTORE(cur ^ 1);
         __syncthreads();
     }
+#undef PN2_GLOAD
+#undef PN2_LSTORE
 
     // ---- epilogue: stats partials + LDS-staged coalesced store
     char* Cs = smem;
@@ -316,25 +331,32 @@ __global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, cons
         }
     }
 
+    // unconditional loads from clamped addresses, zero fill applied at the LDS write (see conv_gather_gemm)
     uint4 ry[NY], rx[NX];
-    auto gload = [&](int step) {
+    unsigned ymask = 0, xmask = 0;
+    const int yco = (y_active && yc_ok) ? co0 + ycv * VEC : 0;
+    auto gload = [&](int step, bool live) {
         const int mb = step * WGP;
+        ymask = 0; xmask = 0;
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
             const int m = mb + yrow + i * RSTEPY;
-            ry[i] = make_uint4(0, 0, 0, 0);
-            if (y_active && yc_ok && m < M) ry[i] = *reinterpret_cast<const uint4*>(dy + (size_t)m * d.ld_dy + co0 + ycv * VEC);
+            const bool ok = live && y_active && yc_ok && m < M;
+            if (ok) ymask |= 1u << i;
+            ry[i] = *reinterpret_cast<const uint4*>(dy + (size_t)(ok ? m : 0) * d.ld_dy + yco);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int m = mb + xrow + i * RSTEPX;
-            rx[i] = make_uint4(0, 0, 0, 0);
             if (PW) {
-                if (xk_ok && m < M) rx[i] = *reinterpret_cast<const uint4*>(x + (size_t)m * d.ld_x + kk);
+                const bool ok = live && xk_ok && m < M;
+                if (ok) xmask |= 1u << i;
+                rx[i] = *reinterpret_cast<const uint4*>(x + (ok ? (size_t)m * d.ld_x + kk : 0));
             } else {
                 const int iy = poy[i] * d.stride - d.pad_h + xr * d.dil_h, ix = pox[i] * d.stride - d.pad_w + xs * d.dil_w;
-                if (xk_ok && m < M && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W)
-                    rx[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(pn[i] * d.H + iy) * d.W + ix) * d.ld_x + xci);
+                const bool ok = live && xk_ok && m < M && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                if (ok) xmask |= 1u << i;
+                rx[i] = *reinterpret_cast<const uint4*>(x + (ok ? ((size_t)(pn[i] * d.H + iy) * d.W + ix) * d.ld_x + xci : 0));
                 pox[i] += WGP;
                 while (pox[i] >= d.OW) { pox[i] -= d.OW; ++poy[i]; }
                 while (poy[i] >= d.OH) { poy[i] -= d.OH; ++pn[i]; }
@@ -346,9 +368,9 @@ __global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, cons
         char* Xs = Ys + WGP * RSY;
 #pragma unroll
         for (int i = 0; i < NY; ++i)
-            if (y_active) *reinterpret_cast<uint4*>(Ys + (yrow + i * RSTEPY) * RSY + ycv * 16) = ry[i];
+            if (y_active) *reinterpret_cast<uint4*>(Ys + (yrow + i * RSTEPY) * RSY + ycv * 16) = (ymask >> i) & 1u ? ry[i] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) *reinterpret_cast<uint4*>(Xs + (xrow + i * RSTEPX) * RSX + xkv * 16) = rx[i];
+        for (int i = 0; i < NX; ++i) *reinterpret_cast<uint4*>(Xs + (xrow + i * RSTEPX) * RSX + xkv * 16) = (xmask >> i) & 1u ? rx[i] : make_uint4(0, 0, 0, 0);
     };
 
     f32x4_t acc[MT][NT];
@@ -358,12 +380,12 @@ __global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, cons
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     if (s_begin < s_end) {
-        gload(s_begin);
+        gload(s_begin, true);
         lstore(0);
         __syncthreads();
         for (int step = s_begin; step < s_end; ++step) {
             const int cur = (step - s_begin) & 1;
-            if (step + 1 < s_end) gload(step + 1);
+            gload(step + 1, step + 1 < s_end);      // branch-free prefetch: the last one is dead (all lanes masked, address clamped)
             const char* Ys = smem + cur * STAGE;
             const char* Xs = Ys + WGP * RSY;
             if constexpr (sizeof(T) == 2) {
@@ -390,7 +412,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, cons
                         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
                 }
             }
-            if (step + 1 < s_end) lstore(cur ^ 1);
+            lstore(cur ^ 1);
             __syncthreads();
         }
     }
@@ -432,32 +454,85 @@ __global__ void pack_weight(const float* __restrict__ w, T* __restrict__ wp, pn2
     }
 }
 
-__global__ void wgrad_reduce_unpack(const float* __restrict__ slab, float* __restrict__ gw, pn2_pack_desc p, int nsplit, int accumulate) {
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_multi(const pn2_pack_job* __restrict__ jobs) {
+    // one launch repacks every conv weight of the model (forward + dgrad panels): blockIdx.y = job
+    const pn2_pack_job j = jobs[blockIdx.y];
+    const pn2_pack_desc p = j.d;
+    const float* w = j.w;
+    T* wp = reinterpret_cast<T*>(j.wp);
+    const size_t total = (size_t)p.Rp * p.Kp;
     const int taps = p.KH * p.KW;
-    const size_t total = (size_t)p.Cout * p.Cin * taps;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int tap = (int)(idx % taps);
-        const int ci = (int)((idx / taps) % p.Cin), co = (int)(idx / ((size_t)taps * p.Cin));
-        const int prow = (co / p.gw_out) * p.gwp_out + co % p.gw_out;
-        const int pcol = tap * p.Cin_p + (ci / p.gw_in) * p.gwp_in + ci % p.gw_in;
-        const float* s = slab + (size_t)prow * p.Kp + pcol;
+    const int cg = p.transposed ? p.Cout_p : p.Cin_p;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int row = (int)(idx / p.Kp), k = (int)(idx - (size_t)row * p.Kp);
+        const int tap = k / cg, c = k - tap * cg;
         float v = 0.f;
-        for (int i = 0; i < nsplit; ++i) v += s[(size_t)i * p.Rp * p.Kp];
-        gw[idx] = accumulate ? gw[idx] + v : v;
+        if (tap < taps) {
+            int co, ci;
+            if (!p.transposed) { co = row < p.Cout_p ? phys2log(row, p.gw_out, p.gwp_out, p.Cout) : -1; ci = phys2log(c, p.gw_in, p.gwp_in, p.Cin); }
+            else { ci = row < p.Cin_p ? phys2log(row, p.gw_in, p.gwp_in, p.Cin) : -1; co = phys2log(c, p.gw_out, p.gwp_out, p.Cout); }
+            if (co >= 0 && ci >= 0) v = w[((size_t)co * p.Cin + ci) * taps + tap];
+        }
+        TT<T>::st(wp + idx, v);
     }
 }
 
-template <typename T, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restrict__ slab, float* __restrict__ gw, pn2_pack_desc p, int nsplit, int accumulate) {
+    // walk the slabs in their own (k-contiguous) order so the nsplit reads per element are coalesced; the single
+    // OIHW write per element is the scattered side.  Fixed summation order over the splits -> deterministic.
+    const int taps = p.KH * p.KW;
+    const int ktot = taps * p.Cin_p;
+    const size_t total = (size_t)p.Cout_p * ktot;
+    const size_t sstride = (size_t)p.Rp * p.Kp;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int prow = (int)(idx / ktot), k = (int)(idx - (size_t)prow * ktot);
+        const int tap = k / p.Cin_p, pc = k - tap * p.Cin_p;
+        const int co = phys2log(prow, p.gw_out, p.gwp_out, p.Cout), ci = phys2log(pc, p.gw_in, p.gwp_in, p.Cin);
+        if (co < 0 || ci < 0) continue;
+        const float* s = slab + (size_t)prow * p.Kp + k;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int i = 0;
+        for (; i + 4 <= nsplit; i += 4) {
+            v0 += s[(size_t)i * sstride]; v1 += s[(size_t)(i + 1) * sstride]; v2 += s[(size_t)(i + 2) * sstride]; v3 += s[(size_t)(i + 3) * sstride];
+        }
+        for (; i < nsplit; ++i) v0 += s[(size_t)i * sstride];
+        const float v = (v0 + v1) + (v2 + v3);
+        float* d = gw + ((size_t)co * p.Cin + ci) * taps + tap;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
 int launch_gemm(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, hipStream_t st) {
     const int M = d.N * d.OH * d.OW;
     const int grid = ((M + BM - 1) / BM) * ((d.Cout + BN - 1) / BN);
     constexpr int main_b = 2 * (BM + BN) * RS, epi_b = BM * (BN * (int)sizeof(T) + 16) + 2 * WM * BN * 4;
     constexpr int lds = main_b > epi_b ? main_b : epi_b;
     const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
-    if (pw) hipLaunchKernelGGL((conv_gather_gemm<T, BN, WM, WN, true>), dim3(grid), dim3(256), lds, st, (const T*)in, (const T*)wp, (T*)out, psum, psq, d);
-    else hipLaunchKernelGGL((conv_gather_gemm<T, BN, WM, WN, false>), dim3(grid), dim3(256), lds, st, (const T*)in, (const T*)wp, (T*)out, psum, psq, d);
+    if (lds > 64 * 1024) {      // opt in to more than 64 KiB of dynamic LDS once per instantiation
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+    }
+    if (pw) hipLaunchKernelGGL((conv_gather_gemm<T, BM, BN, WM, WN, true>), dim3(grid), dim3(256), lds, st, (const T*)in, (const T*)wp, (T*)out, psum, psq, d);
+    else hipLaunchKernelGGL((conv_gather_gemm<T, BM, BN, WM, WN, false>), dim3(grid), dim3(256), lds, st, (const T*)in, (const T*)wp, (T*)out, psum, psq, d);
     PN2_CHECK_LAUNCH();
     return 0;
+}
+
+// tile choice: widest N tile with the least padding, then shrink tiles until the grid can fill 256 CUs
+inline void pick_tiles(int M, int cout, bool f32, int& bm, int& bn) {
+    bn = pn2_conv_tile_n(cout);
+    if (f32 && bn == 128) bn = 64;   // fp32 128-wide epilogue tile would exceed 64 KiB of LDS
+    bm = 128;
+    auto blocks = [&]() { return ((M + bm - 1) / bm) * ((cout + bn - 1) / bn); };
+    if (blocks() < 384) bm = 64;
+    if (blocks() < 256 && bn == 128) bn = 64;
+    if (blocks() < 160 && bn == 64 && cout > 32) bn = 32;
 }
 
 template <typename T, int BMC, int WM, int WN>
@@ -474,13 +549,20 @@ int launch_wgrad(const void* dy, const void* x, float* slab, const pn2_wgrad_des
 
 template <typename T>
 int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, hipStream_t st) {
-    int bn = pn2_conv_tile_n(d.Cout);
-    if (sizeof(T) == 4 && bn == 128) bn = 64;   // fp32 128x128 epilogue tile would exceed 64 KiB of LDS
-    if (bn == 128) {
-        if constexpr (sizeof(T) == 2) return launch_gemm<T, 128, 2, 2>(in, wp, out, psum, psq, d, st);
+    int bm, bn;
+    pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
+    if (bm == 128) {
+        if (bn == 128) {
+            if constexpr (sizeof(T) == 2) return launch_gemm<T, 128, 128, 2, 2>(in, wp, out, psum, psq, d, st);
+        }
+        if (bn == 64) return launch_gemm<T, 128, 64, 2, 2>(in, wp, out, psum, psq, d, st);
+        return launch_gemm<T, 128, 32, 4, 1>(in, wp, out, psum, psq, d, st);
     }
-    if (bn == 64) return launch_gemm<T, 64, 2, 2>(in, wp, out, psum, psq, d, st);
-    return launch_gemm<T, 32, 4, 1>(in, wp, out, psum, psq, d, st);
+    if (bn == 128) {
+        if constexpr (sizeof(T) == 2) return launch_gemm<T, 64, 128, 2, 2>(in, wp, out, psum, psq, d, st);
+    }
+    if (bn == 64) return launch_gemm<T, 64, 64, 2, 2>(in, wp, out, psum, psq, d, st);
+    return launch_gemm<T, 64, 32, 4, 1>(in, wp, out, psum, psq, d, st);
 }
 
 template <typename T>
@@ -507,7 +589,9 @@ int pn2_conv_tile_n(int cout) {
 
 int pn2_wgrad_tile_co(int cout_p) { return cout_p > 64 ? 128 : (cout_p > 32 ? 64 : 32); }
 
-int pn2_conv_stat_blocks(int m) { return (m + BM - 1) / BM; }
+int pn2_conv_tile_m(int m, int cout, int dtype) { int bm, bn; pick_tiles(m, cout, dtype == PN2_F32, bm, bn); return bm; }
+
+int pn2_conv_stat_blocks(int m, int cout, int dtype) { const int bm = pn2_conv_tile_m(m, cout, dtype); return (m + bm - 1) / bm; }
 
 int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, void* stream) {
     if (!in || !wp || !out || !d) return -1;
@@ -537,10 +621,20 @@ int pn2_pack_weight(int dtype, const float* w, void* wp, const pn2_pack_desc* p,
     return 0;
 }
 
+int pn2_pack_weights_multi(int dtype, const pn2_pack_job* jobs_dev, int njobs, int blocks_per_job, void* stream) {
+    if (!jobs_dev || njobs < 1 || blocks_per_job < 1) return -1;
+    dim3 grid(blocks_per_job, njobs);
+    if (dtype == PN2_BF16) hipLaunchKernelGGL(pack_weight_multi<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    else if (dtype == PN2_F32) hipLaunchKernelGGL(pack_weight_multi<float>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
 int pn2_wgrad_reduce(const float* slab, float* gw, const pn2_pack_desc* p, int nsplit, int accumulate, void* stream) {
     if (!slab || !gw || !p) return -1;
-    const size_t total = (size_t)p->Cout * p->Cin * p->KH * p->KW;
-    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const size_t total = (size_t)p->Cout_p * p->Cin_p * p->KH * p->KW;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_unpack, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, gw, *p, nsplit, accumulate);
     PN2_CHECK_LAUNCH();
     return 0;

@@ -29,6 +29,10 @@ class PackDesc(C.Structure):
                                        "Rp", "Kp", "transposed")]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("d", PackDesc)]
+
+
 class BnDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("Cp", C.c_int), ("C", C.c_int), ("gw", C.c_int), ("gwp", C.c_int),
                 ("eps", C.c_float), ("momentum", C.c_float)]
@@ -40,11 +44,13 @@ P, I, LL, FL = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 SIGNATURES = {
     "pn2_conv_tile_n": [I],
     "pn2_wgrad_tile_co": [I],
-    "pn2_conv_stat_blocks": [I],
+    "pn2_conv_tile_m": [I, I, I],
+    "pn2_conv_stat_blocks": [I, I, I],
     "pn2_conv_gemm": [I, P, P, P, P, P, C.POINTER(ConvDesc), P],
     "pn2_conv_wgrad": [I, P, P, P, C.POINTER(WgradDesc), I, P],
     "pn2_pack_weight": [I, P, P, C.POINTER(PackDesc), P],
     "pn2_wgrad_reduce": [P, P, C.POINTER(PackDesc), I, I, P],
+    "pn2_pack_weights_multi": [I, P, I, I, P],
     "pn2_bn_finalize": [P, P, I, C.POINTER(BnDesc), P, P, P, P, P, P, P, P, P],
     "pn2_bn_eval_prepare": [C.POINTER(BnDesc), P, P, P, P, P, P, P],
     "pn2_affine_act": [I, P, I, I, P, I, I, I, P, P, P, I, I, P],
@@ -75,7 +81,7 @@ SIGNATURES = {
     "pn2_eval_tail": [P, P, P, LL, P],
 }
 # entry points that return a value rather than a status
-_VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_bn_bwd_blocks", "pn2_loss_blocks"}
+_VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks"}
 
 _lib = None
 WORK = {}     # profiling annotation for the next launch (algorithmic flops / tag), consumed by pn2.profile.Recorder

@@ -106,8 +106,40 @@ class ParamGrads:
         return self.bufs.get(id(p)) if id(p) in self.written else None
 
 
+class PackCache:
+    """Persistent packed weight panels + the device job table that refreshes all of them in one launch."""
+
+    def __init__(self):
+        self.entries = {}          # key -> (panel tensor, PackDesc)
+        self.jobs = []             # capi.PackJob (host copies)
+        self.keep = []             # weights referenced by the table (pointers must stay valid)
+        self.table = None
+        self.dt = None
+
+    def add(self, key, w, wp, d):
+        self.entries[key] = (wp, d)
+        j = capi.PackJob()
+        j.w, j.wp = w.data_ptr(), wp.data_ptr()
+        C.memmove(C.byref(j.d), C.byref(d), C.sizeof(capi.PackDesc))
+        self.jobs.append(j)
+        self.keep.append(w)
+        self.table = None
+        self.dt = key[4]
+
+    def refresh(self):
+        """Repack every cached panel from the current fp32 master weights (call once per step, before forward)."""
+        if not self.jobs:
+            return
+        if self.table is None:
+            arr = (capi.PackJob * len(self.jobs))(*self.jobs)
+            raw = bytes(memoryview(arr).cast("B"))
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+        call.pn2_pack_weights_multi(self.dt, _p(self.table), len(self.jobs), 8, _stream())
+
+
 class Engine:
-    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True):
+    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None):
+        self.pack_cache = pack_cache
         if not torch.cuda.is_available():
             raise RuntimeError("pranet-v2_amd runs on MI355X only: no GPU visible and there is no CPU fallback")
         capi.load()
@@ -195,9 +227,17 @@ class Engine:
         return d
 
     def pack(self, w, x_map, out_map, transposed):
+        """K-contiguous weight panel in the compute dtype.  With a pack cache (trainer) the panel is persistent and is
+        refreshed for ALL convs by one pn2_pack_weights_multi launch per step instead of one launch per conv."""
+        cache = self.pack_cache
+        key = (id(w), bool(transposed), x_map, out_map, self.dt)
+        if cache is not None and key in cache.entries:
+            return cache.entries[key]
         d = self._pack_desc(w, x_map, out_map, transposed)
         wp = torch.empty((d.Rp, d.Kp), dtype=self.tdt, device=self.dev)
         call.pn2_pack_weight(self.dt, _p(w), _p(wp), C.byref(d), _stream())
+        if cache is not None:
+            cache.add(key, w, wp, d)
         return wp, d
 
     # ------------------------------------------------------------------ conv (+BN +ReLU +residual)
@@ -236,10 +276,11 @@ class Engine:
         cd.transposed, cd.Kp, cd.flags = 0, pd.Kp, (capi.CONV_STATS if train_bn else 0)
         psum = psq = None
         if train_bn:
-            nblk = call.pn2_conv_stat_blocks(M)
+            nblk = call.pn2_conv_stat_blocks(M, Cout_p, self.dt)
             psum, psq = self.fbuf(nblk, Cout_p), self.fbuf(nblk, Cout_p)
         flops = 2 * M * Cout * Cin * KH * KW
-        capi.WORK.update(flops=flops, tag=":fwd")
+        shape = f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}"
+        capi.WORK.update(flops=flops, tag=":fwd", shape=shape)
         call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), st)
 
         scale = shift = mean = invstd = None
@@ -313,9 +354,10 @@ class Engine:
             wd.Rp, wd.Kp = rup(Cout_p, tco), pd.Kp
             tiles = (wd.Rp // tco) * (pd.Kp // 128)
             steps = (M + 31) // 32
-            nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (1024 + tiles - 1) // tiles, 512))
+            # pixel splits: enough workgroups to fill 256 CUs twice, >= 4 steps each, slabs capped at 24 MB
+            nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (640 + tiles - 1) // tiles, (24 << 20) // (wd.Rp * wd.Kp * 4) or 1))
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp)
-            capi.WORK.update(flops=flops, tag="")
+            capi.WORK.update(flops=flops, tag="", shape=shape)
             call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
             gwt, gwa = self.pgrads.sink(w)
             rd = self._pack_desc(w, x_map, o_map, False)
@@ -330,7 +372,7 @@ class Engine:
                 dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Cout_p, Cout_p, x.Cp, gx.stride(2)
                 dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = KH, KW, sh, ph, pw, dh, dw
                 dd.transposed, dd.Kp, dd.flags = 1, ptd.Kp, (capi.CONV_ACCUM if gxa else 0)
-                capi.WORK.update(flops=flops, tag=":dgrad")
+                capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
                 call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
 
         self.record(bwd)
@@ -501,9 +543,11 @@ class Engine:
     # ------------------------------------------------------------------ bookkeeping
     def finish_forward(self):
         """BatchNorm's num_batches_tracked += 1 (nn.BatchNorm2d train-mode side effect)."""
-        seen = set()
+        seen, ctrs = set(), []
         for bn in self.bn_modules:
             if id(bn) not in seen and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+                ctrs.append(bn.num_batches_tracked)
                 seen.add(id(bn))
+        if ctrs:
+            torch._foreach_add_(ctrs, 1)       # one multi-tensor launch for all ~157 counters
         self.bn_modules = []

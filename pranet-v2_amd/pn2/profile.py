@@ -66,13 +66,14 @@ class Recorder:
             def wrapped(*a, _fn=fn, _name=name):
                 fl = capi.WORK.pop("flops", 0)
                 tag = capi.WORK.pop("tag", "")
+                shape = capi.WORK.pop("shape", "")
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _fn(*a)
                 e1.record()
                 if rc != 0:
                     raise RuntimeError(f"{_name} failed with status {rc}")
-                self.rows.append((_name + tag, fl, _bytes(_name, a) if not fl else 0, e0, e1))
+                self.rows.append((_name + tag, fl, _bytes(_name, a) if not fl else 0, e0, e1, shape))
             self.saved[name] = capi.call.__dict__.get(name)
             setattr(capi.call, name, wrapped)
         return self
@@ -84,10 +85,12 @@ class Recorder:
             else:
                 setattr(capi.call, name, old)
 
-    def summary(self):
+    def summary(self, detail=False):
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, by, e0, e1 in self.rows:
+        for name, fl, by, e0, e1, shape in self.rows:
+            if detail and shape:
+                name = name + " " + shape
             d = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0, "bytes": 0})
             d["ms"] += e0.elapsed_time(e1); d["launches"] += 1; d["flops"] += fl; d["bytes"] += by
         return agg

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from .capi import call, F32
-from .engine import Engine, Act, _p, _stream
+from .engine import Engine, Act, PackCache, _p, _stream
 from .graph import get_compute_dtype
 from .dp import GradBuckets
 from . import loss as L
@@ -55,6 +55,7 @@ class Trainer:
         self.buckets = GradBuckets(self.gflat, [(id(p), self.off[id(p)][0], _r4(self.off[id(p)][1])) for p in hot], bucket_bytes, process_group)
         self.graph = None
         self.last_outs = None
+        self.pack_cache = PackCache()
 
     # ------------------------------------------------------------------ pieces
     def _grad_view(self, p):
@@ -63,7 +64,8 @@ class Trainer:
 
     def forward_backward(self, images, gts, reduce_hook=True):
         """forward + loss + backward; returns loss[5] = (l2, l3, l4, l5 pair losses, total) on device."""
-        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True)
+        self.pack_cache.refresh()
+        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache)
         x = eng.from_nchw(images)
         outs = self.model._build(eng, x)
         eng.finish_forward()

@@ -40,7 +40,7 @@ def test_value_helpers_run_without_gpu():
     from pn2.capi import call
     assert call.pn2_conv_tile_n(256) == 128 and call.pn2_conv_tile_n(32) == 32 and call.pn2_conv_tile_n(56) == 64
     assert call.pn2_wgrad_tile_co(32) == 32 and call.pn2_wgrad_tile_co(208) == 128
-    assert call.pn2_conv_stat_blocks(129) == 2
+    assert call.pn2_conv_stat_blocks(129, 256, 1) == 3 and call.pn2_conv_stat_blocks(1 << 20, 256, 1) == 8192
     assert call.pn2_loss_blocks(352 * 352) == 31
 
 
