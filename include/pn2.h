@@ -88,7 +88,7 @@ int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int 
 /* backward pass 1: per-channel partials of sum(dz) and sum(dz*xhat), dz = dy*(y>0 if relu) ; dy has Cdy valid channels */
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
                       int M, int Cp, const float* mean, const float* invstd, float* p1, float* p2, int nblk, void* stream);
-int pn2_bn_bwd_blocks(int M);
+int pn2_bn_bwd_blocks(int M, int Cp, int dtype);   /* rows of the p1/p2 partial buffers */
 /* pass 1b: dgamma/dbeta (logical, optionally accumulated) + per-channel coefficients for pass 2 */
 int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn_desc* d, const float* gamma, const float* invstd,
                         float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);

@@ -152,14 +152,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ d
                 }
             }
         }
+        // combine the row lanes: butterfly over the lanes of a wave that share a channel vector (CVP < 64), then <= 4 partial
+        // rows (one per wave, or one per row lane when CVP >= 64) through LDS.  Fixed order -> deterministic.
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        if (CVP < 64) {
+            for (int off = CVP; off < 64; off <<= 1) {
 #pragma unroll
-        for (int e = 0; e < W; ++e) { shf[(rl * CVP + cvl) * W + e] = a1[e]; shf[((R + rl) * CVP + cvl) * W + e] = a2[e]; }
+                for (int e = 0; e < W; ++e) { a1[e] += __shfl_xor(a1[e], off); a2[e] += __shfl_xor(a2[e], off); }
+            }
+        }
+        const int NR = CVP < 64 ? 4 : R;
+        const int pr = CVP < 64 ? wid : rl;
+        const bool owner = CVP >= 64 || lane < CVP;
+        if (owner) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) { shf[(pr * CVP + cvl) * W + e] = a1[e]; shf[((NR + pr) * CVP + cvl) * W + e] = a2[e]; }
+        }
         __syncthreads();
-        if (rl == 0 && cv < CV) {
+        if (pr == 0 && owner && cv < CV) {
 #pragma unroll
             for (int e = 0; e < W; ++e) {
                 float s1 = 0.f, s2 = 0.f;
-                for (int r = 0; r < R; ++r) { s1 += shf[(r * CVP + cvl) * W + e]; s2 += shf[((R + r) * CVP + cvl) * W + e]; }
+                for (int r = 0; r < NR; ++r) { s1 += shf[(r * CVP + cvl) * W + e]; s2 += shf[((NR + r) * CVP + cvl) * W + e]; }
                 p1[(size_t)blockIdx.x * Cp + c + e] = s1; p2[(size_t)blockIdx.x * Cp + c + e] = s2;
             }
         }
@@ -419,7 +433,15 @@ int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int 
     return -3;
 }
 
-int pn2_bn_bwd_blocks(int M) { int b = (M + 63) / 64; return b > 1024 ? 1024 : (b < 1 ? 1 : b); }
+int pn2_bn_bwd_blocks(int M, int Cp, int dt) {
+    // >= 8 rows per thread: 256 threads = CVP channel vectors x R row lanes
+    const int V = dt == PN2_F32 ? 4 : 8;
+    const int cv = Cp % V == 0 ? Cp / V : Cp;
+    int cvp = 1; while (cvp < cv && cvp < 256) cvp <<= 1;
+    const int rows = (256 / cvp) * 8;
+    int b = (M + rows - 1) / rows;
+    return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+}
 
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
                       int M, int Cp, const float* mean, const float* invstd, float* p1, float* p2, int nblk, void* stream) {

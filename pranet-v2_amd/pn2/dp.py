@@ -38,9 +38,13 @@ class GradBuckets:
         self.works.append(dist.all_reduce(self.gflat[a:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         self.order.append(b)
 
-    def launch_ready(self, written):
-        """Start the all-reduce of every pending bucket whose parameter keys are all in `written`."""
-        for b in [b for b in self.pending if self.buckets[b][2] <= written]:
+    def launch_ready(self, written, before_launch=None):
+        """Start the all-reduce of every pending bucket whose parameter keys are all in `written`.
+        before_launch: called once if anything is about to be launched (e.g. join a side stream that produced the gradients)."""
+        ready = [b for b in self.pending if self.buckets[b][2] <= written]
+        if ready and before_launch is not None:
+            before_launch()
+        for b in ready:
             self._launch(b)
             self.pending.remove(b)
 

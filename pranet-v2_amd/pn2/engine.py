@@ -11,6 +11,7 @@ so the arithmetic is unchanged while every pixel row stays 16-byte aligned.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -152,6 +153,9 @@ class Engine:
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.bn_modules = []            # for num_batches_tracked bookkeeping
         self._lat = None                # contiguous block of the model's full-resolution output maps
+        self._side, self._keep = None, []
+        # experimental: measured no gain on MI355X (wgrad/dgrad grids already fill the chip) and results were not bit-reproducible
+        self.use_side = os.environ.get("PN2_SIDE_STREAM", "0") == "1"
 
     # ------------------------------------------------------------------ allocation / layout
     def empty(self, N, H, W, Cp, dt=None):
@@ -209,6 +213,39 @@ class Engine:
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        self.join_side()
+
+    # ------------------------------------------------------------------ side stream (off-critical-path work)
+    def on_side(self, keep=()):
+        """Context manager: run the enclosed launches on the engine's side HIP stream, ordered after everything issued so far
+        on the current stream.  `keep` tensors stay referenced until join_side() so the allocator cannot recycle them early."""
+        eng = self
+
+        class _Side:
+            def __enter__(s):
+                if not eng.use_side:
+                    return _stream()
+                if eng._side is None:
+                    eng._side = torch.cuda.Stream()
+                ev = torch.cuda.Event()
+                ev.record()
+                eng._side.wait_event(ev)
+                eng._keep.extend(keep)
+                s.ctx = torch.cuda.stream(eng._side)
+                s.ctx.__enter__()
+                return C.c_void_p(eng._side.cuda_stream)
+
+            def __exit__(s, *exc):
+                if eng.use_side:
+                    s.ctx.__exit__(*exc)
+                return False
+        return _Side()
+
+    def join_side(self):
+        """Make the current stream wait for everything queued on the side stream (call before consuming parameter gradients)."""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._keep = []
 
     # ------------------------------------------------------------------ weights
     def _pack_desc(self, w, x_map, out_map, transposed):
@@ -323,7 +360,7 @@ class Engine:
             Cdy = ncopy
             ymask = out if relu else None
             if train_bn:
-                nb = call.pn2_bn_bwd_blocks(M)
+                nb = call.pn2_bn_bwd_blocks(M, Cout_p, self.dt)
                 p1, p2 = self.fbuf(nb, Cout_p), self.fbuf(nb, Cout_p)
                 call.pn2_bn_bwd_reduce(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
                                        _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(p1), _p(p2), nb, st)
@@ -357,12 +394,15 @@ class Engine:
             # pixel splits: enough workgroups to fill 256 CUs twice, >= 4 steps each, slabs capped at 24 MB
             nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (640 + tiles - 1) // tiles, (24 << 20) // (wd.Rp * wd.Kp * 4) or 1))
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp)
-            capi.WORK.update(flops=flops, tag="", shape=shape)
-            call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
             gwt, gwa = self.pgrads.sink(w)
             rd = self._pack_desc(w, x_map, o_map, False)
             rd.Rp = wd.Rp
-            call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, st)
+            # wgrad (+ slab reduce) only feeds the parameter gradient: run it on the side stream so that it overlaps the dgrad /
+            # BN-backward chain of the layers below instead of sitting on the critical path
+            with self.on_side((draw, slab)) as sst:
+                capi.WORK.update(flops=flops, tag="", shape=shape)
+                call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, sst)
+                call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, sst)
             # ---- data gradient
             if x.requires_grad:
                 wt, ptd = self.pack(w, x_map, o_map, True)

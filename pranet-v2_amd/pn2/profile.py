@@ -51,6 +51,22 @@ def _bytes(name, a):
     return 0
 
 
+def _shape(name, a):
+    try:
+        if name == "pn2_affine_act":
+            return f"M{a[6]} C{a[7]} ldx{a[2]} ldy{a[5]} res{1 if a[10].value else 0}"
+        if name in ("pn2_bn_bwd_reduce", "pn2_bn_bwd_apply"):
+            return f"M{a[10]} C{a[11]} lddy{a[3]} ldx{a[9]} y{1 if a[5].value else 0}"
+        if name == "pn2_wgrad_reduce":
+            d = a[2]._obj
+            return f"{d.Cin}->{d.Cout} k{d.KH}x{d.KW} Rp{d.Rp} Kp{d.Kp} ns{a[3]}"
+        if name in ("pn2_bn_finalize", "pn2_bn_bwd_finalize"):
+            return f"nblk{a[2]} Cp{a[3]._obj.Cp}"
+    except Exception:
+        pass
+    return ""
+
+
 class Recorder:
     def __init__(self):
         self.rows = []          # (name, flops, bytes, e0, e1)
@@ -64,9 +80,10 @@ class Recorder:
             fn = getattr(lib, name)
 
             def wrapped(*a, _fn=fn, _name=name):
-                fl = capi.WORK.pop("flops", 0)
-                tag = capi.WORK.pop("tag", "")
-                shape = capi.WORK.pop("shape", "")
+                if _name in ("pn2_conv_gemm", "pn2_conv_wgrad"):
+                    fl, tag, shape = capi.WORK.pop("flops", 0), capi.WORK.pop("tag", ""), capi.WORK.pop("shape", "")
+                else:
+                    fl, tag, shape = 0, "", _shape(_name, a)
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _fn(*a)

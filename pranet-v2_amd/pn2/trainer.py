@@ -87,8 +87,9 @@ class Trainer:
         for fn in reversed(eng.tape):
             fn()
             if self.world > 1 and reduce_hook:
-                self.buckets.launch_ready(eng.pgrads.written)
+                self.buckets.launch_ready(eng.pgrads.written, before_launch=eng.join_side)
         eng.tape = []
+        eng.join_side()
         if self.world > 1:
             self.buckets.finish()
         self.last_outs = lat

@@ -36,3 +36,8 @@ print()
 for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
     if d["flops"]:
         print(f"{name:70s} {d['ms']:7.3f} ms x{d['launches']:3d} {d['flops'] / d['ms'] / 1e9:8.1f} TF/s")
+print()
+for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:400]:
+    if not d["flops"] and d["ms"] > 0.04:
+        bw = f"{d['bytes'] / d['ms'] / 1e6:8.1f} GB/s" if d["bytes"] else ""
+        print(f"{name:80s} {d['ms']:7.3f} ms x{d['launches']:3d} {bw}")
