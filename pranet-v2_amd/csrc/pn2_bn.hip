@@ -40,17 +40,29 @@ __device__ __forceinline__ void reduce_partials(const float* p1, const float* p2
     }
 }
 
+// sum (s1, s2) over the 32 row lanes that share a channel (thread = rl*8 + cl): butterfly inside each wave (8 row lanes),
+// then the 4 wave partials through LDS.  Result valid in the rl == 0 threads.  Fixed order -> deterministic.
+__device__ __forceinline__ void block_reduce_rows(double (*sh)[4][8], double& s1, double& s2) {
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane < 8) { sh[0][wid][lane] = s1; sh[1][wid][lane] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        s1 = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
+        s2 = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ psum, const float* __restrict__ psq, int nblk, pn2_bn_desc d,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
                                                      float* scale, float* shift, float* mean_o, float* invstd_o) {
-    __shared__ double sh[2][32][8];
+    __shared__ double sh[2][4][8];
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
     double s1, s2;
     reduce_partials(psum, psq, nblk, d.Cp, c, rl, s1, s2);
-    sh[0][rl][cl] = s1; sh[1][rl][cl] = s2;
-    __syncthreads();
+    block_reduce_rows(sh, s1, s2);
     if (rl == 0 && c < d.Cp) {
-        for (int r = 1; r < 32; ++r) { s1 += sh[0][r][cl]; s2 += sh[1][r][cl]; }
         const int lc = phys2log(c, d.gw, d.gwp, d.C);
         if (lc < 0) { scale[c] = 0.f; shift[c] = 0.f; mean_o[c] = 0.f; invstd_o[c] = 0.f; return; }
         const double mean = s1 / d.M;
@@ -184,14 +196,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ d
 __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ p1, const float* __restrict__ p2, int nblk, pn2_bn_desc d,
                                                          const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                          float* dgamma, float* dbeta, int accumulate, float* coef) {
-    __shared__ double sh[2][32][8];
+    __shared__ double sh[2][4][8];
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
     double s1, s2;
     reduce_partials(p1, p2, nblk, d.Cp, c, rl, s1, s2);
-    sh[0][rl][cl] = s1; sh[1][rl][cl] = s2;
-    __syncthreads();
+    block_reduce_rows(sh, s1, s2);
     if (rl == 0 && c < d.Cp) {
-        for (int r = 1; r < 32; ++r) { s1 += sh[0][r][cl]; s2 += sh[1][r][cl]; }
         const int lc = phys2log(c, d.gw, d.gwp, d.C);
         if (lc < 0) { coef[c] = 0.f; coef[d.Cp + c] = 0.f; coef[2 * d.Cp + c] = 0.f; return; }
         if (accumulate) { dbeta[lc] += (float)s1; dgamma[lc] += (float)s2; }
@@ -340,7 +350,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
 inline void rows_geometry(int M, int CV, int& cvp, int& rows_per_blk, int& nblk) {
     cvp = 1; while (cvp < CV && cvp < 256) cvp <<= 1;
     const int R = 256 / cvp;
-    rows_per_blk = R * RU * 2;
+    // aim at ~2048 workgroups (8 per CU) so that small tensors still put all their loads in flight at once;
+    // large tensors get up to RU*4 rows per thread
+    int want = (M + 2047) / 2048;
+    rows_per_blk = ((want + R - 1) / R) * R;
+    if (rows_per_blk < R) rows_per_blk = R;
+    if (rows_per_blk > R * RU * 4) rows_per_blk = R * RU * 4;
     nblk = (M + rows_per_blk - 1) / rows_per_blk;
 }
 
@@ -438,7 +453,7 @@ int pn2_bn_bwd_blocks(int M, int Cp, int dt) {
     const int V = dt == PN2_F32 ? 4 : 8;
     const int cv = Cp % V == 0 ? Cp / V : Cp;
     int cvp = 1; while (cvp < cv && cvp < 256) cvp <<= 1;
-    const int rows = (256 / cvp) * 8;
+    const int rows = (256 / cvp) * 2;     // >= 2 rows per thread, at most 1024 partial rows for the finalize pass
     int b = (M + rows - 1) / rows;
     return b > 1024 ? 1024 : (b < 1 ? 1 : b);
 }

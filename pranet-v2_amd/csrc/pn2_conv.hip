@@ -260,6 +260,214 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward / dgrad gather-GEMM, LDS-DMA pipeline (bf16): both operands go global -> LDS with
+// global_load_lds_dwordx4 (no register staging), NS stages deep, counted vmcnt + raw s_barrier so that
+// up to NS-1 K-steps of loads stay in flight across the MFMAs.  The LDS image written by the DMA is
+// lane-linear (128-byte rows, no padding); bank conflicts are removed by an XOR swizzle of the 16-byte
+// chunk index with ((row>>1)&7), applied to the per-lane SOURCE address and to the fragment reads.
+// Padding taps / out-of-range rows read a 16-byte zero vector in global memory instead of branching.
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned pn2_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int BM, int BN, int WM, int WN, bool PW>
+__global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
+                                                     float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d) {
+    using T = bf16_t;
+    constexpr int VEC = 8, BK = 64, ROW = 128, NS = 3;
+    constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
+    constexpr int STAGE = (BM + BN) * ROW;
+    constexpr int CRS = BN * 2 + 16;
+    constexpr int NA = BM / 32, NB = BN / 32, LPS = NA + NB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
+    const int M = d.N * d.OH * d.OW;
+    const int nbn = (d.Cout + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bn = bid % nbn, bm = bid / nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int taps = d.KH * d.KW;
+    const int ktot = taps * d.Cin_p;
+    const int ksteps = (ktot + BK - 1) / BK;
+
+    GatherGeom gg;
+    gg.H = d.H; gg.W = d.W; gg.OH = d.OH; gg.OW = d.OW; gg.KH = d.KH; gg.KW = d.KW; gg.stride = d.stride;
+    gg.sshift = d.stride == 2 ? 1 : 0; gg.pad_h = d.pad_h; gg.pad_w = d.pad_w; gg.dil_h = d.dil_h; gg.dil_w = d.dil_w;
+    gg.transposed = d.transposed;
+
+    // this thread's DMA lanes: row (tid>>3) of every 32-row group, LDS chunk slot (tid&7) which holds GLOBAL chunk cg
+    const int cg = (tid & 7) ^ ((tid >> 4) & 7);
+    int rbase[NA], riy0[NA], rix0[NA]; bool rok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + (tid >> 3) + 32 * i;
+        rok[i] = m < M;
+        const int mm = rok[i] ? m : 0;
+        if (PW) { rbase[i] = mm; riy0[i] = 0; rix0[i] = 0; }
+        else {
+            const int hw = d.OH * d.OW;
+            const int n = mm / hw, rem = mm - n * hw;
+            const int oy = rem / d.OW, ox = rem - oy * d.OW;
+            rbase[i] = n * d.H * d.W;
+            if (!d.transposed) { riy0[i] = oy * d.stride - d.pad_h; rix0[i] = ox * d.stride - d.pad_w; }
+            else { riy0[i] = oy + d.pad_h; rix0[i] = ox + d.pad_w; }
+        }
+    }
+    int ci = cg * VEC, tap = 0;
+    if (!PW) { while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; } }
+    const T* bptr = wp + (size_t)(n0 + (tid >> 3)) * d.Kp + cg * VEC;
+    const char* zsrc = reinterpret_cast<const char*>(pn2_zero16);
+    // wave-uniform LDS row offset of this wave inside a 32-row DMA group
+    const int wrow = __builtin_amdgcn_readfirstlane(wid * 8);
+
+#define PN2_ISSUE(step_, buf_)                                                                                         \
+    do {                                                                                                               \
+        char* sb_ = smem + (buf_) * STAGE;                                                                             \
+        if (PW) {                                                                                                      \
+            const int k_ = (step_) * BK + cg * VEC;                                                                    \
+            const bool kok_ = k_ < d.Cin_p;                                                                            \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+                const char* s_ = (rok[i] && kok_) ? reinterpret_cast<const char*>(in + (size_t)rbase[i] * d.ld_in + k_) : zsrc; \
+                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, 0, 0);         \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            const int r_ = tap / d.KW, c_ = tap - r_ * d.KW;                                                           \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+                int iy_, ix_;                                                                                          \
+                const bool ok_ = rok[i] && tap < taps && tap_pixel(gg, riy0[i], rix0[i], r_, c_, iy_, ix_);            \
+                const char* s_ = ok_ ? reinterpret_cast<const char*>(in + (size_t)(rbase[i] + iy_ * d.W + ix_) * d.ld_in + ci) : zsrc; \
+                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, 0, 0);         \
+            }                                                                                                          \
+            ci += BK;                                                                                                  \
+            while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; }                                                            \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                 \
+            __builtin_amdgcn_global_load_lds((gptr_t)(bptr + (size_t)(32 * i) * d.Kp + (size_t)(step_) * BK),         \
+                                             (lptr_t)(sb_ + BM * ROW + (i * 32 + wrow) * ROW), 16, 0, 0);              \
+    } while (0)
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: global chunk (ks*4 + g) of row (.. + l15) sits in slot chunk ^ ((row>>1)&7); tile bases are multiples of 16
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const int key = (l15 >> 1) & 7;
+    const unsigned so0 = ((g) ^ key) * 16, so1 = ((4 + g) ^ key) * 16;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;     // LDS byte address of the dynamic segment
+
+    PN2_ISSUE(0, 0);
+    if (ksteps > 1) PN2_ISSUE(1, 1);
+    for (int t = 0; t < ksteps; ++t) {
+        // my own DMA of step t has landed once at most one later step (LPS loads) is still outstanding
+        if (t + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // everyone's step-t data is in LDS; everyone finished reading step t-1
+        if (t + 2 < ksteps) {
+            const int nb_ = (t + 2) % NS;
+            PN2_ISSUE(t + 2, nb_);
+        }
+        // Fragment reads are inline asm: for a compiler-visible LDS load hipcc drains ALL outstanding LDS-DMA (vmcnt(0)) first,
+        // which would collapse the pipeline to depth 1.  DS operations return in order, so counted lgkmcnt waits are exact.
+        const unsigned As = lds0 + (t % NS) * STAGE + (wm * WTM + l15) * ROW;
+        const unsigned Bs = lds0 + (t % NS) * STAGE + BM * ROW + (wn * WTN + l15) * ROW;
+        u32x4_t a0[MT], a1[MT], b0[NT], b1[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a0[i]) : "v"(As + i * 16 * ROW + so0));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b0[j]) : "v"(Bs + j * 16 * ROW + so0));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a1[i]) : "v"(As + i * 16 * ROW + so1));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b1[j]) : "v"(Bs + j * 16 * ROW + so1));
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, a0[i]), __builtin_bit_cast(uint4, b0[j]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, a1[i]), __builtin_bit_cast(uint4, b1[j]));
+    }
+#undef PN2_ISSUE
+    __syncthreads();
+
+    // ---- epilogue: stats partials + LDS-staged coalesced store (same as conv_gather_gemm)
+    char* Cs = smem;
+    float* red = reinterpret_cast<float*>(smem + BM * CRS);
+    if (d.flags & PN2_CONV_STATS) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s += v; q += v * v; }
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+            if (g == 0) {
+                red[wm * BN + wn * WTN + j * 16 + l15] = s;
+                red[(WM + wm) * BN + wn * WTN + j * 16 + l15] = q;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
+                TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r]);
+            }
+    __syncthreads();
+    if ((d.flags & PN2_CONV_STATS) && tid < BN) {
+        const int col = n0 + tid;
+        if (col < d.Cout) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { s += red[w * BN + tid]; q += red[(WM + w) * BN + tid]; }
+            psum[(size_t)bm * d.Cout + col] = s;
+            psq[(size_t)bm * d.Cout + col] = q;
+        }
+    }
+    constexpr int VPR = BN / VEC;
+    const bool vec_ok = (d.Cout % VEC == 0) && (d.ld_out % VEC == 0);
+    const bool accum = d.flags & PN2_CONV_ACCUM;
+    for (int idx = tid; idx < BM * VPR; idx += 256) {
+        const int row = idx / VPR, cv = idx - row * VPR;
+        const int m = m0 + row, col = n0 + cv * VEC;
+        if (m >= M || col >= d.Cout) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CRS + cv * 16);
+        T* dst = out + (size_t)m * d.ld_out + col;
+        if (vec_ok) {
+            if (accum) {
+                float x[VEC], y[VEC];
+                TT<T>::unpack(v, x);
+                TT<T>::unpack(*reinterpret_cast<const uint4*>(dst), y);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) x[e] += y[e];
+                v = TT<T>::pack(x);
+            }
+            *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+            float x[VEC];
+            TT<T>::unpack(v, x);
+            for (int e = 0; e < VEC && col + e < d.Cout; ++e) TT<T>::st(dst + e, accum ? x[e] + TT<T>::ld(dst + e) : x[e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient: slab[s][co][k] = sum over this split's pixels of dy[m][co] * gather(x, m, k)
 // ------------------------------------------------------------------------------------------------
 constexpr int WGP = 32;   // pixels (contraction) per step
@@ -485,21 +693,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restri
     const int ktot = taps * p.Cin_p;
     const size_t total = (size_t)p.Cout_p * ktot;
     const size_t sstride = (size_t)p.Rp * p.Kp;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    // 8 consecutive lanes share one element: lane s sums slabs s, s+8, ... (4 loads in flight), then a fixed-order butterfly.
+    // 8x the threads and 1/8 of the serial chain of a thread-per-element loop (these matrices are small, nsplit is large).
+    const int sub = threadIdx.x & 7;
+    const size_t ngroups = ((size_t)gridDim.x * 256) >> 3;
+    for (size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 3; base < total; base += ngroups) {
+        const size_t idx = base;
         const int prow = (int)(idx / ktot), k = (int)(idx - (size_t)prow * ktot);
         const int tap = k / p.Cin_p, pc = k - tap * p.Cin_p;
         const int co = phys2log(prow, p.gw_out, p.gwp_out, p.Cout), ci = phys2log(pc, p.gw_in, p.gwp_in, p.Cin);
-        if (co < 0 || ci < 0) continue;
         const float* s = slab + (size_t)prow * p.Kp + k;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        int i = 0;
-        for (; i + 4 <= nsplit; i += 4) {
-            v0 += s[(size_t)i * sstride]; v1 += s[(size_t)(i + 1) * sstride]; v2 += s[(size_t)(i + 2) * sstride]; v3 += s[(size_t)(i + 3) * sstride];
+        int i = sub;
+        for (; i + 24 < nsplit; i += 32) {
+            v0 += s[(size_t)i * sstride]; v1 += s[(size_t)(i + 8) * sstride]; v2 += s[(size_t)(i + 16) * sstride]; v3 += s[(size_t)(i + 24) * sstride];
         }
-        for (; i < nsplit; ++i) v0 += s[(size_t)i * sstride];
-        const float v = (v0 + v1) + (v2 + v3);
-        float* d = gw + ((size_t)co * p.Cin + ci) * taps + tap;
-        *d = accumulate ? *d + v : v;
+        for (; i < nsplit; i += 8) v0 += s[(size_t)i * sstride];
+        float v = (v0 + v1) + (v2 + v3);
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        if (sub == 0 && co >= 0 && ci >= 0) {
+            float* d = gw + ((size_t)co * p.Cin + ci) * taps + tap;
+            *d = accumulate ? *d + v : v;
+        }
     }
 }
 
@@ -522,6 +737,35 @@ int launch_gemm(const void* in, const void* wp, void* out, float* psum, float* p
     else hipLaunchKernelGGL((conv_gather_gemm<T, BM, BN, WM, WN, false>), dim3(grid), dim3(256), lds, st, (const T*)in, (const T*)wp, (T*)out, psum, psq, d);
     PN2_CHECK_LAUNCH();
     return 0;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_dma(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, hipStream_t st) {
+    const int M = d.N * d.OH * d.OW;
+    const int grid = ((M + BM - 1) / BM) * ((d.Cout + BN - 1) / BN);
+    constexpr int stage_b = (BM + BN) * 128, max_b = 3 * stage_b, epi_b = BM * (BN * 2 + 16) + 2 * WM * BN * 4;
+    // short-K convs (1-2 K-steps) only touch 1-2 ring slots: ask for less LDS so that more workgroups share a CU
+    const int ksteps = (d.KH * d.KW * d.Cin_p + 63) / 64;
+    const int main_b = (ksteps < 3 ? ksteps : 3) * stage_b;
+    const int lds = main_b > epi_b ? main_b : epi_b;
+    const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
+    if (max_b > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            done = true;
+        }
+    }
+    if (pw) hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, true>), dim3(grid), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
+    else hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, false>), dim3(grid), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+inline bool use_dma_kernel() {
+    static const bool on = [] { const char* e = getenv("PN2_CONV_DMA"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 // tile choice: widest N tile with the least padding, then shrink tiles until the grid can fill 256 CUs
@@ -551,6 +795,18 @@ template <typename T>
 int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, hipStream_t st) {
     int bm, bn;
     pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
+    if constexpr (sizeof(T) == 2) {
+        if (use_dma_kernel()) {
+            if (bm == 128) {
+                if (bn == 128) return launch_dma<128, 128, 2, 2>(in, wp, out, psum, psq, d, st);
+                if (bn == 64) return launch_dma<128, 64, 2, 2>(in, wp, out, psum, psq, d, st);
+                return launch_dma<128, 32, 4, 1>(in, wp, out, psum, psq, d, st);
+            }
+            if (bn == 128) return launch_dma<64, 128, 2, 2>(in, wp, out, psum, psq, d, st);
+            if (bn == 64) return launch_dma<64, 64, 2, 2>(in, wp, out, psum, psq, d, st);
+            return launch_dma<64, 32, 4, 1>(in, wp, out, psum, psq, d, st);
+        }
+    }
     if (bm == 128) {
         if (bn == 128) {
             if constexpr (sizeof(T) == 2) return launch_gemm<T, 128, 128, 2, 2>(in, wp, out, psum, psq, d, st);
@@ -634,7 +890,8 @@ int pn2_pack_weights_multi(int dtype, const pn2_pack_job* jobs_dev, int njobs, i
 int pn2_wgrad_reduce(const float* slab, float* gw, const pn2_pack_desc* p, int nsplit, int accumulate, void* stream) {
     if (!slab || !gw || !p) return -1;
     const size_t total = (size_t)p->Cout_p * p->Cin_p * p->KH * p->KW;
-    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    const size_t nthr = total * 8;
+    const int grid = (int)((nthr + 255) / 256 > 16384 ? 16384 : (nthr + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_unpack, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, gw, *p, nsplit, accumulate);
     PN2_CHECK_LAUNCH();
     return 0;
