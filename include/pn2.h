@@ -85,9 +85,11 @@ int pn2_bn_eval_prepare(const pn2_bn_desc* d, const float* gamma, const float* b
 /* y[m][c] = act(x[m][c]*scale[c] + shift[c] + res[m][c]) for c < Cout ; scale==NULL -> identity affine */
 int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int ld_y, int M, int Cout,
                    const float* scale, const float* shift, const void* res, int ld_res, int relu, void* stream);
-/* backward pass 1: per-channel partials of sum(dz) and sum(dz*xhat), dz = dy*(y>0 if relu) ; dy has Cdy valid channels */
+/* backward pass 1: per-channel partials of sum(dz) and sum(dz*xhat), dz = dy*(relu mask) ; dy has Cdy valid channels.
+ * ReLU mask: y>0 when y is given; else recomputed as fmaf(x,mask_scale,mask_shift)>0 when mask_scale is given (saves reading y). */
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
-                      int M, int Cp, const float* mean, const float* invstd, float* p1, float* p2, int nblk, void* stream);
+                      int M, int Cp, const float* mean, const float* invstd, float* p1, float* p2, int nblk,
+                      const float* mask_scale, const float* mask_shift, void* stream);
 int pn2_bn_bwd_blocks(int M, int Cp, int dtype);   /* rows of the p1/p2 partial buffers */
 /* pass 1b: dgamma/dbeta (logical, optionally accumulated) + per-channel coefficients for pass 2 */
 int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn_desc* d, const float* gamma, const float* invstd,
@@ -96,7 +98,7 @@ int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn
  * coef==NULL: pure activation backward (dx = dz), used for eval-mode / affine-only layers.                */
 int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
                      int M, int Cp, const float* mean, const float* invstd, const float* coef, void* dx, int ld_dx,
-                     void* dres, int ld_dres, int dres_accum, void* stream);
+                     void* dres, int ld_dres, int dres_accum, const float* mask_scale, const float* mask_shift, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- pooling
  * nn.MaxPool2d(3,2,1) Res2Net_v1b.py:112 ; nn.AvgPool2d(3,stride,1) :40,80 ; AvgPool2d(s,s,ceil,count_include_pad=False) :131-132 */

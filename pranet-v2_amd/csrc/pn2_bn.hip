@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void affine_act_k(const Ti* __restrict__ x, in
 #pragma unroll
         for (int e = 0; e < W; ++e) {
             float t = v[e];
-            if (scale) t = t * scale[c + e] + shift[c + e];
+            if (scale) t = fmaf(t, scale[c + e], shift[c + e]);
             else if (shift) t += shift[c + e];
             if (res) t += r[e];
             v[e] = relu ? fmaxf(t, 0.f) : t;
@@ -126,7 +126,7 @@ template <typename T, typename Tdy, int W>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
                                                        const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, float* __restrict__ p1, float* __restrict__ p2,
-                                                       int rows_per_blk, int CVP) {
+                                                       int rows_per_blk, int CVP, const float* __restrict__ msc, const float* __restrict__ msh) {
     extern __shared__ __attribute__((aligned(16))) float shf[];   // [2][R][CVP*W]
     const int CV = Cp / W;
     const int R = 256 / CVP;
@@ -135,12 +135,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ d
     int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
     for (int cvb = 0; cvb < CV; cvb += CVP) {
         const int cv = cvb + cvl, c = cv * W;
-        float a1[W], a2[W], mu[W], is[W];
+        float a1[W], a2[W], mu[W], is[W], ks[W], kh[W];
 #pragma unroll
-        for (int e = 0; e < W; ++e) { a1[e] = 0.f; a2[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
+        for (int e = 0; e < W; ++e) { a1[e] = 0.f; a2[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; ks[e] = 0.f; kh[e] = 1.f; }
         if (cv < CV) {
 #pragma unroll
-            for (int e = 0; e < W; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
+            for (int e = 0; e < W; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; if (msc) { ks[e] = msc[c + e]; kh[e] = msh[c + e]; } }
             for (int m = r0 + rl; m < r1; m += R * 4) {
                 float g[4][W], xv[4][W], yv[4][W];
 #pragma unroll
@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ d
                     if (m + u * R < r1) {
 #pragma unroll
                         for (int e = 0; e < W; ++e) {
-                            const float dz = (y && !(yv[u][e] > 0.f)) ? 0.f : g[u][e];
+                            // ReLU mask: from the stored output y, or recomputed from the raw conv output (same fmaf as the forward)
+                            const bool off = y ? !(yv[u][e] > 0.f) : (msc && !(fmaf(xv[u][e], ks[e], kh[e]) > 0.f));
+                            const float dz = off ? 0.f : g[u][e];
                             a1[e] += dz; a2[e] += dz * (xv[u][e] - mu[e]) * is[e];
                         }
                     }
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void affine_rows_k(const T* __restrict__ x, in
                     if (res) TT<T>::unpack(vr[u], r);
 #pragma unroll
                     for (int e = 0; e < V; ++e) {
-                        float t = v[e] * sc[e] + sh[e];
+                        float t = fmaf(v[e], sc[e], sh[e]);
                         if (res) t += r[e];
                         v[e] = relu ? fmaxf(t, 0.f) : t;
                     }
@@ -295,7 +297,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__ dy, int ld_dy, const T* __restrict__ y, int ld_y,
                                                            const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
-                                                           T* __restrict__ dres, int ld_dres, int dres_accum, int rows_per_blk, int CVP) {
+                                                           T* __restrict__ dres, int ld_dres, int dres_accum, int rows_per_blk, int CVP,
+                                                           const float* __restrict__ msc, const float* __restrict__ msh) {
     constexpr int V = TT<T>::VEC;
     const int CV = Cp / V, R = 256 / CVP;
     const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
@@ -304,9 +307,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
     for (int cv = cvl; cv < CV; cv += CVP) {
         const int c = cv * V;
         // dx = a*dz + b*(x - mu) + d  with  a = g, b = -g*c2*invstd, d = -g*c1   (g = gamma*invstd)
-        float ka[V], kb[V], kd[V], kmu[V];
+        float ka[V], kb[V], kd[V], kmu[V], ks[V], kh[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
+            ks[e] = msc ? msc[c + e] : 0.f; kh[e] = msc ? msh[c + e] : 1.f;
             if (coef) {
                 const float g = coef[c + e], c1 = coef[Cp + c + e], c2 = coef[2 * Cp + c + e];
                 ka[e] = g; kb[e] = -g * c2 * invstd[c + e]; kd[e] = -g * c1; kmu[e] = mean[c + e];
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
                 const int mm = m + u * R;
                 if (mm < r1) {
                     vg[u] = *reinterpret_cast<const uint4*>(dy + (size_t)mm * ld_dy + c);
-                    if (coef) vx[u] = *reinterpret_cast<const uint4*>(x + (size_t)mm * ld_x + c);
+                    if (coef || msc) vx[u] = *reinterpret_cast<const uint4*>(x + (size_t)mm * ld_x + c);
                     if (y) vy[u] = *reinterpret_cast<const uint4*>(y + (size_t)mm * ld_y + c);
                     if (dres && dres_accum) vr[u] = *reinterpret_cast<const uint4*>(dres + (size_t)mm * ld_dres + c);
                 }
@@ -330,12 +334,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
                 if (mm < r1) {
                     float g[V], xv[V], yv[V], rr[V], o[V];
                     TT<T>::unpack(vg[u], g);
-                    if (coef) TT<T>::unpack(vx[u], xv);
+                    if (coef || msc) TT<T>::unpack(vx[u], xv);
                     if (y) TT<T>::unpack(vy[u], yv);
                     if (dres && dres_accum) TT<T>::unpack(vr[u], rr);
 #pragma unroll
                     for (int e = 0; e < V; ++e) {
-                        const float dz = (y && !(yv[e] > 0.f)) ? 0.f : g[e];
+                        const bool off = y ? !(yv[e] > 0.f) : (msc && !(fmaf(xv[e], ks[e], kh[e]) > 0.f));
+                        const float dz = off ? 0.f : g[e];
                         o[e] = coef ? ka[e] * dz + kb[e] * (xv[e] - kmu[e]) + kd[e] : dz;
                         rr[e] = (dres && dres_accum) ? rr[e] + dz : dz;
                     }
@@ -383,16 +388,16 @@ int affine_dispatch(const void* x, int ld_x, void* y, int ld_y, int M, int C, co
 
 template <typename T, typename Tdy>
 int bwd_reduce_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, const void* x, int ld_x, int M, int Cp,
-                        const float* mean, const float* invstd, float* p1, float* p2, int nblk, hipStream_t st) {
+                        const float* mean, const float* invstd, float* p1, float* p2, int nblk, const float* msc, const float* msh, hipStream_t st) {
     constexpr int V = TT<T>::VEC;
     const bool vec = sizeof(T) == sizeof(Tdy) && Cdy == Cp && Cp % V == 0 && ld_dy % V == 0 && ld_x % V == 0 && (!y || ld_y % V == 0);
     const int rows = (M + nblk - 1) / nblk;
     if (vec) {
         int cvp = pow2ceil(Cp / V); if (cvp > 256) cvp = 256;
-        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, V>), dim3(nblk), dim3(256), 2 * 256 * V * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp);
+        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, V>), dim3(nblk), dim3(256), 2 * 256 * V * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp, msc, msh);
     } else {
         int cvp = pow2ceil(Cp); if (cvp > 256) cvp = 256;
-        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, 1>), dim3(nblk), dim3(256), 2 * 256 * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp);
+        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, 1>), dim3(nblk), dim3(256), 2 * 256 * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp, msc, msh);
     }
     PN2_CHECK_LAUNCH();
     return 0;
@@ -400,7 +405,7 @@ int bwd_reduce_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int l
 
 template <typename T, typename Tdy>
 int bwd_apply_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, const void* x, int ld_x, int M, int Cp, const float* mean,
-                       const float* invstd, const float* coef, void* dx, int ld_dx, void* dres, int ld_dres, int dres_accum, hipStream_t st) {
+                       const float* invstd, const float* coef, void* dx, int ld_dx, void* dres, int ld_dres, int dres_accum, const float* msc, const float* msh, hipStream_t st) {
     constexpr int V = TT<T>::VEC;
     const bool vec = sizeof(T) == sizeof(Tdy) && Cdy == Cp && Cp % V == 0 && ld_dy % V == 0 && ld_dx % V == 0 && (!coef || ld_x % V == 0) &&
                      (!y || ld_y % V == 0) && (!dres || ld_dres % V == 0);
@@ -408,7 +413,7 @@ int bwd_apply_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int ld
         if (vec) {
             int cvp, rpb, nblk;
             rows_geometry(M, Cp / V, cvp, rpb, nblk);
-            hipLaunchKernelGGL((bn_bwd_apply_rows_k<T>), dim3(nblk), dim3(256), 0, st, (const T*)dy, ld_dy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, rpb, cvp);
+            hipLaunchKernelGGL((bn_bwd_apply_rows_k<T>), dim3(nblk), dim3(256), 0, st, (const T*)dy, ld_dy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, rpb, cvp, msc, msh);
             PN2_CHECK_LAUNCH();
             return 0;
         }
@@ -459,13 +464,14 @@ int pn2_bn_bwd_blocks(int M, int Cp, int dt) {
 }
 
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
-                      int M, int Cp, const float* mean, const float* invstd, float* p1, float* p2, int nblk, void* stream) {
+                      int M, int Cp, const float* mean, const float* invstd, float* p1, float* p2, int nblk,
+                      const float* mask_scale, const float* mask_shift, void* stream) {
     if (!dy || !x || !mean || !invstd || !p1 || !p2) return -1;
     if (y && dt_y != dt) return -2;
     hipStream_t st = (hipStream_t)stream;
-    if (dt == PN2_BF16 && dt_dy == PN2_BF16) return bwd_reduce_dispatch<bf16_t, bf16_t>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, st);
-    if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_reduce_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, st);
-    if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_reduce_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, st);
+    if (dt == PN2_BF16 && dt_dy == PN2_BF16) return bwd_reduce_dispatch<bf16_t, bf16_t>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, mask_scale, mask_shift, st);
+    if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_reduce_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, mask_scale, mask_shift, st);
+    if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_reduce_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, mask_scale, mask_shift, st);
     return -3;
 }
 
@@ -479,14 +485,14 @@ int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn
 
 int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
                      int M, int Cp, const float* mean, const float* invstd, const float* coef, void* dx, int ld_dx,
-                     void* dres, int ld_dres, int dres_accum, void* stream) {
+                     void* dres, int ld_dres, int dres_accum, const float* mask_scale, const float* mask_shift, void* stream) {
     if (!dy || !dx) return -1;
     if (coef && (!x || !mean || !invstd)) return -1;
     if (y && dt_y != dt) return -2;
     hipStream_t st = (hipStream_t)stream;
-    if (dt == PN2_BF16 && dt_dy == PN2_BF16) return bwd_apply_dispatch<bf16_t, bf16_t>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, st);
-    if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_apply_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, st);
-    if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_apply_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, st);
+    if (dt == PN2_BF16 && dt_dy == PN2_BF16) return bwd_apply_dispatch<bf16_t, bf16_t>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, st);
+    if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_apply_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, st);
+    if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_apply_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, st);
     return -3;
 }
 

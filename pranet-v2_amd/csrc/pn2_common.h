@@ -14,11 +14,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #define PN2_BF16 1
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {           // round-to-nearest-even (NaN kept quiet)
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+__device__ __forceinline__ bf16_t f2bf(float f) {           // round-to-nearest-even, gfx950 hardware convert
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(f));
+    return (bf16_t)r;
 }
 
 template <typename T> struct TT;
@@ -45,13 +44,14 @@ template <> struct TT<bf16_t> {
         f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
         f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
     }
+    // gfx950 hardware convert: two f32 -> packed bf16x2, round-to-nearest-even (one VALU op per pair instead of ~12)
+    __device__ static __forceinline__ unsigned cvt2(float lo, float hi) {
+        unsigned r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    }
     __device__ static __forceinline__ uint4 pack(const float* f) {
-        uint4 v;
-        v.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
-        v.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
-        v.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
-        v.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
-        return v;
+        return make_uint4(cvt2(f[0], f[1]), cvt2(f[2], f[3]), cvt2(f[4], f[5]), cvt2(f[6], f[7]));
     }
 };
 

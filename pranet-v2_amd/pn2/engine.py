@@ -359,11 +359,16 @@ class Engine:
             draw = self.empty(N, OH, OW, Cout_p)
             Cdy = ncopy
             ymask = out if relu else None
+            msc = msh = None
+            if os.environ.get("PN2_MASK_FROM_X", "0") == "1" and relu and train_bn and residual is None and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) % 8 == 0:
+                # ReLU mask recomputed from the raw conv output (fmaf(x, scale, shift) > 0, bit-identical to the forward):
+                # the backward passes then do not read y at all
+                ymask, msc, msh = None, scale, shift
             if train_bn:
                 nb = call.pn2_bn_bwd_blocks(M, Cout_p, self.dt)
                 p1, p2 = self.fbuf(nb, Cout_p), self.fbuf(nb, Cout_p)
                 call.pn2_bn_bwd_reduce(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
-                                       _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(p1), _p(p2), nb, st)
+                                       _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(p1), _p(p2), nb, _p(msc), _p(msh), st)
                 coef = self.fbuf(3 * Cout_p)
                 gg, ga = self.pgrads.sink(bn.weight)
                 gb, gba = self.pgrads.sink(bn.bias)
@@ -381,7 +386,7 @@ class Engine:
                 rg, racc = residual.grad_sink()
             call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
                                   _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
-                                  _p(rg), rg.stride(2) if rg is not None else 0, racc, st)
+                                  _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), st)
             # ---- weight gradient
             wd = capi.WgradDesc()
             wd.N, wd.H, wd.W, wd.OH, wd.OW = N, H, W, OH, OW
