@@ -53,6 +53,8 @@ typedef struct pn2_pack_desc {
     int Cin_p, gw_in, gwp_in;
     int Rp, Kp;                         /* packed panel rows / row length */
     int transposed;                     /* 0: [co][tap*Cin_p+ci] (forward, wgrad slabs) ; 1: [ci][tap*Cout_p+co] (dgrad) */
+    int ld, koff;                       /* destination row stride (0 = Kp) and column offset: lets several convs that share an
+                                           input write side by side into ONE panel (fused 1x1 reducers of the RFB / RA stages) */
 } pn2_pack_desc;
 
 int pn2_conv_tile_n(int cout);          /* N tile the forward/dgrad kernel will pick for `cout` */
@@ -75,6 +77,8 @@ typedef struct pn2_bn_desc {
     int Cp;                 /* physical channels of the raw conv output */
     int C, gw, gwp;         /* logical channels and group-padding map of gamma/beta/running stats */
     float eps, momentum;
+    int ldp;                /* row stride of the partial buffers and plane stride of `coef` (0 = Cp): a BN that owns a channel
+                               slice [c0, c0+Cp) of a wider fused conv output passes base pointers offset by c0 and ldp = total */
 } pn2_bn_desc;
 /* batch statistics from the conv epilogue partials -> scale/shift (physical), saved mean/invstd, running-stat update */
 int pn2_bn_finalize(const float* psum, const float* psq, int nblk, const pn2_bn_desc* d, const float* gamma, const float* beta,

@@ -26,9 +26,10 @@ template <typename T, int W> struct VL {   // W == VEC: 16-byte vector ; W == 1:
 // ---------------------------------------------------------------------------------------------
 // reduce [nblk][Cp] partial rows: 8 channels x 32 row-lanes per block, accumulate in double
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void reduce_partials(const float* p1, const float* p2, int nblk, int Cp, int c, int rl, double& s1, double& s2) {
+__device__ __forceinline__ void reduce_partials(const float* p1, const float* p2, int nblk, int Cn, int Cp, int c, int rl, double& s1, double& s2) {
+    // Cn = channels of this BN, Cp = row stride of the partial buffers
     s1 = 0.0; s2 = 0.0;
-    if (c < Cp) {
+    if (c < Cn) {
         int r = rl;
         for (; r + 96 < nblk; r += 128) {        // 4 independent row loads in flight per thread
             const float a0 = p1[(size_t)r * Cp + c], a1 = p1[(size_t)(r + 32) * Cp + c], a2 = p1[(size_t)(r + 64) * Cp + c], a3 = p1[(size_t)(r + 96) * Cp + c];
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
     __shared__ double sh[2][4][8];
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
     double s1, s2;
-    reduce_partials(psum, psq, nblk, d.Cp, c, rl, s1, s2);
+    reduce_partials(psum, psq, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, s1, s2);
     block_reduce_rows(sh, s1, s2);
     if (rl == 0 && c < d.Cp) {
         const int lc = phys2log(c, d.gw, d.gwp, d.C);
@@ -201,16 +202,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
     __shared__ double sh[2][4][8];
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
     double s1, s2;
-    reduce_partials(p1, p2, nblk, d.Cp, c, rl, s1, s2);
+    reduce_partials(p1, p2, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, s1, s2);
+    const int cs = d.ldp ? d.ldp : d.Cp;     // plane stride of coef
     block_reduce_rows(sh, s1, s2);
     if (rl == 0 && c < d.Cp) {
         const int lc = phys2log(c, d.gw, d.gwp, d.C);
-        if (lc < 0) { coef[c] = 0.f; coef[d.Cp + c] = 0.f; coef[2 * d.Cp + c] = 0.f; return; }
+        if (lc < 0) { coef[c] = 0.f; coef[cs + c] = 0.f; coef[2 * cs + c] = 0.f; return; }
         if (accumulate) { dbeta[lc] += (float)s1; dgamma[lc] += (float)s2; }
         else { dbeta[lc] = (float)s1; dgamma[lc] = (float)s2; }
         coef[c] = gamma[lc] * invstd[c];
-        coef[d.Cp + c] = (float)(s1 / d.M);
-        coef[2 * d.Cp + c] = (float)(s2 / d.M);
+        coef[cs + c] = (float)(s1 / d.M);
+        coef[2 * cs + c] = (float)(s2 / d.M);
     }
 }
 

@@ -658,7 +658,7 @@ __global__ void pack_weight(const float* __restrict__ w, T* __restrict__ wp, pn2
             }
             if (co >= 0 && ci >= 0) v = w[((size_t)co * p.Cin + ci) * taps + tap];
         }
-        TT<T>::st(wp + idx, v);
+        TT<T>::st(wp + (size_t)row * (p.ld ? p.ld : p.Kp) + p.koff + k, v);
     }
 }
 
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi(const pn2_pack_job* __r
             else { ci = row < p.Cin_p ? phys2log(row, p.gw_in, p.gwp_in, p.Cin) : -1; co = phys2log(c, p.gw_out, p.gwp_out, p.Cout); }
             if (co >= 0 && ci >= 0) v = w[((size_t)co * p.Cin + ci) * taps + tap];
         }
-        TT<T>::st(wp + idx, v);
+        TT<T>::st(wp + (size_t)row * (p.ld ? p.ld : p.Kp) + p.koff + k, v);
     }
 }
 

@@ -62,19 +62,21 @@ class RFB_modified(nn.Module):
         self.conv_cat = BasicConv2d(4 * out_channel, out_channel, 3, padding=1)
         self.conv_res = BasicConv2d(in_channel, out_channel, 1)
 
-    def _build(self, eng, x):
-        """reference :75-83 — the four branches write straight into the channel slices of the concat buffer,
-        and relu(x_cat + conv_res(x)) is the residual epilogue of conv_cat's BN-apply pass."""
+    def _build(self, eng, x, extra=()):
+        """reference :75-83.  The five Cin->32 1x1 reducers (branch0..3 heads, conv_res) — plus any `extra` 1x1 BasicConv2d
+        that reads the same map (the RA stage's conv1) — run as ONE fused GEMM over x (eng.conv_bn_multi); the branch tails write
+        straight into the channel slices of the concat buffer, and relu(x_cat + conv_res(x)) is the residual epilogue of
+        conv_cat's BN-apply pass.  Returns the RFB output (and the extra outputs, if any)."""
         c = self.conv_cat.conv.out_channels
+        heads = eng.conv_bn_multi(x, [self.branch0[0], self.branch1[0], self.branch2[0], self.branch3[0], self.conv_res] + list(extra))
         cat = eng.new_act(x.N, x.H, x.W, 4 * c)
-        self.branch0[0]._build(eng, x, out=cat.slice(0, c))
+        eng.copy_into(heads[0], cat.slice(0, c))
         for bi, br in enumerate((self.branch1, self.branch2, self.branch3), start=1):
-            t = br[0]._build(eng, x)
-            t = br[1]._build(eng, t)
+            t = br[1]._build(eng, heads[bi])
             t = br[2]._build(eng, t)
             br[3]._build(eng, t, out=cat.slice(bi * c, (bi + 1) * c))
-        res = self.conv_res._build(eng, x)
-        return self.conv_cat._build(eng, cat, relu=True, residual=res)
+        y = self.conv_cat._build(eng, cat, relu=True, residual=heads[4])
+        return (y, heads[5:]) if extra else y
 
     def forward(self, x):
         return run_module(lambda e, a: [self._build(e, a)], [x], list(self.parameters()), self.training)[0]
@@ -124,8 +126,9 @@ class aggregation(nn.Module):
         return run_module(lambda e, a, b, c: self._build(e, a, b, c), [x1, x2, x3], list(self.parameters()), self.training)
 
 
-def _dsra_tail(m, eng, x2, x3, x4, ra5_fg, ra5_bg):
-    """DSRA3/2/1 of reference :349-417 (identical in PVT_PraNet_V2 :205-263); returns the 8 lateral maps."""
+def _dsra_tail(m, eng, t1, ra5_fg, ra5_bg):
+    """DSRA3/2/1 of reference :349-417 (identical in PVT_PraNet_V2 :205-263); returns the 8 lateral maps.
+    t1[s] = ra{s}_conv1(x_s), already computed inside the fused reducer GEMM of the matching RFB."""
     sd = m.sem_downsample
     up = lambda a, s: eng.bilinear(a, s)
 
@@ -135,7 +138,7 @@ def _dsra_tail(m, eng, x2, x3, x4, ra5_fg, ra5_bg):
     l5_fg, l5_bg = final(ra5_fg, 8 / sd, 3), final(ra5_bg, 8 / sd, 7)
     # ---- DSRA3
     c_fg, c_bg = up(ra5_fg, 0.25), up(ra5_bg, 0.25)
-    t = m.ra4_conv1._build(eng, x4)
+    t = t1[4]
     t = m.ra4_conv2._build(eng, t, relu=True)
     t = m.ra4_conv3._build(eng, t, relu=True)
     t = m.ra4_conv4._build(eng, t, relu=True)
@@ -144,9 +147,9 @@ def _dsra_tail(m, eng, x2, x3, x4, ra5_fg, ra5_bg):
     f = eng.dsra_fuse(f, c_fg, c_bg, m.use_softmax)
     l4_fg, l4_bg = final(f, 32 / sd, 2), final(b, 32 / sd, 6)
     lat = {}
-    for s, xs, u in ((3, x3, 16), (2, x2, 8)):
+    for s, u in ((3, 16), (2, 8)):
         c_fg, c_bg = up(f, 2), up(b, 2)
-        t = getattr(m, f"ra{s}_conv1")._build(eng, xs)
+        t = t1[s]
         t = getattr(m, f"ra{s}_conv2")._build(eng, t, relu=True)
         t = getattr(m, f"ra{s}_conv3")._build(eng, t, relu=True)
         f = getattr(m, f"ra{s}_conv4_fg")._build(eng, t, head=True)
@@ -194,11 +197,11 @@ class PraNet_V2(nn.Module):
 
     def _build(self, eng, x):
         x1, x2, x3, x4 = self.backbone._build_features(eng, x)
-        x2_rfb = self.rfb2_1._build(eng, x2)
-        x3_rfb = self.rfb3_1._build(eng, x3)
-        x4_rfb = self.rfb4_1._build(eng, x4)
+        x2_rfb, (t2,) = self.rfb2_1._build(eng, x2, extra=[self.ra2_conv1])
+        x3_rfb, (t3,) = self.rfb3_1._build(eng, x3, extra=[self.ra3_conv1])
+        x4_rfb, (t4,) = self.rfb4_1._build(eng, x4, extra=[self.ra4_conv1])
         ra5_fg, ra5_bg = self.agg1._build(eng, x4_rfb, x3_rfb, x2_rfb)
-        return _dsra_tail(self, eng, x2, x3, x4, ra5_fg, ra5_bg)
+        return _dsra_tail(self, eng, {2: t2, 3: t3, 4: t4}, ra5_fg, ra5_bg)
 
     def forward(self, x, segSize=None):
         return run_module(self._build, [x], self.hot_parameters(), self.training)

@@ -26,7 +26,7 @@ class WgradDesc(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("Cout", "Cin", "KH", "KW", "Cout_p", "gw_out", "gwp_out", "Cin_p", "gw_in", "gwp_in",
-                                       "Rp", "Kp", "transposed")]
+                                       "Rp", "Kp", "transposed", "ld", "koff")]
 
 
 class PackJob(C.Structure):
@@ -35,7 +35,7 @@ class PackJob(C.Structure):
 
 class BnDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("Cp", C.c_int), ("C", C.c_int), ("gw", C.c_int), ("gwp", C.c_int),
-                ("eps", C.c_float), ("momentum", C.c_float)]
+                ("eps", C.c_float), ("momentum", C.c_float), ("ldp", C.c_int)]
 
 
 P, I, LL, FL = C.c_void_p, C.c_int, C.c_longlong, C.c_float

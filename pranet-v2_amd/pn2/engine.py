@@ -423,6 +423,133 @@ class Engine:
         self.record(bwd)
         return out
 
+    # ------------------------------------------------------------------ fused 1x1 reducers sharing one input
+    def conv_bn_multi(self, x, mods):
+        """[BN_j(conv_j(x)) for j] for bias-free 1x1 / stride-1 BasicConv2d-style modules `mods` (each has .conv, .bn; no ReLU).
+
+        The RFB branches, conv_res and the RA stage's conv1 all read the same encoder map (pranet.py:52,55,61,67,73,303,312,320):
+        their weights are packed side by side into ONE panel so the map is read once in forward, dx is written once in dgrad
+        (instead of J read-modify-write passes) and wgrad reads it once.  BatchNorm stays per module (own gamma/beta/running stats).
+        Returns the channel-slice views of the fused [M][sum Cout] output."""
+        convs = [m.conv for m in mods]
+        for c in convs:
+            assert c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0) and c.bias is None and c.in_channels == x.C
+        couts = [c.out_channels for c in convs]
+        assert all(co % 8 == 0 for co in couts)
+        offs = [sum(couts[:j]) for j in range(len(couts))]
+        Ct = sum(couts)
+        N, H, W = x.N, x.H, x.W
+        M = N * H * W
+        st = _stream()
+        train = self.training
+        x_map = (x.gw, x.gwp, x.Cp)
+        Kp = rup(x.Cp, 128)
+        Rp = rup(Ct, 128)
+        Rt, Kt = rup(x.Cp, 128), rup(Ct, 128)          # transposed (dgrad) panel
+
+        def panel(transposed):
+            cache = self.pack_cache
+            key = ("multi", tuple(id(c.weight) for c in convs), transposed, x_map, self.dt)
+            if cache is not None and key in cache.entries:
+                return cache.entries[key][0]
+            wp = torch.zeros((Rt, Kt) if transposed else (Rp, Kp), dtype=self.tdt, device=self.dev)
+            for c, co, off in zip(convs, couts, offs):
+                d = self._pack_desc(c.weight, x_map, (co, co, co), transposed)
+                if transposed:
+                    d.Rp, d.Kp, d.ld, d.koff = Rt, co, Kt, off          # columns [off, off+co) of every row
+                    dst = wp
+                else:
+                    d.Rp, d.Kp = co, Kp                                  # rows [off, off+co)
+                    dst = wp[off:]
+                call.pn2_pack_weight(self.dt, _p(c.weight), _p(dst), C.byref(d), st)
+                if cache is not None:
+                    cache.add(key + (off,), c.weight, dst, d)
+            if cache is not None:
+                cache.entries[key] = (wp, None)
+            return wp
+
+        wp = panel(False)
+        raw = self.empty(N, H, W, Ct)
+        cd = capi.ConvDesc()
+        cd.N, cd.H, cd.W, cd.OH, cd.OW = N, H, W, H, W
+        cd.Cin_p, cd.ld_in, cd.Cout, cd.ld_out = x.Cp, x.ld, Ct, Ct
+        cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = 1, 1, 1, 0, 0, 1, 1
+        cd.transposed, cd.Kp, cd.flags = 0, Kp, (capi.CONV_STATS if train else 0)
+        psum = psq = None
+        if train:
+            nblk = call.pn2_conv_stat_blocks(M, Ct, self.dt)
+            psum, psq = self.fbuf(nblk, Ct), self.fbuf(nblk, Ct)
+        flops = 2 * M * Ct * x.C
+        shape = f"{x.C}->{'+'.join(map(str, couts))} k1x1 s1 d1 {N}x{H}x{W}"
+        capi.WORK.update(flops=flops, tag=":fwd", shape=shape)
+        call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), st)
+        scale, shift = self.fbuf(Ct), self.fbuf(Ct)
+        mean, invstd = (self.fbuf(Ct), self.fbuf(Ct)) if train else (None, None)
+        bds = []
+        for m, co, off in zip(mods, couts, offs):
+            bn = m.bn
+            bd = capi.BnDesc()
+            bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum, bd.ldp = M, co, co, co, co, bn.eps, (bn.momentum if bn.momentum is not None else 0.1), Ct
+            bds.append(bd)
+            if train:
+                call.pn2_bn_finalize(_p(psum[:, off:]), _p(psq[:, off:]), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+                                     _p(scale[off:]), _p(shift[off:]), _p(mean[off:]), _p(invstd[off:]), st)
+                self.bn_modules.append(bn)
+            else:
+                call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(scale[off:]), _p(shift[off:]), st)
+        out = Act(self, self.empty(N, H, W, Ct), Ct, Ct, Ct, self.dt)
+        call.pn2_affine_act(self.dt, _p(raw), Ct, self.dt, out.ptr, out.ld, M, Ct, _p(scale), _p(shift), C.c_void_p(0), 0, 0, st)
+        outs = [out.slice(off, off + co) for co, off in zip(couts, offs)]
+        if not self.need_grad:
+            return outs
+
+        def bwd():
+            st = _stream()
+            if not train:
+                raise RuntimeError("backward through eval-mode BatchNorm is not supported")
+            dy = out.grad_buf()
+            assert out.grad_written or out.child_written
+            nb = call.pn2_bn_bwd_blocks(M, Ct, self.dt)
+            p1, p2 = self.fbuf(nb, Ct), self.fbuf(nb, Ct)
+            nul = C.c_void_p(0)
+            call.pn2_bn_bwd_reduce(self.dt, self.dt, _p(dy), Ct, Ct, nul, 0, self.dt, _p(raw), Ct, M, Ct, _p(mean), _p(invstd), _p(p1), _p(p2), nb, nul, nul, st)
+            coef = self.fbuf(3 * Ct)
+            for m, bd, off in zip(mods, bds, offs):
+                gg, ga = self.pgrads.sink(m.bn.weight)
+                gb, gba = self.pgrads.sink(m.bn.bias)
+                call.pn2_bn_bwd_finalize(_p(p1[:, off:]), _p(p2[:, off:]), nb, C.byref(bd), _p(m.bn.weight), _p(invstd[off:]), _p(gg), _p(gb), ga, _p(coef[off:]), st)
+            draw = self.empty(N, H, W, Ct)
+            call.pn2_bn_bwd_apply(self.dt, self.dt, _p(dy), Ct, Ct, nul, 0, self.dt, _p(raw), Ct, M, Ct, _p(mean), _p(invstd), _p(coef), _p(draw), Ct, nul, 0, 0, nul, nul, st)
+            wd = capi.WgradDesc()
+            wd.N, wd.H, wd.W, wd.OH, wd.OW = N, H, W, H, W
+            wd.Cin_p, wd.ld_x, wd.Cout_p, wd.ld_dy = x.Cp, x.ld, Ct, Ct
+            wd.KH, wd.KW, wd.stride, wd.pad_h, wd.pad_w, wd.dil_h, wd.dil_w = 1, 1, 1, 0, 0, 1, 1
+            tco = call.pn2_wgrad_tile_co(Ct)
+            wd.Rp, wd.Kp = rup(Ct, tco), Kp
+            tiles = (wd.Rp // tco) * (Kp // 128)
+            steps = (M + 31) // 32
+            nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (640 + tiles - 1) // tiles, (24 << 20) // (wd.Rp * wd.Kp * 4) or 1))
+            slab = self.fbuf(nsplit, wd.Rp, wd.Kp)
+            capi.WORK.update(flops=flops, tag="", shape=shape)
+            call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
+            for c, co, off in zip(convs, couts, offs):
+                gwt, gwa = self.pgrads.sink(c.weight)
+                rd = self._pack_desc(c.weight, x_map, (co, co, co), False)
+                rd.Rp, rd.Kp = wd.Rp, Kp
+                call.pn2_wgrad_reduce(_p(slab[:, off:]), _p(gwt), C.byref(rd), nsplit, gwa, st)
+            if x.requires_grad:
+                wt = panel(True)
+                gx, gxa = x.grad_sink()
+                dd = capi.ConvDesc()
+                dd.N, dd.H, dd.W, dd.OH, dd.OW = N, H, W, H, W
+                dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Ct, Ct, x.Cp, gx.stride(2)
+                dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = 1, 1, 1, 0, 0, 1, 1
+                dd.transposed, dd.Kp, dd.flags = 1, Kt, (capi.CONV_ACCUM if gxa else 0)
+                capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
+                call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), nul, nul, C.byref(dd), st)
+        self.record(bwd)
+        return outs
+
     # ------------------------------------------------------------------ pooling
     def maxpool3x3s2(self, x):
         N, H, W = x.N, x.H, x.W
