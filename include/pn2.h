@@ -36,7 +36,7 @@ typedef struct pn2_conv_desc {
     int KH, KW, stride, pad_h, pad_w, dil_h, dil_w;   /* of the FORWARD convolution */
     int transposed;         /* 0 forward gather, 1 dgrad gather */
     int Kp;                 /* packed-weight row length, multiple of 128 */
-    int flags;              /* PN2_CONV_* */
+    int flags;              /* PN2_CONV_* ; bits 8..15 optional tuning code (bf16): kernel | BM<<2 | BN<<4, see pn2_conv_tile_m */
 } pn2_conv_desc;
 
 typedef struct pn2_wgrad_desc {
@@ -45,6 +45,7 @@ typedef struct pn2_wgrad_desc {
     int Cout_p, ld_dy;      /* dy physical channels / stride */
     int KH, KW, stride, pad_h, pad_w, dil_h, dil_w;
     int Rp, Kp;             /* slab rows (multiple of the co tile, normally 128) and row length (multiple of 128) */
+    int tune;               /* 0 heuristic, 1 register-staged kernel, 2 LDS-DMA kernel (bf16) */
 } pn2_wgrad_desc;
 
 typedef struct pn2_pack_desc {

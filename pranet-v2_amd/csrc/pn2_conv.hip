@@ -493,7 +493,7 @@ template <> struct WG<float> {
 };
 
 template <typename T, int BMC, int BNK, int WM, int WN, bool PW>
-__global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ slab, pn2_wgrad_desc d) {
+__global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ slab, pn2_wgrad_desc d, int nsplit) {
     constexpr int VEC = TT<T>::VEC;
     constexpr int WTM = BMC / WM, WTN = BNK / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int RSY = BMC * (int)sizeof(T) + WG<T>::PAD, RSX = BNK * (int)sizeof(T) + WG<T>::PAD;
@@ -508,11 +508,17 @@ __global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, cons
     const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
     const int M = d.N * d.OH * d.OW;
     const int tk = d.Kp / BNK;
-    const int bco = blockIdx.x / tk, bk = blockIdx.x % tk;
+    // XCD-aware mapping (block b runs on XCD b%8): every (co,k) tile of one pixel split goes to the SAME XCD, back to back, so the
+    // dy / x slice of that split is fetched into one L2 once instead of once per XCD (PMC showed ~4x over-fetch otherwise).
+    const int ntile = (d.Rp / BMC) * tk;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jx / ntile), tile = jx % ntile;
+    if (split >= nsplit) return;
+    const int bco = tile / tk, bk = tile % tk;
     const int co0 = bco * BMC, k0 = bk * BNK;
     const int total_steps = (M + WGP - 1) / WGP;
-    const int spb = (total_steps + gridDim.y - 1) / gridDim.y;
-    const int s_begin = blockIdx.y * spb;
+    const int spb = (total_steps + nsplit - 1) / nsplit;
+    const int s_begin = split * spb;
     int s_end = s_begin + spb; if (s_end > total_steps) s_end = total_steps;
     const int taps = d.KH * d.KW;
 
@@ -624,7 +630,157 @@ __global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, cons
             __syncthreads();
         }
     }
-    float* dst = slab + ((size_t)blockIdx.y * d.Rp + co0) * d.Kp + k0;
+    float* dst = slab + ((size_t)split * d.Rp + co0) * d.Kp + k0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[(size_t)(wm * WTM + i * 16 + g * 4 + r) * d.Kp + wn * WTN + j * 16 + l15] = acc[i][j][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient, LDS-DMA pipeline (bf16): 64 pixels per step, 3-deep ring, both operands by global_load_lds.
+// LDS image is chunk-linear [pixel][channel] (no padding); the 16-byte chunk index is XOR-ed with ((pixel&7)<<1) on the
+// SOURCE side and in the ds_read_b64_tr_b16 addresses, which spreads the 8 pixel rows touched by one transpose-read
+// over all 64 banks.  Same k-slot <-> pixel permutation for both operands as conv_wgrad.
+// ------------------------------------------------------------------------------------------------
+template <int BMC, int WM, int WN, bool PW>
+__global__ __launch_bounds__(256) void conv_wgrad_dma(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ slab,
+                                                      pn2_wgrad_desc d, int nsplit) {
+    constexpr int BNK = 128, PX = 64, NS = 3;
+    constexpr int WTM = BMC / WM, WTN = BNK / WN, MT = WTM / 16, NT = WTN / 16;
+    constexpr int RBY = BMC * 2, RBX = BNK * 2;              // row bytes
+    constexpr int CHY = BMC / 8, CHX = BNK / 8;              // 16-byte chunks per row
+    constexpr int NYI = PX * CHY / 256, NXI = PX * CHX / 256, LPS = NYI + NXI;
+    constexpr int KMY = CHY / 2 - 1 < 7 ? CHY / 2 - 1 : 7, KMX = 7;
+    constexpr int STAGE = PX * (RBY + RBX);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
+    const int M = d.N * d.OH * d.OW;
+    const int tk = d.Kp / BNK;
+    const int ntile = (d.Rp / BMC) * tk;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jx / ntile), tile = jx % ntile;
+    if (split >= nsplit) return;
+    const int bco = tile / tk, bk = tile % tk;
+    const int co0 = bco * BMC, k0 = bk * BNK;
+    const int total_steps = (M + PX - 1) / PX;
+    const int spb = (total_steps + nsplit - 1) / nsplit;
+    const int s_begin = split * spb;
+    int s_end = s_begin + spb; if (s_end > total_steps) s_end = total_steps;
+    const int nsteps = s_end > s_begin ? s_end - s_begin : 0;
+    const int taps = d.KH * d.KW;
+    const char* zsrc = reinterpret_cast<const char*>(pn2_zero16);
+
+    // ---- DMA lanes.  dy: row (tid / CHY) of each group of 256/CHY rows, LDS slot tid % CHY holding global chunk gy
+    const int yrow = tid / CHY, gy = (tid % CHY) ^ ((yrow & KMY) << 1);
+    const bool yc_ok = co0 + gy * 8 < d.Cout_p;
+    const bf16_t* ysrc = dy + co0 + gy * 8;
+    const int xrow = tid / CHX, gx = (tid % CHX) ^ ((xrow & KMX) << 1);
+    const int kk = k0 + gx * 8;
+    int xtap = 0, xci = kk;
+    if (!PW) { xtap = kk / d.Cin_p; xci = kk - xtap * d.Cin_p; }
+    const bool xk_ok = PW ? (kk < d.Cin_p) : (xtap < taps);
+    const int xr = PW ? 0 : xtap / d.KW, xs = PW ? 0 : xtap - (xtap / d.KW) * d.KW;
+    int pn[NXI], poy[NXI], pox[NXI];
+    if (!PW) {
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            int m = s_begin * PX + xrow + i * (256 / CHX);
+            if (m >= M) m = M - 1;
+            const int hw = d.OH * d.OW;
+            const int n = m / hw, rem = m - n * hw;
+            pn[i] = n; poy[i] = rem / d.OW; pox[i] = rem - poy[i] * d.OW;
+        }
+    }
+    const int wch = __builtin_amdgcn_readfirstlane(wid * 64);      // this wave's first chunk inside a 256-chunk DMA instruction
+
+#define PN2_WISSUE(step_, buf_)                                                                                        \
+    do {                                                                                                               \
+        char* sb_ = smem + (buf_) * STAGE;                                                                             \
+        const int mb_ = (step_) * PX;                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NYI; ++i) {                                                              \
+            const int m_ = mb_ + yrow + i * (256 / CHY);                                                               \
+            const char* s_ = (yc_ok && m_ < M) ? reinterpret_cast<const char*>(ysrc + (size_t)m_ * d.ld_dy) : zsrc;    \
+            __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 256 + wch) * 16), 16, 0, 0);              \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                              \
+            const int m_ = mb_ + xrow + i * (256 / CHX);                                                               \
+            const char* s_ = zsrc;                                                                                     \
+            if (PW) {                                                                                                  \
+                if (xk_ok && m_ < M) s_ = reinterpret_cast<const char*>(x + (size_t)m_ * d.ld_x + kk);                 \
+            } else {                                                                                                   \
+                const int iy_ = poy[i] * d.stride - d.pad_h + xr * d.dil_h, ix_ = pox[i] * d.stride - d.pad_w + xs * d.dil_w; \
+                if (xk_ok && m_ < M && (unsigned)iy_ < (unsigned)d.H && (unsigned)ix_ < (unsigned)d.W)                 \
+                    s_ = reinterpret_cast<const char*>(x + ((size_t)(pn[i] * d.H + iy_) * d.W + ix_) * d.ld_x + xci);  \
+                pox[i] += PX;                                                                                          \
+                while (pox[i] >= d.OW) { pox[i] -= d.OW; ++poy[i]; }                                                   \
+                while (poy[i] >= d.OH) { poy[i] -= d.OH; ++pn[i]; }                                                    \
+            }                                                                                                          \
+            __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + PX * RBY + (i * 256 + wch) * 16), 16, 0, 0);   \
+        }                                                                                                              \
+    } while (0)
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing (per lane): pixel row g*4 + (l15>>2) (+16, +32*ks), 8 bytes at channel (l15&3)*4 of a 16-channel block
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const int prow = g * 4 + (l15 >> 2);
+    const int keyy = (prow & KMY) << 1, keyx = (prow & KMX) << 1;
+    unsigned offA[MT], offB[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) offA[i] = prow * RBY + ((((wm * WTM) >> 3) + i * 2 + ((l15 & 3) >> 1)) ^ keyy) * 16 + (l15 & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) offB[j] = PX * RBY + prow * RBX + ((((wn * WTN) >> 3) + j * 2 + ((l15 & 3) >> 1)) ^ keyx) * 16 + (l15 & 1) * 8;
+
+    if (nsteps > 0) {
+        PN2_WISSUE(s_begin, 0);
+        if (nsteps > 1) PN2_WISSUE(s_begin + 1, 1);
+        for (int t = 0; t < nsteps; ++t) {
+            if (t + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 2 < nsteps) {
+                const int nb_ = (t + 2) % NS;
+                PN2_WISSUE(s_begin + t + 2, nb_);
+            }
+            const unsigned sb = lds0 + (t % NS) * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x2_t a0[MT], a1[MT], b0[NT], b1[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0[i]) : "v"(sb + offA[i] + ks * 32 * RBY));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a1[i]) : "v"(sb + offA[i] + (ks * 32 + 16) * RBY));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0[j]) : "v"(sb + offB[j] + ks * 32 * RBX));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1[j]) : "v"(sb + offB[j] + (ks * 32 + 16) * RBX));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        MMA<bf16_t>::run(acc[i][j], make_uint4(a0[i].x, a0[i].y, a1[i].x, a1[i].y), make_uint4(b0[j].x, b0[j].y, b1[j].x, b1[j].y));
+            }
+        }
+    }
+#undef PN2_WISSUE
+    float* dst = slab + ((size_t)split * d.Rp + co0) * d.Kp + k0;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -783,10 +939,10 @@ template <typename T, int BMC, int WM, int WN>
 int launch_wgrad(const void* dy, const void* x, float* slab, const pn2_wgrad_desc& d, int nsplit, hipStream_t st) {
     constexpr int BNK = 128;
     constexpr int lds = 2 * WGP * (BMC * (int)sizeof(T) + WG<T>::PAD + BNK * (int)sizeof(T) + WG<T>::PAD);
-    dim3 grid((d.Rp / BMC) * (d.Kp / BNK), nsplit);
+    dim3 grid(8 * ((nsplit + 7) / 8) * (d.Rp / BMC) * (d.Kp / BNK));
     const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
-    if (pw) hipLaunchKernelGGL((conv_wgrad<T, BMC, BNK, WM, WN, true>), grid, dim3(256), lds, st, (const T*)dy, (const T*)x, slab, d);
-    else hipLaunchKernelGGL((conv_wgrad<T, BMC, BNK, WM, WN, false>), grid, dim3(256), lds, st, (const T*)dy, (const T*)x, slab, d);
+    if (pw) hipLaunchKernelGGL((conv_wgrad<T, BMC, BNK, WM, WN, true>), grid, dim3(256), lds, st, (const T*)dy, (const T*)x, slab, d, nsplit);
+    else hipLaunchKernelGGL((conv_wgrad<T, BMC, BNK, WM, WN, false>), grid, dim3(256), lds, st, (const T*)dy, (const T*)x, slab, d, nsplit);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -795,8 +951,13 @@ template <typename T>
 int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, hipStream_t st) {
     int bm, bn;
     pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
+    // optional per-shape tuning code in flags bits 8..15 (bf16 only): kernel (1 register-staged, 2 LDS-DMA), BM, BN
+    const int tune = sizeof(T) == 2 ? (d.flags >> 8) & 0xff : 0;
+    const int tk_ = tune & 3, tbm = (tune >> 2) & 3, tbn = (tune >> 4) & 3;
+    if (tbm) bm = tbm == 1 ? 64 : 128;
+    if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
     if constexpr (sizeof(T) == 2) {
-        if (use_dma_kernel()) {
+        if (tk_ ? tk_ == 2 : use_dma_kernel()) {
             if (bm == 128) {
                 if (bn == 128) return launch_dma<128, 128, 2, 2>(in, wp, out, psum, psq, d, st);
                 if (bn == 64) return launch_dma<128, 64, 2, 2>(in, wp, out, psum, psq, d, st);
@@ -821,10 +982,43 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
     return launch_gemm<T, 64, 32, 4, 1>(in, wp, out, psum, psq, d, st);
 }
 
+template <int BMC, int WM, int WN>
+int launch_wgrad_dma(const void* dy, const void* x, float* slab, const pn2_wgrad_desc& d, int nsplit, hipStream_t st) {
+    constexpr int stage_b = 64 * (BMC * 2 + 256), max_b = 3 * stage_b;
+    const int M = d.N * d.OH * d.OW;
+    const int total_steps = (M + 63) / 64, spb = (total_steps + nsplit - 1) / nsplit;
+    const int lds = (spb < 3 ? (spb < 1 ? 1 : spb) : 3) * stage_b;
+    const int grid = 8 * ((nsplit + 7) / 8) * (d.Rp / BMC) * (d.Kp / 128);
+    const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
+    if (max_b > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma<BMC, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma<BMC, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            done = true;
+        }
+    }
+    if (pw) hipLaunchKernelGGL((conv_wgrad_dma<BMC, WM, WN, true>), dim3(grid), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, slab, d, nsplit);
+    else hipLaunchKernelGGL((conv_wgrad_dma<BMC, WM, WN, false>), dim3(grid), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, slab, d, nsplit);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 int wgrad_dispatch(const void* dy, const void* x, float* slab, const pn2_wgrad_desc& d, int nsplit, hipStream_t st) {
     const int bmc = pn2_wgrad_tile_co(d.Cout_p);
     if (d.Rp % bmc || d.Kp % 128) return -2;
+    if constexpr (sizeof(T) == 2) {
+        static const bool on = [] { const char* e = getenv("PN2_WGRAD_DMA"); return !(e && e[0] == '0'); }();
+        // default: the DMA pipeline pays off for pointwise convs with many pixels; d.tune (1 register-staged, 2 DMA) overrides
+        const bool pw_ = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
+        const bool dma = d.tune ? d.tune == 2 : (on && pw_ && d.N * d.OH * d.OW >= 8192);
+        if (dma) {
+            if (bmc == 128) return launch_wgrad_dma<128, 2, 2>(dy, x, slab, d, nsplit, st);
+            if (bmc == 64) return launch_wgrad_dma<64, 2, 2>(dy, x, slab, d, nsplit, st);
+            return launch_wgrad_dma<32, 1, 4>(dy, x, slab, d, nsplit, st);
+        }
+    }
     if (bmc == 128) return launch_wgrad<T, 128, 2, 2>(dy, x, slab, d, nsplit, st);
     if (bmc == 64) return launch_wgrad<T, 64, 2, 2>(dy, x, slab, d, nsplit, st);
     return launch_wgrad<T, 32, 1, 4>(dy, x, slab, d, nsplit, st);

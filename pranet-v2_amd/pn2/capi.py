@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
 
 class WgradDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "OH", "OW", "Cin_p", "ld_x", "Cout_p", "ld_dy", "KH", "KW", "stride",
-                                       "pad_h", "pad_w", "dil_h", "dil_w", "Rp", "Kp")]
+                                       "pad_h", "pad_w", "dil_h", "dil_w", "Rp", "Kp", "tune")]
 
 
 class PackDesc(C.Structure):

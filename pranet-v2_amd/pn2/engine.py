@@ -19,6 +19,7 @@ from . import capi
 from .capi import call, F32, BF16
 
 TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+TUNER = {}      # process-wide conv shape -> tuned kernel/tile code (see Engine._tune_gemm)
 
 
 def rup(v, m):
@@ -139,8 +140,9 @@ class PackCache:
 
 
 class Engine:
-    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None):
+    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None):
         self.pack_cache = pack_cache
+        self.tuner = tuner              # dict shared across steps: conv shape -> tuned kernel/tile code (bf16 only)
         if not torch.cuda.is_available():
             raise RuntimeError("pranet-v2_amd runs on MI355X only: no GPU visible and there is no CPU fallback")
         capi.load()
@@ -277,6 +279,81 @@ class Engine:
             cache.add(key, w, wp, d)
         return wp, d
 
+    # ------------------------------------------------------------------ per-shape kernel / tile selection
+    def _tune_gemm(self, cd, in_ptr, wp, M, Cout):
+        """Pick (kernel, BM, BN) for this forward/dgrad shape by timing every candidate once (first eager step; results are cached in
+        self.tuner and reused under hipGraph capture).  Returns the code for pn2_conv_desc.flags bits 8..15 (0 = library heuristic)."""
+        t = self.tuner
+        if t is None or self.dt != BF16:
+            return 0
+        key = ("g", cd.N, cd.H, cd.W, cd.OH, cd.OW, cd.Cin_p, cd.ld_in, Cout, cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w, cd.transposed)
+        if key in t:
+            return t[key]
+        if torch.cuda.is_current_stream_capturing():
+            return 0
+        st = _stream()
+        scratch = torch.empty((M, Cout), dtype=torch.bfloat16, device=self.dev)
+        d2 = capi.ConvDesc()
+        C.memmove(C.byref(d2), C.byref(cd), C.sizeof(capi.ConvDesc))
+        d2.ld_out, d2.Cout = Cout, Cout
+        cands = []
+        for kern in (1, 2):
+            for bm in (1, 2):
+                if bm == 2 and M <= 64:
+                    continue
+                for bn in (1, 2, 3):
+                    if (bn == 2 and Cout <= 32) or (bn == 3 and Cout <= 64):
+                        continue
+                    cands.append(kern | (bm << 2) | (bn << 4))
+        evs = []
+        nul = C.c_void_p(0)
+        for code in cands:
+            d2.flags = code << 8
+            call.pn2_conv_gemm(self.dt, in_ptr, _p(wp), _p(scratch), nul, nul, C.byref(d2), st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                call.pn2_conv_gemm(self.dt, in_ptr, _p(wp), _p(scratch), nul, nul, C.byref(d2), st)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        times = [a.elapsed_time(b) for a, b in evs]
+        best = cands[min(range(len(cands)), key=lambda i: times[i])]
+        t[key] = best
+        return best
+
+    def _stat_blocks(self, M, Cout, tune):
+        bm = (tune >> 2) & 3
+        if bm:
+            b = 64 if bm == 1 else 128
+            return (M + b - 1) // b
+        return call.pn2_conv_stat_blocks(M, Cout, self.dt)
+
+    def _tune_wgrad(self, wd, dy_ptr, x_ptr, slab, nsplit):
+        t = self.tuner
+        if t is None or self.dt != BF16:
+            return 0
+        key = ("w", wd.N, wd.H, wd.W, wd.OH, wd.OW, wd.Cin_p, wd.ld_x, wd.Cout_p, wd.ld_dy, wd.KH, wd.KW, wd.stride, wd.pad_h, wd.pad_w, wd.dil_h, wd.dil_w, nsplit)
+        if key in t:
+            return t[key]
+        if torch.cuda.is_current_stream_capturing():
+            return 0
+        st = _stream()
+        evs = []
+        for code in (1, 2):
+            wd.tune = code
+            call.pn2_conv_wgrad(self.dt, dy_ptr, x_ptr, _p(slab), C.byref(wd), nsplit, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                call.pn2_conv_wgrad(self.dt, dy_ptr, x_ptr, _p(slab), C.byref(wd), nsplit, st)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        best = 1 if evs[0][0].elapsed_time(evs[0][1]) <= evs[1][0].elapsed_time(evs[1][1]) else 2
+        t[key] = best
+        return best
+
     # ------------------------------------------------------------------ conv (+BN +ReLU +residual)
     def conv_bn_act(self, x, conv, bn=None, relu=False, residual=None, out=None, out_map=None, y_dt=None, y_C=None, bias=None):
         """y = act(BN(conv(x)) + residual)   — BasicConv2d / Bottle2neck pieces.
@@ -312,8 +389,10 @@ class Engine:
         cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = KH, KW, sh, ph, pw, dh, dw
         cd.transposed, cd.Kp, cd.flags = 0, pd.Kp, (capi.CONV_STATS if train_bn else 0)
         psum = psq = None
+        tune = self._tune_gemm(cd, x.ptr, wp, M, Cout_p)
+        cd.flags |= tune << 8
         if train_bn:
-            nblk = call.pn2_conv_stat_blocks(M, Cout_p, self.dt)
+            nblk = self._stat_blocks(M, Cout_p, tune)
             psum, psq = self.fbuf(nblk, Cout_p), self.fbuf(nblk, Cout_p)
         flops = 2 * M * Cout * Cin * KH * KW
         shape = f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}"
@@ -405,6 +484,7 @@ class Engine:
             # wgrad (+ slab reduce) only feeds the parameter gradient: run it on the side stream so that it overlaps the dgrad /
             # BN-backward chain of the layers below instead of sitting on the critical path
             with self.on_side((draw, slab)) as sst:
+                wd.tune = self._tune_wgrad(wd, _p(draw), x.ptr, slab, nsplit)
                 capi.WORK.update(flops=flops, tag="", shape=shape)
                 call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, sst)
                 call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, sst)
@@ -417,6 +497,7 @@ class Engine:
                 dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Cout_p, Cout_p, x.Cp, gx.stride(2)
                 dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = KH, KW, sh, ph, pw, dh, dw
                 dd.transposed, dd.Kp, dd.flags = 1, ptd.Kp, (capi.CONV_ACCUM if gxa else 0)
+                dd.flags |= self._tune_gemm(dd, _p(draw), wt, N * H * W, x.Cp) << 8
                 capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
                 call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
 
@@ -476,8 +557,10 @@ class Engine:
         cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = 1, 1, 1, 0, 0, 1, 1
         cd.transposed, cd.Kp, cd.flags = 0, Kp, (capi.CONV_STATS if train else 0)
         psum = psq = None
+        tune = self._tune_gemm(cd, x.ptr, wp, M, Ct)
+        cd.flags |= tune << 8
         if train:
-            nblk = call.pn2_conv_stat_blocks(M, Ct, self.dt)
+            nblk = self._stat_blocks(M, Ct, tune)
             psum, psq = self.fbuf(nblk, Ct), self.fbuf(nblk, Ct)
         flops = 2 * M * Ct * x.C
         shape = f"{x.C}->{'+'.join(map(str, couts))} k1x1 s1 d1 {N}x{H}x{W}"
@@ -530,6 +613,7 @@ class Engine:
             steps = (M + 31) // 32
             nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (640 + tiles - 1) // tiles, (24 << 20) // (wd.Rp * wd.Kp * 4) or 1))
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp)
+            wd.tune = self._tune_wgrad(wd, _p(draw), x.ptr, slab, nsplit)
             capi.WORK.update(flops=flops, tag="", shape=shape)
             call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
             for c, co, off in zip(convs, couts, offs):
@@ -545,6 +629,7 @@ class Engine:
                 dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Ct, Ct, x.Cp, gx.stride(2)
                 dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = 1, 1, 1, 0, 0, 1, 1
                 dd.transposed, dd.Kp, dd.flags = 1, Kt, (capi.CONV_ACCUM if gxa else 0)
+                dd.flags |= self._tune_gemm(dd, _p(draw), wt, M, x.Cp) << 8
                 capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
                 call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), nul, nul, C.byref(dd), st)
         self.record(bwd)

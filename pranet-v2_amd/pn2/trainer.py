@@ -8,11 +8,12 @@ collective overlaps the remaining backward kernels; the 1/world scaling is folde
 BatchNorm statistics stay per replica, exactly as nn.DataParallel + nn.BatchNorm2d would do in the reference.
 """
 import ctypes as C
+import os
 
 import torch
 
 from .capi import call, F32
-from .engine import Engine, Act, PackCache, _p, _stream
+from .engine import Engine, Act, PackCache, TUNER, _p, _stream
 from .graph import get_compute_dtype
 from .dp import GradBuckets
 from . import loss as L
@@ -56,6 +57,9 @@ class Trainer:
         self.graph = None
         self.last_outs = None
         self.pack_cache = PackCache()
+        # per-shape conv kernel/tile choices, filled by timing the candidates during the first (eager) step; the table is
+        # per process (= per GPU) so every trainer in the process launches identical kernels (bit-reproducible runs)
+        self.tuner = TUNER if os.environ.get("PN2_AUTOTUNE", "1") == "1" else None
 
     # ------------------------------------------------------------------ pieces
     def _grad_view(self, p):
@@ -65,7 +69,7 @@ class Trainer:
     def forward_backward(self, images, gts, reduce_hook=True):
         """forward + loss + backward; returns loss[5] = (l2, l3, l4, l5 pair losses, total) on device."""
         self.pack_cache.refresh()
-        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache)
+        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner)
         x = eng.from_nchw(images)
         outs = self.model._build(eng, x)
         eng.finish_forward()
