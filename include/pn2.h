@@ -68,7 +68,15 @@ int pn2_pack_weight(int dtype, const float* w_oihw, void* wp, const pn2_pack_des
 int pn2_wgrad_reduce(const float* slab, float* gw_oihw, const pn2_pack_desc* p, int nsplit, int accumulate, void* stream);
 /* one launch that repacks many weights (all convs of a model, forward and dgrad panels) from a DEVICE job table */
 typedef struct pn2_pack_job { const float* w; void* wp; pn2_pack_desc d; } pn2_pack_job;
-int pn2_pack_weights_multi(int dtype, const pn2_pack_job* jobs_dev, int njobs, int blocks_per_job, void* stream);
+/* block_start_dev[j] = first workgroup of job j (njobs + 1 entries, prefix sums of pn2_pack_blocks(&job.d)).  Only real
+ * (non-pad) elements are rewritten: the panels must have been created by pn2_pack_weight(), which also zero-fills the pads. */
+int pn2_pack_blocks(const pn2_pack_desc* p);
+int pn2_pack_weights_multi(int dtype, const pn2_pack_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
+/* the split-K reductions (pn2_wgrad_reduce) of many convs in ONE launch, from a DEVICE job table: they only depend on their own
+ * pn2_conv_wgrad launch, so a training step defers them and runs them together (prefix sums of pn2_wgrad_reduce_blocks). */
+typedef struct pn2_reduce_job { const float* slab; float* gw; pn2_pack_desc d; int nsplit; int accumulate; } pn2_reduce_job;
+int pn2_wgrad_reduce_blocks(const pn2_pack_desc* p);
+int pn2_wgrad_reduce_multi(const pn2_reduce_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- batch norm
  * nn.BatchNorm2d train/eval forward + backward (lib/pranet.py:37,41-42 ; lib/Res2Net_v1b.py:33,45,50,103,106,110,135),

@@ -818,31 +818,71 @@ __global__ void pack_weight(const float* __restrict__ w, T* __restrict__ wp, pn2
     }
 }
 
+// job lookup for the table-driven launches: largest j with bstart[j] <= b   (bstart has njobs + 1 entries)
+__device__ __forceinline__ int find_job(const int* __restrict__ bstart, int njobs, int b) {
+    int lo = 0, hi = njobs;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bstart[mid] <= b) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__host__ __device__ inline int log2phys(int c, int gw, int gwp) { const int g = c / gw; return g * gwp + (c - g * gw); }
+
+// tile of the table-driven repack: CO x CI logical channels, all taps, staged through <= 32 KiB of LDS
+__host__ __device__ inline void pack_tile(int taps, int& CO, int& CI) {
+    if (taps == 1) { CO = 64; CI = 64; }
+    else if (taps <= 7) { CO = 32; CI = 32; }
+    else if (taps <= 9) { CO = 16; CI = 32; }
+    else if (taps <= 25) { CO = 16; CI = 16; }
+    else { CO = 4; CI = 8; }      // taps <= 225
+}
+inline int pack_blocks(const pn2_pack_desc& p) {
+    int CO, CI; pack_tile(p.KH * p.KW, CO, CI);
+    return ((p.Cout + CO - 1) / CO) * ((p.Cin + CI - 1) / CI);
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weight_multi(const pn2_pack_job* __restrict__ jobs) {
-    // one launch repacks every conv weight of the model (forward + dgrad panels): blockIdx.y = job
-    const pn2_pack_job j = jobs[blockIdx.y];
+__global__ __launch_bounds__(256) void pack_weight_multi(const pn2_pack_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    // one launch refreshes every conv panel of the model (forward + dgrad layouts).  A block owns a CO x CI x taps tile of one
+    // weight: the OIHW fp32 master is read in contiguous runs of CI*taps floats, the panel is written in runs along its own
+    // contiguous axis (ci for the forward layout, co for the transposed one).  Pad slots are never written: they hold the
+    // zeros pn2_pack_weight() put there when the panel was created.
+    __shared__ float tile[7296];      // max over pack_tile() of CO * (CI * taps + 1)
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_pack_job j = jobs[jb];
     const pn2_pack_desc p = j.d;
-    const float* w = j.w;
-    T* wp = reinterpret_cast<T*>(j.wp);
-    const size_t total = (size_t)p.Rp * p.Kp;
+    const float* __restrict__ w = j.w;
+    T* __restrict__ wp = reinterpret_cast<T*>(j.wp);
     const int taps = p.KH * p.KW;
-    const int cg = p.transposed ? p.Cout_p : p.Cin_p;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int row = (int)(idx / p.Kp), k = (int)(idx - (size_t)row * p.Kp);
-        const int tap = k / cg, c = k - tap * cg;
-        float v = 0.f;
-        if (tap < taps) {
-            int co, ci;
-            if (!p.transposed) { co = row < p.Cout_p ? phys2log(row, p.gw_out, p.gwp_out, p.Cout) : -1; ci = phys2log(c, p.gw_in, p.gwp_in, p.Cin); }
-            else { ci = row < p.Cin_p ? phys2log(row, p.gw_in, p.gwp_in, p.Cin) : -1; co = phys2log(c, p.gw_out, p.gwp_out, p.Cout); }
-            if (co >= 0 && ci >= 0) v = w[((size_t)co * p.Cin + ci) * taps + tap];
+    int CO, CI; pack_tile(taps, CO, CI);
+    const int local = blockIdx.x - bstart[jb];
+    const int nci = (p.Cin + CI - 1) / CI;
+    const int co0 = (local / nci) * CO, ci0 = (local - (local / nci) * nci) * CI;
+    const int nco_t = min(CO, p.Cout - co0), nci_t = min(CI, p.Cin - ci0);
+    const int run = nci_t * taps, rs = CI * taps + 1;     // +1: the transposed read walks LDS with stride rs
+    for (int e = threadIdx.x; e < nco_t * run; e += 256) {
+        const int col = e / run, r = e - col * run;
+        tile[col * rs + r] = w[((size_t)(co0 + col) * p.Cin + ci0) * taps + r];
+    }
+    __syncthreads();
+    const size_t ld = p.ld ? p.ld : p.Kp;
+    const int n = nco_t * run;
+    if (!p.transposed) {
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int t2 = e / nci_t, cil = e - t2 * nci_t, col = t2 / taps, tap = t2 - col * taps;
+            TT<T>::st(wp + (size_t)log2phys(co0 + col, p.gw_out, p.gwp_out) * ld + p.koff + tap * p.Cin_p + log2phys(ci0 + cil, p.gw_in, p.gwp_in),
+                      tile[col * rs + cil * taps + tap]);
         }
-        TT<T>::st(wp + (size_t)row * (p.ld ? p.ld : p.Kp) + p.koff + k, v);
+    } else {
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int t2 = e / nco_t, col = e - t2 * nco_t, cil = t2 / taps, tap = t2 - cil * taps;
+            TT<T>::st(wp + (size_t)log2phys(ci0 + cil, p.gw_in, p.gwp_in) * ld + p.koff + tap * p.Cout_p + log2phys(co0 + col, p.gw_out, p.gwp_out),
+                      tile[col * rs + cil * taps + tap]);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restrict__ slab, float* __restrict__ gw, pn2_pack_desc p, int nsplit, int accumulate) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slab, float* __restrict__ gw, const pn2_pack_desc& p, int nsplit, int accumulate,
+                                                  int blk, int nblk) {
     // walk the slabs in their own (k-contiguous) order so the nsplit reads per element are coalesced; the single
     // OIHW write per element is the scattered side.  Fixed summation order over the splits -> deterministic.
     const int taps = p.KH * p.KW;
@@ -852,8 +892,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restri
     // 8 consecutive lanes share one element: lane s sums slabs s, s+8, ... (4 loads in flight), then a fixed-order butterfly.
     // 8x the threads and 1/8 of the serial chain of a thread-per-element loop (these matrices are small, nsplit is large).
     const int sub = threadIdx.x & 7;
-    const size_t ngroups = ((size_t)gridDim.x * 256) >> 3;
-    for (size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 3; base < total; base += ngroups) {
+    const size_t ngroups = ((size_t)nblk * 256) >> 3;
+    for (size_t base = ((size_t)blk * 256 + threadIdx.x) >> 3; base < total; base += ngroups) {
         const size_t idx = base;
         const int prow = (int)(idx / ktot), k = (int)(idx - (size_t)prow * ktot);
         const int tap = k / p.Cin_p, pc = k - tap * p.Cin_p;
@@ -872,6 +912,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restri
             *d = accumulate ? *d + v : v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_unpack(const float* __restrict__ slab, float* __restrict__ gw, pn2_pack_desc p, int nsplit, int accumulate) {
+    wgrad_reduce_body(slab, gw, p, nsplit, accumulate, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi(const pn2_reduce_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    // the split-K reductions of many convs in one launch (they do not depend on each other, only on their own wgrad launch)
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_reduce_job j = jobs[jb];
+    wgrad_reduce_body(j.slab, j.gw, j.d, j.nsplit, j.accumulate, blockIdx.x - bstart[jb], bstart[jb + 1] - bstart[jb]);
+}
+
+inline int reduce_blocks(const pn2_pack_desc& p) {
+    const size_t nthr = (size_t)p.Cout_p * p.Cin_p * p.KH * p.KW * 8;
+    const size_t b = (nthr + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -1071,11 +1128,12 @@ int pn2_pack_weight(int dtype, const float* w, void* wp, const pn2_pack_desc* p,
     return 0;
 }
 
-int pn2_pack_weights_multi(int dtype, const pn2_pack_job* jobs_dev, int njobs, int blocks_per_job, void* stream) {
-    if (!jobs_dev || njobs < 1 || blocks_per_job < 1) return -1;
-    dim3 grid(blocks_per_job, njobs);
-    if (dtype == PN2_BF16) hipLaunchKernelGGL(pack_weight_multi<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev);
-    else if (dtype == PN2_F32) hipLaunchKernelGGL(pack_weight_multi<float>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev);
+int pn2_pack_blocks(const pn2_pack_desc* p) { return (p && p->KH * p->KW <= 225) ? pack_blocks(*p) : -1; }
+
+int pn2_pack_weights_multi(int dtype, const pn2_pack_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    if (dtype == PN2_BF16) hipLaunchKernelGGL(pack_weight_multi<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    else if (dtype == PN2_F32) hipLaunchKernelGGL(pack_weight_multi<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
     else return -3;
     PN2_CHECK_LAUNCH();
     return 0;
@@ -1087,6 +1145,15 @@ int pn2_wgrad_reduce(const float* slab, float* gw, const pn2_pack_desc* p, int n
     const size_t nthr = total * 8;
     const int grid = (int)((nthr + 255) / 256 > 16384 ? 16384 : (nthr + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_unpack, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, gw, *p, nsplit, accumulate);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_wgrad_reduce_blocks(const pn2_pack_desc* p) { return p ? reduce_blocks(*p) : -1; }
+
+int pn2_wgrad_reduce_multi(const pn2_reduce_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    hipLaunchKernelGGL(wgrad_reduce_multi, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
     PN2_CHECK_LAUNCH();
     return 0;
 }

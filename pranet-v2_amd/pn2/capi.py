@@ -33,6 +33,10 @@ class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("d", PackDesc)]
 
 
+class ReduceJob(C.Structure):
+    _fields_ = [("slab", C.c_void_p), ("gw", C.c_void_p), ("d", PackDesc), ("nsplit", C.c_int), ("accumulate", C.c_int)]
+
+
 class BnDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("Cp", C.c_int), ("C", C.c_int), ("gw", C.c_int), ("gwp", C.c_int),
                 ("eps", C.c_float), ("momentum", C.c_float), ("ldp", C.c_int)]
@@ -50,7 +54,10 @@ SIGNATURES = {
     "pn2_conv_wgrad": [I, P, P, P, C.POINTER(WgradDesc), I, P],
     "pn2_pack_weight": [I, P, P, C.POINTER(PackDesc), P],
     "pn2_wgrad_reduce": [P, P, C.POINTER(PackDesc), I, I, P],
-    "pn2_pack_weights_multi": [I, P, I, I, P],
+    "pn2_pack_blocks": [C.POINTER(PackDesc)],
+    "pn2_pack_weights_multi": [I, P, P, I, I, P],
+    "pn2_wgrad_reduce_blocks": [C.POINTER(PackDesc)],
+    "pn2_wgrad_reduce_multi": [P, P, I, I, P],
     "pn2_bn_finalize": [P, P, I, C.POINTER(BnDesc), P, P, P, P, P, P, P, P, P],
     "pn2_bn_eval_prepare": [C.POINTER(BnDesc), P, P, P, P, P, P, P],
     "pn2_affine_act": [I, P, I, I, P, I, I, I, P, P, P, I, I, P],
@@ -81,7 +88,8 @@ SIGNATURES = {
     "pn2_eval_tail": [P, P, P, LL, P],
 }
 # entry points that return a value rather than a status
-_VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks"}
+_VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
+                "pn2_pack_blocks", "pn2_wgrad_reduce_blocks"}
 
 _lib = None
 WORK = {}     # profiling annotation for the next launch (algorithmic flops / tag), consumed by pn2.profile.Recorder

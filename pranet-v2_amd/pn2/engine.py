@@ -133,15 +133,81 @@ class PackCache:
         if not self.jobs:
             return
         if self.table is None:
-            arr = (capi.PackJob * len(self.jobs))(*self.jobs)
-            raw = bytes(memoryview(arr).cast("B"))
-            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
-        call.pn2_pack_weights_multi(self.dt, _p(self.table), len(self.jobs), 8, _stream())
+            self.table, self.bstart, self.nblocks = _job_table(capi.PackJob, self.jobs, [call.pn2_pack_blocks(C.byref(j.d)) for j in self.jobs])
+        call.pn2_pack_weights_multi(self.dt, _p(self.table), _p(self.bstart), len(self.jobs), self.nblocks, _stream())
+
+
+def _job_table(struct, jobs, blocks):
+    """-> (device copy of the job array, device prefix sums of the per-job workgroup counts, total workgroups)."""
+    if min(blocks) < 1:
+        raise RuntimeError("job with an unsupported geometry in a table-driven launch")
+    arr = (struct * len(jobs))(*jobs)
+    table = torch.frombuffer(bytearray(bytes(memoryview(arr).cast("B"))), dtype=torch.uint8).cuda()
+    start = [0]
+    for b in blocks:
+        start.append(start[-1] + b)
+    return table, torch.tensor(start, dtype=torch.int32).cuda(), start[-1]
+
+
+class ReduceQueue:
+    """Deferred split-K reductions of the weight gradients.  pn2_conv_wgrad leaves per-split fp32 slabs; summing them into the
+    OIHW gradient only feeds the optimizer, so a training step queues those reductions and runs them as a few table-driven
+    launches (one per flush) instead of one tiny launch per conv.  Shapes are static: the slabs are persistent, the job tables
+    are built during the first step and replayed afterwards (also from inside a captured hipGraph)."""
+
+    def __init__(self):
+        self.slabs = {}
+        self.jobs, self.ptrs = [], []     # every reduction of one step, in backward order
+        self.segments = {}                # (first job, end job) -> (device job table, device block starts, total blocks)
+        self.begin_step()
+
+    def begin_step(self):
+        self.cur = self.start = 0
+
+    def slab(self, key, shape, dev):
+        t = self.slabs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            if t is not None:
+                raise RuntimeError("wgrad slab geometry changed between steps; build a new Trainer for a new input shape")
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("run one eager step before capturing (persistent wgrad slabs are allocated then)")
+            t = self.slabs[key] = torch.empty(shape, dtype=torch.float32, device=dev)
+        return t
+
+    def add(self, slab, gw, rd, nsplit, accumulate):
+        if accumulate:            # a second contribution to the same gradient must see the first one finished
+            self.flush()
+        ptr = (slab.data_ptr(), gw.data_ptr())
+        if self.cur < len(self.jobs):
+            if self.ptrs[self.cur] != ptr:
+                raise RuntimeError("the backward pass changed between steps; build a new Trainer")
+        else:
+            j = capi.ReduceJob()
+            j.slab, j.gw, j.nsplit, j.accumulate = ptr[0], ptr[1], nsplit, accumulate
+            C.memmove(C.byref(j.d), C.byref(rd), C.sizeof(capi.PackDesc))
+            self.jobs.append(j)
+            self.ptrs.append(ptr)
+        self.cur += 1
+
+    def flush(self):
+        """Launch the reductions queued since the previous flush."""
+        if self.cur == self.start:
+            return
+        key = (self.start, self.cur)
+        seg = self.segments.get(key)
+        if seg is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("run one eager step before capturing (reduce tables are built then)")
+            jobs = self.jobs[self.start:self.cur]
+            seg = self.segments[key] = _job_table(capi.ReduceJob, jobs, [call.pn2_wgrad_reduce_blocks(C.byref(j.d)) for j in jobs])
+        call.pn2_wgrad_reduce_multi(_p(seg[0]), _p(seg[1]), self.cur - self.start, seg[2], _stream())
+        self.start = self.cur
 
 
 class Engine:
-    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None):
+    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None, reduce_queue=None):
         self.pack_cache = pack_cache
+        self.reduce_queue = reduce_queue
         self.tuner = tuner              # dict shared across steps: conv shape -> tuned kernel/tile code (bf16 only)
         if not torch.cuda.is_available():
             raise RuntimeError("pranet-v2_amd runs on MI355X only: no GPU visible and there is no CPU fallback")
@@ -477,7 +543,8 @@ class Engine:
             steps = (M + 31) // 32
             # pixel splits: enough workgroups to fill 256 CUs twice, >= 4 steps each, slabs capped at 24 MB
             nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (640 + tiles - 1) // tiles, (24 << 20) // (wd.Rp * wd.Kp * 4) or 1))
-            slab = self.fbuf(nsplit, wd.Rp, wd.Kp)
+            rq = self.reduce_queue
+            slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab(id(w), (nsplit, wd.Rp, wd.Kp), self.dev)
             gwt, gwa = self.pgrads.sink(w)
             rd = self._pack_desc(w, x_map, o_map, False)
             rd.Rp = wd.Rp
@@ -487,7 +554,10 @@ class Engine:
                 wd.tune = self._tune_wgrad(wd, _p(draw), x.ptr, slab, nsplit)
                 capi.WORK.update(flops=flops, tag="", shape=shape)
                 call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, sst)
-                call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, sst)
+                if rq is None:
+                    call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, sst)
+                else:
+                    rq.add(slab, gwt, rd, nsplit, gwa)
             # ---- data gradient
             if x.requires_grad:
                 wt, ptd = self.pack(w, x_map, o_map, True)
@@ -612,7 +682,8 @@ class Engine:
             tiles = (wd.Rp // tco) * (Kp // 128)
             steps = (M + 31) // 32
             nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (640 + tiles - 1) // tiles, (24 << 20) // (wd.Rp * wd.Kp * 4) or 1))
-            slab = self.fbuf(nsplit, wd.Rp, wd.Kp)
+            rq = self.reduce_queue
+            slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab(tuple(id(c.weight) for c in convs), (nsplit, wd.Rp, wd.Kp), self.dev)
             wd.tune = self._tune_wgrad(wd, _p(draw), x.ptr, slab, nsplit)
             capi.WORK.update(flops=flops, tag="", shape=shape)
             call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
@@ -620,7 +691,10 @@ class Engine:
                 gwt, gwa = self.pgrads.sink(c.weight)
                 rd = self._pack_desc(c.weight, x_map, (co, co, co), False)
                 rd.Rp, rd.Kp = wd.Rp, Kp
-                call.pn2_wgrad_reduce(_p(slab[:, off:]), _p(gwt), C.byref(rd), nsplit, gwa, st)
+                if rq is None:
+                    call.pn2_wgrad_reduce(_p(slab[:, off:]), _p(gwt), C.byref(rd), nsplit, gwa, st)
+                else:
+                    rq.add(slab[:, off:], gwt, rd, nsplit, gwa)
             if x.requires_grad:
                 wt = panel(True)
                 gx, gxa = x.grad_sink()

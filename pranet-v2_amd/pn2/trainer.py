@@ -13,7 +13,7 @@ import os
 import torch
 
 from .capi import call, F32
-from .engine import Engine, Act, PackCache, TUNER, _p, _stream
+from .engine import Engine, Act, PackCache, ReduceQueue, TUNER, _p, _stream
 from .graph import get_compute_dtype
 from .dp import GradBuckets
 from . import loss as L
@@ -57,6 +57,7 @@ class Trainer:
         self.graph = None
         self.last_outs = None
         self.pack_cache = PackCache()
+        self.reduce_queue = ReduceQueue() if os.environ.get("PN2_DEFER_WGRAD_REDUCE", "1") == "1" else None
         # per-shape conv kernel/tile choices, filled by timing the candidates during the first (eager) step; the table is
         # per process (= per GPU) so every trainer in the process launches identical kernels (bit-reproducible runs)
         self.tuner = TUNER if os.environ.get("PN2_AUTOTUNE", "1") == "1" else None
@@ -69,7 +70,7 @@ class Trainer:
     def forward_backward(self, images, gts, reduce_hook=True):
         """forward + loss + backward; returns loss[5] = (l2, l3, l4, l5 pair losses, total) on device."""
         self.pack_cache.refresh()
-        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner)
+        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, reduce_queue=self.reduce_queue)
         x = eng.from_nchw(images)
         outs = self.model._build(eng, x)
         eng.finish_forward()
@@ -88,12 +89,20 @@ class Trainer:
             o.grad_written = True
         if self.world > 1:
             self.buckets.reset()
+        rq = self.reduce_queue
+        if rq is not None:
+            rq.begin_step()
+
+        def grads_complete():       # everything queued / running on the side so far must land before a bucket is sent
+            eng.join_side()
+            if rq is not None:
+                rq.flush()
         for fn in reversed(eng.tape):
             fn()
             if self.world > 1 and reduce_hook:
-                self.buckets.launch_ready(eng.pgrads.written, before_launch=eng.join_side)
+                self.buckets.launch_ready(eng.pgrads.written, before_launch=grads_complete)
         eng.tape = []
-        eng.join_side()
+        grads_complete()
         if self.world > 1:
             self.buckets.finish()
         self.last_outs = lat
@@ -122,6 +131,8 @@ class Trainer:
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.step(self.s_images, self.s_gts)
+            if self.world > 1:      # the captured pass has no bucket hooks: let it build its own (single) reduce table eagerly
+                self.forward_backward_local(self.s_images, self.s_gts)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
