@@ -7,6 +7,7 @@
 // All of these are HBM-bound streaming kernels: 16-byte vectors along the NHWC channel axis, one pass.
 // Batch statistics arrive as per-row-block partials from the conv epilogue (pn2_conv.hip), so the
 // forward never re-reads the conv output to compute them.
+#include <cstdlib>
 #include "pn2_common.h"
 #include "../../include/pn2.h"
 
@@ -357,9 +358,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
 inline void rows_geometry(int M, int CV, int& cvp, int& rows_per_blk, int& nblk) {
     cvp = 1; while (cvp < CV && cvp < 256) cvp <<= 1;
     const int R = 256 / cvp;
-    // aim at ~2048 workgroups (8 per CU) so that small tensors still put all their loads in flight at once;
-    // large tensors get up to RU*4 rows per thread
-    int want = (M + 2047) / 2048;
+    // aim at ~512 workgroups (2 per CU): measured on MI355X (tools/bn_micro.py), more and shorter blocks lose 1.5-2x because
+    // every block pays the per-channel parameter prologue; large tensors get up to RU*4 rows per thread
+    static const int target = getenv("PN2_BN_BLOCKS") ? atoi(getenv("PN2_BN_BLOCKS")) : 512;   // experiment knob
+    int want = (M + target - 1) / target;
     rows_per_blk = ((want + R - 1) / R) * R;
     if (rows_per_blk < R) rows_per_blk = R;
     if (rows_per_blk > R * RU * 4) rows_per_blk = R * RU * 4;
@@ -460,9 +462,10 @@ int pn2_bn_bwd_blocks(int M, int Cp, int dt) {
     const int V = dt == PN2_F32 ? 4 : 8;
     const int cv = Cp % V == 0 ? Cp / V : Cp;
     int cvp = 1; while (cvp < cv && cvp < 256) cvp <<= 1;
-    const int rows = (256 / cvp) * 2;     // >= 2 rows per thread, at most 1024 partial rows for the finalize pass
+    const int rows = (256 / cvp) * 2;     // >= 2 rows per thread, at most 512 partial rows for the finalize pass (measured optimum)
     int b = (M + rows - 1) / rows;
-    return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+    static const int cap = getenv("PN2_BN_RBLOCKS") ? atoi(getenv("PN2_BN_RBLOCKS")) : 512;   // experiment knob
+    return b > cap ? cap : (b < 1 ? 1 : b);
 }
 
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,

@@ -232,6 +232,104 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const T* __restrict__ dy, 
     }
 }
 
+// large magnification (the x8 / x16 / x32 lateral maps, K channels): one input pixel gathers hundreds of output pixels, and there
+// are few input pixels -> one WAVE per (pixel, channel), the lanes share the window (consecutive lanes = consecutive ox), then a
+// fixed-order butterfly.  Deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_wave_k(const T* __restrict__ dy, int ld_dy, T* __restrict__ dx, int ld_dx, int N, int H, int Wd, int C, int OH, int OW,
+                                                           int ac, float rh, float rw, int accumulate) {
+    const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (item >= (size_t)N * H * Wd * C) return;
+    const int c = (int)(item % C); size_t p = item / C;
+    const int ix = (int)(p % Wd); p /= Wd; const int iy = (int)(p % H); const int n = (int)(p / H);
+    int oy0, oy1, ox0, ox1;
+    bl_range(iy, rh, ac, OH, oy0, oy1); bl_range(ix, rw, ac, OW, ox0, ox1);
+    const int ncol = ox1 - ox0 + 1, ntap = (oy1 - oy0 + 1) * ncol;
+    float acc = 0.f;
+    for (int t = lane; t < ntap; t += 64) {
+        const int r = t / ncol, oy = oy0 + r, ox = ox0 + (t - r * ncol);
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        bl_src(oy, rh, ac, H, y0, y1, ly0, ly1); bl_src(ox, rw, ac, Wd, x0, x1, lx0, lx1);
+        const float w = ((y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f)) * ((x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f));
+        if (w != 0.f) acc += w * TT<T>::ld(dy + ((size_t)(n * OH + oy) * OW + ox) * ld_dy + c);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        T* d = dx + ((size_t)(n * H + iy) * Wd + ix) * ld_dx + c;
+        TT<T>::st(d, accumulate ? TT<T>::ld(d) + acc : acc);
+    }
+}
+
+// same case, contiguous K-channel rows (ld_dy == C): one block per input row (n, iy).  The block first reduces its window of
+// output rows along y into one row of OW*C column sums (every dy row is read as one coalesced line), then the Wd*C results are
+// short dot products over that row in LDS.  dy is read ~2x in total (each output row feeds two input rows).  Deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_rows_k(const T* __restrict__ dy, T* __restrict__ dx, int ld_dx, int N, int H, int Wd, int C, int OH, int OW,
+                                                           int ac, float rh, float rw, int accumulate) {
+    extern __shared__ float col[];     // [OW * C]
+    const int n = blockIdx.x / H, iy = blockIdx.x - n * H;
+    int oy0, oy1;
+    bl_range(iy, rh, ac, OH, oy0, oy1);
+    const int L = OW * C;
+    const T* base = dy + (size_t)n * OH * L;
+    if constexpr (sizeof(T) == 4) {
+        if ((L & 3) == 0 && L <= 1024) {
+            // 16-byte loads, the window rows split over R row lanes (more bytes in flight: the x16 / x32 maps have few blocks)
+            const int LV = L >> 2;
+            int lvp = 64; while (lvp < LV) lvp <<= 1;
+            const int R = 256 / lvp, jv = threadIdx.x % lvp, rl = threadIdx.x / lvp;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jv < LV) {
+#pragma unroll 8
+                for (int oy = oy0 + rl; oy <= oy1; oy += R) {
+                    int y0, y1; float ly0, ly1;
+                    bl_src(oy, rh, ac, H, y0, y1, ly0, ly1);
+                    const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+                    const float4 v = *reinterpret_cast<const float4*>(base + (size_t)oy * L + jv * 4);
+                    a.x += wy * v.x; a.y += wy * v.y; a.z += wy * v.z; a.w += wy * v.w;
+                }
+            }
+            for (int r = 0; r < R; ++r) {          // combine the row lanes in a fixed order
+                if (rl == r && jv < LV) {
+                    float4* c4 = reinterpret_cast<float4*>(col) + jv;
+                    if (r == 0) *c4 = a;
+                    else { float4 o = *c4; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; *c4 = o; }
+                }
+                __syncthreads();
+            }
+            goto reduce_x;
+        }
+    }
+    for (int j = threadIdx.x; j < L; j += 256) {
+        float a = 0.f;
+#pragma unroll 4
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            int y0, y1; float ly0, ly1;
+            bl_src(oy, rh, ac, H, y0, y1, ly0, ly1);
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            a += wy * TT<T>::ld(base + (size_t)oy * L + j);
+        }
+        col[j] = a;
+    }
+reduce_x:
+    __syncthreads();
+    for (int o = threadIdx.x; o < Wd * C; o += 256) {
+        const int ix = o / C, c = o - ix * C;
+        int ox0, ox1;
+        bl_range(ix, rw, ac, OW, ox0, ox1);
+        float a = 0.f;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            int x0, x1; float lx0, lx1;
+            bl_src(ox, rw, ac, Wd, x0, x1, lx0, lx1);
+            const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+            a += wx * col[ox * C + c];
+        }
+        T* d = dx + ((size_t)(n * H + iy) * Wd + ix) * ld_dx + c;
+        TT<T>::st(d, accumulate ? TT<T>::ld(d) + a : a);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ element-wise
 template <typename T, int W>
 __global__ __launch_bounds__(256) void binary_k(int op, const T* __restrict__ a, int ld_a, const T* __restrict__ b, int ld_b, T* __restrict__ out, int ld_o,
@@ -363,7 +461,11 @@ int pn2_bilinear_bwd(int dt, const void* dy, int ld_dy, void* dx, int ld_dx, int
     if (!dy || !dx) return -1;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dt, {
-        if (vec_ok<T>(C, ld_dy, ld_dx)) hipLaunchKernelGGL((bilinear_bwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * H * W * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
+        if (C < TT<T>::VEC && OH >= 4 * H && OW >= 4 * W && ld_dy == C && OW * C <= 8192)
+            hipLaunchKernelGGL((bilinear_bwd_rows_k<T>), dim3(N * H), dim3(256), OW * C * 4, st, (const T*)dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
+        else if (C < TT<T>::VEC && OH >= 4 * H && OW >= 4 * W)
+            hipLaunchKernelGGL((bilinear_bwd_wave_k<T>), dim3((unsigned)(((size_t)N * H * W * C + 3) / 4)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
+        else if (vec_ok<T>(C, ld_dy, ld_dx)) hipLaunchKernelGGL((bilinear_bwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * H * W * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
         else hipLaunchKernelGGL((bilinear_bwd_k<T, 1>), dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
     })
     PN2_CHECK_LAUNCH();

@@ -783,7 +783,7 @@ class Engine:
             gy = y.grad_buf()
             gx, acc = x.grad_sink()
             st = _stream()
-            if OH >= 4 * H and OW >= 4 * W:
+            if OH >= 4 * H and OW >= 4 * W and x.Cp >= (4 if x.dt == F32 else 8):
                 # separable adjoint: reduce along x first, then along y (keeps per-thread loops short)
                 tmp = self.empty(N, OH, W, x.Cp, x.dt)
                 call.pn2_bilinear_bwd(x.dt, _p(gy), gy.stride(2), _p(tmp), x.Cp, N, OH, W, x.Cp, OH, OW, ac, 1.0, rw, 0, st)

@@ -60,6 +60,12 @@ def _shape(name, a):
         if name == "pn2_wgrad_reduce":
             d = a[2]._obj
             return f"{d.Cin}->{d.Cout} k{d.KH}x{d.KW} Rp{d.Rp} Kp{d.Kp} ns{a[3]}"
+        if name in ("pn2_bilinear_fwd", "pn2_bilinear_bwd", "pn2_avgpool_fwd", "pn2_avgpool_bwd"):
+            return f"dt{a[0]} N{a[5]} {a[6]}x{a[7]} C{a[8]} -> {a[9]}x{a[10]}"
+        if name == "pn2_binary":
+            return f"dt{a[0]} op{a[1]} M{a[8]} C{a[9]} acc{a[10]}"
+        if name == "pn2_copy":
+            return f"dt{a[0]}->{a[3]} M{a[6]} C{a[7]} lds{a[2]} ldd{a[5]} acc{a[8]}"
         if name in ("pn2_bn_finalize", "pn2_bn_bwd_finalize"):
             return f"nblk{a[2]} Cp{a[3]._obj.Cp}"
     except Exception:
