@@ -883,33 +883,53 @@ __global__ __launch_bounds__(256) void pack_weight_multi(const pn2_pack_job* __r
 
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slab, float* __restrict__ gw, const pn2_pack_desc& p, int nsplit, int accumulate,
                                                   int blk, int nblk) {
-    // walk the slabs in their own (k-contiguous) order so the nsplit reads per element are coalesced; the single
-    // OIHW write per element is the scattered side.  Fixed summation order over the splits -> deterministic.
+    // Sum the nsplit slabs and scatter into the OIHW gradient.  A lane owns 4 consecutive packed k of one row (16-byte loads, a
+    // wave reads contiguous 256..1024-byte runs of every slab); the slabs are dealt round-robin to S sub-lanes (S = 1..16, more
+    // when the matrix is small and the split count large) that are combined by a fixed-order butterfly -> deterministic.
     const int taps = p.KH * p.KW;
-    const int ktot = taps * p.Cin_p;
-    const size_t total = (size_t)p.Cout_p * ktot;
+    const int ktot = taps * p.Cin_p;            // multiple of 8
+    const int kv = ktot >> 2;
+    const size_t total = (size_t)p.Cout_p * kv;
     const size_t sstride = (size_t)p.Rp * p.Kp;
-    // 8 consecutive lanes share one element: lane s sums slabs s, s+8, ... (4 loads in flight), then a fixed-order butterfly.
-    // 8x the threads and 1/8 of the serial chain of a thread-per-element loop (these matrices are small, nsplit is large).
-    const int sub = threadIdx.x & 7;
-    const size_t ngroups = ((size_t)nblk * 256) >> 3;
-    for (size_t base = ((size_t)blk * 256 + threadIdx.x) >> 3; base < total; base += ngroups) {
-        const size_t idx = base;
-        const int prow = (int)(idx / ktot), k = (int)(idx - (size_t)prow * ktot);
-        const int tap = k / p.Cin_p, pc = k - tap * p.Cin_p;
-        const int co = phys2log(prow, p.gw_out, p.gwp_out, p.Cout), ci = phys2log(pc, p.gw_in, p.gwp_in, p.Cin);
+    int S = 1;
+    while (S < 16 && total * S < 32768 && 2 * S <= nsplit) S <<= 1;
+    const int EPW = 64 / S;                     // element vectors per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / EPW, ei = lane - sub * EPW;
+    const size_t nwaves = (size_t)nblk * 4;
+    for (size_t base = ((size_t)blk * 4 + wave) * EPW; base < total; base += nwaves * EPW) {
+        const size_t idx = base + ei;
+        const bool live = idx < total;
+        const size_t ii = live ? idx : 0;
+        const int prow = (int)(ii / kv), k = (int)(ii - (size_t)prow * kv) << 2;
         const float* s = slab + (size_t)prow * p.Kp + k;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
         int i = sub;
-        for (; i + 24 < nsplit; i += 32) {
-            v0 += s[(size_t)i * sstride]; v1 += s[(size_t)(i + 8) * sstride]; v2 += s[(size_t)(i + 16) * sstride]; v3 += s[(size_t)(i + 24) * sstride];
+        for (; i + 3 * S < nsplit; i += 4 * S) {
+            const float4 a0 = *reinterpret_cast<const float4*>(s + (size_t)i * sstride), a1 = *reinterpret_cast<const float4*>(s + (size_t)(i + S) * sstride);
+            const float4 a2 = *reinterpret_cast<const float4*>(s + (size_t)(i + 2 * S) * sstride), a3 = *reinterpret_cast<const float4*>(s + (size_t)(i + 3 * S) * sstride);
+            v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w; v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+            v2.x += a2.x; v2.y += a2.y; v2.z += a2.z; v2.w += a2.w; v3.x += a3.x; v3.y += a3.y; v3.z += a3.z; v3.w += a3.w;
         }
-        for (; i < nsplit; i += 8) v0 += s[(size_t)i * sstride];
-        float v = (v0 + v1) + (v2 + v3);
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-        if (sub == 0 && co >= 0 && ci >= 0) {
-            float* d = gw + ((size_t)co * p.Cin + ci) * taps + tap;
-            *d = accumulate ? *d + v : v;
+        for (; i < nsplit; i += S) { const float4 a0 = *reinterpret_cast<const float4*>(s + (size_t)i * sstride); v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w; }
+        float v[4] = {(v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y), (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w)};
+        for (int off = EPW; off < 64; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], off);
+        }
+        if (sub == 0 && live) {
+            const int tap = k / p.Cin_p, pc = k - tap * p.Cin_p;
+            const int co = phys2log(prow, p.gw_out, p.gwp_out, p.Cout);
+            if (co >= 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = phys2log(pc + e, p.gw_in, p.gwp_in, p.Cin);
+                    if (ci >= 0) {
+                        float* d = gw + ((size_t)co * p.Cin + ci) * taps + tap;
+                        *d = accumulate ? *d + v[e] : v[e];
+                    }
+                }
+            }
         }
     }
 }
@@ -926,9 +946,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi(const pn2_reduce_job* 
 }
 
 inline int reduce_blocks(const pn2_pack_desc& p) {
-    const size_t nthr = (size_t)p.Cout_p * p.Cin_p * p.KH * p.KW * 8;
+    const size_t nthr = (size_t)p.Cout_p * p.Cin_p * p.KH * p.KW * 4;      // up to 16 sub-lanes per 4-element vector
     const size_t b = (nthr + 255) / 256;
-    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -1141,9 +1161,7 @@ int pn2_pack_weights_multi(int dtype, const pn2_pack_job* jobs_dev, const int* b
 
 int pn2_wgrad_reduce(const float* slab, float* gw, const pn2_pack_desc* p, int nsplit, int accumulate, void* stream) {
     if (!slab || !gw || !p) return -1;
-    const size_t total = (size_t)p->Cout_p * p->Cin_p * p->KH * p->KW;
-    const size_t nthr = total * 8;
-    const int grid = (int)((nthr + 255) / 256 > 16384 ? 16384 : (nthr + 255) / 256);
+    const int grid = reduce_blocks(*p);
     hipLaunchKernelGGL(wgrad_reduce_unpack, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, gw, *p, nsplit, accumulate);
     PN2_CHECK_LAUNCH();
     return 0;

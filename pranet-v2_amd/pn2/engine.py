@@ -395,28 +395,38 @@ class Engine:
             return (M + b - 1) // b
         return call.pn2_conv_stat_blocks(M, Cout, self.dt)
 
-    def _tune_wgrad(self, wd, dy_ptr, x_ptr, slab, nsplit):
+    def _tune_wgrad(self, wd, dy_ptr, x_ptr, rd, nsplit, wshape):
+        """-> (kernel code, pixel splits) for this wgrad shape.  Candidates: register-staged / LDS-DMA kernel x {1, 1/2, 1/4, 1/8} of
+        the heuristic split count; each is timed together with the slab reduction its split count implies."""
         t = self.tuner
         if t is None or self.dt != BF16:
-            return 0
+            return 0, nsplit
         key = ("w", wd.N, wd.H, wd.W, wd.OH, wd.OW, wd.Cin_p, wd.ld_x, wd.Cout_p, wd.ld_dy, wd.KH, wd.KW, wd.stride, wd.pad_h, wd.pad_w, wd.dil_h, wd.dil_w, nsplit)
         if key in t:
             return t[key]
         if torch.cuda.is_current_stream_capturing():
-            return 0
+            return 0, nsplit
         st = _stream()
+        slab = torch.empty((nsplit, wd.Rp, wd.Kp), dtype=torch.float32, device=self.dev)
+        gw = torch.empty(tuple(wshape), dtype=torch.float32, device=self.dev)
+        cands = [(code, ns) for ns in sorted({max(1, nsplit >> k) for k in range(4)}, reverse=True) for code in (1, 2)]
         evs = []
-        for code in (1, 2):
+
+        def run(code, ns):
             wd.tune = code
-            call.pn2_conv_wgrad(self.dt, dy_ptr, x_ptr, _p(slab), C.byref(wd), nsplit, st)
+            call.pn2_conv_wgrad(self.dt, dy_ptr, x_ptr, _p(slab), C.byref(wd), ns, st)
+            call.pn2_wgrad_reduce(_p(slab), _p(gw), C.byref(rd), ns, 0, st)
+        for code, ns in cands:
+            run(code, ns)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                call.pn2_conv_wgrad(self.dt, dy_ptr, x_ptr, _p(slab), C.byref(wd), nsplit, st)
+                run(code, ns)
             e1.record()
             evs.append((e0, e1))
         torch.cuda.synchronize()
-        best = 1 if evs[0][0].elapsed_time(evs[0][1]) <= evs[1][0].elapsed_time(evs[1][1]) else 2
+        times = [a_.elapsed_time(b_) for a_, b_ in evs]
+        best = cands[min(range(len(cands)), key=lambda i: times[i])]
         t[key] = best
         return best
 
@@ -543,15 +553,15 @@ class Engine:
             steps = (M + 31) // 32
             # pixel splits: enough workgroups to fill 256 CUs twice, >= 4 steps each, slabs capped at 24 MB
             nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (640 + tiles - 1) // tiles, (24 << 20) // (wd.Rp * wd.Kp * 4) or 1))
+            rd = self._pack_desc(w, x_map, o_map, False)
+            rd.Rp = wd.Rp
+            wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd, nsplit, w.shape)
             rq = self.reduce_queue
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab(id(w), (nsplit, wd.Rp, wd.Kp), self.dev)
             gwt, gwa = self.pgrads.sink(w)
-            rd = self._pack_desc(w, x_map, o_map, False)
-            rd.Rp = wd.Rp
             # wgrad (+ slab reduce) only feeds the parameter gradient: run it on the side stream so that it overlaps the dgrad /
             # BN-backward chain of the layers below instead of sitting on the critical path
             with self.on_side((draw, slab)) as sst:
-                wd.tune = self._tune_wgrad(wd, _p(draw), x.ptr, slab, nsplit)
                 capi.WORK.update(flops=flops, tag="", shape=shape)
                 call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, sst)
                 if rq is None:
@@ -682,9 +692,11 @@ class Engine:
             tiles = (wd.Rp // tco) * (Kp // 128)
             steps = (M + 31) // 32
             nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (640 + tiles - 1) // tiles, (24 << 20) // (wd.Rp * wd.Kp * 4) or 1))
+            rd0 = self._pack_desc(convs[0].weight, x_map, (couts[0], couts[0], couts[0]), False)
+            rd0.Rp, rd0.Kp = wd.Rp, Kp
+            wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd0, nsplit, convs[0].weight.shape)
             rq = self.reduce_queue
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab(tuple(id(c.weight) for c in convs), (nsplit, wd.Rp, wd.Kp), self.dev)
-            wd.tune = self._tune_wgrad(wd, _p(draw), x.ptr, slab, nsplit)
             capi.WORK.update(flops=flops, tag="", shape=shape)
             call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
             for c, co, off in zip(convs, couts, offs):

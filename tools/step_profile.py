@@ -41,3 +41,15 @@ for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:400]:
     if not d["flops"] and d["ms"] > 0.04:
         bw = f"{d['bytes'] / d['ms'] / 1e6:8.1f} GB/s" if d["bytes"] else ""
         print(f"{name:80s} {d['ms']:7.3f} ms x{d['launches']:3d} {bw}")
+
+rq = tr.reduce_queue
+if rq is not None:
+    tot = sum(t.numel() * 4 for t in rq.slabs.values())
+    print(f"\nwgrad slabs: {len(rq.slabs)} tensors, {tot / 1e6:.1f} MB total")
+    hist = {}
+    for t in rq.slabs.values():
+        k = tuple(t.shape)
+        hist.setdefault(k, [0, 0]); hist[k][0] += 1; hist[k][1] += t.numel() * 4
+    for k, (n, b) in sorted(hist.items(), key=lambda kv: -kv[1][1])[:25]:
+        print(f"  slab {k}: x{n}  {b / 1e6:.1f} MB")
+    print("tuned wgrad choices:", {k[1:]: v for k, v in tr.tuner.items() if k[0] == "w"} if tr.tuner else None)
