@@ -64,6 +64,14 @@ int pn2_conv_tile_m(int m, int cout, int dtype);        /* M tile (128 or 64) ch
 int pn2_conv_stat_blocks(int m, int cout, int dtype);   /* rows of the psum/psq partial buffers = ceil(m / tile_m) */
 int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, void* stream);
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream);
+/* Many weight gradients in ONE launch.  A wgrad only feeds the optimizer, so a training step may defer them (keeping dy / x alive)
+ * and run all convs that share a kernel instantiation (pn2_conv_wgrad_variant) together, from a DEVICE job table.
+ * block_start_dev: njobs + 1 prefix sums of pn2_conv_wgrad_blocks(&job.d, job.nsplit).  Same arithmetic, bit for bit, as
+ * pn2_conv_wgrad on each job. */
+typedef struct pn2_wgrad_job { const void* dy; const void* x; float* slab; pn2_wgrad_desc d; int nsplit; } pn2_wgrad_job;
+int pn2_conv_wgrad_variant(int dtype, const pn2_wgrad_desc* d);
+int pn2_conv_wgrad_blocks(const pn2_wgrad_desc* d, int nsplit);
+int pn2_conv_wgrad_multi(int dtype, int variant, const pn2_wgrad_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
 int pn2_pack_weight(int dtype, const float* w_oihw, void* wp, const pn2_pack_desc* p, void* stream);
 int pn2_wgrad_reduce(const float* slab, float* gw_oihw, const pn2_pack_desc* p, int nsplit, int accumulate, void* stream);
 /* one launch that repacks many weights (all convs of a model, forward and dgrad panels) from a DEVICE job table */

@@ -472,6 +472,13 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 constexpr int WGP = 32;   // pixels (contraction) per step
 
+// job lookup for the table-driven launches: largest j with bstart[j] <= b   (bstart has njobs + 1 entries)
+__device__ __forceinline__ int find_job(const int* __restrict__ bstart, int njobs, int b) {
+    int lo = 0, hi = njobs;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bstart[mid] <= b) lo = mid; else hi = mid; }
+    return lo;
+}
+
 template <typename T> struct WG;
 template <> struct WG<bf16_t> {
     static constexpr int PAD = 32;   // row stride == 32 B (mod 256 B): conflict-free ds_read_b64_tr_b16
@@ -493,7 +500,9 @@ template <> struct WG<float> {
 };
 
 template <typename T, int BMC, int BNK, int WM, int WN, bool PW>
-__global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ slab, pn2_wgrad_desc d, int nsplit) {
+__device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ slab, const pn2_wgrad_desc& d, int nsplit, int bloc) {
+    // bloc: workgroup index inside this conv's launch (== blockIdx.x for a single-conv launch; table launches start every job
+    // at a multiple of 8 so that bloc % 8 is still the XCD the block runs on)
     constexpr int VEC = TT<T>::VEC;
     constexpr int WTM = BMC / WM, WTN = BNK / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int RSY = BMC * (int)sizeof(T) + WG<T>::PAD, RSX = BNK * (int)sizeof(T) + WG<T>::PAD;
@@ -511,7 +520,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, cons
     // XCD-aware mapping (block b runs on XCD b%8): every (co,k) tile of one pixel split goes to the SAME XCD, back to back, so the
     // dy / x slice of that split is fetched into one L2 once instead of once per XCD (PMC showed ~4x over-fetch otherwise).
     const int ntile = (d.Rp / BMC) * tk;
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int xcd = bloc & 7, jx = bloc >> 3;
     const int split = xcd + 8 * (jx / ntile), tile = jx % ntile;
     if (split >= nsplit) return;
     const int bco = tile / tk, bk = tile % tk;
@@ -647,8 +656,8 @@ __global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, cons
 // over all 64 banks.  Same k-slot <-> pixel permutation for both operands as conv_wgrad.
 // ------------------------------------------------------------------------------------------------
 template <int BMC, int WM, int WN, bool PW>
-__global__ __launch_bounds__(256) void conv_wgrad_dma(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ slab,
-                                                      pn2_wgrad_desc d, int nsplit) {
+__device__ __forceinline__ void conv_wgrad_dma_body(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ slab,
+                                                    const pn2_wgrad_desc& d, int nsplit, int bloc) {
     constexpr int BNK = 128, PX = 64, NS = 3;
     constexpr int WTM = BMC / WM, WTN = BNK / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int RBY = BMC * 2, RBX = BNK * 2;              // row bytes
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const bf16_t* __restrict__
     const int M = d.N * d.OH * d.OW;
     const int tk = d.Kp / BNK;
     const int ntile = (d.Rp / BMC) * tk;
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int xcd = bloc & 7, jx = bloc >> 3;
     const int split = xcd + 8 * (jx / ntile), tile = jx % ntile;
     if (split >= nsplit) return;
     const int bco = tile / tk, bk = tile % tk;
@@ -790,6 +799,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const bf16_t* __restrict__
                 dst[(size_t)(wm * WTM + i * 16 + g * 4 + r) * d.Kp + wn * WTN + j * 16 + l15] = acc[i][j][r];
 }
 
+// single-conv and table-driven (many convs, one launch) entry points of the two wgrad kernels
+template <typename T, int BMC, int BNK, int WM, int WN, bool PW>
+__global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ slab, pn2_wgrad_desc d, int nsplit) {
+    conv_wgrad_body<T, BMC, BNK, WM, WN, PW>(dy, x, slab, d, nsplit, blockIdx.x);
+}
+template <typename T, int BMC, int BNK, int WM, int WN, bool PW>
+__global__ __launch_bounds__(256) void conv_wgrad_tab(const pn2_wgrad_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_wgrad_job j = jobs[jb];
+    conv_wgrad_body<T, BMC, BNK, WM, WN, PW>((const T*)j.dy, (const T*)j.x, j.slab, j.d, j.nsplit, blockIdx.x - bstart[jb]);
+}
+template <int BMC, int WM, int WN, bool PW>
+__global__ __launch_bounds__(256) void conv_wgrad_dma(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ slab, pn2_wgrad_desc d, int nsplit) {
+    conv_wgrad_dma_body<BMC, WM, WN, PW>(dy, x, slab, d, nsplit, blockIdx.x);
+}
+template <int BMC, int WM, int WN, bool PW>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_tab(const pn2_wgrad_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_wgrad_job j = jobs[jb];
+    conv_wgrad_dma_body<BMC, WM, WN, PW>((const bf16_t*)j.dy, (const bf16_t*)j.x, j.slab, j.d, j.nsplit, blockIdx.x - bstart[jb]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight packing (OIHW fp32 master -> K-contiguous panels in the compute dtype) and grad unpacking
 // ------------------------------------------------------------------------------------------------
@@ -816,13 +847,6 @@ __global__ void pack_weight(const float* __restrict__ w, T* __restrict__ wp, pn2
         }
         TT<T>::st(wp + (size_t)row * (p.ld ? p.ld : p.Kp) + p.koff + k, v);
     }
-}
-
-// job lookup for the table-driven launches: largest j with bstart[j] <= b   (bstart has njobs + 1 entries)
-__device__ __forceinline__ int find_job(const int* __restrict__ bstart, int njobs, int b) {
-    int lo = 0, hi = njobs;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bstart[mid] <= b) lo = mid; else hi = mid; }
-    return lo;
 }
 
 __host__ __device__ inline int log2phys(int c, int gw, int gwp) { const int g = c / gw; return g * gwp + (c - g * gw); }
@@ -1081,16 +1105,33 @@ int launch_wgrad_dma(const void* dy, const void* x, float* slab, const pn2_wgrad
     return 0;
 }
 
+inline bool wgrad_pw(const pn2_wgrad_desc& d) { return d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0; }
+
+// kernel instantiation a wgrad job runs on: dma * 6 + (co tile 32/64/128 -> 0/1/2) * 2 + pointwise
+template <typename T>
+int wgrad_variant(const pn2_wgrad_desc& d) {
+    const int bmc = pn2_wgrad_tile_co(d.Cout_p);
+    bool dma = false;
+    if constexpr (sizeof(T) == 2) {
+        static const bool on = [] { const char* e = getenv("PN2_WGRAD_DMA"); return !(e && e[0] == '0'); }();
+        // default: the DMA pipeline pays off for pointwise convs with many pixels; d.tune (1 register-staged, 2 DMA) overrides
+        dma = d.tune ? d.tune == 2 : (on && wgrad_pw(d) && d.N * d.OH * d.OW >= 8192);
+    }
+    return (dma ? 6 : 0) + (bmc == 128 ? 2 : (bmc == 64 ? 1 : 0)) * 2 + (wgrad_pw(d) ? 1 : 0);
+}
+
+inline int wgrad_blocks(const pn2_wgrad_desc& d, int nsplit) {
+    const int bmc = pn2_wgrad_tile_co(d.Cout_p);
+    return 8 * ((nsplit + 7) / 8) * (d.Rp / bmc) * (d.Kp / 128);
+}
+
 template <typename T>
 int wgrad_dispatch(const void* dy, const void* x, float* slab, const pn2_wgrad_desc& d, int nsplit, hipStream_t st) {
     const int bmc = pn2_wgrad_tile_co(d.Cout_p);
     if (d.Rp % bmc || d.Kp % 128) return -2;
+    const int v = wgrad_variant<T>(d);
     if constexpr (sizeof(T) == 2) {
-        static const bool on = [] { const char* e = getenv("PN2_WGRAD_DMA"); return !(e && e[0] == '0'); }();
-        // default: the DMA pipeline pays off for pointwise convs with many pixels; d.tune (1 register-staged, 2 DMA) overrides
-        const bool pw_ = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
-        const bool dma = d.tune ? d.tune == 2 : (on && pw_ && d.N * d.OH * d.OW >= 8192);
-        if (dma) {
+        if (v >= 6) {
             if (bmc == 128) return launch_wgrad_dma<128, 2, 2>(dy, x, slab, d, nsplit, st);
             if (bmc == 64) return launch_wgrad_dma<64, 2, 2>(dy, x, slab, d, nsplit, st);
             return launch_wgrad_dma<32, 1, 4>(dy, x, slab, d, nsplit, st);
@@ -1099,6 +1140,50 @@ int wgrad_dispatch(const void* dy, const void* x, float* slab, const pn2_wgrad_d
     if (bmc == 128) return launch_wgrad<T, 128, 2, 2>(dy, x, slab, d, nsplit, st);
     if (bmc == 64) return launch_wgrad<T, 64, 2, 2>(dy, x, slab, d, nsplit, st);
     return launch_wgrad<T, 32, 1, 4>(dy, x, slab, d, nsplit, st);
+}
+
+template <typename T, int BMC, int WM, int WN>
+int launch_wgrad_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
+    constexpr int BNK = 128;
+    constexpr int lds = 2 * WGP * (BMC * (int)sizeof(T) + WG<T>::PAD + BNK * (int)sizeof(T) + WG<T>::PAD);
+    if (pw) hipLaunchKernelGGL((conv_wgrad_tab<T, BMC, BNK, WM, WN, true>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
+    else hipLaunchKernelGGL((conv_wgrad_tab<T, BMC, BNK, WM, WN, false>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int BMC, int WM, int WN>
+int launch_wgrad_dma_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
+    constexpr int max_b = 3 * 64 * (BMC * 2 + 256);
+    if (max_b > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab<BMC, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab<BMC, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            done = true;
+        }
+    }
+    if (pw) hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, true>), dim3(total), dim3(256), max_b, st, jobs, bstart, njobs);
+    else hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, false>), dim3(total), dim3(256), max_b, st, jobs, bstart, njobs);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int wgrad_multi_dispatch(int v, const pn2_wgrad_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
+    const bool pw = v & 1;
+    const int bi = (v % 6) >> 1;
+    if (v >= 6) {
+        if constexpr (sizeof(T) == 2) {
+            if (bi == 2) return launch_wgrad_dma_tab<128, 2, 2>(pw, jobs, bstart, njobs, total, st);
+            if (bi == 1) return launch_wgrad_dma_tab<64, 2, 2>(pw, jobs, bstart, njobs, total, st);
+            return launch_wgrad_dma_tab<32, 1, 4>(pw, jobs, bstart, njobs, total, st);
+        }
+        return -3;
+    }
+    if (bi == 2) return launch_wgrad_tab<T, 128, 2, 2>(pw, jobs, bstart, njobs, total, st);
+    if (bi == 1) return launch_wgrad_tab<T, 64, 2, 2>(pw, jobs, bstart, njobs, total, st);
+    return launch_wgrad_tab<T, 32, 1, 4>(pw, jobs, bstart, njobs, total, st);
 }
 
 }  // namespace
@@ -1134,6 +1219,25 @@ int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const 
     if (d->Cin_p % 8 || d->ld_x % 8 || d->ld_dy % 8 || d->Cout_p % 8) return -2;
     if (dtype == PN2_BF16) return wgrad_dispatch<bf16_t>(dy, x, slab, *d, nsplit, (hipStream_t)stream);
     if (dtype == PN2_F32) return wgrad_dispatch<float>(dy, x, slab, *d, nsplit, (hipStream_t)stream);
+    return -3;
+}
+
+int pn2_conv_wgrad_variant(int dtype, const pn2_wgrad_desc* d) {
+    if (!d) return -1;
+    return dtype == PN2_BF16 ? wgrad_variant<bf16_t>(*d) : (dtype == PN2_F32 ? wgrad_variant<float>(*d) : -3);
+}
+
+int pn2_conv_wgrad_blocks(const pn2_wgrad_desc* d, int nsplit) {
+    if (!d || nsplit < 1) return -1;
+    const int bmc = pn2_wgrad_tile_co(d->Cout_p);
+    if (d->Rp % bmc || d->Kp % 128) return -2;
+    return wgrad_blocks(*d, nsplit);
+}
+
+int pn2_conv_wgrad_multi(int dtype, int variant, const pn2_wgrad_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1 || variant < 0 || variant >= 12) return -1;
+    if (dtype == PN2_BF16) return wgrad_multi_dispatch<bf16_t>(variant, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
+    if (dtype == PN2_F32) return wgrad_multi_dispatch<float>(variant, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
     return -3;
 }
 

@@ -33,6 +33,10 @@ class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("d", PackDesc)]
 
 
+class WgradJob(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("slab", C.c_void_p), ("d", WgradDesc), ("nsplit", C.c_int)]
+
+
 class ReduceJob(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("gw", C.c_void_p), ("d", PackDesc), ("nsplit", C.c_int), ("accumulate", C.c_int)]
 
@@ -52,6 +56,9 @@ SIGNATURES = {
     "pn2_conv_stat_blocks": [I, I, I],
     "pn2_conv_gemm": [I, P, P, P, P, P, C.POINTER(ConvDesc), P],
     "pn2_conv_wgrad": [I, P, P, P, C.POINTER(WgradDesc), I, P],
+    "pn2_conv_wgrad_variant": [I, C.POINTER(WgradDesc)],
+    "pn2_conv_wgrad_blocks": [C.POINTER(WgradDesc), I],
+    "pn2_conv_wgrad_multi": [I, I, P, P, I, I, P],
     "pn2_pack_weight": [I, P, P, C.POINTER(PackDesc), P],
     "pn2_wgrad_reduce": [P, P, C.POINTER(PackDesc), I, I, P],
     "pn2_pack_blocks": [C.POINTER(PackDesc)],
@@ -89,7 +96,7 @@ SIGNATURES = {
 }
 # entry points that return a value rather than a status
 _VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
-                "pn2_pack_blocks", "pn2_wgrad_reduce_blocks"}
+                "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks"}
 
 _lib = None
 WORK = {}     # profiling annotation for the next launch (algorithmic flops / tag), consumed by pn2.profile.Recorder

@@ -76,7 +76,7 @@ class Act:
             if self.parent is not None:
                 self.grad = self.parent.grad_buf()[..., self.c0:self.c0 + self.Cp]
             else:
-                self.grad = torch.empty(self.t.shape, dtype=self.t.dtype, device=self.t.device)
+                self.grad = self.eng.alloc(self.t.shape, self.t.dtype)
         return self.grad
 
     def grad_sink(self):
@@ -149,20 +149,51 @@ def _job_table(struct, jobs, blocks):
     return table, torch.tensor(start, dtype=torch.int32).cuda(), start[-1]
 
 
-class ReduceQueue:
-    """Deferred split-K reductions of the weight gradients.  pn2_conv_wgrad leaves per-split fp32 slabs; summing them into the
-    OIHW gradient only feeds the optimizer, so a training step queues those reductions and runs them as a few table-driven
-    launches (one per flush) instead of one tiny launch per conv.  Shapes are static: the slabs are persistent, the job tables
-    are built during the first step and replayed afterwards (also from inside a captured hipGraph)."""
+class StepArena:
+    """Bump allocator for everything an Engine allocates during one training step.  The first step runs on the torch allocator
+    and measures the footprint; later steps carve the same sequence of buffers out of one persistent block, so every activation,
+    gradient and scratch buffer has the SAME address in every step (eager or inside a captured hipGraph).  That is what lets the
+    deferred, table-driven launches (GradQueue) reuse their device job tables, and it takes the allocator off the eager path.
+    Sized for a 288 GB part: nothing is recycled inside a step."""
 
     def __init__(self):
+        self.buf, self.off, self.need = None, 0, 0
+
+    def begin_step(self, dev):
+        want = self.need
+        if want and (self.buf is None or self.buf.numel() < want) and not torch.cuda.is_current_stream_capturing():
+            self.buf = None
+            self.buf = torch.empty(want, dtype=torch.uint8, device=dev)
+        self.off, self.need = 0, 0
+
+    def alloc(self, shape, dtype, dev):
+        n = dtype.itemsize
+        for d in shape:
+            n *= d
+        na = (n + 255) // 256 * 256
+        self.need += na
+        if self.buf is not None and self.off + na <= self.buf.numel():
+            t = self.buf[self.off:self.off + n].view(dtype).view(shape)
+            self.off += na
+            return t
+        return torch.empty(shape, dtype=dtype, device=dev)
+
+
+class GradQueue:
+    """Deferred weight-gradient work of one training step.  A conv's wgrad and the split-K slab reduction that follows it only
+    feed the optimizer, so the backward pass queues them (dy / x stay alive in the step arena) and `flush()` runs them as a few
+    table-driven launches: one pn2_conv_wgrad_multi per kernel instantiation, then one pn2_wgrad_reduce_multi.  Device job tables
+    are cached per flush segment and reused for as long as the queued pointers are unchanged (always, with a StepArena)."""
+
+    def __init__(self, defer_wgrad=True):
+        self.defer_wgrad = defer_wgrad
         self.slabs = {}
-        self.jobs, self.ptrs = [], []     # every reduction of one step, in backward order
-        self.segments = {}                # (first job, end job) -> (device job table, device block starts, total blocks)
+        self.cache = {}                   # segment index -> (signature, launches)
         self.begin_step()
 
     def begin_step(self):
-        self.cur = self.start = 0
+        self.seg = 0
+        self.wjobs, self.rjobs, self.keep = [], [], []
 
     def slab(self, key, shape, dev):
         t = self.slabs.get(key)
@@ -170,44 +201,73 @@ class ReduceQueue:
             if t is not None:
                 raise RuntimeError("wgrad slab geometry changed between steps; build a new Trainer for a new input shape")
             if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("run one eager step before capturing (persistent wgrad slabs are allocated then)")
+                raise RuntimeError("run eager steps before capturing (persistent wgrad slabs are allocated then)")
             t = self.slabs[key] = torch.empty(shape, dtype=torch.float32, device=dev)
         return t
 
-    def add(self, slab, gw, rd, nsplit, accumulate):
+    def add_wgrad(self, dt, dy, x_ptr, x_keep, slab, wd, nsplit, flops=0):
+        self.wjobs.append((dt, dy.data_ptr(), x_ptr.value, slab.data_ptr(), wd, nsplit, flops))
+        self.keep.append((dy, x_keep))
+
+    def add_reduce(self, slab, gw, rd, nsplit, accumulate):
         if accumulate:            # a second contribution to the same gradient must see the first one finished
             self.flush()
-        ptr = (slab.data_ptr(), gw.data_ptr())
-        if self.cur < len(self.jobs):
-            if self.ptrs[self.cur] != ptr:
-                raise RuntimeError("the backward pass changed between steps; build a new Trainer")
-        else:
-            j = capi.ReduceJob()
-            j.slab, j.gw, j.nsplit, j.accumulate = ptr[0], ptr[1], nsplit, accumulate
-            C.memmove(C.byref(j.d), C.byref(rd), C.sizeof(capi.PackDesc))
-            self.jobs.append(j)
-            self.ptrs.append(ptr)
-        self.cur += 1
+        self.rjobs.append((slab.data_ptr(), gw.data_ptr(), rd, nsplit, accumulate))
+
+    def _build(self):
+        launches = []
+        groups = {}
+        for dt, dy, x, slab, wd, ns, fl in self.wjobs:
+            v = call.pn2_conv_wgrad_variant(dt, C.byref(wd))
+            if v < 0:
+                raise RuntimeError("unsupported wgrad geometry")
+            groups.setdefault((dt, v), []).append((dy, x, slab, wd, ns, fl))
+        for (dt, v), js in sorted(groups.items()):
+            arr = []
+            for dy, x, slab, wd, ns, fl in js:
+                j = capi.WgradJob()
+                j.dy, j.x, j.slab, j.nsplit = dy, x, slab, ns
+                C.memmove(C.byref(j.d), C.byref(wd), C.sizeof(capi.WgradDesc))
+                arr.append(j)
+            table, bstart, nblocks = _job_table(capi.WgradJob, arr, [call.pn2_conv_wgrad_blocks(C.byref(j.d), j.nsplit) for j in arr])
+            launches.append(("w", dt, v, table, bstart, len(arr), nblocks, sum(j[5] for j in js)))
+        if self.rjobs:
+            arr = []
+            for slab, gw, rd, ns, acc in self.rjobs:
+                j = capi.ReduceJob()
+                j.slab, j.gw, j.nsplit, j.accumulate = slab, gw, ns, acc
+                C.memmove(C.byref(j.d), C.byref(rd), C.sizeof(capi.PackDesc))
+                arr.append(j)
+            table, bstart, nblocks = _job_table(capi.ReduceJob, arr, [call.pn2_wgrad_reduce_blocks(C.byref(j.d)) for j in arr])
+            launches.append(("r", 0, 0, table, bstart, len(arr), nblocks, 0))
+        return launches
 
     def flush(self):
-        """Launch the reductions queued since the previous flush."""
-        if self.cur == self.start:
+        """Launch what was queued since the previous flush."""
+        if not self.wjobs and not self.rjobs:
             return
-        key = (self.start, self.cur)
-        seg = self.segments.get(key)
-        if seg is None:
+        sig = (tuple(j[:4] + (j[5],) for j in self.wjobs), tuple(j[:2] + j[3:] for j in self.rjobs))
+        hit = self.cache.get(self.seg)
+        if hit is None or hit[0] != sig:
             if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("run one eager step before capturing (reduce tables are built then)")
-            jobs = self.jobs[self.start:self.cur]
-            seg = self.segments[key] = _job_table(capi.ReduceJob, jobs, [call.pn2_wgrad_reduce_blocks(C.byref(j.d)) for j in jobs])
-        call.pn2_wgrad_reduce_multi(_p(seg[0]), _p(seg[1]), self.cur - self.start, seg[2], _stream())
-        self.start = self.cur
+                raise RuntimeError("run two eager steps before capturing (the deferred-launch tables are built then)")
+            hit = self.cache[self.seg] = (sig, self._build())
+        st = _stream()
+        for kind, dt, v, table, bstart, njobs, nblocks, flops in hit[1]:
+            if kind == "w":
+                capi.WORK.update(flops=flops, tag="", shape=f"variant{v} jobs{njobs}")
+                call.pn2_conv_wgrad_multi(dt, v, _p(table), _p(bstart), njobs, nblocks, st)
+            else:
+                call.pn2_wgrad_reduce_multi(_p(table), _p(bstart), njobs, nblocks, st)
+        self.seg += 1
+        self.wjobs, self.rjobs, self.keep = [], [], []
 
 
 class Engine:
-    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None, reduce_queue=None):
+    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None, grad_queue=None, arena=None):
         self.pack_cache = pack_cache
-        self.reduce_queue = reduce_queue
+        self.grad_queue = grad_queue
+        self.arena = arena
         self.tuner = tuner              # dict shared across steps: conv shape -> tuned kernel/tile code (bf16 only)
         if not torch.cuda.is_available():
             raise RuntimeError("pranet-v2_amd runs on MI355X only: no GPU visible and there is no CPU fallback")
@@ -226,8 +286,13 @@ class Engine:
         self.use_side = os.environ.get("PN2_SIDE_STREAM", "0") == "1"
 
     # ------------------------------------------------------------------ allocation / layout
+    def alloc(self, shape, dtype):
+        if self.arena is not None:
+            return self.arena.alloc(tuple(shape), dtype, self.dev)
+        return torch.empty(tuple(shape), dtype=dtype, device=self.dev)
+
     def empty(self, N, H, W, Cp, dt=None):
-        return torch.empty((N, H, W, Cp), dtype=TORCH_DT[self.dt if dt is None else dt], device=self.dev)
+        return self.alloc((N, H, W, Cp), TORCH_DT[self.dt if dt is None else dt])
 
     def new_act(self, N, H, W, C_, gw=None, gwp=None, dt=None, zero=False):
         gw = C_ if gw is None else gw
@@ -242,14 +307,14 @@ class Engine:
         """j-th full-resolution fp32 output map, carved from one [nmaps][N][OH][OW][K] block so the fused
         structure-loss kernels can walk all supervision pairs with a single base pointer + stride."""
         if self._lat is None:
-            self._lat = torch.empty((nmaps, N, OH, OW, K), dtype=torch.float32, device=self.dev)
+            self._lat = self.alloc((nmaps, N, OH, OW, K), torch.float32)
         return Act(self, self._lat[j], K, K, K, F32)
 
     def lateral_block(self):
         return self._lat
 
     def fbuf(self, *shape):
-        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+        return self.alloc(shape, torch.float32)
 
     def from_nchw(self, x, requires_grad=False):
         """fp32 NCHW module input -> NHWC compute dtype, channels zero-padded to a multiple of 8."""
@@ -556,18 +621,22 @@ class Engine:
             rd = self._pack_desc(w, x_map, o_map, False)
             rd.Rp = wd.Rp
             wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd, nsplit, w.shape)
-            rq = self.reduce_queue
+            rq = self.grad_queue
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab(id(w), (nsplit, wd.Rp, wd.Kp), self.dev)
             gwt, gwa = self.pgrads.sink(w)
             # wgrad (+ slab reduce) only feeds the parameter gradient: run it on the side stream so that it overlaps the dgrad /
             # BN-backward chain of the layers below instead of sitting on the critical path
-            with self.on_side((draw, slab)) as sst:
-                capi.WORK.update(flops=flops, tag="", shape=shape)
-                call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, sst)
-                if rq is None:
-                    call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, sst)
-                else:
-                    rq.add(slab, gwt, rd, nsplit, gwa)
+            if rq is not None and rq.defer_wgrad:
+                rq.add_wgrad(self.dt, draw, x.ptr, x.t, slab, wd, nsplit, flops)
+                rq.add_reduce(slab, gwt, rd, nsplit, gwa)
+            else:
+                with self.on_side((draw, slab)) as sst:
+                    capi.WORK.update(flops=flops, tag="", shape=shape)
+                    call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, sst)
+                    if rq is None:
+                        call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, sst)
+                    else:
+                        rq.add_reduce(slab, gwt, rd, nsplit, gwa)
             # ---- data gradient
             if x.requires_grad:
                 wt, ptd = self.pack(w, x_map, o_map, True)
@@ -695,10 +764,13 @@ class Engine:
             rd0 = self._pack_desc(convs[0].weight, x_map, (couts[0], couts[0], couts[0]), False)
             rd0.Rp, rd0.Kp = wd.Rp, Kp
             wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd0, nsplit, convs[0].weight.shape)
-            rq = self.reduce_queue
+            rq = self.grad_queue
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab(tuple(id(c.weight) for c in convs), (nsplit, wd.Rp, wd.Kp), self.dev)
-            capi.WORK.update(flops=flops, tag="", shape=shape)
-            call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
+            if rq is not None and rq.defer_wgrad:
+                rq.add_wgrad(self.dt, draw, x.ptr, x.t, slab, wd, nsplit, flops)
+            else:
+                capi.WORK.update(flops=flops, tag="", shape=shape)
+                call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
             for c, co, off in zip(convs, couts, offs):
                 gwt, gwa = self.pgrads.sink(c.weight)
                 rd = self._pack_desc(c.weight, x_map, (co, co, co), False)
@@ -706,7 +778,7 @@ class Engine:
                 if rq is None:
                     call.pn2_wgrad_reduce(_p(slab[:, off:]), _p(gwt), C.byref(rd), nsplit, gwa, st)
                 else:
-                    rq.add(slab[:, off:], gwt, rd, nsplit, gwa)
+                    rq.add_reduce(slab[:, off:], gwt, rd, nsplit, gwa)
             if x.requires_grad:
                 wt = panel(True)
                 gx, gxa = x.grad_sink()

@@ -86,7 +86,7 @@ class Recorder:
             fn = getattr(lib, name)
 
             def wrapped(*a, _fn=fn, _name=name):
-                if _name in ("pn2_conv_gemm", "pn2_conv_wgrad"):
+                if _name in ("pn2_conv_gemm", "pn2_conv_wgrad", "pn2_conv_wgrad_multi"):
                     fl, tag, shape = capi.WORK.pop("flops", 0), capi.WORK.pop("tag", ""), capi.WORK.pop("shape", "")
                 else:
                     fl, tag, shape = 0, "", _shape(_name, a)

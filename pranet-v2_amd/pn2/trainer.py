@@ -13,7 +13,7 @@ import os
 import torch
 
 from .capi import call, F32
-from .engine import Engine, Act, PackCache, ReduceQueue, TUNER, _p, _stream
+from .engine import Engine, Act, PackCache, GradQueue, StepArena, TUNER, _p, _stream
 from .graph import get_compute_dtype
 from .dp import GradBuckets
 from . import loss as L
@@ -57,7 +57,11 @@ class Trainer:
         self.graph = None
         self.last_outs = None
         self.pack_cache = PackCache()
-        self.reduce_queue = ReduceQueue() if os.environ.get("PN2_DEFER_WGRAD_REDUCE", "1") == "1" else None
+        # PN2_DEFER_WGRAD: 2 (default) wgrad + slab reduction deferred into table-driven launches, 1 only the reductions, 0 neither
+        mode = os.environ.get("PN2_DEFER_WGRAD", "2")
+        self.grad_queue = GradQueue(defer_wgrad=mode == "2") if mode in ("1", "2") else None
+        self.arena = StepArena() if os.environ.get("PN2_STEP_ARENA", "1") == "1" else None
+        self.steps_run = 0
         # per-shape conv kernel/tile choices, filled by timing the candidates during the first (eager) step; the table is
         # per process (= per GPU) so every trainer in the process launches identical kernels (bit-reproducible runs)
         self.tuner = TUNER if os.environ.get("PN2_AUTOTUNE", "1") == "1" else None
@@ -70,7 +74,10 @@ class Trainer:
     def forward_backward(self, images, gts, reduce_hook=True):
         """forward + loss + backward; returns loss[5] = (l2, l3, l4, l5 pair losses, total) on device."""
         self.pack_cache.refresh()
-        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, reduce_queue=self.reduce_queue)
+        if self.arena is not None:
+            self.arena.begin_step(self.flat.device)
+        self.steps_run += 1
+        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, grad_queue=self.grad_queue, arena=self.arena)
         x = eng.from_nchw(images)
         outs = self.model._build(eng, x)
         eng.finish_forward()
@@ -82,14 +89,14 @@ class Trainer:
         HW = H * W
         mask = gts.reshape(N, HW).float().contiguous()
         loss, saved = L.loss_forward(lat, P, mask, N, HW, H, W)
-        dlat = torch.empty_like(lat)
+        dlat = eng.alloc(lat.shape, lat.dtype)
         L.loss_backward(lat, dlat, P, mask, saved, N, HW, 1.0)
         for j, o in enumerate(outs):
             o.grad = dlat[j]
             o.grad_written = True
         if self.world > 1:
             self.buckets.reset()
-        rq = self.reduce_queue
+        rq = self.grad_queue
         if rq is not None:
             rq.begin_step()
 
@@ -124,6 +131,9 @@ class Trainer:
     def capture(self, images, gts, warmup=3):
         """Capture forward+loss+backward(+Adam) into hipGraphs and replay them with `replay(images, gts)`.
         With data parallelism the gradient all-reduce stays outside the graphs (between backward and Adam)."""
+        if self.steps_run + warmup < 2:
+            # step 1 measures the arena, step 2 builds the deferred-launch tables on the arena addresses the graph will replay
+            raise RuntimeError("capture() needs at least 2 eager steps before the captured one (warmup >= 2 on a fresh Trainer)")
         self.s_images = images.clone()
         self.s_gts = gts.clone()
         side = torch.cuda.Stream()

@@ -42,7 +42,7 @@ for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:400]:
         bw = f"{d['bytes'] / d['ms'] / 1e6:8.1f} GB/s" if d["bytes"] else ""
         print(f"{name:80s} {d['ms']:7.3f} ms x{d['launches']:3d} {bw}")
 
-rq = tr.reduce_queue
+rq = tr.grad_queue
 if rq is not None:
     tot = sum(t.numel() * 4 for t in rq.slabs.values())
     print(f"\nwgrad slabs: {len(rq.slabs)} tensors, {tot / 1e6:.1f} MB total")
