@@ -197,9 +197,11 @@ class PraNet_V2(nn.Module):
 
     def _build(self, eng, x):
         x1, x2, x3, x4 = self.backbone._build_features(eng, x)
-        x2_rfb, (t2,) = self.rfb2_1._build(eng, x2, extra=[self.ra2_conv1])
-        x3_rfb, (t3,) = self.rfb3_1._build(eng, x3, extra=[self.ra3_conv1])
-        x4_rfb, (t4,) = self.rfb4_1._build(eng, x4, extra=[self.ra4_conv1])
+        # the three RFB modules are independent of each other: one lane (HIP stream) each
+        (x2_rfb, (t2,)), (x3_rfb, (t3,)), (x4_rfb, (t4,)) = eng.lanes([
+            lambda: self.rfb2_1._build(eng, x2, extra=[self.ra2_conv1]),
+            lambda: self.rfb3_1._build(eng, x3, extra=[self.ra3_conv1]),
+            lambda: self.rfb4_1._build(eng, x4, extra=[self.ra4_conv1])])
         ra5_fg, ra5_bg = self.agg1._build(eng, x4_rfb, x3_rfb, x2_rfb)
         return _dsra_tail(self, eng, {2: t2, 3: t3, 4: t4}, ra5_fg, ra5_bg)
 

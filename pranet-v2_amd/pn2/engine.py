@@ -348,6 +348,52 @@ class Engine:
         self.tape = []
         self.join_side()
 
+    # ------------------------------------------------------------------ lanes: independent sub-graphs on their own HIP streams
+    _LANE_STREAMS = []
+
+    def lanes(self, fns):
+        """[f() for f in fns] for sub-graphs that do not depend on each other (e.g. the three RFB modules): each runs on its own
+        HIP stream, forked from and joined back to the current stream, in the forward AND in the backward pass, so their many small
+        launch-bound kernels overlap (inside a captured hipGraph they become parallel branches).  Only with a step arena: buffers
+        are then never recycled inside a step, so cross-stream reuse cannot happen."""
+        # measured on MI355X / ROCm 7.2: parallel hipGraph branches cost more than they overlap (21.3 -> 23.2 ms/step) -> opt-in
+        on = os.environ.get("PN2_LANES", "0") == "1" and self.arena is not None and self.arena.buf is not None and len(fns) > 1
+        if not on:
+            return [f() for f in fns]
+        while len(Engine._LANE_STREAMS) < len(fns):
+            Engine._LANE_STREAMS.append(torch.cuda.Stream())
+        streams = Engine._LANE_STREAMS[:len(fns)]
+        self._lanes_used = streams
+        main = torch.cuda.current_stream()
+
+        def fork():
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            for s_ in streams:
+                s_.wait_event(ev)
+
+        def join():
+            cur = torch.cuda.current_stream()
+            for s_ in streams:
+                cur.wait_stream(s_)
+
+        def on_stream(fn, s_):
+            def run():
+                with torch.cuda.stream(s_):
+                    fn()
+            return run
+        self.record(join)                 # backward: runs last of the region
+        fork()
+        outs = []
+        for f, s_ in zip(fns, streams):
+            t0 = len(self.tape)
+            with torch.cuda.stream(s_):
+                outs.append(f())
+            self.tape[t0:] = [on_stream(fn, s_) for fn in self.tape[t0:]]
+        join()
+        self.record(fork)                 # backward: runs first of the region
+        return outs
+
     # ------------------------------------------------------------------ side stream (off-critical-path work)
     def on_side(self, keep=()):
         """Context manager: run the enclosed launches on the engine's side HIP stream, ordered after everything issued so far
@@ -378,6 +424,8 @@ class Engine:
         """Make the current stream wait for everything queued on the side stream (call before consuming parameter gradients)."""
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+        for s_ in getattr(self, "_lanes_used", ()):
+            torch.cuda.current_stream().wait_stream(s_)
         self._keep = []
 
     # ------------------------------------------------------------------ weights
