@@ -416,6 +416,50 @@ def test_graph_replay_matches_eager_bf16():
     assert torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("fp32", [False, True])
+def test_table_driven_launches_match_single_launches(fp32, monkeypatch):
+    """pn2_conv_wgrad_multi / pn2_wgrad_reduce_multi over the step arena == one pn2_conv_wgrad + pn2_wgrad_reduce per conv, bit for bit."""
+    from pn2.trainer import Trainer
+    from oracle import weights as W
+    x, mask = W.synthetic_batch(2, 96, seed=5)
+    xg, mg = x.to(dev), mask.to(dev)
+    res = []
+    for defer, arena in (("0", "0"), ("1", "1"), ("2", "1")):
+        monkeypatch.setenv("PN2_DEFER_WGRAD", defer)
+        monkeypatch.setenv("PN2_STEP_ARENA", arena)
+        tr = Trainer(_fixture_model(fp32=fp32))
+        for _ in range(3):          # step 1 torch allocator, step 2 builds the tables on arena addresses, step 3 replays them
+            loss = tr.forward_backward(xg, mg)
+        torch.cuda.synchronize()
+        res.append((loss.clone(), tr.gflat.clone()))
+        if defer == "2":
+            assert tr.arena.buf is not None and tr.arena.off > 0 and len(tr.grad_queue.cache) >= 1
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
+
+
+def test_pack_weights_multi_matches_single_pack():
+    """The one-launch tiled repack (pn2_pack_weights_multi) rewrites every cached panel exactly as pn2_pack_weight builds it."""
+    from pn2.trainer import Trainer
+    from pn2.engine import PackCache
+    from oracle import weights as W
+    x, mask = W.synthetic_batch(2, 96, seed=6)
+    xg, mg = x.to(dev), mask.to(dev)
+    tr = Trainer(_fixture_model(fp32=False))
+    tr.forward_backward(xg, mg)                       # panels created by pn2_pack_weight
+    first = tr.pack_cache
+    with torch.no_grad():
+        tr.flat.mul_(1.25).add_(0.01)                 # new master weights
+    first.refresh()                                   # multi-job repack in place
+    torch.cuda.synchronize()
+    tr.pack_cache = PackCache()
+    tr.forward_backward(xg, mg)                       # same weights, panels built from scratch by pn2_pack_weight
+    torch.cuda.synchronize()
+    assert len(first.entries) == len(tr.pack_cache.entries) > 100
+    for key, (wp, _) in first.entries.items():
+        assert torch.equal(wp, tr.pack_cache.entries[key][0]), key
+
+
 def test_full_size_properties_bs32_352_bf16():
     """BASELINE config 2 shape: size-independent properties instead of an oracle run (which would take minutes on the CPU)."""
     from pn2.trainer import Trainer
