@@ -160,6 +160,32 @@ int pn2_structure_loss_fwd(const float* preds, long long map_stride, int P, cons
 int pn2_structure_loss_bwd(const float* preds, float* dpreds, long long map_stride, int P, const float* mask, const float* weit,
                            const float* wsum, const float* sums, float gscale, int N, int HW, void* stream);
 
+/* ---------------------------------------------------------------------------------------------- fused DSRA tail (K = 1)
+ * The memory-bound end of the training step as two kernels: lateral = bilinear(low-res fg|bg map, x8/x16/x32) for all 2P maps
+ * (pranet.py:354,371,393,415) + the dual structure loss of MyTrain_med.py:19-38,78-82 in ONE pass that writes the 2P full-resolution
+ * maps once; and its backward, which recomputes the logits from the low-res maps and applies the bilinear adjoint on the fly, so the
+ * 2P full-resolution gradient maps are never materialised.  Algorithmic traffic per image (S = OH*OW*4 B): forward 2P*S written +
+ * 2*S read (mask, weit); backward ~2*S*(#distinct scales)*2 read.                                                               */
+#define PN2_TAIL_MAX_MAPS 16
+typedef struct pn2_tail_map {
+    const float* src;       /* low-res K=1 logits [N][h][w] fp32 */
+    float* dsrc;            /* their gradient, same layout (backward only) */
+    int h, w;
+    float rh, rw;           /* source-index scales of the resize (1/scale_factor; (h-1)/(OH-1) with align_corners) */
+    int accumulate;         /* backward: dsrc += instead of = */
+    int pad_;
+} pn2_tail_map;
+typedef struct pn2_tail_desc {
+    int N, OH, OW, P, align_corners, pad_;
+    pn2_tail_map maps[PN2_TAIL_MAX_MAPS];       /* maps[j] j<P: fg logits of pair j ; maps[P+j]: bg logits of pair j */
+} pn2_tail_desc;
+int pn2_dsra_tail_blocks(int OH);               /* row bands per image of `partial`: [P][N][blocks][5] floats */
+/* lat: [2P][N][OH*OW] fp32 written ; sums/wsum/loss as pn2_structure_loss_fwd */
+int pn2_dsra_tail_fwd(const pn2_tail_desc* d, float* lat, const float* mask, const float* weit, float* partial,
+                      float* sums, float* wsum, float* loss, void* stream);
+int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* weit, const float* wsum, const float* sums,
+                      float gscale, void* stream);
+
 /* ---------------------------------------------------------------------------------------------- element-wise / layout */
 int pn2_binary(int dt, int op /*0 add,1 mul*/, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream);
 int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld_d, int M, int C, int accumulate, void* stream);

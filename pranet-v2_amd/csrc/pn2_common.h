@@ -69,4 +69,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// PyTorch upsample_bilinear2d index math (area_pixel_compute_source_index), shared by pn2_spatial.hip and the fused DSRA tail:
+//   align_corners: src = r*dst ; else src = max(r*(dst+0.5)-0.5, 0) ; i0 = (int)src ; i1 = i0 + (i0 < In-1) ; l1 = src - i0.
+__device__ __forceinline__ void bl_src(int o, float r, int ac, int In, int& i0, int& i1, float& l0, float& l1) {
+    float s = ac ? r * (float)o : fmaxf(r * ((float)o + 0.5f) - 0.5f, 0.f);
+    i0 = (int)s; if (i0 > In - 1) i0 = In - 1;
+    i1 = i0 + (i0 < In - 1 ? 1 : 0);
+    l1 = s - (float)i0; l0 = 1.f - l1;
+}
+
+// candidate output range whose 2-tap footprint can touch input index i (monotone src): conservative +-1, exact test in loop
+__device__ __forceinline__ void bl_range(int i, float r, int ac, int On, int& lo, int& hi) {
+    float a, b;
+    if (ac) { if (r <= 0.f) { lo = 0; hi = On - 1; return; } a = ((float)i - 1.f) / r; b = ((float)i + 1.f) / r; }
+    else { a = ((float)i - 0.5f) / r - 0.5f; b = ((float)i + 1.5f) / r - 0.5f; }
+    lo = (int)floorf(a) - 1; hi = (int)ceilf(b) + 1;
+    if (lo < 0) lo = 0; if (hi > On - 1) hi = On - 1;
+}
+
 #define PN2_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

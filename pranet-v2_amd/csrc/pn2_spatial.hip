@@ -158,13 +158,6 @@ __global__ __launch_bounds__(256) void avgpool_bwd_k(const T* __restrict__ dy, i
 // ------------------------------------------------------------------------------------------ bilinear
 // PyTorch upsample_bilinear2d index math (area_pixel_compute_source_index):
 //   align_corners: src = r*dst ; else src = max(r*(dst+0.5)-0.5, 0) ; i0 = (int)src ; i1 = i0 + (i0 < In-1) ; l1 = src - i0.
-__device__ __forceinline__ void bl_src(int o, float r, int ac, int In, int& i0, int& i1, float& l0, float& l1) {
-    float s = ac ? r * (float)o : fmaxf(r * ((float)o + 0.5f) - 0.5f, 0.f);
-    i0 = (int)s; if (i0 > In - 1) i0 = In - 1;
-    i1 = i0 + (i0 < In - 1 ? 1 : 0);
-    l1 = s - (float)i0; l0 = 1.f - l1;
-}
-
 template <typename T, int W>
 __global__ __launch_bounds__(256) void bilinear_fwd_k(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int N, int H, int Wd, int C, int OH, int OW,
                                                       int ac, float rh, float rw) {
@@ -183,15 +176,6 @@ __global__ __launch_bounds__(256) void bilinear_fwd_k(const T* __restrict__ x, i
         for (int e = 0; e < W; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bq[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
         VL<T, W>::store(y + ((size_t)(n * OH + oy) * OW + ox) * ld_y + cv * W, o);
     }
-}
-
-// candidate output range whose 2-tap footprint can touch input index i (monotone src): conservative +-1, exact test in loop
-__device__ __forceinline__ void bl_range(int i, float r, int ac, int On, int& lo, int& hi) {
-    float a, b;
-    if (ac) { if (r <= 0.f) { lo = 0; hi = On - 1; return; } a = ((float)i - 1.f) / r; b = ((float)i + 1.f) / r; }
-    else { a = ((float)i - 0.5f) / r - 0.5f; b = ((float)i + 1.5f) / r - 0.5f; }
-    lo = (int)floorf(a) - 1; hi = (int)ceilf(b) + 1;
-    if (lo < 0) lo = 0; if (hi > On - 1) hi = On - 1;
 }
 
 template <typename T, int W>

@@ -136,6 +136,15 @@ __global__ __launch_bounds__(256) void loss_weights_k(const float* __restrict__ 
 
 __device__ __forceinline__ float bce_logits(float x, float z) { return fmaxf(x, 0.f) - x * z + log1pf(__expf(-fabsf(x))); }
 
+// sigmoid(x) and softplus(x) = log(1 + e^x) from ONE hardware exp + one hardware log (v_exp_f32 / v_log_f32): e = e^-|x| <= 1, so
+// nothing overflows; log(1 + e) loses at most one ulp of 1.0 (6e-8 absolute) against log1p, far below the 1e-6 loss tolerance.
+// BCE-with-logits(x, z) = softplus(x) - x*z, the same stable form torch uses.
+__device__ __forceinline__ void sig_softplus(float x, float& sig, float& sp) {
+    const float e = __expf(-fabsf(x)), r = __frcp_rn(1.f + e);
+    sig = x >= 0.f ? r : e * r;
+    sp = fmaxf(x, 0.f) + __logf(1.f + e);
+}
+
 // partial[p][n][blk][5] = { sum w*bce_fg, sum w*bce_bg, sum p*m*w, sum (p+m)*w, sum w }
 __global__ __launch_bounds__(256) void loss_fwd_k(const float* __restrict__ preds, long long map_stride, int P, const float* __restrict__ mask,
                                                   const float* __restrict__ weit, float* __restrict__ partial, int N, int HW) {
@@ -205,6 +214,181 @@ __global__ __launch_bounds__(256) void loss_bwd_k(const float* __restrict__ pred
         const float dwiou = -(m * w * D - (I + 1.f) * (w - m * w)) * invD2;
         dpreds[of + i] = gs * (w * (pr - m) * invW + dwiou * pr * (1.f - pr));
         dpreds[ob + i] = gs * 0.8f * w * (pb - (1.f - m)) * invW;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ fused DSRA tail (K = 1)
+constexpr int TRB = 8;          // output rows per forward block
+
+// 4 consecutive output pixels (oy, ox..ox+3) of one lateral map from its low-res rows staged in LDS (rows ylo.. of width mp.w);
+// same expression as bilinear_fwd_k
+__device__ __forceinline__ void tail_up4(const float* rows, int ylo, const pn2_tail_map& mp, int ac, int oy, int ox, float* z) {
+    int y0, y1; float ly0, ly1;
+    bl_src(oy, mp.rh, ac, mp.h, y0, y1, ly0, ly1);
+    const float* r0 = rows + (y0 - ylo) * mp.w; const float* r1 = rows + (y1 - ylo) * mp.w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int x0, x1; float lx0, lx1;
+        bl_src(ox + e, mp.rw, ac, mp.w, x0, x1, lx0, lx1);
+        z[e] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void tail_fwd_k(pn2_tail_desc d, float* __restrict__ lat, const float* __restrict__ mask, const float* __restrict__ weit,
+                                                  float* __restrict__ partial) {
+    extern __shared__ float lds[];
+    __shared__ float red[4 * P + 1][4];
+    __shared__ int s_off[2 * P], s_ylo[2 * P];
+    const int n = blockIdx.y, band = blockIdx.x, nb = gridDim.x, ac = d.align_corners;
+    const int oyA = band * TRB;
+    int oyB = oyA + TRB - 1; if (oyB > d.OH - 1) oyB = d.OH - 1;
+    int off = 0;
+    for (int j = 0; j < 2 * P; ++j) {
+        const pn2_tail_map& mp = d.maps[j];
+        int ya0, ya1, yb0, yb1; float t0, t1;
+        bl_src(oyA, mp.rh, ac, mp.h, ya0, ya1, t0, t1);
+        bl_src(oyB, mp.rh, ac, mp.h, yb0, yb1, t0, t1);
+        const int nr = yb1 - ya0 + 1;
+        const float* src = mp.src + ((size_t)n * mp.h + ya0) * mp.w;
+        for (int i = threadIdx.x; i < nr * mp.w; i += 256) lds[off + i] = src[i];
+        if (threadIdx.x == 0) { s_off[j] = off; s_ylo[j] = ya0; }
+        off += nr * mp.w;
+    }
+    __syncthreads();
+    float acc[P][4], wacc = 0.f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) { acc[p][0] = 0.f; acc[p][1] = 0.f; acc[p][2] = 0.f; acc[p][3] = 0.f; }
+    const int OW4 = d.OW >> 2, rows = oyB - oyA + 1;
+    const size_t img = (size_t)d.OH * d.OW;
+    for (int it = threadIdx.x; it < rows * OW4; it += 256) {
+        const int r = it / OW4, ox = (it - r * OW4) * 4, oy = oyA + r;
+        const size_t pix = (size_t)n * img + (size_t)oy * d.OW + ox;
+        const float4 m4 = *reinterpret_cast<const float4*>(mask + pix), w4 = *reinterpret_cast<const float4*>(weit + pix);
+        const float m[4] = {m4.x, m4.y, m4.z, m4.w}, w[4] = {w4.x, w4.y, w4.z, w4.w};
+        wacc += (w[0] + w[1]) + (w[2] + w[3]);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float f[4], b[4];
+            tail_up4(lds + s_off[p], s_ylo[p], d.maps[p], ac, oy, ox, f);
+            tail_up4(lds + s_off[P + p], s_ylo[P + p], d.maps[P + p], ac, oy, ox, b);
+            *reinterpret_cast<float4*>(lat + (size_t)p * d.N * img + pix) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4*>(lat + (size_t)(P + p) * d.N * img + pix) = make_float4(b[0], b[1], b[2], b[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pr, spf, pb, spb;
+                sig_softplus(f[e], pr, spf); sig_softplus(b[e], pb, spb);
+                acc[p][0] += w[e] * (spf - f[e] * m[e]); acc[p][1] += w[e] * (spb - b[e] * (1.f - m[e]));
+                acc[p][2] += pr * m[e] * w[e]; acc[p][3] += (pr + m[e]) * w[e];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float v = wave_sum(acc[p][k]); if (lane == 0) red[p * 4 + k][wv] = v; }
+    { const float v = wave_sum(wacc); if (lane == 0) red[4 * P][wv] = v; }
+    __syncthreads();
+    if (threadIdx.x < 5 * P) {          // partial[p][n][band][5] = {w*bce_fg, w*bce_bg, p*m*w, (p+m)*w, w}
+        const int p = threadIdx.x / 5, k = threadIdx.x - p * 5, row = k < 4 ? p * 4 + k : 4 * P;
+        partial[(((size_t)p * d.N + n) * nb + band) * 5 + k] = (red[row][0] + red[row][1]) + (red[row][2] + red[row][3]);
+    }
+}
+
+// backward work list: maps that share a low-res geometry are processed together (<= 4 per block, they share the mask / weit reads)
+struct tail_groups { int ng; int start[PN2_TAIL_MAX_MAPS + 1]; int nm[PN2_TAIL_MAX_MAPS]; int idx[PN2_TAIL_MAX_MAPS][4]; };
+
+__global__ __launch_bounds__(256) void tail_bwd_k(pn2_tail_desc d, tail_groups G, const float* __restrict__ mask, const float* __restrict__ weit,
+                                                  const float* __restrict__ wsum, const float* __restrict__ sums, float gscale) {
+    extern __shared__ float lds[];          // [nm][nr][w] low-res rows, then [nm][OW] column sums
+    int g = 0;
+    while (g + 1 < G.ng && (int)blockIdx.x >= G.start[g + 1]) ++g;
+    const int nm = G.nm[g], ac = d.align_corners, P = d.P;
+    const pn2_tail_map& m0 = d.maps[G.idx[g][0]];
+    const int h = m0.h, w = m0.w;
+    const int local = blockIdx.x - G.start[g], n = local / h, iy = local - n * h;
+    int oy0, oy1;
+    bl_range(iy, m0.rh, ac, d.OH, oy0, oy1);
+    int ya0, ya1, yb0, yb1; float t0, t1;
+    bl_src(oy0, m0.rh, ac, h, ya0, ya1, t0, t1);
+    bl_src(oy1, m0.rh, ac, h, yb0, yb1, t0, t1);
+    const int ylo = ya0, nr = yb1 - ya0 + 1;
+    for (int q = 0; q < nm; ++q) {
+        const float* src = d.maps[G.idx[g][q]].src + ((size_t)n * h + ylo) * w;
+        for (int i = threadIdx.x; i < nr * w; i += 256) lds[q * nr * w + i] = src[i];
+    }
+    float* col = lds + ((nm * nr * w + 3) & ~3);       // 16-byte aligned for the float4 column sums
+    __syncthreads();
+    const int OW = d.OW, LV = OW >> 2;
+    int lvp = 64; while (lvp < LV) lvp <<= 1;
+    const int R = 256 / lvp, jv = threadIdx.x % lvp, rl = threadIdx.x / lvp;
+    const size_t img = (size_t)d.OH * OW;
+    const float gs = gscale / (float)d.N, invW = 1.f / wsum[n];
+    // per-map constants of this image
+    float cI[4], cD[4], cinvD2[4]; int isbg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = G.idx[g][q < nm ? q : 0], p = j >= P ? j - P : j;
+        const float* s = sums + ((size_t)p * d.N + n) * 4;
+        cI[q] = s[2]; cD[q] = s[3] - s[2] + 1.f; cinvD2[q] = 1.f / (cD[q] * cD[q]); isbg[q] = j >= P;
+    }
+    float a[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[q][0] = 0.f; a[q][1] = 0.f; a[q][2] = 0.f; a[q][3] = 0.f; }
+    if (jv < LV) {
+        for (int oy = oy0 + rl; oy <= oy1; oy += R) {
+            int y0, y1; float ly0, ly1;
+            bl_src(oy, m0.rh, ac, h, y0, y1, ly0, ly1);
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            const size_t pix = (size_t)n * img + (size_t)oy * OW + jv * 4;
+            const float4 m4 = *reinterpret_cast<const float4*>(mask + pix), w4 = *reinterpret_cast<const float4*>(weit + pix);
+            const float m[4] = {m4.x, m4.y, m4.z, m4.w}, wt[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nm) {
+                    float z[4];
+                    tail_up4(lds + q * nr * w, ylo, d.maps[G.idx[g][q]], ac, oy, jv * 4, z);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float ex = __expf(-fabsf(z[e])), rr = __frcp_rn(1.f + ex), pr = z[e] >= 0.f ? rr : ex * rr;
+                        float dl;
+                        if (isbg[q]) dl = gs * 0.8f * wt[e] * (pr - (1.f - m[e])) * invW;
+                        else {
+                            const float dwiou = -(m[e] * wt[e] * cD[q] - (cI[q] + 1.f) * (wt[e] - m[e] * wt[e])) * cinvD2[q];
+                            dl = gs * (wt[e] * (pr - m[e]) * invW + dwiou * pr * (1.f - pr));
+                        }
+                        a[q][e] += wy * dl;
+                    }
+                }
+            }
+        }
+    }
+    for (int r = 0; r < R; ++r) {              // combine the row lanes in a fixed order
+        if (rl == r && jv < LV) {
+            for (int q = 0; q < nm; ++q) {
+                float4* c4 = reinterpret_cast<float4*>(col + q * OW) + jv;
+                if (r == 0) *c4 = make_float4(a[q][0], a[q][1], a[q][2], a[q][3]);
+                else { float4 o = *c4; o.x += a[q][0]; o.y += a[q][1]; o.z += a[q][2]; o.w += a[q][3]; *c4 = o; }
+            }
+        }
+        __syncthreads();
+    }
+    for (int o = threadIdx.x; o < nm * w; o += 256) {
+        const int q = o / w, ix = o - q * w;
+        const pn2_tail_map& mp = d.maps[G.idx[g][q]];
+        int ox0, ox1;
+        bl_range(ix, mp.rw, ac, OW, ox0, ox1);
+        float sacc = 0.f;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            int x0, x1; float lx0, lx1;
+            bl_src(ox, mp.rw, ac, w, x0, x1, lx0, lx1);
+            const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+            sacc += wx * col[q * OW + ox];
+        }
+        float* dst = mp.dsrc + ((size_t)n * h + iy) * w + ix;
+        *dst = mp.accumulate ? *dst + sacc : sacc;
     }
 }
 
@@ -366,6 +550,69 @@ int pn2_eval_tail(const float* res, unsigned char* out, float* minmax, long long
     hipLaunchKernelGGL(minmax_k, dim3(nb), dim3(256), 0, st, res, n, minmax);
     hipLaunchKernelGGL(minmax_final_k, dim3(1), dim3(64), 0, st, minmax, nb);
     hipLaunchKernelGGL(eval_u8_k, dim3(grid_for((size_t)n)), dim3(256), 0, st, res, out, minmax, n);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_dsra_tail_blocks(int OH) { return (OH + TRB - 1) / TRB; }
+
+static int tail_check(const pn2_tail_desc* d) {
+    if (!d || d->P < 1 || d->P > 4 || (d->OW & 3) || d->OW > 1024 || d->N < 1 || d->P * d->N > 512) return -2;
+    for (int j = 0; j < 2 * d->P; ++j) {
+        const pn2_tail_map& m = d->maps[j];
+        if (!m.src || m.h < 1 || m.w < 1 || m.w > d->OW || m.h > d->OH) return -2;
+    }
+    return 0;
+}
+
+int pn2_dsra_tail_fwd(const pn2_tail_desc* d, float* lat, const float* mask, const float* weit, float* partial,
+                      float* sums, float* wsum, float* loss, void* stream) {
+    if (!lat || !mask || !weit || !partial || !sums || !wsum || !loss) return -1;
+    if (int rc = tail_check(d)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    size_t lds = 0;
+    for (int j = 0; j < 2 * d->P; ++j) lds += (size_t)((int)(TRB * d->maps[j].rh) + 3) * d->maps[j].w * 4;
+    if (lds > 60 * 1024) return -2;
+    const int nb = pn2_dsra_tail_blocks(d->OH);
+    dim3 grid(nb, d->N);
+    switch (d->P) {
+        case 1: hipLaunchKernelGGL(tail_fwd_k<1>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
+        case 2: hipLaunchKernelGGL(tail_fwd_k<2>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
+        case 3: hipLaunchKernelGGL(tail_fwd_k<3>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
+        default: hipLaunchKernelGGL(tail_fwd_k<4>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
+    }
+    hipLaunchKernelGGL(loss_finalize_k, dim3(1), dim3(512), 0, st, partial, d->P, d->N, nb, sums, wsum, loss);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* weit, const float* wsum, const float* sums,
+                      float gscale, void* stream) {
+    if (!mask || !weit || !wsum || !sums) return -1;
+    if (int rc = tail_check(d)) return rc;
+    tail_groups G;
+    G.ng = 0; G.start[0] = 0;
+    bool used[PN2_TAIL_MAX_MAPS] = {false};
+    size_t lds = 0;
+    for (int j = 0; j < 2 * d->P; ++j) {
+        if (used[j]) continue;
+        if (!d->maps[j].dsrc) return -1;
+        const pn2_tail_map& a = d->maps[j];
+        int g = G.ng++;
+        G.nm[g] = 0;
+        for (int k = j; k < 2 * d->P && G.nm[g] < 4; ++k) {
+            const pn2_tail_map& b = d->maps[k];
+            if (!used[k] && b.h == a.h && b.w == a.w && b.rh == a.rh && b.rw == a.rw) { used[k] = true; G.idx[g][G.nm[g]++] = k; }
+        }
+        for (int q = G.nm[g]; q < 4; ++q) G.idx[g][q] = G.idx[g][0];
+        G.start[g + 1] = G.start[g] + d->N * a.h;
+        // low-res rows a window can touch: window ~ 2/rh + 4 output rows -> (window * rh) + 3 source rows
+        const int win = (int)(2.f / a.rh) + 6, nr = (int)(win * a.rh) + 4;
+        const size_t need = ((size_t)G.nm[g] * nr * a.w + 4 + (size_t)G.nm[g] * d->OW) * 4;
+        if (need > lds) lds = need;
+    }
+    if (lds > 60 * 1024) return -2;
+    hipLaunchKernelGGL(tail_bwd_k, dim3(G.start[G.ng]), dim3(256), lds, (hipStream_t)stream, *d, G, mask, weit, wsum, sums, gscale);
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -155,7 +155,7 @@ def _dsra_tail(m, eng, t1, ra5_fg, ra5_bg):
         f = getattr(m, f"ra{s}_conv4_fg")._build(eng, t, head=True)
         b = getattr(m, f"ra{s}_conv4_bg")._build(eng, t, head=True)
         f = eng.dsra_fuse(f, c_fg, c_bg, m.use_softmax)
-        lat[s] = (final(f, u / sd, 3 - s), final(b, u / sd, 7 - s))
+        lat[s] = (final(f, u / sd, s - 2), final(b, u / sd, s + 2))     # slot = position in the returned 8-tuple
     return [lat[2][0], lat[3][0], l4_fg, l5_fg, lat[2][1], lat[3][1], l4_bg, l5_bg]
 
 

@@ -41,6 +41,16 @@ class ReduceJob(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("gw", C.c_void_p), ("d", PackDesc), ("nsplit", C.c_int), ("accumulate", C.c_int)]
 
 
+class TailMap(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dsrc", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("rh", C.c_float), ("rw", C.c_float),
+                ("accumulate", C.c_int), ("pad_", C.c_int)]
+
+
+class TailDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("OH", C.c_int), ("OW", C.c_int), ("P", C.c_int), ("align_corners", C.c_int), ("pad_", C.c_int),
+                ("maps", TailMap * 16)]
+
+
 class BnDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("Cp", C.c_int), ("C", C.c_int), ("gw", C.c_int), ("gwp", C.c_int),
                 ("eps", C.c_float), ("momentum", C.c_float), ("ldp", C.c_int)]
@@ -86,6 +96,9 @@ SIGNATURES = {
     "pn2_loss_blocks": [I],
     "pn2_structure_loss_fwd": [P, LL, I, P, P, P, P, P, P, I, I, P],
     "pn2_structure_loss_bwd": [P, P, LL, I, P, P, P, P, FL, I, I, P],
+    "pn2_dsra_tail_blocks": [I],
+    "pn2_dsra_tail_fwd": [C.POINTER(TailDesc), P, P, P, P, P, P, P, P],
+    "pn2_dsra_tail_bwd": [C.POINTER(TailDesc), P, P, P, P, FL, P],
     "pn2_binary": [I, I, P, I, P, I, P, I, I, I, I, P],
     "pn2_copy": [I, P, I, I, P, I, I, I, I, P],
     "pn2_nchw_to_nhwc": [I, P, P, I, I, I, I, I, P],
@@ -96,7 +109,8 @@ SIGNATURES = {
 }
 # entry points that return a value rather than a status
 _VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
-                "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks"}
+                "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
+                "pn2_dsra_tail_blocks"}
 
 _lib = None
 WORK = {}     # profiling annotation for the next launch (algorithmic flops / tag), consumed by pn2.profile.Recorder

@@ -36,7 +36,7 @@ def _p(t):
 
 class Act:
     """NHWC activation view.  t: torch tensor (N,H,W,Cp) whose last dim is contiguous; ld = pixel stride."""
-    __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0")
+    __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0", "lat")
 
     def __init__(self, eng, t, C_, gw=None, gwp=None, dt=None, requires_grad=True):
         self.eng, self.t = eng, t
@@ -47,6 +47,7 @@ class Act:
         self.dt = dt if dt is not None else (F32 if t.dtype == torch.float32 else BF16)
         self.grad, self._written, self.child_written, self.requires_grad = None, False, False, requires_grad
         self.parent, self.c0 = None, 0
+        self.lat = None                 # index of the full-resolution lateral output slot this Act is (Engine.lateral_out)
 
     @property
     def grad_written(self):
@@ -281,6 +282,8 @@ class Engine:
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.bn_modules = []            # for num_batches_tracked bookkeeping
         self._lat = None                # contiguous block of the model's full-resolution output maps
+        self.fuse_tail = False          # trainer: leave the lateral up-sampling to the fused DSRA tail kernels (K = 1)
+        self.tail = {}                  # lateral slot -> (low-res source Act, align_corners, rh, rw) when fuse_tail
         self._side, self._keep = None, []
         # experimental: measured no gain on MI355X (wgrad/dgrad grids already fill the chip) and results were not bit-reproducible
         self.use_side = os.environ.get("PN2_SIDE_STREAM", "0") == "1"
@@ -308,7 +311,9 @@ class Engine:
         structure-loss kernels can walk all supervision pairs with a single base pointer + stride."""
         if self._lat is None:
             self._lat = self.alloc((nmaps, N, OH, OW, K), torch.float32)
-        return Act(self, self._lat[j], K, K, K, F32)
+        a = Act(self, self._lat[j], K, K, K, F32)
+        a.lat = j
+        return a
 
     def lateral_block(self):
         return self._lat
@@ -907,6 +912,9 @@ class Engine:
         N, H, W = x.N, x.H, x.W
         y = out if out is not None else Act(self, self.empty(N, OH, OW, x.Cp, x.dt), x.C, x.gw, x.gwp, x.dt)
         ac = 1 if ac else 0
+        if self.fuse_tail and out is not None and out.lat is not None and x.dt == F32 and x.Cp == 1 and x.ld == 1 and OW % 4 == 0 and OW <= 1024:
+            self.tail[out.lat] = (x, ac, rh, rw)      # produced (and differentiated) by pn2_dsra_tail_fwd / _bwd
+            return y
         call.pn2_bilinear_fwd(x.dt, x.ptr, x.ld, y.ptr, y.ld, N, H, W, x.Cp, OH, OW, ac, rh, rw, _stream())
 
         def bwd():

@@ -31,6 +31,47 @@ def loss_backward(buf, dbuf, P, mask, saved, N, HW, gscale=1.0):
     call.pn2_structure_loss_bwd(_p(buf), _p(dbuf), N * HW, P, _p(mask), _p(weit), _p(wsum), _p(sums), float(gscale), N, HW, _stream())
 
 
+def tail_desc(eng, tail, P, N, OH, OW):
+    """pn2_tail_desc for the engine's deferred lateral maps (Engine.tail: slot j -> (low-res Act, align_corners, rh, rw))."""
+    from . import capi
+    d = capi.TailDesc()
+    d.N, d.OH, d.OW, d.P = N, OH, OW, P
+    acs = {t[1] for t in tail.values()}
+    if len(acs) != 1:
+        raise RuntimeError("lateral maps mix align_corners modes")
+    d.align_corners = acs.pop()
+    for j in range(2 * P):
+        x, _, rh, rw = tail[j]
+        m = d.maps[j]
+        m.src, m.h, m.w, m.rh, m.rw = x.t.data_ptr(), x.H, x.W, rh, rw
+    return d
+
+
+def tail_forward(eng, tail, lat, P, mask, N, H, W):
+    """Fused lateral up-sampling + dual structure loss (pn2_dsra_tail_fwd).  Returns (loss[P+1], saved)."""
+    HW = H * W
+    weit = eng.alloc((N, HW), torch.float32)
+    call.pn2_loss_weights(_p(mask), _p(weit), N, H, W, 31, _stream())
+    nb = call.pn2_dsra_tail_blocks(H)
+    partial = eng.alloc((P, N, nb, 5), torch.float32)
+    sums = eng.alloc((P, N, 4), torch.float32)
+    wsum = eng.alloc((N,), torch.float32)
+    loss = torch.empty((P + 1,), dtype=torch.float32, device=lat.device)
+    d = tail_desc(eng, tail, P, N, H, W)
+    call.pn2_dsra_tail_fwd(C.byref(d), _p(lat), _p(mask), _p(weit), _p(partial), _p(sums), _p(wsum), _p(loss), _stream())
+    return loss, (weit, sums, wsum, d)
+
+
+def tail_backward(eng, tail, P, mask, saved, gscale=1.0):
+    """Loss gradient + bilinear adjoint straight into the low-res maps' gradients (pn2_dsra_tail_bwd)."""
+    weit, sums, wsum, d = saved
+    for j in range(2 * P):
+        x = tail[j][0]
+        g, acc = x.grad_sink()
+        d.maps[j].dsrc, d.maps[j].accumulate = g.data_ptr(), acc
+    call.pn2_dsra_tail_bwd(C.byref(d), _p(mask), _p(weit), _p(wsum), _p(sums), float(gscale), _stream())
+
+
 class _StructureLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mask, P, *preds):

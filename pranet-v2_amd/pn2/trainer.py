@@ -62,6 +62,7 @@ class Trainer:
         self.grad_queue = GradQueue(defer_wgrad=mode == "2") if mode in ("1", "2") else None
         self.arena = StepArena() if os.environ.get("PN2_STEP_ARENA", "1") == "1" else None
         self.steps_run = 0
+        self.fuse_tail = os.environ.get("PN2_FUSED_TAIL", "1") == "1"
         # per-shape conv kernel/tile choices, filled by timing the candidates during the first (eager) step; the table is
         # per process (= per GPU) so every trainer in the process launches identical kernels (bit-reproducible runs)
         self.tuner = TUNER if os.environ.get("PN2_AUTOTUNE", "1") == "1" else None
@@ -78,6 +79,7 @@ class Trainer:
             self.arena.begin_step(self.flat.device)
         self.steps_run += 1
         eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, grad_queue=self.grad_queue, arena=self.arena)
+        eng.fuse_tail = self.fuse_tail
         x = eng.from_nchw(images)
         outs = self.model._build(eng, x)
         eng.finish_forward()
@@ -88,12 +90,19 @@ class Trainer:
             lat = torch.stack([o.t for o in outs])
         HW = H * W
         mask = gts.reshape(N, HW).float().contiguous()
-        loss, saved = L.loss_forward(lat, P, mask, N, HW, H, W)
-        dlat = eng.alloc(lat.shape, lat.dtype)
-        L.loss_backward(lat, dlat, P, mask, saved, N, HW, 1.0)
-        for j, o in enumerate(outs):
-            o.grad = dlat[j]
-            o.grad_written = True
+        fused = len(eng.tail) == len(outs) and outs[0].C == 1
+        if eng.tail and not fused:
+            raise RuntimeError("only some lateral maps were deferred to the fused DSRA tail")
+        if fused:       # up-sampling + loss in one pass; the backward goes straight to the low-res maps
+            loss, saved = L.tail_forward(eng, eng.tail, lat, P, mask, N, H, W)
+            L.tail_backward(eng, eng.tail, P, mask, saved, 1.0)
+        else:
+            loss, saved = L.loss_forward(lat, P, mask, N, HW, H, W)
+            dlat = eng.alloc(lat.shape, lat.dtype)
+            L.loss_backward(lat, dlat, P, mask, saved, N, HW, 1.0)
+            for j, o in enumerate(outs):
+                o.grad = dlat[j]
+                o.grad_written = True
         if self.world > 1:
             self.buckets.reset()
         rq = self.grad_queue

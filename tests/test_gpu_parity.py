@@ -438,6 +438,26 @@ def test_table_driven_launches_match_single_launches(fp32, monkeypatch):
         assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
 
 
+def test_fused_dsra_tail_matches_unfused_path(monkeypatch):
+    """pn2_dsra_tail_fwd/_bwd (up-sampling + structure loss + adjoint in two kernels) against the op-by-op path
+    (pn2_bilinear_fwd -> pn2_structure_loss_fwd/_bwd -> pn2_bilinear_bwd), fp32 compute, same weights and batch."""
+    from pn2.trainer import Trainer
+    from oracle import weights as W
+    x, mask = W.synthetic_batch(3, 96, seed=8)
+    xg, mg = x.to(dev), mask.to(dev)
+    res = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("PN2_FUSED_TAIL", fused)
+        tr = Trainer(_fixture_model(fp32=True))
+        loss = tr.forward_backward(xg, mg)
+        torch.cuda.synchronize()
+        res.append((loss.clone(), tr.last_outs.clone(), tr.gflat.clone()))
+    (l0, o0, g0), (l1, o1, g1) = res
+    assert relmax(l1, l0) < 2e-6
+    assert relmax(o1, o0) < 1e-6
+    assert rell2(g1, g0) < 2e-5 and relmax(g1, g0) < 2e-4
+
+
 def test_pack_weights_multi_matches_single_pack():
     """The one-launch tiled repack (pn2_pack_weights_multi) rewrites every cached panel exactly as pn2_pack_weight builds it."""
     from pn2.trainer import Trainer
