@@ -201,6 +201,10 @@ int pn2_adam_tick(float* bias_corr /* [4]: bc1, bc2, b1^t, b2^t */, float beta1,
 
 /* MyTest_med.py:104-111 tail on device: sum of 4 maps already resized -> sigmoid -> min-max -> uint8 */
 int pn2_eval_tail(const float* res, unsigned char* out, float* minmax /* scratch [2 + 2*512] */, long long n, void* stream);
+/* MyTrain_med.py:163-164 / eval.py:22-50 threshold sweep without a numpy round trip of the maps: hist[0..255] = pixel counts per
+ * uint8 prediction value, hist[256..511] = the same restricted to gt > 0.5 (integer atomics: deterministic).  All 256-threshold
+ * metrics of Fmeasure_calu (eval_functions.py:131-166) and the MAE follow from these counts (pn2/evaltail.py).                    */
+int pn2_eval_hist(const unsigned char* pred_u8, const float* gt, long long n, unsigned* hist, void* stream);
 
 #ifdef __cplusplus
 }

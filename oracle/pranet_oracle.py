@@ -294,5 +294,25 @@ def mean_dice(pred_u8, gt):
     return float(dice.mean())
 
 
+def threshold_metrics(pred_u8, gt):
+    """Threshold sweep of eval.py:22-50: for each of the 256 thresholds linspace(1, 0, 256) the (precision, recall, specificity, Dice,
+    F-measure, IoU) of Fmeasure_calu (eval_functions.py:131-166), plus MAE (eval.py:33).  Returns (curves[256, 6], mae)."""
+    import numpy as np
+    pm = pred_u8.astype(np.float64) / 255
+    g = (gt > 0.5).astype(np.float64)
+    cols = np.zeros((256, 6))
+    for i, t in enumerate(np.linspace(1, 0, 256)):
+        lab = pm >= min(t, 1)
+        num_rec, num_no_rec = int(lab.sum()), int((~lab).sum())
+        num_and, num_obj = int((lab & (g == 1)).sum()), g.sum()
+        fn, fp = num_obj - num_and, num_rec - num_and
+        tn = num_no_rec - fn
+        if num_and == 0:
+            continue
+        pre, rec = num_and / num_rec, num_and / num_obj
+        cols[i] = (pre, rec, tn / (tn + fp), 2 * num_and / (num_obj + num_rec), (2.0 * pre * rec) / (pre + rec), num_and / (fn + num_rec))
+    return cols, float(np.mean(np.abs(g - pm)))
+
+
 def clone_sd(sd):
     return OrderedDict((k, v.clone()) for k, v in sd.items())

@@ -424,6 +424,24 @@ __global__ __launch_bounds__(256) void clamp_adam_k(float* __restrict__ p, float
     }
 }
 
+// ------------------------------------------------------------------------------------------ eval metrics
+// Integer histograms of the uint8 prediction map (all pixels / pixels where gt > 0.5).  Every quantity of the reference's 256-threshold
+// sweep (eval.py:22-50, Fmeasure_calu eval_functions.py:131-166: NumRec, NumAnd, num_obj -> precision, recall, specificity, Dice, F, IoU)
+// and the MAE is a function of these 512 counts, so the host finishes in float64 with the reference's own expressions (bit-identical).
+__global__ __launch_bounds__(256) void eval_hist_k(const unsigned char* __restrict__ pred, const float* __restrict__ gt, long long n, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[512];
+    h[threadIdx.x] = 0; h[threadIdx.x + 256] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned v = pred[i];
+        atomicAdd(&h[v], 1u);
+        if (gt[i] > 0.5f) atomicAdd(&h[256 + v], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    if (h[threadIdx.x + 256]) atomicAdd(&hist[threadIdx.x + 256], h[threadIdx.x + 256]);
+}
+
 // ------------------------------------------------------------------------------------------ eval tail
 __global__ __launch_bounds__(256) void minmax_k(const float* __restrict__ x, long long n, float* __restrict__ part) {
     __shared__ float smn[4], smx[4];
@@ -613,6 +631,16 @@ int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* we
     }
     if (lds > 60 * 1024) return -2;
     hipLaunchKernelGGL(tail_bwd_k, dim3(G.start[G.ng]), dim3(256), lds, (hipStream_t)stream, *d, G, mask, weit, wsum, sums, gscale);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_eval_hist(const unsigned char* pred_u8, const float* gt, long long n, unsigned* hist, void* stream) {
+    if (!pred_u8 || !gt || !hist || n < 1) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(hist, 0, 512 * sizeof(unsigned), st) != hipSuccess) return -4;
+    long long g = (n + 256 * 16 - 1) / (256 * 16);
+    hipLaunchKernelGGL(eval_hist_k, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, st, pred_u8, gt, n, hist);
     PN2_CHECK_LAUNCH();
     return 0;
 }

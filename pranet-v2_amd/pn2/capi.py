@@ -106,6 +106,7 @@ SIGNATURES = {
     "pn2_clamp_adam": [P, P, P, P, LL, FL, FL, FL, FL, FL, FL, P, P],
     "pn2_adam_tick": [P, FL, FL, P],
     "pn2_eval_tail": [P, P, P, LL, P],
+    "pn2_eval_hist": [P, P, LL, P, P],
 }
 # entry points that return a value rather than a status
 _VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",

@@ -31,6 +31,12 @@ def _bytes(name, a):
         if name in ("pn2_maxpool3x3s2_fwd", "pn2_maxpool3x3s2_bwd"):
             dt, N, H, W, C, OH, OW = a[0], a[6], a[7], a[8], a[9], a[10], a[11]
             return N * C * (_EL[dt] * (H * W + OH * OW) + OH * OW)
+        if name in ("pn2_dsra_tail_fwd", "pn2_dsra_tail_bwd"):
+            # SURVEY 8(d) fully-fused figure, 17*S per image for K=1 (S = OH*OW*4 B): forward writes the 2P maps and reads the mask,
+            # backward accounts for re-reading the 2P maps (this implementation recomputes them from the low-res logits instead)
+            d = a[0]._obj
+            S = d.N * d.OH * d.OW * 4
+            return S * (2 * d.P + 1) if name.endswith("fwd") else S * 2 * d.P
         if name == "pn2_structure_loss_fwd":
             P, N, HW = a[2], a[9], a[10]
             return N * HW * 4 * (2 * P + 2)
@@ -139,9 +145,10 @@ def measure_step(trainer, x, m, dtype):
     roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4),
                 "traffic": None, "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                 "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
-    tail = [agg[k] for k in ("pn2_structure_loss_fwd", "pn2_structure_loss_bwd") if k in agg]
+    names = ("pn2_dsra_tail_fwd", "pn2_dsra_tail_bwd") if "pn2_dsra_tail_fwd" in agg else ("pn2_structure_loss_fwd", "pn2_structure_loss_bwd")
+    tail = [agg[k] for k in names if k in agg]
     if tail:
         by = sum(t["bytes"] for t in tail); ms = sum(t["ms"] for t in tail)
-        roofline["hbm_loss_tail"] = {"bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                                     "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4)}
+        roofline["hbm_dsra_tail"] = {"kernels": list(names), "bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                     "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_MB": round(by / 1e6, 1), "us": round(ms * 1e3, 1)}
     return {"roofline": roofline, "kernels": kernels}

@@ -252,8 +252,37 @@ def gen_v1(size=96, n=2):
     save("pranet_v1_96.npz", **out)
 
 
+def gen_eval_metrics():
+    """Threshold-sweep metrics of eval.py:22-50 (Fmeasure_calu, eval_functions.py:131-166) + MAE on small synthetic maps."""
+    import importlib
+    cwd = os.getcwd(); os.chdir("/root/reference/binary_seg")
+    try:
+        ef = importlib.import_module("utils.eval_functions")
+    finally:
+        os.chdir(cwd)
+    rng = np.random.default_rng(5)
+    H, Wd = 64, 80
+    yy, xx = np.mgrid[0:H, 0:Wd]
+    blob = (((yy - 30) / 14.0) ** 2 + ((xx - 42) / 22.0) ** 2 < 1).astype(np.float64)
+    smooth = np.clip(255 * (0.75 * blob + 0.25 * rng.random((H, Wd))) + 12 * rng.standard_normal((H, Wd)), 0, 255).astype(np.uint8)
+    cases = {"blob": (smooth, blob), "zero_pred": (np.zeros((H, Wd), np.uint8), blob), "zero_gt": (smooth, np.zeros((H, Wd))),
+             "exact": ((255 * blob).astype(np.uint8), blob), "full": (np.full((H, Wd), 255, np.uint8), np.ones((H, Wd)))}
+    out = {}
+    thr = np.linspace(1, 0, 256)
+    for tag, (pred, gt) in cases.items():
+        gt_mask = (gt > 0.5).astype(np.float64)
+        pm = pred.astype(np.float64) / 255
+        cols = np.array([ef.Fmeasure_calu(pm, gt_mask, t) for t in thr], dtype=np.float64)    # Pr, Rec, Spe, Dice, F, IoU
+        out[tag + "_pred"] = pred; out[tag + "_gt"] = gt.astype(np.float32)
+        out[tag + "_means"] = cols.mean(axis=0)
+        out[tag + "_curves"] = cols
+        out[tag + "_mae"] = np.float64(np.mean(np.abs(gt_mask - pm)))
+    save("eval_metrics.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["manifest", "loss", "dsra", "blocks", "m96", "m352", "v1"]
+    which = sys.argv[1:] or ["manifest", "loss", "dsra", "blocks", "m96", "m352", "v1", "evalm"]
+    if "evalm" in which: gen_eval_metrics()
     if "manifest" in which: gen_manifest()
     if "loss" in which: gen_structure_loss()
     if "dsra" in which: gen_dsra()

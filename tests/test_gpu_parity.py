@@ -372,6 +372,26 @@ def test_eval_tail_and_dice_on_train_mode_logits():
     assert abs(O.mean_dice(ours, gt) - O.mean_dice(ref, gt)) < 1e-3
 
 
+def test_threshold_metrics_vs_reference_and_oracle():
+    """GPU histogram sweep == the imported reference's Fmeasure_calu curves (golden) bit for bit, and == the oracle at 352x352."""
+    from pn2.evaltail import threshold_metrics
+    from oracle import pranet_oracle as O
+    z = np.load(os.path.join(G, "eval_metrics.npz"))
+    for tag in ("blob", "zero_pred", "zero_gt", "exact", "full"):
+        r = threshold_metrics(torch.from_numpy(z[tag + "_pred"]).to(dev), torch.from_numpy(z[tag + "_gt"]).to(dev))
+        assert np.array_equal(r["curves"], z[tag + "_curves"], equal_nan=True), tag
+        assert abs(r["mae"] - float(z[tag + "_mae"])) < 1e-12
+        if tag != "full":
+            assert r["meanDic"] == float(z[tag + "_means"][3]) and r["meanIoU"] == float(z[tag + "_means"][5])
+    rng = np.random.default_rng(11)
+    pred = rng.integers(0, 256, (352, 352), dtype=np.uint8)
+    gt = (rng.random((352, 352)) < 0.2).astype(np.float32)
+    r = threshold_metrics(torch.from_numpy(pred).to(dev), torch.from_numpy(gt).to(dev))
+    cols, mae = O.threshold_metrics(pred, gt)
+    assert np.array_equal(r["curves"], cols) and abs(r["mae"] - mae) < 1e-12
+    assert abs(r["meanDic"] - O.mean_dice(pred, gt)) < 1e-12
+
+
 def test_v1_forward_vs_reference():
     import pn2
     from lib.PraNet_Res2Net import PraNet

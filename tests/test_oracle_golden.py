@@ -149,3 +149,16 @@ def test_v1_forward():
     outs = O.pranet_v1_forward(P, x, True)
     for i, o in enumerate(outs):
         assert (o - T(z[f"out{i}"])).abs().max() < 1e-4, i
+
+
+def test_threshold_metrics_oracle_matches_reference_curves():
+    """oracle.threshold_metrics == the imported reference's Fmeasure_calu sweep (tests/golden/make_golden.py evalm), NaNs included."""
+    import warnings
+    z = np.load(os.path.join(G, "eval_metrics.npz"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag in ("blob", "zero_pred", "zero_gt", "exact", "full"):
+            cols, mae = O.threshold_metrics(z[tag + "_pred"], z[tag + "_gt"])
+            assert np.array_equal(cols, z[tag + "_curves"], equal_nan=True), tag
+            assert mae == float(z[tag + "_mae"])
+            assert abs(O.mean_dice(z[tag + "_pred"], z[tag + "_gt"]) - float(z[tag + "_means"][3])) < 1e-12
