@@ -22,6 +22,28 @@ TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
 TUNER = {}      # process-wide conv shape -> tuned kernel/tile code (see Engine._tune_gemm)
 
 
+def load_tuner(path):
+    """Merge a saved tuning table (PN2_TUNE_CACHE=<file>) so that a run does not have to time the candidates again."""
+    import ast
+    import json
+    try:
+        with open(path) as f:
+            for k, v in json.load(f).items():
+                TUNER.setdefault(ast.literal_eval(k), tuple(v) if isinstance(v, list) else v)
+    except (OSError, ValueError):
+        pass
+
+
+def save_tuner(path):
+    import json
+    with open(path, "w") as f:
+        json.dump({repr(k): v for k, v in TUNER.items()}, f)
+
+
+if os.environ.get("PN2_TUNE_CACHE"):
+    load_tuner(os.environ["PN2_TUNE_CACHE"])
+
+
 def rup(v, m):
     return (v + m - 1) // m * m
 

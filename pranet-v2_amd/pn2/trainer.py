@@ -66,6 +66,7 @@ class Trainer:
         # per-shape conv kernel/tile choices, filled by timing the candidates during the first (eager) step; the table is
         # per process (= per GPU) so every trainer in the process launches identical kernels (bit-reproducible runs)
         self.tuner = TUNER if os.environ.get("PN2_AUTOTUNE", "1") == "1" else None
+        self._tuned = len(self.tuner) if self.tuner is not None else 0
 
     # ------------------------------------------------------------------ pieces
     def _grad_view(self, p):
@@ -122,6 +123,10 @@ class Trainer:
         if self.world > 1:
             self.buckets.finish()
         self.last_outs = lat
+        if self.tuner is not None and len(self.tuner) != self._tuned and os.environ.get("PN2_TUNE_CACHE"):
+            from .engine import save_tuner
+            save_tuner(os.environ["PN2_TUNE_CACHE"])
+        self._tuned = len(self.tuner) if self.tuner is not None else 0
         return loss
 
     def optimizer_step(self):
