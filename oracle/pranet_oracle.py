@@ -143,10 +143,76 @@ def dsra_fuse(fg, crop_fg, crop_bg, use_softmax=True):
     return fg + fg * (crop_fg - crop_bg)
 
 
-def pranet_v2_forward(P, x, training, use_softmax=True, sem_downsample=1):
+# ------------------------------------------------------------------------------------------------ PVTv2 encoder (lib/pvtv2.py)
+def _ln(P, name, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], eps)
+
+
+def _lin(P, name, x):
+    return F.linear(x, P[name + ".weight"], P[name + ".bias"])
+
+
+def pvt_attention(P, p, x, H, W, heads, sr):
+    """Attention.forward (pvtv2.py:90-111): spatial-reduction attention; dropout rates are 0 in pvt_v2_b2 (:402-406)."""
+    B, N, C = x.shape
+    hd = C // heads
+    q = _lin(P, p + "q", x).reshape(B, N, heads, hd).permute(0, 2, 1, 3)
+    if sr > 1:
+        x_ = x.permute(0, 2, 1).reshape(B, C, H, W)
+        x_ = F.conv2d(x_, P[p + "sr.weight"], P[p + "sr.bias"], stride=sr).reshape(B, C, -1).permute(0, 2, 1)
+        x_ = _ln(P, p + "norm", x_, 1e-5)                      # nn.LayerNorm(dim) default eps (:71)
+    else:
+        x_ = x
+    kv = _lin(P, p + "kv", x_).reshape(B, -1, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    k, v = kv[0], kv[1]
+    attn = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
+    return _lin(P, p + "proj", (attn @ v).transpose(1, 2).reshape(B, N, C))
+
+
+def pvt_mlp(P, p, x, H, W):
+    """Mlp.forward (pvtv2.py:42-49) with DWConv (:368-374) and exact GELU."""
+    B, N, _ = x.shape
+    x = _lin(P, p + "fc1", x)
+    Ch = x.shape[-1]
+    x = F.conv2d(x.transpose(1, 2).reshape(B, Ch, H, W), P[p + "dwconv.dwconv.weight"], P[p + "dwconv.dwconv.bias"], padding=1, groups=Ch)
+    x = F.gelu(x.flatten(2).transpose(1, 2))
+    return _lin(P, p + "fc2", x)
+
+
+def pvt_block(P, p, x, H, W, heads, sr):
+    """Block.forward (pvtv2.py:147-151) with DropPath = identity (drop_path forced to 0 for parity)."""
+    x = x + pvt_attention(P, p + "attn.", _ln(P, p + "norm1", x, 1e-6), H, W, heads, sr)
+    return x + pvt_mlp(P, p + "mlp.", _ln(P, p + "norm2", x, 1e-6), H, W)
+
+
+def pvt_features(P, p, x, cfg=None):
+    """PyramidVisionTransformerImpr.forward_features (pvtv2.py:307-341) for pvt_v2_b2 (:399-406): four NCHW feature maps."""
+    from oracle.weights import PVT_B2
+    cfg = cfg or PVT_B2
+    B = x.shape[0]
+    outs = []
+    for i in range(4):
+        k, s = (7, 4) if i == 0 else (3, 2)
+        x = F.conv2d(x, P[f"{p}patch_embed{i + 1}.proj.weight"], P[f"{p}patch_embed{i + 1}.proj.bias"], stride=s, padding=k // 2)
+        H, W = x.shape[2:]
+        x = _ln(P, f"{p}patch_embed{i + 1}.norm", x.flatten(2).transpose(1, 2), 1e-5)        # OverlapPatchEmbed.norm default eps (:169)
+        for j in range(cfg["depths"][i]):
+            x = pvt_block(P, f"{p}block{i + 1}.{j}.", x, H, W, cfg["num_heads"][i], cfg["sr_ratios"][i])
+        x = _ln(P, f"{p}norm{i + 1}", x, 1e-6)
+        x = x.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+        outs.append(x)
+    return outs
+
+
+def pvt_pranet_v2_forward(P, x, training, use_softmax=True, sem_downsample=1):
+    """PVT_PraNet_V2.forward (pranet.py:205-263): PVTv2-B2 features, then exactly the PraNet_V2 heads."""
+    return pranet_v2_forward(P, x, training, use_softmax, sem_downsample, features=lambda P_, x_, ctx: pvt_features(P_, "backbone.", x_))
+
+
+def pranet_v2_forward(P, x, training, use_softmax=True, sem_downsample=1, features=None):
     """PraNet_V2.forward (pranet.py:329-417).  Mutates BN running stats in P when training."""
     ctx = Ctx(training)
-    x1, x2, x3, x4 = res2net_features(P, "backbone.", x, ctx)
+    x1, x2, x3, x4 = features(P, x, ctx) if features is not None else res2net_features(P, "backbone.", x, ctx)
     x2_rfb = rfb(P, "rfb2_1.", x2, ctx)
     x3_rfb = rfb(P, "rfb3_1.", x3, ctx)
     x4_rfb = rfb(P, "rfb4_1.", x4, ctx)

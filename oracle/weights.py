@@ -123,6 +123,61 @@ def manifest_pranet_v1(channel=32):
     return m
 
 
+def _ln(m, name, c):
+    m[name + ".weight"] = (c,)
+    m[name + ".bias"] = (c,)
+
+
+def _linear(m, name, cout, cin):
+    m[name + ".weight"] = (cout, cin)
+    m[name + ".bias"] = (cout,)
+
+
+PVT_B2 = dict(embed_dims=(64, 128, 320, 512), num_heads=(1, 2, 5, 8), mlp_ratios=(8, 8, 4, 4), depths=(3, 4, 6, 3), sr_ratios=(8, 4, 2, 1))
+
+
+def _pvt_v2(m, p, cfg=PVT_B2, in_chans=3):
+    """PyramidVisionTransformerImpr registration order (lib/pvtv2.py:197-243; Block :114-130, Attention :52-72, Mlp :14-23,
+    OverlapPatchEmbed :154-170, DWConv :363-366)."""
+    dims = cfg["embed_dims"]
+    for i in range(4):
+        k = 7 if i == 0 else 3
+        _conv(m, f"{p}patch_embed{i + 1}.proj", dims[i], in_chans if i == 0 else dims[i - 1], k, k, bias=True)
+        _ln(m, f"{p}patch_embed{i + 1}.norm", dims[i])
+    for i in range(4):
+        d, hid, sr = dims[i], dims[i] * cfg["mlp_ratios"][i], cfg["sr_ratios"][i]
+        for j in range(cfg["depths"][i]):
+            q = f"{p}block{i + 1}.{j}."
+            _ln(m, q + "norm1", d)
+            _linear(m, q + "attn.q", d, d); _linear(m, q + "attn.kv", 2 * d, d); _linear(m, q + "attn.proj", d, d)
+            if sr > 1:
+                _conv(m, q + "attn.sr", d, d, sr, sr, bias=True)
+                _ln(m, q + "attn.norm", d)
+            _ln(m, q + "norm2", d)
+            _linear(m, q + "mlp.fc1", hid, d)
+            _conv(m, q + "mlp.dwconv.dwconv", hid, 1, 3, 3, bias=True)
+            _linear(m, q + "mlp.fc2", d, hid)
+        _ln(m, f"{p}norm{i + 1}", d)
+
+
+def manifest_pvt_pranet_v2(num_class=1, channel=32):
+    """PVT_PraNet_V2 (lib/pranet.py:129-203): key -> shape in state_dict() order."""
+    m = OrderedDict()
+    _conv(m, "conv.0", 3, 1, 1, 1, bias=True); _bn(m, "conv.1", 3)
+    _pvt_v2(m, "backbone.")
+    _rfb(m, "rfb2_1.", 128, channel); _rfb(m, "rfb3_1.", 320, channel); _rfb(m, "rfb4_1.", 512, channel)
+    _agg(m, "agg1.", channel, num_class)
+    _basic(m, "ra4_conv1", 512, 256, 1)
+    for i in (2, 3, 4):
+        _basic(m, f"ra4_conv{i}", 256, 256, 5)
+    _basic(m, "ra4_conv5_fg", 256, num_class, 1); _basic(m, "ra4_conv5_bg", 256, num_class, 1)
+    for s, cin in ((3, 320), (2, 128)):
+        _basic(m, f"ra{s}_conv1", cin, 64, 1)
+        _basic(m, f"ra{s}_conv2", 64, 64, 3); _basic(m, f"ra{s}_conv3", 64, 64, 3)
+        _basic(m, f"ra{s}_conv4_fg", 64, num_class, 3); _basic(m, f"ra{s}_conv4_bg", 64, num_class, 3)
+    return m
+
+
 def make_state_dict(manifest, seed=0):
     """Deterministic non-trivial weights: every tensor from its own CPU generator.
 

@@ -252,6 +252,75 @@ def gen_v1(size=96, n=2):
     save("pranet_v1_96.npz", **out)
 
 
+PVT_PROBES = [
+    "backbone.patch_embed1.proj.weight", "backbone.patch_embed1.proj.bias", "backbone.patch_embed1.norm.weight",
+    "backbone.block1.0.norm1.weight", "backbone.block1.0.attn.q.weight", "backbone.block1.0.attn.kv.bias", "backbone.block1.0.attn.sr.weight",
+    "backbone.block1.0.attn.norm.bias", "backbone.block1.2.mlp.fc1.weight", "backbone.block1.2.mlp.dwconv.dwconv.weight",
+    "backbone.block2.1.attn.proj.weight", "backbone.block2.1.mlp.dwconv.dwconv.bias", "backbone.block2.3.mlp.fc2.bias", "backbone.patch_embed3.proj.weight",
+    "backbone.block3.2.attn.kv.weight", "backbone.block3.5.norm2.bias", "backbone.block4.0.attn.q.bias", "backbone.block4.0.mlp.fc1.weight",
+    "backbone.block4.2.mlp.fc2.weight", "backbone.norm2.weight", "backbone.norm4.bias",
+    "rfb2_1.branch0.0.conv.weight", "rfb4_1.conv_cat.conv.weight", "agg1.conv5_fg.weight", "ra4_conv1.conv.weight", "ra2_conv4_fg.conv.weight",
+]
+
+
+def _ref_pvt_model(dtype=torch.float32):
+    """Reference PVT_PraNet_V2 without its checkpoint file: torch.load patched to {} around construction; DropPath off."""
+    orig = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        m = R.pranet.PVT_PraNet_V2(num_class=1)
+    finally:
+        torch.load = orig
+    m.backbone.reset_drop_path(0.0)          # stochastic depth is the one RNG-dependent op of the path; parity is pinned with it off
+    return m.to(dtype)
+
+
+def gen_pvt(size=96, n=2):
+    man = W.manifest_pvt_pranet_v2(1)
+    model = _ref_pvt_model()
+    ref = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert list(ref.items()) == [(k, list(v)) for k, v in man.items()], "manifest mismatch (PVT)"
+    with open(os.path.join(HERE, "manifest_pvt.json"), "w") as f:
+        json.dump({"pvt_pranet_v2_k1": ref, "n_params": sum(p.numel() for p in model.parameters())}, f)
+    sd0 = W.make_state_dict(man, seed=3)
+    model.load_state_dict(sd0, strict=True)
+    model.train()
+    x, mask = W.synthetic_batch(n, size, seed=4321)
+    out = {"size": np.array(size), "n": np.array(n)}
+    # backbone features alone (4 NCHW maps)
+    with torch.no_grad():
+        feats = model.backbone(x)
+    for i, f_ in enumerate(feats):
+        out[f"feat{i}"] = npy(f_)
+    outs = model(x)
+    losses = [R.train.structure_loss(outs[i], outs[i + 4], mask, 1 - mask) for i in range(4)]
+    loss = losses[3] + losses[2] + losses[1] + losses[0]
+    loss.backward()
+    names = dict(model.named_parameters())
+    out["losses"] = np.array([float(l) for l in losses]); out["loss"] = npy(loss)
+    for i, o in enumerate(outs):
+        out[f"out{i}"] = npy(o)
+    for k in PVT_PROBES:
+        out["graw." + k] = head(names[k].grad)
+        out["grawnorm." + k] = npy(names[k].grad.norm())
+    m64 = _ref_pvt_model()
+    m64.load_state_dict(sd0, strict=True)
+    m64 = m64.double().train()
+    o64 = m64(x.double())
+    l64 = [R.train.structure_loss(o64[i], o64[i + 4], mask.double(), 1 - mask.double()) for i in range(4)]
+    (l64[3] + l64[2] + l64[1] + l64[0]).backward()
+    n64 = dict(m64.named_parameters())
+    out["f64.losses"] = np.array([float(l) for l in l64])
+    for i, f_ in enumerate(m64.backbone(x.double())):
+        out[f"f64.feat{i}"] = npy(f_).astype(np.float64)
+    for i, o in enumerate(o64):
+        out[f"f64.out{i}"] = npy(o).astype(np.float64)
+    for k in PVT_PROBES:
+        out["f64.graw." + k] = head(n64[k].grad)
+        out["f64.grawnorm." + k] = npy(n64[k].grad.norm())
+    save("pvt_pranet_v2_96.npz", **out)
+
+
 def gen_eval_metrics():
     """Threshold-sweep metrics of eval.py:22-50 (Fmeasure_calu, eval_functions.py:131-166) + MAE on small synthetic maps."""
     import importlib
@@ -281,8 +350,9 @@ def gen_eval_metrics():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["manifest", "loss", "dsra", "blocks", "m96", "m352", "v1", "evalm"]
+    which = sys.argv[1:] or ["manifest", "loss", "dsra", "blocks", "m96", "m352", "v1", "evalm", "pvt"]
     if "evalm" in which: gen_eval_metrics()
+    if "pvt" in which: gen_pvt()
     if "manifest" in which: gen_manifest()
     if "loss" in which: gen_structure_loss()
     if "dsra" in which: gen_dsra()

@@ -162,3 +162,31 @@ def test_threshold_metrics_oracle_matches_reference_curves():
             assert np.array_equal(cols, z[tag + "_curves"], equal_nan=True), tag
             assert mae == float(z[tag + "_mae"])
             assert abs(O.mean_dice(z[tag + "_pred"], z[tag + "_gt"]) - float(z[tag + "_means"][3])) < 1e-12
+
+
+def test_pvt_manifest_and_oracle_match_reference():
+    """PVT_PraNet_V2: state_dict manifest and the oracle's PVTv2-B2 restatement (features, 8 outputs, loss, gradient probes) against the
+    vectors the imported reference produced (tests/golden/make_golden.py pvt; DropPath off)."""
+    ref = json.load(open(os.path.join(G, "manifest_pvt.json")))
+    man = W.manifest_pvt_pranet_v2(1)
+    assert [(k, list(v)) for k, v in man.items()] == list(ref["pvt_pranet_v2_k1"].items())
+    z = np.load(os.path.join(G, "pvt_pranet_v2_96.npz"))
+    sd = W.make_state_dict(man, seed=3)
+    x, mask = W.synthetic_batch(2, 96, seed=4321)
+    P = O.clone_sd(sd)
+    with torch.no_grad():
+        for i, f in enumerate(O.pvt_features(P, "backbone.", x)):
+            assert float((f - torch.from_numpy(z[f"feat{i}"])).abs().max()) < 1e-5
+    for k, v in P.items():
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    outs = O.pvt_pranet_v2_forward(P, x, True)
+    for i, o in enumerate(outs):
+        assert float((o.detach() - torch.from_numpy(z[f"out{i}"])).abs().max()) < 1e-4
+    loss = O.total_loss(outs, mask)
+    assert abs(float(loss) - float(z["loss"])) < 1e-4
+    loss.backward()
+    for k in z.files:
+        if k.startswith("grawnorm."):
+            g = P[k[len("grawnorm."):]].grad
+            assert abs(float(g.norm()) - float(z[k])) <= 2e-3 * float(z[k]) + 1e-6, k
