@@ -186,6 +186,38 @@ int pn2_dsra_tail_fwd(const pn2_tail_desc* d, float* lat, const float* mask, con
 int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* weit, const float* wsum, const float* sums,
                       float gscale, void* stream);
 
+/* ---------------------------------------------------------------------------------------------- PVTv2 encoder (lib/pvtv2.py)
+ * Tokens [B, N, C] of the reference are NHWC pixels here.  The nn.Linear layers run as 1x1 pn2_conv_gemm / pn2_conv_wgrad.      */
+/* nn.LayerNorm over the C channels of each of M rows (pvtv2.py:71,119,126,169,224-247); mean/rstd [M] fp32 are kept for the backward */
+int pn2_layernorm_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* gamma, const float* beta, float eps,
+                      float* mean, float* rstd, void* stream);
+int pn2_ln_slots(int dt, int C);                /* rows a workgroup handles at a time (row unit of the partial buffers) */
+int pn2_rows_blocks(int M, int unit);           /* partial rows (= workgroups) of the column-reduction kernels below */
+/* dx (+)= LN backward ; pg/pb [nblk][C] partial dgamma/dbeta rows, nblk = pn2_rows_blocks(M, pn2_ln_slots(dt, C)); finish with pn2_colsum_finalize */
+int pn2_layernorm_bwd(int dt, const void* dy, int ld_dy, const void* x, int ld_x, int M, int C, const float* gamma, const float* mean, const float* rstd,
+                      void* dx, int ld_dx, int accumulate_dx, float* pg, float* pb, int nblk, void* stream);
+/* bias gradients: partial[nblk][C] = per-block column sums of dy [M][C] (nblk = pn2_rows_blocks(M, pn2_colsum_unit(dt, C))), then
+ * out[c] (+)= sum_b partial[b*ld + c] in a fixed order */
+int pn2_colsum_unit(int dt, int C);
+int pn2_colsum(int dt, const void* dy, int ld, int M, int C, float* partial, int nblk, void* stream);
+int pn2_colsum_finalize(const float* partial, int nblk, int C, int ld, float* out, int accumulate, void* stream);
+/* DWConv (pvtv2.py:363-374, groups = C, 3x3, pad 1) [+ bias] [+ nn.GELU of Mlp.forward :45]: z = dw(x) + b (kept for the backward),
+ * y_gelu = gelu(z) when non-null.  flip=1 correlates with the mirrored kernel = data gradient of the same conv.  w [C][9] fp32. */
+int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z, void* y_gelu, int N, int H, int W, int C, int flip, int accumulate, void* stream);
+int pn2_gelu_bwd(int dt, const void* dy, const void* z, void* dz, long long n, void* stream);      /* dz = dy * gelu'(z), exact erf form */
+/* partial[nblk][C*10]: columns c*9+tap = dW, C*9+c = dbias ; nblk = pn2_rows_blocks(N*H*W, pn2_colsum_unit(dt, C)) ; finish with pn2_colsum_finalize */
+int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, int nblk, int N, int H, int W, int C, void* stream);
+/* Spatial-reduction attention (Attention.forward pvtv2.py:90-111), head_dim 64, Nkv <= 256:
+ * q [B][Nq][heads*64] ; kv [B][Nkv][2*heads*64] (k then v, heads inner, as the reference's reshape(B,-1,2,heads,hd)) ;
+ * out = softmax(q k^T * scale) v, heads concatenated ; lse [B][heads][Nq] fp32 saved for the backward.
+ * Backward scratch: P, dS [B][heads][Nq][roundup(Nkv,64)] fp32. */
+/* DropPath (stochastic depth, pvtv2.py:125,148-149): y[n] = x[n] * scale[n], scale[n] = bernoulli(keep)/keep drawn by the caller; its own adjoint */
+int pn2_scale_samples(int dt, const void* x, void* y, const float* scale, int N, long long elems_per_sample, void* stream);
+int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, void* out, int ld_o, float* lse, int B, int Nq, int Nkv, int heads, int head_dim,
+                 float scale, void* stream);
+int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, const void* dout, int ld_do, const float* lse, void* dq, int ld_dq, void* dkv, int ld_dkv,
+                 float* P_scratch, float* dS_scratch, int B, int Nq, int Nkv, int heads, int head_dim, float scale, void* stream);
+
 /* ---------------------------------------------------------------------------------------------- element-wise / layout */
 int pn2_binary(int dt, int op /*0 add,1 mul*/, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream);
 int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld_d, int M, int C, int accumulate, void* stream);

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
 
     GatherGeom gg;
     gg.H = d.H; gg.W = d.W; gg.OH = d.OH; gg.OW = d.OW; gg.KH = d.KH; gg.KW = d.KW; gg.stride = d.stride;
-    gg.sshift = d.stride == 2 ? 1 : 0; gg.pad_h = d.pad_h; gg.pad_w = d.pad_w; gg.dil_h = d.dil_h; gg.dil_w = d.dil_w;
+    gg.sshift = __builtin_ctz(d.stride); gg.pad_h = d.pad_h; gg.pad_w = d.pad_w; gg.dil_h = d.dil_h; gg.dil_w = d.dil_w;
     gg.transposed = d.transposed;
 
     // ---- per-thread A rows
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
 
     GatherGeom gg;
     gg.H = d.H; gg.W = d.W; gg.OH = d.OH; gg.OW = d.OW; gg.KH = d.KH; gg.KW = d.KW; gg.stride = d.stride;
-    gg.sshift = d.stride == 2 ? 1 : 0; gg.pad_h = d.pad_h; gg.pad_w = d.pad_w; gg.dil_h = d.dil_h; gg.dil_w = d.dil_w;
+    gg.sshift = __builtin_ctz(d.stride); gg.pad_h = d.pad_h; gg.pad_w = d.pad_w; gg.dil_h = d.dil_h; gg.dil_w = d.dil_w;
     gg.transposed = d.transposed;
 
     // this thread's DMA lanes: row (tid>>3) of every 32-row group, LDS chunk slot (tid&7) which holds GLOBAL chunk cg
@@ -1207,7 +1207,7 @@ int pn2_conv_stat_blocks(int m, int cout, int dtype) { const int bm = pn2_conv_t
 
 int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, void* stream) {
     if (!in || !wp || !out || !d) return -1;
-    if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2)) return -2;
+    if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
     if ((d->flags & PN2_CONV_STATS) && (!psum || !psq)) return -1;
     if (dtype == PN2_BF16) return gemm_dispatch<bf16_t>(in, wp, out, psum, psq, *d, (hipStream_t)stream);
     if (dtype == PN2_F32) return gemm_dispatch<float>(in, wp, out, psum, psq, *d, (hipStream_t)stream);

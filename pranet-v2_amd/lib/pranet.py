@@ -210,8 +210,7 @@ class PraNet_V2(nn.Module):
 
 
 class PVT_PraNet_V2(nn.Module):
-    """PVTv2-B2 variant (reference :129-263).  Heads are shared with PraNet_V2; the transformer encoder kernels are
-    the next row of the build plan, so construction is available but forward raises."""
+    """PVTv2-B2 variant (reference :129-263): the transformer encoder of lib/pvtv2.py feeding exactly the PraNet_V2 heads."""
 
     def __init__(self, channel=32, num_class=3, sem_downsample=1, use_softmax=True):
         super().__init__()
@@ -249,6 +248,11 @@ class PVT_PraNet_V2(nn.Module):
         self.ra2_conv4_fg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
         self.ra2_conv4_bg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
 
+    def hot_parameters(self):
+        """Parameters that forward() touches (self.conv only serves 1-channel inputs — reference :190-191)."""
+        return [p for n, p in self.named_parameters() if not n.startswith('conv.')]
+
+    _build = PraNet_V2._build           # backbone._build_features -> RFBs -> aggregation -> DSRA tail: identical head code (:193-263)
+
     def forward(self, x, segSize=None):
-        raise NotImplementedError("PVT_PraNet_V2.forward: the PVTv2-B2 encoder kernels (LayerNorm, SR-attention, DW-conv) are the next "
-                                  "scope row (SURVEY.md §8 a11 / f2); there is no PyTorch fallback by design")
+        return run_module(self._build, [x], self.hot_parameters(), self.training)

@@ -56,6 +56,19 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _w4(w):
+    """OIHW shape of a conv weight; an nn.Linear weight [out, in] is a 1x1 conv weight with the same memory layout."""
+    return tuple(w.shape) if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
+
+
+class _LinearAsConv:
+    """nn.Linear over the channel axis of NHWC tokens == 1x1 convolution (pvtv2.py:19,22,62-65)."""
+    __slots__ = ("weight", "stride", "padding", "dilation", "groups")
+
+    def __init__(self, lin):
+        self.weight, self.stride, self.padding, self.dilation, self.groups = lin.weight, (1, 1), (0, 0), (1, 1), 1
+
+
 class Act:
     """NHWC activation view.  t: torch tensor (N,H,W,Cp) whose last dim is contiguous; ld = pixel stride."""
     __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0", "lat")
@@ -457,7 +470,7 @@ class Engine:
 
     # ------------------------------------------------------------------ weights
     def _pack_desc(self, w, x_map, out_map, transposed):
-        Cout, Cin, KH, KW = w.shape
+        Cout, Cin, KH, KW = _w4(w)
         gw_in, gwp_in, Cin_p = x_map
         gw_out, gwp_out, Cout_p = out_map
         d = capi.PackDesc()
@@ -580,7 +593,7 @@ class Engine:
         y_dt/y_C: fp32 K-channel head outputs (physical raw output stays padded to 8).
         """
         w = conv.weight
-        Cout, Cin, KH, KW = w.shape
+        Cout, Cin, KH, KW = _w4(w)
         sh, sw = conv.stride
         assert sh == sw and conv.groups == 1
         ph, pw = conv.padding
@@ -629,8 +642,11 @@ class Engine:
             else:
                 call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), st)
         elif bias is not None:
-            shift = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
-            shift[:Cout] = bias.detach()
+            if Cout_p == Cout:
+                shift = bias.detach()
+            else:
+                shift = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
+                shift[:Cout] = bias.detach()
 
         y_dt = self.dt if y_dt is None else y_dt
         if out is None:
@@ -673,15 +689,21 @@ class Engine:
                 coef = None
                 if bn is not None:
                     raise RuntimeError("backward through eval-mode BatchNorm is not supported")
-                if bias is not None:
-                    gb, gba = self.pgrads.sink(bias)
+                if bias is not None and out.dt == F32 and self.dt != F32 or (bias is not None and Cdy != Cout_p):
+                    gb, gba = self.pgrads.sink(bias)          # fp32 K-channel head maps: sum the fp32 gradient itself
                     call.pn2_bias_grad(_p(dy), M, Cdy, _p(gb), gba, st)
+                    bias_done = True
+                else:
+                    bias_done = bias is None
             rg, racc = (None, 0)
             if residual is not None and residual.requires_grad:
                 rg, racc = residual.grad_sink()
             call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
                                   _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
                                   _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), st)
+            if not train_bn and not bias_done:                 # biased conv / nn.Linear: db = column sums of dz
+                gb, gba = self.pgrads.sink(bias)
+                self.colsum(draw, M, Cout_p, Cout, gb, gba)
             # ---- weight gradient
             wd = capi.WgradDesc()
             wd.N, wd.H, wd.W, wd.OH, wd.OW = N, H, W, OH, OW
@@ -697,7 +719,7 @@ class Engine:
             rd.Rp = wd.Rp
             wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd, nsplit, w.shape)
             rq = self.grad_queue
-            slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab(id(w), (nsplit, wd.Rp, wd.Kp), self.dev)
+            slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab((id(w), x.M), (nsplit, wd.Rp, wd.Kp), self.dev)
             gwt, gwa = self.pgrads.sink(w)
             # wgrad (+ slab reduce) only feeds the parameter gradient: run it on the side stream so that it overlaps the dgrad /
             # BN-backward chain of the layers below instead of sitting on the critical path
@@ -867,6 +889,120 @@ class Engine:
                 call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), nul, nul, C.byref(dd), st)
         self.record(bwd)
         return outs
+
+    # ------------------------------------------------------------------ PVTv2 encoder ops (lib/pvtv2.py)
+    def colsum(self, t, M, Cp, Cc, out, accumulate):
+        """out[:Cc] (+)= column sums of the [M][Cp] tensor t (bias gradients)."""
+        st = _stream()
+        dt = F32 if t.dtype == torch.float32 else BF16
+        nb = call.pn2_rows_blocks(M, call.pn2_colsum_unit(dt, Cp))
+        part = self.fbuf(nb, Cp)
+        call.pn2_colsum(dt, _p(t), Cp, M, Cp, _p(part), nb, st)
+        call.pn2_colsum_finalize(_p(part), nb, Cc, Cp, _p(out), accumulate, st)
+
+    def linear(self, x, lin, residual=None):
+        """nn.Linear (+ residual add) over the channels of NHWC tokens."""
+        return self.conv_bn_act(x, _LinearAsConv(lin), None, bias=lin.bias, residual=residual)
+
+    def conv_bias(self, x, conv):
+        """biased nn.Conv2d without BN (patch embedding pvtv2.py:167, spatial reduction :70)."""
+        return self.conv_bn_act(x, conv, None, bias=conv.bias)
+
+    def layernorm(self, x, ln):
+        """nn.LayerNorm over the channel axis (tokens = pixels)."""
+        assert x.Cp == x.C and x.ld == x.Cp and tuple(ln.normalized_shape) == (x.C,)
+        M, Cc, st = x.M, x.C, _stream()
+        y = Act(self, self.empty(x.N, x.H, x.W, Cc), Cc, Cc, Cc, self.dt)
+        mean, rstd = self.fbuf(M), self.fbuf(M)
+        call.pn2_layernorm_fwd(self.dt, x.ptr, x.ld, y.ptr, y.ld, M, Cc, _p(ln.weight), _p(ln.bias), float(ln.eps), _p(mean), _p(rstd), st)
+
+        def bwd():
+            st = _stream()
+            dy = y.grad_buf()
+            assert y.grad_written
+            nb = call.pn2_rows_blocks(M, call.pn2_ln_slots(self.dt, Cc))
+            pg, pb = self.fbuf(nb, Cc), self.fbuf(nb, Cc)
+            gx, acc = x.grad_sink() if x.requires_grad else (self.empty(x.N, x.H, x.W, Cc), 0)
+            call.pn2_layernorm_bwd(self.dt, _p(dy), dy.stride(2), x.ptr, x.ld, M, Cc, _p(ln.weight), _p(mean), _p(rstd), _p(gx), gx.stride(2), acc,
+                                   _p(pg), _p(pb), nb, st)
+            gg, ga = self.pgrads.sink(ln.weight)
+            gb, gba = self.pgrads.sink(ln.bias)
+            call.pn2_colsum_finalize(_p(pg), nb, Cc, Cc, _p(gg), ga, st)
+            call.pn2_colsum_finalize(_p(pb), nb, Cc, Cc, _p(gb), gba, st)
+        self.record(bwd)
+        return y
+
+    def dwconv_gelu(self, x, conv):
+        """gelu(DWConv(x)) of Mlp.forward (pvtv2.py:44-45): depth-wise 3x3, pad 1, bias, exact GELU."""
+        Cc = x.C
+        assert x.Cp == Cc and x.ld == Cc and conv.groups == Cc and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1)
+        N, H, W, st = x.N, x.H, x.W, _stream()
+        z = self.empty(N, H, W, Cc)
+        y = Act(self, self.empty(N, H, W, Cc), Cc, Cc, Cc, self.dt)
+        call.pn2_dwconv3x3(self.dt, x.ptr, _p(conv.weight), _p(conv.bias), _p(z), y.ptr, N, H, W, Cc, 0, 0, st)
+
+        def bwd():
+            st = _stream()
+            dy = y.grad_buf()
+            assert y.grad_written and dy.stride(2) == Cc
+            dz = self.empty(N, H, W, Cc)
+            call.pn2_gelu_bwd(self.dt, _p(dy), _p(z), _p(dz), dz.numel(), st)
+            M = N * H * W
+            nb = call.pn2_rows_blocks(M, call.pn2_colsum_unit(self.dt, Cc))
+            part = self.fbuf(nb, Cc * 10)
+            call.pn2_dwconv3x3_wgrad(self.dt, _p(dz), x.ptr, _p(part), nb, N, H, W, Cc, st)
+            gw, gwa = self.pgrads.sink(conv.weight)
+            gb, gba = self.pgrads.sink(conv.bias)
+            call.pn2_colsum_finalize(_p(part), nb, Cc * 9, Cc * 10, _p(gw), gwa, st)
+            call.pn2_colsum_finalize(_p(part[:, Cc * 9:]), nb, Cc, Cc * 10, _p(gb), gba, st)
+            if x.requires_grad:
+                gx, acc = x.grad_sink()
+                assert gx.stride(2) == Cc
+                call.pn2_dwconv3x3(self.dt, _p(dz), _p(conv.weight), C.c_void_p(0), _p(gx), C.c_void_p(0), N, H, W, Cc, 1, acc, st)
+        self.record(bwd)
+        return y
+
+    def drop_path(self, x, drop_prob):
+        """timm DropPath in train mode: every sample is kept with probability 1 - drop_prob and rescaled by 1 / keep."""
+        if drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - drop_prob
+        sc = torch.empty(x.N, dtype=torch.float32, device=self.dev).bernoulli_(keep).div_(keep)
+        assert x.ld == x.Cp
+        y = Act(self, self.empty(x.N, x.H, x.W, x.Cp), x.C, x.gw, x.gwp, self.dt)
+        per = x.H * x.W * x.Cp
+        call.pn2_scale_samples(self.dt, x.ptr, y.ptr, _p(sc), x.N, per, _stream())
+
+        def bwd():
+            dy = y.grad_buf()
+            assert y.grad_written and not x.grad_written
+            gx, _ = x.grad_sink()
+            call.pn2_scale_samples(self.dt, _p(dy), _p(gx), _p(sc), x.N, per, _stream())
+        self.record(bwd)
+        return y
+
+    def attention(self, q, kv, heads):
+        """softmax(q k^T / sqrt(hd)) v with the heads concatenated (Attention.forward pvtv2.py:103-107); kv holds k then v."""
+        Cc = q.C
+        hd = Cc // heads
+        assert q.Cp == Cc and q.ld == Cc and kv.C == 2 * Cc and kv.ld == 2 * Cc and kv.N == q.N
+        B, Nq, Nkv, st = q.N, q.H * q.W, kv.H * kv.W, _stream()
+        scale = hd ** -0.5
+        o = Act(self, self.empty(q.N, q.H, q.W, Cc), Cc, Cc, Cc, self.dt)
+        lse = self.fbuf(B, heads, Nq)
+        call.pn2_attn_fwd(self.dt, q.ptr, Cc, kv.ptr, 2 * Cc, o.ptr, Cc, _p(lse), B, Nq, Nkv, heads, hd, scale, st)
+
+        def bwd():
+            st = _stream()
+            do = o.grad_buf()
+            assert o.grad_written and do.stride(2) == Cc and not q.grad_written and not kv.grad_written
+            NP = rup(Nkv, 64)
+            Pm, dS = self.fbuf(B, heads, Nq, NP), self.fbuf(B, heads, Nq, NP)
+            gq, _ = q.grad_sink()
+            gkv, _ = kv.grad_sink()
+            call.pn2_attn_bwd(self.dt, q.ptr, Cc, kv.ptr, 2 * Cc, _p(do), Cc, _p(lse), _p(gq), Cc, _p(gkv), 2 * Cc, _p(Pm), _p(dS), B, Nq, Nkv, heads, hd, scale, st)
+        self.record(bwd)
+        return o
 
     # ------------------------------------------------------------------ pooling
     def maxpool3x3s2(self, x):

@@ -90,9 +90,13 @@ def test_no_cpu_fallback():
         PraNet_V2(num_class=1)(torch.randn(1, 3, 64, 64))
     with pytest.raises(RuntimeError):
         structure_loss(torch.randn(1, 1, 8, 8), torch.randn(1, 1, 8, 8), torch.zeros(1, 1, 8, 8), torch.ones(1, 1, 8, 8))
-    with pytest.raises(NotImplementedError):
-        from lib.pranet import PVT_PraNet_V2
-        PVT_PraNet_V2()
+    from lib.pranet import PVT_PraNet_V2
+    os.environ["PN2_NO_PRETRAINED"] = "1"
+    pvt = PVT_PraNet_V2(num_class=1)
+    with pytest.raises(RuntimeError):
+        pvt(torch.randn(1, 3, 64, 64))
+    with pytest.raises(RuntimeError):
+        pvt.backbone(torch.randn(1, 3, 64, 64))
 
 
 def test_product_never_imports_oracle():

@@ -1,0 +1,226 @@
+"""GPU parity tests of the PVTv2 encoder path (config 4): every new op through the C ABI against torch on the CPU (float64), one
+transformer Block against the oracle, and the whole PVT_PraNet_V2 training forward/backward against the vectors the imported reference
+produced (tests/golden/pvt_pranet_v2_96.npz, DropPath off).  Tolerances as in test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("PN2_NO_PRETRAINED", "1")
+dev = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pn2
+    pn2.load_library()
+    yield
+    pn2.set_compute_dtype("bf16")
+
+
+def relmax(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def rell2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _run(dtn, build, ref, x, params):
+    """build(eng, act) on the GPU vs ref(x64) in float64; returns after asserting output, input-gradient and parameter gradients."""
+    from pn2 import F32, BF16
+    from pn2.engine import Engine
+    from pn2.graph import _seed_grad
+    dt = F32 if dtn == "fp32" else BF16
+    err, tol = (relmax, 5e-5) if dt == F32 else (rell2, 3e-2)
+    eng = Engine(dt, True, need_grad=True)
+    a = eng.from_nchw(x, requires_grad=True)
+    y = build(eng, a)
+    out = eng.to_nchw(y).clone()
+    gy = torch.randn_like(out)
+    _seed_grad(y, gy)
+    eng.backward()
+    xc = (x.bfloat16().float() if dt == BF16 else x).double().cpu().requires_grad_(True)
+    p64 = [p.detach().double().cpu().requires_grad_(True) for p in params]
+    r = ref(xc, *p64)
+    r.backward(gy.double().cpu())
+    assert err(out, r) < tol, "forward"
+    assert err(a.grad[..., :x.shape[1]].float().permute(0, 3, 1, 2), xc.grad) < tol, "input gradient"
+    for p, q in zip(params, p64):
+        assert err(eng.pgrads.get(p), q.grad) < tol, "parameter gradient"
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+@pytest.mark.parametrize("C_", [64, 128, 320, 512])
+def test_layernorm(dtn, C_):
+    torch.manual_seed(C_)
+    ln = nn.LayerNorm(C_, eps=1e-6).to(dev)
+    ln.weight.data.uniform_(0.5, 1.5); ln.bias.data.normal_(0, 0.2)
+    x = torch.randn(3, C_, 7, 5, device=dev) * 2 + 0.3
+    _run(dtn, lambda e, a: e.layernorm(a, ln),
+         lambda t, g, b: F.layer_norm(t.permute(0, 2, 3, 1), (C_,), g, b, 1e-6).permute(0, 3, 1, 2), x, [ln.weight, ln.bias])
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+def test_linear_bias_residual_and_strided_biased_convs(dtn):
+    torch.manual_seed(3)
+    lin = nn.Linear(64, 320).to(dev)
+    x = torch.randn(2, 64, 6, 9, device=dev)
+    _run(dtn, lambda e, a: e.linear(a, lin), lambda t, w, b: F.linear(t.permute(0, 2, 3, 1), w, b).permute(0, 3, 1, 2), x, [lin.weight, lin.bias])
+    lin2 = nn.Linear(128, 128).to(dev)
+    x2 = torch.randn(2, 128, 5, 5, device=dev)
+    _run(dtn, lambda e, a: e.linear(a, lin2, residual=a), lambda t, w, b: F.linear(t.permute(0, 2, 3, 1), w, b).permute(0, 3, 1, 2) + t, x2, [lin2.weight, lin2.bias])
+    for (cin, cout, k, s, p, H) in ((3, 64, 7, 4, 3, 33), (64, 128, 3, 2, 1, 13), (64, 64, 8, 8, 0, 24), (128, 128, 4, 4, 0, 12), (320, 320, 2, 2, 0, 6)):
+        conv = nn.Conv2d(cin, cout, k, s, p).to(dev)
+        conv.bias.data.normal_(0, 0.2)
+        xx = torch.randn(2, cin, H, H, device=dev)
+        _run(dtn, lambda e, a: e.conv_bias(a, conv), lambda t, w, b: F.conv2d(t, w, b, s, p), xx, [conv.weight, conv.bias])
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+def test_dwconv_gelu(dtn):
+    torch.manual_seed(4)
+    for C_, H, W in ((64, 9, 7), (512, 5, 6), (1280, 3, 3)):
+        conv = nn.Conv2d(C_, C_, 3, 1, 1, groups=C_).to(dev)
+        conv.weight.data.normal_(0, 0.4); conv.bias.data.normal_(0, 0.3)
+        x = torch.randn(2, C_, H, W, device=dev)
+        _run(dtn, lambda e, a: e.dwconv_gelu(a, conv), lambda t, w, b: F.gelu(F.conv2d(t, w, b, 1, 1, groups=C_)), x, [conv.weight, conv.bias])
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+@pytest.mark.parametrize("cfg", [(1, 12, 12, 3, 3), (2, 6, 6, 3, 3), (5, 4, 5, 11, 11), (8, 3, 3, 3, 3), (2, 16, 16, 14, 14)])
+def test_attention(dtn, cfg):
+    """q [B, Nq, heads*64] against kv [B, Nkv, 2*heads*64] (k then v, heads inner), softmax over Nkv (1..196 keys)."""
+    from pn2 import F32, BF16
+    from pn2.engine import Engine
+    from pn2.graph import _seed_grad
+    heads, qh, qw, kh, kw = cfg
+    dt = F32 if dtn == "fp32" else BF16
+    err, tol = (relmax, 5e-5) if dt == F32 else (rell2, 3e-2)
+    torch.manual_seed(heads)
+    B, Cc = 2, heads * 64
+    q = torch.randn(B, Cc, qh, qw, device=dev)
+    kv = torch.randn(B, 2 * Cc, kh, kw, device=dev)
+    eng = Engine(dt, True, need_grad=True)
+    qa, kva = eng.from_nchw(q, True), eng.from_nchw(kv, True)
+    o = eng.attention(qa, kva, heads)
+    out = eng.to_nchw(o).clone()
+    go = torch.randn_like(out)
+    _seed_grad(o, go); eng.backward()
+    cast = (lambda t: t.bfloat16().float()) if dt == BF16 else (lambda t: t)
+    q64 = cast(q).double().cpu().requires_grad_(True); kv64 = cast(kv).double().cpu().requires_grad_(True)
+    Nq, Nkv = qh * qw, kh * kw
+    qq = q64.flatten(2).transpose(1, 2).reshape(B, Nq, heads, 64).permute(0, 2, 1, 3)
+    kk = kv64.flatten(2).transpose(1, 2).reshape(B, Nkv, 2, heads, 64).permute(2, 0, 3, 1, 4)
+    attn = ((qq @ kk[0].transpose(-2, -1)) * 64 ** -0.5).softmax(dim=-1)
+    r = (attn @ kk[1]).transpose(1, 2).reshape(B, Nq, Cc).transpose(1, 2).reshape(B, Cc, qh, qw)
+    r.backward(go.double().cpu())
+    assert err(out, r) < tol
+    assert err(qa.grad.float().permute(0, 3, 1, 2), q64.grad) < tol
+    assert err(kva.grad.float().permute(0, 3, 1, 2), kv64.grad) < tol
+
+
+def _pvt_model(fp32=True):
+    import pn2
+    from lib.pranet import PVT_PraNet_V2
+    from oracle import weights as W
+    pn2.set_compute_dtype("fp32" if fp32 else "bf16")
+    model = PVT_PraNet_V2(num_class=1)
+    model.load_state_dict(W.make_state_dict(W.manifest_pvt_pranet_v2(1), seed=3), strict=True)
+    model.backbone.reset_drop_path(0.0)
+    return model.to(dev).train()
+
+
+def test_pvt_state_dict_manifest():
+    import json
+    from lib.pranet import PVT_PraNet_V2
+    ref = json.load(open(os.path.join(G, "manifest_pvt.json")))["pvt_pranet_v2_k1"]
+    model = PVT_PraNet_V2(num_class=1)
+    assert [(k, list(v.shape)) for k, v in model.state_dict().items()] == list(ref.items())
+
+
+def test_pvt_backbone_features_vs_reference():
+    z = np.load(os.path.join(G, "pvt_pranet_v2_96.npz"))
+    from oracle import weights as W
+    model = _pvt_model(fp32=True)
+    x, _ = W.synthetic_batch(2, 96, seed=4321)
+    with torch.no_grad():
+        feats = model.backbone(x.to(dev))
+    for i, f in enumerate(feats):
+        ref64 = torch.from_numpy(z[f"f64.feat{i}"])
+        own = float((torch.from_numpy(z[f"feat{i}"]).double() - ref64).abs().max())
+        assert float((f.double().cpu() - ref64).abs().max()) <= max(1e-4, 3 * own), i
+
+
+@pytest.mark.parametrize("fp32", [True, False])
+def test_pvt_pranet_v2_forward_backward_vs_reference(fp32):
+    """Whole config-4 model, train mode, through nn.Module + torch autograd: 8 outputs, the 4-pair loss and 26 gradient probes."""
+    from pn2.loss import structure_loss
+    from oracle import weights as W
+    z = np.load(os.path.join(G, "pvt_pranet_v2_96.npz"))
+    model = _pvt_model(fp32=fp32)
+    x, mask = W.synthetic_batch(2, 96, seed=4321)
+    xg, mg = x.to(dev), mask.to(dev)
+    outs = model(xg)
+    losses = [structure_loss(outs[i], outs[i + 4], mg, 1 - mg) for i in range(4)]
+    loss = losses[3] + losses[2] + losses[1] + losses[0]
+    loss.backward()
+    names = dict(model.named_parameters())
+    if fp32:
+        for i, o in enumerate(outs):
+            ref64 = torch.from_numpy(z[f"f64.out{i}"])
+            own = float((torch.from_numpy(z[f"out{i}"]).double() - ref64).abs().max())
+            assert float((o.detach().double().cpu() - ref64).abs().max()) <= max(1e-4, 3 * own), i
+        assert abs(float(loss) - float(z["f64.losses"].sum())) < max(1e-4, 3 * abs(float(z["loss"]) - float(z["f64.losses"].sum())))
+        for k in z.files:
+            if k.startswith("f64.grawnorm."):
+                name = k[len("f64.grawnorm."):]
+                g = names[name].grad
+                r64, r32 = float(z[k]), float(z["grawnorm." + name])
+                assert abs(float(g.norm()) - r64) <= max(2e-4 * r64, 3 * abs(r32 - r64)) + 1e-7, name
+                h64 = torch.from_numpy(z["f64.graw." + name]).double()
+                h32 = torch.from_numpy(z["graw." + name]).double()
+                ours = g.detach().reshape(-1)[:h64.numel()].double().cpu()
+                assert float((ours - h64).norm()) <= max(2e-4 * float(h64.norm()), 3 * float((h32 - h64).norm())) + 1e-7, name
+    else:
+        # bf16 storage through 16 transformer blocks + train-mode BN heads on 3x3..12x12 maps: a sanity band, not a parity bound
+        for i, o in enumerate(outs):
+            assert rell2(o, torch.from_numpy(z[f"f64.out{i}"])) < 0.15, i
+        assert abs(float(loss) - float(z["loss"])) < 5e-2 * float(z["loss"])
+        for k in z.files:
+            if k.startswith("f64.grawnorm."):
+                name = k[len("f64.grawnorm."):]
+                assert abs(float(names[name].grad.norm()) - float(z[k])) < 0.3 * float(z[k]) + 5e-3, name      # (norm4.bias: exactly 0 analytically, BN cancels it)
+
+
+def test_pvt_trainer_step_and_graph_replay():
+    """The fused trainer (arena, deferred wgrad tables, fused tail) drives the PVT model too; hipGraph replay == eager bit for bit."""
+    from pn2.trainer import Trainer
+    from oracle import weights as W
+    x, mask = W.synthetic_batch(2, 96, seed=4321)
+    xg, mg = x.to(dev), mask.to(dev)
+    z = np.load(os.path.join(G, "pvt_pranet_v2_96.npz"))
+    res = []
+    for graph in (False, True):
+        tr = Trainer(_pvt_model(fp32=False), lr=1e-4, clip=0.5)
+        if graph:
+            tr.capture(xg, mg, warmup=2)
+            loss = tr.replay()
+        else:
+            for i in range(3):
+                loss = tr.step(xg, mg)
+                if i == 0:
+                    assert abs(float(loss[-1]) - float(z["loss"])) < 5e-2 * float(z["loss"])
+        torch.cuda.synchronize()
+        res.append((loss.clone(), tr.flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
