@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--size", type=int, default=352)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--model", default="res2net", choices=["res2net", "pvt"], help="res2net = BASELINE config 2/3 (headline); pvt = config 4 (PVT_PraNet_V2, use --batch 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     args = ap.parse_args()
@@ -88,10 +89,10 @@ def main():
 
     import pn2
     from pn2.trainer import Trainer
-    from lib.pranet import PraNet_V2
+    from lib.pranet import PraNet_V2, PVT_PraNet_V2
     pn2.set_compute_dtype(args.dtype)
     torch.manual_seed(0)
-    model = PraNet_V2(num_class=1).to(dev).train()
+    model = (PraNet_V2 if args.model == "res2net" else PVT_PraNet_V2)(num_class=1).to(dev).train()
     tr = Trainer(model, lr=1e-4, clip=0.5, process_group=pg)
     x, m = synthetic(args.batch, args.size, 1234 + rank, dev)
 
@@ -132,11 +133,11 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"PraNet-V2 Res2Net50 training step (fwd+4x structure_loss+bwd+clamp+Adam), bs={args.batch}/GPU {args.size}x{args.size}, "
+            "config": {"workload": f"{'PraNet-V2 Res2Net50' if args.model == 'res2net' else 'PVT-PraNet-V2 (pvt_v2_b2, DropPath 0.1)'} training step (fwd+4x structure_loss+bwd+clamp+Adam), bs={args.batch}/GPU {args.size}x{args.size}, "
                                    f"random-init, synthetic ellipse masks", "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "loss": loss_v,
-            "mfma_frac_whole_step": round(ips / world * TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4),
+            "mfma_frac_whole_step": round(ips / world * (TRAIN_GFLOP_PER_IMG if args.model == "res2net" else 72.3) / 1e3 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4),
             "roofline": roof["roofline"], "kernels": roof["kernels"],
         }
         if world == 1 and not args.no_cpu_baseline:

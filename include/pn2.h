@@ -210,13 +210,14 @@ int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, i
 /* Spatial-reduction attention (Attention.forward pvtv2.py:90-111), head_dim 64, Nkv <= 256:
  * q [B][Nq][heads*64] ; kv [B][Nkv][2*heads*64] (k then v, heads inner, as the reference's reshape(B,-1,2,heads,hd)) ;
  * out = softmax(q k^T * scale) v, heads concatenated ; lse [B][heads][Nq] fp32 saved for the backward.
- * Backward scratch: P, dS [B][heads][Nq][roundup(Nkv,64)] fp32. */
+ * Backward: dq, dkv written (not accumulated); `partial` is scratch (see pn2_attn_bwd_blocks). */
 /* DropPath (stochastic depth, pvtv2.py:125,148-149): y[n] = x[n] * scale[n], scale[n] = bernoulli(keep)/keep drawn by the caller; its own adjoint */
 int pn2_scale_samples(int dt, const void* x, void* y, const float* scale, int N, long long elems_per_sample, void* stream);
 int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, void* out, int ld_o, float* lse, int B, int Nq, int Nkv, int heads, int head_dim,
                  float scale, void* stream);
+int pn2_attn_bwd_blocks(int Nq);                /* query chunks per (b, head): partial holds [B][heads][chunks][2][roundup(Nkv,64)][64] fp32 */
 int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, const void* dout, int ld_do, const float* lse, void* dq, int ld_dq, void* dkv, int ld_dkv,
-                 float* P_scratch, float* dS_scratch, int B, int Nq, int Nkv, int heads, int head_dim, float scale, void* stream);
+                 float* partial, int B, int Nq, int Nkv, int heads, int head_dim, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- element-wise / layout */
 int pn2_binary(int dt, int op /*0 add,1 mul*/, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream);

@@ -132,17 +132,26 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, int ld
     }
 }
 
-// out[c] (+)= sum_b p[b*ld + c]   (fixed order; double accumulation)
+// out[c] (+)= sum_b p[b*ld + c]   (fixed order; double accumulation).  32 columns x 8 row lanes per block, 4 loads in flight per thread.
 __global__ __launch_bounds__(256) void colsum_finalize_k(const float* __restrict__ p, int nblk, int C, int ld, float* __restrict__ out, int accumulate) {
-    __shared__ double sh[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    __shared__ double sh[8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     double s = 0.0;
-    if (c < C) for (int r = rl; r < nblk; r += 4) s += (double)p[(size_t)r * ld + c];
+    if (c < C) {
+        int r = rl;
+        for (; r + 24 < nblk; r += 32) {
+            const float a0 = p[(size_t)r * ld + c], a1 = p[(size_t)(r + 8) * ld + c], a2 = p[(size_t)(r + 16) * ld + c], a3 = p[(size_t)(r + 24) * ld + c];
+            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        }
+        for (; r < nblk; r += 8) s += (double)p[(size_t)r * ld + c];
+    }
     sh[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < C) {
-        const float v = (float)((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]));
-        out[c] = accumulate ? out[c] + v : v;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][cl];
+        out[c] = accumulate ? out[c] + (float)t : (float)t;
     }
 }
 
@@ -189,38 +198,47 @@ __device__ __forceinline__ float gelu_grad(float x) {       // d/dx [x * Phi(x)]
 }
 
 // z = sum_taps w[c][tap] * x[pixel + tap][c] (+ b[c]) ; y = gelu(z) (optional).  flip: correlate with the mirrored kernel (data gradient).
+// A thread owns one channel vector (its 9 x VEC weights and bias stay in registers) and walks the pixels of the block's range.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_k(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, T* __restrict__ z, T* __restrict__ y,
-                                                   int N, int H, int W, int C, int flip, int accumulate) {
+                                                   int N, int H, int W, int C, int flip, int accumulate, int pix_per_blk, int CVP) {
     constexpr int V = TT<T>::VEC;
-    const int CV = C / V;
-    const size_t total = (size_t)N * H * W * CV;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int cv = (int)(idx % CV); size_t p = idx / CV;
-        const int ox = (int)(p % W); p /= W; const int oy = (int)(p % H); const int n = (int)(p / H);
-        float a[V];
+    const int CV = C / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
+    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
+    for (int cv = cvl; cv < CV; cv += CVP) {
+        float wr[9][V], br[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) a[e] = b ? b[cv * V + e] : 0.f;
+        for (int e = 0; e < V; ++e) {
+            br[e] = b ? b[cv * V + e] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                float xv[V];
-                ldv<T>(x + (((size_t)n * H + iy) * W + ix) * C + cv * V, xv);
-                const int tw = flip ? 8 - t : t;
-#pragma unroll
-                for (int e = 0; e < V; ++e) a[e] += w[(cv * V + e) * 9 + tw] * xv[e];
-            }
+            for (int t = 0; t < 9; ++t) wr[t][e] = w[(cv * V + e) * 9 + (flip ? 8 - t : t)];
         }
-        const size_t o = (((size_t)n * H + oy) * W + ox) * C + cv * V;
-        if (accumulate) { float old[V]; ldv<T>(z + o, old);
+        for (int m = p0 + rl; m < p1; m += R) {
+            const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
+            float a[V];
 #pragma unroll
-            for (int e = 0; e < V; ++e) a[e] += old[e]; }
-        stv<T>(z + o, a);
-        if (y) {
+            for (int e = 0; e < V; ++e) a[e] = br[e];
 #pragma unroll
-            for (int e = 0; e < V; ++e) a[e] = gelu_f(a[e]);
-            stv<T>(y + o, a);
+            for (int t = 0; t < 9; ++t) {
+                const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    float xv[V];
+                    ldv<T>(x + (((size_t)n * H + iy) * W + ix) * C + cv * V, xv);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) a[e] += wr[t][e] * xv[e];
+                }
+            }
+            const size_t o = (size_t)m * C + cv * V;
+            if (accumulate) { float old[V]; ldv<T>(z + o, old);
+#pragma unroll
+                for (int e = 0; e < V; ++e) a[e] += old[e]; }
+            stv<T>(z + o, a);
+            if (y) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) a[e] = gelu_f(a[e]);
+                stv<T>(y + o, a);
+            }
         }
     }
 }
@@ -312,132 +330,176 @@ __device__ __forceinline__ void attn_stage_kv(const T* __restrict__ kv, int ld_k
     }
 }
 
-template <typename T>
+__device__ __forceinline__ float rdlane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+constexpr int AT_QB = 4;         // queries a wave works on at once: every K / V value read from LDS is used AT_QB times
+
+template <typename T, int NK>
 __global__ __launch_bounds__(256) void attn_fwd_k(const T* __restrict__ q, int ld_q, const T* __restrict__ kv, int ld_kv, T* __restrict__ out, int ld_o,
                                                   float* __restrict__ lse, int Nq, int Nkv, int heads, float scale, int q_per_blk) {
     extern __shared__ float lds[];
-    const int NP = (Nkv + 63) & ~63, NK = NP >> 6, RS = NP + 1;
+    constexpr int NP = NK * 64, RS = NP + 1;
     float* Kt = lds; float* Vt = lds + 64 * RS;
     const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     attn_stage_kv<T>(kv + (size_t)b * Nkv * ld_kv, ld_kv, Nkv, NP, heads, h, Kt, Vt);
     __syncthreads();
     const int q0 = blockIdx.x * q_per_blk;
     int q1 = q0 + q_per_blk; if (q1 > Nq) q1 = Nq;
-    for (int qi = q0 + wid; qi < q1; qi += 4) {
-        const size_t qo = ((size_t)b * Nq + qi);
-        const float qd = TT<T>::ld(q + qo * ld_q + h * 64 + lane) * scale;
-        float s[AT_MAXK];
+    for (int qb = q0 + wid * AT_QB; qb < q1; qb += 4 * AT_QB) {
+        float qd[AT_QB], s[AT_QB][NK];
 #pragma unroll
-        for (int k = 0; k < AT_MAXK; ++k) s[k] = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < 64; ++d) {
-            const float qq = __shfl(qd, d);
+        for (int i = 0; i < AT_QB; ++i) {
+            const int qi = qb + i < q1 ? qb + i : q1 - 1;
+            qd[i] = TT<T>::ld(q + ((size_t)b * Nq + qi) * ld_q + h * 64 + lane) * scale;
 #pragma unroll
-            for (int k = 0; k < AT_MAXK; ++k) if (k < NK) s[k] += qq * Kt[d * RS + k * 64 + lane];
+            for (int k = 0; k < NK; ++k) s[i][k] = 0.f;
         }
-        float mx = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < AT_MAXK; ++k) if (k < NK && k * 64 + lane < Nkv) mx = fmaxf(mx, s[k]);
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sum = 0.f, p[AT_MAXK];
+        for (int d = 0; d < 64; ++d) {
+            float kk[NK];
 #pragma unroll
-        for (int k = 0; k < AT_MAXK; ++k) { p[k] = (k < NK && k * 64 + lane < Nkv) ? expf(s[k] - mx) : 0.f; sum += p[k]; }
-        sum = wave_sum(sum);
-        const float inv = 1.f / sum;
-        float o_ = 0.f;
+            for (int k = 0; k < NK; ++k) kk[k] = Kt[d * RS + k * 64 + lane];
 #pragma unroll
-        for (int k = 0; k < AT_MAXK; ++k) {
-            if (k < NK) {
-#pragma unroll 8
-                for (int l = 0; l < 64; ++l) o_ += __shfl(p[k], l) * Vt[lane * RS + k * 64 + l];
+            for (int i = 0; i < AT_QB; ++i) {
+                const float qq = rdlane(qd[i], d);
+#pragma unroll
+                for (int k = 0; k < NK; ++k) s[i][k] += qq * kk[k];
             }
         }
-        TT<T>::st(out + qo * ld_o + h * 64 + lane, o_ * inv);
-        if (lane == 0) lse[((size_t)b * heads + h) * Nq + qi] = mx + logf(sum);
+        float inv[AT_QB], o_[AT_QB];
+#pragma unroll
+        for (int i = 0; i < AT_QB; ++i) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) if (k * 64 + lane < Nkv) mx = fmaxf(mx, s[i][k]);
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { s[i][k] = (k * 64 + lane < Nkv) ? expf(s[i][k] - mx) : 0.f; sum += s[i][k]; }
+            sum = wave_sum(sum);
+            inv[i] = 1.f / sum; o_[i] = 0.f;
+            if (lane == 0 && qb + i < q1) lse[((size_t)b * heads + h) * Nq + qb + i] = mx + logf(sum);
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) {
+                const float vv = Vt[lane * RS + k * 64 + l];
+#pragma unroll
+                for (int i = 0; i < AT_QB; ++i) o_[i] += rdlane(s[i][k], l) * vv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AT_QB; ++i)
+            if (qb + i < q1) TT<T>::st(out + ((size_t)b * Nq + qb + i) * ld_o + h * 64 + lane, o_[i] * inv[i]);
     }
 }
 
-// backward, per query: recompute p from the saved log-sum-exp, dP = dO V^T, dS = p (dP - sum p dP), dq = scale dS K; P and dS are stored
-// ([B][heads][Nq][NP] fp32) for the key/value pass below
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_q_k(const T* __restrict__ q, int ld_q, const T* __restrict__ kv, int ld_kv, const T* __restrict__ dout, int ld_do,
-                                                    const float* __restrict__ lse, T* __restrict__ dq, int ld_dq, float* __restrict__ Pm, float* __restrict__ dSm,
-                                                    int Nq, int Nkv, int heads, float scale, int q_per_blk) {
+// backward.  A block owns a chunk of queries of one (b, head).  Per group of 4 x QB queries (QB per wave): phase A recomputes
+// p = exp(s - lse), dP = dO V^T, dS = p (dP - sum p dP) and dq = scale dS K exactly like the forward walks K / V; P, dS, q, dO of the
+// group go to LDS tiles.  Phase B: every wave owns NP/4 keys and accumulates dK[l][d] += dS[q][l] q[q][d], dV[l][d] += P[q][l] dO[q][d]
+// in registers (lane = d, broadcast LDS reads).  Block partials [2][NP][64] are summed over the query chunks by attn_bwd_kv_reduce_k.
+constexpr int AT_QCHUNK = 256;
+
+template <typename T, int NK, int QB>
+__global__ __launch_bounds__(256) void attn_bwd_k(const T* __restrict__ q, int ld_q, const T* __restrict__ kv, int ld_kv, const T* __restrict__ dout, int ld_do,
+                                                  const float* __restrict__ lse, T* __restrict__ dq, int ld_dq, float* __restrict__ part,
+                                                  int Nq, int Nkv, int heads, float scale) {
     extern __shared__ float lds[];
-    const int NP = (Nkv + 63) & ~63, NK = NP >> 6, RS = NP + 1;
-    float* Kt = lds; float* Vt = lds + 64 * RS;
+    constexpr int NP = NK * 64, RS = NP + 1, KPW = NP / 4;
+    float* Kt = lds; float* Vt = Kt + 64 * RS;
+    constexpr int GQ = 4 * QB;          // queries per group
+    float* Pt = Vt + 64 * RS; float* dSt = Pt + GQ * NP; float* qt = dSt + GQ * NP; float* dot = qt + GQ * 64;
     const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     attn_stage_kv<T>(kv + (size_t)b * Nkv * ld_kv, ld_kv, Nkv, NP, heads, h, Kt, Vt);
     __syncthreads();
-    const int q0 = blockIdx.x * q_per_blk;
-    int q1 = q0 + q_per_blk; if (q1 > Nq) q1 = Nq;
-    for (int qi = q0 + wid; qi < q1; qi += 4) {
-        const size_t qo = ((size_t)b * Nq + qi);
-        const float qd = TT<T>::ld(q + qo * ld_q + h * 64 + lane) * scale;
-        const float dod = TT<T>::ld(dout + qo * ld_do + h * 64 + lane);
-        const float L = lse[((size_t)b * heads + h) * Nq + qi];
-        float s[AT_MAXK], dp[AT_MAXK];
+    const int q0 = blockIdx.x * AT_QCHUNK;
+    int q1 = q0 + AT_QCHUNK; if (q1 > Nq) q1 = Nq;
+    float ak[KPW], av[KPW];
 #pragma unroll
-        for (int k = 0; k < AT_MAXK; ++k) { s[k] = 0.f; dp[k] = 0.f; }
-#pragma unroll 8
+    for (int j = 0; j < KPW; ++j) { ak[j] = 0.f; av[j] = 0.f; }
+    for (int g0 = q0; g0 < q1; g0 += 4 * QB) {
+        const int qb = g0 + wid * QB;
+        float qd[QB], dod[QB], L[QB], s[QB][NK], dp[QB][NK];
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+            const bool ok = qb + i < q1;
+            const int qi = ok ? qb + i : q1 - 1;
+            const size_t qo = (size_t)b * Nq + qi;
+            qd[i] = ok ? TT<T>::ld(q + qo * ld_q + h * 64 + lane) * scale : 0.f;
+            dod[i] = ok ? TT<T>::ld(dout + qo * ld_do + h * 64 + lane) : 0.f;
+            L[i] = lse[((size_t)b * heads + h) * Nq + qi];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { s[i][k] = 0.f; dp[i][k] = 0.f; }
+        }
+#pragma unroll
         for (int d = 0; d < 64; ++d) {
-            const float qq = __shfl(qd, d), gg = __shfl(dod, d);
+            float kk[NK], vv[NK];
 #pragma unroll
-            for (int k = 0; k < AT_MAXK; ++k) if (k < NK) { s[k] += qq * Kt[d * RS + k * 64 + lane]; dp[k] += gg * Vt[d * RS + k * 64 + lane]; }
-        }
-        float p[AT_MAXK], delta = 0.f;
+            for (int k = 0; k < NK; ++k) { kk[k] = Kt[d * RS + k * 64 + lane]; vv[k] = Vt[d * RS + k * 64 + lane]; }
 #pragma unroll
-        for (int k = 0; k < AT_MAXK; ++k) { p[k] = (k < NK && k * 64 + lane < Nkv) ? expf(s[k] - L) : 0.f; delta += p[k] * dp[k]; }
-        delta = wave_sum(delta);
-        float ds[AT_MAXK], dqd = 0.f;
-        const size_t po = (((size_t)b * heads + h) * Nq + qi) * NP;
+            for (int i = 0; i < QB; ++i) {
+                const float qq = rdlane(qd[i], d), gg = rdlane(dod[i], d);
 #pragma unroll
-        for (int k = 0; k < AT_MAXK; ++k) {
-            ds[k] = p[k] * (dp[k] - delta);
-            if (k < NK) { Pm[po + k * 64 + lane] = p[k]; dSm[po + k * 64 + lane] = ds[k]; }
-        }
-#pragma unroll
-        for (int k = 0; k < AT_MAXK; ++k) {
-            if (k < NK) {
-#pragma unroll 8
-                for (int l = 0; l < 64; ++l) dqd += __shfl(ds[k], l) * Kt[lane * RS + k * 64 + l];
+                for (int k = 0; k < NK; ++k) { s[i][k] += qq * kk[k]; dp[i][k] += gg * vv[k]; }
             }
         }
-        TT<T>::st(dq + qo * ld_dq + h * 64 + lane, dqd * scale);
+        float dqd[QB];
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+            const bool ok = qb + i < q1;
+            float delta = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { s[i][k] = (ok && k * 64 + lane < Nkv) ? expf(s[i][k] - L[i]) : 0.f; delta += s[i][k] * dp[i][k]; }
+            delta = wave_sum(delta);
+            const int row = wid * QB + i;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                dp[i][k] = s[i][k] * (dp[i][k] - delta);          // dS
+                Pt[row * NP + k * 64 + lane] = s[i][k]; dSt[row * NP + k * 64 + lane] = dp[i][k];
+            }
+            qt[row * 64 + lane] = qd[i]; dot[row * 64 + lane] = dod[i];
+            dqd[i] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) {
+                const float kk = Kt[lane * RS + k * 64 + l];
+#pragma unroll
+                for (int i = 0; i < QB; ++i) dqd[i] += rdlane(dp[i][k], l) * kk;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < QB; ++i)
+            if (qb + i < q1) TT<T>::st(dq + ((size_t)b * Nq + qb + i) * ld_dq + h * 64 + lane, dqd[i] * scale);
+        __syncthreads();
+        // phase B: this wave's keys [wid*KPW, +KPW), all queries of the group
+        for (int r = 0; r < GQ; ++r) {
+            const float qv = qt[r * 64 + lane], gv = dot[r * 64 + lane];
+            const float* pr = Pt + r * NP + wid * KPW; const float* dr = dSt + r * NP + wid * KPW;
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) { ak[j] += dr[j] * qv; av[j] += pr[j] * gv; }
+        }
+        __syncthreads();
+    }
+    float* dst = part + ((((size_t)b * heads + h) * gridDim.x + blockIdx.x) * 2) * NP * 64;
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        dst[(size_t)(wid * KPW + j) * 64 + lane] = ak[j];                 // qd carried the softmax scale already
+        dst[(size_t)NP * 64 + (size_t)(wid * KPW + j) * 64 + lane] = av[j];
     }
 }
 
-// backward, keys/values: dK[l] = scale * sum_q dS[q][l] q[q], dV[l] = sum_q P[q][l] dO[q] for a chunk of AT_KC keys of one (b, head);
-// the 4 waves split the queries, lane = dimension; fixed-order cross-wave sum through LDS
-constexpr int AT_KC = 8;
-
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kv_k(const T* __restrict__ q, int ld_q, const T* __restrict__ dout, int ld_do, const float* __restrict__ Pm,
-                                                     const float* __restrict__ dSm, T* __restrict__ dkv, int ld_dkv, int Nq, int Nkv, int heads, float scale) {
-    __shared__ float red[4][2 * AT_KC][64];
-    const int NP = (Nkv + 63) & ~63;
-    const int b = blockIdx.z, h = blockIdx.y, l0 = blockIdx.x * AT_KC, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float ak[AT_KC], av[AT_KC];
-#pragma unroll
-    for (int j = 0; j < AT_KC; ++j) { ak[j] = 0.f; av[j] = 0.f; }
-    const size_t pb = ((size_t)b * heads + h) * Nq;
-    for (int qi = wid; qi < Nq; qi += 4) {
-        const size_t qo = ((size_t)b * Nq + qi);
-        const float qd = TT<T>::ld(q + qo * ld_q + h * 64 + lane), dod = TT<T>::ld(dout + qo * ld_do + h * 64 + lane);
-        const float* pr = Pm + (pb + qi) * NP + l0; const float* dr = dSm + (pb + qi) * NP + l0;
-#pragma unroll
-        for (int j = 0; j < AT_KC; ++j) { ak[j] += dr[j] * qd; av[j] += pr[j] * dod; }     // l0 + j < NP always (NP multiple of 64, AT_KC divides 64)
-    }
-#pragma unroll
-    for (int j = 0; j < AT_KC; ++j) { red[wid][j][lane] = ak[j]; red[wid][AT_KC + j][lane] = av[j]; }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * AT_KC * 64; i += 256) {
-        const int j = i >> 6, d = i & 63, l = l0 + (j % AT_KC);
-        if (l >= Nkv) continue;
-        const float s = (red[0][j][d] + red[1][j][d]) + (red[2][j][d] + red[3][j][d]);
-        T* dst = dkv + ((size_t)b * Nkv + l) * ld_dkv + (j < AT_KC ? h * 64 : heads * 64 + h * 64) + d;
-        TT<T>::st(dst, j < AT_KC ? s * scale : s);
-    }
+__global__ __launch_bounds__(64) void attn_bwd_kv_reduce_k(const float* __restrict__ part, T* __restrict__ dkv, int ld_dkv, int Nkv, int NP, int heads, int nqb) {
+    const int l = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
+    const float* p = part + (((size_t)b * heads + h) * nqb * 2) * NP * 64 + (size_t)l * 64 + d;
+    float sk = 0.f, sv = 0.f;
+    for (int c = 0; c < nqb; ++c) { sk += p[(size_t)c * 2 * NP * 64]; sv += p[(size_t)c * 2 * NP * 64 + (size_t)NP * 64]; }
+    T* dst = dkv + ((size_t)b * Nkv + l) * ld_dkv;
+    TT<T>::st(dst + h * 64 + d, sk);
+    TT<T>::st(dst + heads * 64 + h * 64 + d, sv);
 }
 
 // y[n][r][c] = x[n][r][c] * s[n]   (DropPath: per-sample keep mask / keep_prob, timm.models.layers.DropPath used at pvtv2.py:125,148-149)
@@ -485,8 +547,8 @@ int pn2_layernorm_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int M,
     return 0;
 }
 
-static int rows_for(int M, int unit) {          /* rows per block of the column-sum style reductions: ~512 blocks, a multiple of `unit` */
-    int rows = (M + 511) / 512;
+static int rows_for(int M, int unit) {          /* rows per block of the column-sum style reductions: ~256 blocks, a multiple of `unit` */
+    int rows = (M + 255) / 256;
     rows = ((rows + unit - 1) / unit) * unit;
     return rows < unit ? unit : rows;
 }
@@ -513,7 +575,7 @@ int pn2_ln_slots(int dt, int C) { const int lpr = ln_lpr(dt, C); return lpr < 0 
 
 int pn2_colsum_finalize(const float* partial, int nblk, int C, int ld, float* out, int accumulate, void* stream) {
     if (!partial || !out || nblk < 1 || C < 1) return -1;
-    hipLaunchKernelGGL(colsum_finalize_k, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, ld, out, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_k, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, ld, out, accumulate);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -536,8 +598,13 @@ int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z
     if (!x || !w || !z) return -1;
     const int V = dt == PN2_F32 ? 4 : 8;
     if (C % V) return -2;
-    VIT_DISPATCH(dt, { hipLaunchKernelGGL(dwconv3x3_k<T>, dim3(grid_for((size_t)N * H * W * (C / V))), dim3(256), 0, (hipStream_t)stream, (const T*)x, w, b, (T*)z, (T*)y_gelu,
-                                          N, H, W, C, flip, accumulate); })
+    int cvp = pow2ceil(C / V); if (cvp > 256) cvp = 256;
+    const int R = 256 / cvp, M = N * H * W;
+    int pix = (M + 2047) / 2048;                      // ~2048 blocks; every thread re-reads its 9 x VEC weights once per block
+    pix = ((pix + R - 1) / R) * R;
+    if (pix < 4 * R) pix = 4 * R;
+    VIT_DISPATCH(dt, { hipLaunchKernelGGL(dwconv3x3_k<T>, dim3((M + pix - 1) / pix), dim3(256), 0, (hipStream_t)stream, (const T*)x, w, b, (T*)z, (T*)y_gelu,
+                                          N, H, W, C, flip, accumulate, pix, cvp); })
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -569,32 +636,39 @@ int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, voi
                  float scale, void* stream) {
     if (!q || !kv || !out || !lse) return -1;
     if (int rc = attn_geom(Nkv, heads, head_dim)) return rc;
-    const int NP = (Nkv + 63) & ~63;
+    const int NK = (Nkv + 63) / 64, NP = NK * 64;
     const size_t lds = (size_t)2 * 64 * (NP + 1) * 4;
     const int qpb = 64;
-    VIT_DISPATCH(dt, {
-        static bool done = false;
-        if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_k<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 257 * 4); done = true; }
-        hipLaunchKernelGGL(attn_fwd_k<T>, dim3((Nq + qpb - 1) / qpb, heads, B), dim3(256), lds, (hipStream_t)stream, (const T*)q, ld_q, (const T*)kv, ld_kv, (T*)out, ld_o, lse,
-                           Nq, Nkv, heads, scale, qpb); })
+    const dim3 grid((Nq + qpb - 1) / qpb, heads, B);
+    hipStream_t st = (hipStream_t)stream;
+#define PN2_ATTN_FWD(NKV) { if (lds > 64 * 1024) { static bool done = false; if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_k<T, NKV>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; } } \
+        hipLaunchKernelGGL((attn_fwd_k<T, NKV>), grid, dim3(256), lds, st, (const T*)q, ld_q, (const T*)kv, ld_kv, (T*)out, ld_o, lse, Nq, Nkv, heads, scale, qpb); }
+    VIT_DISPATCH(dt, { if (NK == 1) PN2_ATTN_FWD(1) else if (NK == 2) PN2_ATTN_FWD(2) else if (NK == 3) PN2_ATTN_FWD(3) else PN2_ATTN_FWD(4) })
+#undef PN2_ATTN_FWD
     PN2_CHECK_LAUNCH();
     return 0;
 }
 
+int pn2_attn_bwd_blocks(int Nq) { return Nq < 1 ? -1 : (Nq + AT_QCHUNK - 1) / AT_QCHUNK; }
+
 int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, const void* dout, int ld_do, const float* lse, void* dq, int ld_dq, void* dkv, int ld_dkv,
-                 float* P_scratch, float* dS_scratch, int B, int Nq, int Nkv, int heads, int head_dim, float scale, void* stream) {
-    if (!q || !kv || !dout || !lse || !dq || !dkv || !P_scratch || !dS_scratch) return -1;
+                 float* partial, int B, int Nq, int Nkv, int heads, int head_dim, float scale, void* stream) {
+    if (!q || !kv || !dout || !lse || !dq || !dkv || !partial) return -1;
     if (int rc = attn_geom(Nkv, heads, head_dim)) return rc;
-    const int NP = (Nkv + 63) & ~63;
-    const size_t lds = (size_t)2 * 64 * (NP + 1) * 4;
-    const int qpb = 64;
+    const int NK = (Nkv + 63) / 64, NP = NK * 64, nqb = pn2_attn_bwd_blocks(Nq);
+    const int QB = NK == 4 ? 2 : AT_QB;                 // 256 keys: smaller query groups so that K, V and the tiles fit the 160 KiB of LDS
+    const size_t lds = ((size_t)2 * 64 * (NP + 1) + 2 * 4 * QB * NP + 2 * 4 * QB * 64) * 4;
+    const dim3 grid(nqb, heads, B);
+    hipStream_t st = (hipStream_t)stream;
+#define PN2_ATTN_BWD(NKV, QBV) { if (lds > 64 * 1024) { static bool done = false; if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_k<T, NKV, QBV>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; } } \
+        hipLaunchKernelGGL((attn_bwd_k<T, NKV, QBV>), grid, dim3(256), lds, st, (const T*)q, ld_q, (const T*)kv, ld_kv, (const T*)dout, ld_do, lse, (T*)dq, ld_dq, \
+                           partial, Nq, Nkv, heads, scale); }
     VIT_DISPATCH(dt, {
-        static bool done = false;
-        if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_k<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 257 * 4); done = true; }
-        hipLaunchKernelGGL(attn_bwd_q_k<T>, dim3((Nq + qpb - 1) / qpb, heads, B), dim3(256), lds, (hipStream_t)stream, (const T*)q, ld_q, (const T*)kv, ld_kv, (const T*)dout, ld_do,
-                           lse, (T*)dq, ld_dq, P_scratch, dS_scratch, Nq, Nkv, heads, scale, qpb);
-        hipLaunchKernelGGL(attn_bwd_kv_k<T>, dim3((Nkv + AT_KC - 1) / AT_KC, heads, B), dim3(256), 0, (hipStream_t)stream, (const T*)q, ld_q, (const T*)dout, ld_do, P_scratch,
-                           dS_scratch, (T*)dkv, ld_dkv, Nq, Nkv, heads, scale); })
+        if (NK == 1) PN2_ATTN_BWD(1, AT_QB) else if (NK == 2) PN2_ATTN_BWD(2, AT_QB) else if (NK == 3) PN2_ATTN_BWD(3, AT_QB) else PN2_ATTN_BWD(4, 2)
+        hipLaunchKernelGGL(attn_bwd_kv_reduce_k<T>, dim3(Nkv, heads, B), dim3(64), 0, st, partial, (T*)dkv, ld_dkv, Nkv, NP, heads, nqb); })
+#undef PN2_ATTN_BWD
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -111,7 +111,8 @@ SIGNATURES = {
     "pn2_dwconv3x3_wgrad": [I, P, P, P, I, I, I, I, I, P],
     "pn2_scale_samples": [I, P, P, P, I, LL, P],
     "pn2_attn_fwd": [I, P, I, P, I, P, I, P, I, I, I, I, I, FL, P],
-    "pn2_attn_bwd": [I, P, I, P, I, P, I, P, P, I, P, I, P, P, I, I, I, I, I, FL, P],
+    "pn2_attn_bwd_blocks": [I],
+    "pn2_attn_bwd": [I, P, I, P, I, P, I, P, P, I, P, I, P, I, I, I, I, I, FL, P],
     "pn2_binary": [I, I, P, I, P, I, P, I, I, I, I, P],
     "pn2_copy": [I, P, I, I, P, I, I, I, I, P],
     "pn2_nchw_to_nhwc": [I, P, P, I, I, I, I, I, P],
@@ -124,7 +125,7 @@ SIGNATURES = {
 # entry points that return a value rather than a status
 _VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
                 "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
-                "pn2_dsra_tail_blocks", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit"}
+                "pn2_dsra_tail_blocks", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks"}
 
 _lib = None
 WORK = {}     # profiling annotation for the next launch (algorithmic flops / tag), consumed by pn2.profile.Recorder
