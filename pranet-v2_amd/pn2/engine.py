@@ -356,16 +356,25 @@ class Engine:
     def fbuf(self, *shape):
         return self.alloc(shape, torch.float32)
 
-    def from_nchw(self, x, requires_grad=False):
-        """fp32 NCHW module input -> NHWC compute dtype, channels zero-padded to a multiple of 8."""
+    def from_nchw(self, x, requires_grad=False, dt=None):
+        """fp32 NCHW module input -> NHWC compute dtype (or `dt`), channels zero-padded to a multiple of 8."""
         if not x.is_cuda:
             raise RuntimeError("pranet-v2_amd ops need GPU tensors (no CPU fallback)")
         x = x.contiguous().float()
         N, Cc, H, W = x.shape
-        a = self.new_act(N, H, W, Cc)
-        call.pn2_nchw_to_nhwc(self.dt, _p(x), a.ptr, a.ld, N, Cc, H * W, a.Cp, _stream())
+        a = self.new_act(N, H, W, Cc, dt=dt)
+        call.pn2_nchw_to_nhwc(a.dt, _p(x), a.ptr, a.ld, N, Cc, H * W, a.Cp, _stream())
         a.requires_grad = requires_grad and self.need_grad
         return a
+
+    def cast(self, a, dt):
+        """Same activation in another storage dtype (no gradient: used on the resized network input)."""
+        if a.dt == dt:
+            return a
+        assert a.ld == a.Cp
+        y = Act(self, self.empty(a.N, a.H, a.W, a.Cp, dt), a.C, a.gw, a.gwp, dt, requires_grad=False)
+        call.pn2_copy(a.dt, a.ptr, a.ld, dt, y.ptr, y.ld, a.M, a.Cp, 0, _stream())
+        return y
 
     def to_nchw(self, a):
         """Module output: (N,C,H,W) fp32 tensor.  K=1 maps are returned as zero-copy views."""

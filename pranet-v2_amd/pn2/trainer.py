@@ -54,14 +54,12 @@ class Trainer:
         self.hot = hot
         # gradient buckets in arena order (backward completes them from the tail)
         self.buckets = GradBuckets(self.gflat, [(id(p), self.off[id(p)][0], _r4(self.off[id(p)][1])) for p in hot], bucket_bytes, process_group)
-        self.graph = None
         self.last_outs = None
         self.pack_cache = PackCache()
-        # PN2_DEFER_WGRAD: 2 (default) wgrad + slab reduction deferred into table-driven launches, 1 only the reductions, 0 neither
-        mode = os.environ.get("PN2_DEFER_WGRAD", "2")
-        self.grad_queue = GradQueue(defer_wgrad=mode == "2") if mode in ("1", "2") else None
-        self.arena = StepArena() if os.environ.get("PN2_STEP_ARENA", "1") == "1" else None
-        self.steps_run = 0
+        # Everything shape-dependent (step arena, deferred-launch tables, captured graphs) lives in a per-shape state, so the
+        # 0.75x / 1x / 1.25x multi-scale schedule of MyTrain_med.py:55,70-73 alternates between three warm states.
+        self._states = {}
+        self._cur = None
         self.fuse_tail = os.environ.get("PN2_FUSED_TAIL", "1") == "1"
         # per-shape conv kernel/tile choices, filled by timing the candidates during the first (eager) step; the table is
         # per process (= per GPU) so every trainer in the process launches identical kernels (bit-reproducible runs)
@@ -73,15 +71,44 @@ class Trainer:
         off, n = self.off[id(p)]
         return self.gflat[off:off + n].view(p.shape)
 
-    def forward_backward(self, images, gts, reduce_hook=True):
-        """forward + loss + backward; returns loss[5] = (l2, l3, l4, l5 pair losses, total) on device."""
+    def _state(self, images, size=None):
+        N, _, H, W = images.shape
+        key = (N, H, W, size if size is not None else H)
+        st = self._states.get(key)
+        if st is None:
+            from types import SimpleNamespace
+            # PN2_DEFER_WGRAD: 2 (default) wgrad + slab reduction deferred into table-driven launches, 1 only the reductions, 0 neither
+            mode = os.environ.get("PN2_DEFER_WGRAD", "2")
+            st = self._states[key] = SimpleNamespace(
+                key=key, steps_run=0, graph=None, graph_opt=None, s_images=None, s_gts=None, s_loss=None,
+                grad_queue=GradQueue(defer_wgrad=mode == "2") if mode in ("1", "2") else None,
+                arena=StepArena() if os.environ.get("PN2_STEP_ARENA", "1") == "1" else None)
+        self._cur = st
+        return st
+
+    # the state of the most recent step (tools / tests look at these)
+    arena = property(lambda self: self._cur.arena if self._cur else None)
+    grad_queue = property(lambda self: self._cur.grad_queue if self._cur else None)
+    steps_run = property(lambda self: self._cur.steps_run if self._cur else 0)
+
+    def forward_backward(self, images, gts, reduce_hook=True, size=None):
+        """forward + loss + backward; returns loss[5] = (l2, l3, l4, l5 pair losses, total) on device.
+        size: train at size x size — images and masks are resized on the device first, bilinear with align_corners=True, exactly the
+        multi-scale rescale of MyTrain_med.py:70-73."""
+        st = self._state(images, size)
         self.pack_cache.refresh()
-        if self.arena is not None:
-            self.arena.begin_step(self.flat.device)
-        self.steps_run += 1
-        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, grad_queue=self.grad_queue, arena=self.arena)
+        if st.arena is not None:
+            st.arena.begin_step(self.flat.device)
+        st.steps_run += 1
+        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, grad_queue=st.grad_queue, arena=st.arena)
         eng.fuse_tail = self.fuse_tail
-        x = eng.from_nchw(images)
+        if size is not None and (size != images.shape[2] or size != images.shape[3]):
+            x = eng.cast(eng.resize_to(eng.from_nchw(images, dt=F32), size, size, align_corners=True), self.dtype)
+            n_, _, h_, w_ = gts.shape
+            g = Act(eng, gts.reshape(n_, h_, w_, 1).float().contiguous(), 1, 1, 1, F32, requires_grad=False)
+            gts = eng.resize_to(g, size, size, align_corners=True).t
+        else:
+            x = eng.from_nchw(images)
         outs = self.model._build(eng, x)
         eng.finish_forward()
         N, H, W = outs[0].N, outs[0].H, outs[0].W
@@ -106,7 +133,7 @@ class Trainer:
                 o.grad_written = True
         if self.world > 1:
             self.buckets.reset()
-        rq = self.grad_queue
+        rq = st.grad_queue
         if rq is not None:
             rq.begin_step()
 
@@ -135,56 +162,62 @@ class Trainer:
         call.pn2_clamp_adam(_p(self.flat), _p(self.gflat), _p(self.exp_avg), _p(self.exp_avg_sq), self.n_hot, self.lr, self.betas[0], self.betas[1],
                             self.eps, self.clip, 1.0 / self.world, _p(self.bias_corr), st)
 
-    def step(self, images, gts):
-        """One MyTrain_med.py:59-86 iteration.  Returns the device tensor [loss5, loss4, loss3, loss2, total]."""
-        loss = self.forward_backward(images, gts)
+    def step(self, images, gts, size=None):
+        """One MyTrain_med.py:59-86 iteration (at `size` x `size` when given).  Returns the device tensor [loss2, loss3, loss4, loss5, total]."""
+        loss = self.forward_backward(images, gts, size=size)
         self.optimizer_step()
         return loss
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
-    def capture(self, images, gts, warmup=3):
+    def capture(self, images, gts, warmup=3, size=None):
         """Capture forward+loss+backward(+Adam) into hipGraphs and replay them with `replay(images, gts)`.
-        With data parallelism the gradient all-reduce stays outside the graphs (between backward and Adam)."""
-        if self.steps_run + warmup < 2:
+        With data parallelism the gradient all-reduce stays outside the graphs (between backward and Adam).
+        One set of graphs per (batch shape, train size): call once per scale of a multi-scale schedule."""
+        st = self._state(images, size)
+        if st.steps_run + warmup < 2:
             # step 1 measures the arena, step 2 builds the deferred-launch tables on the arena addresses the graph will replay
             raise RuntimeError("capture() needs at least 2 eager steps before the captured one (warmup >= 2 on a fresh Trainer)")
-        self.s_images = images.clone()
-        self.s_gts = gts.clone()
+        st.s_images = images.clone()
+        st.s_gts = gts.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.step(self.s_images, self.s_gts)
+                self.step(st.s_images, st.s_gts, size=size)
             if self.world > 1:      # the captured pass has no bucket hooks: let it build its own (single) reduce table eagerly
-                self.forward_backward_local(self.s_images, self.s_gts)
+                self.forward_backward_local(st.s_images, st.s_gts, size=size)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        st.graph = torch.cuda.CUDAGraph()
         if self.world == 1:
-            with torch.cuda.graph(self.graph):
-                self.s_loss = self.step(self.s_images, self.s_gts)
-            self.graph_opt = None
+            with torch.cuda.graph(st.graph):
+                st.s_loss = self.step(st.s_images, st.s_gts, size=size)
+            st.graph_opt = None
         else:
-            with torch.cuda.graph(self.graph):
-                self.s_loss = self.forward_backward_local(self.s_images, self.s_gts)
-            self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt):
+            with torch.cuda.graph(st.graph):
+                st.s_loss = self.forward_backward_local(st.s_images, st.s_gts, size=size)
+            st.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st.graph_opt):
                 self.optimizer_step()
         return self
 
-    def forward_backward_local(self, images, gts):
+    def forward_backward_local(self, images, gts, size=None):
         w, self.world = self.world, 1
         try:
-            return self.forward_backward(images, gts)
+            return self.forward_backward(images, gts, size=size)
         finally:
             self.world = w
 
-    def replay(self, images=None, gts=None):
+    def replay(self, images=None, gts=None, size=None):
+        """Replay the graphs captured for this batch shape / train size (the most recently used state when called without arguments)."""
+        st = self._cur if images is None else self._state(images, size)
+        if st is None or st.graph is None:
+            raise RuntimeError("capture() this batch shape / train size first")
         if images is not None:
-            self.s_images.copy_(images, non_blocking=True)
-            self.s_gts.copy_(gts, non_blocking=True)
-        self.graph.replay()
-        if self.graph_opt is not None:
+            st.s_images.copy_(images, non_blocking=True)
+            st.s_gts.copy_(gts, non_blocking=True)
+        st.graph.replay()
+        if st.graph_opt is not None:
             self.buckets.reduce_all()
-            self.graph_opt.replay()
-        return self.s_loss
+            st.graph_opt.replay()
+        return st.s_loss

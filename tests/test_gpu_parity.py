@@ -500,6 +500,49 @@ def test_pack_weights_multi_matches_single_pack():
         assert torch.equal(wp, tr.pack_cache.entries[key][0]), key
 
 
+def test_multiscale_schedule_vs_oracle_and_per_scale_graphs():
+    """MyTrain_med.py:55,70-73: every batch is trained at 0.75x, 1x and 1.25x (bilinear, align_corners=True, images and masks).  The trainer
+    keeps one warm state (arena, job tables, graphs) per scale; losses are checked against the oracle run on F.interpolate'd inputs."""
+    from pn2.trainer import Trainer
+    from oracle import weights as W
+    from oracle import pranet_oracle as O
+    x, mask = W.synthetic_batch(2, 96, seed=21)
+    xg, mg = x.to(dev), mask.to(dev)
+    sizes = [int(round(96 * r / 32) * 32) for r in (0.75, 1, 1.25)]
+    assert sizes == [64, 96, 128]
+    tr = Trainer(_fixture_model(fp32=True), lr=1e-4)
+    sd = W.make_state_dict(W.manifest_pranet_v2(1), seed=0)
+    for S in sizes:
+        loss = tr.forward_backward(xg, mg, size=S)
+        P = O.clone_sd(sd)
+        xr = F.interpolate(x, size=(S, S), mode="bilinear", align_corners=True) if S != 96 else x
+        mr = F.interpolate(mask, size=(S, S), mode="bilinear", align_corners=True) if S != 96 else mask
+        with torch.no_grad():
+            ref = O.total_loss(O.pranet_v2_forward(P, xr, True), mr)
+        assert abs(float(loss[-1]) - float(ref)) < 2e-3 * float(ref), (S, float(loss[-1]), float(ref))
+        assert tr.last_outs.shape == (8, 2, S, S, 1)
+    # bf16: eager multi-scale steps == per-scale captured graphs, bit for bit, over two rounds of the schedule
+    res = []
+    for graph in (False, True):
+        tr = Trainer(_fixture_model(fp32=False), lr=1e-4)
+        if graph:
+            for S in sizes:
+                tr.capture(xg, mg, warmup=2, size=S)          # 2 eager steps per scale, then its graphs
+            for _ in range(2):
+                for S in sizes:
+                    loss = tr.replay(xg, mg, size=S)
+        else:
+            for S in sizes:
+                for _ in range(2):
+                    tr.step(xg, mg, size=S)
+            for _ in range(2):
+                for S in sizes:
+                    loss = tr.step(xg, mg, size=S)
+        torch.cuda.synchronize()
+        res.append((loss.clone(), tr.flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_full_size_properties_bs32_352_bf16():
     """BASELINE config 2 shape: size-independent properties instead of an oracle run (which would take minutes on the CPU)."""
     from pn2.trainer import Trainer
