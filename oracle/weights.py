@@ -178,6 +178,49 @@ def manifest_pvt_pranet_v2(num_class=1, channel=32):
     return m
 
 
+def _emcad_decoder(m, p, channels=(512, 320, 128, 64), kernel_sizes=(1, 3, 5), expansion=2, num_class=9):
+    """EMCAD_dual registration order (multiclass_seg/EMCAD/lib/decoders.py:407-440; MSCB :104-140, MSDC :83-99, EUCB :166-181, LGAG :190-207,
+    CAB :216-232, SAB :244-251, BasicConv2d :14-22)."""
+    def mscb(q, c):
+        ex = c * expansion
+        _conv(m, q + "0.pconv1.0", ex, c, 1, 1); _bn(m, q + "0.pconv1.1", ex)
+        for i, k in enumerate(kernel_sizes):
+            _conv(m, q + f"0.msdc.dwconvs.{i}.0", ex, 1, k, k); _bn(m, q + f"0.msdc.dwconvs.{i}.1", ex)
+        _conv(m, q + "0.pconv2.0", c, ex, 1, 1); _bn(m, q + "0.pconv2.1", c)
+
+    def eucb(q, cin, cout):
+        _conv(m, q + "up_dwc.1", cin, 1, 3, 3); _bn(m, q + "up_dwc.2", cin)
+        _conv(m, q + "pwc.0", cout, cin, 1, 1, bias=True)
+
+    def lgag(q, c):
+        fi = c // 2
+        for w in ("W_g", "W_x"):
+            _conv(m, q + w + ".0", fi, 2, 3, 3, bias=True); _bn(m, q + w + ".1", fi)       # groups = F_int: 2 input channels per group
+        _conv(m, q + "psi.0", 1, fi, 1, 1, bias=True); _bn(m, q + "psi.1", 1)
+    c = channels
+    mscb(p + "mscb4.", c[0])
+    for i, lvl in ((1, 3), (2, 2), (3, 1)):
+        eucb(p + f"eucb{lvl}.", c[i - 1], c[i]); lgag(p + f"lgag{lvl}.", c[i]); mscb(p + f"mscb{lvl}.", c[i])
+    for i, lvl in enumerate((4, 3, 2, 1)):
+        r = c[i] // 16 if c[i] >= 16 else 1
+        m[p + f"cab{lvl}.fc1.weight"] = (r, c[i], 1, 1); m[p + f"cab{lvl}.fc2.weight"] = (c[i], r, 1, 1)
+    m[p + "sab.conv.weight"] = (1, 2, 7, 7)
+    for i, lvl in enumerate((4, 3, 2, 1)):
+        k = 1 if lvl == 4 else 3
+        _basic(m, p + f"ConvBlock{lvl}_fg", c[i], num_class, k); _basic(m, p + f"ConvBlock{lvl}_bg", c[i], num_class, k)
+
+
+def manifest_emcadnet(num_classes=9):
+    """EMCADNet(dual=True, encoder='pvt_v2_b2') (multiclass_seg/EMCAD/lib/networks.py:10-98): key -> shape in state_dict() order."""
+    m = OrderedDict()
+    _conv(m, "conv.0", 3, 1, 1, 1, bias=True); _bn(m, "conv.1", 3)
+    _pvt_v2(m, "backbone.")
+    _emcad_decoder(m, "decoder.", num_class=num_classes)
+    for i, cch in zip((4, 3, 2, 1), (512, 320, 128, 64)):
+        _conv(m, f"out_head{i}", num_classes, cch, 1, 1, bias=True)
+    return m
+
+
 def make_state_dict(manifest, seed=0):
     """Deterministic non-trivial weights: every tensor from its own CPU generator.
 

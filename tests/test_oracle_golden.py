@@ -190,3 +190,27 @@ def test_pvt_manifest_and_oracle_match_reference():
         if k.startswith("grawnorm."):
             g = P[k[len("grawnorm."):]].grad
             assert abs(float(g.norm()) - float(z[k])) <= 2e-3 * float(z[k]) + 1e-6, k
+
+
+def test_emcad_manifest_and_oracle_match_reference():
+    """BASELINE config 5: EMCADNet(dual, K=9, pvt_v2_b2) manifest + oracle/emcad_oracle.py (8 outputs, the 15-subset CE+Dice+BCE loss, gradient
+    probes) against the imported reference's vectors (tests/golden/make_golden_emcad.py)."""
+    from oracle import emcad_oracle as E
+    ref = json.load(open(os.path.join(G, "manifest_emcad.json")))
+    man = W.manifest_emcadnet(9)
+    assert [(k, list(v)) for k, v in man.items()] == list(ref["emcadnet_dual_k9"].items())
+    z = np.load(os.path.join(G, "emcad_64.npz"))
+    P = O.clone_sd(W.make_state_dict(man, seed=5))
+    for k, v in P.items():
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    outs = E.emcadnet_forward(P, torch.from_numpy(z["x"]), True)
+    for i, o in enumerate(outs):
+        assert float((o.detach() - torch.from_numpy(z[f"out{i}"])).abs().max()) < 1e-4
+    loss = E.mutation_loss(outs, torch.from_numpy(z["label"]), torch.from_numpy(z["bg_mask"]))
+    assert abs(float(loss) - float(z["loss"])) < 1e-4
+    loss.backward()
+    for k in z.files:
+        if k.startswith("grawnorm."):
+            g = P[k[len("grawnorm."):]].grad
+            assert abs(float(g.norm()) - float(z[k])) <= 2e-3 * float(z[k]) + 2e-6, k
