@@ -110,7 +110,7 @@ int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int 
  * ReLU mask: y>0 when y is given; else recomputed as fmaf(x,mask_scale,mask_shift)>0 when mask_scale is given (saves reading y). */
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
                       int M, int Cp, const float* mean, const float* invstd, float* p1, float* p2, int nblk,
-                      const float* mask_scale, const float* mask_shift, void* stream);
+                      const float* mask_scale, const float* mask_shift, int relu6, void* stream);
 int pn2_bn_bwd_blocks(int M, int Cp, int dtype);   /* rows of the p1/p2 partial buffers */
 /* pass 1b: dgamma/dbeta (logical, optionally accumulated) + per-channel coefficients for pass 2 */
 int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn_desc* d, const float* gamma, const float* invstd,
@@ -119,7 +119,7 @@ int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn
  * coef==NULL: pure activation backward (dx = dz), used for eval-mode / affine-only layers.                */
 int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
                      int M, int Cp, const float* mean, const float* invstd, const float* coef, void* dx, int ld_dx,
-                     void* dres, int ld_dres, int dres_accum, const float* mask_scale, const float* mask_shift, void* stream);
+                     void* dres, int ld_dres, int dres_accum, const float* mask_scale, const float* mask_shift, int relu6, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- pooling
  * nn.MaxPool2d(3,2,1) Res2Net_v1b.py:112 ; nn.AvgPool2d(3,stride,1) :40,80 ; AvgPool2d(s,s,ceil,count_include_pad=False) :131-132 */
@@ -218,6 +218,43 @@ int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, voi
 int pn2_attn_bwd_blocks(int Nq);                /* query chunks per (b, head): partial holds [B][heads][chunks][2][roundup(Nkv,64)][64] fp32 */
 int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, const void* dout, int ld_do, const float* lse, void* dq, int ld_dq, void* dkv, int ld_dkv,
                  float* partial, int B, int Nq, int Nkv, int heads, int head_dim, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- EMCAD decoder (multiclass_seg/EMCAD/lib/decoders.py)
+ * Memory-bound pieces of config 5; the 1x1 / 3x3 / 7x7 convs are pn2_conv_*, BatchNorm is pn2_bn_* fed by the partial rows below.          */
+int pn2_dwconv_blocks(int dt, int M, int C);
+/* depth-wise K x K conv, pad K/2, stride 1, no bias: z (+)= dw(x); flip = mirrored kernel (data gradient).  psum/psq non-null:
+ * per-block partial sums of z, z^2 as [pn2_dwconv_blocks(dt, N*H*W, C)][C] rows for pn2_bn_finalize */
+int pn2_dwconv(int dt, const void* x, const float* w, void* z, int N, int H, int W, int C, int K, int flip, int accumulate, float* psum, float* psq, void* stream);
+/* partial[pn2_dwconv_blocks][C*K*K] of the depth-wise weight gradient; finish with pn2_colsum_finalize(partial, nblk, C*K*K, C*K*K, dW, acc) */
+int pn2_dwconv_wgrad(int dt, const void* dz, const void* x, float* partial, int N, int H, int W, int C, int K, void* stream);
+int pn2_pairconv_blocks(int M, int F);
+/* grouped 3x3 conv, groups = F, 2 input channels per group (LGAG.W_g / W_x), pad 1, bias-free here (the bias is folded by the caller):
+ * x [M][2F] -> z [M][F] + BN partial rows [pn2_pairconv_blocks(M, F)][F] ; w [F][2][9] fp32 */
+int pn2_pairconv3x3_fwd(int dt, const void* x, const float* w, void* z, int N, int H, int W, int F, float* psum, float* psq, void* stream);
+int pn2_pairconv3x3_dgrad(int dt, const void* dz, const float* w, void* dx, int N, int H, int W, int F, int accumulate, void* stream);
+/* partial[pn2_pairconv_blocks(M, F)][F*18] ; finish with pn2_colsum_finalize */
+int pn2_pairconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, int N, int H, int W, int F, void* stream);
+/* y (+)= x * gate ; mode 0: gate [N][C] (CAB), mode 1: gate [N][HW] (SAB, LGAG) ; gate fp32.  Also the data gradient (x := dy). */
+int pn2_gate_mul(int dt, const void* x, const float* gate, void* y, int N, int HW, int C, int mode, int accumulate, void* stream);
+/* gate gradient.  mode 1: dgate [N][HW] = sum_c dy*x, written directly.  mode 0: partial [pn2_gate_blocks(dt, HW, C)][N*C] rows, finish with
+ * pn2_colsum_finalize(partial, nblk, N*C, N*C, dgate, acc) */
+int pn2_gate_blocks(int dt, int HW, int C);
+int pn2_gate_bwd(int dt, const void* dy, const void* x, float* dgate_or_partial, int N, int HW, int C, int mode, void* stream);
+/* nn.AdaptiveAvgPool2d(1) and nn.AdaptiveMaxPool2d(1) in one pass (CAB): avg, mx [N][C] in the compute dtype, arg [N][C] = argmax pixel */
+int pn2_global_pool(int dt, const void* x, void* avg, void* mx, int* arg, int N, int HW, int C, void* stream);
+int pn2_global_pool_bwd(int dt, const void* davg, const void* dmax, const int* arg, void* dx, int N, int HW, int C, int accumulate, void* stream);
+/* SAB input: out [NP][8] = (mean over channels, max over channels, 0 x 6), arg [NP] = argmax channel */
+int pn2_chan_stats(int dt, const void* x, void* out8, int* arg, long long NP, int C, void* stream);
+int pn2_chan_stats_bwd(int dt, const void* dout8, const int* arg, void* dx, long long NP, int C, int accumulate, void* stream);
+/* nn.Upsample(scale_factor=2) (nearest) and its adjoint */
+int pn2_upsample_nearest2x(int dt, const void* x, void* y, int N, int H, int W, int C, void* stream);
+int pn2_upsample_nearest2x_bwd(int dt, const void* dy, void* dx, int N, int H, int W, int C, int accumulate, void* stream);
+/* y[p][c] = a[p][perm[c]] + b[p][perm[c]] + c[p][perm[c]]   (b, c optional): the MSDC branch sum written through channel_shuffle, and (with the
+ * inverse permutation, b = c = null) its adjoint */
+int pn2_gather_sum(int dt, const void* a, const void* b, const void* c, const int* perm, void* y, long long M, int C, void* stream);
+/* y = sigmoid(x) as fp32 [n] from a [rows][ld] map with C used channels; dx (+)= dy * y * (1 - y) */
+int pn2_sigmoid(int dt_in, const void* x, int ld, int C, float* y, long long n, void* stream);
+int pn2_sigmoid_bwd(int dt_out, const float* dy, const float* y, void* dx, int ld, int C, long long n, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- element-wise / layout */
 int pn2_binary(int dt, int op /*0 add,1 mul*/, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream);

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void affine_act_k(const Ti* __restrict__ x, in
             if (scale) t = fmaf(t, scale[c + e], shift[c + e]);
             else if (shift) t += shift[c + e];
             if (res) t += r[e];
-            v[e] = relu ? fmaxf(t, 0.f) : t;
+            v[e] = relu ? (relu == 2 ? fminf(fmaxf(t, 0.f), 6.f) : fmaxf(t, 0.f)) : t;
         }
         if constexpr (sizeof(Ti) == sizeof(To)) VL<To, W>::store(y + (size_t)m * ld_y + c, v);
         else {
@@ -128,7 +128,7 @@ template <typename T, typename Tdy, int W>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
                                                        const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, float* __restrict__ p1, float* __restrict__ p2,
-                                                       int rows_per_blk, int CVP, const float* __restrict__ msc, const float* __restrict__ msh) {
+                                                       int rows_per_blk, int CVP, const float* __restrict__ msc, const float* __restrict__ msh, int r6) {
     extern __shared__ __attribute__((aligned(16))) float shf[];   // [2][R][CVP*W]
     const int CV = Cp / W;
     const int R = 256 / CVP;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ d
 #pragma unroll
                         for (int e = 0; e < W; ++e) {
                             // ReLU mask: from the stored output y, or recomputed from the raw conv output (same fmaf as the forward)
-                            const bool off = y ? !(yv[u][e] > 0.f) : (msc && !(fmaf(xv[u][e], ks[e], kh[e]) > 0.f));
+                            const bool off = y ? (!(yv[u][e] > 0.f) || (r6 && yv[u][e] >= 6.f)) : (msc && !(fmaf(xv[u][e], ks[e], kh[e]) > 0.f));
                             const float dz = off ? 0.f : g[u][e];
                             a1[e] += dz; a2[e] += dz * (xv[u][e] - mu[e]) * is[e];
                         }
@@ -221,7 +221,7 @@ template <typename T, typename Tdy, int W>
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
                                                       const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
-                                                      T* __restrict__ dres, int ld_dres, int dres_accum) {
+                                                      T* __restrict__ dres, int ld_dres, int dres_accum, int r6) {
     const int CV = Cp / W;
     const size_t total = (size_t)M * CV;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const Tdy* __restrict__ dy
         if (dres && dres_accum) VL<T, W>::load(dres + (size_t)m * ld_dres + c, rr);
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-            const float dz = (y && !(yv[e] > 0.f)) ? 0.f : g[e];
+            const float dz = (y && (!(yv[e] > 0.f) || (r6 && yv[e] >= 6.f))) ? 0.f : g[e];
             if (coef) {
                 const float xh = (xv[e] - mean[c + e]) * invstd[c + e];
                 o[e] = coef[c + e] * (dz - coef[Cp + c + e] - xh * coef[2 * Cp + c + e]);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void affine_rows_k(const T* __restrict__ x, in
                     for (int e = 0; e < V; ++e) {
                         float t = fmaf(v[e], sc[e], sh[e]);
                         if (res) t += r[e];
-                        v[e] = relu ? fmaxf(t, 0.f) : t;
+                        v[e] = relu ? (relu == 2 ? fminf(fmaxf(t, 0.f), 6.f) : fmaxf(t, 0.f)) : t;
                     }
                     *reinterpret_cast<uint4*>(y + (size_t)mm * ld_y + c) = TT<T>::pack(v);
                 }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
                                                            const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
                                                            T* __restrict__ dres, int ld_dres, int dres_accum, int rows_per_blk, int CVP,
-                                                           const float* __restrict__ msc, const float* __restrict__ msh) {
+                                                           const float* __restrict__ msc, const float* __restrict__ msh, int r6) {
     constexpr int V = TT<T>::VEC;
     const int CV = Cp / V, R = 256 / CVP;
     const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
                     if (dres && dres_accum) TT<T>::unpack(vr[u], rr);
 #pragma unroll
                     for (int e = 0; e < V; ++e) {
-                        const bool off = y ? !(yv[e] > 0.f) : (msc && !(fmaf(xv[e], ks[e], kh[e]) > 0.f));
+                        const bool off = y ? (!(yv[e] > 0.f) || (r6 && yv[e] >= 6.f)) : (msc && !(fmaf(xv[e], ks[e], kh[e]) > 0.f));
                         const float dz = off ? 0.f : g[e];
                         o[e] = coef ? ka[e] * dz + kb[e] * (xv[e] - kmu[e]) + kd[e] : dz;
                         rr[e] = (dres && dres_accum) ? rr[e] + dz : dz;
@@ -392,16 +392,16 @@ int affine_dispatch(const void* x, int ld_x, void* y, int ld_y, int M, int C, co
 
 template <typename T, typename Tdy>
 int bwd_reduce_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, const void* x, int ld_x, int M, int Cp,
-                        const float* mean, const float* invstd, float* p1, float* p2, int nblk, const float* msc, const float* msh, hipStream_t st) {
+                        const float* mean, const float* invstd, float* p1, float* p2, int nblk, const float* msc, const float* msh, int r6, hipStream_t st) {
     constexpr int V = TT<T>::VEC;
     const bool vec = sizeof(T) == sizeof(Tdy) && Cdy == Cp && Cp % V == 0 && ld_dy % V == 0 && ld_x % V == 0 && (!y || ld_y % V == 0);
     const int rows = (M + nblk - 1) / nblk;
     if (vec) {
         int cvp = pow2ceil(Cp / V); if (cvp > 256) cvp = 256;
-        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, V>), dim3(nblk), dim3(256), 2 * 256 * V * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp, msc, msh);
+        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, V>), dim3(nblk), dim3(256), 2 * 256 * V * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp, msc, msh, r6);
     } else {
         int cvp = pow2ceil(Cp); if (cvp > 256) cvp = 256;
-        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, 1>), dim3(nblk), dim3(256), 2 * 256 * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp, msc, msh);
+        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, 1>), dim3(nblk), dim3(256), 2 * 256 * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp, msc, msh, r6);
     }
     PN2_CHECK_LAUNCH();
     return 0;
@@ -409,7 +409,7 @@ int bwd_reduce_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int l
 
 template <typename T, typename Tdy>
 int bwd_apply_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, const void* x, int ld_x, int M, int Cp, const float* mean,
-                       const float* invstd, const float* coef, void* dx, int ld_dx, void* dres, int ld_dres, int dres_accum, const float* msc, const float* msh, hipStream_t st) {
+                       const float* invstd, const float* coef, void* dx, int ld_dx, void* dres, int ld_dres, int dres_accum, const float* msc, const float* msh, int r6, hipStream_t st) {
     constexpr int V = TT<T>::VEC;
     const bool vec = sizeof(T) == sizeof(Tdy) && Cdy == Cp && Cp % V == 0 && ld_dy % V == 0 && ld_dx % V == 0 && (!coef || ld_x % V == 0) &&
                      (!y || ld_y % V == 0) && (!dres || ld_dres % V == 0);
@@ -417,13 +417,13 @@ int bwd_apply_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int ld
         if (vec) {
             int cvp, rpb, nblk;
             rows_geometry(M, Cp / V, cvp, rpb, nblk);
-            hipLaunchKernelGGL((bn_bwd_apply_rows_k<T>), dim3(nblk), dim3(256), 0, st, (const T*)dy, ld_dy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, rpb, cvp, msc, msh);
+            hipLaunchKernelGGL((bn_bwd_apply_rows_k<T>), dim3(nblk), dim3(256), 0, st, (const T*)dy, ld_dy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, rpb, cvp, msc, msh, r6);
             PN2_CHECK_LAUNCH();
             return 0;
         }
     }
-    if (vec) hipLaunchKernelGGL((bn_bwd_apply_k<T, Tdy, V>), dim3(grid_for((size_t)M * (Cp / V))), dim3(256), 0, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum);
-    else hipLaunchKernelGGL((bn_bwd_apply_k<T, Tdy, 1>), dim3(grid_for((size_t)M * Cp)), dim3(256), 0, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum);
+    if (vec) hipLaunchKernelGGL((bn_bwd_apply_k<T, Tdy, V>), dim3(grid_for((size_t)M * (Cp / V))), dim3(256), 0, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, r6);
+    else hipLaunchKernelGGL((bn_bwd_apply_k<T, Tdy, 1>), dim3(grid_for((size_t)M * Cp)), dim3(256), 0, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, r6);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -470,13 +470,13 @@ int pn2_bn_bwd_blocks(int M, int Cp, int dt) {
 
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
                       int M, int Cp, const float* mean, const float* invstd, float* p1, float* p2, int nblk,
-                      const float* mask_scale, const float* mask_shift, void* stream) {
+                      const float* mask_scale, const float* mask_shift, int relu6, void* stream) {
     if (!dy || !x || !mean || !invstd || !p1 || !p2) return -1;
     if (y && dt_y != dt) return -2;
     hipStream_t st = (hipStream_t)stream;
-    if (dt == PN2_BF16 && dt_dy == PN2_BF16) return bwd_reduce_dispatch<bf16_t, bf16_t>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, mask_scale, mask_shift, st);
-    if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_reduce_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, mask_scale, mask_shift, st);
-    if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_reduce_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, mask_scale, mask_shift, st);
+    if (dt == PN2_BF16 && dt_dy == PN2_BF16) return bwd_reduce_dispatch<bf16_t, bf16_t>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, mask_scale, mask_shift, relu6, st);
+    if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_reduce_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, mask_scale, mask_shift, relu6, st);
+    if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_reduce_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, mask_scale, mask_shift, relu6, st);
     return -3;
 }
 
@@ -490,14 +490,14 @@ int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn
 
 int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,
                      int M, int Cp, const float* mean, const float* invstd, const float* coef, void* dx, int ld_dx,
-                     void* dres, int ld_dres, int dres_accum, const float* mask_scale, const float* mask_shift, void* stream) {
+                     void* dres, int ld_dres, int dres_accum, const float* mask_scale, const float* mask_shift, int relu6, void* stream) {
     if (!dy || !dx) return -1;
     if (coef && (!x || !mean || !invstd)) return -1;
     if (y && dt_y != dt) return -2;
     hipStream_t st = (hipStream_t)stream;
-    if (dt == PN2_BF16 && dt_dy == PN2_BF16) return bwd_apply_dispatch<bf16_t, bf16_t>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, st);
-    if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_apply_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, st);
-    if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_apply_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, st);
+    if (dt == PN2_BF16 && dt_dy == PN2_BF16) return bwd_apply_dispatch<bf16_t, bf16_t>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, relu6, st);
+    if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_apply_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, relu6, st);
+    if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_apply_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, relu6, st);
     return -3;
 }
 

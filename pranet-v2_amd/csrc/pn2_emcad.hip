@@ -1,0 +1,684 @@
+// pn2_emcad.hip — kernels of the EMCAD decoder (reference: /root/reference/multiclass_seg/EMCAD/lib/decoders.py, BASELINE config 5):
+//   depth-wise k x k convs (k = 1, 3, 5) feeding BatchNorm      MSDC :83-99, EUCB.up_dwc :170-175
+//   grouped 3x3 conv with 2 input channels per group            LGAG.W_g / W_x :193-200 (groups = F_int)
+//   channel / pixel gates x * g                                  CAB :233-241 and SAB :252-258 used at EMCAD_dual.forward :442-443 ; LGAG :214
+//   global average + max pooling, channel mean + max             CAB :234-237, SAB :253-255
+//   nearest x2 up-sampling                                       EUCB :171
+//   sum of the three MSDC branches written through channel_shuffle   MSCB.forward :147-154 with channel_shuffle :69-77
+//   sigmoid on small fp32 maps                                   CAB / SAB / LGAG.psi
+// All element-wise / memory-bound; BatchNorm statistics come out of the producing kernel as per-block partial rows, like the conv
+// epilogue of pn2_conv.hip, so pn2_bn_finalize / pn2_affine_act / pn2_bn_bwd_* are reused unchanged.  Deterministic (no atomics).
+#include "pn2_common.h"
+#include "../../include/pn2.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void ldv(const T* p, float* f) { TT<T>::unpack(*reinterpret_cast<const uint4*>(p), f); }
+template <typename T> __device__ __forceinline__ void stv(T* p, const float* f) { *reinterpret_cast<uint4*>(p) = TT<T>::pack(f); }
+inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+inline int grid_for(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g)); }
+
+// rows (pixels) per block of the "thread owns a channel vector and walks pixels" kernels: ~1024 blocks, a multiple of R
+inline void walk_geometry(int M, int CV, int& cvp, int& pix, int& nblk) {
+    cvp = pow2ceil(CV); if (cvp > 256) cvp = 256;
+    const int R = 256 / cvp;
+    pix = (M + 1023) / 1024;
+    pix = ((pix + R - 1) / R) * R;
+    if (pix < 4 * R) pix = 4 * R;
+    nblk = (M + pix - 1) / pix;
+}
+
+// cross-row-lane sum of per-thread channel-vector accumulators a[V] -> dst[c] (block partial row), through LDS, fixed order
+template <int V>
+__device__ __forceinline__ void block_colsum(float* sh, const float* a, int CVP, int R, int cvl, int rl, bool active, float* dst) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) sh[(rl * CVP + cvl) * V + e] = a[e];
+    __syncthreads();
+    if (rl == 0 && active) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float s = 0.f;
+            for (int r = 0; r < R; ++r) s += sh[(r * CVP + cvl) * V + e];
+            dst[e] = s;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ depth-wise K x K
+// z[p][c] = sum_taps w[c][tap] x[p + tap][c]; optional per-block partial sums of z and z^2 (BatchNorm batch statistics).
+// flip: mirrored kernel = data gradient.  The thread's K*K x VEC weights stay in registers.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_k(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ z, int N, int H, int W, int C, int flip, int accumulate,
+                                                float* __restrict__ psum, float* __restrict__ psq, int pix_per_blk, int CVP) {
+    constexpr int V = TT<T>::VEC, KK = K * K, PD = K / 2;
+    extern __shared__ float sh[];
+    const int CV = C / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
+    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
+    for (int cvb = 0; cvb < CV; cvb += CVP) {
+        const int cv = cvb + cvl;
+        const bool act = cv < CV;
+        float wr[KK][V], s1[V], s2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            s1[e] = 0.f; s2[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < KK; ++t) wr[t][e] = act ? w[(cv * V + e) * KK + (flip ? KK - 1 - t : t)] : 0.f;
+        }
+        if (act) {
+            for (int m = p0 + rl; m < p1; m += R) {
+                const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
+                float a[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) a[e] = 0.f;
+#pragma unroll
+                for (int t = 0; t < KK; ++t) {
+                    const int iy = oy + t / K - PD, ix = ox + t % K - PD;
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                        float xv[V];
+                        ldv<T>(x + (((size_t)n * H + iy) * W + ix) * C + cv * V, xv);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) a[e] += wr[t][e] * xv[e];
+                    }
+                }
+                const size_t o = (size_t)m * C + cv * V;
+                if (accumulate) { float old[V]; ldv<T>(z + o, old);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) a[e] += old[e]; }
+                stv<T>(z + o, a);
+                if (psum) {       // statistics of the values as stored (rounded to T), like the conv epilogue
+                    float zz[V]; const uint4 pk = TT<T>::pack(a); TT<T>::unpack(pk, zz);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) { s1[e] += zz[e]; s2[e] += zz[e] * zz[e]; }
+                }
+            }
+        }
+        if (psum) {
+            block_colsum<V>(sh, s1, CVP, R, cvl, rl, act, psum + (size_t)blockIdx.x * C + cv * V);
+            block_colsum<V>(sh, s2, CVP, R, cvl, rl, act, psq + (size_t)blockIdx.x * C + cv * V);
+        }
+    }
+}
+
+// partial[blk][C*K*K]: [c*KK + tap] = sum_pixels dz[p][c] * x[p + tap][c]   (taps processed in passes of <= 9 to bound registers)
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_k(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ partial, int N, int H, int W, int C,
+                                                      int pix_per_blk, int CVP) {
+    constexpr int V = TT<T>::VEC, KK = K * K, PD = K / 2, TP = KK < 9 ? KK : 9;
+    extern __shared__ float sh[];
+    const int CV = C / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
+    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
+    for (int cvb = 0; cvb < CV; cvb += CVP) {
+        const int cv = cvb + cvl;
+        const bool act = cv < CV;
+        for (int t0 = 0; t0 < KK; t0 += TP) {
+            float a[TP][V];
+#pragma unroll
+            for (int t = 0; t < TP; ++t)
+#pragma unroll
+                for (int e = 0; e < V; ++e) a[t][e] = 0.f;
+            if (act) {
+                for (int m = p0 + rl; m < p1; m += R) {
+                    const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
+                    float d[V];
+                    ldv<T>(dz + (size_t)m * C + cv * V, d);
+#pragma unroll
+                    for (int t = 0; t < TP; ++t) {
+                        const int tt = t0 + t;
+                        const int iy = oy + tt / K - PD, ix = ox + tt % K - PD;
+                        if (tt < KK && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                            float xv[V];
+                            ldv<T>(x + (((size_t)n * H + iy) * W + ix) * C + cv * V, xv);
+#pragma unroll
+                            for (int e = 0; e < V; ++e) a[t][e] += d[e] * xv[e];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+                if (t0 + t < KK) {
+                    float tmp[V];
+                    block_colsum<V>(sh, a[t], CVP, R, cvl, rl, act, tmp);
+                    if (rl == 0 && act) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) partial[(size_t)blockIdx.x * C * KK + (size_t)(cv * V + e) * KK + t0 + t] = tmp[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ grouped 3x3, two input channels per group
+// z[p][o] = b[o] + sum_{j<2, taps} w[o][j][tap] x[p + tap][2o + j] ;  one thread = one (pixel, 8 outputs) item (16 inputs = two vectors)
+template <typename T>
+__global__ __launch_bounds__(256) void pairconv_fwd_k(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ z, int N, int H, int W, int F,
+                                                      float* __restrict__ psum, float* __restrict__ psq, int pix_per_blk, int CVP) {
+    extern __shared__ float sh[];
+    constexpr int V = 8;                      // outputs per thread (both dtypes: simple scalar loads)
+    const int FV = F / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
+    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
+    for (int cvb = 0; cvb < FV; cvb += CVP) {
+        const int fv = cvb + cvl;
+        const bool act = fv < FV;
+        float s1[V], s2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+        if (act) {
+            for (int m = p0 + rl; m < p1; m += R) {
+                const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
+                float a[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) a[e] = 0.f;
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                        const T* xp = x + (((size_t)n * H + iy) * W + ix) * (2 * F) + fv * 2 * V;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float* wp = w + (size_t)(fv * V + e) * 18;
+                            a[e] += wp[t] * TT<T>::ld(xp + 2 * e) + wp[9 + t] * TT<T>::ld(xp + 2 * e + 1);
+                        }
+                    }
+                }
+                T* zp = z + (size_t)m * F + fv * V;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    TT<T>::st(zp + e, a[e]);
+                    const float zz = TT<T>::ld(zp + e);
+                    s1[e] += zz; s2[e] += zz * zz;
+                }
+            }
+        }
+        block_colsum<V>(sh, s1, CVP, R, cvl, rl, act, psum + (size_t)blockIdx.x * F + fv * V);
+        block_colsum<V>(sh, s2, CVP, R, cvl, rl, act, psq + (size_t)blockIdx.x * F + fv * V);
+    }
+}
+
+// dx[p][2o + j] (+)= sum_taps w[o][j][8 - tap] dz[p + tap][o]
+template <typename T>
+__global__ __launch_bounds__(256) void pairconv_dgrad_k(const T* __restrict__ dz, const float* __restrict__ w, T* __restrict__ dx, int N, int H, int W, int F, int accumulate) {
+    const size_t total = (size_t)N * H * W * F;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int o = (int)(idx % F); size_t p = idx / F;
+        const int ox = (int)(p % W); p /= W; const int oy = (int)(p % H); const int n = (int)(p / H);
+        float a0 = 0.f, a1 = 0.f;
+        for (int t = 0; t < 9; ++t) {
+            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const float d = TT<T>::ld(dz + (((size_t)n * H + iy) * W + ix) * F + o);
+                a0 += w[(size_t)o * 18 + 8 - t] * d; a1 += w[(size_t)o * 18 + 9 + 8 - t] * d;
+            }
+        }
+        T* dp = dx + (((size_t)n * H + oy) * W + ox) * (2 * F) + 2 * o;
+        if (accumulate) { a0 += TT<T>::ld(dp); a1 += TT<T>::ld(dp + 1); }
+        TT<T>::st(dp, a0); TT<T>::st(dp + 1, a1);
+    }
+}
+
+// partial[blk][F*18]: [o*18 + j*9 + tap] = sum_p dz[p][o] x[p + tap][2o + j]
+template <typename T>
+__global__ __launch_bounds__(256) void pairconv_wgrad_k(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ partial, int N, int H, int W, int F,
+                                                        int pix_per_blk, int FP) {
+    extern __shared__ float sh[];             // [R][FP]
+    const int R = 256 / FP, ol = threadIdx.x % FP, rl = threadIdx.x / FP;
+    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
+    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
+    for (int ob = 0; ob < F; ob += FP) {
+        const int o = ob + ol;
+        const bool act = o < F;
+        float a[18];
+#pragma unroll
+        for (int t = 0; t < 18; ++t) a[t] = 0.f;
+        if (act) {
+            for (int m = p0 + rl; m < p1; m += R) {
+                const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
+                const float d = TT<T>::ld(dz + (size_t)m * F + o);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                        const T* xp = x + (((size_t)n * H + iy) * W + ix) * (2 * F) + 2 * o;
+                        a[t] += d * TT<T>::ld(xp); a[9 + t] += d * TT<T>::ld(xp + 1);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {
+            sh[rl * FP + ol] = a[t];
+            __syncthreads();
+            if (rl == 0 && act) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += sh[r * FP + ol];
+                partial[(size_t)blockIdx.x * F * 18 + (size_t)o * 18 + t] = s;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ gates
+// mode 0: y[n][p][c] = x * g[n][c]   (channel gate, CAB) ; mode 1: y = x * g[n][p]   (pixel gate, SAB / LGAG.psi)
+template <typename T>
+__global__ __launch_bounds__(256) void gate_mul_k(const T* __restrict__ x, const float* __restrict__ g, T* __restrict__ y, int N, int HW, int C, int mode, int accumulate) {
+    constexpr int V = TT<T>::VEC;
+    const int CV = C / V;
+    const size_t total = (size_t)N * HW * CV;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int cv = (int)(idx % CV); const size_t p = idx / CV; const int n = (int)(p / HW);
+        float v[V], o[V];
+        ldv<T>(x + p * C + cv * V, v);
+        if (accumulate) ldv<T>(y + p * C + cv * V, o);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float t = v[e] * (mode ? g[p] : g[(size_t)n * C + cv * V + e]);
+            o[e] = accumulate ? o[e] + t : t;
+        }
+        stv<T>(y + p * C + cv * V, o);
+    }
+}
+
+// pixel gate gradient: dg[n][p] = sum_c dy * x   (one 8/16-lane group per pixel)
+template <typename T>
+__global__ __launch_bounds__(256) void gate_dpix_k(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dg, size_t NP, int C) {
+    constexpr int V = TT<T>::VEC;
+    const int CV = C / V;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((size_t)gridDim.x * 256) >> 6;
+    for (size_t p = wave; p < NP; p += nw) {
+        float s = 0.f;
+        for (int cv = lane; cv < CV; cv += 64) {
+            float a[V], b[V];
+            ldv<T>(dy + p * C + cv * V, a); ldv<T>(x + p * C + cv * V, b);
+#pragma unroll
+            for (int e = 0; e < V; ++e) s += a[e] * b[e];
+        }
+        s = wave_sum(s);
+        if (lane == 0) dg[p] = s;
+    }
+}
+
+// channel gate gradient partials: part[blk][n*C + c] = sum over the block's pixels of sample n of dy * x   (grid: blocks x N)
+template <typename T>
+__global__ __launch_bounds__(256) void gate_dchan_k(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part, int N, int HW, int C, int pix_per_blk, int CVP) {
+    constexpr int V = TT<T>::VEC;
+    extern __shared__ float sh[];
+    const int CV = C / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP, n = blockIdx.y;
+    const int p0 = blockIdx.x * pix_per_blk;
+    int p1 = p0 + pix_per_blk; if (p1 > HW) p1 = HW;
+    for (int cvb = 0; cvb < CV; cvb += CVP) {
+        const int cv = cvb + cvl;
+        const bool act = cv < CV;
+        float a[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] = 0.f;
+        if (act) {
+            for (int m = p0 + rl; m < p1; m += R) {
+                float d[V], xv[V];
+                const size_t o = ((size_t)n * HW + m) * C + cv * V;
+                ldv<T>(dy + o, d); ldv<T>(x + o, xv);
+#pragma unroll
+                for (int e = 0; e < V; ++e) a[e] += d[e] * xv[e];
+            }
+        }
+        block_colsum<V>(sh, a, CVP, R, cvl, rl, act, part + (size_t)blockIdx.x * N * C + (size_t)n * C + cv * V);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ global avg + max pooling (CAB)
+// one block per (n, channel-vector chunk): avg[n][c], mx[n][c] (compute dtype, rows of an [N][1][1][C] map) and the argmax pixel
+template <typename T>
+__global__ __launch_bounds__(256) void global_pool_k(const T* __restrict__ x, T* __restrict__ avg, T* __restrict__ mx, int* __restrict__ arg, int HW, int C) {
+    constexpr int V = TT<T>::VEC;
+    __shared__ float ssum[32][8]; __shared__ float smax[32][8]; __shared__ int sarg[32][8];
+    const int CV = C / V, n = blockIdx.y;
+    const int cvl = threadIdx.x % 8, rl = threadIdx.x / 8, cv = blockIdx.x * 8 + cvl;      // 8 channel vectors x 32 row lanes
+    float s[V], m[V]; int am[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s[e] = 0.f; m[e] = -INFINITY; am[e] = 0; }
+    if (cv < CV) {
+        for (int p = rl; p < HW; p += 32) {
+            float v[V];
+            ldv<T>(x + ((size_t)n * HW + p) * C + cv * V, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { s[e] += v[e]; if (v[e] > m[e]) { m[e] = v[e]; am[e] = p; } }
+        }
+    }
+    // reduce the 32 row lanes per channel (sequential in lane order: first maximum wins, as torch's max pooling does)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        ssum[rl][cvl] = s[e]; smax[rl][cvl] = m[e]; sarg[rl][cvl] = am[e];
+        __syncthreads();
+        if (rl == 0 && cv < CV) {
+            float ts = 0.f, tm = -INFINITY; int ta = 0;
+            for (int r = 0; r < 32; ++r) {
+                ts += ssum[r][cvl];
+                if (smax[r][cvl] > tm || (smax[r][cvl] == tm && sarg[r][cvl] < ta)) { tm = smax[r][cvl]; ta = sarg[r][cvl]; }
+            }
+            const int c = cv * V + e;
+            TT<T>::st(avg + (size_t)n * C + c, ts / (float)HW);
+            TT<T>::st(mx + (size_t)n * C + c, tm);
+            arg[(size_t)n * C + c] = ta;
+        }
+        __syncthreads();
+    }
+}
+
+// dx[n][p][c] (+)= davg[n][c] / HW + (p == arg[n][c]) * dmax[n][c]
+template <typename T>
+__global__ __launch_bounds__(256) void global_pool_bwd_k(const T* __restrict__ davg, const T* __restrict__ dmax, const int* __restrict__ arg, T* __restrict__ dx,
+                                                         int N, int HW, int C, int accumulate) {
+    const size_t total = (size_t)N * HW * C;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C); const size_t p = idx / C; const int n = (int)(p / HW), pp = (int)(p % HW);
+        float v = TT<T>::ld(davg + (size_t)n * C + c) / (float)HW;
+        if (arg[(size_t)n * C + c] == pp) v += TT<T>::ld(dmax + (size_t)n * C + c);
+        if (accumulate) v += TT<T>::ld(dx + idx);
+        TT<T>::st(dx + idx, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ channel mean + max per pixel (SAB)
+// out[p][0] = mean_c x, out[p][1] = max_c x, out[p][2..7] = 0 ; arg[p] = first channel attaining the max
+template <typename T>
+__global__ __launch_bounds__(256) void chan_stats_k(const T* __restrict__ x, T* __restrict__ out, int* __restrict__ arg, size_t NP, int C) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((size_t)gridDim.x * 256) >> 6;
+    for (size_t p = wave; p < NP; p += nw) {
+        float s = 0.f, m = -INFINITY; int am = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float v = TT<T>::ld(x + p * C + c);
+            s += v;
+            if (v > m) { m = v; am = c; }
+        }
+        s = wave_sum(s);
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(m, o); const int oa = __shfl_xor(am, o);
+            if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+        }
+        if (lane < 8) TT<T>::st(out + p * 8 + lane, lane == 0 ? s / (float)C : (lane == 1 ? m : 0.f));
+        if (lane == 0) arg[p] = am;
+    }
+}
+
+// dx[p][c] (+)= dout[p][0] / C + (c == arg[p]) * dout[p][1]
+template <typename T>
+__global__ __launch_bounds__(256) void chan_stats_bwd_k(const T* __restrict__ dout, const int* __restrict__ arg, T* __restrict__ dx, size_t NP, int C, int accumulate) {
+    const size_t total = NP * C;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C); const size_t p = idx / C;
+        float v = TT<T>::ld(dout + p * 8) / (float)C;
+        if (arg[p] == c) v += TT<T>::ld(dout + p * 8 + 1);
+        if (accumulate) v += TT<T>::ld(dx + idx);
+        TT<T>::st(dx + idx, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ nearest x2
+template <typename T>
+__global__ __launch_bounds__(256) void up2_k(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
+    constexpr int V = TT<T>::VEC;
+    const int CV = C / V, OH = 2 * H, OW = 2 * W;
+    const size_t total = (size_t)N * OH * OW * CV;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int n = (int)(p / OH);
+        *reinterpret_cast<uint4*>(y + (((size_t)n * OH + oy) * OW + ox) * C + cv * V) =
+            *reinterpret_cast<const uint4*>(x + (((size_t)n * H + (oy >> 1)) * W + (ox >> 1)) * C + cv * V);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void up2_bwd_k(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int accumulate) {
+    constexpr int V = TT<T>::VEC;
+    const int CV = C / V, OW = 2 * W;
+    const size_t total = (size_t)N * H * W * CV;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int ix = (int)(p % W); p /= W; const int iy = (int)(p % H); const int n = (int)(p / H);
+        float a[V], b[V];
+        const T* base = dy + (((size_t)n * 2 * H + 2 * iy) * OW + 2 * ix) * C + cv * V;
+        ldv<T>(base, a);
+        ldv<T>(base + C, b);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += b[e];
+        ldv<T>(base + (size_t)OW * C, b);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += b[e];
+        ldv<T>(base + (size_t)OW * C + C, b);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += b[e];
+        T* d = dx + (((size_t)n * H + iy) * W + ix) * C + cv * V;
+        if (accumulate) { ldv<T>(d, b);
+#pragma unroll
+            for (int e = 0; e < V; ++e) a[e] += b[e]; }
+        stv<T>(d, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ sum of up to 3 tensors through a channel permutation
+// y[p][c] = a[p][perm[c]] (+ b[p][perm[c]] + c3[p][perm[c]])     (MSCB: dout = channel_shuffle(sum of the MSDC branches); backward: one gather)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_sum_k(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c3, const int* __restrict__ perm,
+                                                    T* __restrict__ y, size_t M, int C) {
+    const size_t total = M * C;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C); const size_t p = idx / C;
+        const size_t s = p * C + perm[c];
+        float v = TT<T>::ld(a + s);
+        if (b) v += TT<T>::ld(b + s);
+        if (c3) v += TT<T>::ld(c3 + s);
+        TT<T>::st(y + idx, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ sigmoid on small maps
+template <typename Ti>
+__global__ __launch_bounds__(256) void sigmoid_k(const Ti* __restrict__ x, float* __restrict__ y, size_t n, int ld, int C) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = TT<Ti>::ld(x + (i / C) * ld + i % C);
+        y[i] = 1.f / (1.f + expf(-v));
+    }
+}
+template <typename To>
+__global__ __launch_bounds__(256) void sigmoid_bwd_k(const float* __restrict__ dy, const float* __restrict__ y, To* __restrict__ dx, size_t n, int ld, int C, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        To* d = dx + (i / C) * ld + i % C;
+        const float g = dy[i] * y[i] * (1.f - y[i]);
+        TT<To>::st(d, accumulate ? TT<To>::ld(d) + g : g);
+    }
+}
+
+}  // namespace
+
+#define EM_DISPATCH(dt, BODY) \
+    if ((dt) == PN2_BF16) { typedef bf16_t T; BODY } else if ((dt) == PN2_F32) { typedef float T; BODY } else return -3;
+#define EM_K(K_, BODY) \
+    if ((K_) == 1) { constexpr int KK_ = 1; BODY } else if ((K_) == 3) { constexpr int KK_ = 3; BODY } else if ((K_) == 5) { constexpr int KK_ = 5; BODY } else return -2;
+
+extern "C" {
+
+int pn2_dwconv_blocks(int dt, int M, int C) {
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (M < 1 || C % V) return -1;
+    int cvp, pix, nblk; walk_geometry(M, C / V, cvp, pix, nblk);
+    return nblk;
+}
+
+/* depth-wise K x K conv, pad K/2, stride 1, no bias: z (+)= dw(x); flip = mirrored kernel (data gradient).  psum/psq non-null:
+ * per-block partial sums of z, z^2 as [pn2_dwconv_blocks(dt, N*H*W, C)][C] rows for pn2_bn_finalize */
+int pn2_dwconv(int dt, const void* x, const float* w, void* z, int N, int H, int W, int C, int K, int flip, int accumulate, float* psum, float* psq, void* stream) {
+    if (!x || !w || !z || (psum && !psq)) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (C % V) return -2;
+    int cvp, pix, nblk; walk_geometry(N * H * W, C / V, cvp, pix, nblk);
+    EM_DISPATCH(dt, EM_K(K, { hipLaunchKernelGGL((dwconv_k<T, KK_>), dim3(nblk), dim3(256), 256 * TT<T>::VEC * 4, (hipStream_t)stream, (const T*)x, w, (T*)z, N, H, W, C,
+                                                  flip, accumulate, psum, psq, pix, cvp); }))
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* partial[pn2_dwconv_blocks][C*K*K] of the depth-wise weight gradient; finish with pn2_colsum_finalize(partial, nblk, C*K*K, C*K*K, dW, acc) */
+int pn2_dwconv_wgrad(int dt, const void* dz, const void* x, float* partial, int N, int H, int W, int C, int K, void* stream) {
+    if (!dz || !x || !partial) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (C % V) return -2;
+    int cvp, pix, nblk; walk_geometry(N * H * W, C / V, cvp, pix, nblk);
+    EM_DISPATCH(dt, EM_K(K, { hipLaunchKernelGGL((dwconv_wgrad_k<T, KK_>), dim3(nblk), dim3(256), 256 * TT<T>::VEC * 4, (hipStream_t)stream, (const T*)dz, (const T*)x, partial,
+                                                  N, H, W, C, pix, cvp); }))
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_pairconv_blocks(int M, int F) {
+    if (M < 1 || F % 8) return -1;
+    int cvp, pix, nblk; walk_geometry(M, F / 8, cvp, pix, nblk);
+    return nblk;
+}
+
+/* grouped 3x3 conv, groups = F, 2 input channels per group (LGAG.W_g / W_x), pad 1, bias-free here (the bias is folded by the caller):
+ * x [M][2F] -> z [M][F] + BN partial rows [pn2_pairconv_blocks(M, F)][F] ; w [F][2][9] fp32 */
+int pn2_pairconv3x3_fwd(int dt, const void* x, const float* w, void* z, int N, int H, int W, int F, float* psum, float* psq, void* stream) {
+    if (!x || !w || !z || !psum || !psq) return -1;
+    if (F % 8) return -2;
+    int cvp, pix, nblk; walk_geometry(N * H * W, F / 8, cvp, pix, nblk);
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(pairconv_fwd_k<T>, dim3(nblk), dim3(256), 256 * 8 * 4, (hipStream_t)stream, (const T*)x, w, (T*)z, N, H, W, F, psum, psq, pix, cvp); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_pairconv3x3_dgrad(int dt, const void* dz, const float* w, void* dx, int N, int H, int W, int F, int accumulate, void* stream) {
+    if (!dz || !w || !dx) return -1;
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(pairconv_dgrad_k<T>, dim3(grid_for((size_t)N * H * W * F)), dim3(256), 0, (hipStream_t)stream, (const T*)dz, w, (T*)dx, N, H, W, F, accumulate); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* partial[pn2_pairconv_blocks(M, F)][F*18] ; finish with pn2_colsum_finalize */
+int pn2_pairconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, int N, int H, int W, int F, void* stream) {
+    if (!dz || !x || !partial) return -1;
+    if (F % 8) return -2;
+    int cvp, pix, nblk; walk_geometry(N * H * W, F / 8, cvp, pix, nblk);
+    int fp = pow2ceil(F); if (fp > 256) fp = 256;
+    const int R = 256 / fp;
+    if (pix % R) pix = ((pix + R - 1) / R) * R;           // same block count: pix only grows to a multiple of R when R > the fwd R (never for F >= 32)
+    if ((N * H * W + pix - 1) / pix != nblk) return -2;
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(pairconv_wgrad_k<T>, dim3(nblk), dim3(256), 256 * 4, (hipStream_t)stream, (const T*)dz, (const T*)x, partial, N, H, W, F, pix, fp); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* y (+)= x * gate ; mode 0: gate [N][C] (CAB), mode 1: gate [N][HW] (SAB, LGAG) ; gate fp32.  Also the data gradient (x := dy). */
+int pn2_gate_mul(int dt, const void* x, const float* gate, void* y, int N, int HW, int C, int mode, int accumulate, void* stream) {
+    if (!x || !gate || !y) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (C % V) return -2;
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(gate_mul_k<T>, dim3(grid_for((size_t)N * HW * (C / V))), dim3(256), 0, (hipStream_t)stream, (const T*)x, gate, (T*)y, N, HW, C, mode, accumulate); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* gate gradient.  mode 1: dgate [N][HW] = sum_c dy*x, written directly.  mode 0: partial [pn2_gate_blocks(dt, HW, C)][N*C] rows, finish with
+ * pn2_colsum_finalize(partial, nblk, N*C, N*C, dgate, acc) */
+int pn2_gate_blocks(int dt, int HW, int C) {
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (HW < 1 || C % V) return -1;
+    int cvp, pix, nblk; walk_geometry(HW, C / V, cvp, pix, nblk);
+    return nblk;
+}
+
+int pn2_gate_bwd(int dt, const void* dy, const void* x, float* dgate_or_partial, int N, int HW, int C, int mode, void* stream) {
+    if (!dy || !x || !dgate_or_partial) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (C % V) return -2;
+    if (mode == 1) {
+        EM_DISPATCH(dt, { hipLaunchKernelGGL(gate_dpix_k<T>, dim3(grid_for((size_t)N * HW * 64)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)x, dgate_or_partial, (size_t)N * HW, C); })
+    } else {
+        int cvp, pix, nblk; walk_geometry(HW, C / V, cvp, pix, nblk);
+        EM_DISPATCH(dt, { hipLaunchKernelGGL(gate_dchan_k<T>, dim3(nblk, N), dim3(256), 256 * TT<T>::VEC * 4, (hipStream_t)stream, (const T*)dy, (const T*)x, dgate_or_partial, N, HW, C, pix, cvp); })
+    }
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* nn.AdaptiveAvgPool2d(1) and nn.AdaptiveMaxPool2d(1) in one pass (CAB): avg, mx [N][C] in the compute dtype, arg [N][C] = argmax pixel */
+int pn2_global_pool(int dt, const void* x, void* avg, void* mx, int* arg, int N, int HW, int C, void* stream) {
+    if (!x || !avg || !mx || !arg) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (C % V) return -2;
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(global_pool_k<T>, dim3((C / V + 7) / 8, N), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)avg, (T*)mx, arg, HW, C); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_global_pool_bwd(int dt, const void* davg, const void* dmax, const int* arg, void* dx, int N, int HW, int C, int accumulate, void* stream) {
+    if (!davg || !dmax || !arg || !dx) return -1;
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(global_pool_bwd_k<T>, dim3(grid_for((size_t)N * HW * C)), dim3(256), 0, (hipStream_t)stream, (const T*)davg, (const T*)dmax, arg, (T*)dx, N, HW, C, accumulate); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* SAB input: out [NP][8] = (mean over channels, max over channels, 0 x 6), arg [NP] = argmax channel */
+int pn2_chan_stats(int dt, const void* x, void* out8, int* arg, long long NP, int C, void* stream) {
+    if (!x || !out8 || !arg) return -1;
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(chan_stats_k<T>, dim3(grid_for((size_t)NP * 64)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out8, arg, (size_t)NP, C); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_chan_stats_bwd(int dt, const void* dout8, const int* arg, void* dx, long long NP, int C, int accumulate, void* stream) {
+    if (!dout8 || !arg || !dx) return -1;
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(chan_stats_bwd_k<T>, dim3(grid_for((size_t)NP * C)), dim3(256), 0, (hipStream_t)stream, (const T*)dout8, arg, (T*)dx, (size_t)NP, C, accumulate); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* nn.Upsample(scale_factor=2) (nearest) and its adjoint */
+int pn2_upsample_nearest2x(int dt, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+    if (!x || !y) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (C % V) return -2;
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(up2_k<T>, dim3(grid_for((size_t)N * 4 * H * W * (C / V))), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, N, H, W, C); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_upsample_nearest2x_bwd(int dt, const void* dy, void* dx, int N, int H, int W, int C, int accumulate, void* stream) {
+    if (!dy || !dx) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (C % V) return -2;
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(up2_bwd_k<T>, dim3(grid_for((size_t)N * H * W * (C / V))), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, N, H, W, C, accumulate); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* y[p][c] = a[p][perm[c]] + b[p][perm[c]] + c[p][perm[c]]   (b, c optional): the MSDC branch sum written through channel_shuffle, and (with the
+ * inverse permutation, b = c = null) its adjoint */
+int pn2_gather_sum(int dt, const void* a, const void* b, const void* c, const int* perm, void* y, long long M, int C, void* stream) {
+    if (!a || !perm || !y) return -1;
+    EM_DISPATCH(dt, { hipLaunchKernelGGL(gather_sum_k<T>, dim3(grid_for((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (const T*)c, perm, (T*)y, (size_t)M, C); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* y = sigmoid(x) as fp32 [n] from a [rows][ld] map with C used channels; dx (+)= dy * y * (1 - y) */
+int pn2_sigmoid(int dt_in, const void* x, int ld, int C, float* y, long long n, void* stream) {
+    if (!x || !y || n < 1) return -1;
+    EM_DISPATCH(dt_in, { hipLaunchKernelGGL(sigmoid_k<T>, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, y, (size_t)n, ld, C); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_sigmoid_bwd(int dt_out, const float* dy, const float* y, void* dx, int ld, int C, long long n, int accumulate, void* stream) {
+    if (!dy || !y || !dx || n < 1) return -1;
+    EM_DISPATCH(dt_out, { hipLaunchKernelGGL(sigmoid_bwd_k<T>, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, dy, y, (T*)dx, (size_t)n, ld, C, accumulate); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

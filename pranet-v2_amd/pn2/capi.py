@@ -78,10 +78,10 @@ SIGNATURES = {
     "pn2_bn_finalize": [P, P, I, C.POINTER(BnDesc), P, P, P, P, P, P, P, P, P],
     "pn2_bn_eval_prepare": [C.POINTER(BnDesc), P, P, P, P, P, P, P],
     "pn2_affine_act": [I, P, I, I, P, I, I, I, P, P, P, I, I, P],
-    "pn2_bn_bwd_reduce": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, P, P],
+    "pn2_bn_bwd_reduce": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, P, I, P],
     "pn2_bn_bwd_blocks": [I, I, I],
     "pn2_bn_bwd_finalize": [P, P, I, C.POINTER(BnDesc), P, P, P, P, I, P, P],
-    "pn2_bn_bwd_apply": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, I, I, P, P, P],
+    "pn2_bn_bwd_apply": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, I, I, P, P, I, P],
     "pn2_maxpool3x3s2_fwd": [I, P, I, P, I, P, I, I, I, I, I, I, P],
     "pn2_maxpool3x3s2_bwd": [I, P, I, P, P, I, I, I, I, I, I, I, P],
     "pn2_avgpool_fwd": [I, P, I, P, I, I, I, I, I, I, I, I, I, I, I, P],
@@ -113,6 +113,25 @@ SIGNATURES = {
     "pn2_attn_fwd": [I, P, I, P, I, P, I, P, I, I, I, I, I, FL, P],
     "pn2_attn_bwd_blocks": [I],
     "pn2_attn_bwd": [I, P, I, P, I, P, I, P, P, I, P, I, P, I, I, I, I, I, FL, P],
+    "pn2_dwconv_blocks": [I, I, I],
+    "pn2_dwconv": [I, P, P, P, I, I, I, I, I, I, I, P, P, P],
+    "pn2_dwconv_wgrad": [I, P, P, P, I, I, I, I, I, P],
+    "pn2_pairconv_blocks": [I, I],
+    "pn2_pairconv3x3_fwd": [I, P, P, P, I, I, I, I, P, P, P],
+    "pn2_pairconv3x3_dgrad": [I, P, P, P, I, I, I, I, I, P],
+    "pn2_pairconv3x3_wgrad": [I, P, P, P, I, I, I, I, P],
+    "pn2_gate_mul": [I, P, P, P, I, I, I, I, I, P],
+    "pn2_gate_blocks": [I, I, I],
+    "pn2_gate_bwd": [I, P, P, P, I, I, I, I, P],
+    "pn2_global_pool": [I, P, P, P, P, I, I, I, P],
+    "pn2_global_pool_bwd": [I, P, P, P, P, I, I, I, I, P],
+    "pn2_chan_stats": [I, P, P, P, LL, I, P],
+    "pn2_chan_stats_bwd": [I, P, P, P, LL, I, I, P],
+    "pn2_upsample_nearest2x": [I, P, P, I, I, I, I, P],
+    "pn2_upsample_nearest2x_bwd": [I, P, P, I, I, I, I, I, P],
+    "pn2_gather_sum": [I, P, P, P, P, P, LL, I, P],
+    "pn2_sigmoid": [I, P, I, I, P, LL, P],
+    "pn2_sigmoid_bwd": [I, P, P, P, I, I, LL, I, P],
     "pn2_binary": [I, I, P, I, P, I, P, I, I, I, I, P],
     "pn2_copy": [I, P, I, I, P, I, I, I, I, P],
     "pn2_nchw_to_nhwc": [I, P, P, I, I, I, I, I, P],
@@ -125,7 +144,8 @@ SIGNATURES = {
 # entry points that return a value rather than a status
 _VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
                 "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
-                "pn2_dsra_tail_blocks", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks"}
+                "pn2_dsra_tail_blocks", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks",
+                "pn2_dwconv_blocks", "pn2_pairconv_blocks", "pn2_gate_blocks"}
 
 _lib = None
 WORK = {}     # profiling annotation for the next launch (algorithmic flops / tag), consumed by pn2.profile.Recorder

@@ -19,6 +19,7 @@ from . import capi
 from .capi import call, F32, BF16
 
 TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+_PERMS = {}     # channel_shuffle permutations (device int32 tensors) by (channels, groups)
 TUNER = {}      # process-wide conv shape -> tuned kernel/tile code (see Engine._tune_gemm)
 
 
@@ -648,8 +649,13 @@ class Engine:
                 call.pn2_bn_finalize(_p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
                                      _p(scale), _p(shift), _p(mean), _p(invstd), st)
                 self.bn_modules.append(bn)
+                if bias is not None:          # biased conv followed by train-mode BN: the output is unchanged, only the running mean sees the bias
+                    with torch.no_grad():
+                        bn.running_mean.add_(bias.detach(), alpha=bd.momentum)
             else:
                 call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), st)
+                if bias is not None:
+                    shift[:Cout] += bias.detach() * scale[:Cout]
         elif bias is not None:
             if Cout_p == Cout:
                 shift = bias.detach()
@@ -667,7 +673,7 @@ class Engine:
         if residual is not None:
             assert residual.Cp == Cout_p and residual.dt == self.dt
         call.pn2_affine_act(self.dt, _p(raw), Cout_p, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
-                            residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, 1 if relu else 0, st)
+                            residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
 
         if not self.need_grad:
             return out
@@ -679,6 +685,7 @@ class Engine:
             draw = self.empty(N, OH, OW, Cout_p)
             Cdy = ncopy
             ymask = out if relu else None
+            r6 = 1 if relu == 2 else 0          # relu: False / True (ReLU) / 2 (ReLU6: the mask also drops the saturated y == 6)
             msc = msh = None
             if os.environ.get("PN2_MASK_FROM_X", "0") == "1" and relu and train_bn and residual is None and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) % 8 == 0:
                 # ReLU mask recomputed from the raw conv output (fmaf(x, scale, shift) > 0, bit-identical to the forward):
@@ -688,7 +695,7 @@ class Engine:
                 nb = call.pn2_bn_bwd_blocks(M, Cout_p, self.dt)
                 p1, p2 = self.fbuf(nb, Cout_p), self.fbuf(nb, Cout_p)
                 call.pn2_bn_bwd_reduce(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
-                                       _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(p1), _p(p2), nb, _p(msc), _p(msh), st)
+                                       _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(p1), _p(p2), nb, _p(msc), _p(msh), r6, st)
                 coef = self.fbuf(3 * Cout_p)
                 gg, ga = self.pgrads.sink(bn.weight)
                 gb, gba = self.pgrads.sink(bn.bias)
@@ -709,8 +716,10 @@ class Engine:
                 rg, racc = residual.grad_sink()
             call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
                                   _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
-                                  _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), st)
-            if not train_bn and not bias_done:                 # biased conv / nn.Linear: db = column sums of dz
+                                  _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), r6, st)
+            if train_bn:
+                bias_done = bias is None
+            if not bias_done:                                  # biased conv / nn.Linear: db = column sums of dz (~0 under a train-mode BN)
                 gb, gba = self.pgrads.sink(bias)
                 self.colsum(draw, M, Cout_p, Cout, gb, gba)
             # ---- weight gradient
@@ -850,14 +859,14 @@ class Engine:
             nb = call.pn2_bn_bwd_blocks(M, Ct, self.dt)
             p1, p2 = self.fbuf(nb, Ct), self.fbuf(nb, Ct)
             nul = C.c_void_p(0)
-            call.pn2_bn_bwd_reduce(self.dt, self.dt, _p(dy), Ct, Ct, nul, 0, self.dt, _p(raw), Ct, M, Ct, _p(mean), _p(invstd), _p(p1), _p(p2), nb, nul, nul, st)
+            call.pn2_bn_bwd_reduce(self.dt, self.dt, _p(dy), Ct, Ct, nul, 0, self.dt, _p(raw), Ct, M, Ct, _p(mean), _p(invstd), _p(p1), _p(p2), nb, nul, nul, 0, st)
             coef = self.fbuf(3 * Ct)
             for m, bd, off in zip(mods, bds, offs):
                 gg, ga = self.pgrads.sink(m.bn.weight)
                 gb, gba = self.pgrads.sink(m.bn.bias)
                 call.pn2_bn_bwd_finalize(_p(p1[:, off:]), _p(p2[:, off:]), nb, C.byref(bd), _p(m.bn.weight), _p(invstd[off:]), _p(gg), _p(gb), ga, _p(coef[off:]), st)
             draw = self.empty(N, H, W, Ct)
-            call.pn2_bn_bwd_apply(self.dt, self.dt, _p(dy), Ct, Ct, nul, 0, self.dt, _p(raw), Ct, M, Ct, _p(mean), _p(invstd), _p(coef), _p(draw), Ct, nul, 0, 0, nul, nul, st)
+            call.pn2_bn_bwd_apply(self.dt, self.dt, _p(dy), Ct, Ct, nul, 0, self.dt, _p(raw), Ct, M, Ct, _p(mean), _p(invstd), _p(coef), _p(draw), Ct, nul, 0, 0, nul, nul, 0, st)
             wd = capi.WgradDesc()
             wd.N, wd.H, wd.W, wd.OH, wd.OW = N, H, W, H, W
             wd.Cin_p, wd.ld_x, wd.Cout_p, wd.ld_dy = x.Cp, x.ld, Ct, Ct
@@ -1011,6 +1020,238 @@ class Engine:
             call.pn2_attn_bwd(self.dt, q.ptr, Cc, kv.ptr, 2 * Cc, _p(do), Cc, _p(lse), _p(gq), Cc, _p(gkv), 2 * Cc, _p(part), B, Nq, Nkv, heads, hd, scale, st)
         self.record(bwd)
         return o
+
+    # ------------------------------------------------------------------ EMCAD decoder ops (multiclass_seg/EMCAD/lib/decoders.py)
+    def bn_after(self, N, H, W, Cc, nblk, launch, back, bn, relu=False, residual=None, bias=None):
+        """y = act(BN(raw) + residual) for a producer other than the implicit-GEMM conv: `launch(raw, psum, psq)` writes raw [M][Cc] and
+        nblk partial rows of sum / sum of squares; `back(draw)` receives the gradient w.r.t. raw.  relu: False / True / 2 (ReLU6)."""
+        assert Cc % 8 == 0
+        M, st, train = N * H * W, _stream(), self.training
+        raw = self.empty(N, H, W, Cc)
+        psum, psq = (self.fbuf(nblk, Cc), self.fbuf(nblk, Cc)) if train else (None, None)
+        launch(raw, psum, psq)
+        bd = capi.BnDesc()
+        bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, Cc, Cc, Cc, Cc, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
+        scale, shift = self.fbuf(Cc), self.fbuf(Cc)
+        mean = invstd = None
+        if train:
+            mean, invstd = self.fbuf(Cc), self.fbuf(Cc)
+            call.pn2_bn_finalize(_p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+                                 _p(scale), _p(shift), _p(mean), _p(invstd), st)
+            self.bn_modules.append(bn)
+            if bias is not None:
+                with torch.no_grad():
+                    bn.running_mean.add_(bias.detach(), alpha=bd.momentum)
+        else:
+            call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), st)
+            if bias is not None:
+                shift += bias.detach() * scale
+        out = Act(self, self.empty(N, H, W, Cc), Cc, Cc, Cc, self.dt)
+        if residual is not None:
+            assert residual.Cp == Cc and residual.dt == self.dt
+        call.pn2_affine_act(self.dt, _p(raw), Cc, self.dt, out.ptr, out.ld, M, Cc, _p(scale), _p(shift),
+                            residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
+        if not self.need_grad:
+            return out
+
+        def bwd():
+            st = _stream()
+            if not train:
+                raise RuntimeError("backward through eval-mode BatchNorm is not supported")
+            dy = out.grad_buf()
+            assert out.grad_written or out.child_written
+            draw = self.empty(N, H, W, Cc)
+            ymask = out if relu else None
+            r6 = 1 if relu == 2 else 0
+            nul = C.c_void_p(0)
+            nb = call.pn2_bn_bwd_blocks(M, Cc, self.dt)
+            p1, p2 = self.fbuf(nb, Cc), self.fbuf(nb, Cc)
+            call.pn2_bn_bwd_reduce(self.dt, self.dt, _p(dy), dy.stride(2), Cc, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
+                                   _p(raw), Cc, M, Cc, _p(mean), _p(invstd), _p(p1), _p(p2), nb, nul, nul, r6, st)
+            coef = self.fbuf(3 * Cc)
+            gg, ga = self.pgrads.sink(bn.weight)
+            gb, gba = self.pgrads.sink(bn.bias)
+            call.pn2_bn_bwd_finalize(_p(p1), _p(p2), nb, C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
+            rg, racc = (None, 0)
+            if residual is not None and residual.requires_grad:
+                rg, racc = residual.grad_sink()
+            call.pn2_bn_bwd_apply(self.dt, self.dt, _p(dy), dy.stride(2), Cc, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
+                                  _p(raw), Cc, M, Cc, _p(mean), _p(invstd), _p(coef), _p(draw), Cc,
+                                  _p(rg), rg.stride(2) if rg is not None else 0, racc, nul, nul, r6, st)
+            if bias is not None:
+                gbi, gbia = self.pgrads.sink(bias)
+                self.colsum(draw, M, Cc, Cc, gbi, gbia)
+            back(draw)
+        self.record(bwd)
+        return out
+
+    def dwconv_bn_act(self, x, conv, bn, relu=False):
+        """act(BN(depth-wise KxK conv(x))), K in (1, 3, 5), stride 1, pad K/2, bias-free (MSDC decoders.py:90-96, EUCB :172-174)."""
+        Cc, K = x.C, conv.kernel_size[0]
+        assert x.Cp == Cc and x.ld == Cc and conv.groups == Cc and conv.bias is None and conv.stride == (1, 1) and conv.padding == (K // 2, K // 2)
+        N, H, W = x.N, x.H, x.W
+        nblk = call.pn2_dwconv_blocks(self.dt, N * H * W, Cc)
+        w = conv.weight
+
+        def launch(raw, psum, psq):
+            call.pn2_dwconv(self.dt, x.ptr, _p(w), _p(raw), N, H, W, Cc, K, 0, 0, _p(psum), _p(psq), _stream())
+
+        def back(draw):
+            st = _stream()
+            part = self.fbuf(nblk, Cc * K * K)
+            call.pn2_dwconv_wgrad(self.dt, _p(draw), x.ptr, _p(part), N, H, W, Cc, K, st)
+            gw, gwa = self.pgrads.sink(w)
+            call.pn2_colsum_finalize(_p(part), nblk, Cc * K * K, Cc * K * K, _p(gw), gwa, st)
+            if x.requires_grad:
+                gx, acc = x.grad_sink()
+                assert gx.stride(2) == Cc
+                call.pn2_dwconv(self.dt, _p(draw), _p(w), _p(gx), N, H, W, Cc, K, 1, acc, C.c_void_p(0), C.c_void_p(0), st)
+        return self.bn_after(N, H, W, Cc, nblk, launch, back, bn, relu=relu)
+
+    def pairconv_bn(self, x, conv, bn, relu=False, residual=None):
+        """act(BN(grouped 3x3 conv with two input channels per group (+bias)) + residual)   (LGAG.W_g / W_x, decoders.py:193-200)."""
+        F_ = conv.out_channels
+        assert x.C == 2 * F_ and x.Cp == x.C and x.ld == x.C and conv.groups == F_ and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
+        N, H, W = x.N, x.H, x.W
+        nblk = call.pn2_pairconv_blocks(N * H * W, F_)
+        w = conv.weight
+
+        def launch(raw, psum, psq):
+            if psum is None:
+                psum, psq = self.fbuf(nblk, F_), self.fbuf(nblk, F_)
+            call.pn2_pairconv3x3_fwd(self.dt, x.ptr, _p(w), _p(raw), N, H, W, F_, _p(psum), _p(psq), _stream())
+
+        def back(draw):
+            st = _stream()
+            part = self.fbuf(nblk, F_ * 18)
+            call.pn2_pairconv3x3_wgrad(self.dt, _p(draw), x.ptr, _p(part), N, H, W, F_, st)
+            gw, gwa = self.pgrads.sink(w)
+            call.pn2_colsum_finalize(_p(part), nblk, F_ * 18, F_ * 18, _p(gw), gwa, st)
+            if x.requires_grad:
+                gx, acc = x.grad_sink()
+                assert gx.stride(2) == 2 * F_
+                call.pn2_pairconv3x3_dgrad(self.dt, _p(draw), _p(w), _p(gx), N, H, W, F_, acc, st)
+        return self.bn_after(N, H, W, F_, nblk, launch, back, bn, relu=relu, residual=residual, bias=conv.bias)
+
+    def upsample2x(self, x):
+        """nn.Upsample(scale_factor=2), nearest (EUCB decoders.py:171)."""
+        assert x.ld == x.Cp
+        y = Act(self, self.empty(x.N, 2 * x.H, 2 * x.W, x.Cp), x.C, x.gw, x.gwp, x.dt)
+        call.pn2_upsample_nearest2x(x.dt, x.ptr, y.ptr, x.N, x.H, x.W, x.Cp, _stream())
+
+        def bwd():
+            if x.requires_grad:
+                gy = y.grad_buf()
+                gx, acc = x.grad_sink()
+                assert gx.stride(2) == x.Cp
+                call.pn2_upsample_nearest2x_bwd(x.dt, _p(gy), _p(gx), x.N, x.H, x.W, x.Cp, acc, _stream())
+        self.record(bwd)
+        return y
+
+    def shuffled_sum(self, parts, groups):
+        """channel_shuffle(sum(parts), groups)  (MSCB.forward decoders.py:147-154, channel_shuffle :69-77) in one pass; the backward is one gather whose
+        result is the gradient of every part."""
+        a = parts[0]
+        Cc, M = a.C, a.M
+        assert all(p.C == Cc and p.Cp == Cc and p.ld == Cc for p in parts) and 1 <= len(parts) <= 3 and Cc % groups == 0
+        cpg = Cc // groups
+        key = ("perm", Cc, groups)
+        if key not in _PERMS:
+            fwd = torch.tensor([(j % groups) * cpg + j // groups for j in range(Cc)], dtype=torch.int32)
+            inv = torch.empty_like(fwd); inv[fwd.long()] = torch.arange(Cc, dtype=torch.int32)
+            _PERMS[key] = (fwd.to(self.dev), inv.to(self.dev))
+        fwd, inv = _PERMS[key]
+        y = Act(self, self.empty(a.N, a.H, a.W, Cc), Cc, Cc, Cc, self.dt)
+        ps = [p.ptr for p in parts] + [C.c_void_p(0)] * (3 - len(parts))
+        call.pn2_gather_sum(self.dt, ps[0], ps[1], ps[2], _p(fwd), y.ptr, M, Cc, _stream())
+
+        def bwd():
+            gy = y.grad_buf()
+            assert y.grad_written and gy.stride(2) == Cc
+            g = self.empty(a.N, a.H, a.W, Cc)
+            call.pn2_gather_sum(self.dt, _p(gy), C.c_void_p(0), C.c_void_p(0), _p(inv), _p(g), M, Cc, _stream())
+            for p in parts:         # single-consumer BN outputs: the shared tensor is only read
+                assert not p.grad_written
+                p.grad = g
+                p.grad_written = True
+        self.record(bwd)
+        return y
+
+    def sigmoid_gate(self, x, pre, mode):
+        """x * sigmoid(pre): mode 0 channel gate, pre = [N,1,1,C] (CAB decoders.py:241,442); mode 1 pixel gate, pre = [N,H,W,1] (SAB :258,443; LGAG :213-214)."""
+        N, HW, Cc = x.N, x.H * x.W, x.C
+        assert x.Cp == Cc and x.ld == Cc
+        n = N * Cc if mode == 0 else N * HW
+        usedC = Cc if mode == 0 else 1
+        assert pre.M * usedC == n and pre.C >= usedC
+        st = _stream()
+        g = self.fbuf(n)
+        call.pn2_sigmoid(pre.dt, pre.ptr, pre.ld, usedC, _p(g), n, st)
+        y = Act(self, self.empty(x.N, x.H, x.W, Cc), Cc, Cc, Cc, self.dt)
+        call.pn2_gate_mul(self.dt, x.ptr, _p(g), y.ptr, N, HW, Cc, mode, 0, st)
+
+        def bwd():
+            st = _stream()
+            gy = y.grad_buf()
+            assert y.grad_written and gy.stride(2) == Cc
+            dg = self.fbuf(n)
+            if mode == 1:
+                call.pn2_gate_bwd(self.dt, _p(gy), x.ptr, _p(dg), N, HW, Cc, 1, st)
+            else:
+                nb = call.pn2_gate_blocks(self.dt, HW, Cc)
+                part = self.fbuf(nb, N * Cc)
+                call.pn2_gate_bwd(self.dt, _p(gy), x.ptr, _p(part), N, HW, Cc, 0, st)
+                call.pn2_colsum_finalize(_p(part), nb, N * Cc, N * Cc, _p(dg), 0, st)
+            gp, pacc = pre.grad_sink()
+            call.pn2_sigmoid_bwd(pre.dt, _p(dg), _p(g), _p(gp), gp.stride(2), usedC, n, pacc, st)
+            if x.requires_grad:
+                gx, acc = x.grad_sink()
+                assert gx.stride(2) == Cc
+                call.pn2_gate_mul(self.dt, _p(gy), _p(g), _p(gx), N, HW, Cc, mode, acc, st)
+        self.record(bwd)
+        return y
+
+    def global_pool(self, x):
+        """(AdaptiveAvgPool2d(1)(x), AdaptiveMaxPool2d(1)(x)) as two [N,1,1,C] maps (CAB decoders.py:234-237)."""
+        N, HW, Cc = x.N, x.H * x.W, x.C
+        assert x.Cp == Cc and x.ld == Cc
+        avg = Act(self, self.empty(N, 1, 1, Cc), Cc, Cc, Cc, self.dt)
+        mx = Act(self, self.empty(N, 1, 1, Cc), Cc, Cc, Cc, self.dt)
+        arg = self.alloc((N, Cc), torch.int32)
+        call.pn2_global_pool(self.dt, x.ptr, avg.ptr, mx.ptr, _p(arg), N, HW, Cc, _stream())
+
+        def bwd():
+            if not x.requires_grad:
+                return
+            ga, gm = avg.grad_buf(), mx.grad_buf()
+            if not avg.grad_written:
+                ga.zero_()
+            if not mx.grad_written:
+                gm.zero_()
+            gx, acc = x.grad_sink()
+            assert gx.stride(2) == Cc
+            call.pn2_global_pool_bwd(self.dt, _p(ga), _p(gm), _p(arg), _p(gx), N, HW, Cc, acc, _stream())
+        self.record(bwd)
+        return avg, mx
+
+    def chan_stats(self, x):
+        """cat([mean over channels, max over channels]) as a 2-channel map (8 physical slots)   (SAB decoders.py:253-255)."""
+        Cc = x.C
+        assert x.Cp == Cc and x.ld == Cc
+        y = Act(self, self.empty(x.N, x.H, x.W, 8), 2, 2, 8, self.dt)
+        arg = self.alloc((x.M,), torch.int32)
+        call.pn2_chan_stats(self.dt, x.ptr, y.ptr, _p(arg), x.M, Cc, _stream())
+
+        def bwd():
+            if not x.requires_grad:
+                return
+            gy = y.grad_buf()
+            assert y.grad_written and gy.stride(2) == 8
+            gx, acc = x.grad_sink()
+            assert gx.stride(2) == Cc
+            call.pn2_chan_stats_bwd(self.dt, _p(gy), _p(arg), _p(gx), x.M, Cc, acc, _stream())
+        self.record(bwd)
+        return y
 
     # ------------------------------------------------------------------ pooling
     def maxpool3x3s2(self, x):

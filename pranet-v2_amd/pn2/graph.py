@@ -33,7 +33,9 @@ def _seed_grad(act, g):
         buf.zero_()
     elif act.Cp == C and act.t.dtype == torch.float32:
         gg = g.permute(0, 2, 3, 1)
-        act.grad = gg if gg.is_contiguous() else gg.contiguous()
+        # always a private copy: another consumer of this activation accumulates into the buffer in place, and autograd's
+        # incoming gradient tensors must not be modified
+        act.grad = gg.clone(memory_format=torch.contiguous_format)
     else:
         buf = act.grad_buf()
         buf.zero_()

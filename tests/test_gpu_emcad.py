@@ -1,0 +1,214 @@
+"""GPU parity tests of the EMCAD decoder path (BASELINE config 5): each decoder block through the C ABI against the oracle's restatement
+(float64 on the CPU), then the whole EMCADNet(dual, K=9) training forward/backward against the vectors of the imported reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("PN2_NO_PRETRAINED", "1")
+dev = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pn2
+    pn2.load_library()
+    yield
+    pn2.set_compute_dtype("bf16")
+
+
+def relmax(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def rell2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _randomize(mod, seed):
+    g = torch.Generator().manual_seed(seed)
+    for n, p in mod.named_parameters():
+        if p.dim() > 1:
+            fan = p[0].numel()
+            p.data = torch.randn(p.shape, generator=g) * (1.0 / fan) ** 0.5
+        elif n.endswith("weight"):
+            p.data = torch.rand(p.shape, generator=g) * 0.8 + 0.6
+        else:
+            p.data = torch.randn(p.shape, generator=g) * 0.1
+    return mod.to(dev).train()
+
+
+def _check(dtn, mod, build, ref, xs):
+    """build(eng, *acts) vs ref(P64, *x64) where P64 is the module's state_dict in float64 (oracle conventions)."""
+    from pn2 import F32, BF16
+    from pn2.engine import Engine
+    from pn2.graph import _seed_grad
+    dt = F32 if dtn == "fp32" else BF16
+    err, tol = (relmax, 1e-4) if dt == F32 else (rell2, 4e-2)
+    eng = Engine(dt, True, need_grad=True)
+    acts = [eng.from_nchw(x, requires_grad=True) for x in xs]
+    y = build(eng, *acts)
+    out = eng.to_nchw(y).clone()
+    torch.manual_seed(1234)
+    gy = torch.randn_like(out)
+    _seed_grad(y, gy)
+    eng.backward()
+    cast = (lambda t: t.bfloat16().float()) if dt == BF16 else (lambda t: t)
+    x64 = [cast(x).double().cpu().requires_grad_(True) for x in xs]
+    P = {k: (v.detach().double().cpu().clone() if v.dtype.is_floating_point else v.detach().cpu().clone()) for k, v in mod.state_dict().items()}
+    for k, v in P.items():
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    r = ref(P, *x64)
+    r.backward(gy.double().cpu())
+    assert err(out, r) < tol, "forward"
+    for a, x, xr in zip(acts, xs, x64):
+        assert err(a.grad[..., :x.shape[1]].float().permute(0, 3, 1, 2), xr.grad) < (tol if dt == F32 else 8e-2), "input gradient"
+    names = dict(mod.named_parameters())
+    for k, p in names.items():
+        g = eng.pgrads.get(p)
+        assert g is not None, k
+        scale = float(P[k].grad.abs().max())
+        if scale < 1e-6:          # biases in front of a train-mode BN: analytically zero
+            assert float(g.abs().max()) < (1e-4 if dt == F32 else 5e-2), k
+        else:
+            assert err(g, P[k].grad) < (tol if dt == F32 else 0.2), k      # bf16: ReLU / ReLU6 mask flips at 0 and 6 through three stacked BNs
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+def test_mscb_and_eucb(dtn):
+    from lib.decoders import MSCB, EUCB
+    from oracle import emcad_oracle as E
+    from oracle.pranet_oracle import Ctx
+    m = _randomize(MSCB(64, 64, 1, kernel_sizes=[1, 3, 5], expansion_factor=2, activation="relu6"), 1)
+    x = torch.randn(2, 64, 9, 7, device=dev) * 1.5
+    _check(dtn, m, lambda e, a: m._build(e, a), lambda P, t: E.mscb(P, "", t, Ctx(True)), [x])
+    u = _randomize(EUCB(64, 32), 2)
+    _check(dtn, u, lambda e, a: u._build(e, a), lambda P, t: E.eucb(P, "", t, Ctx(True)), [torch.randn(2, 64, 5, 6, device=dev)])
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+def test_gates_lgag_cab_sab(dtn):
+    from lib.decoders import LGAG, CAB, SAB
+    from oracle import emcad_oracle as E
+    from oracle.pranet_oracle import Ctx
+    l = _randomize(LGAG(64, 64, 32, kernel_size=3, groups=32), 3)
+    g, x = torch.randn(2, 64, 7, 6, device=dev), torch.randn(2, 64, 7, 6, device=dev)
+    _check(dtn, l, lambda e, a, b: l._build(e, a, b), lambda P, a, b: E.lgag(P, "", a, b, Ctx(True)), [g, x])
+    c = _randomize(CAB(128), 4)
+    xc = torch.randn(3, 128, 6, 5, device=dev)
+    _check(dtn, c, lambda e, a: c._build_gated(e, a), lambda P, t: E.cab(P, "", t) * t, [xc])
+    s = _randomize(SAB(), 5)
+    _check(dtn, s, lambda e, a: s._build_gated(e, a), lambda P, t: E.sab(P, "", t) * t, [torch.randn(2, 64, 9, 8, device=dev)])
+
+
+def test_emcad_dual_decoder_vs_oracle_fp32():
+    """The whole decoder (4 stages, LGAG/CAB/SAB gates, K=9 DSRA heads) on well-sized random encoder features: forward and all parameter gradients
+    against the oracle in float64.  (The 64x64 whole-model vectors below run its deepest stage on 2x2 maps, where train-mode BN is ill-conditioned.)"""
+    from pn2 import F32
+    from pn2.engine import Engine
+    from pn2.graph import _seed_grad
+    from lib.decoders import EMCAD_dual
+    from oracle import emcad_oracle as E
+    from oracle.pranet_oracle import Ctx
+    dec = _randomize(EMCAD_dual(channels=[512, 320, 128, 64], kernel_sizes=[1, 3, 5], expansion_factor=2, activation="relu6", num_class=9), 7)
+    torch.manual_seed(8)
+    feats = [torch.randn(3, c, s, s, device=dev) for c, s in ((512, 6), (320, 12), (128, 24), (64, 48))]
+    eng = Engine(F32, True, need_grad=True)
+    acts = [eng.from_nchw(f, requires_grad=True) for f in feats]
+    outs = dec._build(eng, acts[0], acts[1:])
+    o_t = [eng.to_nchw(o).clone() for o in outs]
+    torch.manual_seed(99)
+    gys = [torch.randn_like(o) for o in o_t]
+    for o, g in zip(outs, gys):
+        _seed_grad(o, g)
+    eng.backward()
+    def oracle(dtype):
+        P = {k: (v.detach().to(dtype).cpu().clone() if v.dtype.is_floating_point else v.detach().cpu().clone()) for k, v in dec.state_dict().items()}
+        for k, v in P.items():
+            if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        fx = [f.to(dtype).cpu().requires_grad_(True) for f in feats]
+        ref = E.emcad_dual(P, "", fx[0], fx[1:], Ctx(True))
+        sum((r * g.to(dtype).cpu()).sum() for r, g in zip(ref, gys)).backward()
+        return P, fx, ref
+    P, f64, ref = oracle(torch.float64)
+    P32, f32, _ = oracle(torch.float32)
+    # ReLU6 / max-pool / gate discontinuities after train-mode BN over ~100 samples make the deep-stage gradients ill-conditioned: the oracle's own
+    # fp32 run is up to ~1e-2 away from its float64 run here, so (as for the whole models) the bound is a multiple (8x: the
+    # error grows stage by stage, 2e-4 at the shallowest input to 8e-3 at the deepest) of that measured distance
+    for i, (o, r) in enumerate(zip(o_t, ref)):
+        assert relmax(o, r) < 2e-4, i
+    for a, f, fr, fr32 in zip(acts, feats, f64, f32):
+        assert rell2(a.grad[..., :f.shape[1]].permute(0, 3, 1, 2), fr.grad) < max(5e-3, 8 * rell2(fr32.grad, fr.grad))
+    for k, p in dec.named_parameters():
+        g = eng.pgrads.get(p)
+        scale = float(P[k].grad.abs().max())
+        if scale < 1e-6:          # conv biases in front of a train-mode BN: analytically zero, other gradients here are O(1e2)
+            assert float(g.abs().max()) < 2e-3, k
+        else:
+            assert rell2(g, P[k].grad) < max(5e-3, 8 * rell2(P32[k].grad, P[k].grad)), k        # floor: a single ReLU6 mask flip (|x - 6| ~ 1e-6) moves a bias gradient by ~1e-3
+
+
+def _model(fp32=True):
+    import pn2
+    from lib.networks import EMCADNet
+    from oracle import weights as W
+    pn2.set_compute_dtype("fp32" if fp32 else "bf16")
+    m = EMCADNet(num_classes=9, kernel_sizes=[1, 3, 5], expansion_factor=2, dw_parallel=True, add=True, lgag_ks=3, activation="relu6", encoder="pvt_v2_b2",
+                 pretrain=False, dual=True)
+    m.load_state_dict(W.make_state_dict(W.manifest_emcadnet(9), seed=5), strict=True)
+    m.backbone.reset_drop_path(0.0)
+    return m.to(dev).train()
+
+
+def test_emcad_state_dict_manifest():
+    import json
+    from lib.networks import EMCADNet
+    ref = json.load(open(os.path.join(G, "manifest_emcad.json")))["emcadnet_dual_k9"]
+    m = EMCADNet(num_classes=9, activation="relu6", pretrain=False, dual=True)
+    assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == list(ref.items())
+
+
+@pytest.mark.parametrize("fp32", [True, False])
+def test_emcadnet_forward_backward_vs_reference(fp32):
+    """EMCADNet.forward(dual) + the reference trainer's 15-subset CE + Dice + BCE loss (torch ops on the module outputs, as trainer.py does) + backward."""
+    from oracle import emcad_oracle as E
+    z = np.load(os.path.join(G, "emcad_64.npz"))
+    model = _model(fp32)
+    x = torch.from_numpy(z["x"]).to(dev); label = torch.from_numpy(z["label"]).to(dev); bg = torch.from_numpy(z["bg_mask"]).to(dev)
+    outs = model(x, mode="train")
+    loss = E.mutation_loss(outs, label, bg)          # plain torch ops on GPU tensors = what the reference's trainer.py:106-140 runs
+    loss.backward()
+    names = dict(model.named_parameters())
+    if fp32:
+        for i, o in enumerate(outs):
+            ref64 = torch.from_numpy(z[f"f64.out{i}"])
+            own = float((torch.from_numpy(z[f"out{i}"]).double() - ref64).abs().max())
+            assert float((o.detach().double().cpu() - ref64).abs().max()) <= max(1e-4, 3 * own), i
+        assert abs(float(loss) - float(z["f64.loss"])) < max(1e-4, 3 * abs(float(z["loss"]) - float(z["f64.loss"])))
+        for k in z.files:
+            if k.startswith("f64.grawnorm."):
+                name = k[len("f64.grawnorm."):]
+                g = names[name].grad
+                r64, r32 = float(z[k]), float(z["grawnorm." + name])
+                # 64x64 inputs put the deepest decoder stage on 2x2 maps (8 samples per BatchNorm channel) behind ReLU6 / max-pool / gate
+                # discontinuities: the reference's own fp32 gradients are 0.5-4 % away from its float64 run on these probes, so this is a
+                # sanity band; the tight bound is test_emcad_dual_decoder_vs_oracle_fp32 (8x the oracle's fp32 distance at healthy sizes)
+                assert abs(float(g.norm()) - r64) <= max(1e-2 * r64, 3 * abs(r32 - r64)) + 2e-6, name
+                h64 = torch.from_numpy(z["f64.graw." + name]).double(); h32 = torch.from_numpy(z["graw." + name]).double()
+                ours = g.detach().reshape(-1)[:h64.numel()].double().cpu()
+                assert float((ours - h64).norm()) <= max(6e-2 * float(h64.norm()), 3 * float((h32 - h64).norm())) + 2e-6, name
+    else:
+        for i, o in enumerate(outs):          # bf16 on 2x2 .. 16x16 train-mode-BN maps: sanity band only
+            assert rell2(o, torch.from_numpy(z[f"f64.out{i}"])) < 0.25, i
+        assert abs(float(loss) - float(z["loss"])) < 5e-2 * float(z["loss"])
