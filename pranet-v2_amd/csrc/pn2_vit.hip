@@ -6,6 +6,7 @@
 // Tokens [B, N, C] of the reference are NHWC pixels here (N = H*W), so no transposes are needed anywhere.
 // The Linear layers themselves run on the implicit-GEMM conv kernels (1x1) of pn2_conv.hip.
 // All kernels are deterministic (fixed-order reductions, no floating-point atomics).
+#include <cstdlib>
 #include "pn2_common.h"
 #include "../../include/pn2.h"
 
@@ -502,6 +503,221 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_reduce_k(const float* __restri
     TT<T>::st(dst + heads * 64 + h * 64 + d, sv);
 }
 
+// ------------------------------------------------------------------------------------------ bf16 MFMA attention
+// Same math as attn_fwd_k / attn_bwd_k on v_mfma_f32_16x16x32_bf16.  A block = 4 waves = 64 queries of one (b, head); every wave owns 16 queries.
+// Fragment layouts (lane l): A[l&15][(l>>4)*8 + j], B[(l>>4)*8 + j][l&15], C: column l&15, rows (l>>4)*4 + r.
+// LDS tiles keep 16-byte fragment rows with an 8-element pad so the 16 lanes of a quarter-wave hit distinct banks.
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+__device__ __forceinline__ f32x4v mfma16(const uint4& a, const uint4& b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+template <int NK>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_k(const bf16_t* __restrict__ q, int ld_q, const bf16_t* __restrict__ kv, int ld_kv, bf16_t* __restrict__ out, int ld_o,
+                                                       float* __restrict__ lse, int Nq, int Nkv, int heads, float scale) {
+    constexpr int NP = NK * 64, NT = NP / 16, KR = 72, VR = NP + 8;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    bf16_t* Ks = smem;                    // [NP][KR]   key rows (d contiguous)            -> B operand of S = Q K^T
+    bf16_t* Vt = Ks + NP * KR;            // [64][VR]   V transposed (keys contiguous)     -> B operand of O = P V
+    bf16_t* Ps = Vt + 64 * VR;            // [4 waves][16][VR] probabilities               -> A operand of O = P V
+    const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const bf16_t* kvb = kv + (size_t)b * Nkv * ld_kv;
+    for (int i = threadIdx.x; i < NP * 8; i += 256) {                 // K rows: 8 x 16-byte chunks per key
+        const int key = i >> 3, ch = i & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < Nkv) v = *reinterpret_cast<const uint4*>(kvb + (size_t)key * ld_kv + h * 64 + ch * 8);
+        *reinterpret_cast<uint4*>(Ks + key * KR + ch * 8) = v;
+    }
+    for (int i = threadIdx.x; i < NP * 64; i += 256) {                // V transposed
+        const int key = i >> 6, d = i & 63;
+        Vt[d * VR + key] = key < Nkv ? kvb[(size_t)key * ld_kv + heads * 64 + h * 64 + d] : (bf16_t)0;
+    }
+    __syncthreads();
+    const int q0 = blockIdx.x * 64 + wid * 16;
+    const int qa = min(q0 + l15, Nq - 1);                             // A-operand row of this lane
+    const bf16_t* qp = q + ((size_t)b * Nq + qa) * ld_q + h * 64 + g * 8;
+    const uint4 aq0 = *reinterpret_cast<const uint4*>(qp), aq1 = *reinterpret_cast<const uint4*>(qp + 32);
+    f32x4v s[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const bf16_t* kp = Ks + (nt * 16 + l15) * KR + g * 8;
+        f32x4v c = {0.f, 0.f, 0.f, 0.f};
+        c = mfma16(aq0, *reinterpret_cast<const uint4*>(kp), c);
+        c = mfma16(aq1, *reinterpret_cast<const uint4*>(kp + 32), c);
+        s[nt] = c;
+    }
+    float mx[4], sum[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { const float v = (nt * 16 + l15 < Nkv) ? s[nt][r] * scale : -INFINITY; s[nt][r] = v; m = fmaxf(m, v); }
+        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
+        float t = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { const float p = __expf(s[nt][r] - m); s[nt][r] = p; t += p; }
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        mx[r] = m; sum[r] = t;
+    }
+    bf16_t* pw = Ps + wid * 16 * VR;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[(g * 4 + r) * VR + nt * 16 + l15] = f2bf(s[nt][r]);
+    __syncthreads();
+    f32x4v o[4];
+#pragma unroll
+    for (int nd = 0; nd < 4; ++nd) o[nd] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NP / 32; ++ks) {
+        const uint4 ap = *reinterpret_cast<const uint4*>(pw + l15 * VR + ks * 32 + g * 8);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) o[nd] = mfma16(ap, *reinterpret_cast<const uint4*>(Vt + (nd * 16 + l15) * VR + ks * 32 + g * 8), o[nd]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + g * 4 + r;
+        if (qi < Nq) {
+            const float inv = 1.f / sum[r];
+            bf16_t* op = out + ((size_t)b * Nq + qi) * ld_o + h * 64 + l15;
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) op[nd * 16] = f2bf(o[nd][r] * inv);
+            if (l15 == 0) lse[((size_t)b * heads + h) * Nq + qi] = mx[r] + __logf(sum[r]);
+        }
+    }
+}
+
+// delta[b][h][q] = sum_d dO[q][h*64 + d] * O[q][h*64 + d]   (= sum_keys P dP: lets the backward treat key ranges independently)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_k(const T* __restrict__ dout, int ld_do, const T* __restrict__ o, int ld_o, float* __restrict__ delta, int B, int Nq, int heads) {
+    const int lane = threadIdx.x & 63;
+    const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), total = (size_t)B * Nq * heads;
+    if (item >= total) return;
+    const int h = (int)(item % heads); const size_t bq = item / heads;          // bq = b * Nq + q
+    float v = TT<T>::ld(dout + bq * ld_do + h * 64 + lane) * TT<T>::ld(o + bq * ld_o + h * 64 + lane);
+    v = wave_sum(v);
+    if (lane == 0) { const size_t b = bq / Nq, qi = bq % Nq; delta[(b * heads + h) * Nq + qi] = v; }
+}
+
+// backward for the keys [key0, key0 + NKB*64) of one (b, head) and one 64-query tile:
+//   S = Q K^T, dP = dO V^T (MFMA) -> P = exp(S scale - lse), dS = P (dP - delta) scale
+//   dQ (+)= dS K ; partial dK = dS^T Q, dV = P^T dO  (fp32 [2][NPT][64] per query tile, summed by attn_bwd_kv_reduce_k)
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_k(const bf16_t* __restrict__ q, int ld_q, const bf16_t* __restrict__ kv, int ld_kv, const bf16_t* __restrict__ dout, int ld_do,
+                                                       const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dq, int ld_dq, float* __restrict__ part,
+                                                       int Nq, int Nkv, int heads, float scale, int key0, int NPT, int dq_acc) {
+    constexpr int NP = NKB * 64, NT = NP / 16, KR = 72, TR = NP + 8;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    bf16_t* Ks = smem;                    // [NP][KR]  K rows
+    bf16_t* Vs = Ks + NP * KR;            // [NP][KR]  V rows
+    bf16_t* Kt = Vs + NP * KR;            // [64][TR]  K transposed
+    bf16_t* Qt = Kt + 64 * TR;            // [64][KR]  Q tile transposed  [d][q]
+    bf16_t* Gt = Qt + 64 * KR;            // [64][KR]  dO tile transposed [d][q]
+    bf16_t* Sa = Gt + 64 * KR;            // [4][16][TR] dS, A layout per wave
+    bf16_t* St = Sa + 64 * TR;            // [NP][KR]  dS transposed [key][q]
+    bf16_t* Pt = St + NP * KR;            // [NP][KR]  P transposed  [key][q]
+    const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const bf16_t* kvb = kv + (size_t)b * Nkv * ld_kv;
+    const int qt0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < NP * 8; i += 256) {
+        const int kl = i >> 3, ch = i & 7, key = key0 + kl;
+        uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
+        if (key < Nkv) { kk = *reinterpret_cast<const uint4*>(kvb + (size_t)key * ld_kv + h * 64 + ch * 8);
+                         vv = *reinterpret_cast<const uint4*>(kvb + (size_t)key * ld_kv + heads * 64 + h * 64 + ch * 8); }
+        *reinterpret_cast<uint4*>(Ks + kl * KR + ch * 8) = kk;
+        *reinterpret_cast<uint4*>(Vs + kl * KR + ch * 8) = vv;
+    }
+    for (int i = threadIdx.x; i < NP * 64; i += 256) {
+        const int kl = i >> 6, d = i & 63, key = key0 + kl;
+        Kt[d * TR + kl] = key < Nkv ? kvb[(size_t)key * ld_kv + h * 64 + d] : (bf16_t)0;
+    }
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int ql = i >> 6, d = i & 63, qi = qt0 + ql;
+        const bool ok = qi < Nq;
+        const size_t ro = (size_t)b * Nq + (ok ? qi : Nq - 1);
+        Qt[d * KR + ql] = ok ? q[ro * ld_q + h * 64 + d] : (bf16_t)0;
+        Gt[d * KR + ql] = ok ? dout[ro * ld_do + h * 64 + d] : (bf16_t)0;
+    }
+    __syncthreads();
+    const int q0 = qt0 + wid * 16;
+    const size_t ra = (size_t)b * Nq + min(q0 + l15, Nq - 1);
+    const bf16_t* qp = q + ra * ld_q + h * 64 + g * 8; const bf16_t* gp = dout + ra * ld_do + h * 64 + g * 8;
+    const uint4 aq0 = *reinterpret_cast<const uint4*>(qp), aq1 = *reinterpret_cast<const uint4*>(qp + 32);
+    const uint4 ag0 = *reinterpret_cast<const uint4*>(gp), ag1 = *reinterpret_cast<const uint4*>(gp + 32);
+    float L[4], D[4]; bool rok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + g * 4 + r;
+        rok[r] = qi < Nq;
+        const size_t li = ((size_t)b * heads + h) * Nq + (rok[r] ? qi : Nq - 1);
+        L[r] = lse[li]; D[r] = delta[li];
+    }
+    bf16_t* sa = Sa + wid * 16 * TR;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const bf16_t* kp = Ks + (nt * 16 + l15) * KR + g * 8; const bf16_t* vp = Vs + (nt * 16 + l15) * KR + g * 8;
+        f32x4v s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = mfma16(aq0, *reinterpret_cast<const uint4*>(kp), s); s = mfma16(aq1, *reinterpret_cast<const uint4*>(kp + 32), s);
+        dp = mfma16(ag0, *reinterpret_cast<const uint4*>(vp), dp); dp = mfma16(ag1, *reinterpret_cast<const uint4*>(vp + 32), dp);
+        const bool kok = key0 + nt * 16 + l15 < Nkv;
+        bf16_t pb[4], sb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = (kok && rok[r]) ? __expf(s[r] * scale - L[r]) : 0.f;
+            const float ds = p * (dp[r] - D[r]) * scale;
+            pb[r] = f2bf(p); sb[r] = f2bf(ds);
+            sa[(g * 4 + r) * TR + nt * 16 + l15] = sb[r];
+        }
+        // transposed tiles [key][query]: 4 consecutive queries of this lane -> one 8-byte store each
+        const int key = nt * 16 + l15, qc = wid * 16 + g * 4;
+        *reinterpret_cast<uint2*>(St + key * KR + qc) = make_uint2((unsigned)sb[0] | ((unsigned)sb[1] << 16), (unsigned)sb[2] | ((unsigned)sb[3] << 16));
+        *reinterpret_cast<uint2*>(Pt + key * KR + qc) = make_uint2((unsigned)pb[0] | ((unsigned)pb[1] << 16), (unsigned)pb[2] | ((unsigned)pb[3] << 16));
+    }
+    __syncthreads();
+    // dQ = dS K  (this wave's 16 queries x 64 dims)
+    f32x4v dqa[4];
+#pragma unroll
+    for (int nd = 0; nd < 4; ++nd) dqa[nd] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NP / 32; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4*>(sa + l15 * TR + ks * 32 + g * 8);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) dqa[nd] = mfma16(a, *reinterpret_cast<const uint4*>(Kt + (nd * 16 + l15) * TR + ks * 32 + g * 8), dqa[nd]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (rok[r]) {
+            bf16_t* dp_ = dq + ((size_t)b * Nq + q0 + g * 4 + r) * ld_dq + h * 64 + l15;
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) dp_[nd * 16] = f2bf(dq_acc ? bf2f(dp_[nd * 16]) + dqa[nd][r] : dqa[nd][r]);
+        }
+    }
+    // dK = dS^T Q, dV = P^T dO : this wave's key tiles (kt = wid, wid + 4, ...), contraction over the 64 queries
+    float* dst = part + ((((size_t)b * heads + h) * gridDim.x + blockIdx.x) * 2) * (size_t)NPT * 64;
+#pragma unroll
+    for (int kt = wid; kt < NT; kt += 4) {
+        f32x4v ak[4], av[4];
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) { ak[nd] = f32x4v{0.f, 0.f, 0.f, 0.f}; av[nd] = ak[nd]; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 as = *reinterpret_cast<const uint4*>(St + (kt * 16 + l15) * KR + ks * 32 + g * 8);
+            const uint4 ap = *reinterpret_cast<const uint4*>(Pt + (kt * 16 + l15) * KR + ks * 32 + g * 8);
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) {
+                ak[nd] = mfma16(as, *reinterpret_cast<const uint4*>(Qt + (nd * 16 + l15) * KR + ks * 32 + g * 8), ak[nd]);
+                av[nd] = mfma16(ap, *reinterpret_cast<const uint4*>(Gt + (nd * 16 + l15) * KR + ks * 32 + g * 8), av[nd]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t row = (size_t)(key0 + kt * 16 + g * 4 + r) * 64 + l15;
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) { dst[row + nd * 16] = ak[nd][r]; dst[(size_t)NPT * 64 + row + nd * 16] = av[nd][r]; }
+        }
+    }
+}
+
 // y[n][r][c] = x[n][r][c] * s[n]   (DropPath: per-sample keep mask / keep_prob, timm.models.layers.DropPath used at pvtv2.py:125,148-149)
 template <typename T>
 __global__ __launch_bounds__(256) void scale_samples_k(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ s, size_t vec_per_sample, size_t nvec) {
@@ -644,23 +860,65 @@ int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, voi
 #define PN2_ATTN_FWD(NKV) { if (lds > 64 * 1024) { static bool done = false; if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_k<T, NKV>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; } } \
         hipLaunchKernelGGL((attn_fwd_k<T, NKV>), grid, dim3(256), lds, st, (const T*)q, ld_q, (const T*)kv, ld_kv, (T*)out, ld_o, lse, Nq, Nkv, heads, scale, qpb); }
+    static const bool use_mfma = [] { const char* e = getenv("PN2_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    if (dt == PN2_BF16 && use_mfma && (ld_q % 8) == 0 && (ld_kv % 8) == 0 && (ld_o % 8) == 0) {
+        const size_t lm = ((size_t)NP * 72 + 64 * (NP + 8) + 4 * 16 * (NP + 8)) * 2;
+        const dim3 gm((Nq + 63) / 64, heads, B);
+#define PN2_ATTN_FWD_M(NKV) { if (lm > 64 * 1024) { static bool done = false; if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_k<NKV>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); done = true; } } \
+        hipLaunchKernelGGL((attn_fwd_mfma_k<NKV>), gm, dim3(256), lm, st, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, (bf16_t*)out, ld_o, lse, Nq, Nkv, heads, scale); }
+        if (NK == 1) PN2_ATTN_FWD_M(1) else if (NK == 2) PN2_ATTN_FWD_M(2) else if (NK == 3) PN2_ATTN_FWD_M(3) else PN2_ATTN_FWD_M(4)
+#undef PN2_ATTN_FWD_M
+        PN2_CHECK_LAUNCH();
+        return 0;
+    }
     VIT_DISPATCH(dt, { if (NK == 1) PN2_ATTN_FWD(1) else if (NK == 2) PN2_ATTN_FWD(2) else if (NK == 3) PN2_ATTN_FWD(3) else PN2_ATTN_FWD(4) })
 #undef PN2_ATTN_FWD
     PN2_CHECK_LAUNCH();
     return 0;
 }
 
-int pn2_attn_bwd_blocks(int Nq) { return Nq < 1 ? -1 : (Nq + AT_QCHUNK - 1) / AT_QCHUNK; }
+static bool attn_use_mfma(int dt, int ld_a, int ld_b) {
+    static const bool on = [] { const char* e = getenv("PN2_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    return on && dt == PN2_BF16 && (ld_a % 8) == 0 && (ld_b % 8) == 0;
+}
 
-int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, const void* dout, int ld_do, const float* lse, void* dq, int ld_dq, void* dkv, int ld_dkv,
-                 float* partial, int B, int Nq, int Nkv, int heads, int head_dim, float scale, void* stream) {
-    if (!q || !kv || !dout || !lse || !dq || !dkv || !partial) return -1;
+int pn2_attn_bwd_blocks(int dt, int Nq) { return Nq < 1 ? -1 : (dt == PN2_BF16 ? (Nq + 63) / 64 : (Nq + AT_QCHUNK - 1) / AT_QCHUNK); }
+
+int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, const void* out, int ld_o, const void* dout, int ld_do, const float* lse, void* dq, int ld_dq,
+                 void* dkv, int ld_dkv, float* partial, float* delta, int B, int Nq, int Nkv, int heads, int head_dim, float scale, void* stream) {
+    if (!q || !kv || !out || !dout || !lse || !dq || !dkv || !partial || !delta) return -1;
     if (int rc = attn_geom(Nkv, heads, head_dim)) return rc;
-    const int NK = (Nkv + 63) / 64, NP = NK * 64, nqb = pn2_attn_bwd_blocks(Nq);
+    const int NK = (Nkv + 63) / 64, NP = NK * 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (attn_use_mfma(dt, ld_q, ld_kv) && (ld_do % 8) == 0 && (ld_dq % 8) == 0) {
+        const int nqt = (Nq + 63) / 64;
+        hipLaunchKernelGGL(attn_delta_k<bf16_t>, dim3((unsigned)(((size_t)B * Nq * heads + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dout, ld_do, (const bf16_t*)out, ld_o, delta, B, Nq, heads);
+        const dim3 grid(nqt, heads, B);
+        for (int key0 = 0; key0 < NP; key0 += 128) {
+            const int nkb = NP - key0 >= 128 ? 2 : 1;
+            const int np = nkb * 64;
+            const size_t lm = ((size_t)3 * np * 72 + 64 * (np + 8) + 2 * 64 * 72 + 64 * (np + 8) + np * 72) * 2;
+            if (nkb == 2) {
+                static bool done = false;
+                if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); done = true; }
+                hipLaunchKernelGGL(attn_bwd_mfma_k<2>, grid, dim3(256), lm, st, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, (const bf16_t*)dout, ld_do, lse, delta, (bf16_t*)dq, ld_dq,
+                                   partial, Nq, Nkv, heads, scale, key0, NP, key0 > 0 ? 1 : 0);
+            } else {
+                static bool done1 = false;
+                if (!done1) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); done1 = true; }
+                hipLaunchKernelGGL(attn_bwd_mfma_k<1>, grid, dim3(256), lm, st, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, (const bf16_t*)dout, ld_do, lse, delta, (bf16_t*)dq, ld_dq,
+                                   partial, Nq, Nkv, heads, scale, key0, NP, key0 > 0 ? 1 : 0);
+            }
+        }
+        hipLaunchKernelGGL(attn_bwd_kv_reduce_k<bf16_t>, dim3(Nkv, heads, B), dim3(64), 0, st, partial, (bf16_t*)dkv, ld_dkv, Nkv, NP, heads, nqt);
+        PN2_CHECK_LAUNCH();
+        return 0;
+    }
+    const int nqb = (Nq + AT_QCHUNK - 1) / AT_QCHUNK;
     const int QB = NK == 4 ? 2 : AT_QB;                 // 256 keys: smaller query groups so that K, V and the tiles fit the 160 KiB of LDS
     const size_t lds = ((size_t)2 * 64 * (NP + 1) + 2 * 4 * QB * NP + 2 * 4 * QB * 64) * 4;
     const dim3 grid(nqb, heads, B);
-    hipStream_t st = (hipStream_t)stream;
 #define PN2_ATTN_BWD(NKV, QBV) { if (lds > 64 * 1024) { static bool done = false; if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_k<T, NKV, QBV>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; } } \
         hipLaunchKernelGGL((attn_bwd_k<T, NKV, QBV>), grid, dim3(256), lds, st, (const T*)q, ld_q, (const T*)kv, ld_kv, (const T*)dout, ld_do, lse, (T*)dq, ld_dq, \

@@ -1014,10 +1014,12 @@ class Engine:
             st = _stream()
             do = o.grad_buf()
             assert o.grad_written and do.stride(2) == Cc and not q.grad_written and not kv.grad_written
-            part = self.fbuf(B, heads, call.pn2_attn_bwd_blocks(Nq), 2, rup(Nkv, 64), 64)
+            part = self.fbuf(B, heads, call.pn2_attn_bwd_blocks(self.dt, Nq), 2, rup(Nkv, 64), 64)
+            delta = self.fbuf(B, heads, Nq)
             gq, _ = q.grad_sink()
             gkv, _ = kv.grad_sink()
-            call.pn2_attn_bwd(self.dt, q.ptr, Cc, kv.ptr, 2 * Cc, _p(do), Cc, _p(lse), _p(gq), Cc, _p(gkv), 2 * Cc, _p(part), B, Nq, Nkv, heads, hd, scale, st)
+            call.pn2_attn_bwd(self.dt, q.ptr, Cc, kv.ptr, 2 * Cc, o.ptr, Cc, _p(do), Cc, _p(lse), _p(gq), Cc, _p(gkv), 2 * Cc, _p(part), _p(delta),
+                              B, Nq, Nkv, heads, hd, scale, st)
         self.record(bwd)
         return o
 
