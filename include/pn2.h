@@ -257,6 +257,18 @@ int pn2_gather_sum(int dt, const void* a, const void* b, const void* c, const in
 int pn2_sigmoid(int dt_in, const void* x, int ld, int C, float* y, long long n, void* stream);
 int pn2_sigmoid_bwd(int dt_out, const float* dy, const float* y, void* dx, int ld, int C, long long n, int accumulate, void* stream);
 
+/* EMCAD/trainer.py:106-140 ("mutation" supervision, dual): sum over the 15 non-empty subsets s of the 4 scales of
+ *   lc1 * CrossEntropy(sum_{i in s} fg_i, label) + lc2 * DiceLoss(softmax(sum fg_i), label) (utils/utils.py:102-138) + lc3 * BCEWithLogits(sum_{i in s} bg_i, bg_mask)
+ * in ONE pass over the 8 maps.  fg[4] / bg[4] (host arrays of device pointers): [N][H][W][K] fp32, K = 9; label [N][H][W] int64; bg_mask [N][K][H][W] fp32.
+ * partial [pn2_mutation_loss_blocks(N*HW)][pn2_mutation_loss_width(K)] scratch; sums [width] kept for the backward; loss[1].
+ * Backward: dfg[i] / dbg[i] = gscale * d loss / d map, same layout (written, not accumulated). */
+int pn2_mutation_loss_blocks(long long npix);
+int pn2_mutation_loss_width(int K);
+int pn2_mutation_loss_fwd(const float* const* fg, const float* const* bg, const long long* label, const float* bg_mask, int N, long long HW, int K,
+                          float lc1, float lc2, float lc3, float* partial, float* sums, float* loss, void* stream);
+int pn2_mutation_loss_bwd(const float* const* fg, const float* const* bg, float* const* dfg, float* const* dbg, const long long* label, const float* bg_mask,
+                          int N, long long HW, int K, float lc1, float lc2, float lc3, const float* sums, float gscale, void* stream);
+
 /* ---------------------------------------------------------------------------------------------- element-wise / layout */
 int pn2_binary(int dt, int op /*0 add,1 mul*/, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream);
 int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld_d, int M, int C, int accumulate, void* stream);

@@ -494,6 +494,159 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_k(const float* __restrict__ d
     }
 }
 
+// ------------------------------------------------------------------------------------------ multi-class "mutation" loss (config 5)
+// EMCAD/trainer.py:106-140 (dual, supervision='mutation') with utils/utils.py:102-138 (DiceLoss, softmax=True):
+//   loss = sum over the 15 non-empty subsets s of the 4 scales of
+//          lc1 * CE(sum_{i in s} fg_i, label) + lc2 * Dice(softmax(sum fg_i), onehot(label)) + lc3 * BCEWithLogits(sum_{i in s} bg_i, bg_mask)
+// One pass over the 8 K-channel maps (NHWC fp32): a thread keeps its pixel's 8*K logits in registers and walks the 15 subsets; the per-subset
+// sums (CE, BCE, per-class intersect and sum p^2) are reduced per wave and written as partial rows.  The backward recomputes the softmaxes.
+constexpr int ML_NS = 15;
+template <int K> struct MLW { static constexpr int W = 2 + 2 * K; };      // values per subset: CE, BCE, I[K], Z[K]
+
+struct ml_maps { const float* fg[4]; const float* bg[4]; float* dfg[4]; float* dbg[4]; };
+
+template <int K>
+__global__ __launch_bounds__(256) void mloss_fwd_k(ml_maps m, const long long* __restrict__ label, const float* __restrict__ bgm, size_t NP, size_t HW,
+                                                   float* __restrict__ partial) {
+    constexpr int W = MLW<K>::W;
+    __shared__ float red[4][ML_NS * W + K];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = p < NP;
+    float f[4][K], b[4][K], mk[K];
+    int lab = -1;
+    if (ok) {
+        lab = (int)label[p];
+        const size_t n = p / HW, hw = p % HW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < K; ++k) { f[i][k] = m.fg[i][p * K + k]; b[i][k] = m.bg[i][p * K + k]; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) mk[k] = bgm[(n * K + k) * HW + hw];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {          // label histogram (sum of target^2 per class), once
+        float t = (ok && lab == k) ? 1.f : 0.f;
+        t = wave_sum(t);
+        if (lane == 0) red[wid][ML_NS * W + k] = t;
+    }
+#pragma unroll
+    for (int s = 1; s <= ML_NS; ++s) {
+        float z[K], zb[K], v[W];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            z[k] = 0.f; zb[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (s >> i & 1) { z[k] += f[i][k]; zb[k] += b[i][k]; }
+        }
+        float mx = z[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+        float se = 0.f, e[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
+        const float inv = 1.f / se, lse = mx + logf(se);
+        float ce = 0.f, bce = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float pk = e[k] * inv;
+            if (lab == k) ce = lse - z[k];
+            v[2 + k] = (lab == k) ? pk : 0.f;
+            v[2 + K + k] = pk * pk;
+            bce += fmaxf(zb[k], 0.f) - zb[k] * mk[k] + log1pf(expf(-fabsf(zb[k])));
+        }
+        v[0] = ce; v[1] = bce;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            float t = ok ? v[j] : 0.f;
+            t = wave_sum(t);
+            if (lane == 0) red[wid][(s - 1) * W + j] = t;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < ML_NS * W + K; j += 256)
+        partial[(size_t)blockIdx.x * (ML_NS * W + K) + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+}
+
+// sums[ML_NS*W + K] (double-accumulated over the partial rows) and the scalar loss
+template <int K>
+__global__ void mloss_finalize_k(const float* __restrict__ partial, int nblk, float* __restrict__ sums, float* __restrict__ loss, double npix, float lc1, float lc2, float lc3) {
+    constexpr int W = MLW<K>::W, NV = ML_NS * W + K;
+    __shared__ double sh[NV];
+    for (int j = threadIdx.x; j < NV; j += blockDim.x) {
+        double a = 0.0;
+        for (int r = 0; r < nblk; ++r) a += (double)partial[(size_t)r * NV + j];
+        sh[j] = a; sums[j] = (float)a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int s = 0; s < ML_NS; ++s) {
+            const double ce = sh[s * W] / npix, bce = sh[s * W + 1] / (npix * K);
+            double dice = 0.0;
+            for (int k = 0; k < K; ++k) dice += 1.0 - (2.0 * sh[s * W + 2 + k] + 1e-5) / (sh[s * W + 2 + K + k] + sh[ML_NS * W + k] + 1e-5);
+            tot += lc1 * ce + lc2 * dice / K + lc3 * bce;
+        }
+        loss[0] = (float)tot;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void mloss_bwd_k(ml_maps m, const long long* __restrict__ label, const float* __restrict__ bgm, size_t NP, size_t HW,
+                                                   const float* __restrict__ sums, float gscale, float lc1, float lc2, float lc3) {
+    constexpr int W = MLW<K>::W;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    const int lab = (int)label[p];
+    const size_t n = p / HW, hw = p % HW;
+    float f[4][K], b[4][K], mk[K], gf[4][K], gb[4][K];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < K; ++k) { f[i][k] = m.fg[i][p * K + k]; b[i][k] = m.bg[i][p * K + k]; gf[i][k] = 0.f; gb[i][k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < K; ++k) mk[k] = bgm[(n * K + k) * HW + hw];
+    const float wce = gscale * lc1 / (float)NP, wbce = gscale * lc3 / ((float)NP * K), wdice = gscale * lc2 / K;
+#pragma unroll
+    for (int s = 1; s <= ML_NS; ++s) {
+        float z[K], zb[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            z[k] = 0.f; zb[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (s >> i & 1) { z[k] += f[i][k]; zb[k] += b[i][k]; }
+        }
+        float mx = z[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+        float se = 0.f, pr[K], g[K], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { pr[k] = expf(z[k] - mx); se += pr[k]; }
+        const float inv = 1.f / se;
+        const float* S = sums + (s - 1) * W;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            pr[k] *= inv;
+            // d dice_k / d p_k = -(2 t / D - (2 I + eps) 2 p / D^2),  D = Z + T + eps
+            const float D = S[2 + K + k] + sums[ML_NS * W + k] + 1e-5f, t = lab == k ? 1.f : 0.f;
+            g[k] = -wdice * (2.f * t / D - (2.f * S[2 + k] + 1e-5f) * 2.f * pr[k] / (D * D));
+            dot += g[k] * pr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float dz = wce * (pr[k] - (lab == k ? 1.f : 0.f)) + pr[k] * (g[k] - dot);
+            const float sg = 1.f / (1.f + expf(-zb[k])), dzb = wbce * (sg - mk[k]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (s >> i & 1) { gf[i][k] += dz; gb[i][k] += dzb; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < K; ++k) { m.dfg[i][p * K + k] = gf[i][k]; m.dbg[i][p * K + k] = gb[i][k]; }
+}
+
 }  // namespace
 
 #define EM_DISPATCH(dt, BODY) \
@@ -677,6 +830,39 @@ int pn2_sigmoid(int dt_in, const void* x, int ld, int C, float* y, long long n, 
 int pn2_sigmoid_bwd(int dt_out, const float* dy, const float* y, void* dx, int ld, int C, long long n, int accumulate, void* stream) {
     if (!dy || !y || !dx || n < 1) return -1;
     EM_DISPATCH(dt_out, { hipLaunchKernelGGL(sigmoid_bwd_k<T>, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, dy, y, (T*)dx, (size_t)n, ld, C, accumulate); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_mutation_loss_blocks(long long npix) { return npix < 1 ? -1 : (int)((npix + 255) / 256); }
+int pn2_mutation_loss_width(int K) { return K == 9 ? ML_NS * MLW<9>::W + 9 : -1; }
+
+/* EMCAD/trainer.py:106-140: sum over the 15 non-empty subsets of the 4 scales of lc1*CE + lc2*Dice(softmax) + lc3*BCEWithLogits on the summed maps.
+ * fg[4], bg[4]: [N][H][W][K] fp32 maps (K = 9); label [N][H][W] int64; bg_mask [N][K][H][W] fp32.  partial: [pn2_mutation_loss_blocks][pn2_mutation_loss_width]
+ * scratch; sums [pn2_mutation_loss_width] is kept for the backward; loss[1]. */
+int pn2_mutation_loss_fwd(const float* const* fg, const float* const* bg, const long long* label, const float* bg_mask, int N, long long HW, int K,
+                          float lc1, float lc2, float lc3, float* partial, float* sums, float* loss, void* stream) {
+    if (!fg || !bg || !label || !bg_mask || !partial || !sums || !loss) return -1;
+    if (K != 9) return -2;
+    ml_maps m;
+    for (int i = 0; i < 4; ++i) { m.fg[i] = fg[i]; m.bg[i] = bg[i]; m.dfg[i] = nullptr; m.dbg[i] = nullptr; if (!fg[i] || !bg[i]) return -1; }
+    const size_t NP = (size_t)N * HW;
+    const int nblk = pn2_mutation_loss_blocks((long long)NP);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mloss_fwd_k<9>, dim3(nblk), dim3(256), 0, st, m, label, bg_mask, NP, (size_t)HW, partial);
+    hipLaunchKernelGGL(mloss_finalize_k<9>, dim3(1), dim3(256), 0, st, partial, nblk, sums, loss, (double)NP, lc1, lc2, lc3);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_mutation_loss_bwd(const float* const* fg, const float* const* bg, float* const* dfg, float* const* dbg, const long long* label, const float* bg_mask,
+                          int N, long long HW, int K, float lc1, float lc2, float lc3, const float* sums, float gscale, void* stream) {
+    if (!fg || !bg || !dfg || !dbg || !label || !bg_mask || !sums) return -1;
+    if (K != 9) return -2;
+    ml_maps m;
+    for (int i = 0; i < 4; ++i) { m.fg[i] = fg[i]; m.bg[i] = bg[i]; m.dfg[i] = dfg[i]; m.dbg[i] = dbg[i]; if (!fg[i] || !bg[i] || !dfg[i] || !dbg[i]) return -1; }
+    const size_t NP = (size_t)N * HW;
+    hipLaunchKernelGGL(mloss_bwd_k<9>, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, (hipStream_t)stream, m, label, bg_mask, NP, (size_t)HW, sums, gscale, lc1, lc2, lc3);
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -132,6 +132,10 @@ SIGNATURES = {
     "pn2_gather_sum": [I, P, P, P, P, P, LL, I, P],
     "pn2_sigmoid": [I, P, I, I, P, LL, P],
     "pn2_sigmoid_bwd": [I, P, P, P, I, I, LL, I, P],
+    "pn2_mutation_loss_blocks": [LL],
+    "pn2_mutation_loss_width": [I],
+    "pn2_mutation_loss_fwd": [P, P, P, P, I, LL, I, FL, FL, FL, P, P, P, P],
+    "pn2_mutation_loss_bwd": [P, P, P, P, P, P, I, LL, I, FL, FL, FL, P, FL, P],
     "pn2_binary": [I, I, P, I, P, I, P, I, I, I, I, P],
     "pn2_copy": [I, P, I, I, P, I, I, I, I, P],
     "pn2_nchw_to_nhwc": [I, P, P, I, I, I, I, I, P],
@@ -144,7 +148,7 @@ SIGNATURES = {
 # entry points that return a value rather than a status
 _VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
                 "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
-                "pn2_dsra_tail_blocks", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks",
+                "pn2_dsra_tail_blocks", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks", "pn2_mutation_loss_blocks", "pn2_mutation_loss_width",
                 "pn2_dwconv_blocks", "pn2_pairconv_blocks", "pn2_gate_blocks"}
 
 _lib = None

@@ -112,3 +112,46 @@ def structure_loss_multi(preds_fg, preds_bg, mask, return_pairs=False):
 def structure_loss(pred, pred_bg, mask_fg, mask_bg=None):
     """Reference signature (MyTrain_med.py:19).  mask_bg is taken to be 1 - mask_fg, as at its call sites."""
     return structure_loss_multi([pred], [pred_bg], mask_fg)
+
+
+class _MutationLoss(torch.autograd.Function):
+    """The multi-class dual-supervision loss of EMCAD/trainer.py:106-140 as two kernels (pn2_mutation_loss_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, label, bg_mask, lc, *maps):
+        if not maps[0].is_cuda:
+            raise RuntimeError("pn2.mutation_loss needs GPU tensors (no CPU fallback)")
+        N, K, H, W = maps[0].shape
+        nhwc = [m.permute(0, 2, 3, 1).float().contiguous() for m in maps]          # no copy for the engine's K-channel output maps
+        lab = label.long().contiguous()
+        bgm = bg_mask.float().contiguous()
+        nb, wd = call.pn2_mutation_loss_blocks(N * H * W), call.pn2_mutation_loss_width(K)
+        if wd < 0:
+            raise RuntimeError(f"pn2.mutation_loss is built for K = 9 classes (got {K})")
+        dev = maps[0].device
+        partial = torch.empty((nb, wd), dtype=torch.float32, device=dev)
+        sums = torch.empty(wd, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        PA = C.c_void_p * 4
+        fg, bg = PA(*[t.data_ptr() for t in nhwc[:4]]), PA(*[t.data_ptr() for t in nhwc[4:]])
+        call.pn2_mutation_loss_fwd(fg, bg, _p(lab), _p(bgm), N, H * W, K, lc[0], lc[1], lc[2], _p(partial), _p(sums), _p(loss), _stream())
+        ctx.save_for_backward(lab, bgm, sums, *nhwc)
+        ctx.meta = (N, K, H, W, lc)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lab, bgm, sums, *nhwc = ctx.saved_tensors
+        N, K, H, W, lc = ctx.meta
+        grads = [torch.empty_like(t) for t in nhwc]
+        PA = C.c_void_p * 4
+        fg, bg = PA(*[t.data_ptr() for t in nhwc[:4]]), PA(*[t.data_ptr() for t in nhwc[4:]])
+        dfg, dbg = PA(*[t.data_ptr() for t in grads[:4]]), PA(*[t.data_ptr() for t in grads[4:]])
+        call.pn2_mutation_loss_bwd(fg, bg, dfg, dbg, _p(lab), _p(bgm), N, H * W, K, lc[0], lc[1], lc[2], _p(sums), 1.0, _stream())
+        return (None, None, None, *[(gr * g).permute(0, 3, 1, 2) for gr in grads])
+
+
+def mutation_loss(outs, label, bg_mask, lc=(0.5, 0.7, 0.3)):
+    """sum over the 15 non-empty subsets s of the 4 scales of lc1*CE(sum fg) + lc2*Dice(softmax(sum fg)) + lc3*BCEWithLogits(sum bg, bg_mask)
+    (EMCAD/trainer.py:106-140, supervision='mutation', dual): outs = the 8 maps EMCADNet returns, label (N,H,W) int, bg_mask (N,K,H,W)."""
+    return _MutationLoss.apply(label, bg_mask, tuple(float(v) for v in lc), *outs)

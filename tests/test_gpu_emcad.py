@@ -159,6 +159,26 @@ def test_emcad_dual_decoder_vs_oracle_fp32():
             assert rell2(g, P[k].grad) < max(5e-3, 8 * rell2(P32[k].grad, P[k].grad)), k        # floor: a single ReLU6 mask flip (|x - 6| ~ 1e-6) moves a bias gradient by ~1e-3
 
 
+def test_mutation_loss_kernels_vs_reference_formula():
+    """pn2.loss.mutation_loss (one forward pass + one backward pass over the 8 maps) against the oracle's restatement of trainer.py:106-140
+    evaluated in float64: value and the gradient of every map."""
+    from pn2.loss import mutation_loss
+    from oracle import emcad_oracle as E
+    torch.manual_seed(3)
+    N, K, H, W = 3, 9, 20, 28
+    maps = [(torch.randn(N, K, H, W, device=dev) * 1.5).requires_grad_(True) for _ in range(8)]
+    label = torch.randint(0, K, (N, H, W), device=dev)
+    bg = torch.stack([(label != k).float() for k in range(K)], 1)
+    loss = mutation_loss(maps, label, bg)
+    loss.backward()
+    m64 = [m.detach().double().cpu().requires_grad_(True) for m in maps]
+    ref = E.mutation_loss(m64, label.cpu(), bg.double().cpu())
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * float(ref)
+    for a, b in zip(maps, m64):
+        assert relmax(a.grad, b.grad) < 2e-5
+
+
 def _model(fp32=True):
     import pn2
     from lib.networks import EMCADNet
@@ -187,7 +207,8 @@ def test_emcadnet_forward_backward_vs_reference(fp32):
     model = _model(fp32)
     x = torch.from_numpy(z["x"]).to(dev); label = torch.from_numpy(z["label"]).to(dev); bg = torch.from_numpy(z["bg_mask"]).to(dev)
     outs = model(x, mode="train")
-    loss = E.mutation_loss(outs, label, bg)          # plain torch ops on GPU tensors = what the reference's trainer.py:106-140 runs
+    from pn2.loss import mutation_loss
+    loss = mutation_loss(outs, label, bg)            # trainer.py:106-140 as the fused kernel pair
     loss.backward()
     names = dict(model.named_parameters())
     if fp32:

@@ -33,12 +33,19 @@ def dice(logits, target):
     return loss / 9
 
 
+FUSED = os.environ.get("EMCAD_TORCH_LOSS", "0") != "1"
+from pn2.loss import mutation_loss
+
+
 def step():
     P = model(x, mode="train")
-    loss = 0.0
-    for s in subsets:
-        iout = sum(P[i] for i in s); ibg = sum(P[4 + i] for i in s)
-        loss = loss + 0.5 * F.cross_entropy(iout, label) + 0.7 * dice(iout, label) + 0.3 * F.binary_cross_entropy_with_logits(ibg, bg)
+    if FUSED:
+        loss = mutation_loss(P, label, bg)
+    else:
+        loss = 0.0
+        for s in subsets:
+            iout = sum(P[i] for i in s); ibg = sum(P[4 + i] for i in s)
+            loss = loss + 0.5 * F.cross_entropy(iout, label) + 0.7 * dice(iout, label) + 0.3 * F.binary_cross_entropy_with_logits(ibg, bg)
     opt.zero_grad(); loss.backward(); opt.step()
     return loss
 
@@ -49,7 +56,7 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-print(f"EMCADNet dual K=9 bs={bs} {size}x{size} bf16: {1e3 * dt:.1f} ms/step  {bs / dt:.1f} img/s  loss {float(l):.3f}")
+print(f"EMCADNet dual K=9 bs={bs} {size}x{size} bf16 ({'fused pn2.loss.mutation_loss' if FUSED else 'torch loss'}): {1e3 * dt:.1f} ms/step  {bs / dt:.1f} img/s  loss {float(l):.3f}")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 with Recorder() as rec:
     P = model(x, mode="train")
