@@ -205,8 +205,11 @@ int pn2_colsum_finalize(const float* partial, int nblk, int C, int ld, float* ou
  * y_gelu = gelu(z) when non-null.  flip=1 correlates with the mirrored kernel = data gradient of the same conv.  w [C][9] fp32. */
 int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z, void* y_gelu, int N, int H, int W, int C, int flip, int accumulate, void* stream);
 int pn2_gelu_bwd(int dt, const void* dy, const void* z, void* dz, long long n, void* stream);      /* dz = dy * gelu'(z), exact erf form */
-/* partial[nblk][C*10]: columns c*9+tap = dW, C*9+c = dbias ; nblk = pn2_rows_blocks(N*H*W, pn2_colsum_unit(dt, C)) ; finish with pn2_colsum_finalize */
-int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, int nblk, int N, int H, int W, int C, void* stream);
+/* partial[nblk][C*10]: columns c*9+tap = dW, C*9+c = dbias ; nblk = pn2_dwconv3x3_wgrad_blocks(dt, N, H, W, C) ; finish with pn2_colsum_finalize.
+ * zpre non-null: `dz` holds dy (the gradient of the GELU output), dz = dy * gelu'(zpre) is formed in the same pass and written to dz_out
+ * (the pn2_gelu_bwd pass fused in; dz_out then feeds the flip=1 data-gradient launch). */
+int pn2_dwconv3x3_wgrad_blocks(int dt, int N, int H, int W, int C);
+int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, int nblk, int N, int H, int W, int C, const void* zpre, void* dz_out, void* stream);
 /* Spatial-reduction attention (Attention.forward pvtv2.py:90-111), head_dim 64, Nkv <= 256:
  * q [B][Nq][heads*64] ; kv [B][Nkv][2*heads*64] (k then v, heads inner, as the reference's reshape(B,-1,2,heads,hd)) ;
  * out = softmax(q k^T * scale) v, heads concatenated ; lse [B][heads][Nq] fp32 saved for the backward.

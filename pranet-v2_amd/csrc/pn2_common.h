@@ -63,6 +63,13 @@ __device__ __forceinline__ int phys2log(int p, int gw, int gwp, int C) {
     return (o < gw && c < C) ? c : -1;
 }
 
+// bijective XCD-aware remap: hardware places block b on XCD b%8; give every XCD a contiguous range of logical tiles / pixel chunks so that
+// neighbours (shared A rows and weight panels of the GEMMs, halo rows of the depth-wise convs) meet in one L2 instead of being fetched by several.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

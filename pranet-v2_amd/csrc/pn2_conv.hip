@@ -41,12 +41,6 @@ template <> struct MMA<float> {
     }
 };
 
-// bijective XCD-aware remap: hardware places block b on XCD b%8; give every XCD a contiguous
-// range of logical tiles so neighbouring tiles (which share A rows / weight panels) share one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
 
 struct GatherGeom {
     int H, W, OH, OW, KH, KW, stride, sshift, pad_h, pad_w, dil_h, dil_w, transposed;

@@ -569,14 +569,32 @@ __global__ __launch_bounds__(256) void mloss_fwd_k(ml_maps m, const long long* _
         partial[(size_t)blockIdx.x * (ML_NS * W + K) + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
 }
 
-// sums[ML_NS*W + K] (double-accumulated over the partial rows) and the scalar loss
+// partial rows -> ML_RG group rows in double (every group sums a contiguous range of block rows, 4 independent chains per thread)
+constexpr int ML_RG = 128;
 template <int K>
-__global__ void mloss_finalize_k(const float* __restrict__ partial, int nblk, float* __restrict__ sums, float* __restrict__ loss, double npix, float lc1, float lc2, float lc3) {
+__global__ __launch_bounds__(256) void mloss_reduce_k(const float* __restrict__ partial, int nblk, double* __restrict__ grp) {
+    constexpr int NV = ML_NS * MLW<K>::W + K;
+    const int rb = (nblk + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * rb, r1 = min(nblk, r0 + rb);
+    for (int j = threadIdx.x; j < NV; j += 256) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
+            a0 += (double)partial[(size_t)r * NV + j]; a1 += (double)partial[(size_t)(r + 1) * NV + j];
+            a2 += (double)partial[(size_t)(r + 2) * NV + j]; a3 += (double)partial[(size_t)(r + 3) * NV + j];
+        }
+        for (; r < r1; ++r) a0 += (double)partial[(size_t)r * NV + j];
+        grp[(size_t)blockIdx.x * NV + j] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+// sums[ML_NS*W + K] (double-accumulated over the group rows) and the scalar loss
+template <int K>
+__global__ void mloss_finalize_k(const double* __restrict__ grp, int ngrp, float* __restrict__ sums, float* __restrict__ loss, double npix, float lc1, float lc2, float lc3) {
     constexpr int W = MLW<K>::W, NV = ML_NS * W + K;
     __shared__ double sh[NV];
     for (int j = threadIdx.x; j < NV; j += blockDim.x) {
         double a = 0.0;
-        for (int r = 0; r < nblk; ++r) a += (double)partial[(size_t)r * NV + j];
+        for (int r = 0; r < ngrp; ++r) a += grp[(size_t)r * NV + j];
         sh[j] = a; sums[j] = (float)a;
     }
     __syncthreads();
@@ -834,7 +852,9 @@ int pn2_sigmoid_bwd(int dt_out, const float* dy, const float* y, void* dx, int l
     return 0;
 }
 
-int pn2_mutation_loss_blocks(long long npix) { return npix < 1 ? -1 : (int)((npix + 255) / 256); }
+static int ml_blocks(long long npix) { return (int)((npix + 255) / 256); }
+/* rows of the `partial` scratch: one per 256 pixels + the double-precision group rows of the second reduction level */
+int pn2_mutation_loss_blocks(long long npix) { return npix < 1 ? -1 : ml_blocks(npix) + 2 * ML_RG + 1; }
 int pn2_mutation_loss_width(int K) { return K == 9 ? ML_NS * MLW<9>::W + 9 : -1; }
 
 /* EMCAD/trainer.py:106-140: sum over the 15 non-empty subsets of the 4 scales of lc1*CE + lc2*Dice(softmax) + lc3*BCEWithLogits on the summed maps.
@@ -847,10 +867,13 @@ int pn2_mutation_loss_fwd(const float* const* fg, const float* const* bg, const 
     ml_maps m;
     for (int i = 0; i < 4; ++i) { m.fg[i] = fg[i]; m.bg[i] = bg[i]; m.dfg[i] = nullptr; m.dbg[i] = nullptr; if (!fg[i] || !bg[i]) return -1; }
     const size_t NP = (size_t)N * HW;
-    const int nblk = pn2_mutation_loss_blocks((long long)NP);
+    const int nblk = ml_blocks((long long)NP), NV = ML_NS * MLW<9>::W + 9;
+    const int ngrp = nblk < 8 * ML_RG ? (nblk + 7) / 8 : ML_RG;
+    double* grp = reinterpret_cast<double*>(partial + (((size_t)nblk * NV + 1) & ~(size_t)1));          // 8-byte aligned, after the block rows
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(mloss_fwd_k<9>, dim3(nblk), dim3(256), 0, st, m, label, bg_mask, NP, (size_t)HW, partial);
-    hipLaunchKernelGGL(mloss_finalize_k<9>, dim3(1), dim3(256), 0, st, partial, nblk, sums, loss, (double)NP, lc1, lc2, lc3);
+    hipLaunchKernelGGL(mloss_reduce_k<9>, dim3(ngrp), dim3(256), 0, st, partial, nblk, grp);
+    hipLaunchKernelGGL(mloss_finalize_k<9>, dim3(1), dim3(256), 0, st, grp, ngrp, sums, loss, (double)NP, lc1, lc2, lc3);
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -6,6 +6,7 @@
 // Tokens [B, N, C] of the reference are NHWC pixels here (N = H*W), so no transposes are needed anywhere.
 // The Linear layers themselves run on the implicit-GEMM conv kernels (1x1) of pn2_conv.hip.
 // All kernels are deterministic (fixed-order reductions, no floating-point atomics).
+#include <cstdint>
 #include <cstdlib>
 #include "pn2_common.h"
 #include "../../include/pn2.h"
@@ -199,51 +200,6 @@ __device__ __forceinline__ float gelu_grad(float x) {       // d/dx [x * Phi(x)]
 }
 
 // z = sum_taps w[c][tap] * x[pixel + tap][c] (+ b[c]) ; y = gelu(z) (optional).  flip: correlate with the mirrored kernel (data gradient).
-// A thread owns one channel vector (its 9 x VEC weights and bias stay in registers) and walks the pixels of the block's range.
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv3x3_k(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, T* __restrict__ z, T* __restrict__ y,
-                                                   int N, int H, int W, int C, int flip, int accumulate, int pix_per_blk, int CVP) {
-    constexpr int V = TT<T>::VEC;
-    const int CV = C / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
-    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
-    for (int cv = cvl; cv < CV; cv += CVP) {
-        float wr[9][V], br[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            br[e] = b ? b[cv * V + e] : 0.f;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) wr[t][e] = w[(cv * V + e) * 9 + (flip ? 8 - t : t)];
-        }
-        for (int m = p0 + rl; m < p1; m += R) {
-            const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
-            float a[V];
-#pragma unroll
-            for (int e = 0; e < V; ++e) a[e] = br[e];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                    float xv[V];
-                    ldv<T>(x + (((size_t)n * H + iy) * W + ix) * C + cv * V, xv);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) a[e] += wr[t][e] * xv[e];
-                }
-            }
-            const size_t o = (size_t)m * C + cv * V;
-            if (accumulate) { float old[V]; ldv<T>(z + o, old);
-#pragma unroll
-                for (int e = 0; e < V; ++e) a[e] += old[e]; }
-            stv<T>(z + o, a);
-            if (y) {
-#pragma unroll
-                for (int e = 0; e < V; ++e) a[e] = gelu_f(a[e]);
-                stv<T>(y + o, a);
-            }
-        }
-    }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_bwd_k(const T* __restrict__ dy, const T* __restrict__ z, T* __restrict__ dz, size_t nvec) {
     constexpr int V = TT<T>::VEC;
@@ -257,55 +213,219 @@ __global__ __launch_bounds__(256) void gelu_bwd_k(const T* __restrict__ dy, cons
 }
 
 // partial[blk][C*10]: [c*9 + tap] = sum_pixels dz[p][c] * x[p + tap][c] ; [C*9 + c] = sum_pixels dz[p][c]
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv3x3_wgrad_k(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ partial, int N, int H, int W, int C,
-                                                         int pix_per_blk, int CVP) {
-    constexpr int V = TT<T>::VEC;
-    extern __shared__ float sh[];            // [R][CVP*V] reused for each of the 10 sums
-    const int CV = C / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
-    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
-    for (int cvb = 0; cvb < CV; cvb += CVP) {
-        const int cv = cvb + cvl;
-        float a[10][V];
+// ---- sliding-window walk: a thread owns VT channels and walks a row segment of SEG output pixels, keeping the 3x3 input window packed in
+// registers — 3 new loads per output pixel instead of 9 (a 9-load walk ran at ~1.5 TB/s, bound by the L1/TA requests in flight).
+// VT = 8 / 4 / 2 channels per thread (16 / 8 / 4-byte loads for bf16): the narrow variants trade load width for 2-4x more waves, which is
+// what the small late-stage tensors need (they are latency-bound, one short segment per thread).
+template <typename T, int VT> struct DwVec {
+    static constexpr int NW = VT * (int)sizeof(T) / 4;          // 32-bit words per packed vector
+    unsigned w[NW];
+    __device__ __forceinline__ void zero() {
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
+        for (int i = 0; i < NW; ++i) w[i] = 0u;
+    }
+    __device__ __forceinline__ void load(const T* p) {
+        if constexpr (NW == 4) { const uint4 v = *reinterpret_cast<const uint4*>(p); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+        else if constexpr (NW == 2) { const uint2 v = *reinterpret_cast<const uint2*>(p); w[0] = v.x; w[1] = v.y; }
+        else { w[0] = *reinterpret_cast<const unsigned*>(p); }
+    }
+    __device__ __forceinline__ void store(T* p) const {
+        if constexpr (NW == 4) *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        else if constexpr (NW == 2) *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+        else *reinterpret_cast<unsigned*>(p) = w[0];
+    }
+    __device__ __forceinline__ void unpack(float* f) const {
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) a[t][e] = 0.f;
-        if (cv < CV) {
-            for (int m = p0 + rl; m < p1; m += R) {
-                const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
-                float d[V];
-                ldv<T>(dz + (size_t)m * C + cv * V, d);
+            for (int i = 0; i < NW; ++i) f[i] = __uint_as_float(w[i]);
+        } else {
 #pragma unroll
-                for (int e = 0; e < V; ++e) a[9][e] += d[e];
+            for (int i = 0; i < NW; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+        }
+    }
+    __device__ __forceinline__ void pack(const float* f) {
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                        float xv[V];
-                        ldv<T>(x + (((size_t)n * H + iy) * W + ix) * C + cv * V, xv);
+            for (int i = 0; i < NW; ++i) w[i] = __float_as_uint(f[i]);
+        } else {
 #pragma unroll
-                        for (int e = 0; e < V; ++e) a[t][e] += d[e] * xv[e];
-                    }
+            for (int i = 0; i < NW; ++i) w[i] = TT<bf16_t>::cvt2(f[2 * i], f[2 * i + 1]);
+        }
+    }
+};
+
+template <typename T, int VT>
+__device__ __forceinline__ void dw_load_col(const T* const (&rowp)[3], const bool (&vy)[3], int ix, int W, int C, DwVec<T, VT> (&col)[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        col[r].zero();
+        if (vy[r] && (unsigned)ix < (unsigned)W) col[r].load(rowp[r] + (size_t)ix * C);
+    }
+}
+
+template <typename T, int VT>
+__device__ __forceinline__ void dw_rows(const T* x, int row, int oy, int H, int W, int C, int cv, const T* (&rowp)[3], bool (&vy)[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        vy[r] = (unsigned)(oy + r - 1) < (unsigned)H;
+        rowp[r] = x + ((ptrdiff_t)(row + r - 1) * W) * C + cv * VT;
+    }
+}
+
+template <typename T, int VT>
+__global__ __launch_bounds__(256) void dwconv3x3_row_k(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, T* __restrict__ z, T* __restrict__ y,
+                                                       int N, int H, int W, int C, int flip, int accumulate, int SEG, int SPR, int CVP, int walign) {
+    typedef DwVec<T, VT> Vec;
+    const int CV = C / VT, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);          // consecutive segments (and their halo rows) share an XCD's L2
+    const int s = bid * R + rl, cv = blockIdx.y * CVP + cvl;
+    if (s >= N * H * SPR || cv >= CV) return;
+    const int sx = s % SPR, row = s / SPR, oy = row % H;
+    const int x0 = sx * SEG, x1 = min(W, x0 + SEG);
+    float wr[9][VT], br[VT];
+    {
+        float wf[9 * VT];                                       // the 9*VT weights of this channel group are contiguous
+        const float* wp = w + (size_t)cv * VT * 9;
+        if constexpr (VT % 4 == 0) {
+            if (walign) {
+#pragma unroll
+                for (int i = 0; i < 9 * VT / 4; ++i) {
+                    const float4 q = reinterpret_cast<const float4*>(wp)[i];
+                    wf[4 * i] = q.x; wf[4 * i + 1] = q.y; wf[4 * i + 2] = q.z; wf[4 * i + 3] = q.w;
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9 * VT; ++i) wf[i] = wp[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9 * VT; ++i) wf[i] = wp[i];
+        }
+#pragma unroll
+        for (int e = 0; e < VT; ++e) {
+            br[e] = b ? b[cv * VT + e] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wr[t][e] = flip ? wf[e * 9 + 8 - t] : wf[e * 9 + t];
+        }
+    }
+    const T* rowp[3]; bool vy[3];
+    dw_rows<T, VT>(x, row, oy, H, W, C, cv, rowp, vy);
+    Vec c0[3], c1[3], c2[3], n1[3], n2[3];
+    dw_load_col<T, VT>(rowp, vy, x0 - 1, W, C, c0); dw_load_col<T, VT>(rowp, vy, x0, W, C, c1); dw_load_col<T, VT>(rowp, vy, x0 + 1, W, C, c2);
+    dw_load_col<T, VT>(rowp, vy, x0 + 2 < x1 + 1 ? x0 + 2 : -1, W, C, n1);
+    for (int ox = x0; ox < x1; ++ox) {
+        dw_load_col<T, VT>(rowp, vy, ox + 3 < x1 + 1 ? ox + 3 : -1, W, C, n2);      // columns past the segment's halo are never needed
+        float a[VT], xv[VT];
+#pragma unroll
+        for (int e = 0; e < VT; ++e) a[e] = br[e];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            c0[r].unpack(xv);
+#pragma unroll
+            for (int e = 0; e < VT; ++e) a[e] += wr[r * 3][e] * xv[e];
+            c1[r].unpack(xv);
+#pragma unroll
+            for (int e = 0; e < VT; ++e) a[e] += wr[r * 3 + 1][e] * xv[e];
+            c2[r].unpack(xv);
+#pragma unroll
+            for (int e = 0; e < VT; ++e) a[e] += wr[r * 3 + 2][e] * xv[e];
+        }
+        const size_t o = ((size_t)row * W + ox) * C + cv * VT;
+        Vec ov;
+        if (accumulate) {
+            ov.load(z + o); ov.unpack(xv);
+#pragma unroll
+            for (int e = 0; e < VT; ++e) a[e] += xv[e];
+        }
+        ov.pack(a); ov.store(z + o);
+        if (y) {
+#pragma unroll
+            for (int e = 0; e < VT; ++e) a[e] = gelu_f(a[e]);
+            ov.pack(a); ov.store(y + o);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; c2[r] = n1[r]; n1[r] = n2[r]; }
+    }
+}
+
+// weight gradient, same walk: partial[chunk][C*10]; a block = CVP channel groups x R segment lanes, a chunk = SPC segments.
+// zpre non-null: dz = dy * gelu'(zpre) is formed here (and written to dz_out) instead of by a separate pn2_gelu_bwd pass.
+template <typename T, int VT>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_row_k(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ partial, int N, int H, int W, int C,
+                                                             int SEG, int SPR, int SPC, int CVP, const T* __restrict__ zpre, T* __restrict__ dz_out) {
+    typedef DwVec<T, VT> Vec;
+    extern __shared__ float sh[];            // [R][CVP*VT] reused for each of the 10 sums
+    const int CV = C / VT, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int chunk = xcd_remap(blockIdx.x, gridDim.x), cv = blockIdx.y * CVP + cvl;
+    const int nseg = N * H * SPR;
+    float a[10][VT];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int e = 0; e < VT; ++e) a[t][e] = 0.f;
+    if (cv < CV) {
+        const int s1 = min(nseg, (chunk + 1) * SPC);
+        for (int s = chunk * SPC + rl; s < s1; s += R) {
+            const int sx = s % SPR, row = s / SPR, oy = row % H;
+            const int x0 = sx * SEG, x1 = min(W, x0 + SEG);
+            const T* rowp[3]; bool vy[3];
+            dw_rows<T, VT>(x, row, oy, H, W, C, cv, rowp, vy);
+            const size_t o0 = ((size_t)row * W) * C + cv * VT;
+            Vec c0[3], c1[3], c2[3], n1[3], dn, zn;
+            zn.zero();
+            dw_load_col<T, VT>(rowp, vy, x0 - 1, W, C, c0); dw_load_col<T, VT>(rowp, vy, x0, W, C, c1); dw_load_col<T, VT>(rowp, vy, x0 + 1, W, C, c2);
+            dn.load(dz + o0 + (size_t)x0 * C);
+            if (zpre) zn.load(zpre + o0 + (size_t)x0 * C);
+            for (int ox = x0; ox < x1; ++ox) {
+                const Vec dc = dn, zc = zn;
+                dw_load_col<T, VT>(rowp, vy, ox + 2 < x1 + 1 ? ox + 2 : -1, W, C, n1);
+                if (ox + 1 < x1) {
+                    dn.load(dz + o0 + (size_t)(ox + 1) * C);
+                    if (zpre) zn.load(zpre + o0 + (size_t)(ox + 1) * C);
+                }
+                float d[VT], xv[VT];
+                dc.unpack(d);
+                if (zpre) {
+                    zc.unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) d[e] *= gelu_grad(xv[e]);
+                    Vec pk; pk.pack(d); pk.store(dz_out + o0 + (size_t)ox * C);
+                    pk.unpack(d);                              // accumulate what the data-gradient pass will read (the rounded value)
+                }
+#pragma unroll
+                for (int e = 0; e < VT; ++e) a[9][e] += d[e];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    c0[r].unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) a[r * 3][e] += d[e] * xv[e];
+                    c1[r].unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) a[r * 3 + 1][e] += d[e] * xv[e];
+                    c2[r].unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) a[r * 3 + 2][e] += d[e] * xv[e];
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; c2[r] = n1[r]; }
             }
         }
-        for (int t = 0; t < 10; ++t) {
+    }
 #pragma unroll
-            for (int e = 0; e < V; ++e) sh[(rl * CVP + cvl) * V + e] = a[t][e];
-            __syncthreads();
-            if (rl == 0 && cv < CV) {
+    for (int t = 0; t < 10; ++t) {
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    float s = 0.f;
-                    for (int r = 0; r < R; ++r) s += sh[(r * CVP + cvl) * V + e];
-                    const int c = cv * V + e;
-                    partial[(size_t)blockIdx.x * C * 10 + (t < 9 ? c * 9 + t : C * 9 + c)] = s;
-                }
+        for (int e = 0; e < VT; ++e) sh[(rl * CVP + cvl) * VT + e] = a[t][e];
+        __syncthreads();
+        if (rl == 0 && cv < CV) {
+#pragma unroll
+            for (int e = 0; e < VT; ++e) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += sh[(r * CVP + cvl) * VT + e];
+                const int c = cv * VT + e;
+                partial[(size_t)chunk * C * 10 + (t < 9 ? c * 9 + t : C * 9 + c)] = s;
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
 }
 
@@ -810,17 +930,43 @@ int pn2_colsum(int dt, const void* dy, int ld, int M, int C, float* partial, int
 
 int pn2_colsum_unit(int dt, int C) { const int V = dt == PN2_F32 ? 4 : 8; int cvp = pow2ceil(C / V); if (cvp > 256) cvp = 256; return 256 / cvp; }
 
+static int dw_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+
+// channels per thread (VT) and segment length of the depth-wise walks, from a sweep on MI355X (tools/dw_micro.py; PN2_DW_VT / PN2_DW_SEG override):
+// kind 0 = conv + GELU (ALU-heavier: 8-byte vectors, more waves), 1 = plain conv / data gradient (16-byte vectors while there are threads to
+// spare), 2 = weight gradient (80 accumulators per 8 channels: 2 channels per thread keeps 8 waves per SIMD).  Short segments for small tensors.
+static void dw_row_geometry(int dt, int kind, int N, int H, int W, int C, int& VT, int& SEG, int& SPR) {
+    const int vmax = dt == PN2_F32 ? 4 : 8;
+    auto threads = [&](int vt, int target) { return (long long)N * H * ((W + target - 1) / target) * (C / vt); };
+    int target = 16;
+    if (kind == 2) VT = 2;
+    else {
+        VT = kind == 0 ? vmax / 2 : vmax;
+        while (VT > 2 && ((C % VT) || (VT == vmax && kind == 1 && threads(VT, 16) < 2LL * 256 * 8 * 64))) VT >>= 1;
+        if (threads(VT, 16) < 200000) target = 8;
+    }
+    static const int evt = dw_env("PN2_DW_VT"), eseg = dw_env("PN2_DW_SEG");
+    if (evt && evt <= vmax && C % evt == 0) VT = evt;
+    if (eseg) target = eseg;
+    SPR = (W + target - 1) / target; SEG = (W + SPR - 1) / SPR;
+}
+
+#define DW_VT(VT, BODY) switch (VT) { case 8: { constexpr int VT_ = 8; BODY } break; case 4: { constexpr int VT_ = 4; BODY } break; default: { constexpr int VT_ = 2; BODY } }
+
 int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z, void* y_gelu, int N, int H, int W, int C, int flip, int accumulate, void* stream) {
     if (!x || !w || !z) return -1;
-    const int V = dt == PN2_F32 ? 4 : 8;
-    if (C % V) return -2;
-    int cvp = pow2ceil(C / V); if (cvp > 256) cvp = 256;
-    const int R = 256 / cvp, M = N * H * W;
-    int pix = (M + 2047) / 2048;                      // ~2048 blocks; every thread re-reads its 9 x VEC weights once per block
-    pix = ((pix + R - 1) / R) * R;
-    if (pix < 4 * R) pix = 4 * R;
-    VIT_DISPATCH(dt, { hipLaunchKernelGGL(dwconv3x3_k<T>, dim3((M + pix - 1) / pix), dim3(256), 0, (hipStream_t)stream, (const T*)x, w, b, (T*)z, (T*)y_gelu,
-                                          N, H, W, C, flip, accumulate, pix, cvp); })
+    if (C % 2 || (dt == PN2_BF16 && C % 2) || N < 1 || H < 1 || W < 1) return -2;
+    int VT, SEG, SPR; dw_row_geometry(dt, y_gelu ? 0 : 1, N, H, W, C, VT, SEG, SPR);
+    const int CV = C / VT, lanes = (dt == PN2_F32 ? 256 : 512) / VT;     // channel groups per block: 1 KB of one pixel
+    const int cvp = CV >= lanes ? lanes : pow2ceil(CV), R = 256 / cvp, nseg = N * H * SPR;
+    const int walign = ((uintptr_t)w & 15) == 0;
+    const dim3 grid((nseg + R - 1) / R, (CV + cvp - 1) / cvp);
+    if (dt == PN2_BF16) { DW_VT(VT, { hipLaunchKernelGGL((dwconv3x3_row_k<bf16_t, VT_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, b, (bf16_t*)z, (bf16_t*)y_gelu,
+                                                      N, H, W, C, flip, accumulate, SEG, SPR, cvp, walign); }) }
+    else if (dt == PN2_F32) {
+        if (VT == 4) hipLaunchKernelGGL((dwconv3x3_row_k<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, w, b, (float*)z, (float*)y_gelu, N, H, W, C, flip, accumulate, SEG, SPR, cvp, walign);
+        else hipLaunchKernelGGL((dwconv3x3_row_k<float, 2>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, w, b, (float*)z, (float*)y_gelu, N, H, W, C, flip, accumulate, SEG, SPR, cvp, walign);
+    } else return -3;
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -834,14 +980,37 @@ int pn2_gelu_bwd(int dt, const void* dy, const void* z, void* dz, long long n, v
     return 0;
 }
 
-int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, int nblk, int N, int H, int W, int C, void* stream) {
-    if (!dz || !x || !partial || nblk < 1) return -1;
-    const int V = dt == PN2_F32 ? 4 : 8;
-    if (C % V) return -2;
-    int cvp = pow2ceil(C / V); if (cvp > 256) cvp = 256;
-    const int M = N * H * W, pix = rows_for(M, 256 / cvp);
-    if ((M + pix - 1) / pix != nblk) return -2;            // nblk must be pn2_rows_blocks(N*H*W, pn2_colsum_unit(dt, C))
-    VIT_DISPATCH(dt, { hipLaunchKernelGGL(dwconv3x3_wgrad_k<T>, dim3(nblk), dim3(256), 256 * TT<T>::VEC * 4, (hipStream_t)stream, (const T*)dz, (const T*)x, partial, N, H, W, C, pix, cvp); })
+static void dw_wgrad_geometry(int dt, int N, int H, int W, int C, int& VT, int& SEG, int& SPR, int& SPC, int& cvp, int& nchunk) {
+    dw_row_geometry(dt, 2, N, H, W, C, VT, SEG, SPR);
+    const int CV = C / VT, lanes = (dt == PN2_F32 ? 32 : 64) / VT * 2;          // 256 contiguous bytes of one pixel per block
+    cvp = CV >= lanes ? lanes : pow2ceil(CV);
+    const int R = 256 / cvp, gy = (CV + cvp - 1) / cvp, nseg = N * H * SPR;
+    int want = 1536 / gy; if (want < 1) want = 1;            // ~1536 workgroups over (chunks x channel groups)
+    SPC = (nseg + want - 1) / want;
+    SPC = ((SPC + R - 1) / R) * R;
+    nchunk = (nseg + SPC - 1) / SPC;
+}
+
+int pn2_dwconv3x3_wgrad_blocks(int dt, int N, int H, int W, int C) {
+    if ((dt != PN2_F32 && dt != PN2_BF16) || C % 2 || N < 1 || H < 1 || W < 1) return -1;
+    int VT, SEG, SPR, SPC, cvp, nchunk; dw_wgrad_geometry(dt, N, H, W, C, VT, SEG, SPR, SPC, cvp, nchunk);
+    return nchunk;
+}
+
+int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, int nblk, int N, int H, int W, int C, const void* zpre, void* dz_out, void* stream) {
+    if (!dz || !x || !partial || nblk < 1 || (zpre && !dz_out)) return -1;
+    if (C % 2) return -2;
+    int VT, SEG, SPR, SPC, cvp, nchunk; dw_wgrad_geometry(dt, N, H, W, C, VT, SEG, SPR, SPC, cvp, nchunk);
+    if (nchunk != nblk) return -2;                           // nblk must be pn2_dwconv3x3_wgrad_blocks(dt, N, H, W, C)
+    const int CV = C / VT;
+    const dim3 grid(nchunk, (CV + cvp - 1) / cvp);
+    const size_t lds = (size_t)256 * VT * 4;
+    if (dt == PN2_BF16) { DW_VT(VT, { hipLaunchKernelGGL((dwconv3x3_wgrad_row_k<bf16_t, VT_>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)x, partial,
+                                                      N, H, W, C, SEG, SPR, SPC, cvp, (const bf16_t*)zpre, (bf16_t*)dz_out); }) }
+    else if (dt == PN2_F32) {
+        if (VT == 4) hipLaunchKernelGGL((dwconv3x3_wgrad_row_k<float, 4>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)dz, (const float*)x, partial, N, H, W, C, SEG, SPR, SPC, cvp, (const float*)zpre, (float*)dz_out);
+        else hipLaunchKernelGGL((dwconv3x3_wgrad_row_k<float, 2>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)dz, (const float*)x, partial, N, H, W, C, SEG, SPR, SPC, cvp, (const float*)zpre, (float*)dz_out);
+    } else return -3;
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -108,7 +108,8 @@ SIGNATURES = {
     "pn2_colsum_finalize": [P, I, I, I, P, I, P],
     "pn2_dwconv3x3": [I, P, P, P, P, P, I, I, I, I, I, I, P],
     "pn2_gelu_bwd": [I, P, P, P, LL, P],
-    "pn2_dwconv3x3_wgrad": [I, P, P, P, I, I, I, I, I, P],
+    "pn2_dwconv3x3_wgrad_blocks": [I, I, I, I, I],
+    "pn2_dwconv3x3_wgrad": [I, P, P, P, I, I, I, I, I, P, P, P],
     "pn2_scale_samples": [I, P, P, P, I, LL, P],
     "pn2_attn_fwd": [I, P, I, P, I, P, I, P, I, I, I, I, I, FL, P],
     "pn2_attn_bwd_blocks": [I, I],
@@ -146,7 +147,7 @@ SIGNATURES = {
     "pn2_eval_hist": [P, P, LL, P, P],
 }
 # entry points that return a value rather than a status
-_VALUE_FUNCS = {"pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
+_VALUE_FUNCS = {"pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
                 "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
                 "pn2_dsra_tail_blocks", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks", "pn2_mutation_loss_blocks", "pn2_mutation_loss_width",
                 "pn2_dwconv_blocks", "pn2_pairconv_blocks", "pn2_gate_blocks"}

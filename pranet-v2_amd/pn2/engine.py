@@ -964,11 +964,10 @@ class Engine:
             dy = y.grad_buf()
             assert y.grad_written and dy.stride(2) == Cc
             dz = self.empty(N, H, W, Cc)
-            call.pn2_gelu_bwd(self.dt, _p(dy), _p(z), _p(dz), dz.numel(), st)
-            M = N * H * W
-            nb = call.pn2_rows_blocks(M, call.pn2_colsum_unit(self.dt, Cc))
+            nb = call.pn2_dwconv3x3_wgrad_blocks(self.dt, N, H, W, Cc)
             part = self.fbuf(nb, Cc * 10)
-            call.pn2_dwconv3x3_wgrad(self.dt, _p(dz), x.ptr, _p(part), nb, N, H, W, Cc, st)
+            # dz = dy * gelu'(z) is formed inside the weight-gradient walk (one pass over dy, z, x) and kept for the data gradient
+            call.pn2_dwconv3x3_wgrad(self.dt, _p(dy), x.ptr, _p(part), nb, N, H, W, Cc, _p(z), _p(dz), st)
             gw, gwa = self.pgrads.sink(conv.weight)
             gb, gba = self.pgrads.sink(conv.bias)
             call.pn2_colsum_finalize(_p(part), nb, Cc * 9, Cc * 10, _p(gw), gwa, st)

@@ -9,7 +9,7 @@ import os
 import torch
 
 from .capi import F32, BF16
-from .engine import Engine
+from .engine import Engine, PackCache, TUNER
 
 _DT = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "float32": F32, "f32": F32}
 _compute_dtype = _DT[os.environ.get("PN2_DTYPE", "bf16").lower()]
@@ -23,6 +23,28 @@ def set_compute_dtype(name):
 
 def get_compute_dtype():
     return _compute_dtype
+
+
+def _pack_cache(dtype, params):
+    """Packed-panel cache of one module call site.  The packed weight panels of a call site persist across calls (the cache hangs off the module's
+    first parameter, so it lives and dies with the module) and are ALL rebuilt from the current fp32 weights by one table-driven launch
+    at the start of every call - never reused unrefreshed, whatever touched the weights in between.  Conv tiles come from the
+    process-wide per-shape tuner, as in pn2.trainer.Trainer."""
+    pc = None
+    if params and os.environ.get("PN2_MODULE_PACK_CACHE", "1") == "1":
+        slot = params[0].__dict__.setdefault("_pn2_pack", {})
+        pc = slot.get(dtype)
+        if pc is None:
+            pc = slot[dtype] = PackCache()
+        if pc.keep and any(j.w != w.data_ptr() for j, w in zip(pc.jobs, pc.keep)):
+            pc = slot[dtype] = PackCache()            # a weight was re-allocated (p.data = ...): start over
+        pc.refresh()
+    return pc
+
+
+def _module_engine(dtype, training, need_grad, pc):
+    tuner = TUNER if os.environ.get("PN2_AUTOTUNE", "1") == "1" else None
+    return Engine(dtype, training, need_grad=need_grad, pack_cache=pc, tuner=tuner)
 
 
 def _seed_grad(act, g):
@@ -50,9 +72,9 @@ def _seed_grad(act, g):
 
 class _GraphFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, build, training, dtype, n_in, *tensors):
+    def forward(ctx, build, training, dtype, pc, n_in, *tensors):
         inputs, params = tensors[:n_in], tensors[n_in:]
-        eng = Engine(dtype, training, need_grad=True)
+        eng = _module_engine(dtype, training, True, pc)
         acts = [eng.from_nchw(x, requires_grad=x.requires_grad) for x in inputs]
         outs = build(eng, *acts)
         eng.finish_forward()
@@ -73,7 +95,7 @@ class _GraphFn(torch.autograd.Function):
                 gin.append(None)
         gpar = [eng.pgrads.get(p) for p in ctx.params]
         ctx.eng = ctx.acts = ctx.outs = None
-        return (None, None, None, None, *gin, *gpar)
+        return (None, None, None, None, None, *gin, *gpar)
 
 
 def run_module(build, inputs, params, training, dtype=None):
@@ -81,10 +103,11 @@ def run_module(build, inputs, params, training, dtype=None):
     dtype = _compute_dtype if dtype is None else dtype
     params = [p for p in params]
     need = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(x.requires_grad for x in inputs))
+    pc = _pack_cache(dtype, params)
     if not need:
-        eng = Engine(dtype, training, need_grad=False)
+        eng = _module_engine(dtype, training, False, pc)
         acts = [eng.from_nchw(x) for x in inputs]
         outs = build(eng, *acts)
         eng.finish_forward()
         return tuple(eng.to_nchw(o) for o in outs)
-    return _GraphFn.apply(build, training, dtype, len(inputs), *inputs, *params)
+    return _GraphFn.apply(build, training, dtype, pc, len(inputs), *inputs, *params)

@@ -76,6 +76,28 @@ def _shape(name, a):
             return f"dt{a[0]}->{a[3]} M{a[6]} C{a[7]} lds{a[2]} ldd{a[5]} acc{a[8]}"
         if name in ("pn2_bn_finalize", "pn2_bn_bwd_finalize"):
             return f"nblk{a[2]} Cp{a[3]._obj.Cp}"
+        if name == "pn2_dwconv":
+            return f"{a[4]}x{a[5]}x{a[6]}x{a[7]} k{a[8]} flip{a[9]} acc{a[10]} stats{1 if a[11].value else 0}"
+        if name == "pn2_dwconv_wgrad":
+            return f"{a[4]}x{a[5]}x{a[6]}x{a[7]} k{a[8]}"
+        if name == "pn2_dwconv3x3":
+            return f"{a[6]}x{a[7]}x{a[8]}x{a[9]} flip{a[10]} acc{a[11]} gelu{1 if a[5].value else 0}"
+        if name == "pn2_dwconv3x3_wgrad":
+            return f"{a[5]}x{a[6]}x{a[7]}x{a[8]} gelu{1 if a[9].value else 0}"
+        if name == "pn2_attn_fwd":
+            return f"B{a[8]} Nq{a[9]} Nkv{a[10]} h{a[11]}"
+        if name == "pn2_attn_bwd":
+            return f"B{a[16]} Nq{a[17]} Nkv{a[18]} h{a[19]}"
+        if name in ("pn2_layernorm_fwd", "pn2_layernorm_bwd"):
+            return f"M{a[5]} C{a[6]}"
+        if name == "pn2_colsum":
+            return f"M{a[3]} C{a[4]}"
+        if name == "pn2_colsum_finalize":
+            return f"nblk{a[1]} C{a[2]}"
+        if name == "pn2_gather_sum":
+            return f"n{a[6]} k{a[7]}"
+        if name in ("pn2_upsample_nearest2x", "pn2_upsample_nearest2x_bwd"):
+            return f"{a[3]}x{a[4]}x{a[5]}x{a[6]}"
     except Exception:
         pass
     return ""

@@ -57,14 +57,13 @@ for _ in range(steps):
     l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
 print(f"EMCADNet dual K=9 bs={bs} {size}x{size} bf16 ({'fused pn2.loss.mutation_loss' if FUSED else 'torch loss'}): {1e3 * dt:.1f} ms/step  {bs / dt:.1f} img/s  loss {float(l):.3f}")
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 with Recorder() as rec:
-    P = model(x, mode="train")
-    e0.record(); loss = sum(0.5 * F.cross_entropy(sum(P[i] for i in s), label) + 0.7 * dice(sum(P[i] for i in s), label) +
-                            0.3 * F.binary_cross_entropy_with_logits(sum(P[4 + i] for i in s), bg) for s in subsets); e1.record()
-    loss.backward()
+    l = step()
 agg = rec.summary()
 torch.cuda.synchronize()
-print(f"torch loss forward (15 subsets): {e0.elapsed_time(e1):.1f} ms; pn2 kernel time {sum(d['ms'] for d in agg.values()):.1f} ms")
-for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:22]:
+print(f"pn2 kernel time (event-bracketed, eager) {sum(d['ms'] for d in agg.values()):.1f} ms")
+for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:24]:
     print(f"{k:34s} {d['ms']:8.3f} ms {d['launches']:5d} launches")
+print()
+for k, d in sorted(rec.summary(detail=True).items(), key=lambda kv: -kv[1]["ms"])[:45]:
+    print(f"{k:90s} {d['ms']:8.3f} ms x{d['launches']:3d}")
