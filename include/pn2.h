@@ -218,7 +218,7 @@ int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, i
 int pn2_scale_samples(int dt, const void* x, void* y, const float* scale, int N, long long elems_per_sample, void* stream);
 int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, void* out, int ld_o, float* lse, int B, int Nq, int Nkv, int heads, int head_dim,
                  float scale, void* stream);
-int pn2_attn_bwd_blocks(int dt, int Nq);        /* query tiles per (b, head): partial holds [B][heads][tiles][2][roundup(Nkv,64)][64] fp32 */
+int pn2_attn_bwd_blocks(int dt, int B, int heads, int Nq);   /* partial slots per (b, head): partial holds [B][heads][slots][2][roundup(Nkv,64)][64] fp32 */
 /* out = the forward result (delta = rowsum(dO * out) lets the bf16 MFMA path treat key ranges independently); delta: [B][heads][Nq] fp32 scratch */
 int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, const void* out, int ld_o, const void* dout, int ld_do, const float* lse, void* dq, int ld_dq,
                  void* dkv, int ld_dkv, float* partial, float* delta, int B, int Nq, int Nkv, int heads, int head_dim, float scale, void* stream);

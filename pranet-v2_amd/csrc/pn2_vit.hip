@@ -632,78 +632,101 @@ __device__ __forceinline__ f32x4v mfma16(const uint4& a, const uint4& b, f32x4v 
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// Fragment (A[i][k] or B[k][i], i = lane & 15) of a 16-wide column block of a ROW-MAJOR LDS tile [k][col] whose rows are the contraction index,
+// through the transposing LDS read: k-slot (g, j) <-> tile row (j >> 2) * 16 + g * 4 + (j & 3).  The other operand of the MFMA has to walk the
+// contraction in the same order (perm_frag).  Conflict-free when the row stride is an odd multiple of 32 bytes (ATR = 80 elements).
+constexpr int ATR = 80;
+__device__ __forceinline__ uint4 tr_frag(const bf16_t* tile, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    unsigned a = (unsigned)(size_t)(reinterpret_cast<const char*>(tile) + (g * 4 + (i >> 2)) * (ATR * 2) + (col0 + (i & 3) * 4) * 2);
+    asm volatile("" : "+v"(a));            // keep the tile offset out of the instruction's immediate field
+    const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a));
+    const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a + 16 * ATR * 2));
+    const uint2 lo = __builtin_bit_cast(uint2, v0), hi = __builtin_bit_cast(uint2, v1);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+// the matching fragment of an operand stored with the contraction index contiguous: row[k0 + g*4 .. +3] and row[k0 + 16 + g*4 .. +3]
+__device__ __forceinline__ uint4 perm_frag(const bf16_t* row, int k0, int g) {
+    const uint2 lo = *reinterpret_cast<const uint2*>(row + k0 + g * 4), hi = *reinterpret_cast<const uint2*>(row + k0 + 16 + g * 4);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// Forward.  A block = 8 waves = 128 queries per step; K and V rows of the (b, head) are staged once (16-byte copies, no transposes) and the block
+// walks query tiles blockIdx.x, blockIdx.x + gridDim.x, ...  (the K/V staging of the one-tile-per-block version cost more than its MFMAs).
 template <int NK>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_k(const bf16_t* __restrict__ q, int ld_q, const bf16_t* __restrict__ kv, int ld_kv, bf16_t* __restrict__ out, int ld_o,
+__global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict__ q, int ld_q, const bf16_t* __restrict__ kv, int ld_kv, bf16_t* __restrict__ out, int ld_o,
                                                        float* __restrict__ lse, int Nq, int Nkv, int heads, float scale) {
-    constexpr int NP = NK * 64, NT = NP / 16, KR = 72, VR = NP + 8;
+    constexpr int NP = NK * 64, NT = NP / 16, KR = 72, PR = NP + 8;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    bf16_t* Ks = smem;                    // [NP][KR]   key rows (d contiguous)            -> B operand of S = Q K^T
-    bf16_t* Vt = Ks + NP * KR;            // [64][VR]   V transposed (keys contiguous)     -> B operand of O = P V
-    bf16_t* Ps = Vt + 64 * VR;            // [4 waves][16][VR] probabilities               -> A operand of O = P V
+    bf16_t* Ks = smem;                    // [NP][KR]   key rows                   -> B operand of S = Q K^T (lane = key, 16 bytes of d)
+    bf16_t* Vs = Ks + NP * KR;            // [NP][ATR]  value rows                 -> B operand of O = P V through tr_frag (contraction = keys)
+    bf16_t* Ps = Vs + NP * ATR;           // [8 waves][16][PR] probabilities       -> A operand of O = P V (perm_frag)
     const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
     const bf16_t* kvb = kv + (size_t)b * Nkv * ld_kv;
-    for (int i = threadIdx.x; i < NP * 8; i += 256) {                 // K rows: 8 x 16-byte chunks per key
+    for (int i = threadIdx.x; i < NP * 8; i += 512) {
         const int key = i >> 3, ch = i & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < Nkv) v = *reinterpret_cast<const uint4*>(kvb + (size_t)key * ld_kv + h * 64 + ch * 8);
-        *reinterpret_cast<uint4*>(Ks + key * KR + ch * 8) = v;
-    }
-    for (int i = threadIdx.x; i < NP * 64; i += 256) {                // V transposed
-        const int key = i >> 6, d = i & 63;
-        Vt[d * VR + key] = key < Nkv ? kvb[(size_t)key * ld_kv + heads * 64 + h * 64 + d] : (bf16_t)0;
+        uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
+        if (key < Nkv) { kk = *reinterpret_cast<const uint4*>(kvb + (size_t)key * ld_kv + h * 64 + ch * 8);
+                         vv = *reinterpret_cast<const uint4*>(kvb + (size_t)key * ld_kv + heads * 64 + h * 64 + ch * 8); }
+        *reinterpret_cast<uint4*>(Ks + key * KR + ch * 8) = kk;
+        *reinterpret_cast<uint4*>(Vs + key * ATR + ch * 8) = vv;
     }
     __syncthreads();
-    const int q0 = blockIdx.x * 64 + wid * 16;
-    const int qa = min(q0 + l15, Nq - 1);                             // A-operand row of this lane
-    const bf16_t* qp = q + ((size_t)b * Nq + qa) * ld_q + h * 64 + g * 8;
-    const uint4 aq0 = *reinterpret_cast<const uint4*>(qp), aq1 = *reinterpret_cast<const uint4*>(qp + 32);
-    f32x4v s[NT];
+    bf16_t* pw = Ps + wid * 16 * PR;
+    const int ntile = (Nq + 127) / 128;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int q0 = tile * 128 + wid * 16;
+        const int qa = min(q0 + l15, Nq - 1);                             // A-operand row of this lane
+        const bf16_t* qp = q + ((size_t)b * Nq + qa) * ld_q + h * 64 + g * 8;
+        const uint4 aq0 = *reinterpret_cast<const uint4*>(qp), aq1 = *reinterpret_cast<const uint4*>(qp + 32);
+        f32x4v s[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const bf16_t* kp = Ks + (nt * 16 + l15) * KR + g * 8;
-        f32x4v c = {0.f, 0.f, 0.f, 0.f};
-        c = mfma16(aq0, *reinterpret_cast<const uint4*>(kp), c);
-        c = mfma16(aq1, *reinterpret_cast<const uint4*>(kp + 32), c);
-        s[nt] = c;
-    }
-    float mx[4], sum[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { const float v = (nt * 16 + l15 < Nkv) ? s[nt][r] * scale : -INFINITY; s[nt][r] = v; m = fmaxf(m, v); }
-        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
-        float t = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { const float p = __expf(s[nt][r] - m); s[nt][r] = p; t += p; }
-        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-        mx[r] = m; sum[r] = t;
-    }
-    bf16_t* pw = Ps + wid * 16 * VR;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pw[(g * 4 + r) * VR + nt * 16 + l15] = f2bf(s[nt][r]);
-    __syncthreads();
-    f32x4v o[4];
-#pragma unroll
-    for (int nd = 0; nd < 4; ++nd) o[nd] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < NP / 32; ++ks) {
-        const uint4 ap = *reinterpret_cast<const uint4*>(pw + l15 * VR + ks * 32 + g * 8);
-#pragma unroll
-        for (int nd = 0; nd < 4; ++nd) o[nd] = mfma16(ap, *reinterpret_cast<const uint4*>(Vt + (nd * 16 + l15) * VR + ks * 32 + g * 8), o[nd]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + g * 4 + r;
-        if (qi < Nq) {
-            const float inv = 1.f / sum[r];
-            bf16_t* op = out + ((size_t)b * Nq + qi) * ld_o + h * 64 + l15;
-#pragma unroll
-            for (int nd = 0; nd < 4; ++nd) op[nd * 16] = f2bf(o[nd][r] * inv);
-            if (l15 == 0) lse[((size_t)b * heads + h) * Nq + qi] = mx[r] + __logf(sum[r]);
+        for (int nt = 0; nt < NT; ++nt) {
+            const bf16_t* kp = Ks + (nt * 16 + l15) * KR + g * 8;
+            f32x4v c = {0.f, 0.f, 0.f, 0.f};
+            c = mfma16(aq0, *reinterpret_cast<const uint4*>(kp), c);
+            c = mfma16(aq1, *reinterpret_cast<const uint4*>(kp + 32), c);
+            s[nt] = c;
         }
+        float mx[4], sum[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { const float v = (nt * 16 + l15 < Nkv) ? s[nt][r] * scale : -INFINITY; s[nt][r] = v; m = fmaxf(m, v); }
+            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
+            float t = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { const float p = __expf(s[nt][r] - m); s[nt][r] = p; t += p; }
+            t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+            mx[r] = m; sum[r] = t;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pw[(g * 4 + r) * PR + nt * 16 + l15] = f2bf(s[nt][r]);
+        __syncthreads();                                                  // (every wave walks the same number of tiles)
+        f32x4v o[4];
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) o[nd] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NP / 32; ++ks) {
+            const uint4 ap = perm_frag(pw + l15 * PR, ks * 32, g);
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) o[nd] = mfma16(ap, tr_frag(Vs + ks * 32 * ATR, nd * 16, lane), o[nd]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + g * 4 + r;
+            if (qi < Nq) {
+                const float inv = 1.f / sum[r];
+                bf16_t* op = out + ((size_t)b * Nq + qi) * ld_o + h * 64 + l15;
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) op[nd * 16] = f2bf(o[nd][r] * inv);
+                if (l15 == 0) lse[((size_t)b * heads + h) * Nq + qi] = mx[r] + __logf(sum[r]);
+            }
+        }
+        __syncthreads();                                                  // the next tile's probabilities overwrite Ps
     }
 }
 
@@ -719,121 +742,129 @@ __global__ __launch_bounds__(256) void attn_delta_k(const T* __restrict__ dout, 
     if (lane == 0) { const size_t b = bq / Nq, qi = bq % Nq; delta[(b * heads + h) * Nq + qi] = v; }
 }
 
-// backward for the keys [key0, key0 + NKB*64) of one (b, head) and one 64-query tile:
+// backward for the keys [key0, key0 + NKB*64) of one (b, head); the block walks 64-query tiles blockIdx.x, blockIdx.x + gridDim.x, ...:
 //   S = Q K^T, dP = dO V^T (MFMA) -> P = exp(S scale - lse), dS = P (dP - delta) scale
-//   dQ (+)= dS K ; partial dK = dS^T Q, dV = P^T dO  (fp32 [2][NPT][64] per query tile, summed by attn_bwd_kv_reduce_k)
+//   dQ (+)= dS K ; dK += dS^T Q, dV += P^T dO accumulate in registers over the tiles of the block and leave as ONE fp32 partial [2][NPT][64]
+//   per block (summed by attn_bwd_kv_reduce_k).  K, V, Q and dO tiles are staged row-major with 16-byte copies; every product whose contraction
+//   runs over tile rows (keys for dQ, queries for dK / dV) reads its B operand with the transposing LDS read (tr_frag), so nothing is transposed.
 template <int NKB>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_k(const bf16_t* __restrict__ q, int ld_q, const bf16_t* __restrict__ kv, int ld_kv, const bf16_t* __restrict__ dout, int ld_do,
                                                        const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dq, int ld_dq, float* __restrict__ part,
                                                        int Nq, int Nkv, int heads, float scale, int key0, int NPT, int dq_acc) {
-    constexpr int NP = NKB * 64, NT = NP / 16, KR = 72, TR = NP + 8;
+    constexpr int NP = NKB * 64, NT = NP / 16, KR = 72, TR = NP + 8, NKT = NT / 4;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    bf16_t* Ks = smem;                    // [NP][KR]  K rows
-    bf16_t* Vs = Ks + NP * KR;            // [NP][KR]  V rows
-    bf16_t* Kt = Vs + NP * KR;            // [64][TR]  K transposed
-    bf16_t* Qt = Kt + 64 * TR;            // [64][KR]  Q tile transposed  [d][q]
-    bf16_t* Gt = Qt + 64 * KR;            // [64][KR]  dO tile transposed [d][q]
-    bf16_t* Sa = Gt + 64 * KR;            // [4][16][TR] dS, A layout per wave
-    bf16_t* St = Sa + 64 * TR;            // [NP][KR]  dS transposed [key][q]
+    bf16_t* Ks = smem;                    // [NP][ATR] K rows: B of S = Q K^T (16-byte reads) and of dQ = dS K (tr_frag, contraction = keys)
+    bf16_t* Vs = Ks + NP * ATR;           // [NP][KR]  V rows: B of dP = dO V^T
+    bf16_t* Qs = Vs + NP * KR;            // [64][ATR] Q tile  [q][d]: A of S, B of dK (tr_frag, contraction = queries)
+    bf16_t* Gs = Qs + 64 * ATR;           // [64][ATR] dO tile [q][d]: A of dP, B of dV
+    bf16_t* Sa = Gs + 64 * ATR;           // [4][16][TR] dS, A layout per wave (perm_frag over keys)
+    bf16_t* St = Sa + 64 * TR;            // [NP][KR]  dS transposed [key][q]  (perm_frag over queries)
     bf16_t* Pt = St + NP * KR;            // [NP][KR]  P transposed  [key][q]
     const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
     const bf16_t* kvb = kv + (size_t)b * Nkv * ld_kv;
-    const int qt0 = blockIdx.x * 64;
     for (int i = threadIdx.x; i < NP * 8; i += 256) {
         const int kl = i >> 3, ch = i & 7, key = key0 + kl;
         uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
         if (key < Nkv) { kk = *reinterpret_cast<const uint4*>(kvb + (size_t)key * ld_kv + h * 64 + ch * 8);
                          vv = *reinterpret_cast<const uint4*>(kvb + (size_t)key * ld_kv + heads * 64 + h * 64 + ch * 8); }
-        *reinterpret_cast<uint4*>(Ks + kl * KR + ch * 8) = kk;
+        *reinterpret_cast<uint4*>(Ks + kl * ATR + ch * 8) = kk;
         *reinterpret_cast<uint4*>(Vs + kl * KR + ch * 8) = vv;
     }
-    for (int i = threadIdx.x; i < NP * 64; i += 256) {
-        const int kl = i >> 6, d = i & 63, key = key0 + kl;
-        Kt[d * TR + kl] = key < Nkv ? kvb[(size_t)key * ld_kv + h * 64 + d] : (bf16_t)0;
-    }
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int ql = i >> 6, d = i & 63, qi = qt0 + ql;
-        const bool ok = qi < Nq;
-        const size_t ro = (size_t)b * Nq + (ok ? qi : Nq - 1);
-        Qt[d * KR + ql] = ok ? q[ro * ld_q + h * 64 + d] : (bf16_t)0;
-        Gt[d * KR + ql] = ok ? dout[ro * ld_do + h * 64 + d] : (bf16_t)0;
-    }
-    __syncthreads();
-    const int q0 = qt0 + wid * 16;
-    const size_t ra = (size_t)b * Nq + min(q0 + l15, Nq - 1);
-    const bf16_t* qp = q + ra * ld_q + h * 64 + g * 8; const bf16_t* gp = dout + ra * ld_do + h * 64 + g * 8;
-    const uint4 aq0 = *reinterpret_cast<const uint4*>(qp), aq1 = *reinterpret_cast<const uint4*>(qp + 32);
-    const uint4 ag0 = *reinterpret_cast<const uint4*>(gp), ag1 = *reinterpret_cast<const uint4*>(gp + 32);
-    float L[4], D[4]; bool rok[4];
+    f32x4v ak[NKT][4], av[NKT][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + g * 4 + r;
-        rok[r] = qi < Nq;
-        const size_t li = ((size_t)b * heads + h) * Nq + (rok[r] ? qi : Nq - 1);
-        L[r] = lse[li]; D[r] = delta[li];
-    }
+    for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) { ak[i][nd] = f32x4v{0.f, 0.f, 0.f, 0.f}; av[i][nd] = ak[i][nd]; }
     bf16_t* sa = Sa + wid * 16 * TR;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const bf16_t* kp = Ks + (nt * 16 + l15) * KR + g * 8; const bf16_t* vp = Vs + (nt * 16 + l15) * KR + g * 8;
-        f32x4v s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = mfma16(aq0, *reinterpret_cast<const uint4*>(kp), s); s = mfma16(aq1, *reinterpret_cast<const uint4*>(kp + 32), s);
-        dp = mfma16(ag0, *reinterpret_cast<const uint4*>(vp), dp); dp = mfma16(ag1, *reinterpret_cast<const uint4*>(vp + 32), dp);
-        const bool kok = key0 + nt * 16 + l15 < Nkv;
-        bf16_t pb[4], sb[4];
+    const int ntile = (Nq + 63) / 64;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int qt0 = tile * 64;
+        __syncthreads();                                                  // the previous tile's readers of Qs / Gs / St / Pt are done (and K / V are in)
+        for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+            const int ql = i >> 3, ch = i & 7, qi = qt0 + ql;
+            uint4 qq = make_uint4(0, 0, 0, 0), gg = qq;
+            if (qi < Nq) { qq = *reinterpret_cast<const uint4*>(q + ((size_t)b * Nq + qi) * ld_q + h * 64 + ch * 8);
+                           gg = *reinterpret_cast<const uint4*>(dout + ((size_t)b * Nq + qi) * ld_do + h * 64 + ch * 8); }
+            *reinterpret_cast<uint4*>(Qs + ql * ATR + ch * 8) = qq;
+            *reinterpret_cast<uint4*>(Gs + ql * ATR + ch * 8) = gg;
+        }
+        const int q0 = qt0 + wid * 16;
+        float L[4], D[4]; bool rok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float p = (kok && rok[r]) ? __expf(s[r] * scale - L[r]) : 0.f;
-            const float ds = p * (dp[r] - D[r]) * scale;
-            pb[r] = f2bf(p); sb[r] = f2bf(ds);
-            sa[(g * 4 + r) * TR + nt * 16 + l15] = sb[r];
+            const int qi = q0 + g * 4 + r;
+            rok[r] = qi < Nq;
+            const size_t li = ((size_t)b * heads + h) * Nq + (rok[r] ? qi : Nq - 1);
+            L[r] = lse[li]; D[r] = delta[li];
         }
-        // transposed tiles [key][query]: 4 consecutive queries of this lane -> one 8-byte store each
-        const int key = nt * 16 + l15, qc = wid * 16 + g * 4;
-        *reinterpret_cast<uint2*>(St + key * KR + qc) = make_uint2((unsigned)sb[0] | ((unsigned)sb[1] << 16), (unsigned)sb[2] | ((unsigned)sb[3] << 16));
-        *reinterpret_cast<uint2*>(Pt + key * KR + qc) = make_uint2((unsigned)pb[0] | ((unsigned)pb[1] << 16), (unsigned)pb[2] | ((unsigned)pb[3] << 16));
-    }
-    __syncthreads();
-    // dQ = dS K  (this wave's 16 queries x 64 dims)
-    f32x4v dqa[4];
+        __syncthreads();
+        const bf16_t* qrow = Qs + (wid * 16 + l15) * ATR + g * 8; const bf16_t* grow = Gs + (wid * 16 + l15) * ATR + g * 8;
+        const uint4 aq0 = *reinterpret_cast<const uint4*>(qrow), aq1 = *reinterpret_cast<const uint4*>(qrow + 32);
+        const uint4 ag0 = *reinterpret_cast<const uint4*>(grow), ag1 = *reinterpret_cast<const uint4*>(grow + 32);
 #pragma unroll
-    for (int nd = 0; nd < 4; ++nd) dqa[nd] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) {
+            const bf16_t* kp = Ks + (nt * 16 + l15) * ATR + g * 8; const bf16_t* vp = Vs + (nt * 16 + l15) * KR + g * 8;
+            f32x4v s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = mfma16(aq0, *reinterpret_cast<const uint4*>(kp), s); s = mfma16(aq1, *reinterpret_cast<const uint4*>(kp + 32), s);
+            dp = mfma16(ag0, *reinterpret_cast<const uint4*>(vp), dp); dp = mfma16(ag1, *reinterpret_cast<const uint4*>(vp + 32), dp);
+            const bool kok = key0 + nt * 16 + l15 < Nkv;
+            bf16_t pb[4], sb[4];
 #pragma unroll
-    for (int ks = 0; ks < NP / 32; ++ks) {
-        const uint4 a = *reinterpret_cast<const uint4*>(sa + l15 * TR + ks * 32 + g * 8);
-#pragma unroll
-        for (int nd = 0; nd < 4; ++nd) dqa[nd] = mfma16(a, *reinterpret_cast<const uint4*>(Kt + (nd * 16 + l15) * TR + ks * 32 + g * 8), dqa[nd]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (rok[r]) {
-            bf16_t* dp_ = dq + ((size_t)b * Nq + q0 + g * 4 + r) * ld_dq + h * 64 + l15;
-#pragma unroll
-            for (int nd = 0; nd < 4; ++nd) dp_[nd * 16] = f2bf(dq_acc ? bf2f(dp_[nd * 16]) + dqa[nd][r] : dqa[nd][r]);
+            for (int r = 0; r < 4; ++r) {
+                const float p = (kok && rok[r]) ? __expf(s[r] * scale - L[r]) : 0.f;
+                const float ds = p * (dp[r] - D[r]) * scale;
+                pb[r] = f2bf(p); sb[r] = f2bf(ds);
+                sa[(g * 4 + r) * TR + nt * 16 + l15] = sb[r];
+            }
+            // transposed tiles [key][query]: 4 consecutive queries of this lane -> one 8-byte store each
+            const int key = nt * 16 + l15, qc = wid * 16 + g * 4;
+            *reinterpret_cast<uint2*>(St + key * KR + qc) = make_uint2((unsigned)sb[0] | ((unsigned)sb[1] << 16), (unsigned)sb[2] | ((unsigned)sb[3] << 16));
+            *reinterpret_cast<uint2*>(Pt + key * KR + qc) = make_uint2((unsigned)pb[0] | ((unsigned)pb[1] << 16), (unsigned)pb[2] | ((unsigned)pb[3] << 16));
         }
-    }
-    // dK = dS^T Q, dV = P^T dO : this wave's key tiles (kt = wid, wid + 4, ...), contraction over the 64 queries
-    float* dst = part + ((((size_t)b * heads + h) * gridDim.x + blockIdx.x) * 2) * (size_t)NPT * 64;
+        __syncthreads();
+        // dQ = dS K  (this wave's 16 queries x 64 dims, contraction over the keys of this range)
+        f32x4v dqa[4];
 #pragma unroll
-    for (int kt = wid; kt < NT; kt += 4) {
-        f32x4v ak[4], av[4];
+        for (int nd = 0; nd < 4; ++nd) dqa[nd] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd) { ak[nd] = f32x4v{0.f, 0.f, 0.f, 0.f}; av[nd] = ak[nd]; }
+        for (int ks = 0; ks < NP / 32; ++ks) {
+            const uint4 a = perm_frag(sa + l15 * TR, ks * 32, g);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const uint4 as = *reinterpret_cast<const uint4*>(St + (kt * 16 + l15) * KR + ks * 32 + g * 8);
-            const uint4 ap = *reinterpret_cast<const uint4*>(Pt + (kt * 16 + l15) * KR + ks * 32 + g * 8);
+            for (int nd = 0; nd < 4; ++nd) dqa[nd] = mfma16(a, tr_frag(Ks + ks * 32 * ATR, nd * 16, lane), dqa[nd]);
+        }
 #pragma unroll
-            for (int nd = 0; nd < 4; ++nd) {
-                ak[nd] = mfma16(as, *reinterpret_cast<const uint4*>(Qt + (nd * 16 + l15) * KR + ks * 32 + g * 8), ak[nd]);
-                av[nd] = mfma16(ap, *reinterpret_cast<const uint4*>(Gt + (nd * 16 + l15) * KR + ks * 32 + g * 8), av[nd]);
+        for (int r = 0; r < 4; ++r) {
+            if (rok[r]) {
+                bf16_t* dp_ = dq + ((size_t)b * Nq + q0 + g * 4 + r) * ld_dq + h * 64 + l15;
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) dp_[nd * 16] = f2bf(dq_acc ? bf2f(dp_[nd * 16]) + dqa[nd][r] : dqa[nd][r]);
             }
         }
+        // dK += dS^T Q, dV += P^T dO : this wave's key tiles (kt = wid, wid + 4, ...), contraction over the 64 queries of the tile
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) {
+            const int kt = wid + 4 * i;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 as = perm_frag(St + (kt * 16 + l15) * KR, ks * 32, g);
+                const uint4 ap = perm_frag(Pt + (kt * 16 + l15) * KR, ks * 32, g);
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) {
+                    ak[i][nd] = mfma16(as, tr_frag(Qs + ks * 32 * ATR, nd * 16, lane), ak[i][nd]);
+                    av[i][nd] = mfma16(ap, tr_frag(Gs + ks * 32 * ATR, nd * 16, lane), av[i][nd]);
+                }
+            }
+        }
+    }
+    float* dst = part + ((((size_t)b * heads + h) * gridDim.x + blockIdx.x) * 2) * (size_t)NPT * 64;
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {
+        const int kt = wid + 4 * i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const size_t row = (size_t)(key0 + kt * 16 + g * 4 + r) * 64 + l15;
 #pragma unroll
-            for (int nd = 0; nd < 4; ++nd) { dst[row + nd * 16] = ak[nd][r]; dst[(size_t)NPT * 64 + row + nd * 16] = av[nd][r]; }
+            for (int nd = 0; nd < 4; ++nd) { dst[row + nd * 16] = ak[i][nd][r]; dst[(size_t)NPT * 64 + row + nd * 16] = av[i][nd][r]; }
         }
     }
 }
@@ -1017,6 +1048,14 @@ int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, i
 
 static int attn_geom(int Nkv, int heads, int head_dim) { return (head_dim == 64 && Nkv >= 1 && Nkv <= 64 * AT_MAXK && heads >= 1) ? 0 : -2; }
 
+// persistent attention blocks per launch: the blocks of one (b, head) share its K / V and walk the query tiles between them
+static int attn_target_blocks() { static const int v = [] { const char* e = getenv("PN2_ATTN_BLOCKS"); return e ? atoi(e) : 512; }(); return v; }
+static int attn_bwd_gx(int B, int heads, int Nq) {
+    const int ntile = (Nq + 63) / 64;
+    int gx = (attn_target_blocks() + B * heads - 1) / (B * heads);
+    return gx > ntile ? ntile : (gx < 1 ? 1 : gx);
+}
+
 int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, void* out, int ld_o, float* lse, int B, int Nq, int Nkv, int heads, int head_dim,
                  float scale, void* stream) {
     if (!q || !kv || !out || !lse) return -1;
@@ -1031,12 +1070,15 @@ int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, voi
         hipLaunchKernelGGL((attn_fwd_k<T, NKV>), grid, dim3(256), lds, st, (const T*)q, ld_q, (const T*)kv, ld_kv, (T*)out, ld_o, lse, Nq, Nkv, heads, scale, qpb); }
     static const bool use_mfma = [] { const char* e = getenv("PN2_ATTN_MFMA"); return !(e && e[0] == '0'); }();
     if (dt == PN2_BF16 && use_mfma && (ld_q % 8) == 0 && (ld_kv % 8) == 0 && (ld_o % 8) == 0) {
-        const size_t lm = ((size_t)NP * 72 + 64 * (NP + 8) + 4 * 16 * (NP + 8)) * 2;
-        const dim3 gm((Nq + 63) / 64, heads, B);
+        const int NPK = NK == 3 ? 256 : NP;                        // 129..192 keys run the 256-key instantiation (zero-padded keys are masked)
+        const size_t lm = ((size_t)NPK * 72 + (size_t)NPK * ATR + 8 * 16 * (NPK + 8)) * 2;
+        const int ntile = (Nq + 127) / 128;
+        int gx = (attn_target_blocks() + B * heads - 1) / (B * heads); if (gx > ntile) gx = ntile; if (gx < 1) gx = 1;
+        const dim3 gm(gx, heads, B);
 #define PN2_ATTN_FWD_M(NKV) { if (lm > 64 * 1024) { static bool done = false; if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_k<NKV>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); done = true; } } \
-        hipLaunchKernelGGL((attn_fwd_mfma_k<NKV>), gm, dim3(256), lm, st, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, (bf16_t*)out, ld_o, lse, Nq, Nkv, heads, scale); }
-        if (NK == 1) PN2_ATTN_FWD_M(1) else if (NK == 2) PN2_ATTN_FWD_M(2) else if (NK == 3) PN2_ATTN_FWD_M(3) else PN2_ATTN_FWD_M(4)
+        hipLaunchKernelGGL((attn_fwd_mfma_k<NKV>), gm, dim3(512), lm, st, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, (bf16_t*)out, ld_o, lse, Nq, Nkv, heads, scale); }
+        if (NK == 1) PN2_ATTN_FWD_M(1) else if (NK == 2) PN2_ATTN_FWD_M(2) else PN2_ATTN_FWD_M(4)
 #undef PN2_ATTN_FWD_M
         PN2_CHECK_LAUNCH();
         return 0;
@@ -1052,7 +1094,10 @@ static bool attn_use_mfma(int dt, int ld_a, int ld_b) {
     return on && dt == PN2_BF16 && (ld_a % 8) == 0 && (ld_b % 8) == 0;
 }
 
-int pn2_attn_bwd_blocks(int dt, int Nq) { return Nq < 1 ? -1 : (dt == PN2_BF16 ? (Nq + 63) / 64 : (Nq + AT_QCHUNK - 1) / AT_QCHUNK); }
+int pn2_attn_bwd_blocks(int dt, int B, int heads, int Nq) {
+    if (Nq < 1 || B < 1 || heads < 1) return -1;
+    return dt == PN2_BF16 ? attn_bwd_gx(B, heads, Nq) : (Nq + AT_QCHUNK - 1) / AT_QCHUNK;
+}
 
 int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, const void* out, int ld_o, const void* dout, int ld_do, const float* lse, void* dq, int ld_dq,
                  void* dkv, int ld_dkv, float* partial, float* delta, int B, int Nq, int Nkv, int heads, int head_dim, float scale, void* stream) {
@@ -1061,13 +1106,13 @@ int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, con
     const int NK = (Nkv + 63) / 64, NP = NK * 64;
     hipStream_t st = (hipStream_t)stream;
     if (attn_use_mfma(dt, ld_q, ld_kv) && (ld_do % 8) == 0 && (ld_dq % 8) == 0) {
-        const int nqt = (Nq + 63) / 64;
+        const int nqt = attn_bwd_gx(B, heads, Nq);                   // persistent blocks (= partial slots) per (b, head)
         hipLaunchKernelGGL(attn_delta_k<bf16_t>, dim3((unsigned)(((size_t)B * Nq * heads + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dout, ld_do, (const bf16_t*)out, ld_o, delta, B, Nq, heads);
         const dim3 grid(nqt, heads, B);
         for (int key0 = 0; key0 < NP; key0 += 128) {
             const int nkb = NP - key0 >= 128 ? 2 : 1;
             const int np = nkb * 64;
-            const size_t lm = ((size_t)3 * np * 72 + 64 * (np + 8) + 2 * 64 * 72 + 64 * (np + 8) + np * 72) * 2;
+            const size_t lm = ((size_t)np * ATR + (size_t)np * 72 + 2 * 64 * ATR + 64 * (np + 8) + 2 * (size_t)np * 72) * 2;
             if (nkb == 2) {
                 static bool done = false;
                 if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); done = true; }

@@ -1013,7 +1013,7 @@ class Engine:
             st = _stream()
             do = o.grad_buf()
             assert o.grad_written and do.stride(2) == Cc and not q.grad_written and not kv.grad_written
-            part = self.fbuf(B, heads, call.pn2_attn_bwd_blocks(self.dt, Nq), 2, rup(Nkv, 64), 64)
+            part = self.fbuf(B, heads, call.pn2_attn_bwd_blocks(self.dt, B, heads, Nq), 2, rup(Nkv, 64), 64)
             delta = self.fbuf(B, heads, Nq)
             gq, _ = q.grad_sink()
             gkv, _ = kv.grad_sink()

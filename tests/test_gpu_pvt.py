@@ -98,9 +98,9 @@ def test_dwconv_gelu(dtn):
 
 
 @pytest.mark.parametrize("dtn", ["fp32", "bf16"])
-@pytest.mark.parametrize("cfg", [(1, 12, 12, 3, 3), (2, 6, 6, 3, 3), (5, 4, 5, 11, 11), (8, 3, 3, 3, 3), (2, 16, 16, 14, 14)])
+@pytest.mark.parametrize("cfg", [(1, 12, 12, 3, 3), (2, 6, 6, 3, 3), (5, 4, 5, 11, 11), (8, 3, 3, 3, 3), (2, 16, 16, 14, 14), (1, 20, 13, 13, 12), (2, 9, 30, 16, 16)])
 def test_attention(dtn, cfg):
-    """q [B, Nq, heads*64] against kv [B, Nkv, 2*heads*64] (k then v, heads inner), softmax over Nkv (1..196 keys)."""
+    """q [B, Nq, heads*64] against kv [B, Nkv, 2*heads*64] (k then v, heads inner), softmax over Nkv (9..256 keys: every 64-key bucket, several query tiles per block)."""
     from pn2 import F32, BF16
     from pn2.engine import Engine
     from pn2.graph import _seed_grad
