@@ -225,11 +225,12 @@ int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, con
 
 /* ---------------------------------------------------------------------------------------------- EMCAD decoder (multiclass_seg/EMCAD/lib/decoders.py)
  * Memory-bound pieces of config 5; the 1x1 / 3x3 / 7x7 convs are pn2_conv_*, BatchNorm is pn2_bn_* fed by the partial rows below.          */
-int pn2_dwconv_blocks(int dt, int M, int C);
-/* depth-wise K x K conv, pad K/2, stride 1, no bias: z (+)= dw(x); flip = mirrored kernel (data gradient).  psum/psq non-null:
- * per-block partial sums of z, z^2 as [pn2_dwconv_blocks(dt, N*H*W, C)][C] rows for pn2_bn_finalize */
+/* rows of the BatchNorm partial buffers of pn2_dwconv (wgrad = 0) / of the partial buffer of pn2_dwconv_wgrad (wgrad = 1) */
+int pn2_dwconv_blocks(int dt, int N, int H, int W, int C, int K, int wgrad);
+/* depth-wise K x K conv (K = 1, 3, 5), pad K/2, stride 1, no bias: z (+)= dw(x); flip = mirrored kernel (data gradient).  psum/psq non-null:
+ * per-block partial sums of z, z^2 as [pn2_dwconv_blocks(dt, N, H, W, C, K, 0)][C] rows for pn2_bn_finalize */
 int pn2_dwconv(int dt, const void* x, const float* w, void* z, int N, int H, int W, int C, int K, int flip, int accumulate, float* psum, float* psq, void* stream);
-/* partial[pn2_dwconv_blocks][C*K*K] of the depth-wise weight gradient; finish with pn2_colsum_finalize(partial, nblk, C*K*K, C*K*K, dW, acc) */
+/* partial[pn2_dwconv_blocks(.., 1)][C*K*K] of the depth-wise weight gradient; finish with pn2_colsum_finalize(partial, nblk, C*K*K, C*K*K, dW, acc) */
 int pn2_dwconv_wgrad(int dt, const void* dz, const void* x, float* partial, int N, int H, int W, int C, int K, void* stream);
 int pn2_pairconv_blocks(int M, int F);
 /* grouped 3x3 conv, groups = F, 2 input channels per group (LGAG.W_g / W_x), pad 1, bias-free here (the bias is folded by the caller):

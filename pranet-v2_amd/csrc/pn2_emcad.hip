@@ -9,6 +9,7 @@
 // All element-wise / memory-bound; BatchNorm statistics come out of the producing kernel as per-block partial rows, like the conv
 // epilogue of pn2_conv.hip, so pn2_bn_finalize / pn2_affine_act / pn2_bn_bwd_* are reused unchanged.  Deterministic (no atomics).
 #include "pn2_common.h"
+#include "pn2_dw.h"
 #include "../../include/pn2.h"
 
 namespace {
@@ -47,107 +48,148 @@ __device__ __forceinline__ void block_colsum(float* sh, const float* a, int CVP,
 
 // ------------------------------------------------------------------------------------------ depth-wise K x K
 // z[p][c] = sum_taps w[c][tap] x[p + tap][c]; optional per-block partial sums of z and z^2 (BatchNorm batch statistics).
-// flip: mirrored kernel = data gradient.  The thread's K*K x VEC weights stay in registers.
-template <typename T, int K>
-__global__ __launch_bounds__(256) void dwconv_k(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ z, int N, int H, int W, int C, int flip, int accumulate,
-                                                float* __restrict__ psum, float* __restrict__ psq, int pix_per_blk, int CVP) {
-    constexpr int V = TT<T>::VEC, KK = K * K, PD = K / 2;
-    extern __shared__ float sh[];
-    const int CV = C / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
-    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
-    for (int cvb = 0; cvb < CV; cvb += CVP) {
-        const int cv = cvb + cvl;
-        const bool act = cv < CV;
-        float wr[KK][V], s1[V], s2[V];
+// flip: mirrored kernel = data gradient.  Sliding window (as the 3x3 + GELU kernels of pn2_vit.hip): a thread owns VT channels, keeps their
+// K*K weights and the K x K input window (packed) in registers and walks row segments of SEG output pixels - K new loads per output pixel
+// instead of K*K.  A block = CVP channel groups x R lanes; a lane walks the segments bid*SPB + rl, + R, ... of the block's range.
+template <typename T, int K, int VT>
+__device__ __forceinline__ void dwk_load_col(const T* base, const bool (&vy)[K], int ix, int W, int C, DwVec<T, VT> (&col)[K]) {
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            s1[e] = 0.f; s2[e] = 0.f;
-#pragma unroll
-            for (int t = 0; t < KK; ++t) wr[t][e] = act ? w[(cv * V + e) * KK + (flip ? KK - 1 - t : t)] : 0.f;
-        }
-        if (act) {
-            for (int m = p0 + rl; m < p1; m += R) {
-                const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
-                float a[V];
-#pragma unroll
-                for (int e = 0; e < V; ++e) a[e] = 0.f;
-#pragma unroll
-                for (int t = 0; t < KK; ++t) {
-                    const int iy = oy + t / K - PD, ix = ox + t % K - PD;
-                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                        float xv[V];
-                        ldv<T>(x + (((size_t)n * H + iy) * W + ix) * C + cv * V, xv);
-#pragma unroll
-                        for (int e = 0; e < V; ++e) a[e] += wr[t][e] * xv[e];
-                    }
-                }
-                const size_t o = (size_t)m * C + cv * V;
-                if (accumulate) { float old[V]; ldv<T>(z + o, old);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) a[e] += old[e]; }
-                stv<T>(z + o, a);
-                if (psum) {       // statistics of the values as stored (rounded to T), like the conv epilogue
-                    float zz[V]; const uint4 pk = TT<T>::pack(a); TT<T>::unpack(pk, zz);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) { s1[e] += zz[e]; s2[e] += zz[e] * zz[e]; }
-                }
-            }
-        }
-        if (psum) {
-            block_colsum<V>(sh, s1, CVP, R, cvl, rl, act, psum + (size_t)blockIdx.x * C + cv * V);
-            block_colsum<V>(sh, s2, CVP, R, cvl, rl, act, psq + (size_t)blockIdx.x * C + cv * V);
-        }
+    for (int r = 0; r < K; ++r) {
+        col[r].zero();
+        if (vy[r] && (unsigned)ix < (unsigned)W) col[r].load(base + ((ptrdiff_t)(r - K / 2) * W + ix) * C);
     }
 }
 
-// partial[blk][C*K*K]: [c*KK + tap] = sum_pixels dz[p][c] * x[p + tap][c]   (taps processed in passes of <= 9 to bound registers)
-template <typename T, int K>
-__global__ __launch_bounds__(256) void dwconv_wgrad_k(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ partial, int N, int H, int W, int C,
-                                                      int pix_per_blk, int CVP) {
-    constexpr int V = TT<T>::VEC, KK = K * K, PD = K / 2, TP = KK < 9 ? KK : 9;
+template <typename T, int K, int VT>
+__global__ __launch_bounds__(256) void dwconv_row_k(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ z, int N, int H, int W, int C, int flip, int accumulate,
+                                                    float* __restrict__ psum, float* __restrict__ psq, int SEG, int SPR, int SPB, int CVP) {
+    typedef DwVec<T, VT> Vec;
+    constexpr int KK = K * K, PD = K / 2;
     extern __shared__ float sh[];
-    const int CV = C / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
-    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
-    for (int cvb = 0; cvb < CV; cvb += CVP) {
-        const int cv = cvb + cvl;
-        const bool act = cv < CV;
-        for (int t0 = 0; t0 < KK; t0 += TP) {
-            float a[TP][V];
+    const int CV = C / VT, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x), cv = blockIdx.y * CVP + cvl;
+    const bool act = cv < CV;
+    const int nseg = N * H * SPR;
+    float wr[KK][VT], s1[VT], s2[VT];
 #pragma unroll
-            for (int t = 0; t < TP; ++t)
+    for (int e = 0; e < VT; ++e) {
+        s1[e] = 0.f; s2[e] = 0.f;
 #pragma unroll
-                for (int e = 0; e < V; ++e) a[t][e] = 0.f;
-            if (act) {
-                for (int m = p0 + rl; m < p1; m += R) {
-                    const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
-                    float d[V];
-                    ldv<T>(dz + (size_t)m * C + cv * V, d);
+        for (int t = 0; t < KK; ++t) wr[t][e] = act ? w[(size_t)(cv * VT + e) * KK + (flip ? KK - 1 - t : t)] : 0.f;
+    }
+    if (act) {
+        const int send = min(nseg, (bid + 1) * SPB);
+        for (int s = bid * SPB + rl; s < send; s += R) {
+            const int sx = s % SPR, row = s / SPR, oy = row % H;
+            const int x0 = sx * SEG, x1 = min(W, x0 + SEG);
+            bool vy[K];
 #pragma unroll
-                    for (int t = 0; t < TP; ++t) {
-                        const int tt = t0 + t;
-                        const int iy = oy + tt / K - PD, ix = ox + tt % K - PD;
-                        if (tt < KK && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                            float xv[V];
-                            ldv<T>(x + (((size_t)n * H + iy) * W + ix) * C + cv * V, xv);
+            for (int r = 0; r < K; ++r) vy[r] = (unsigned)(oy + r - PD) < (unsigned)H;
+            const T* base = x + ((size_t)row * W) * C + cv * VT;           // pixel (row, 0) of this channel group
+            Vec win[K][K], nx[K];                                         // win[j] = column x0 - PD + j
 #pragma unroll
-                            for (int e = 0; e < V; ++e) a[t][e] += d[e] * xv[e];
-                        }
+            for (int j = 0; j < K; ++j) dwk_load_col<T, K, VT>(base, vy, x0 - PD + j, W, C, win[j]);
+            for (int ox = x0; ox < x1; ++ox) {
+                dwk_load_col<T, K, VT>(base, vy, ox + 1 < x1 ? ox + PD + 1 : -1, W, C, nx);     // the column the next pixel adds
+                float a[VT], xv[VT];
+#pragma unroll
+                for (int e = 0; e < VT; ++e) a[e] = 0.f;
+#pragma unroll
+                for (int r = 0; r < K; ++r)
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        win[j][r].unpack(xv);
+#pragma unroll
+                        for (int e = 0; e < VT; ++e) a[e] += wr[r * K + j][e] * xv[e];
                     }
+                const size_t o = ((size_t)row * W + ox) * C + cv * VT;
+                Vec ov;
+                if (accumulate) {
+                    ov.load(z + o); ov.unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) a[e] += xv[e];
                 }
+                ov.pack(a); ov.store(z + o);
+                if (psum) {       // statistics of the values as stored (rounded to T), like the conv epilogue
+                    ov.unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+                }
+#pragma unroll
+                for (int j = 0; j + 1 < K; ++j)
+#pragma unroll
+                    for (int r = 0; r < K; ++r) win[j][r] = win[j + 1][r];
+#pragma unroll
+                for (int r = 0; r < K; ++r) win[K - 1][r] = nx[r];
             }
+        }
+    }
+    if (psum) {
+        block_colsum<VT>(sh, s1, CVP, R, cvl, rl, act, psum + (size_t)bid * C + cv * VT);
+        block_colsum<VT>(sh, s2, CVP, R, cvl, rl, act, psq + (size_t)bid * C + cv * VT);
+    }
+}
+
+// partial[blk][C*K*K]: [c*KK + tap] = sum_pixels dz[p][c] * x[p + tap][c], same walk
+template <typename T, int K, int VT>
+__global__ __launch_bounds__(256) void dwconv_wgrad_row_k(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ partial, int N, int H, int W, int C,
+                                                          int SEG, int SPR, int SPB, int CVP) {
+    typedef DwVec<T, VT> Vec;
+    constexpr int KK = K * K, PD = K / 2;
+    extern __shared__ float sh[];
+    const int CV = C / VT, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x), cv = blockIdx.y * CVP + cvl;
+    const bool act = cv < CV;
+    const int nseg = N * H * SPR;
+    float a[KK][VT];
 #pragma unroll
-            for (int t = 0; t < TP; ++t) {
-                if (t0 + t < KK) {
-                    float tmp[V];
-                    block_colsum<V>(sh, a[t], CVP, R, cvl, rl, act, tmp);
-                    if (rl == 0 && act) {
+    for (int t = 0; t < KK; ++t)
 #pragma unroll
-                        for (int e = 0; e < V; ++e) partial[(size_t)blockIdx.x * C * KK + (size_t)(cv * V + e) * KK + t0 + t] = tmp[e];
+        for (int e = 0; e < VT; ++e) a[t][e] = 0.f;
+    if (act) {
+        const int send = min(nseg, (bid + 1) * SPB);
+        for (int s = bid * SPB + rl; s < send; s += R) {
+            const int sx = s % SPR, row = s / SPR, oy = row % H;
+            const int x0 = sx * SEG, x1 = min(W, x0 + SEG);
+            bool vy[K];
+#pragma unroll
+            for (int r = 0; r < K; ++r) vy[r] = (unsigned)(oy + r - PD) < (unsigned)H;
+            const size_t o0 = ((size_t)row * W) * C + cv * VT;
+            const T* base = x + o0;
+            Vec win[K][K], nx[K], dn;
+#pragma unroll
+            for (int j = 0; j < K; ++j) dwk_load_col<T, K, VT>(base, vy, x0 - PD + j, W, C, win[j]);
+            dn.load(dz + o0 + (size_t)x0 * C);
+            for (int ox = x0; ox < x1; ++ox) {
+                const Vec dc = dn;
+                dwk_load_col<T, K, VT>(base, vy, ox + 1 < x1 ? ox + PD + 1 : -1, W, C, nx);
+                if (ox + 1 < x1) dn.load(dz + o0 + (size_t)(ox + 1) * C);
+                float d[VT], xv[VT];
+                dc.unpack(d);
+#pragma unroll
+                for (int r = 0; r < K; ++r)
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        win[j][r].unpack(xv);
+#pragma unroll
+                        for (int e = 0; e < VT; ++e) a[r * K + j][e] += d[e] * xv[e];
                     }
-                }
+#pragma unroll
+                for (int j = 0; j + 1 < K; ++j)
+#pragma unroll
+                    for (int r = 0; r < K; ++r) win[j][r] = win[j + 1][r];
+#pragma unroll
+                for (int r = 0; r < K; ++r) win[K - 1][r] = nx[r];
             }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        float tmp[VT];
+        block_colsum<VT>(sh, a[t], CVP, R, cvl, rl, act, tmp);
+        if (rl == 0 && act) {
+#pragma unroll
+            for (int e = 0; e < VT; ++e) partial[(size_t)bid * C * KK + (size_t)(cv * VT + e) * KK + t] = tmp[e];
         }
     }
 }
@@ -674,34 +716,80 @@ __global__ __launch_bounds__(256) void mloss_bwd_k(ml_maps m, const long long* _
 
 extern "C" {
 
-int pn2_dwconv_blocks(int dt, int M, int C) {
-    const int V = dt == PN2_F32 ? 4 : 8;
-    if (M < 1 || C % V) return -1;
-    int cvp, pix, nblk; walk_geometry(M, C / V, cvp, pix, nblk);
-    return nblk;
+// geometry of the K x K depth-wise walks.  kind 0: forward / data gradient, 1: weight gradient.  Channels per thread shrink with the window
+// (registers: K*K weights or accumulators per channel); blocks.x is capped near 1024 because it is also the number of partial rows.
+static int dwk_geometry(int dt, int kind, int N, int H, int W, int C, int K, int& VT, int& SEG, int& SPR, int& SPB, int& cvp, int& gx, int& gy) {
+    const int vmax = dt == PN2_F32 ? 4 : 8;
+    VT = K == 1 ? vmax : (K == 3 ? (kind ? 2 : 4) : 2);
+    if (VT > vmax) VT = vmax;
+    while (VT > 1 && C % VT) VT >>= 1;
+    if (VT * (dt == PN2_F32 ? 4 : 2) < 4) return -2;          // at least one 32-bit word per thread (bf16: even channel counts)
+    const int CV = C / VT;
+    int target = 16;
+    if ((long long)N * H * ((W + 15) / 16) * CV < 200000) target = 8;
+    SPR = (W + target - 1) / target; SEG = (W + SPR - 1) / SPR;
+    const int lanes = (dt == PN2_F32 ? 64 : 128) / VT;        // 256 contiguous bytes of one pixel per block
+    cvp = CV >= lanes ? lanes : pow2ceil(CV);
+    const int R = 256 / cvp, nseg = N * H * SPR;
+    gy = (CV + cvp - 1) / cvp;
+    int want = 2048 / gy; if (want < 1) want = 1; if (want > 1024) want = 1024;
+    SPB = (nseg + want - 1) / want;
+    SPB = ((SPB + R - 1) / R) * R;
+    gx = (nseg + SPB - 1) / SPB;
+    return 0;
 }
 
-/* depth-wise K x K conv, pad K/2, stride 1, no bias: z (+)= dw(x); flip = mirrored kernel (data gradient).  psum/psq non-null:
- * per-block partial sums of z, z^2 as [pn2_dwconv_blocks(dt, N*H*W, C)][C] rows for pn2_bn_finalize */
+/* rows of the BatchNorm partial buffers of pn2_dwconv (wgrad = 0) / of the partial buffer of pn2_dwconv_wgrad (wgrad = 1) */
+int pn2_dwconv_blocks(int dt, int N, int H, int W, int C, int K, int wgrad) {
+    if (N < 1 || H < 1 || W < 1 || (K != 1 && K != 3 && K != 5)) return -1;
+    int VT, SEG, SPR, SPB, cvp, gx, gy;
+    if (dwk_geometry(dt, wgrad ? 1 : 0, N, H, W, C, K, VT, SEG, SPR, SPB, cvp, gx, gy)) return -1;
+    return gx;
+}
+
+#define EM_KV(K_, VT_, BODY) \
+    if ((K_) == 1 && (VT_) == 8) { constexpr int KK_ = 1, VV_ = 8; BODY } else if ((K_) == 1 && (VT_) == 4) { constexpr int KK_ = 1, VV_ = 4; BODY } \
+    else if ((K_) == 1 && (VT_) == 2) { constexpr int KK_ = 1, VV_ = 2; BODY } else if ((K_) == 3 && (VT_) == 4) { constexpr int KK_ = 3, VV_ = 4; BODY } \
+    else if ((K_) == 3 && (VT_) == 2) { constexpr int KK_ = 3, VV_ = 2; BODY } else if ((K_) == 5 && (VT_) == 2) { constexpr int KK_ = 5, VV_ = 2; BODY } \
+    else return -2;
+#define EM_KV32(K_, VT_, BODY) \
+    if ((K_) == 1 && (VT_) == 4) { constexpr int KK_ = 1, VV_ = 4; BODY } else if ((K_) == 1 && (VT_) == 2) { constexpr int KK_ = 1, VV_ = 2; BODY } \
+    else if ((K_) == 1 && (VT_) == 1) { constexpr int KK_ = 1, VV_ = 1; BODY } else if ((K_) == 3 && (VT_) == 4) { constexpr int KK_ = 3, VV_ = 4; BODY } \
+    else if ((K_) == 3 && (VT_) == 2) { constexpr int KK_ = 3, VV_ = 2; BODY } else if ((K_) == 3 && (VT_) == 1) { constexpr int KK_ = 3, VV_ = 1; BODY } \
+    else if ((K_) == 5 && (VT_) == 2) { constexpr int KK_ = 5, VV_ = 2; BODY } else if ((K_) == 5 && (VT_) == 1) { constexpr int KK_ = 5, VV_ = 1; BODY } \
+    else return -2;
+
+/* depth-wise K x K conv (K = 1, 3, 5), pad K/2, stride 1, no bias; flip = data gradient; psum/psq: BatchNorm partial rows
+ * [pn2_dwconv_blocks(dt, N, H, W, C, K, 0)][C] */
 int pn2_dwconv(int dt, const void* x, const float* w, void* z, int N, int H, int W, int C, int K, int flip, int accumulate, float* psum, float* psq, void* stream) {
     if (!x || !w || !z || (psum && !psq)) return -1;
-    const int V = dt == PN2_F32 ? 4 : 8;
-    if (C % V) return -2;
-    int cvp, pix, nblk; walk_geometry(N * H * W, C / V, cvp, pix, nblk);
-    EM_DISPATCH(dt, EM_K(K, { hipLaunchKernelGGL((dwconv_k<T, KK_>), dim3(nblk), dim3(256), 256 * TT<T>::VEC * 4, (hipStream_t)stream, (const T*)x, w, (T*)z, N, H, W, C,
-                                                  flip, accumulate, psum, psq, pix, cvp); }))
+    int VT, SEG, SPR, SPB, cvp, gx, gy;
+    if (dwk_geometry(dt, 0, N, H, W, C, K, VT, SEG, SPR, SPB, cvp, gx, gy)) return -2;
+    const dim3 grid(gx, gy);
+    const size_t lds = (size_t)256 * VT * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16) { EM_KV(K, VT, { hipLaunchKernelGGL((dwconv_row_k<bf16_t, KK_, VV_>), grid, dim3(256), lds, st, (const bf16_t*)x, w, (bf16_t*)z, N, H, W, C, flip, accumulate,
+                                                            psum, psq, SEG, SPR, SPB, cvp); }) }
+    else if (dt == PN2_F32) { EM_KV32(K, VT, { hipLaunchKernelGGL((dwconv_row_k<float, KK_, VV_>), grid, dim3(256), lds, st, (const float*)x, w, (float*)z, N, H, W, C, flip, accumulate,
+                                                                  psum, psq, SEG, SPR, SPB, cvp); }) }
+    else return -3;
     PN2_CHECK_LAUNCH();
     return 0;
 }
 
-/* partial[pn2_dwconv_blocks][C*K*K] of the depth-wise weight gradient; finish with pn2_colsum_finalize(partial, nblk, C*K*K, C*K*K, dW, acc) */
+/* partial[pn2_dwconv_blocks(dt, N, H, W, C, K, 1)][C*K*K] of the depth-wise weight gradient; finish with pn2_colsum_finalize(partial, nblk, C*K*K, C*K*K, dW, acc) */
 int pn2_dwconv_wgrad(int dt, const void* dz, const void* x, float* partial, int N, int H, int W, int C, int K, void* stream) {
     if (!dz || !x || !partial) return -1;
-    const int V = dt == PN2_F32 ? 4 : 8;
-    if (C % V) return -2;
-    int cvp, pix, nblk; walk_geometry(N * H * W, C / V, cvp, pix, nblk);
-    EM_DISPATCH(dt, EM_K(K, { hipLaunchKernelGGL((dwconv_wgrad_k<T, KK_>), dim3(nblk), dim3(256), 256 * TT<T>::VEC * 4, (hipStream_t)stream, (const T*)dz, (const T*)x, partial,
-                                                  N, H, W, C, pix, cvp); }))
+    int VT, SEG, SPR, SPB, cvp, gx, gy;
+    if (dwk_geometry(dt, 1, N, H, W, C, K, VT, SEG, SPR, SPB, cvp, gx, gy)) return -2;
+    const dim3 grid(gx, gy);
+    const size_t lds = (size_t)256 * VT * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16) { EM_KV(K, VT, { hipLaunchKernelGGL((dwconv_wgrad_row_k<bf16_t, KK_, VV_>), grid, dim3(256), lds, st, (const bf16_t*)dz, (const bf16_t*)x, partial,
+                                                            N, H, W, C, SEG, SPR, SPB, cvp); }) }
+    else if (dt == PN2_F32) { EM_KV32(K, VT, { hipLaunchKernelGGL((dwconv_wgrad_row_k<float, KK_, VV_>), grid, dim3(256), lds, st, (const float*)dz, (const float*)x, partial,
+                                                                  N, H, W, C, SEG, SPR, SPB, cvp); }) }
+    else return -3;
     PN2_CHECK_LAUNCH();
     return 0;
 }

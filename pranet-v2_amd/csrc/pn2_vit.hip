@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include "pn2_common.h"
+#include "pn2_dw.h"
 #include "../../include/pn2.h"
 
 namespace {
@@ -217,43 +218,6 @@ __global__ __launch_bounds__(256) void gelu_bwd_k(const T* __restrict__ dy, cons
 // registers — 3 new loads per output pixel instead of 9 (a 9-load walk ran at ~1.5 TB/s, bound by the L1/TA requests in flight).
 // VT = 8 / 4 / 2 channels per thread (16 / 8 / 4-byte loads for bf16): the narrow variants trade load width for 2-4x more waves, which is
 // what the small late-stage tensors need (they are latency-bound, one short segment per thread).
-template <typename T, int VT> struct DwVec {
-    static constexpr int NW = VT * (int)sizeof(T) / 4;          // 32-bit words per packed vector
-    unsigned w[NW];
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int i = 0; i < NW; ++i) w[i] = 0u;
-    }
-    __device__ __forceinline__ void load(const T* p) {
-        if constexpr (NW == 4) { const uint4 v = *reinterpret_cast<const uint4*>(p); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-        else if constexpr (NW == 2) { const uint2 v = *reinterpret_cast<const uint2*>(p); w[0] = v.x; w[1] = v.y; }
-        else { w[0] = *reinterpret_cast<const unsigned*>(p); }
-    }
-    __device__ __forceinline__ void store(T* p) const {
-        if constexpr (NW == 4) *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-        else if constexpr (NW == 2) *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
-        else *reinterpret_cast<unsigned*>(p) = w[0];
-    }
-    __device__ __forceinline__ void unpack(float* f) const {
-        if constexpr (sizeof(T) == 4) {
-#pragma unroll
-            for (int i = 0; i < NW; ++i) f[i] = __uint_as_float(w[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NW; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-        }
-    }
-    __device__ __forceinline__ void pack(const float* f) {
-        if constexpr (sizeof(T) == 4) {
-#pragma unroll
-            for (int i = 0; i < NW; ++i) w[i] = __float_as_uint(f[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NW; ++i) w[i] = TT<bf16_t>::cvt2(f[2 * i], f[2 * i + 1]);
-        }
-    }
-};
-
 template <typename T, int VT>
 __device__ __forceinline__ void dw_load_col(const T* const (&rowp)[3], const bool (&vy)[3], int ix, int W, int C, DwVec<T, VT> (&col)[3]) {
 #pragma unroll

@@ -114,7 +114,7 @@ SIGNATURES = {
     "pn2_attn_fwd": [I, P, I, P, I, P, I, P, I, I, I, I, I, FL, P],
     "pn2_attn_bwd_blocks": [I, I, I, I],
     "pn2_attn_bwd": [I, P, I, P, I, P, I, P, I, P, P, I, P, I, P, P, I, I, I, I, I, FL, P],
-    "pn2_dwconv_blocks": [I, I, I],
+    "pn2_dwconv_blocks": [I, I, I, I, I, I, I],
     "pn2_dwconv": [I, P, P, P, I, I, I, I, I, I, I, P, P, P],
     "pn2_dwconv_wgrad": [I, P, P, P, I, I, I, I, I, P],
     "pn2_pairconv_blocks": [I, I],

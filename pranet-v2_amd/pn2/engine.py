@@ -1091,7 +1091,7 @@ class Engine:
         Cc, K = x.C, conv.kernel_size[0]
         assert x.Cp == Cc and x.ld == Cc and conv.groups == Cc and conv.bias is None and conv.stride == (1, 1) and conv.padding == (K // 2, K // 2)
         N, H, W = x.N, x.H, x.W
-        nblk = call.pn2_dwconv_blocks(self.dt, N * H * W, Cc)
+        nblk = call.pn2_dwconv_blocks(self.dt, N, H, W, Cc, K, 0)
         w = conv.weight
 
         def launch(raw, psum, psq):
@@ -1099,10 +1099,11 @@ class Engine:
 
         def back(draw):
             st = _stream()
-            part = self.fbuf(nblk, Cc * K * K)
+            nbw = call.pn2_dwconv_blocks(self.dt, N, H, W, Cc, K, 1)
+            part = self.fbuf(nbw, Cc * K * K)
             call.pn2_dwconv_wgrad(self.dt, _p(draw), x.ptr, _p(part), N, H, W, Cc, K, st)
             gw, gwa = self.pgrads.sink(w)
-            call.pn2_colsum_finalize(_p(part), nblk, Cc * K * K, Cc * K * K, _p(gw), gwa, st)
+            call.pn2_colsum_finalize(_p(part), nbw, Cc * K * K, Cc * K * K, _p(gw), gwa, st)
             if x.requires_grad:
                 gx, acc = x.grad_sink()
                 assert gx.stride(2) == Cc
