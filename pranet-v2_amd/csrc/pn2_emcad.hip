@@ -540,9 +540,18 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_k(const float* __restrict__ d
 // EMCAD/trainer.py:106-140 (dual, supervision='mutation') with utils/utils.py:102-138 (DiceLoss, softmax=True):
 //   loss = sum over the 15 non-empty subsets s of the 4 scales of
 //          lc1 * CE(sum_{i in s} fg_i, label) + lc2 * Dice(softmax(sum fg_i), onehot(label)) + lc3 * BCEWithLogits(sum_{i in s} bg_i, bg_mask)
+// (hardware exp2 / log2 / rcp: the kernels are ALU-bound - ~300 transcendentals per pixel - and the sums are means over >= 10^6 terms)
 // One pass over the 8 K-channel maps (NHWC fp32): a thread keeps its pixel's 8*K logits in registers and walks the 15 subsets; the per-subset
 // sums (CE, BCE, per-class intersect and sum p^2) are reduced per wave and written as partial rows.  The backward recomputes the softmaxes.
 constexpr int ML_NS = 15;
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a DPP row by rotations (row_ror:8/4/2/1 fold into v_add_f32_dpp - no LDS permutes); every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0x128>(v); v += dpp_f<0x124>(v); v += dpp_f<0x122>(v); v += dpp_f<0x121>(v);
+    return v;
+}
 template <int K> struct MLW { static constexpr int W = 2 + 2 * K; };      // values per subset: CE, BCE, I[K], Z[K]
 
 struct ml_maps { const float* fg[4]; const float* bg[4]; float* dfg[4]; float* dbg[4]; };
@@ -551,8 +560,11 @@ template <int K>
 __global__ __launch_bounds__(256) void mloss_fwd_k(ml_maps m, const long long* __restrict__ label, const float* __restrict__ bgm, size_t NP, size_t HW,
                                                    float* __restrict__ partial) {
     constexpr int W = MLW<K>::W;
-    __shared__ float red[4][ML_NS * W + K];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // per-value sums stop at the 16-lane rows (DPP adds only); the 16 row partials of the block meet in LDS.  A full 64-lane butterfly per value
+    // needs two LDS permutes each, and with ~300 values per pixel their latency was most of this kernel.
+    __shared__ float red[16][ML_NS * W + K];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, rrow = wid * 4 + (lane >> 4);
+    const bool rlead = (lane & 15) == 0;
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool ok = p < NP;
     float f[4][K], b[4][K], mk[K];
@@ -570,8 +582,8 @@ __global__ __launch_bounds__(256) void mloss_fwd_k(ml_maps m, const long long* _
 #pragma unroll
     for (int k = 0; k < K; ++k) {          // label histogram (sum of target^2 per class), once
         float t = (ok && lab == k) ? 1.f : 0.f;
-        t = wave_sum(t);
-        if (lane == 0) red[wid][ML_NS * W + k] = t;
+        t = row16_sum(t);
+        if (rlead) red[rrow][ML_NS * W + k] = t;
     }
 #pragma unroll
     for (int s = 1; s <= ML_NS; ++s) {
@@ -587,8 +599,8 @@ __global__ __launch_bounds__(256) void mloss_fwd_k(ml_maps m, const long long* _
         for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
         float se = 0.f, e[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
-        const float inv = 1.f / se, lse = mx + logf(se);
+        for (int k = 0; k < K; ++k) { e[k] = __expf(z[k] - mx); se += e[k]; }
+        const float inv = __builtin_amdgcn_rcpf(se), lse = mx + __logf(se);
         float ce = 0.f, bce = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -596,19 +608,23 @@ __global__ __launch_bounds__(256) void mloss_fwd_k(ml_maps m, const long long* _
             if (lab == k) ce = lse - z[k];
             v[2 + k] = (lab == k) ? pk : 0.f;
             v[2 + K + k] = pk * pk;
-            bce += fmaxf(zb[k], 0.f) - zb[k] * mk[k] + log1pf(expf(-fabsf(zb[k])));
+            bce += fmaxf(zb[k], 0.f) - zb[k] * mk[k] + __logf(1.f + __expf(-fabsf(zb[k])));
         }
         v[0] = ce; v[1] = bce;
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-            float t = ok ? v[j] : 0.f;
-            t = wave_sum(t);
-            if (lane == 0) red[wid][(s - 1) * W + j] = t;
+        for (int j = 0; j < W; ++j) v[j] = row16_sum(ok ? v[j] : 0.f);
+        if (rlead) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) red[rrow][(s - 1) * W + j] = v[j];
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < ML_NS * W + K; j += 256)
-        partial[(size_t)blockIdx.x * (ML_NS * W + K) + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    for (int j = threadIdx.x; j < ML_NS * W + K; j += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][j];
+        partial[(size_t)blockIdx.x * (ML_NS * W + K) + j] = t;
+    }
 }
 
 // partial rows -> ML_RG group rows in double (every group sums a contiguous range of block rows, 4 independent chains per thread)
@@ -682,8 +698,8 @@ __global__ __launch_bounds__(256) void mloss_bwd_k(ml_maps m, const long long* _
         for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
         float se = 0.f, pr[K], g[K], dot = 0.f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) { pr[k] = expf(z[k] - mx); se += pr[k]; }
-        const float inv = 1.f / se;
+        for (int k = 0; k < K; ++k) { pr[k] = __expf(z[k] - mx); se += pr[k]; }
+        const float inv = __builtin_amdgcn_rcpf(se);
         const float* S = sums + (s - 1) * W;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -696,7 +712,7 @@ __global__ __launch_bounds__(256) void mloss_bwd_k(ml_maps m, const long long* _
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float dz = wce * (pr[k] - (lab == k ? 1.f : 0.f)) + pr[k] * (g[k] - dot);
-            const float sg = 1.f / (1.f + expf(-zb[k])), dzb = wbce * (sg - mk[k]);
+            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-zb[k])), dzb = wbce * (sg - mk[k]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (s >> i & 1) { gf[i][k] += dz; gb[i][k] += dzb; }
         }
