@@ -201,6 +201,11 @@ int pn2_layernorm_bwd(int dt, const void* dy, int ld_dy, const void* x, int ld_x
 int pn2_colsum_unit(int dt, int C);
 int pn2_colsum(int dt, const void* dy, int ld, int M, int C, float* partial, int nblk, void* stream);
 int pn2_colsum_finalize(const float* partial, int nblk, int C, int ld, float* out, int accumulate, void* stream);
+/* many pn2_colsum_finalize in ONE launch from a DEVICE job table (prefix sums of pn2_colsum_finalize_blocks(C) per job): the bias / LayerNorm /
+ * depth-wise parameter-gradient sums of a training step only feed the optimizer, so the backward pass queues them and runs them together */
+typedef struct pn2_colsum_job { const float* partial; float* out; int nblk, C, ld, accumulate; } pn2_colsum_job;
+int pn2_colsum_finalize_blocks(int C);
+int pn2_colsum_finalize_multi(const pn2_colsum_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
 /* DWConv (pvtv2.py:363-374, groups = C, 3x3, pad 1) [+ bias] [+ nn.GELU of Mlp.forward :45]: z = dw(x) + b (kept for the backward),
  * y_gelu = gelu(z) when non-null.  flip=1 correlates with the mirrored kernel = data gradient of the same conv.  w [C][9] fp32. */
 int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z, void* y_gelu, int N, int H, int W, int C, int flip, int accumulate, void* stream);

@@ -70,6 +70,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// job lookup for the table-driven launches: largest j with bstart[j] <= b   (bstart has njobs + 1 entries)
+__device__ __forceinline__ int find_job(const int* __restrict__ bstart, int njobs, int b) {
+    int lo = 0, hi = njobs;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bstart[mid] <= b) lo = mid; else hi = mid; }
+    return lo;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

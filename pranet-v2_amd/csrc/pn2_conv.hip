@@ -466,12 +466,6 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 constexpr int WGP = 32;   // pixels (contraction) per step
 
-// job lookup for the table-driven launches: largest j with bstart[j] <= b   (bstart has njobs + 1 entries)
-__device__ __forceinline__ int find_job(const int* __restrict__ bstart, int njobs, int b) {
-    int lo = 0, hi = njobs;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bstart[mid] <= b) lo = mid; else hi = mid; }
-    return lo;
-}
 
 template <typename T> struct WG;
 template <> struct WG<bf16_t> {

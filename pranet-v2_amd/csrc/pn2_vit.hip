@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, int ld
 }
 
 // out[c] (+)= sum_b p[b*ld + c]   (fixed order; double accumulation).  32 columns x 8 row lanes per block, 4 loads in flight per thread.
-__global__ __launch_bounds__(256) void colsum_finalize_k(const float* __restrict__ p, int nblk, int C, int ld, float* __restrict__ out, int accumulate) {
+__device__ __forceinline__ void colsum_finalize_body(const float* __restrict__ p, int nblk, int C, int ld, float* __restrict__ out, int accumulate, int bloc) {
     __shared__ double sh[8][32];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = bloc * 32 + cl;
     double s = 0.0;
     if (c < C) {
         int r = rl;
@@ -156,6 +156,16 @@ __global__ __launch_bounds__(256) void colsum_finalize_k(const float* __restrict
         for (int k = 0; k < 8; ++k) t += sh[k][cl];
         out[c] = accumulate ? out[c] + (float)t : (float)t;
     }
+}
+__global__ __launch_bounds__(256) void colsum_finalize_k(const float* __restrict__ p, int nblk, int C, int ld, float* __restrict__ out, int accumulate) {
+    colsum_finalize_body(p, nblk, C, ld, out, accumulate, blockIdx.x);
+}
+// many finalisations in one launch, from a device job table (the parameter-gradient sums of a step only feed the optimizer, so the
+// backward pass queues them): block b works on job j = find_job(bstart, b), local block b - bstart[j]
+__global__ __launch_bounds__(256) void colsum_finalize_multi_k(const pn2_colsum_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_colsum_job j = jobs[jb];
+    colsum_finalize_body(j.partial, j.nblk, j.C, j.ld, j.out, j.accumulate, blockIdx.x - bstart[jb]);
 }
 
 // partial[blk][C] = sum over the block's rows of dy[row][c]
@@ -907,6 +917,15 @@ int pn2_ln_slots(int dt, int C) { const int lpr = ln_lpr(dt, C); return lpr < 0 
 int pn2_colsum_finalize(const float* partial, int nblk, int C, int ld, float* out, int accumulate, void* stream) {
     if (!partial || !out || nblk < 1 || C < 1) return -1;
     hipLaunchKernelGGL(colsum_finalize_k, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, ld, out, accumulate);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_colsum_finalize_blocks(int C) { return C < 1 ? -1 : (C + 31) / 32; }
+
+int pn2_colsum_finalize_multi(const pn2_colsum_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    hipLaunchKernelGGL(colsum_finalize_multi_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -216,6 +216,9 @@ class StepArena:
         return torch.empty(shape, dtype=dtype, device=dev)
 
 
+DEFER_COLSUM = os.environ.get("PN2_DEFER_COLSUM", "1") == "1"
+
+
 class GradQueue:
     """Deferred weight-gradient work of one training step.  A conv's wgrad and the split-K slab reduction that follows it only
     feed the optimizer, so the backward pass queues them (dy / x stay alive in the step arena) and `flush()` runs them as a few
@@ -226,6 +229,7 @@ class GradQueue:
         self.defer_wgrad = defer_wgrad
         self.slabs = {}
         self.cache = {}                   # segment index -> (signature, launches)
+        self.ccache = {}                  # same for the engine's queued column-sum finalisations
         self.begin_step()
 
     def begin_step(self):
@@ -314,6 +318,7 @@ class Engine:
         self.training = training
         self.need_grad = need_grad      # decided by the caller (grad mode is off inside autograd.Function.forward)
         self.tape = []
+        self.cjobs, self.ckeep, self.cseg, self.ctables = [], [], 0, []      # queued pn2_colsum_finalize jobs (see colsum_finalize)
         self.pgrads = ParamGrads(grad_provider)
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.bn_modules = []            # for num_batches_tracked bookkeeping
@@ -396,6 +401,7 @@ class Engine:
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        self.flush_colsum()
         self.join_side()
 
     # ------------------------------------------------------------------ lanes: independent sub-graphs on their own HIP streams
@@ -714,9 +720,12 @@ class Engine:
             rg, racc = (None, 0)
             if residual is not None and residual.requires_grad:
                 rg, racc = residual.grad_sink()
-            call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
-                                  _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
-                                  _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), r6, st)
+            if coef is None and ymask is None and rg is None and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) == Cout_p and dy.is_contiguous():
+                draw = dy               # no BN, no activation, no residual (nn.Linear / biased conv): dz IS dy - no copy pass
+            else:
+                call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
+                                      _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
+                                      _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), r6, st)
             if train_bn:
                 bias_done = bias is None
             if not bias_done:                                  # biased conv / nn.Linear: db = column sums of dz (~0 under a train-mode BN)
@@ -909,6 +918,39 @@ class Engine:
         return outs
 
     # ------------------------------------------------------------------ PVTv2 encoder ops (lib/pvtv2.py)
+    def colsum_finalize(self, part, nblk, Cc, ld, out, accumulate):
+        """out[:Cc] (+)= sum of the nblk partial rows.  These sums only feed parameter gradients: they are queued and run as ONE
+        table-driven launch per flush (end of backward / before a gradient bucket leaves), not one launch each."""
+        if not DEFER_COLSUM or self.grad_queue is None:      # (without a persistent queue the job table would be rebuilt and uploaded every step)
+            call.pn2_colsum_finalize(_p(part), nblk, Cc, ld, _p(out), accumulate, _stream())
+            return
+        if accumulate:                  # a second contribution to the same gradient must see the first one finished
+            self.flush_colsum()
+        self.cjobs.append((part.data_ptr(), out.data_ptr(), nblk, Cc, ld, accumulate))
+        self.ckeep.append((part, out))  # the partial rows must not be recycled before the launch is queued
+
+    def flush_colsum(self):
+        if not self.cjobs:
+            return
+        sig = tuple(self.cjobs)
+        cache = self.grad_queue.ccache if self.grad_queue is not None else None
+        hit = cache.get(self.cseg) if cache is not None else None
+        if hit is None or hit[0] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("run two eager steps before capturing (the deferred-launch tables are built then)")
+            arr = []
+            for part, out, nblk, Cc, ld, acc in self.cjobs:
+                j = capi.ColsumJob()
+                j.partial, j.out, j.nblk, j.C, j.ld, j.accumulate = part, out, nblk, Cc, ld, acc
+                arr.append(j)
+            hit = (sig,) + _job_table(capi.ColsumJob, arr, [call.pn2_colsum_finalize_blocks(j.C) for j in arr])
+            if cache is not None:
+                cache[self.cseg] = hit
+        call.pn2_colsum_finalize_multi(_p(hit[1]), _p(hit[2]), len(self.cjobs), hit[3], _stream())
+        self.ctables.append(hit)        # the table must outlive the launch
+        self.cseg += 1
+        self.cjobs, self.ckeep = [], []
+
     def colsum(self, t, M, Cp, Cc, out, accumulate):
         """out[:Cc] (+)= column sums of the [M][Cp] tensor t (bias gradients)."""
         st = _stream()
@@ -916,7 +958,7 @@ class Engine:
         nb = call.pn2_rows_blocks(M, call.pn2_colsum_unit(dt, Cp))
         part = self.fbuf(nb, Cp)
         call.pn2_colsum(dt, _p(t), Cp, M, Cp, _p(part), nb, st)
-        call.pn2_colsum_finalize(_p(part), nb, Cc, Cp, _p(out), accumulate, st)
+        self.colsum_finalize(part, nb, Cc, Cp, out, accumulate)
 
     def linear(self, x, lin, residual=None):
         """nn.Linear (+ residual add) over the channels of NHWC tokens."""
@@ -945,8 +987,8 @@ class Engine:
                                    _p(pg), _p(pb), nb, st)
             gg, ga = self.pgrads.sink(ln.weight)
             gb, gba = self.pgrads.sink(ln.bias)
-            call.pn2_colsum_finalize(_p(pg), nb, Cc, Cc, _p(gg), ga, st)
-            call.pn2_colsum_finalize(_p(pb), nb, Cc, Cc, _p(gb), gba, st)
+            self.colsum_finalize(pg, nb, Cc, Cc, gg, ga)
+            self.colsum_finalize(pb, nb, Cc, Cc, gb, gba)
         self.record(bwd)
         return y
 
@@ -970,8 +1012,8 @@ class Engine:
             call.pn2_dwconv3x3_wgrad(self.dt, _p(dy), x.ptr, _p(part), nb, N, H, W, Cc, _p(z), _p(dz), st)
             gw, gwa = self.pgrads.sink(conv.weight)
             gb, gba = self.pgrads.sink(conv.bias)
-            call.pn2_colsum_finalize(_p(part), nb, Cc * 9, Cc * 10, _p(gw), gwa, st)
-            call.pn2_colsum_finalize(_p(part[:, Cc * 9:]), nb, Cc, Cc * 10, _p(gb), gba, st)
+            self.colsum_finalize(part, nb, Cc * 9, Cc * 10, gw, gwa)
+            self.colsum_finalize(part[:, Cc * 9:], nb, Cc, Cc * 10, gb, gba)
             if x.requires_grad:
                 gx, acc = x.grad_sink()
                 assert gx.stride(2) == Cc
@@ -1103,7 +1145,7 @@ class Engine:
             part = self.fbuf(nbw, Cc * K * K)
             call.pn2_dwconv_wgrad(self.dt, _p(draw), x.ptr, _p(part), N, H, W, Cc, K, st)
             gw, gwa = self.pgrads.sink(w)
-            call.pn2_colsum_finalize(_p(part), nbw, Cc * K * K, Cc * K * K, _p(gw), gwa, st)
+            self.colsum_finalize(part, nbw, Cc * K * K, Cc * K * K, gw, gwa)
             if x.requires_grad:
                 gx, acc = x.grad_sink()
                 assert gx.stride(2) == Cc
@@ -1128,7 +1170,7 @@ class Engine:
             part = self.fbuf(nblk, F_ * 18)
             call.pn2_pairconv3x3_wgrad(self.dt, _p(draw), x.ptr, _p(part), N, H, W, F_, st)
             gw, gwa = self.pgrads.sink(w)
-            call.pn2_colsum_finalize(_p(part), nblk, F_ * 18, F_ * 18, _p(gw), gwa, st)
+            self.colsum_finalize(part, nblk, F_ * 18, F_ * 18, gw, gwa)
             if x.requires_grad:
                 gx, acc = x.grad_sink()
                 assert gx.stride(2) == 2 * F_

@@ -139,6 +139,7 @@ class Trainer:
 
         def grads_complete():       # everything queued / running on the side so far must land before a bucket is sent
             eng.join_side()
+            eng.flush_colsum()
             if rq is not None:
                 rq.flush()
         for fn in reversed(eng.tape):

@@ -156,7 +156,10 @@ def test_emcad_dual_decoder_vs_oracle_fp32():
         if scale < 1e-6:          # conv biases in front of a train-mode BN: analytically zero, other gradients here are O(1e2)
             assert float(g.abs().max()) < 2e-3, k
         else:
-            assert rell2(g, P[k].grad) < max(1e-2, 8 * rell2(P32[k].grad, P[k].grad)), k        # floor: a single ReLU6 mask flip (|x - 6| ~ 1e-6) moves a bias gradient by ~1e-3
+            # floor: a single ReLU6 mask flip (|x - 6| ~ 1e-6) moves a bias gradient by ~1e-3; the one-element BatchNorm of the LGAG psi branch
+            # (one number summed over every pixel behind those flips) moves by up to ~1.5e-2 when only the summation order of the statistics changes
+            floor = 2.5e-2 if p.numel() == 1 else 1e-2
+            assert rell2(g, P[k].grad) < max(floor, 8 * rell2(P32[k].grad, P[k].grad)), k
 
 
 def test_mutation_loss_kernels_vs_reference_formula():
