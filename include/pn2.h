@@ -23,6 +23,7 @@ extern "C" {
 #define PN2_BF16 1
 #define PN2_CONV_STATS 1   /* emit per-channel sum / sum-of-squares partials (fused BN batch statistics) */
 #define PN2_CONV_ACCUM 2   /* out += result (gradient accumulation) */
+#define PN2_CONV_BIAS 4    /* `psum` is a [Cout] fp32 bias (physical columns) added in the epilogue; excludes PN2_CONV_STATS */
 
 /* ---------------------------------------------------------------------------------------------- conv
  * F.conv2d / nn.Conv2d forward and its autograd backward:

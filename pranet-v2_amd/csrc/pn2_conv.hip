@@ -206,6 +206,12 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
             }
         }
     }
+    float bj[NT];                                   // PN2_CONV_BIAS: psum carries a per-output-channel fp32 bias (biased conv / nn.Linear without BN)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int cg = n0 + wn * WTN + j * 16 + l15;
+        bj[j] = ((d.flags & PN2_CONV_BIAS) && cg < d.Cout) ? psum[cg] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
-                TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r]);
+                TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r] + bj[j]);
             }
     __syncthreads();
     if ((d.flags & PN2_CONV_STATS) && tid < BN) {
@@ -414,6 +420,12 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
             }
         }
     }
+    float bj[NT];                                   // PN2_CONV_BIAS: psum carries a per-output-channel fp32 bias (biased conv / nn.Linear without BN)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int cg = n0 + wn * WTN + j * 16 + l15;
+        bj[j] = ((d.flags & PN2_CONV_BIAS) && cg < d.Cout) ? psum[cg] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -421,7 +433,7 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
-                TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r]);
+                TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r] + bj[j]);
             }
     __syncthreads();
     if ((d.flags & PN2_CONV_STATS) && tid < BN) {
@@ -1197,6 +1209,7 @@ int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* p
     if (!in || !wp || !out || !d) return -1;
     if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
     if ((d->flags & PN2_CONV_STATS) && (!psum || !psq)) return -1;
+    if ((d->flags & PN2_CONV_BIAS) && (!psum || (d->flags & PN2_CONV_STATS))) return -1;
     if (dtype == PN2_BF16) return gemm_dispatch<bf16_t>(in, wp, out, psum, psq, *d, (hipStream_t)stream);
     if (dtype == PN2_F32) return gemm_dispatch<float>(in, wp, out, psum, psq, *d, (hipStream_t)stream);
     return -3;

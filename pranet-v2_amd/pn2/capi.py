@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpn2_hip.so")
 
 F32, BF16 = 0, 1
-CONV_STATS, CONV_ACCUM = 1, 2
+CONV_STATS, CONV_ACCUM, CONV_BIAS = 1, 2, 4
 
 
 class ConvDesc(C.Structure):

@@ -217,6 +217,7 @@ class StepArena:
 
 
 DEFER_COLSUM = os.environ.get("PN2_DEFER_COLSUM", "1") == "1"
+FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 
 
 class GradQueue:
@@ -627,7 +628,20 @@ class Engine:
         train_bn = bn is not None and self.training
 
         wp, pd = self.pack(w, x_map, o_map, False)
-        raw = self.empty(N, OH, OW, Cout_p)
+        # biased conv / nn.Linear with nothing behind it (no BN, activation, residual or re-layout): the bias goes into the GEMM epilogue and
+        # the GEMM writes the output itself - no separate affine pass
+        fuse_bias = (FUSE_BIAS and bn is None and bias is not None and not relu and residual is None and out is None and y_C is None
+                     and (y_dt is None or y_dt == self.dt))
+        if fuse_bias:
+            out = Act(self, self.empty(N, OH, OW, Cout_p), Cout, gw_o, gwp_o, self.dt)
+            raw = out.t
+            if Cout_p == Cout:
+                bvec = bias.detach()
+            else:
+                bvec = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
+                bvec[:Cout] = bias.detach()
+        else:
+            raw = self.empty(N, OH, OW, Cout_p)
         cd = capi.ConvDesc()
         cd.N, cd.H, cd.W, cd.OH, cd.OW = N, H, W, OH, OW
         cd.Cin_p, cd.ld_in, cd.Cout, cd.ld_out = x.Cp, x.ld, Cout_p, Cout_p
@@ -642,7 +656,11 @@ class Engine:
         flops = 2 * M * Cout * Cin * KH * KW
         shape = f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}"
         capi.WORK.update(flops=flops, tag=":fwd", shape=shape)
-        call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), st)
+        if fuse_bias:
+            cd.flags |= capi.CONV_BIAS
+            call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(bvec), _p(None), C.byref(cd), st)
+        else:
+            call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), st)
 
         scale = shift = mean = invstd = None
         bd = None
@@ -678,8 +696,9 @@ class Engine:
         ncopy = y_C if y_C is not None else Cout_p
         if residual is not None:
             assert residual.Cp == Cout_p and residual.dt == self.dt
-        call.pn2_affine_act(self.dt, _p(raw), Cout_p, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
-                            residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
+        if not fuse_bias:
+            call.pn2_affine_act(self.dt, _p(raw), Cout_p, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
+                                residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
 
         if not self.need_grad:
             return out
