@@ -220,8 +220,9 @@ int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, i
  * q [B][Nq][heads*64] ; kv [B][Nkv][2*heads*64] (k then v, heads inner, as the reference's reshape(B,-1,2,heads,hd)) ;
  * out = softmax(q k^T * scale) v, heads concatenated ; lse [B][heads][Nq] fp32 saved for the backward.
  * Backward: dq, dkv written (not accumulated); `partial` is scratch (see pn2_attn_bwd_blocks). */
-/* DropPath (stochastic depth, pvtv2.py:125,148-149): y[n] = x[n] * scale[n], scale[n] = bernoulli(keep)/keep drawn by the caller; its own adjoint */
-int pn2_scale_samples(int dt, const void* x, void* y, const float* scale, int N, long long elems_per_sample, void* stream);
+/* DropPath (stochastic depth, pvtv2.py:125,148-149): y[n] = x[n] * scale[n] (+ res[n]: the residual add of Block.forward :148-149 in the same pass),
+ * scale[n] = bernoulli(keep)/keep drawn by the caller; with res == NULL it is its own adjoint */
+int pn2_scale_samples(int dt, const void* x, void* y, const float* scale, const void* res, int N, long long per_sample, void* stream);
 int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, void* out, int ld_o, float* lse, int B, int Nq, int Nkv, int heads, int head_dim,
                  float scale, void* stream);
 int pn2_attn_bwd_blocks(int dt, int B, int heads, int Nq);   /* partial slots per (b, head): partial holds [B][heads][slots][2][roundup(Nkv,64)][64] fp32 */

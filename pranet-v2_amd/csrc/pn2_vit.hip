@@ -845,14 +845,21 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_k(const bf16_t* __restrict_
 
 // y[n][r][c] = x[n][r][c] * s[n]   (DropPath: per-sample keep mask / keep_prob, timm.models.layers.DropPath used at pvtv2.py:125,148-149)
 template <typename T>
-__global__ __launch_bounds__(256) void scale_samples_k(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ s, size_t vec_per_sample, size_t nvec) {
+__global__ __launch_bounds__(256) void scale_samples_k(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ s, const T* __restrict__ res,
+                                                       size_t vec_per_sample, size_t nvec) {
     constexpr int V = TT<T>::VEC;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-        float v[V];
+        float v[V], r[V];
         ldv<T>(x + i * V, v);
         const float f = s[i / vec_per_sample];
+        if (res) {                    // x + drop_path(f(x)) of Block.forward in one pass
+            ldv<T>(res + i * V, r);
 #pragma unroll
-        for (int e = 0; e < V; ++e) v[e] *= f;
+            for (int e = 0; e < V; ++e) v[e] = v[e] * f + r[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] *= f;
+        }
         stv<T>(y + i * V, v);
     }
 }
@@ -1128,11 +1135,11 @@ int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, con
     return 0;
 }
 
-int pn2_scale_samples(int dt, const void* x, void* y, const float* scale, int N, long long per_sample, void* stream) {
+int pn2_scale_samples(int dt, const void* x, void* y, const float* scale, const void* res, int N, long long per_sample, void* stream) {
     if (!x || !y || !scale || N < 1) return -1;
     const int V = dt == PN2_F32 ? 4 : 8;
     if (per_sample % V) return -2;
-    VIT_DISPATCH(dt, { hipLaunchKernelGGL(scale_samples_k<T>, dim3(grid_for((size_t)N * per_sample / V)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, scale,
+    VIT_DISPATCH(dt, { hipLaunchKernelGGL(scale_samples_k<T>, dim3(grid_for((size_t)N * per_sample / V)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, scale, (const T*)res,
                                           (size_t)per_sample / V, (size_t)N * per_sample / V); })
     PN2_CHECK_LAUNCH();
     return 0;

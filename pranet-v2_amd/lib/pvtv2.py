@@ -116,8 +116,8 @@ class Block(nn.Module):
         """Block.forward :147-151"""
         p = getattr(self.drop_path, "drop_prob", 0.0)
         if p > 0.0 and eng.training:
-            x = eng.add(x, eng.drop_path(self.attn._build(eng, eng.layernorm(x, self.norm1)), p))
-            return eng.add(x, eng.drop_path(self.mlp._build(eng, eng.layernorm(x, self.norm2)), p))
+            x = eng.drop_path_add(x, self.attn._build(eng, eng.layernorm(x, self.norm1)), p)
+            return eng.drop_path_add(x, self.mlp._build(eng, eng.layernorm(x, self.norm2)), p)
         x = self.attn._build(eng, eng.layernorm(x, self.norm1), residual=x)
         return self.mlp._build(eng, eng.layernorm(x, self.norm2), residual=x)
 

@@ -116,7 +116,7 @@ SIGNATURES = {
     "pn2_gelu_bwd": [I, P, P, P, LL, P],
     "pn2_dwconv3x3_wgrad_blocks": [I, I, I, I, I],
     "pn2_dwconv3x3_wgrad": [I, P, P, P, I, I, I, I, I, P, P, P],
-    "pn2_scale_samples": [I, P, P, P, I, LL, P],
+    "pn2_scale_samples": [I, P, P, P, P, I, LL, P],
     "pn2_attn_fwd": [I, P, I, P, I, P, I, P, I, I, I, I, I, FL, P],
     "pn2_attn_bwd_blocks": [I, I, I, I],
     "pn2_attn_bwd": [I, P, I, P, I, P, I, P, I, P, P, I, P, I, P, P, I, I, I, I, I, FL, P],

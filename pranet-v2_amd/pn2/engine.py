@@ -1049,13 +1049,36 @@ class Engine:
         assert x.ld == x.Cp
         y = Act(self, self.empty(x.N, x.H, x.W, x.Cp), x.C, x.gw, x.gwp, self.dt)
         per = x.H * x.W * x.Cp
-        call.pn2_scale_samples(self.dt, x.ptr, y.ptr, _p(sc), x.N, per, _stream())
+        call.pn2_scale_samples(self.dt, x.ptr, y.ptr, _p(sc), C.c_void_p(0), x.N, per, _stream())
 
         def bwd():
             dy = y.grad_buf()
             assert y.grad_written and not x.grad_written
             gx, _ = x.grad_sink()
-            call.pn2_scale_samples(self.dt, _p(dy), _p(gx), _p(sc), x.N, per, _stream())
+            call.pn2_scale_samples(self.dt, _p(dy), _p(gx), _p(sc), C.c_void_p(0), x.N, per, _stream())
+        self.record(bwd)
+        return y
+
+    def drop_path_add(self, res, x, drop_prob):
+        """res + DropPath(x) in one pass (Block.forward pvtv2.py:148-149 in train mode); plain add when nothing is dropped."""
+        if drop_prob == 0.0 or not self.training:
+            return self.add(res, x)
+        keep = 1.0 - drop_prob
+        sc = torch.empty(x.N, dtype=torch.float32, device=self.dev).bernoulli_(keep).div_(keep)
+        assert x.ld == x.Cp and res.ld == res.Cp and (res.N, res.H, res.W, res.Cp) == (x.N, x.H, x.W, x.Cp) and res.dt == x.dt == self.dt
+        y = Act(self, self.empty(x.N, x.H, x.W, x.Cp), x.C, x.gw, x.gwp, self.dt)
+        per = x.H * x.W * x.Cp
+        call.pn2_scale_samples(self.dt, x.ptr, y.ptr, _p(sc), res.ptr, x.N, per, _stream())
+
+        def bwd():
+            st = _stream()
+            dy = y.grad_buf()
+            assert y.grad_written and not x.grad_written and dy.stride(2) == x.Cp
+            gx, _ = x.grad_sink()
+            call.pn2_scale_samples(self.dt, _p(dy), _p(gx), _p(sc), C.c_void_p(0), x.N, per, st)
+            if res.requires_grad:
+                gr, acc = res.grad_sink()
+                call.pn2_copy(self.dt, _p(dy), dy.stride(2), self.dt, _p(gr), gr.stride(2), x.M, x.Cp, acc, st)
         self.record(bwd)
         return y
 
