@@ -75,6 +75,11 @@ int pn2_conv_wgrad_blocks(const pn2_wgrad_desc* d, int nsplit);
 int pn2_conv_wgrad_multi(int dtype, int variant, const pn2_wgrad_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
 int pn2_pack_weight(int dtype, const float* w_oihw, void* wp, const pn2_pack_desc* p, void* stream);
 int pn2_wgrad_reduce(const float* slab, float* gw_oihw, const pn2_pack_desc* p, int nsplit, int accumulate, void* stream);
+/* Data gradient of a "patchify" conv (kernel == stride, pad 0: the spatial-reduction convs, pvtv2.py:70) as GEMM + depth-to-space instead of the
+ * transposed gather: pn2_pack_patch_weight builds wp[(tap*Cin_p + ci)][co] = w[co][ci][tap] ([Rp][Kp], zero pads), pn2_conv_gemm (1x1) gives
+ * t[(n,oy,ox)][(tap, ci)], pn2_depth_to_space writes dx[n][oy*S+kh][ox*S+kw][c] (+)= t[..][(kh*S+kw)*C + c] (zero outside the patch area). */
+int pn2_pack_patch_weight(int dtype, const float* w_oihw, void* wp, int Cout, int Cin, int KH, int KW, int Cin_p, int Rp, int Kp, void* stream);
+int pn2_depth_to_space(int dtype, const void* t, int ld_t, void* dx, int ld_dx, int N, int H, int W, int OH, int OW, int S, int C, int accumulate, void* stream);
 /* one launch that repacks many weights (all convs of a model, forward and dgrad panels) from a DEVICE job table */
 typedef struct pn2_pack_job { const float* w; void* wp; pn2_pack_desc d; } pn2_pack_job;
 /* block_start_dev[j] = first workgroup of job j (njobs + 1 entries, prefix sums of pn2_pack_blocks(&job.d)).  Only real
@@ -290,7 +295,8 @@ int pn2_bias_grad(const float* dy, int M, int K, float* db, int accumulate, void
  * clip_gradient (utils/utils.py:7-17: per-element clamp) + torch.optim.Adam step (MyTrain_med.py:149,85-86), one launch over
  * the flat parameter arena.  step_ptr: device int64 step counter incremented by the kernel launch before (graph friendly). */
 int pn2_clamp_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
-                   float eps, float clip, float grad_scale, const float* bias_corr /* device [2]: 1-b1^t, 1-b2^t */, void* stream);
+                   float eps, float clip, float grad_scale, const float* bias_corr /* device [2]: 1-b1^t, 1-b2^t */,
+                   float weight_decay /* decoupled (torch.optim.AdamW, EMCAD/trainer.py:75): p *= 1 - lr*wd ; 0 = Adam */, void* stream);
 int pn2_adam_tick(float* bias_corr /* [4]: bc1, bc2, b1^t, b2^t */, float beta1, float beta2, void* stream);
 
 /* MyTest_med.py:104-111 tail on device: sum of 4 maps already resized -> sigmoid -> min-max -> uint8 */

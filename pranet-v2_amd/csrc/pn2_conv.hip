@@ -1186,6 +1186,50 @@ int wgrad_multi_dispatch(int v, const pn2_wgrad_job* jobs, const int* bstart, in
     return launch_wgrad_tab<T, 32, 1, 4>(pw, jobs, bstart, njobs, total, st);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Data gradient of a "patchify" conv (kernel == stride, no padding, no dilation: the spatial-reduction convs of PVTv2, pvtv2.py:70).  Every
+// input pixel belongs to exactly one patch and one tap, so dX is a plain GEMM  T[(n,oy,ox)][(kh,kw,ci)] = dy[(n,oy,ox)][co] * W[co][ci][kh][kw]
+// (pn2_conv_gemm, 1x1) followed by a depth-to-space copy - the generic transposed gather would walk all KH*KW taps per input pixel and find
+// one of them valid (6.9 TF/s for the 8x8 stride-8 conv).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_patch_k(const float* __restrict__ w, T* __restrict__ wp, int Cout, int Cin, int KH, int KW, int Cin_p, int Rp, int Kp) {
+    const size_t total = (size_t)Rp * Kp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int row = (int)(i / Kp), k = (int)(i - (size_t)row * Kp);
+        const int tap = row / Cin_p, ci = row - tap * Cin_p;
+        float v = 0.f;
+        if (tap < KH * KW && ci < Cin && k < Cout) v = w[((size_t)k * Cin + ci) * KH * KW + tap];
+        TT<T>::st(wp + i, v);
+    }
+}
+
+// dx[n][oy*S + kh][ox*S + kw][c] (+)= t[(n, oy, ox)][(kh*S + kw)*C + c] ; pixels outside the OH*S x OW*S patch area receive zero
+template <typename T>
+__global__ __launch_bounds__(256) void depth_to_space_k(const T* __restrict__ t, int ld_t, T* __restrict__ dx, int ld_dx, int N, int H, int W, int OH, int OW, int S, int C,
+                                                        int accumulate) {
+    constexpr int V = TT<T>::VEC;
+    const int CV = C / V;
+    const size_t total = (size_t)N * H * W * CV;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cv = (int)(i % CV); const size_t pix = i / CV;
+        const int ix = (int)(pix % W), iy = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+        const int oy = iy / S, ox = ix / S, kh = iy - oy * S, kw = ix - ox * S;
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = 0.f;
+        if (oy < OH && ox < OW) TT<T>::unpack(*reinterpret_cast<const uint4*>(t + (((size_t)n * OH + oy) * OW + ox) * ld_t + (size_t)(kh * S + kw) * C + cv * V), v);
+        T* dst = dx + pix * ld_dx + cv * V;
+        if (accumulate) {
+            float o[V];
+            TT<T>::unpack(*reinterpret_cast<const uint4*>(dst), o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] += o[e];
+        }
+        *reinterpret_cast<uint4*>(dst) = TT<T>::pack(v);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1277,6 +1321,33 @@ int pn2_wgrad_reduce_blocks(const pn2_pack_desc* p) { return p ? reduce_blocks(*
 int pn2_wgrad_reduce_multi(const pn2_reduce_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
     if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
     hipLaunchKernelGGL(wgrad_reduce_multi, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+
+/* panel of the patchify data gradient: wp[(tap*Cin_p + ci)][co] = w[co][ci][tap] (zero pads), [Rp][Kp] in the compute dtype */
+int pn2_pack_patch_weight(int dtype, const float* w_oihw, void* wp, int Cout, int Cin, int KH, int KW, int Cin_p, int Rp, int Kp, void* stream) {
+    if (!w_oihw || !wp || Cin_p < Cin || Rp < KH * KW * Cin_p || Kp < Cout) return -1;
+    const size_t total = (size_t)Rp * Kp;
+    const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == PN2_BF16) hipLaunchKernelGGL(pack_patch_k<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, (bf16_t*)wp, Cout, Cin, KH, KW, Cin_p, Rp, Kp);
+    else if (dtype == PN2_F32) hipLaunchKernelGGL(pack_patch_k<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, (float*)wp, Cout, Cin, KH, KW, Cin_p, Rp, Kp);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* dx[n][oy*S+kh][ox*S+kw][c] (+)= t[(n,oy,ox)][(kh*S+kw)*C + c]: scatters the GEMM result of the patchify data gradient back to NHWC */
+int pn2_depth_to_space(int dtype, const void* t, int ld_t, void* dx, int ld_dx, int N, int H, int W, int OH, int OW, int S, int C, int accumulate, void* stream) {
+    if (!t || !dx || N < 1 || S < 1) return -1;
+    const int V = dtype == PN2_F32 ? 4 : 8;
+    if (C % V || ld_t % V || ld_dx % V || OH * S > H || OW * S > W) return -2;
+    const size_t total = (size_t)N * H * W * (C / V);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    if (dtype == PN2_BF16) hipLaunchKernelGGL(depth_to_space_k<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, ld_t, (bf16_t*)dx, ld_dx, N, H, W, OH, OW, S, C, accumulate);
+    else if (dtype == PN2_F32) hipLaunchKernelGGL(depth_to_space_k<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)t, ld_t, (float*)dx, ld_dx, N, H, W, OH, OW, S, C, accumulate);
+    else return -3;
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -399,8 +399,8 @@ __global__ void adam_tick_k(float* bc, float b1, float b2) {
 }
 
 __global__ __launch_bounds__(256) void clamp_adam_k(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
-                                                    float lr, float b1, float b2, float eps, float clip, float gsc, const float* __restrict__ bc) {
-    const float step = lr / bc[0], rs2 = 1.f / sqrtf(bc[1]);
+                                                    float lr, float b1, float b2, float eps, float clip, float gsc, const float* __restrict__ bc, float wd) {
+    const float step = lr / bc[0], rs2 = 1.f / sqrtf(bc[1]), keep = 1.f - lr * wd;       // wd: decoupled weight decay (torch.optim.AdamW), 0 = Adam
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i], Mv = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void clamp_adam_k(float* __restrict__ p, float
             gg[e] = ge;
             mm[e] = b1 * mm[e] + (1.f - b1) * ge;
             vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
-            pp[e] -= step * mm[e] / (sqrtf(vv[e]) * rs2 + eps);
+            pp[e] = pp[e] * keep - step * mm[e] / (sqrtf(vv[e]) * rs2 + eps);
         }
         reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(g)[i] = G; reinterpret_cast<float4*>(m)[i] = Mv; reinterpret_cast<float4*>(v)[i] = V;
     }
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void clamp_adam_k(float* __restrict__ p, float
         g[i] = ge;
         m[i] = b1 * m[i] + (1.f - b1) * ge;
         v[i] = b2 * v[i] + (1.f - b2) * ge * ge;
-        p[i] -= step * m[i] / (sqrtf(v[i]) * rs2 + eps);
+        p[i] = p[i] * keep - step * m[i] / (sqrtf(v[i]) * rs2 + eps);
     }
 }
 
@@ -553,10 +553,10 @@ int pn2_adam_tick(float* bc, float beta1, float beta2, void* stream) {
 }
 
 int pn2_clamp_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
-                   float eps, float clip, float grad_scale, const float* bias_corr, void* stream) {
+                   float eps, float clip, float grad_scale, const float* bias_corr, float weight_decay, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !bias_corr) return -1;
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return -2;
-    hipLaunchKernelGGL(clamp_adam_k, dim3(grid_for((size_t)(n / 4 + 1), 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, clip, grad_scale, bias_corr);
+    hipLaunchKernelGGL(clamp_adam_k, dim3(grid_for((size_t)(n / 4 + 1), 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, clip, grad_scale, bias_corr, weight_decay);
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -74,6 +74,8 @@ SIGNATURES = {
     "pn2_conv_wgrad_blocks": [C.POINTER(WgradDesc), I],
     "pn2_conv_wgrad_multi": [I, I, P, P, I, I, P],
     "pn2_pack_weight": [I, P, P, C.POINTER(PackDesc), P],
+    "pn2_pack_patch_weight": [I, P, P, I, I, I, I, I, I, I, P],
+    "pn2_depth_to_space": [I, P, I, P, I, I, I, I, I, I, I, I, I, P],
     "pn2_wgrad_reduce": [P, P, C.POINTER(PackDesc), I, I, P],
     "pn2_pack_blocks": [C.POINTER(PackDesc)],
     "pn2_pack_weights_multi": [I, P, P, I, I, P],
@@ -147,7 +149,7 @@ SIGNATURES = {
     "pn2_copy": [I, P, I, I, P, I, I, I, I, P],
     "pn2_nchw_to_nhwc": [I, P, P, I, I, I, I, I, P],
     "pn2_bias_grad": [P, I, I, P, I, P],
-    "pn2_clamp_adam": [P, P, P, P, LL, FL, FL, FL, FL, FL, FL, P, P],
+    "pn2_clamp_adam": [P, P, P, P, LL, FL, FL, FL, FL, FL, FL, P, FL, P],
     "pn2_adam_tick": [P, FL, FL, P],
     "pn2_eval_tail": [P, P, P, LL, P],
     "pn2_eval_hist": [P, P, LL, P, P],

@@ -217,6 +217,7 @@ class StepArena:
 
 
 DEFER_COLSUM = os.environ.get("PN2_DEFER_COLSUM", "1") == "1"
+PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 
 
@@ -236,8 +237,14 @@ class GradQueue:
     def begin_step(self):
         self.seg = 0
         self.wjobs, self.rjobs, self.keep = [], [], []
+        self.uses = {}
 
     def slab(self, key, shape, dev):
+        # a weight applied twice in one step (CAB's shared fc1 / fc2 on the average- and max-pooled vectors) needs a slab per use: the
+        # deferred wgrads of both uses run before either reduction
+        n = self.uses.get(key, 0)
+        self.uses[key] = n + 1
+        key = key + (n,)
         t = self.slabs.get(key)
         if t is None or tuple(t.shape) != tuple(shape):
             if t is not None:
@@ -781,7 +788,25 @@ class Engine:
                     else:
                         rq.add_reduce(slab, gwt, rd, nsplit, gwa)
             # ---- data gradient
-            if x.requires_grad:
+            if x.requires_grad and PATCH_DGRAD and KH == sh and KW == sw and KH > 1 and ph == 0 and pw == 0 and dh == 1 and dw == 1 \
+                    and x.gw == x.gwp and gw_o == gwp_o and x.ld == x.Cp:
+                # patchify conv (kernel == stride): every input pixel sees exactly one tap -> GEMM over the patches + depth-to-space
+                gx, gxa = x.grad_sink()
+                taps, Ct = KH * KW, KH * KW * x.Cp
+                Rp2, Kp2 = rup(Ct, 128), rup(Cout_p, 128)
+                wp2 = self.alloc((Rp2, Kp2), self.tdt)
+                call.pn2_pack_patch_weight(self.dt, _p(w), _p(wp2), Cout, Cin, KH, KW, x.Cp, Rp2, Kp2, st)
+                tpatch = self.empty(N, OH, OW, Ct)
+                dd = capi.ConvDesc()
+                dd.N, dd.H, dd.W, dd.OH, dd.OW = N, OH, OW, OH, OW
+                dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Cout_p, Cout_p, Ct, Ct
+                dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = 1, 1, 1, 0, 0, 1, 1
+                dd.transposed, dd.Kp, dd.flags = 0, Kp2, 0
+                dd.flags |= self._tune_gemm(dd, _p(draw), wp2, M, Ct) << 8
+                capi.WORK.update(flops=flops, tag=":dgrad", shape=shape + " patch")
+                call.pn2_conv_gemm(self.dt, _p(draw), _p(wp2), _p(tpatch), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
+                call.pn2_depth_to_space(self.dt, _p(tpatch), Ct, _p(gx), gx.stride(2), N, H, W, OH, OW, KH, x.Cp, gxa, st)
+            elif x.requires_grad:
                 wt, ptd = self.pack(w, x_map, o_map, True)
                 gx, gxa = x.grad_sink()
                 dd = capi.ConvDesc()

@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from .capi import call
+from .capi import F32, call
 from .engine import _p, _stream
 
 
@@ -149,6 +149,31 @@ class _MutationLoss(torch.autograd.Function):
         dfg, dbg = PA(*[t.data_ptr() for t in grads[:4]]), PA(*[t.data_ptr() for t in grads[4:]])
         call.pn2_mutation_loss_bwd(fg, bg, dfg, dbg, _p(lab), _p(bgm), N, H * W, K, lc[0], lc[1], lc[2], _p(sums), 1.0, _stream())
         return (None, None, None, *[(gr * g).permute(0, 3, 1, 2) for gr in grads])
+
+
+def mutation_forward_backward(eng, outs, label, bg_mask, lc=(0.5, 0.7, 0.3), gscale=1.0):
+    """Trainer path of the same loss: `outs` are the engine's 8 fp32 [N][H][W][K] maps; the loss kernel reads them in place and the backward
+    kernel writes their gradients straight into the activations' gradient buffers (no autograd bridge, no copies).  Returns loss[1]."""
+    N, H, W, K = outs[0].N, outs[0].H, outs[0].W, outs[0].C
+    for o in outs:
+        assert o.dt == F32 and o.ld == K and (o.N, o.H, o.W, o.C) == (N, H, W, K)
+    nb, wd = call.pn2_mutation_loss_blocks(N * H * W), call.pn2_mutation_loss_width(K)
+    if wd < 0:
+        raise RuntimeError(f"pn2.mutation_loss is built for K = 9 classes (got {K})")
+    lab = label.long().contiguous()
+    bgm = bg_mask.float().contiguous()
+    partial, sums, loss = eng.fbuf(nb, wd), eng.fbuf(wd), eng.fbuf(1)
+    PA = C.c_void_p * 4
+    fg, bg = PA(*[o.t.data_ptr() for o in outs[:4]]), PA(*[o.t.data_ptr() for o in outs[4:]])
+    st = _stream()
+    call.pn2_mutation_loss_fwd(fg, bg, _p(lab), _p(bgm), N, H * W, K, lc[0], lc[1], lc[2], _p(partial), _p(sums), _p(loss), st)
+    grads = [o.grad_buf() for o in outs]
+    dfg, dbg = PA(*[g.data_ptr() for g in grads[:4]]), PA(*[g.data_ptr() for g in grads[4:]])
+    call.pn2_mutation_loss_bwd(fg, bg, dfg, dbg, _p(lab), _p(bgm), N, H * W, K, lc[0], lc[1], lc[2], _p(sums), float(gscale), st)
+    for o in outs:
+        o.grad_written = True
+    eng.keep_alive = (lab, bgm)
+    return loss
 
 
 def mutation_loss(outs, label, bg_mask, lc=(0.5, 0.7, 0.3)):

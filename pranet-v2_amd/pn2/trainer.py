@@ -24,13 +24,22 @@ def _r4(n):
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8, dtype=None, process_group=None, bucket_bytes=32 << 20):
+    def __init__(self, model, lr=1e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8, dtype=None, process_group=None, bucket_bytes=32 << 20,
+                 loss="structure", loss_weights=(0.5, 0.7, 0.3), weight_decay=0.0, hot=None):
+        """loss: "structure" - the 4-pair structure loss of MyTrain_med.py:78-82 on (images, masks), Adam + clip_gradient (binary_seg);
+                 "mutation"  - the 15-subset CE + Dice + BCE loss of EMCAD/trainer.py:106-140 on (images, (label, bg_mask)) with the 8 maps of a
+                               dual EMCADNet; pass clip=None and weight_decay=1e-4 for its AdamW (trainer.py:75).
+        hot: the parameters the step trains (default model.hot_parameters())."""
         self.model = model
+        self.loss_kind, self.loss_weights, self.weight_decay = loss, tuple(float(v) for v in loss_weights), float(weight_decay)
+        if loss not in ("structure", "mutation"):
+            raise ValueError(f"unknown loss {loss!r}")
+        clip = 3.0e38 if clip is None else clip
         self.lr, self.clip, self.betas, self.eps = lr, clip, betas, eps
         self.dtype = get_compute_dtype() if dtype is None else dtype
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
-        hot = list(model.hot_parameters())
+        hot = list(model.hot_parameters()) if hot is None else list(hot)
         hot_ids = {id(p) for p in hot}
         cold = [p for p in model.parameters() if id(p) not in hot_ids]
         dev = hot[0].device
@@ -101,7 +110,7 @@ class Trainer:
             st.arena.begin_step(self.flat.device)
         st.steps_run += 1
         eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, grad_queue=st.grad_queue, arena=st.arena)
-        eng.fuse_tail = self.fuse_tail
+        eng.fuse_tail = self.fuse_tail and self.loss_kind == "structure"
         if size is not None and (size != images.shape[2] or size != images.shape[3]):
             x = eng.cast(eng.resize_to(eng.from_nchw(images, dt=F32), size, size, align_corners=True), self.dtype)
             n_, _, h_, w_ = gts.shape
@@ -111,6 +120,10 @@ class Trainer:
             x = eng.from_nchw(images)
         outs = self.model._build(eng, x)
         eng.finish_forward()
+        if self.loss_kind == "mutation":
+            label, bg_mask = gts
+            loss = L.mutation_forward_backward(eng, outs, label, bg_mask, self.loss_weights)
+            return self._backward(eng, st, loss, None, reduce_hook)
         N, H, W = outs[0].N, outs[0].H, outs[0].W
         P = len(outs) // 2
         lat = eng.lateral_block()
@@ -131,6 +144,9 @@ class Trainer:
             for j, o in enumerate(outs):
                 o.grad = dlat[j]
                 o.grad_written = True
+        return self._backward(eng, st, loss, lat, reduce_hook)
+
+    def _backward(self, eng, st, loss, lat, reduce_hook):
         if self.world > 1:
             self.buckets.reset()
         rq = st.grad_queue
@@ -161,7 +177,7 @@ class Trainer:
         st = _stream()
         call.pn2_adam_tick(_p(self.bias_corr), self.betas[0], self.betas[1], st)
         call.pn2_clamp_adam(_p(self.flat), _p(self.gflat), _p(self.exp_avg), _p(self.exp_avg_sq), self.n_hot, self.lr, self.betas[0], self.betas[1],
-                            self.eps, self.clip, 1.0 / self.world, _p(self.bias_corr), st)
+                            self.eps, self.clip, 1.0 / self.world, _p(self.bias_corr), self.weight_decay, st)
 
     def step(self, images, gts, size=None):
         """One MyTrain_med.py:59-86 iteration (at `size` x `size` when given).  Returns the device tensor [loss2, loss3, loss4, loss5, total]."""
@@ -179,7 +195,7 @@ class Trainer:
             # step 1 measures the arena, step 2 builds the deferred-launch tables on the arena addresses the graph will replay
             raise RuntimeError("capture() needs at least 2 eager steps before the captured one (warmup >= 2 on a fresh Trainer)")
         st.s_images = images.clone()
-        st.s_gts = gts.clone()
+        st.s_gts = tuple(g.clone() for g in gts) if isinstance(gts, (tuple, list)) else gts.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -216,7 +232,11 @@ class Trainer:
             raise RuntimeError("capture() this batch shape / train size first")
         if images is not None:
             st.s_images.copy_(images, non_blocking=True)
-            st.s_gts.copy_(gts, non_blocking=True)
+            if isinstance(gts, (tuple, list)):
+                for d_, s_ in zip(st.s_gts, gts):
+                    d_.copy_(s_, non_blocking=True)
+            else:
+                st.s_gts.copy_(gts, non_blocking=True)
         st.graph.replay()
         if st.graph_opt is not None:
             self.buckets.reduce_all()

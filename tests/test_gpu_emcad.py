@@ -236,3 +236,62 @@ def test_emcadnet_forward_backward_vs_reference(fp32):
         for i, o in enumerate(outs):          # bf16 on 2x2 .. 16x16 train-mode-BN maps: sanity band only
             assert rell2(o, torch.from_numpy(z[f"f64.out{i}"])) < 0.25, i
         assert abs(float(loss) - float(z["loss"])) < 5e-2 * float(z["loss"])
+
+
+def test_trainer_mutation_step_matches_module_surface_and_adamw():
+    """pn2.trainer.Trainer(loss="mutation") - step arena, deferred table-driven launches, loss kernels writing the map gradients in place,
+    AdamW kernel, hipGraph replay - against the nn.Module surface + pn2.loss.mutation_loss + torch.optim.AdamW on the same weights and batch
+    (fp32 compute): loss, every parameter gradient, the parameters after two steps, and eager == graph replay bit for bit."""
+    from pn2.loss import mutation_loss
+    from pn2.trainer import Trainer
+    z = np.load(os.path.join(G, "emcad_64.npz"))
+    x = torch.from_numpy(z["x"]).to(dev); label = torch.from_numpy(z["label"]).to(dev); bg = torch.from_numpy(z["bg_mask"]).to(dev)
+    lr, wd = 1e-3, 1e-2
+    # ---- module surface
+    ma = _model(True)
+    hot_a = ma.hot_parameters(x.shape[1] == 1)
+    opt = torch.optim.AdamW(hot_a, lr=lr, weight_decay=wd)
+    losses_a = []
+    for _ in range(2):
+        loss = mutation_loss(ma(x, mode="train"), label, bg)
+        opt.zero_grad(); loss.backward()
+        if not losses_a:
+            g_a = [p.grad.clone() for p in hot_a]
+        opt.step(); losses_a.append(float(loss))
+    # ---- trainer
+    mb = _model(True)
+    hot_b = mb.hot_parameters(x.shape[1] == 1)
+    tr = Trainer(mb, lr=lr, clip=None, weight_decay=wd, loss="mutation", hot=hot_b)
+    l1 = tr.forward_backward(x, (label, bg))
+    torch.cuda.synchronize()
+    assert abs(float(l1[0]) - losses_a[0]) < 1e-6 * abs(losses_a[0])
+    for (n, _), pa, pb in zip([(n, p) for n, p in mb.named_parameters() if any(p is q for q in hot_b)], g_a, hot_b):
+        gb = tr._grad_view(pb)
+        scale = float(pa.abs().max())
+        assert float((gb - pa).abs().max()) <= 1e-5 * max(scale, 1e-3), n          # same kernels; only the launch grouping differs
+    tr.optimizer_step()
+    l2 = tr.step(x, (label, bg))
+    torch.cuda.synchronize()
+    assert abs(float(l2[0]) - losses_a[1]) < 1e-5 * abs(losses_a[1])
+    # Adam divides by sqrt(v): where a gradient is rounding noise (conv biases in front of a train-mode BN: analytically zero) the update is +-lr
+    # whatever the noise says, so individual elements may differ by up to 2 lr per step; everything else agrees to fp32 accuracy
+    bad = tot = 0
+    for pa, pb in zip(hot_a, hot_b):
+        d = (pb.data - pa.data).abs()
+        assert float(d.max()) <= 4.5 * lr
+        bad += int((d > 0.05 * lr).sum()); tot += d.numel()          # an update that is off by more than 5 % of the step size
+    assert bad <= 1e-2 * tot, (bad, tot)
+    # ---- hipGraph replay == eager, bit for bit (bf16, two trainers from identical weights)
+    res = []
+    for graph in (False, True):
+        m2 = _model(False)
+        tr2 = Trainer(m2, lr=lr, clip=None, weight_decay=wd, loss="mutation", hot=m2.hot_parameters(True))
+        if graph:
+            tr2.capture(x, (label, bg), warmup=2)
+            out = tr2.replay(x, (label, bg))
+        else:
+            for _ in range(3):
+                out = tr2.step(x, (label, bg))
+        torch.cuda.synchronize()
+        res.append((out.clone(), tr2.flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])

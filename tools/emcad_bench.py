@@ -17,7 +17,8 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 pn2.set_compute_dtype("bf16")
 torch.manual_seed(0)
 model = EMCADNet(num_classes=9, kernel_sizes=[1, 3, 5], expansion_factor=2, activation="relu6", encoder="pvt_v2_b2", pretrain=False, dual=True).cuda().train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+GRAPH = os.environ.get("EMCAD_GRAPH", "0") == "1"          # replay the whole step (forward, loss, backward, AdamW) from one hipGraph
+opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=GRAPH)
 x = torch.randn(bs, 1, size, size, device="cuda")
 label = torch.randint(0, 9, (bs, size // 16, size // 16), device="cuda")
 label = F.interpolate(label[:, None].float(), size=(size, size), mode="nearest")[:, 0].long()
@@ -37,6 +38,32 @@ FUSED = os.environ.get("EMCAD_TORCH_LOSS", "0") != "1"
 from pn2.loss import mutation_loss
 
 
+TRAINER = os.environ.get("EMCAD_TRAINER", "0") == "1"      # pn2.trainer.Trainer(loss="mutation"): arena, deferred table launches, AdamW kernel, hipGraph
+if TRAINER:
+    from pn2.trainer import Trainer
+    tr = Trainer(model, lr=1e-4, clip=None, weight_decay=1e-4, loss="mutation", hot=model.hot_parameters(True))
+    for _ in range(3):
+        l = tr.step(x, (label, bg))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        l = tr.step(x, (label, bg))
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    print(f"EMCADNet dual K=9 bs={bs} {size}x{size} bf16 (Trainer, eager): {1e3 * dt:.1f} ms/step  {bs / dt:.1f} img/s  loss {float(l[0]):.3f}")
+    tr.capture(x, (label, bg), warmup=2)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        l = tr.replay()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    print(f"EMCADNet dual K=9 bs={bs} {size}x{size} bf16 (Trainer, hipGraph replay): {1e3 * dt:.1f} ms/step  {bs / dt:.1f} img/s  loss {float(l[0]):.3f}")
+    with Recorder() as rec:
+        tr.step(x, (label, bg))
+    agg = rec.summary()
+    print(f"pn2 kernel time (event-bracketed, eager) {sum(d['ms'] for d in agg.values()):.1f} ms")
+    for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:28]:
+        print(f"{k:34s} {d['ms']:8.3f} ms {d['launches']:5d} launches")
+    sys.exit(0)
+
+
 def step():
     P = model(x, mode="train")
     if FUSED:
@@ -50,13 +77,28 @@ def step():
     return loss
 
 
-for _ in range(2):
-    l = step()
+if GRAPH:
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            l = step()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        l = step()
+    run = graph.replay
+else:
+    run = step
+    for _ in range(2):
+        l = step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
-    l = step()
+    r = run()
+    l = l if GRAPH else r
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-print(f"EMCADNet dual K=9 bs={bs} {size}x{size} bf16 ({'fused pn2.loss.mutation_loss' if FUSED else 'torch loss'}): {1e3 * dt:.1f} ms/step  {bs / dt:.1f} img/s  loss {float(l):.3f}")
+print(f"EMCADNet dual K=9 bs={bs} {size}x{size} bf16 ({'fused pn2.loss.mutation_loss' if FUSED else 'torch loss'}{', hipGraph replay' if GRAPH else ''}): {1e3 * dt:.1f} ms/step  {bs / dt:.1f} img/s  loss {float(l.detach()):.3f}")
+if GRAPH:
+    sys.exit(0)
 with Recorder() as rec:
     l = step()
 agg = rec.summary()

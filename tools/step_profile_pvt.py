@@ -28,3 +28,7 @@ print(f"total kernel ms {tot:.2f}")
 for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
     extra = f"{d['flops'] / d['ms'] / 1e9:8.1f} TF/s" if d["flops"] else ""
     print(f"{k:34s} {d['ms']:8.3f} ms {d['launches']:5d} launches {extra}")
+print()
+for k, d in sorted(rec.summary(detail=True).items(), key=lambda kv: -kv[1]["ms"])[:48]:
+    extra = f"{d['flops'] / d['ms'] / 1e9:8.1f} TF/s" if d["flops"] else ""
+    print(f"{k:84s} {d['ms']:8.3f} ms x{d['launches']:3d} {extra}")
