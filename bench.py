@@ -71,7 +71,9 @@ def main():
     ap.add_argument("--size", type=int, default=352)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--model", default="res2net", choices=["res2net", "pvt"], help="res2net = BASELINE config 2/3 (headline); pvt = config 4 (PVT_PraNet_V2, use --batch 16)")
+    ap.add_argument("--model", default="res2net", choices=["res2net", "pvt", "emcad"],
+                    help="res2net = BASELINE config 2/3 (headline); pvt = config 4 (PVT_PraNet_V2, use --batch 16); "
+                         "emcad = config 5 (EMCADNet dual K=9 + the 15-subset loss + AdamW, use --batch 16 --size 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     args = ap.parse_args()
@@ -92,9 +94,20 @@ def main():
     from lib.pranet import PraNet_V2, PVT_PraNet_V2
     pn2.set_compute_dtype(args.dtype)
     torch.manual_seed(0)
-    model = (PraNet_V2 if args.model == "res2net" else PVT_PraNet_V2)(num_class=1).to(dev).train()
-    tr = Trainer(model, lr=1e-4, clip=0.5, process_group=pg)
-    x, m = synthetic(args.batch, args.size, 1234 + rank, dev)
+    if args.model == "emcad":
+        # EMCAD/trainer.py: 1-channel Synapse slices, 9 classes, AdamW(lr 1e-4, wd 1e-4), supervision='mutation' on the dual heads
+        from lib.networks import EMCADNet
+        model = EMCADNet(num_classes=9, kernel_sizes=[1, 3, 5], expansion_factor=2, activation="relu6", encoder="pvt_v2_b2", pretrain=False, dual=True).to(dev).train()
+        tr = Trainer(model, lr=1e-4, clip=None, weight_decay=1e-4, loss="mutation", hot=model.hot_parameters(True), process_group=pg)
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        x = torch.randn(args.batch, 1, args.size, args.size, generator=g).to(dev)
+        lab = torch.randint(0, 9, (args.batch, args.size // 16, args.size // 16), generator=g).to(dev)
+        lab = torch.nn.functional.interpolate(lab[:, None].float(), size=(args.size, args.size), mode="nearest")[:, 0].long()
+        m = (lab, torch.stack([(lab != k).float() for k in range(9)], 1))
+    else:
+        model = (PraNet_V2 if args.model == "res2net" else PVT_PraNet_V2)(num_class=1).to(dev).train()
+        tr = Trainer(model, lr=1e-4, clip=0.5, process_group=pg)
+        x, m = synthetic(args.batch, args.size, 1234 + rank, dev)
 
     use_graph = not args.no_graph
     if use_graph:
@@ -125,6 +138,8 @@ def main():
     # ---- instrumented extra step: per-kernel-family HIP-event timing (not part of the timed region)
     from pn2 import profile as prof
     roof = prof.measure_step(tr, x, m, args.dtype)
+    names = {"res2net": "PraNet-V2 Res2Net50", "pvt": "PVT-PraNet-V2 (pvt_v2_b2, DropPath 0.1)", "emcad": "EMCADNet dual K=9 (pvt_v2_b2 encoder, EMCAD decoder)"}
+    what = ("fwd+15-subset CE/Dice/BCE loss+bwd+AdamW" if args.model == "emcad" else "fwd+4x structure_loss+bwd+clamp+Adam")
 
     if rank == 0:
         ips = world * args.batch * args.steps / el
@@ -133,14 +148,15 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{'PraNet-V2 Res2Net50' if args.model == 'res2net' else 'PVT-PraNet-V2 (pvt_v2_b2, DropPath 0.1)'} training step (fwd+4x structure_loss+bwd+clamp+Adam), bs={args.batch}/GPU {args.size}x{args.size}, "
-                                   f"random-init, synthetic ellipse masks", "global_batch": world * args.batch, "parallelism": f"dp{world}",
+            "config": {"workload": f"{names[args.model]} training step ({what}), bs={args.batch}/GPU {args.size}x{args.size}, "
+                                   f"random-init, synthetic {'block labels' if args.model == 'emcad' else 'ellipse masks'}", "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "loss": loss_v,
-            "mfma_frac_whole_step": round(ips / world * (TRAIN_GFLOP_PER_IMG if args.model == "res2net" else 72.3) / 1e3 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4),
+            "mfma_frac_whole_step": (None if args.model == "emcad" else
+                                     round(ips / world * (TRAIN_GFLOP_PER_IMG if args.model == "res2net" else 72.3) / 1e3 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4)),
             "roofline": roof["roofline"], "kernels": roof["kernels"],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model != "emcad":
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_batch)
         print(json.dumps(out), flush=True)
     if world > 1:
