@@ -209,6 +209,11 @@ int pn2_colsum(int dt, const void* dy, int ld, int M, int C, float* partial, int
 int pn2_colsum_finalize(const float* partial, int nblk, int C, int ld, float* out, int accumulate, void* stream);
 /* many pn2_colsum_finalize in ONE launch from a DEVICE job table (prefix sums of pn2_colsum_finalize_blocks(C) per job): the bias / LayerNorm /
  * depth-wise parameter-gradient sums of a training step only feed the optimizer, so the backward pass queues them and runs them together */
+/* the column sums themselves (pn2_colsum) for many tensors of one dtype in ONE launch; pn2_colsum_job_blocks fills rows / cvp and returns the job's
+ * workgroup count = rows of its partial buffer */
+typedef struct pn2_colsum_in_job { const void* dy; float* partial; int ld, M, C, rows, cvp, pad_; } pn2_colsum_in_job;
+int pn2_colsum_job_blocks(int dt, pn2_colsum_in_job* job);
+int pn2_colsum_multi(int dt, const pn2_colsum_in_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
 typedef struct pn2_colsum_job { const float* partial; float* out; int nblk, C, ld, accumulate; } pn2_colsum_job;
 int pn2_colsum_finalize_blocks(int C);
 int pn2_colsum_finalize_multi(const pn2_colsum_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);

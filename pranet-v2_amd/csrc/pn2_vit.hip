@@ -170,11 +170,11 @@ __global__ __launch_bounds__(256) void colsum_finalize_multi_k(const pn2_colsum_
 
 // partial[blk][C] = sum over the block's rows of dy[row][c]
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ dy, int ld, int M, int C, float* __restrict__ partial, int rows_per_blk, int CVP) {
+__device__ __forceinline__ void colsum_body(const T* __restrict__ dy, int ld, int M, int C, float* __restrict__ partial, int rows_per_blk, int CVP, int bloc) {
     constexpr int V = TT<T>::VEC;
     extern __shared__ float sh[];            // [R][CVP*V]
     const int CV = C / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int r0 = blockIdx.x * rows_per_blk;
+    const int r0 = bloc * rows_per_blk;
     int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
     for (int cvb = 0; cvb < CV; cvb += CVP) {
         const int cv = cvb + cvl;
@@ -197,11 +197,22 @@ __global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ dy, int ld
             for (int e = 0; e < V; ++e) {
                 float s = 0.f;
                 for (int r = 0; r < R; ++r) s += sh[(r * CVP + cvl) * V + e];
-                partial[(size_t)blockIdx.x * C + cv * V + e] = s;
+                partial[(size_t)bloc * C + cv * V + e] = s;
             }
         }
         __syncthreads();
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ dy, int ld, int M, int C, float* __restrict__ partial, int rows_per_blk, int CVP) {
+    colsum_body<T>(dy, ld, M, C, partial, rows_per_blk, CVP, blockIdx.x);
+}
+// the column sums of many tensors in one launch (device job table, as colsum_finalize_multi_k): the bias gradients of a step
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_multi_k(const pn2_colsum_in_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_colsum_in_job j = jobs[jb];
+    colsum_body<T>((const T*)j.dy, j.ld, j.M, j.C, j.partial, j.rows, j.cvp, blockIdx.x - bstart[jb]);
 }
 
 // ------------------------------------------------------------------------------------------ depth-wise 3x3 (+bias, +GELU)
@@ -945,6 +956,23 @@ int pn2_colsum(int dt, const void* dy, int ld, int M, int C, float* partial, int
     const int rows = rows_for(M, 256 / cvp);
     if ((M + rows - 1) / rows != nblk) return -2;          // nblk must be pn2_rows_blocks(M, pn2_colsum_unit(dt, C))
     VIT_DISPATCH(dt, { hipLaunchKernelGGL(colsum_k<T>, dim3(nblk), dim3(256), 256 * TT<T>::VEC * 4, (hipStream_t)stream, (const T*)dy, ld, M, C, partial, rows, cvp); })
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* fills rows / cvp of a job for pn2_colsum_multi and returns its workgroup count (= rows of its partial buffer, as pn2_rows_blocks gives) */
+int pn2_colsum_job_blocks(int dt, pn2_colsum_in_job* j) {
+    if (!j || !j->dy || !j->partial || j->M < 1) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (j->C % V || j->ld % V) return -2;
+    int cvp = pow2ceil(j->C / V); if (cvp > 256) cvp = 256;
+    j->cvp = cvp; j->rows = rows_for(j->M, 256 / cvp);
+    return (j->M + j->rows - 1) / j->rows;
+}
+
+int pn2_colsum_multi(int dt, const pn2_colsum_in_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    VIT_DISPATCH(dt, { hipLaunchKernelGGL(colsum_multi_k<T>, dim3(total_blocks), dim3(256), 256 * TT<T>::VEC * 4, (hipStream_t)stream, jobs_dev, block_start_dev, njobs); })
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -41,6 +41,10 @@ class ReduceJob(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("gw", C.c_void_p), ("d", PackDesc), ("nsplit", C.c_int), ("accumulate", C.c_int)]
 
 
+class ColsumInJob(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("partial", C.c_void_p), ("ld", C.c_int), ("M", C.c_int), ("C", C.c_int), ("rows", C.c_int), ("cvp", C.c_int), ("pad_", C.c_int)]
+
+
 class ColsumJob(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("out", C.c_void_p), ("nblk", C.c_int), ("C", C.c_int), ("ld", C.c_int), ("accumulate", C.c_int)]
 
@@ -112,6 +116,8 @@ SIGNATURES = {
     "pn2_colsum_unit": [I, I],
     "pn2_colsum": [I, P, I, I, I, P, I, P],
     "pn2_colsum_finalize": [P, I, I, I, P, I, P],
+    "pn2_colsum_job_blocks": [I, C.POINTER(ColsumInJob)],
+    "pn2_colsum_multi": [I, P, P, I, I, P],
     "pn2_colsum_finalize_blocks": [I],
     "pn2_colsum_finalize_multi": [P, P, I, I, P],
     "pn2_dwconv3x3": [I, P, P, P, P, P, I, I, I, I, I, I, P],
@@ -155,7 +161,7 @@ SIGNATURES = {
     "pn2_eval_hist": [P, P, LL, P, P],
 }
 # entry points that return a value rather than a status
-_VALUE_FUNCS = {"pn2_colsum_finalize_blocks", "pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
+_VALUE_FUNCS = {"pn2_colsum_job_blocks", "pn2_colsum_finalize_blocks", "pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
                 "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
                 "pn2_dsra_tail_blocks", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks", "pn2_mutation_loss_blocks", "pn2_mutation_loss_width",
                 "pn2_dwconv_blocks", "pn2_pairconv_blocks", "pn2_gate_blocks"}

@@ -326,7 +326,7 @@ class Engine:
         self.training = training
         self.need_grad = need_grad      # decided by the caller (grad mode is off inside autograd.Function.forward)
         self.tape = []
-        self.cjobs, self.ckeep, self.cseg, self.ctables = [], [], 0, []      # queued pn2_colsum_finalize jobs (see colsum_finalize)
+        self.cjobs, self.cin, self.ckeep, self.cseg, self.ctables = [], [], [], 0, []      # queued pn2_colsum_finalize jobs (see colsum_finalize)
         self.pgrads = ParamGrads(grad_provider)
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.bn_modules = []            # for num_batches_tracked bookkeeping
@@ -974,34 +974,60 @@ class Engine:
         self.ckeep.append((part, out))  # the partial rows must not be recycled before the launch is queued
 
     def flush_colsum(self):
-        if not self.cjobs:
+        """Run the queued column sums (one pn2_colsum_multi per dtype) and then their finalisations (one pn2_colsum_finalize_multi)."""
+        if not self.cjobs and not self.cin:
             return
-        sig = tuple(self.cjobs)
+        sig = (tuple(self.cin), tuple(self.cjobs))
         cache = self.grad_queue.ccache if self.grad_queue is not None else None
         hit = cache.get(self.cseg) if cache is not None else None
         if hit is None or hit[0] != sig:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("run two eager steps before capturing (the deferred-launch tables are built then)")
-            arr = []
-            for part, out, nblk, Cc, ld, acc in self.cjobs:
-                j = capi.ColsumJob()
-                j.partial, j.out, j.nblk, j.C, j.ld, j.accumulate = part, out, nblk, Cc, ld, acc
-                arr.append(j)
-            hit = (sig,) + _job_table(capi.ColsumJob, arr, [call.pn2_colsum_finalize_blocks(j.C) for j in arr])
+            launches = []
+            for dt in sorted({j[0] for j in self.cin}):
+                arr, blocks = [], []
+                for d_, ptr, part, ld, M, Cc in self.cin:
+                    if d_ != dt:
+                        continue
+                    j = capi.ColsumInJob()
+                    j.dy, j.partial, j.ld, j.M, j.C = ptr, part, ld, M, Cc
+                    nb = call.pn2_colsum_job_blocks(dt, C.byref(j))
+                    if nb < 1:
+                        raise RuntimeError("unsupported column-sum geometry")
+                    arr.append(j); blocks.append(nb)
+                launches.append(("s", dt, len(arr)) + _job_table(capi.ColsumInJob, arr, blocks))
+            if self.cjobs:
+                arr = []
+                for part, out, nblk, Cc, ld, acc in self.cjobs:
+                    j = capi.ColsumJob()
+                    j.partial, j.out, j.nblk, j.C, j.ld, j.accumulate = part, out, nblk, Cc, ld, acc
+                    arr.append(j)
+                launches.append(("f", 0, len(arr)) + _job_table(capi.ColsumJob, arr, [call.pn2_colsum_finalize_blocks(j.C) for j in arr]))
+            hit = (sig, launches)
             if cache is not None:
                 cache[self.cseg] = hit
-        call.pn2_colsum_finalize_multi(_p(hit[1]), _p(hit[2]), len(self.cjobs), hit[3], _stream())
-        self.ctables.append(hit)        # the table must outlive the launch
+        st = _stream()
+        for kind, dt, n, table, bstart, nblocks in hit[1]:
+            if kind == "s":
+                call.pn2_colsum_multi(dt, _p(table), _p(bstart), n, nblocks, st)
+            else:
+                call.pn2_colsum_finalize_multi(_p(table), _p(bstart), n, nblocks, st)
+        self.ctables.append(hit)        # the tables must outlive the launches
         self.cseg += 1
-        self.cjobs, self.ckeep = [], []
+        self.cjobs, self.cin, self.ckeep = [], [], []
 
     def colsum(self, t, M, Cp, Cc, out, accumulate):
-        """out[:Cc] (+)= column sums of the [M][Cp] tensor t (bias gradients)."""
+        """out[:Cc] (+)= column sums of the [M][Cp] tensor t (bias gradients).  With a gradient queue both passes are deferred into the
+        table-driven launches of flush_colsum (t stays alive in the step arena)."""
         st = _stream()
         dt = F32 if t.dtype == torch.float32 else BF16
         nb = call.pn2_rows_blocks(M, call.pn2_colsum_unit(dt, Cp))
         part = self.fbuf(nb, Cp)
-        call.pn2_colsum(dt, _p(t), Cp, M, Cp, _p(part), nb, st)
+        if DEFER_COLSUM and self.grad_queue is not None:
+            self.cin.append((dt, t.data_ptr(), part.data_ptr(), Cp, M, Cp))
+            self.ckeep.append(t)
+        else:
+            call.pn2_colsum(dt, _p(t), Cp, M, Cp, _p(part), nb, st)
         self.colsum_finalize(part, nb, Cc, Cp, out, accumulate)
 
     def linear(self, x, lin, residual=None):
