@@ -80,6 +80,10 @@ int pn2_wgrad_reduce(const float* slab, float* gw_oihw, const pn2_pack_desc* p, 
  * t[(n,oy,ox)][(tap, ci)], pn2_depth_to_space writes dx[n][oy*S+kh][ox*S+kw][c] (+)= t[..][(kh*S+kw)*C + c] (zero outside the patch area). */
 int pn2_pack_patch_weight(int dtype, const float* w_oihw, void* wp, int Cout, int Cin, int KH, int KW, int Cin_p, int Rp, int Kp, void* stream);
 int pn2_depth_to_space(int dtype, const void* t, int ld_t, void* dx, int ld_dx, int N, int H, int W, int OH, int OW, int S, int C, int accumulate, void* stream);
+/* Data gradient of a strided conv with <= 4 input channels (the 7x7 stride-4 patch embedding behind EMCADNet's 1 -> 3 channel stem,
+ * EMCAD/lib/networks.py:100-102): a thread per input pixel walks only the taps that land on an output pixel; w is the fp32 OIHW master. */
+int pn2_conv_dgrad_small_cin(int dtype, const void* dy, int ld_dy, const float* w_oihw, void* dx, int ld_dx, int N, int H, int W, int OH, int OW,
+                             int Cout, int Cin, int KH, int KW, int stride, int pad, int accumulate, void* stream);
 /* one launch that repacks many weights (all convs of a model, forward and dgrad panels) from a DEVICE job table */
 typedef struct pn2_pack_job { const float* w; void* wp; pn2_pack_desc d; } pn2_pack_job;
 /* block_start_dev[j] = first workgroup of job j (njobs + 1 entries, prefix sums of pn2_pack_blocks(&job.d)).  Only real

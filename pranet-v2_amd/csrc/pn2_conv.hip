@@ -1230,6 +1230,65 @@ __global__ __launch_bounds__(256) void depth_to_space_k(const T* __restrict__ t,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Data gradient of a strided conv with very few input channels (the 7x7 stride-4 patch embedding behind EMCADNet's 1 -> 3 channel stem,
+// networks.py:100-102): dx[pixel][ci < 4].  The implicit GEMM would pad the 3 output columns to a 32-wide tile and walk all KH*KW taps per
+// pixel although only ceil(K/S)^2 of them land on an output pixel (2.3 ms for 16x512x512).  Here a thread owns one input pixel, visits only
+// its valid taps and keeps the <= 4 sums in registers; the weights sit in LDS as float4 [r][co][s] (the 4 phases of s hit distinct banks).
+template <typename T>
+__global__ __launch_bounds__(256) void dgrad_small_cin_k(const T* __restrict__ dy, int ld_dy, const float* __restrict__ w, T* __restrict__ dx, int ld_dx,
+                                                         int N, int H, int W, int OH, int OW, int Cout, int Cin, int KH, int KW, int S, int pad, int accumulate,
+                                                         int pix_per_blk) {
+    constexpr int V = TT<T>::VEC;
+    extern __shared__ __attribute__((aligned(16))) float4 wl[];            // [KH][Cout][KW]
+    for (int i = threadIdx.x; i < KH * Cout * KW; i += 256) {
+        const int s_ = i % KW, co = (i / KW) % Cout, r = i / (KW * Cout);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* qq = &q.x;
+        for (int ci = 0; ci < Cin; ++ci) qq[ci] = w[(((size_t)co * Cin + ci) * KH + r) * KW + s_];
+        wl[i] = q;
+    }
+    __syncthreads();
+    const size_t M = (size_t)N * H * W;
+    const size_t p0 = (size_t)blockIdx.x * pix_per_blk;
+    for (size_t p = p0 + threadIdx.x; p < p0 + pix_per_blk && p < M; p += 256) {
+        const int ix = (int)(p % W), iy = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int r = (iy + pad) % S; r < KH; r += S) {
+            const int oy = (iy + pad - r) / S;
+            if (iy + pad - r < 0 || oy >= OH) continue;
+            for (int s_ = (ix + pad) % S; s_ < KW; s_ += S) {
+                const int ox = (ix + pad - s_) / S;
+                if (ix + pad - s_ < 0 || ox >= OW) continue;
+                const T* dp = dy + (((size_t)n * OH + oy) * OW + ox) * ld_dy;
+                const float4* wp = wl + (size_t)r * Cout * KW + s_;
+                for (int c0 = 0; c0 < Cout; c0 += V) {
+                    float d[V];
+                    TT<T>::unpack(*reinterpret_cast<const uint4*>(dp + c0), d);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const float4 q = wp[(size_t)(c0 + e) * KW];
+                        a0 += d[e] * q.x; a1 += d[e] * q.y; a2 += d[e] * q.z; a3 += d[e] * q.w;
+                    }
+                }
+            }
+        }
+        T* dst = dx + p * ld_dx;
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = 0.f;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+        if (accumulate) {
+            float old[V];
+            TT<T>::unpack(*reinterpret_cast<const uint4*>(dst), old);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] += old[e];
+        }
+        *reinterpret_cast<uint4*>(dst) = TT<T>::pack(o);                   // the first VEC physical channels (Cin <= 4 <= VEC); pads stay zero
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1347,6 +1406,28 @@ int pn2_depth_to_space(int dtype, const void* t, int ld_t, void* dx, int ld_dx, 
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     if (dtype == PN2_BF16) hipLaunchKernelGGL(depth_to_space_k<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, ld_t, (bf16_t*)dx, ld_dx, N, H, W, OH, OW, S, C, accumulate);
     else if (dtype == PN2_F32) hipLaunchKernelGGL(depth_to_space_k<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)t, ld_t, (float*)dx, ld_dx, N, H, W, OH, OW, S, C, accumulate);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+
+/* dx[n][iy][ix][ci] (+)= sum over the taps (r, s) that land on an output pixel and over co of dy[n][oy][ox][co] * w[co][ci][r][s]   (Cin <= 4,
+ * dilation 1): data gradient of a strided few-channel conv without the zero taps / padded columns of the implicit GEMM.  w: fp32 OIHW master.
+ * dx rows are ld_dx wide with at least 4 (fp32) / 8 (bf16) physical channels; channels Cin.. of that first vector are written as zero. */
+int pn2_conv_dgrad_small_cin(int dtype, const void* dy, int ld_dy, const float* w_oihw, void* dx, int ld_dx, int N, int H, int W, int OH, int OW,
+                             int Cout, int Cin, int KH, int KW, int stride, int pad, int accumulate, void* stream) {
+    if (!dy || !w_oihw || !dx || N < 1 || stride < 1) return -1;
+    const int V = dtype == PN2_F32 ? 4 : 8;
+    const size_t lds = (size_t)KH * KW * Cout * sizeof(float4);
+    if (Cin < 1 || Cin > 4 || Cout % V || ld_dy % V || ld_dx % V || ld_dx < V || lds > 64 * 1024) return -2;
+    const size_t M = (size_t)N * H * W;
+    const int pix = 1024;
+    const unsigned grid = (unsigned)((M + pix - 1) / pix);
+    if (dtype == PN2_BF16) hipLaunchKernelGGL(dgrad_small_cin_k<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, ld_dy, w_oihw, (bf16_t*)dx, ld_dx,
+                                              N, H, W, OH, OW, Cout, Cin, KH, KW, stride, pad, accumulate, pix);
+    else if (dtype == PN2_F32) hipLaunchKernelGGL(dgrad_small_cin_k<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const float*)dy, ld_dy, w_oihw, (float*)dx, ld_dx,
+                                                  N, H, W, OH, OW, Cout, Cin, KH, KW, stride, pad, accumulate, pix);
     else return -3;
     PN2_CHECK_LAUNCH();
     return 0;

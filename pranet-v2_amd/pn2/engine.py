@@ -217,6 +217,7 @@ class StepArena:
 
 
 DEFER_COLSUM = os.environ.get("PN2_DEFER_COLSUM", "1") == "1"
+SMALL_CIN_DGRAD = os.environ.get("PN2_SMALL_CIN_DGRAD", "1") == "1"  # strided convs with <= 4 input channels: per-pixel data gradient
 PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 
@@ -806,6 +807,12 @@ class Engine:
                 capi.WORK.update(flops=flops, tag=":dgrad", shape=shape + " patch")
                 call.pn2_conv_gemm(self.dt, _p(draw), _p(wp2), _p(tpatch), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
                 call.pn2_depth_to_space(self.dt, _p(tpatch), Ct, _p(gx), gx.stride(2), N, H, W, OH, OW, KH, x.Cp, gxa, st)
+            elif x.requires_grad and SMALL_CIN_DGRAD and Cin <= 4 and sh > 1 and dh == 1 and dw == 1 and ph == pw and (x.gw == x.gwp or x.Cp == x.gwp) and gw_o == gwp_o \
+                    and Cout_p == Cout and KH * KW * Cout * 16 <= 64 * 1024 and x.ld == x.Cp:
+                # few-channel strided conv (EMCADNet's patch embedding behind the 1 -> 3 stem): only the taps that land on an output pixel
+                gx, gxa = x.grad_sink()
+                capi.WORK.update(flops=flops, tag=":dgrad", shape=shape + " small-cin")
+                call.pn2_conv_dgrad_small_cin(self.dt, _p(draw), Cout_p, _p(w), _p(gx), gx.stride(2), N, H, W, OH, OW, Cout, Cin, KH, KW, sh, ph, gxa, st)
             elif x.requires_grad:
                 wt, ptd = self.pack(w, x_map, o_map, True)
                 gx, gxa = x.grad_sink()
