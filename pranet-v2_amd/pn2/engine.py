@@ -238,7 +238,7 @@ class GradQueue:
     def begin_step(self):
         self.seg = 0
         self.wjobs, self.rjobs, self.keep = [], [], []
-        self.uses = {}
+        self.uses, self.levels = {}, {}
 
     def slab(self, key, shape, dev):
         # a weight applied twice in one step (CAB's shared fc1 / fc2 on the average- and max-pooled vectors) needs a slab per use: the
@@ -260,9 +260,15 @@ class GradQueue:
         self.keep.append((dy, x_keep))
 
     def add_reduce(self, slab, gw, rd, nsplit, accumulate):
-        if accumulate:            # a second contribution to the same gradient must see the first one finished
-            self.flush()
-        self.rjobs.append((slab.data_ptr(), gw.data_ptr(), rd, nsplit, accumulate))
+        # a weight applied more than once in a step (CAB's shared fc1 / fc2): the k-th contribution to a gradient goes into reduction level k of
+        # this segment - one pn2_wgrad_reduce_multi per level, launched in order - instead of cutting the segment (the wgrads themselves
+        # write private slabs and need no order)
+        lvl = self.levels.get(gw.data_ptr(), 0)
+        if accumulate and lvl == 0:
+            self.flush()          # the earlier contribution was not queued here (an immediate kernel): it must be finished first
+            lvl = 0
+        self.levels[gw.data_ptr()] = lvl + 1
+        self.rjobs.append((slab.data_ptr(), gw.data_ptr(), rd, nsplit, accumulate, lvl))
 
     def _build(self):
         launches = []
@@ -281,9 +287,11 @@ class GradQueue:
                 arr.append(j)
             table, bstart, nblocks = _job_table(capi.WgradJob, arr, [call.pn2_conv_wgrad_blocks(C.byref(j.d), j.nsplit) for j in arr])
             launches.append(("w", dt, v, table, bstart, len(arr), nblocks, sum(j[5] for j in js)))
-        if self.rjobs:
+        for lvl in sorted({j[5] for j in self.rjobs}):
             arr = []
-            for slab, gw, rd, ns, acc in self.rjobs:
+            for slab, gw, rd, ns, acc, l_ in self.rjobs:
+                if l_ != lvl:
+                    continue
                 j = capi.ReduceJob()
                 j.slab, j.gw, j.nsplit, j.accumulate = slab, gw, ns, acc
                 C.memmove(C.byref(j.d), C.byref(rd), C.sizeof(capi.PackDesc))
@@ -311,6 +319,7 @@ class GradQueue:
                 call.pn2_wgrad_reduce_multi(_p(table), _p(bstart), njobs, nblocks, st)
         self.seg += 1
         self.wjobs, self.rjobs, self.keep = [], [], []
+        self.levels = {}
 
 
 class Engine:
