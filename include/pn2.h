@@ -315,6 +315,17 @@ int pn2_eval_tail(const float* res, unsigned char* out, float* minmax /* scratch
  * metrics of Fmeasure_calu (eval_functions.py:131-166) and the MAE follow from these counts (pn2/evaltail.py).                    */
 int pn2_eval_hist(const unsigned char* pred_u8, const float* gt, long long n, unsigned* hist, void* stream);
 
+/* ---------------------------------------------------------------------------------------------- input transform
+ * binary_seg/utils/dataloader.py:104-111 (PolypDataset) / :176-181 (test_dataset): transforms.Resize((S, S)) on the decoded PIL image
+ * (= PIL.Image.resize(BILINEAR): separable antialiased triangle filter, uint8 after each pass, 22-bit fixed-point taps; Pillow Resample.c),
+ * transforms.ToTensor() and transforms.Normalize(mean, std), on device uint8 HWC images.  Bit-exact with Pillow: pn2_resize_coeffs is HOST
+ * code computing the taps of one axis in double exactly as Pillow does; copy them to the device and run the width pass, then the height pass. */
+int pn2_resize_ksize(int in_size, int out_size);
+int pn2_resize_coeffs(int in_size, int out_size, int* xmin, int* count, int* kk /* [out_size][pn2_resize_ksize] */);
+int pn2_resize_u8_pass(const unsigned char* src, unsigned char* dst, int H, int W, int C, int out_size, int axis /* 1: width, 0: height */,
+                       const int* xmin_dev, const int* count_dev, const int* kk_dev, int ksize, void* stream);
+int pn2_u8_to_tensor(const unsigned char* src, float* dst_chw, int H, int W, int C, const float* mean_dev, const float* std_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

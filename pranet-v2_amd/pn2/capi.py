@@ -156,13 +156,17 @@ SIGNATURES = {
     "pn2_copy": [I, P, I, I, P, I, I, I, I, P],
     "pn2_nchw_to_nhwc": [I, P, P, I, I, I, I, I, P],
     "pn2_bias_grad": [P, I, I, P, I, P],
+    "pn2_resize_ksize": [I, I],
+    "pn2_resize_coeffs": [I, I, P, P, P],
+    "pn2_resize_u8_pass": [P, P, I, I, I, I, I, P, P, P, I, P],
+    "pn2_u8_to_tensor": [P, P, I, I, I, P, P, P],
     "pn2_clamp_adam": [P, P, P, P, LL, FL, FL, FL, FL, FL, FL, P, FL, P],
     "pn2_adam_tick": [P, FL, FL, P],
     "pn2_eval_tail": [P, P, P, LL, P],
     "pn2_eval_hist": [P, P, LL, P, P],
 }
 # entry points that return a value rather than a status
-_VALUE_FUNCS = {"pn2_colsum_job_blocks", "pn2_colsum_finalize_blocks", "pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
+_VALUE_FUNCS = {"pn2_resize_ksize", "pn2_colsum_job_blocks", "pn2_colsum_finalize_blocks", "pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
                 "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
                 "pn2_dsra_tail_blocks", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks", "pn2_mutation_loss_blocks", "pn2_mutation_loss_width",
                 "pn2_dwconv_blocks", "pn2_pairconv_blocks", "pn2_gate_blocks"}

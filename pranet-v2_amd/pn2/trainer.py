@@ -185,6 +185,29 @@ class Trainer:
         self.optimizer_step()
         return loss
 
+    # ------------------------------------------------------------------ checkpoint / resume (the reference saves weights only, MyTrain_med.py:99-103)
+    def state_dict(self):
+        """Everything a resumed run needs: the model's state_dict (weights + BN running statistics) and the optimizer state
+        (Adam moments over the flat arena, bias-correction powers = step count, hyper-parameters)."""
+        return {"model": {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                "optimizer": {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "bias_corr": self.bias_corr.clone(),
+                              "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "clip": self.clip, "weight_decay": self.weight_decay,
+                              "layout": [(n, self.off[id(p)][0], p.numel()) for n, p in self.model.named_parameters() if id(p) in self.off]}}
+
+    def load_state_dict(self, sd):
+        """Restore a state_dict() of a Trainer built over the same model class; the next step continues bit for bit."""
+        layout = [(n, self.off[id(p)][0], p.numel()) for n, p in self.model.named_parameters() if id(p) in self.off]
+        o = sd["optimizer"]
+        if [tuple(x) for x in o["layout"]] != layout:
+            raise RuntimeError("optimizer state was saved for a different parameter layout")
+        self.model.load_state_dict(sd["model"], strict=True)          # copies into the arena views in place
+        with torch.no_grad():
+            self.exp_avg.copy_(o["exp_avg"]); self.exp_avg_sq.copy_(o["exp_avg_sq"]); self.bias_corr.copy_(o["bias_corr"])
+        self.lr, self.betas, self.eps, self.clip, self.weight_decay = o["lr"], tuple(o["betas"]), o["eps"], o["clip"], o["weight_decay"]
+        for st in self._states.values():                               # captured graphs baked the old hyper-parameters in
+            st.graph = st.graph_opt = None
+        return self
+
     # ------------------------------------------------------------------ hipGraph replay of the whole step
     def capture(self, images, gts, warmup=3, size=None):
         """Capture forward+loss+backward(+Adam) into hipGraphs and replay them with `replay(images, gts)`.

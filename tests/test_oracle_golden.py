@@ -214,3 +214,20 @@ def test_emcad_manifest_and_oracle_match_reference():
         if k.startswith("grawnorm."):
             g = P[k[len("grawnorm."):]].grad
             assert abs(float(g.norm()) - float(z[k])) <= 2e-3 * float(z[k]) + 2e-6, k
+
+
+def test_input_transform_oracle_matches_pillow_vectors():
+    """oracle.input_oracle (restatement of Pillow's antialiased bilinear resize + ToTensor + Normalize, dataloader.py:104-111) against the vectors
+    Pillow itself produced (tests/golden/make_golden_input.py): the uint8 resize bit for bit, the tensors exactly."""
+    from oracle import input_oracle as I
+    z = np.load(os.path.join(G, "input_pipeline.npz"))
+    names = sorted({k.split(".")[0] for k in z.files})
+    assert {"down", "up", "mixed", "gt", "small", "same", "big"} <= set(names)
+    for n in names:
+        img = z[n + ".in"]; S = z[n + ".resized"].shape[0]
+        assert np.array_equal(I.pil_resize_bilinear_u8(img, S, S), z[n + ".resized"]), n
+        if n + ".tensor" in z.files and img.ndim == 3:
+            t, _ = I.train_transform(img, img[:, :, 0], S)
+            assert np.array_equal(t, z[n + ".tensor"]), n
+    _, g = I.train_transform(z["down.in"], z["gt.in"], 96)
+    assert np.array_equal(g, z["gt.tensor"])
