@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void ln_fwd_k(const T* __restrict__ x, int ld_
             for (int e = 0; e < V; ++e) s += v[k][e];
         }
     }
-    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+    s = group_sum(s, LPR);
     const float mu = s / (float)C;
     float q = 0.f;
 #pragma unroll
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_k(const T* __restrict__ x, int ld_
             for (int e = 0; e < V; ++e) { const float d = v[k][e] - mu; q += d * d; }
         }
     }
-    for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o);
+    q = group_sum(q, LPR);
     const float rs = rsqrtf(q / (float)C + eps);
     if (live && lr == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, int ld
                 }
             }
         }
-        for (int o = 1; o < LPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 = group_sum(s1, LPR); s2 = group_sum(s2, LPR);
         const float c1 = s1 / (float)C, c2 = s2 / (float)C;
 #pragma unroll
         for (int k = 0; k < LN_NV; ++k) {
@@ -1070,7 +1070,8 @@ static int attn_geom(int Nkv, int heads, int head_dim) { return (head_dim == 64 
 static int attn_target_blocks() { static const int v = [] { const char* e = getenv("PN2_ATTN_BLOCKS"); return e ? atoi(e) : 512; }(); return v; }
 static int attn_bwd_gx(int B, int heads, int Nq) {
     const int ntile = (Nq + 63) / 64;
-    int gx = (attn_target_blocks() + B * heads - 1) / (B * heads);
+    // backward: one block per CU measured best (the block state - K, V, two 64-query tiles, dS / P and their transposes - fills the LDS anyway)
+    int gx = (attn_target_blocks() / 2 + B * heads - 1) / (B * heads);
     return gx > ntile ? ntile : (gx < 1 ? 1 : gx);
 }
 
