@@ -77,28 +77,6 @@ __device__ __forceinline__ int find_job(const int* __restrict__ bstart, int njob
     return lo;
 }
 
-// Cross-lane exchange inside a 16-lane DPP row without the LDS permute network (__shfl_xor compiles to ds_bpermute_b32 here, ~100 cycles of
-// latency per step): xor 1 / 2 are quad permutes, "xor 4" / "xor 8" are the half-row / row mirrors - equivalent to the xor butterfly once the
-// lanes of each quad (8-group) already hold the same value, which is the case inside a butterfly reduction.
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-// butterfly step `o` (1, 2, 4, 8 through DPP; 16, 32 through the permute network) of a sum / max over aligned groups of lanes
-__device__ __forceinline__ float bfly_get(float v, int o) {
-    switch (o) {
-        case 1: return dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
-        case 2: return dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
-        case 4: return dpp_mov<0x141>(v);      // row_half_mirror
-        case 8: return dpp_mov<0x140>(v);      // row_mirror
-        default: return __shfl_xor(v, o);
-    }
-}
-// sum over aligned groups of LPR lanes (LPR a power of two <= 64); every lane of a group gets the total.  Steps must run in increasing order.
-__device__ __forceinline__ float group_sum(float v, int LPR) {
-    for (int o = 1; o < LPR; o <<= 1) v += bfly_get(v, o);
-    return v;
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void ln_fwd_k(const T* __restrict__ x, int ld_
             for (int e = 0; e < V; ++e) s += v[k][e];
         }
     }
-    s = group_sum(s, LPR);
+    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
     const float mu = s / (float)C;
     float q = 0.f;
 #pragma unroll
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_k(const T* __restrict__ x, int ld_
             for (int e = 0; e < V; ++e) { const float d = v[k][e] - mu; q += d * d; }
         }
     }
-    q = group_sum(q, LPR);
+    for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o);
     const float rs = rsqrtf(q / (float)C + eps);
     if (live && lr == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, int ld
                 }
             }
         }
-        s1 = group_sum(s1, LPR); s2 = group_sum(s2, LPR);
+        for (int o = 1; o < LPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
         const float c1 = s1 / (float)C, c2 = s2 / (float)C;
 #pragma unroll
         for (int k = 0; k < LN_NV; ++k) {

@@ -61,6 +61,10 @@ if TRAINER:
     print(f"pn2 kernel time (event-bracketed, eager) {sum(d['ms'] for d in agg.values()):.1f} ms")
     for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:28]:
         print(f"{k:34s} {d['ms']:8.3f} ms {d['launches']:5d} launches")
+    print()
+    for k, d in sorted(rec.summary(detail=True).items(), key=lambda kv: -kv[1]["ms"])[:60]:
+        extra = f"{d['flops'] / d['ms'] / 1e9:8.1f} TF/s" if d["flops"] else ""
+        print(f"{k:90s} {d['ms']:8.3f} ms x{d['launches']:3d} {extra}")
     sys.exit(0)
 
 
