@@ -14,13 +14,16 @@
 
 namespace {
 
+struct __attribute__((packed, aligned(4))) f32x3_t { float a, b, c; };      // 12-byte vector of the fp32 K-channel maps (K = 9 = 3 x 3)
 template <typename T, int W> struct VL {
     __device__ static __forceinline__ void load(const T* p, float* f) {
         if constexpr (W == 1) f[0] = TT<T>::ld(p);
+        else if constexpr (W == 3) { const f32x3_t v = *reinterpret_cast<const f32x3_t*>(p); f[0] = v.a; f[1] = v.b; f[2] = v.c; }
         else TT<T>::unpack(*reinterpret_cast<const uint4*>(p), f);
     }
     __device__ static __forceinline__ void store(T* p, const float* f) {
         if constexpr (W == 1) TT<T>::st(p, f[0]);
+        else if constexpr (W == 3) { f32x3_t v; v.a = f[0]; v.b = f[1]; v.c = f[2]; *reinterpret_cast<f32x3_t*>(p) = v; }
         else *reinterpret_cast<uint4*>(p) = TT<T>::pack(f);
     }
 };
@@ -435,6 +438,8 @@ int pn2_bilinear_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int N, 
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dt, {
         if (vec_ok<T>(C, ld_x, ld_y)) hipLaunchKernelGGL((bilinear_fwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * OH * OW * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, N, H, W, C, OH, OW, ac, rh, rw);
+        else if (sizeof(T) == 4 && C % 3 == 0 && ld_x % 3 == 0 && ld_y % 3 == 0)      // fp32 K = 9 class maps: 12-byte vectors
+            hipLaunchKernelGGL((bilinear_fwd_k<float, 3>), dim3(grid_for((size_t)N * OH * OW * C / 3)), dim3(256), 0, st, (const float*)x, ld_x, (float*)y, ld_y, N, H, W, C, OH, OW, ac, rh, rw);
         else hipLaunchKernelGGL((bilinear_fwd_k<T, 1>), dim3(grid_for((size_t)N * OH * OW * C)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, N, H, W, C, OH, OW, ac, rh, rw);
     })
     PN2_CHECK_LAUNCH();
@@ -445,11 +450,13 @@ int pn2_bilinear_bwd(int dt, const void* dy, int ld_dy, void* dx, int ld_dx, int
     if (!dy || !dx) return -1;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dt, {
-        if (C < TT<T>::VEC && OH >= 4 * H && OW >= 4 * W && ld_dy == C && OW * C <= 8192)
+        if ((C < TT<T>::VEC || (sizeof(T) == 4 && C <= 16)) && OH >= 4 * H && OW >= 4 * W && ld_dy == C && OW * C <= 8192)      // K-channel fp32 maps (K = 1 .. 9)
             hipLaunchKernelGGL((bilinear_bwd_rows_k<T>), dim3(N * H), dim3(256), OW * C * 4, st, (const T*)dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
         else if (C < TT<T>::VEC && OH >= 4 * H && OW >= 4 * W)
             hipLaunchKernelGGL((bilinear_bwd_wave_k<T>), dim3((unsigned)(((size_t)N * H * W * C + 3) / 4)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
         else if (vec_ok<T>(C, ld_dy, ld_dx)) hipLaunchKernelGGL((bilinear_bwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * H * W * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
+        else if (sizeof(T) == 4 && C % 3 == 0 && ld_dy % 3 == 0 && ld_dx % 3 == 0)      // fp32 K = 9 class maps: 12-byte vectors
+            hipLaunchKernelGGL((bilinear_bwd_k<float, 3>), dim3(grid_for((size_t)N * H * W * C / 3)), dim3(256), 0, st, (const float*)dy, ld_dy, (float*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
         else hipLaunchKernelGGL((bilinear_bwd_k<T, 1>), dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, ac, rh, rw, accumulate);
     })
     PN2_CHECK_LAUNCH();
