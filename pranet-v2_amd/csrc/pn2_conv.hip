@@ -269,11 +269,13 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) unsigned pn2_zero16[4] = {0u, 0u, 0u, 0u};
 
-template <int BM, int BN, int WM, int WN, bool PW>
+// NS = 3: two K-steps of loads in flight; NS = 2: one step ahead and a third less LDS, so that three (64x128) instead of two workgroups share
+// a CU - the per-shape tuner picks (the K loop runs at ~27 % of the MFMA rate with two resident workgroups: barrier / wait stalls).
+template <int BM, int BN, int WM, int WN, bool PW, int NS = 3>
 __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
                                                      float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d) {
     using T = bf16_t;
-    constexpr int VEC = 8, BK = 64, ROW = 128, NS = 3;
+    constexpr int VEC = 8, BK = 64, ROW = 128;
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int STAGE = (BM + BN) * ROW;
     constexpr int CRS = BN * 2 + 16;
@@ -362,15 +364,24 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;     // LDS byte address of the dynamic segment
 
     PN2_ISSUE(0, 0);
-    if (ksteps > 1) PN2_ISSUE(1, 1);
+    if (NS == 3 && ksteps > 1) PN2_ISSUE(1, 1);
     for (int t = 0; t < ksteps; ++t) {
-        // my own DMA of step t has landed once at most one later step (LPS loads) is still outstanding
-        if (t + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();              // everyone's step-t data is in LDS; everyone finished reading step t-1
-        if (t + 2 < ksteps) {
-            const int nb_ = (t + 2) % NS;
-            PN2_ISSUE(t + 2, nb_);
+        if constexpr (NS == 3) {
+            // my own DMA of step t has landed once at most one later step (LPS loads) is still outstanding
+            if (t + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // everyone's step-t data is in LDS; everyone finished reading step t-1
+            if (t + 2 < ksteps) {
+                const int nb_ = (t + 2) % NS;
+                PN2_ISSUE(t + 2, nb_);
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // only step t is outstanding
+            __builtin_amdgcn_s_barrier();              // step t is in LDS for everyone; everyone finished reading the other buffer (step t-1)
+            if (t + 1 < ksteps) {
+                const int nb_ = (t + 1) % NS;
+                PN2_ISSUE(t + 1, nb_);
+            }
         }
         // Fragment reads are inline asm: for a compiler-visible LDS load hipcc drains ALL outstanding LDS-DMA (vmcnt(0)) first,
         // which would collapse the pipeline to depth 1.  DS operations return in order, so counted lgkmcnt waits are exact.
@@ -996,26 +1007,26 @@ int launch_gemm(const void* in, const void* wp, void* out, float* psum, float* p
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS = 3>
 int launch_dma(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, hipStream_t st) {
     const int M = d.N * d.OH * d.OW;
     const int grid = ((M + BM - 1) / BM) * ((d.Cout + BN - 1) / BN);
-    constexpr int stage_b = (BM + BN) * 128, max_b = 3 * stage_b, epi_b = BM * (BN * 2 + 16) + 2 * WM * BN * 4;
+    constexpr int stage_b = (BM + BN) * 128, max_b = NS * stage_b, epi_b = BM * (BN * 2 + 16) + 2 * WM * BN * 4;
     // short-K convs (1-2 K-steps) only touch 1-2 ring slots: ask for less LDS so that more workgroups share a CU
     const int ksteps = (d.KH * d.KW * d.Cin_p + 63) / 64;
-    const int main_b = (ksteps < 3 ? ksteps : 3) * stage_b;
+    const int main_b = (ksteps < NS ? ksteps : NS) * stage_b;
     const int lds = main_b > epi_b ? main_b : epi_b;
     const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
-    if (max_b > 64 * 1024) {
+    if (max_b > 64 * 1024 || epi_b > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, true, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b > epi_b ? max_b : epi_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, false, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b > epi_b ? max_b : epi_b);
             done = true;
         }
     }
-    if (pw) hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, true>), dim3(grid), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
-    else hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, false>), dim3(grid), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
+    if (pw) hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, true, NS>), dim3(grid), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
+    else hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, false, NS>), dim3(grid), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -1052,12 +1063,22 @@ template <typename T>
 int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, hipStream_t st) {
     int bm, bn;
     pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
-    // optional per-shape tuning code in flags bits 8..15 (bf16 only): kernel (1 register-staged, 2 LDS-DMA), BM, BN
+    // optional per-shape tuning code in flags bits 8..15 (bf16 only): kernel (1 register-staged, 2 LDS-DMA 3-stage, 3 LDS-DMA 2-stage), BM, BN
     const int tune = sizeof(T) == 2 ? (d.flags >> 8) & 0xff : 0;
     const int tk_ = tune & 3, tbm = (tune >> 2) & 3, tbn = (tune >> 4) & 3;
     if (tbm) bm = tbm == 1 ? 64 : 128;
     if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
     if constexpr (sizeof(T) == 2) {
+        if (tk_ == 3) {              // LDS-DMA, 2-stage ring (more workgroups per CU)
+            if (bm == 128) {
+                if (bn == 128) return launch_dma<128, 128, 2, 2, 2>(in, wp, out, psum, psq, d, st);
+                if (bn == 64) return launch_dma<128, 64, 2, 2, 2>(in, wp, out, psum, psq, d, st);
+                return launch_dma<128, 32, 4, 1, 2>(in, wp, out, psum, psq, d, st);
+            }
+            if (bn == 128) return launch_dma<64, 128, 2, 2, 2>(in, wp, out, psum, psq, d, st);
+            if (bn == 64) return launch_dma<64, 64, 2, 2, 2>(in, wp, out, psum, psq, d, st);
+            return launch_dma<64, 32, 4, 1, 2>(in, wp, out, psum, psq, d, st);
+        }
         if (tk_ ? tk_ == 2 : use_dma_kernel()) {
             if (bm == 128) {
                 if (bn == 128) return launch_dma<128, 128, 2, 2>(in, wp, out, psum, psq, d, st);
