@@ -253,12 +253,12 @@ int pn2_dwconv_blocks(int dt, int N, int H, int W, int C, int K, int wgrad);
 int pn2_dwconv(int dt, const void* x, const float* w, void* z, int N, int H, int W, int C, int K, int flip, int accumulate, float* psum, float* psq, void* stream);
 /* partial[pn2_dwconv_blocks(.., 1)][C*K*K] of the depth-wise weight gradient; finish with pn2_colsum_finalize(partial, nblk, C*K*K, C*K*K, dW, acc) */
 int pn2_dwconv_wgrad(int dt, const void* dz, const void* x, float* partial, int N, int H, int W, int C, int K, void* stream);
-int pn2_pairconv_blocks(int M, int F);
+int pn2_pairconv_blocks(int dt, int N, int H, int W, int F);   /* rows of the BN partial buffers of _fwd and of the partial buffer of _wgrad */
 /* grouped 3x3 conv, groups = F, 2 input channels per group (LGAG.W_g / W_x), pad 1, bias-free here (the bias is folded by the caller):
- * x [M][2F] -> z [M][F] + BN partial rows [pn2_pairconv_blocks(M, F)][F] ; w [F][2][9] fp32 */
+ * x [M][2F] -> z [M][F] + BN partial rows [pn2_pairconv_blocks(dt, N, H, W, F)][F] ; w [F][2][9] fp32 */
 int pn2_pairconv3x3_fwd(int dt, const void* x, const float* w, void* z, int N, int H, int W, int F, float* psum, float* psq, void* stream);
 int pn2_pairconv3x3_dgrad(int dt, const void* dz, const float* w, void* dx, int N, int H, int W, int F, int accumulate, void* stream);
-/* partial[pn2_pairconv_blocks(M, F)][F*18] ; finish with pn2_colsum_finalize */
+/* partial[pn2_pairconv_blocks(dt, N, H, W, F)][F*18] ; finish with pn2_colsum_finalize */
 int pn2_pairconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, int N, int H, int W, int F, void* stream);
 /* y (+)= x * gate ; mode 0: gate [N][C] (CAB), mode 1: gate [N][HW] (SAB, LGAG) ; gate fp32.  Also the data gradient (x := dy). */
 int pn2_gate_mul(int dt, const void* x, const float* gate, void* y, int N, int HW, int C, int mode, int accumulate, void* stream);

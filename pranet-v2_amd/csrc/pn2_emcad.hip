@@ -195,111 +195,194 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_row_k(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ grouped 3x3, two input channels per group
-// z[p][o] = b[o] + sum_{j<2, taps} w[o][j][tap] x[p + tap][2o + j] ;  one thread = one (pixel, 8 outputs) item (16 inputs = two vectors)
-template <typename T>
+// z[p][o] = sum_{j<2, taps} w[o][j][tap] x[p + tap][2o + j]   (LGAG.W_g / W_x, decoders.py:193-200; the bias is folded by the caller).
+// Sliding-window walks as the depth-wise kernels: a thread owns VT outputs (= one 16-byte vector of 2*VT inputs), keeps their 18*VT weights and
+// the packed 3x3 input window in registers and walks a row segment.
+template <typename T, int VT>
+__device__ __forceinline__ void pc_load_col(const T* base, const bool (&vy)[3], int ix, int W, int ld, DwVec<T, 2 * VT> (&col)[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        col[r].zero();
+        if (vy[r] && (unsigned)ix < (unsigned)W) col[r].load(base + ((ptrdiff_t)(r - 1) * W + ix) * ld);
+    }
+}
+template <typename T, int VT>
+__device__ __forceinline__ void pc_load_col1(const T* base, const bool (&vy)[3], int ix, int W, int ld, DwVec<T, VT> (&col)[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        col[r].zero();
+        if (vy[r] && (unsigned)ix < (unsigned)W) col[r].load(base + ((ptrdiff_t)(r - 1) * W + ix) * ld);
+    }
+}
+
+template <typename T, int VT>
 __global__ __launch_bounds__(256) void pairconv_fwd_k(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ z, int N, int H, int W, int F,
-                                                      float* __restrict__ psum, float* __restrict__ psq, int pix_per_blk, int CVP) {
+                                                      float* __restrict__ psum, float* __restrict__ psq, int SEG, int SPR, int SPB, int CVP) {
+    typedef DwVec<T, 2 * VT> VI; typedef DwVec<T, VT> VO;
     extern __shared__ float sh[];
-    constexpr int V = 8;                      // outputs per thread (both dtypes: simple scalar loads)
-    const int FV = F / V, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
-    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
-    for (int cvb = 0; cvb < FV; cvb += CVP) {
-        const int fv = cvb + cvl;
-        const bool act = fv < FV;
-        float s1[V], s2[V];
+    const int FV = F / VT, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x), fv = blockIdx.y * CVP + cvl;
+    const bool act = fv < FV;
+    const int nseg = N * H * SPR;
+    float wr[VT][18], s1[VT], s2[VT];
 #pragma unroll
-        for (int e = 0; e < V; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-        if (act) {
-            for (int m = p0 + rl; m < p1; m += R) {
-                const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
-                float a[V];
+    for (int e = 0; e < VT; ++e) {
+        s1[e] = 0.f; s2[e] = 0.f;
 #pragma unroll
-                for (int e = 0; e < V; ++e) a[e] = 0.f;
-                for (int t = 0; t < 9; ++t) {
-                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                        const T* xp = x + (((size_t)n * H + iy) * W + ix) * (2 * F) + fv * 2 * V;
+        for (int t = 0; t < 18; ++t) wr[e][t] = act ? w[(size_t)(fv * VT + e) * 18 + t] : 0.f;
+    }
+    if (act) {
+        const int send = min(nseg, (bid + 1) * SPB);
+        for (int s = bid * SPB + rl; s < send; s += R) {
+            const int sx = s % SPR, row = s / SPR, oy = row % H;
+            const int x0 = sx * SEG, x1 = min(W, x0 + SEG);
+            bool vy[3];
 #pragma unroll
-                        for (int e = 0; e < V; ++e) {
-                            const float* wp = w + (size_t)(fv * V + e) * 18;
-                            a[e] += wp[t] * TT<T>::ld(xp + 2 * e) + wp[9 + t] * TT<T>::ld(xp + 2 * e + 1);
-                        }
-                    }
+            for (int r = 0; r < 3; ++r) vy[r] = (unsigned)(oy + r - 1) < (unsigned)H;
+            const T* base = x + ((size_t)row * W) * (2 * F) + fv * 2 * VT;
+            VI c0[3], c1[3], c2[3], nx[3];
+            pc_load_col<T, VT>(base, vy, x0 - 1, W, 2 * F, c0); pc_load_col<T, VT>(base, vy, x0, W, 2 * F, c1); pc_load_col<T, VT>(base, vy, x0 + 1, W, 2 * F, c2);
+            for (int ox = x0; ox < x1; ++ox) {
+                pc_load_col<T, VT>(base, vy, ox + 1 < x1 ? ox + 2 : -1, W, 2 * F, nx);
+                float a[VT], xv[2 * VT];
+#pragma unroll
+                for (int e = 0; e < VT; ++e) a[e] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    c0[r].unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) a[e] += wr[e][r * 3] * xv[2 * e] + wr[e][9 + r * 3] * xv[2 * e + 1];
+                    c1[r].unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) a[e] += wr[e][r * 3 + 1] * xv[2 * e] + wr[e][9 + r * 3 + 1] * xv[2 * e + 1];
+                    c2[r].unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) a[e] += wr[e][r * 3 + 2] * xv[2 * e] + wr[e][9 + r * 3 + 2] * xv[2 * e + 1];
                 }
-                T* zp = z + (size_t)m * F + fv * V;
+                VO ov; ov.pack(a); ov.store(z + ((size_t)row * W + ox) * F + fv * VT);
+                ov.unpack(a);                     // statistics of the stored (rounded) values, like the conv epilogue
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    TT<T>::st(zp + e, a[e]);
-                    const float zz = TT<T>::ld(zp + e);
-                    s1[e] += zz; s2[e] += zz * zz;
-                }
+                for (int e = 0; e < VT; ++e) { s1[e] += a[e]; s2[e] += a[e] * a[e]; }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; c2[r] = nx[r]; }
             }
         }
-        block_colsum<V>(sh, s1, CVP, R, cvl, rl, act, psum + (size_t)blockIdx.x * F + fv * V);
-        block_colsum<V>(sh, s2, CVP, R, cvl, rl, act, psq + (size_t)blockIdx.x * F + fv * V);
     }
+    block_colsum<VT>(sh, s1, CVP, R, cvl, rl, act, psum + (size_t)bid * F + fv * VT);
+    block_colsum<VT>(sh, s2, CVP, R, cvl, rl, act, psq + (size_t)bid * F + fv * VT);
 }
 
 // dx[p][2o + j] (+)= sum_taps w[o][j][8 - tap] dz[p + tap][o]
-template <typename T>
-__global__ __launch_bounds__(256) void pairconv_dgrad_k(const T* __restrict__ dz, const float* __restrict__ w, T* __restrict__ dx, int N, int H, int W, int F, int accumulate) {
-    const size_t total = (size_t)N * H * W * F;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int o = (int)(idx % F); size_t p = idx / F;
-        const int ox = (int)(p % W); p /= W; const int oy = (int)(p % H); const int n = (int)(p / H);
-        float a0 = 0.f, a1 = 0.f;
-        for (int t = 0; t < 9; ++t) {
-            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                const float d = TT<T>::ld(dz + (((size_t)n * H + iy) * W + ix) * F + o);
-                a0 += w[(size_t)o * 18 + 8 - t] * d; a1 += w[(size_t)o * 18 + 9 + 8 - t] * d;
-            }
+template <typename T, int VT>
+__global__ __launch_bounds__(256) void pairconv_dgrad_k(const T* __restrict__ dz, const float* __restrict__ w, T* __restrict__ dx, int N, int H, int W, int F, int accumulate,
+                                                        int SEG, int SPR, int CVP) {
+    typedef DwVec<T, 2 * VT> VI; typedef DwVec<T, VT> VO;
+    const int FV = F / VT, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x), fv = blockIdx.y * CVP + cvl;
+    const int s = bid * R + rl;
+    if (s >= N * H * SPR || fv >= FV) return;
+    float wr[VT][18];
+#pragma unroll
+    for (int e = 0; e < VT; ++e)
+#pragma unroll
+        for (int t = 0; t < 18; ++t) wr[e][t] = w[(size_t)(fv * VT + e) * 18 + t];
+    const int sx = s % SPR, row = s / SPR, oy = row % H;
+    const int x0 = sx * SEG, x1 = min(W, x0 + SEG);
+    bool vy[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) vy[r] = (unsigned)(oy + r - 1) < (unsigned)H;
+    const T* base = dz + ((size_t)row * W) * F + fv * VT;
+    VO c0[3], c1[3], c2[3], nx[3];
+    pc_load_col1<T, VT>(base, vy, x0 - 1, W, F, c0); pc_load_col1<T, VT>(base, vy, x0, W, F, c1); pc_load_col1<T, VT>(base, vy, x0 + 1, W, F, c2);
+    for (int ox = x0; ox < x1; ++ox) {
+        pc_load_col1<T, VT>(base, vy, ox + 1 < x1 ? ox + 2 : -1, W, F, nx);
+        float a[2 * VT], d[VT];
+#pragma unroll
+        for (int e = 0; e < 2 * VT; ++e) a[e] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {          // tap t = r*3 + j uses the mirrored weight 8 - t
+            c0[r].unpack(d);
+#pragma unroll
+            for (int e = 0; e < VT; ++e) { a[2 * e] += wr[e][8 - r * 3] * d[e]; a[2 * e + 1] += wr[e][17 - r * 3] * d[e]; }
+            c1[r].unpack(d);
+#pragma unroll
+            for (int e = 0; e < VT; ++e) { a[2 * e] += wr[e][7 - r * 3] * d[e]; a[2 * e + 1] += wr[e][16 - r * 3] * d[e]; }
+            c2[r].unpack(d);
+#pragma unroll
+            for (int e = 0; e < VT; ++e) { a[2 * e] += wr[e][6 - r * 3] * d[e]; a[2 * e + 1] += wr[e][15 - r * 3] * d[e]; }
         }
-        T* dp = dx + (((size_t)n * H + oy) * W + ox) * (2 * F) + 2 * o;
-        if (accumulate) { a0 += TT<T>::ld(dp); a1 += TT<T>::ld(dp + 1); }
-        TT<T>::st(dp, a0); TT<T>::st(dp + 1, a1);
+        T* dp = dx + ((size_t)row * W + ox) * (2 * F) + fv * 2 * VT;
+        VI ov;
+        if (accumulate) {
+            float o[2 * VT];
+            ov.load(dp); ov.unpack(o);
+#pragma unroll
+            for (int e = 0; e < 2 * VT; ++e) a[e] += o[e];
+        }
+        ov.pack(a); ov.store(dp);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; c2[r] = nx[r]; }
     }
 }
 
-// partial[blk][F*18]: [o*18 + j*9 + tap] = sum_p dz[p][o] x[p + tap][2o + j]
-template <typename T>
+// partial[blk][F*18]: [o*18 + j*9 + tap] = sum_pixels dz[p][o] * x[p + tap][2o + j]
+template <typename T, int VT>
 __global__ __launch_bounds__(256) void pairconv_wgrad_k(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ partial, int N, int H, int W, int F,
-                                                        int pix_per_blk, int FP) {
-    extern __shared__ float sh[];             // [R][FP]
-    const int R = 256 / FP, ol = threadIdx.x % FP, rl = threadIdx.x / FP;
-    const int M = N * H * W, p0 = blockIdx.x * pix_per_blk;
-    int p1 = p0 + pix_per_blk; if (p1 > M) p1 = M;
-    for (int ob = 0; ob < F; ob += FP) {
-        const int o = ob + ol;
-        const bool act = o < F;
-        float a[18];
+                                                        int SEG, int SPR, int SPB, int CVP) {
+    typedef DwVec<T, 2 * VT> VI; typedef DwVec<T, VT> VO;
+    extern __shared__ float sh[];
+    const int FV = F / VT, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x), fv = blockIdx.y * CVP + cvl;
+    const bool act = fv < FV;
+    const int nseg = N * H * SPR;
+    float a[18][VT];
 #pragma unroll
-        for (int t = 0; t < 18; ++t) a[t] = 0.f;
-        if (act) {
-            for (int m = p0 + rl; m < p1; m += R) {
-                const int ox = m % W, oy = (m / W) % H, n = m / (W * H);
-                const float d = TT<T>::ld(dz + (size_t)m * F + o);
+    for (int t = 0; t < 18; ++t)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                        const T* xp = x + (((size_t)n * H + iy) * W + ix) * (2 * F) + 2 * o;
-                        a[t] += d * TT<T>::ld(xp); a[9 + t] += d * TT<T>::ld(xp + 1);
-                    }
+        for (int e = 0; e < VT; ++e) a[t][e] = 0.f;
+    if (act) {
+        const int send = min(nseg, (bid + 1) * SPB);
+        for (int s = bid * SPB + rl; s < send; s += R) {
+            const int sx = s % SPR, row = s / SPR, oy = row % H;
+            const int x0 = sx * SEG, x1 = min(W, x0 + SEG);
+            bool vy[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) vy[r] = (unsigned)(oy + r - 1) < (unsigned)H;
+            const T* base = x + ((size_t)row * W) * (2 * F) + fv * 2 * VT;
+            const T* dbase = dz + ((size_t)row * W) * F + fv * VT;
+            VI c0[3], c1[3], c2[3], nx[3]; VO dn;
+            pc_load_col<T, VT>(base, vy, x0 - 1, W, 2 * F, c0); pc_load_col<T, VT>(base, vy, x0, W, 2 * F, c1); pc_load_col<T, VT>(base, vy, x0 + 1, W, 2 * F, c2);
+            dn.load(dbase + (size_t)x0 * F);
+            for (int ox = x0; ox < x1; ++ox) {
+                const VO dc = dn;
+                pc_load_col<T, VT>(base, vy, ox + 1 < x1 ? ox + 2 : -1, W, 2 * F, nx);
+                if (ox + 1 < x1) dn.load(dbase + (size_t)(ox + 1) * F);
+                float d[VT], xv[2 * VT];
+                dc.unpack(d);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    c0[r].unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) { a[r * 3][e] += d[e] * xv[2 * e]; a[9 + r * 3][e] += d[e] * xv[2 * e + 1]; }
+                    c1[r].unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) { a[r * 3 + 1][e] += d[e] * xv[2 * e]; a[9 + r * 3 + 1][e] += d[e] * xv[2 * e + 1]; }
+                    c2[r].unpack(xv);
+#pragma unroll
+                    for (int e = 0; e < VT; ++e) { a[r * 3 + 2][e] += d[e] * xv[2 * e]; a[9 + r * 3 + 2][e] += d[e] * xv[2 * e + 1]; }
                 }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; c2[r] = nx[r]; }
             }
         }
+    }
 #pragma unroll
-        for (int t = 0; t < 18; ++t) {
-            sh[rl * FP + ol] = a[t];
-            __syncthreads();
-            if (rl == 0 && act) {
-                float s = 0.f;
-                for (int r = 0; r < R; ++r) s += sh[r * FP + ol];
-                partial[(size_t)blockIdx.x * F * 18 + (size_t)o * 18 + t] = s;
-            }
-            __syncthreads();
+    for (int t = 0; t < 18; ++t) {
+        float tmp[VT];
+        block_colsum<VT>(sh, a[t], CVP, R, cvl, rl, act, tmp);
+        if (rl == 0 && act) {
+#pragma unroll
+            for (int e = 0; e < VT; ++e) partial[(size_t)bid * F * 18 + (size_t)(fv * VT + e) * 18 + t] = tmp[e];
         }
     }
 }
@@ -810,40 +893,68 @@ int pn2_dwconv_wgrad(int dt, const void* dz, const void* x, float* partial, int 
     return 0;
 }
 
-int pn2_pairconv_blocks(int M, int F) {
-    if (M < 1 || F % 8) return -1;
-    int cvp, pix, nblk; walk_geometry(M, F / 8, cvp, pix, nblk);
-    return nblk;
+// geometry of the pair-conv walks: VT outputs per thread (one 16-byte vector of 2*VT inputs), segments as the depth-wise kernels
+static int pc_geometry(int dt, int N, int H, int W, int F, int& VT, int& SEG, int& SPR, int& SPB, int& cvp, int& gx, int& gy) {
+    VT = dt == PN2_F32 ? 2 : 4;
+    if (F % VT || N < 1 || H < 1 || W < 1) return -2;
+    const int FV = F / VT;
+    int target = 16;
+    if ((long long)N * H * ((W + 15) / 16) * FV < 200000) target = 8;
+    SPR = (W + target - 1) / target; SEG = (W + SPR - 1) / SPR;
+    cvp = FV >= 32 ? 32 : pow2ceil(FV);
+    const int R = 256 / cvp, nseg = N * H * SPR;
+    gy = (FV + cvp - 1) / cvp;
+    int want = 2048 / gy; if (want < 1) want = 1; if (want > 1024) want = 1024;
+    SPB = (nseg + want - 1) / want;
+    SPB = ((SPB + R - 1) / R) * R;
+    gx = (nseg + SPB - 1) / SPB;
+    return 0;
+}
+
+/* rows of the BatchNorm partial buffers of pn2_pairconv3x3_fwd and of the partial buffer of pn2_pairconv3x3_wgrad */
+int pn2_pairconv_blocks(int dt, int N, int H, int W, int F) {
+    int VT, SEG, SPR, SPB, cvp, gx, gy;
+    if (pc_geometry(dt, N, H, W, F, VT, SEG, SPR, SPB, cvp, gx, gy)) return -1;
+    return gx;
 }
 
 /* grouped 3x3 conv, groups = F, 2 input channels per group (LGAG.W_g / W_x), pad 1, bias-free here (the bias is folded by the caller):
- * x [M][2F] -> z [M][F] + BN partial rows [pn2_pairconv_blocks(M, F)][F] ; w [F][2][9] fp32 */
+ * x [M][2F] -> z [M][F] + BN partial rows [pn2_pairconv_blocks(dt, N, H, W, F)][F] ; w [F][2][9] fp32 */
 int pn2_pairconv3x3_fwd(int dt, const void* x, const float* w, void* z, int N, int H, int W, int F, float* psum, float* psq, void* stream) {
     if (!x || !w || !z || !psum || !psq) return -1;
-    if (F % 8) return -2;
-    int cvp, pix, nblk; walk_geometry(N * H * W, F / 8, cvp, pix, nblk);
-    EM_DISPATCH(dt, { hipLaunchKernelGGL(pairconv_fwd_k<T>, dim3(nblk), dim3(256), 256 * 8 * 4, (hipStream_t)stream, (const T*)x, w, (T*)z, N, H, W, F, psum, psq, pix, cvp); })
+    int VT, SEG, SPR, SPB, cvp, gx, gy;
+    if (pc_geometry(dt, N, H, W, F, VT, SEG, SPR, SPB, cvp, gx, gy)) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((pairconv_fwd_k<bf16_t, 4>), dim3(gx, gy), dim3(256), 256 * 4 * 4, st, (const bf16_t*)x, w, (bf16_t*)z, N, H, W, F, psum, psq, SEG, SPR, SPB, cvp);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((pairconv_fwd_k<float, 2>), dim3(gx, gy), dim3(256), 256 * 2 * 4, st, (const float*)x, w, (float*)z, N, H, W, F, psum, psq, SEG, SPR, SPB, cvp);
+    else return -3;
     PN2_CHECK_LAUNCH();
     return 0;
 }
 
 int pn2_pairconv3x3_dgrad(int dt, const void* dz, const float* w, void* dx, int N, int H, int W, int F, int accumulate, void* stream) {
     if (!dz || !w || !dx) return -1;
-    EM_DISPATCH(dt, { hipLaunchKernelGGL(pairconv_dgrad_k<T>, dim3(grid_for((size_t)N * H * W * F)), dim3(256), 0, (hipStream_t)stream, (const T*)dz, w, (T*)dx, N, H, W, F, accumulate); })
+    int VT, SEG, SPR, SPB, cvp, gx, gy;
+    if (pc_geometry(dt, N, H, W, F, VT, SEG, SPR, SPB, cvp, gx, gy)) return -2;
+    const int R = 256 / cvp, nseg = N * H * SPR;
+    const dim3 grid((nseg + R - 1) / R, gy);
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((pairconv_dgrad_k<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)dz, w, (bf16_t*)dx, N, H, W, F, accumulate, SEG, SPR, cvp);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((pairconv_dgrad_k<float, 2>), grid, dim3(256), 0, st, (const float*)dz, w, (float*)dx, N, H, W, F, accumulate, SEG, SPR, cvp);
+    else return -3;
     PN2_CHECK_LAUNCH();
     return 0;
 }
 
-/* partial[pn2_pairconv_blocks(M, F)][F*18] ; finish with pn2_colsum_finalize */
+/* partial[pn2_pairconv_blocks(dt, N, H, W, F)][F*18] ; finish with pn2_colsum_finalize */
 int pn2_pairconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, int N, int H, int W, int F, void* stream) {
     if (!dz || !x || !partial) return -1;
-    if (F % 8) return -2;
-    int cvp, pix, nblk; walk_geometry(N * H * W, F / 8, cvp, pix, nblk);
-    int fp = pow2ceil(F); if (fp > 256) fp = 256;
-    const int R = 256 / fp;
-    if (pix % R) pix = ((pix + R - 1) / R) * R;           // same block count: pix only grows to a multiple of R when R > the fwd R (never for F >= 32)
-    if ((N * H * W + pix - 1) / pix != nblk) return -2;
-    EM_DISPATCH(dt, { hipLaunchKernelGGL(pairconv_wgrad_k<T>, dim3(nblk), dim3(256), 256 * 4, (hipStream_t)stream, (const T*)dz, (const T*)x, partial, N, H, W, F, pix, fp); })
+    int VT, SEG, SPR, SPB, cvp, gx, gy;
+    if (pc_geometry(dt, N, H, W, F, VT, SEG, SPR, SPB, cvp, gx, gy)) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((pairconv_wgrad_k<bf16_t, 4>), dim3(gx, gy), dim3(256), 256 * 4 * 4, st, (const bf16_t*)dz, (const bf16_t*)x, partial, N, H, W, F, SEG, SPR, SPB, cvp);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((pairconv_wgrad_k<float, 2>), dim3(gx, gy), dim3(256), 256 * 2 * 4, st, (const float*)dz, (const float*)x, partial, N, H, W, F, SEG, SPR, SPB, cvp);
+    else return -3;
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -132,7 +132,7 @@ SIGNATURES = {
     "pn2_dwconv_blocks": [I, I, I, I, I, I, I],
     "pn2_dwconv": [I, P, P, P, I, I, I, I, I, I, I, P, P, P],
     "pn2_dwconv_wgrad": [I, P, P, P, I, I, I, I, I, P],
-    "pn2_pairconv_blocks": [I, I],
+    "pn2_pairconv_blocks": [I, I, I, I, I],
     "pn2_pairconv3x3_fwd": [I, P, P, P, I, I, I, I, P, P, P],
     "pn2_pairconv3x3_dgrad": [I, P, P, P, I, I, I, I, I, P],
     "pn2_pairconv3x3_wgrad": [I, P, P, P, I, I, I, I, P],

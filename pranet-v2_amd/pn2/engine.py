@@ -1288,7 +1288,7 @@ class Engine:
         F_ = conv.out_channels
         assert x.C == 2 * F_ and x.Cp == x.C and x.ld == x.C and conv.groups == F_ and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
         N, H, W = x.N, x.H, x.W
-        nblk = call.pn2_pairconv_blocks(N * H * W, F_)
+        nblk = call.pn2_pairconv_blocks(self.dt, N, H, W, F_)
         w = conv.weight
 
         def launch(raw, psum, psq):
