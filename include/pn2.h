@@ -23,6 +23,9 @@ extern "C" {
 #define PN2_BF16 1
 #define PN2_CONV_STATS 1   /* emit per-channel sum / sum-of-squares partials (fused BN batch statistics) */
 #define PN2_CONV_ACCUM 2   /* out += result (gradient accumulation) */
+#define PN2_CONV_SPLITK(n) ((n) << 16)   /* bf16 LDS-DMA kernels only (tuning code kernel 2 / 3): n = 2..15 workgroups share the K loop of a tile and
+                                            write fp32 partial tiles to `psum` = workspace [n][M][Cout]; finish with pn2_conv_splitk_reduce.  For convs with
+                                            few output rows and a long contraction (5x5 on 11x11 maps).  Excludes STATS / BIAS / ACCUM (the reduce does those). */
 #define PN2_CONV_BIAS 4    /* `psum` is a [Cout] fp32 bias (physical columns) added in the epilogue; excludes PN2_CONV_STATS */
 
 /* ---------------------------------------------------------------------------------------------- conv
@@ -64,6 +67,8 @@ int pn2_wgrad_tile_co(int cout_p);      /* co tile of the wgrad kernel */
 int pn2_conv_tile_m(int m, int cout, int dtype);        /* M tile (128 or 64) chosen for m output pixels x cout channels */
 int pn2_conv_stat_blocks(int m, int cout, int dtype);   /* rows of the psum/psq partial buffers = ceil(m / tile_m) */
 int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, void* stream);
+int pn2_conv_splitk_reduce(int dtype, const float* ws, int ksplit, int M, int Cout, void* out, int ld_out, const float* bias, float* psum, float* psq,
+                           int accumulate, void* stream);   /* psum / psq: BatchNorm partial rows [ceil(M / 64)][Cout] of the summed result, or NULL */
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream);
 /* Many weight gradients in ONE launch.  A wgrad only feeds the optimizer, so a training step may defer them (keeping dy / x alive)
  * and run all convs that share a kernel instantiation (pn2_conv_wgrad_variant) together, from a DEVICE job table.

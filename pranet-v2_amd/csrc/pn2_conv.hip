@@ -293,7 +293,12 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
     const int m0 = bm * BM, n0 = bn * BN;
     const int taps = d.KH * d.KW;
     const int ktot = taps * d.Cin_p;
-    const int ksteps = (ktot + BK - 1) / BK;
+    const int ksteps_all = (ktot + BK - 1) / BK;
+    // split-K (PN2_CONV_SPLITK, small-M long-K convs): blockIdx.y owns the K-steps [kt0, kt0 + ksteps) and leaves an fp32 partial tile
+    const int ksplit = (d.flags >> 16) & 15;
+    const int kper = ksplit > 1 ? (ksteps_all + ksplit - 1) / ksplit : ksteps_all;
+    const int kt0 = ksplit > 1 ? (int)blockIdx.y * kper : 0;
+    const int ksteps = max(0, min(ksteps_all - kt0, kper));
 
     GatherGeom gg;
     gg.H = d.H; gg.W = d.W; gg.OH = d.OH; gg.OW = d.OW; gg.KH = d.KH; gg.KW = d.KW; gg.stride = d.stride;
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
             else { riy0[i] = oy + d.pad_h; rix0[i] = ox + d.pad_w; }
         }
     }
-    int ci = cg * VEC, tap = 0;
+    int ci = cg * VEC + kt0 * BK, tap = 0;
     if (!PW) { while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; } }
     const T* bptr = wp + (size_t)(n0 + (tid >> 3)) * d.Kp + cg * VEC;
     const char* zsrc = reinterpret_cast<const char*>(pn2_zero16);
@@ -363,8 +368,8 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
     const unsigned so0 = ((g) ^ key) * 16, so1 = ((4 + g) ^ key) * 16;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;     // LDS byte address of the dynamic segment
 
-    PN2_ISSUE(0, 0);
-    if (NS == 3 && ksteps > 1) PN2_ISSUE(1, 1);
+    if (ksteps > 0) PN2_ISSUE(kt0, 0);
+    if (NS == 3 && ksteps > 1) PN2_ISSUE(kt0 + 1, 1);
     for (int t = 0; t < ksteps; ++t) {
         if constexpr (NS == 3) {
             // my own DMA of step t has landed once at most one later step (LPS loads) is still outstanding
@@ -373,14 +378,14 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
             __builtin_amdgcn_s_barrier();              // everyone's step-t data is in LDS; everyone finished reading step t-1
             if (t + 2 < ksteps) {
                 const int nb_ = (t + 2) % NS;
-                PN2_ISSUE(t + 2, nb_);
+                PN2_ISSUE(kt0 + t + 2, nb_);
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // only step t is outstanding
             __builtin_amdgcn_s_barrier();              // step t is in LDS for everyone; everyone finished reading the other buffer (step t-1)
             if (t + 1 < ksteps) {
                 const int nb_ = (t + 1) % NS;
-                PN2_ISSUE(t + 1, nb_);
+                PN2_ISSUE(kt0 + t + 1, nb_);
             }
         }
         // Fragment reads are inline asm: for a compiler-visible LDS load hipcc drains ALL outstanding LDS-DMA (vmcnt(0)) first,
@@ -412,6 +417,19 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
 #undef PN2_ISSUE
     __syncthreads();
 
+    if (ksplit > 1) {            // fp32 partial tile -> workspace [ksplit][M][Cout] (psum); pn2_conv_splitk_reduce finishes (sum, stats, bias, store)
+        float* ws = psum + (size_t)blockIdx.y * M * d.Cout;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * WTM + i * 16 + g * 4 + r, col = n0 + wn * WTN + j * 16 + l15;
+                    if (m < M && col < d.Cout) ws[(size_t)m * d.Cout + col] = acc[i][j][r];
+                }
+        return;
+    }
     // ---- epilogue: stats partials + LDS-staged coalesced store (same as conv_gather_gemm)
     char* Cs = smem;
     float* red = reinterpret_cast<float*>(smem + BM * CRS);
@@ -1025,8 +1043,10 @@ int launch_dma(const void* in, const void* wp, void* out, float* psum, float* ps
             done = true;
         }
     }
-    if (pw) hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, true, NS>), dim3(grid), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
-    else hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, false, NS>), dim3(grid), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
+    const int ksplit = (d.flags >> 16) & 15;
+    const dim3 g3(grid, ksplit > 1 ? ksplit : 1);
+    if (pw) hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, true, NS>), g3, dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
+    else hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, false, NS>), g3, dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -1310,6 +1330,55 @@ __global__ __launch_bounds__(256) void dgrad_small_cin_k(const T* __restrict__ d
     }
 }
 
+
+// Split-K epilogue: out[m][c] (+)= sum_s ws[s][m][c] (+ bias[c]) in the conv's storage dtype, with the BatchNorm partial rows of a 64-row
+// block (sums of the fp32 totals, as the GEMM epilogue takes them).  One workgroup = 64 rows; a thread owns 4 columns (16-byte loads) and
+// every R-th row, the R row lanes meet in LDS in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ ws, int S, int M, int C, T* __restrict__ out, int ld_out, const float* __restrict__ bias,
+                                                       float* __restrict__ psum, float* __restrict__ psq, int accumulate, int LANES) {
+    __shared__ float sh[2][256][4];
+    const int CV = C >> 2, R = 256 / LANES, cl = threadIdx.x % LANES, rl = threadIdx.x / LANES;
+    const int m0 = blockIdx.x * 64;
+    for (int cb = 0; cb < CV; cb += LANES) {
+        const int cv = cb + cl, c = cv * 4;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cv < CV) {
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) { b[0] = bias[c]; b[1] = bias[c + 1]; b[2] = bias[c + 2]; b[3] = bias[c + 3]; }
+            for (int m = m0 + rl; m < m0 + 64 && m < M; m += R) {
+                float4 v = *reinterpret_cast<const float4*>(ws + (size_t)m * C + c);
+                for (int s = 1; s < S; ++s) {
+                    const float4 u = *reinterpret_cast<const float4*>(ws + ((size_t)s * M + m) * C + c);
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                T* dst = out + (size_t)m * ld_out + c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] += vv[e]; s2[e] += vv[e] * vv[e];
+                    const float o = vv[e] + b[e];
+                    TT<T>::st(dst + e, accumulate ? o + TT<T>::ld(dst + e) : o);
+                }
+            }
+        }
+        if (psum) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sh[0][threadIdx.x][e] = s1[e]; sh[1][threadIdx.x][e] = s2[e]; }
+            __syncthreads();
+            if (rl == 0 && cv < CV) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = 0.f, q = 0.f;
+                    for (int r = 0; r < R; ++r) { a += sh[0][r * LANES + cl][e]; q += sh[1][r * LANES + cl][e]; }
+                    psum[(size_t)blockIdx.x * C + c + e] = a; psq[(size_t)blockIdx.x * C + c + e] = q;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1334,6 +1403,7 @@ int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* p
     if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
     if ((d->flags & PN2_CONV_STATS) && (!psum || !psq)) return -1;
     if ((d->flags & PN2_CONV_BIAS) && (!psum || (d->flags & PN2_CONV_STATS))) return -1;
+    if (((d->flags >> 16) & 15) > 1 && (dtype != PN2_BF16 || !psum || (d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS | PN2_CONV_ACCUM)) || ((d->flags >> 8) & 3) < 2)) return -2;
     if (dtype == PN2_BF16) return gemm_dispatch<bf16_t>(in, wp, out, psum, psq, *d, (hipStream_t)stream);
     if (dtype == PN2_F32) return gemm_dispatch<float>(in, wp, out, psum, psq, *d, (hipStream_t)stream);
     return -3;
@@ -1449,6 +1519,22 @@ int pn2_conv_dgrad_small_cin(int dtype, const void* dy, int ld_dy, const float* 
                                               N, H, W, OH, OW, Cout, Cin, KH, KW, stride, pad, accumulate, pix);
     else if (dtype == PN2_F32) hipLaunchKernelGGL(dgrad_small_cin_k<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const float*)dy, ld_dy, w_oihw, (float*)dx, ld_dx,
                                                   N, H, W, OH, OW, Cout, Cin, KH, KW, stride, pad, accumulate, pix);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+
+/* finishes a PN2_CONV_SPLITK launch: out (+)= sum of the ksplit fp32 partial tiles in ws (+ bias); psum / psq (optional): BatchNorm partial rows
+ * [ceil(M / 64)][Cout] */
+int pn2_conv_splitk_reduce(int dtype, const float* ws, int ksplit, int M, int Cout, void* out, int ld_out, const float* bias, float* psum, float* psq, int accumulate,
+                           void* stream) {
+    if (!ws || !out || ksplit < 1 || M < 1 || Cout < 1 || ((psum == nullptr) != (psq == nullptr))) return -1;
+    if (Cout % 4) return -2;
+    const dim3 grid((M + 63) / 64);
+    int lanes = 1; while (lanes < Cout / 4 && lanes < 64) lanes <<= 1;          // <= 64 column lanes -> >= 4 row lanes
+    if (dtype == PN2_BF16) hipLaunchKernelGGL(splitk_reduce_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, ws, ksplit, M, Cout, (bf16_t*)out, ld_out, bias, psum, psq, accumulate, lanes);
+    else if (dtype == PN2_F32) hipLaunchKernelGGL(splitk_reduce_k<float>, grid, dim3(256), 0, (hipStream_t)stream, ws, ksplit, M, Cout, (float*)out, ld_out, bias, psum, psq, accumulate, lanes);
     else return -3;
     PN2_CHECK_LAUNCH();
     return 0;

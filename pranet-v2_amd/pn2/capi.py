@@ -79,6 +79,7 @@ SIGNATURES = {
     "pn2_conv_wgrad_multi": [I, I, P, P, I, I, P],
     "pn2_pack_weight": [I, P, P, C.POINTER(PackDesc), P],
     "pn2_conv_dgrad_small_cin": [I, P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "pn2_conv_splitk_reduce": [I, P, I, I, I, P, I, P, P, P, I, P],
     "pn2_pack_patch_weight": [I, P, P, I, I, I, I, I, I, I, P],
     "pn2_depth_to_space": [I, P, I, P, I, I, I, I, I, I, I, I, I, P],
     "pn2_wgrad_reduce": [P, P, C.POINTER(PackDesc), I, I, P],

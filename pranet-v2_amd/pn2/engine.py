@@ -231,6 +231,7 @@ def _thrash():
 
 DEFER_COLSUM = os.environ.get("PN2_DEFER_COLSUM", "1") == "1"
 SMALL_CIN_DGRAD = os.environ.get("PN2_SMALL_CIN_DGRAD", "1") == "1"  # strided convs with <= 4 input channels: per-pixel data gradient
+SPLITK = os.environ.get("PN2_SPLITK", "1") == "1"                     # split-K for few-row / long-contraction convs
 PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 
@@ -593,6 +594,14 @@ class Engine:
         t[key] = best
         return best
 
+    def _ksplit(self, M, K, Cout_p):
+        """Split-K factor for a conv GEMM with M output rows and contraction K (bf16 LDS-DMA kernels only).  Measured on cold operands
+        (tools/splitk_micro.py): 4 pays for K >= 4096 with M <= 4096 (5x5, 256 channels, 11x11 maps: 66 -> 49 us); shorter contractions lose
+        to the partial-tile traffic."""
+        if not SPLITK or self.dt != BF16 or K < 4096 or M > 4096 or Cout_p % 8:
+            return 1
+        return 4
+
     def _stat_blocks(self, M, Cout, tune):
         bm = (tune >> 2) & 3
         if bm:
@@ -695,7 +704,19 @@ class Engine:
         flops = 2 * M * Cout * Cin * KH * KW
         shape = f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}"
         capi.WORK.update(flops=flops, tag=":fwd", shape=shape)
-        if fuse_bias:
+        ksplit = self._ksplit(M, KH * KW * x.Cp, Cout_p)
+        if ksplit > 1:
+            # few output rows, long contraction (the 5x5 convs of the ra4 branch on 11x11 maps): the K loop of every tile is shared by ksplit
+            # workgroups that leave fp32 partial tiles; the reduce sums them and takes the BatchNorm statistics / adds the bias
+            ws = self.fbuf(ksplit, M, Cout_p)
+            cd.flags = ((2 | (1 << 2) | ((3 if Cout_p > 64 else 2) << 4)) << 8) | (ksplit << 16)
+            if train_bn:
+                nblk = (M + 63) // 64
+                psum, psq = self.fbuf(nblk, Cout_p), self.fbuf(nblk, Cout_p)
+            call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(ws), _p(None), C.byref(cd), st)
+            call.pn2_conv_splitk_reduce(self.dt, _p(ws), ksplit, M, Cout_p, _p(raw), Cout_p, _p(bvec) if fuse_bias else _p(None),
+                                        _p(psum) if train_bn else _p(None), _p(psq) if train_bn else _p(None), 0, st)
+        elif fuse_bias:
             cd.flags |= capi.CONV_BIAS
             call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(bvec), _p(None), C.byref(cd), st)
         else:
@@ -852,9 +873,16 @@ class Engine:
                 dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Cout_p, Cout_p, x.Cp, gx.stride(2)
                 dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = KH, KW, sh, ph, pw, dh, dw
                 dd.transposed, dd.Kp, dd.flags = 1, ptd.Kp, (capi.CONV_ACCUM if gxa else 0)
-                dd.flags |= self._tune_gemm(dd, _p(draw), wt, N * H * W, x.Cp) << 8
+                ks = self._ksplit(N * H * W, KH * KW * Cout_p, x.Cp) if gx.stride(2) == x.Cp else 1
                 capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
-                call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
+                if ks > 1:
+                    ws = self.fbuf(ks, N * H * W, x.Cp)
+                    dd.flags = ((2 | (1 << 2) | ((3 if x.Cp > 64 else 2) << 4)) << 8) | (ks << 16)
+                    call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), _p(ws), C.c_void_p(0), C.byref(dd), st)
+                    call.pn2_conv_splitk_reduce(self.dt, _p(ws), ks, N * H * W, x.Cp, _p(gx), x.Cp, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), gxa, st)
+                else:
+                    dd.flags |= self._tune_gemm(dd, _p(draw), wt, N * H * W, x.Cp) << 8
+                    call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
 
         self.record(bwd)
         return out
