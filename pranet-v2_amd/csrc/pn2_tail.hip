@@ -174,12 +174,18 @@ __global__ __launch_bounds__(256) void loss_fwd_k(const float* __restrict__ pred
 
 __global__ void loss_finalize_k(const float* __restrict__ partial, int P, int N, int nb, float* __restrict__ sums, float* __restrict__ wsum, float* __restrict__ loss) {
     __shared__ float per[64 * 8];                  // per (p,n) loss term
+    __shared__ double acc[64 * 8 * 5];             // per (p,n,j) band sums: one thread each (the band loop of one thread per (p,n) took 17 us)
     const int t = threadIdx.x;
+    for (int idx = t; idx < P * N * 5; idx += blockDim.x) {
+        const int pn = idx / 5, j = idx - pn * 5;
+        double a = 0.0;
+        for (int b = 0; b < nb; ++b) a += (double)partial[((size_t)pn * nb + b) * 5 + j];
+        acc[idx] = a;
+    }
+    __syncthreads();
     if (t < P * N) {
         const int p = t / N, n = t % N;
-        double a[5] = {0, 0, 0, 0, 0};
-        for (int b = 0; b < nb; ++b)
-            for (int j = 0; j < 5; ++j) a[j] += (double)partial[(((size_t)p * N + n) * nb + b) * 5 + j];
+        const double* a = acc + (size_t)t * 5;
         float* s = sums + ((size_t)p * N + n) * 4;
         s[0] = (float)a[0]; s[1] = (float)a[1]; s[2] = (float)a[2]; s[3] = (float)a[3];
         if (p == 0) wsum[n] = (float)a[4];
