@@ -155,6 +155,13 @@ class PackCache:
         self.table = None
         self.dt = None
 
+    # a cache hangs off a module parameter on the nn.Module surface: pickling / deep-copying the module must not drag device job tables along
+    def __reduce__(self):
+        return (PackCache, ())
+
+    def __deepcopy__(self, memo):
+        return PackCache()
+
     def add(self, key, w, wp, d):
         self.entries[key] = (wp, d)
         j = capi.PackJob()
