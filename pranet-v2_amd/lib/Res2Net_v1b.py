@@ -53,7 +53,8 @@ class Bottle2neck(nn.Module):
         cat = eng.new_act(out1.N, OH, OW, w * sc, w, wp)
         sp = None
         for i in range(self.nums):
-            s_in = spx[i] if (i == 0 or stage) else eng.add(sp, spx[i])
+            # spx[i] feeds only this sum: its gradient slice of out1 doubles as the sum's gradient buffer (no copy in the backward pass)
+            s_in = spx[i] if (i == 0 or stage) else eng.add(sp, spx[i], grad_alias=True)
             sp = eng.conv_bn_act(s_in, self.convs[i], self.bns[i], relu=True, out=cat.slice(i * wp, (i + 1) * wp, w, w, wp), out_map=(w, wp))
         last = cat.slice(self.nums * wp, sc * wp, w, w, wp)
         if stage:

@@ -72,7 +72,7 @@ class _LinearAsConv:
 
 class Act:
     """NHWC activation view.  t: torch tensor (N,H,W,Cp) whose last dim is contiguous; ld = pixel stride."""
-    __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0", "lat")
+    __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0", "lat", "galias")
 
     def __init__(self, eng, t, C_, gw=None, gwp=None, dt=None, requires_grad=True):
         self.eng, self.t = eng, t
@@ -84,6 +84,7 @@ class Act:
         self.grad, self._written, self.child_written, self.requires_grad = None, False, False, requires_grad
         self.parent, self.c0 = None, 0
         self.lat = None                 # index of the full-resolution lateral output slot this Act is (Engine.lateral_out)
+        self.galias = None              # Act whose gradient storage this one shares (Engine.binary(..., grad_alias=True))
 
     @property
     def grad_written(self):
@@ -110,7 +111,9 @@ class Act:
     def grad_buf(self):
         """Gradient storage (allocated on first use, uninitialised)."""
         if self.grad is None:
-            if self.parent is not None:
+            if self.galias is not None:
+                self.grad = self.galias.grad_buf()
+            elif self.parent is not None:
                 self.grad = self.parent.grad_buf()[..., self.c0:self.c0 + self.Cp]
             else:
                 self.grad = self.eng.alloc(self.t.shape, self.t.dtype)
@@ -238,6 +241,7 @@ def _thrash():
 
 DEFER_COLSUM = os.environ.get("PN2_DEFER_COLSUM", "1") == "1"
 SMALL_CIN_DGRAD = os.environ.get("PN2_SMALL_CIN_DGRAD", "1") == "1"  # strided convs with <= 4 input channels: per-pixel data gradient
+GRAD_ALIAS = os.environ.get("PN2_GRAD_ALIAS", "1") == "1"             # sums whose second operand has no other consumer share its gradient storage
 SPLITK = os.environ.get("PN2_SPLITK", "1") == "1"                     # split-K for few-row / long-contraction convs
 PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
@@ -1551,17 +1555,25 @@ class Engine:
         return y
 
     # ------------------------------------------------------------------ element-wise
-    def binary(self, op, a, b, out=None):
-        """op 0: a+b ; op 1: a*b (same geometry).  Gradients flow to both operands."""
+    def binary(self, op, a, b, out=None, grad_alias=False):
+        """op 0: a+b ; op 1: a*b (same geometry).  Gradients flow to both operands.
+        grad_alias (op 0 only): the caller guarantees that `b` has no other consumer - the sum then keeps its gradient IN b's gradient
+        storage (d(a+b)/db = 1), so the backward pass is one accumulate into a's gradient instead of two copies."""
         assert (a.N, a.H, a.W, a.Cp) == (b.N, b.H, b.W, b.Cp) and a.dt == b.dt
         y = out if out is not None else Act(self, self.empty(a.N, a.H, a.W, a.Cp, a.dt), a.C, a.gw, a.gwp, a.dt)
         call.pn2_binary(a.dt, op, a.ptr, a.ld, b.ptr, b.ld, y.ptr, y.ld, a.M, a.Cp, 0, _stream())
+        alias = GRAD_ALIAS and bool(grad_alias) and op == 0 and out is None and b.requires_grad and self.need_grad
+        if alias:
+            y.galias = b
 
         def bwd():
             gy = y.grad_buf()
             st = _stream()
+            if alias:
+                assert not b._written, "grad_alias: the aliased operand received another gradient"
+                b.grad_written = True
             for u, v in ((a, b), (b, a)):
-                if not u.requires_grad:
+                if not u.requires_grad or (alias and u is b):
                     continue
                 gu, acc = u.grad_sink()
                 if op == 0:
@@ -1571,8 +1583,8 @@ class Engine:
         self.record(bwd)
         return y
 
-    def add(self, a, b, out=None):
-        return self.binary(0, a, b, out)
+    def add(self, a, b, out=None, grad_alias=False):
+        return self.binary(0, a, b, out, grad_alias)
 
     def mul(self, a, b, out=None):
         return self.binary(1, a, b, out)
