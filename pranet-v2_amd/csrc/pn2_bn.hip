@@ -25,45 +25,52 @@ template <typename T, int W> struct VL {   // W == VEC: 16-byte vector ; W == 1:
 };
 
 // ---------------------------------------------------------------------------------------------
-// reduce [nblk][Cp] partial rows: 8 channels x 32 row-lanes per block, accumulate in double
+// reduce [nblk][Cp] partial rows: CPB channels x (256 / CPB) row-lanes per block, accumulate in double.  CPB = 8 for short partial buffers;
+// tall ones (the stem / layer1 convs leave thousands of rows) take fewer channels per block so that every thread walks <= ~8 rows.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void reduce_partials(const float* p1, const float* p2, int nblk, int Cn, int Cp, int c, int rl, double& s1, double& s2) {
-    // Cn = channels of this BN, Cp = row stride of the partial buffers
+__device__ __forceinline__ void reduce_partials(const float* p1, const float* p2, int nblk, int Cn, int Cp, int c, int rl, int RL, double& s1, double& s2) {
+    // Cn = channels of this BN, Cp = row stride of the partial buffers, RL = row lanes
     s1 = 0.0; s2 = 0.0;
     if (c < Cn) {
         int r = rl;
-        for (; r + 96 < nblk; r += 128) {        // 4 independent row loads in flight per thread
-            const float a0 = p1[(size_t)r * Cp + c], a1 = p1[(size_t)(r + 32) * Cp + c], a2 = p1[(size_t)(r + 64) * Cp + c], a3 = p1[(size_t)(r + 96) * Cp + c];
-            const float b0 = p2[(size_t)r * Cp + c], b1 = p2[(size_t)(r + 32) * Cp + c], b2 = p2[(size_t)(r + 64) * Cp + c], b3 = p2[(size_t)(r + 96) * Cp + c];
+        for (; r + 3 * RL < nblk; r += 4 * RL) {        // 4 independent row loads in flight per thread
+            const float a0 = p1[(size_t)r * Cp + c], a1 = p1[(size_t)(r + RL) * Cp + c], a2 = p1[(size_t)(r + 2 * RL) * Cp + c], a3 = p1[(size_t)(r + 3 * RL) * Cp + c];
+            const float b0 = p2[(size_t)r * Cp + c], b1 = p2[(size_t)(r + RL) * Cp + c], b2 = p2[(size_t)(r + 2 * RL) * Cp + c], b3 = p2[(size_t)(r + 3 * RL) * Cp + c];
             s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
             s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
         }
-        for (; r < nblk; r += 32) { s1 += (double)p1[(size_t)r * Cp + c]; s2 += (double)p2[(size_t)r * Cp + c]; }
+        for (; r < nblk; r += RL) { s1 += (double)p1[(size_t)r * Cp + c]; s2 += (double)p2[(size_t)r * Cp + c]; }
     }
 }
 
-// sum (s1, s2) over the 32 row lanes that share a channel (thread = rl*8 + cl): butterfly inside each wave (8 row lanes),
-// then the 4 wave partials through LDS.  Result valid in the rl == 0 threads.  Fixed order -> deterministic.
-__device__ __forceinline__ void block_reduce_rows(double (*sh)[4][8], double& s1, double& s2) {
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+// sum (s1, s2) over the row lanes that share a channel (thread = rl*CPB + cl): butterfly inside each wave, then the 4 wave partials
+// through LDS.  Result valid in the threads < CPB.  Fixed order -> deterministic.
+__device__ __forceinline__ void block_reduce_rows(double (*sh)[4][8], int CPB, double& s1, double& s2) {
+    for (int off = CPB; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane < 8) { sh[0][wid][lane] = s1; sh[1][wid][lane] = s2; }
+    if (lane < CPB) { sh[0][wid][lane] = s1; sh[1][wid][lane] = s2; }
     __syncthreads();
-    if (threadIdx.x < 8) {
+    if ((int)threadIdx.x < CPB) {
         s1 = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
         s2 = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
     }
 }
+inline int finalize_cpb(int nblk) {
+    static const int forced = getenv("PN2_BN_FIN_CPB") ? atoi(getenv("PN2_BN_FIN_CPB")) : 0;   // experiment knob (8 = the fixed geometry)
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+    int cpb = 8;
+    while (cpb > 1 && nblk / (256 / cpb) > 8) cpb >>= 1;
+    return cpb;
+}
 
 __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ psum, const float* __restrict__ psq, int nblk, pn2_bn_desc d,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
-                                                     float* scale, float* shift, float* mean_o, float* invstd_o) {
+                                                     float* scale, float* shift, float* mean_o, float* invstd_o, int CPB) {
     __shared__ double sh[2][4][8];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
+    const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
     double s1, s2;
-    reduce_partials(psum, psq, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, s1, s2);
-    block_reduce_rows(sh, s1, s2);
+    reduce_partials(psum, psq, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, 256 / CPB, s1, s2);
+    block_reduce_rows(sh, CPB, s1, s2);
     if (rl == 0 && c < d.Cp) {
         const int lc = phys2log(c, d.gw, d.gwp, d.C);
         if (lc < 0) { scale[c] = 0.f; shift[c] = 0.f; mean_o[c] = 0.f; invstd_o[c] = 0.f; return; }
@@ -199,13 +206,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ d
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ p1, const float* __restrict__ p2, int nblk, pn2_bn_desc d,
                                                          const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                         float* dgamma, float* dbeta, int accumulate, float* coef) {
+                                                         float* dgamma, float* dbeta, int accumulate, float* coef, int CPB) {
     __shared__ double sh[2][4][8];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
+    const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
     double s1, s2;
-    reduce_partials(p1, p2, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, s1, s2);
+    reduce_partials(p1, p2, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, 256 / CPB, s1, s2);
     const int cs = d.ldp ? d.ldp : d.Cp;     // plane stride of coef
-    block_reduce_rows(sh, s1, s2);
+    block_reduce_rows(sh, CPB, s1, s2);
     if (rl == 0 && c < d.Cp) {
         const int lc = phys2log(c, d.gw, d.gwp, d.C);
         if (lc < 0) { coef[c] = 0.f; coef[cs + c] = 0.f; coef[2 * cs + c] = 0.f; return; }
@@ -435,7 +442,8 @@ extern "C" {
 int pn2_bn_finalize(const float* psum, const float* psq, int nblk, const pn2_bn_desc* d, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
     if (!psum || !psq || !d || !gamma || !beta || !scale || !shift || !mean || !invstd) return -1;
-    hipLaunchKernelGGL(bn_finalize_k, dim3((d->Cp + 7) / 8), dim3(256), 0, (hipStream_t)stream, psum, psq, nblk, *d, gamma, beta, running_mean, running_var, scale, shift, mean, invstd);
+    const int cpb = finalize_cpb(nblk);
+    hipLaunchKernelGGL(bn_finalize_k, dim3((d->Cp + cpb - 1) / cpb), dim3(256), 0, (hipStream_t)stream, psum, psq, nblk, *d, gamma, beta, running_mean, running_var, scale, shift, mean, invstd, cpb);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -483,7 +491,8 @@ int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, con
 int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn_desc* d, const float* gamma, const float* invstd,
                         float* dgamma, float* dbeta, int accumulate, float* coef, void* stream) {
     if (!p1 || !p2 || !d || !gamma || !invstd || !dgamma || !dbeta || !coef) return -1;
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((d->Cp + 7) / 8), dim3(256), 0, (hipStream_t)stream, p1, p2, nblk, *d, gamma, invstd, dgamma, dbeta, accumulate, coef);
+    const int cpb = finalize_cpb(nblk);
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((d->Cp + cpb - 1) / cpb), dim3(256), 0, (hipStream_t)stream, p1, p2, nblk, *d, gamma, invstd, dgamma, dbeta, accumulate, coef, cpb);
     PN2_CHECK_LAUNCH();
     return 0;
 }
