@@ -295,3 +295,67 @@ def test_trainer_mutation_step_matches_module_surface_and_adamw():
         torch.cuda.synchronize()
         res.append((out.clone(), tr2.flat.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+def test_depthwise_kxk_and_pair_conv_kernels_at_edge_geometries(dtn):
+    """pn2_dwconv (K = 1, 3, 5: forward with BatchNorm partial rows, mirrored data gradient, weight gradient) and pn2_pairconv3x3_* straight
+    through the C ABI against torch, at sizes that stress the row-segment walks: single pixels / rows / columns, widths that are not a multiple
+    of the segment length, channel counts that select every vector width."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from pn2.capi import call, F32, BF16
+    dt, tdt = (F32, torch.float32) if dtn == "fp32" else (BF16, torch.bfloat16)
+    tol = 2e-5 if dt == F32 else 2e-2
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    for N, H, W, Cc in ((1, 1, 1, 8), (2, 1, 29, 16), (1, 21, 1, 8), (2, 7, 33, 24), (2, 19, 18, 40), (1, 40, 52, 128)):
+        for K in (1, 3, 5):
+            x = torch.randn(N, Cc, H, W, generator=g).to(dev).to(tdt).float()
+            w = (torch.randn(Cc, 1, K, K, generator=g) * 0.4).to(dev)
+            dz = torch.randn(N, Cc, H, W, generator=g).to(dev).to(tdt).float()
+            xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+            zr = F.conv2d(xr, wr, None, 1, K // 2, groups=Cc)
+            zr.backward(dz)
+            xh, dzh = nhwc(x).to(tdt), nhwc(dz).to(tdt)
+            z = torch.empty_like(xh); dx = torch.empty_like(xh)
+            nb = call.pn2_dwconv_blocks(dt, N, H, W, Cc, K, 0)
+            ps, pq = torch.zeros(nb, Cc, device=dev), torch.zeros(nb, Cc, device=dev)
+            wf = w.reshape(Cc, K * K).contiguous()
+            call.pn2_dwconv(dt, P(xh), P(wf), P(z), N, H, W, Cc, K, 0, 0, P(ps), P(pq), st)
+            call.pn2_dwconv(dt, P(dzh), P(wf), P(dx), N, H, W, Cc, K, 1, 0, C.c_void_p(0), C.c_void_p(0), st)
+            nbw = call.pn2_dwconv_blocks(dt, N, H, W, Cc, K, 1)
+            part = torch.zeros(nbw, Cc * K * K, device=dev)
+            call.pn2_dwconv_wgrad(dt, P(dzh), P(xh), P(part), N, H, W, Cc, K, st)
+            torch.cuda.synchronize()
+            tag = (N, H, W, Cc, K)
+            assert rell2(z.float().permute(0, 3, 1, 2), zr) < tol, tag
+            assert rell2(dx.float().permute(0, 3, 1, 2), xr.grad) < tol, tag
+            assert rell2(part.sum(0).reshape(Cc, 1, K, K), wr.grad) < tol, tag
+            zs = z.float().reshape(-1, Cc)
+            assert rell2(ps.sum(0), zs.sum(0)) < 1e-4 and rell2(pq.sum(0), (zs * zs).sum(0)) < 1e-4, tag
+    for N, H, W, Fo in ((1, 1, 1, 8), (2, 1, 31, 8), (1, 17, 1, 16), (2, 9, 35, 24), (1, 33, 40, 64)):
+        x = torch.randn(N, 2 * Fo, H, W, generator=g).to(dev).to(tdt).float()
+        w = (torch.randn(Fo, 2, 3, 3, generator=g) * 0.3).to(dev)
+        dz = torch.randn(N, Fo, H, W, generator=g).to(dev).to(tdt).float()
+        xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+        zr = F.conv2d(xr, wr, None, 1, 1, groups=Fo)
+        zr.backward(dz)
+        xh, dzh = nhwc(x).to(tdt), nhwc(dz).to(tdt)
+        z = torch.empty(N, H, W, Fo, device=dev, dtype=tdt); dx = torch.empty_like(xh)
+        nb = call.pn2_pairconv_blocks(dt, N, H, W, Fo)
+        ps, pq = torch.zeros(nb, Fo, device=dev), torch.zeros(nb, Fo, device=dev)
+        wf = w.reshape(Fo, 18).contiguous()
+        call.pn2_pairconv3x3_fwd(dt, P(xh), P(wf), P(z), N, H, W, Fo, P(ps), P(pq), st)
+        call.pn2_pairconv3x3_dgrad(dt, P(dzh), P(wf), P(dx), N, H, W, Fo, 0, st)
+        part = torch.zeros(nb, Fo * 18, device=dev)
+        call.pn2_pairconv3x3_wgrad(dt, P(dzh), P(xh), P(part), N, H, W, Fo, st)
+        torch.cuda.synchronize()
+        tag = ("pair", N, H, W, Fo)
+        assert rell2(z.float().permute(0, 3, 1, 2), zr) < tol, tag
+        assert rell2(dx.float().permute(0, 3, 1, 2), xr.grad) < tol, tag
+        assert rell2(part.sum(0).reshape(Fo, 2, 3, 3), wr.grad) < tol, tag
+        zs = z.float().reshape(-1, Fo)
+        assert rell2(ps.sum(0), zs.sum(0)) < 1e-4 and rell2(pq.sum(0), (zs * zs).sum(0)) < 1e-4, tag

@@ -224,3 +224,29 @@ def test_pvt_trainer_step_and_graph_replay():
         torch.cuda.synchronize()
         res.append((loss.clone(), tr.flat.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+def test_sliding_window_depthwise_edge_geometries(dtn):
+    """The row-segment walks of the depth-wise 3x3 (+GELU) kernels at awkward sizes: one-pixel and one-row images, widths that are not a
+    multiple of the segment length, channel counts that force the narrow vector variants, large tensors that take the wide ones."""
+    torch.manual_seed(14)
+    for C_, H, W in ((8, 1, 1), (8, 1, 37), (16, 23, 1), (24, 5, 33), (40, 9, 9), (72, 17, 19), (512, 40, 47)):
+        conv = nn.Conv2d(C_, C_, 3, 1, 1, groups=C_).to(dev)
+        conv.weight.data.normal_(0, 0.4); conv.bias.data.normal_(0, 0.3)
+        x = torch.randn(2, C_, H, W, device=dev)
+        _run(dtn, lambda e, a: e.dwconv_gelu(a, conv), lambda t, w, b: F.gelu(F.conv2d(t, w, b, 1, 1, groups=C_)), x, [conv.weight, conv.bias])
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+def test_patchify_and_few_channel_strided_data_gradients(dtn):
+    """Data gradients that do not run the transposed-gather GEMM: kernel == stride convs (GEMM over the patches + depth-to-space, also when the
+    image is not a multiple of the stride: the remainder rows / columns get zero) and strided convs with <= 4 input channels (per-pixel walk
+    over the taps that land on an output pixel)."""
+    torch.manual_seed(15)
+    cases = [(64, 64, 8, 8, 0, 24, 24), (64, 64, 4, 4, 0, 22, 18), (32, 48, 2, 2, 0, 11, 13),      # patchify, incl. sizes with a remainder
+             (3, 64, 7, 4, 3, 40, 36), (3, 32, 3, 2, 1, 21, 19), (1, 16, 5, 4, 2, 33, 30), (4, 24, 3, 2, 1, 16, 16)]   # few input channels
+    for cin, cout, k, s, p, H, W in cases:
+        conv = nn.Conv2d(cin, cout, k, s, p).to(dev)
+        x = torch.randn(2, cin, H, W, device=dev)
+        _run(dtn, lambda e, a: e.conv_bias(a, conv), lambda t, w, b: F.conv2d(t, w, b, s, p), x, [conv.weight, conv.bias])
