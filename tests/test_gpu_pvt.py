@@ -250,3 +250,54 @@ def test_patchify_and_few_channel_strided_data_gradients(dtn):
         conv = nn.Conv2d(cin, cout, k, s, p).to(dev)
         x = torch.randn(2, cin, H, W, device=dev)
         _run(dtn, lambda e, a: e.conv_bias(a, conv), lambda t, w, b: F.conv2d(t, w, b, s, p), x, [conv.weight, conv.bias])
+
+
+def test_deferred_column_sums_and_splitk_match_immediate_launches(monkeypatch):
+    """pn2_colsum_multi + pn2_colsum_finalize_multi (one table-driven launch per flush) against one pn2_colsum / pn2_colsum_finalize per
+    bias, LayerNorm and depth-wise parameter: bit for bit over a PVT-PraNet-V2 training step; and the split-K launch of a few-row / long-
+    contraction conv (fp32 partial tiles + reduce with the BatchNorm statistics) against the plain launch."""
+    import ctypes as C
+    from pn2 import engine, capi
+    from pn2.capi import call, BF16
+    from pn2.trainer import Trainer
+    from oracle import weights as W
+    x, m = W.synthetic_batch(2, 96, seed=31)
+    x, m = x.to(dev), m.to(dev)
+    res = []
+    for defer in (False, True):
+        monkeypatch.setattr(engine, "DEFER_COLSUM", defer)
+        tr = Trainer(_pvt_model(fp32=False))
+        for _ in range(3):
+            loss = tr.forward_backward(x, m)
+        torch.cuda.synchronize()
+        res.append((loss.clone(), tr.gflat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # ---- split-K
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(2)
+    N, H, Wd, Cin, Cout, k = 4, 11, 11, 256, 200, 5
+    M, K = N * H * Wd, k * k * Cin
+    Kp = (K + 127) // 128 * 128
+    xin = torch.randn(M, Cin, device=dev).bfloat16()
+    wp = (torch.randn((Cout + 127) // 128 * 128, Kp, device=dev) * 0.03).bfloat16()
+    wp[Cout:] = 0; wp[:, K:] = 0
+    d = capi.ConvDesc()
+    d.N, d.H, d.W, d.OH, d.OW = N, H, Wd, H, Wd
+    d.Cin_p, d.ld_in, d.Cout, d.ld_out = Cin, Cin, Cout, Cout
+    d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.dil_h, d.dil_w = k, k, 1, 2, 2, 1, 1
+    d.transposed, d.Kp = 0, Kp
+    nb = (M + 63) // 64
+    code = 2 | (1 << 2) | (3 << 4)
+    o1 = torch.empty(M, Cout, device=dev, dtype=torch.bfloat16); o2 = torch.empty_like(o1)
+    ps1, pq1, ps2, pq2 = (torch.zeros(nb, Cout, device=dev) for _ in range(4))
+    d.flags = (code << 8) | capi.CONV_STATS
+    call.pn2_conv_gemm(BF16, P(xin), P(wp), P(o1), P(ps1), P(pq1), C.byref(d), st)
+    for S in (2, 4, 7):
+        ws = torch.empty(S, M, Cout, device=dev)
+        d.flags = (code << 8) | (S << 16)
+        call.pn2_conv_gemm(BF16, P(xin), P(wp), P(o2), P(ws), C.c_void_p(0), C.byref(d), st)
+        call.pn2_conv_splitk_reduce(BF16, P(ws), S, M, Cout, P(o2), Cout, C.c_void_p(0), P(ps2), P(pq2), 0, st)
+        torch.cuda.synchronize()
+        assert relmax(o2.float(), o1.float()) < 1e-2                      # one bf16 ulp where the fp32 sums round differently
+        assert rell2(ps2.sum(0), ps1.sum(0)) < 1e-5 and rell2(pq2.sum(0), pq1.sum(0)) < 1e-5
