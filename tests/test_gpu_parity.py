@@ -562,3 +562,31 @@ def test_full_size_properties_bs32_352_bf16():
     assert abs(float(l3[-1]) - float(l1[-1])) < 2e-2 * abs(float(l1[-1]))
     # per-image loss sums: total == sum of the four pair losses
     assert abs(float(l1[:4].sum()) - float(l1[4])) < 1e-5 * abs(float(l1[4]))
+
+
+def test_inference_predictor_graph_matches_module_eval():
+    """pn2.infer.Predictor (eval forward + MyTest_med.py:104-111 tail replayed from one hipGraph) against the nn.Module surface in eval mode
+    + pn2.evaltail.test_postprocess: same maps, same uint8 prediction, for two different images through the same captured graph."""
+    import time
+    from pn2.infer import Predictor
+    from pn2.evaltail import test_postprocess
+    model = _fixture_model(fp32=False).eval()
+    pred = Predictor(model)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for k in range(2):
+        x = torch.randn(1, 3, 96, 96, generator=g).to(dev)
+        with torch.no_grad():
+            ref = model(x)
+        outs = pred(x)
+        assert len(outs) == len(ref)
+        for a, b in zip(outs, ref):
+            assert torch.equal(a, b)
+        u8 = pred.postprocess(x, (123, 77))
+        assert torch.equal(u8, test_postprocess(ref, (123, 77)))
+    x = torch.randn(1, 3, 352, 352, generator=g).to(dev)
+    pred.postprocess(x, (500, 574)); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        pred.postprocess(x, (500, 574))
+    torch.cuda.synchronize()
+    print(f"\\ninference 1x3x352x352 + tail (hipGraph replay): {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms/image")
