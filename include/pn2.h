@@ -121,6 +121,10 @@ int pn2_bn_eval_prepare(const pn2_bn_desc* d, const float* gamma, const float* b
 /* y[m][c] = act(x[m][c]*scale[c] + shift[c] + res[m][c]) for c < Cout ; scale==NULL -> identity affine */
 int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int ld_y, int M, int Cout,
                    const float* scale, const float* shift, const void* res, int ld_res, int relu, void* stream);
+/* pn2_affine_act (same dtype, no residual) with a second output y2 = y + add: Bottle2neck's branch sum sp + spx[i] (Res2Net_v1b.py:66-68)
+ * written by the pass that produces sp.  16-byte aligned rows only (-2 otherwise). */
+int pn2_affine_act_sum(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* scale, const float* shift, int relu,
+                       const void* add, int ld_add, void* y2, int ld_y2, void* stream);
 /* backward pass 1: per-channel partials of sum(dz) and sum(dz*xhat), dz = dy*(relu mask) ; dy has Cdy valid channels.
  * ReLU mask: y>0 when y is given; else recomputed as fmaf(x,mask_scale,mask_shift)>0 when mask_scale is given (saves reading y). */
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,

@@ -262,7 +262,10 @@ constexpr int RU = 4;   // rows in flight per thread
 template <typename T>
 __global__ __launch_bounds__(256) void affine_rows_k(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int M, int C,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                                     const T* __restrict__ res, int ld_res, int relu, int rows_per_blk, int CVP) {
+                                                     const T* __restrict__ res, int ld_res, int relu, int rows_per_blk, int CVP,
+                                                     const T* __restrict__ add = nullptr, int ld_add = 0, T* __restrict__ y2 = nullptr, int ld_y2 = 0) {
+    // add / y2 (optional): second output y2 = y + add - the "sp + spx[i+1]" of Bottle2neck.forward (Res2Net_v1b.py:68) written by the pass
+    // that produces sp instead of by a separate element-wise launch
     constexpr int V = TT<T>::VEC;
     const int CV = C / V, R = 256 / CVP;
     const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
@@ -296,7 +299,16 @@ __global__ __launch_bounds__(256) void affine_rows_k(const T* __restrict__ x, in
                         if (res) t += r[e];
                         v[e] = relu ? (relu == 2 ? fminf(fmaxf(t, 0.f), 6.f) : fmaxf(t, 0.f)) : t;
                     }
-                    *reinterpret_cast<uint4*>(y + (size_t)mm * ld_y + c) = TT<T>::pack(v);
+                    const uint4 pk = TT<T>::pack(v);
+                    *reinterpret_cast<uint4*>(y + (size_t)mm * ld_y + c) = pk;
+                    if (y2) {                     // sum of the STORED (rounded) y and the other operand, as a separate add of the two tensors gives
+                        float a[V];
+                        TT<T>::unpack(pk, v);
+                        TT<T>::unpack(*reinterpret_cast<const uint4*>(add + (size_t)mm * ld_add + c), a);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) v[e] += a[e];
+                        *reinterpret_cast<uint4*>(y2 + (size_t)mm * ld_y2 + c) = TT<T>::pack(v);
+                    }
                 }
             }
         }
@@ -508,6 +520,26 @@ int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, cons
     if (dt == PN2_BF16 && dt_dy == PN2_F32) return bwd_apply_dispatch<bf16_t, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, relu6, st);
     if (dt == PN2_F32 && dt_dy == PN2_F32) return bwd_apply_dispatch<float, float>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, mask_scale, mask_shift, relu6, st);
     return -3;
+}
+
+
+/* pn2_affine_act (same dtype in / out, no residual) with a second output y2 = y + add: the branch sum of Bottle2neck.forward
+ * (Res2Net_v1b.py:66-68, sp = sp + spx[i]) produced by the pass that writes sp.  16-byte aligned rows only (-2 otherwise). */
+int pn2_affine_act_sum(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* scale, const float* shift, int relu,
+                       const void* add, int ld_add, void* y2, int ld_y2, void* stream) {
+    if (!x || !y || !add || !y2) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (C % V || ld_x % V || ld_y % V || ld_add % V || ld_y2 % V) return -2;
+    int cvp, rpb, nblk;
+    rows_geometry(M, C / V, cvp, rpb, nblk);
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((affine_rows_k<bf16_t>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, ld_x, (bf16_t*)y, ld_y, M, C, scale, shift, (const bf16_t*)nullptr, 0, relu, rpb, cvp,
+                                           (const bf16_t*)add, ld_add, (bf16_t*)y2, ld_y2);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((affine_rows_k<float>), dim3(nblk), dim3(256), 0, st, (const float*)x, ld_x, (float*)y, ld_y, M, C, scale, shift, (const float*)nullptr, 0, relu, rpb, cvp,
+                                               (const float*)add, ld_add, (float*)y2, ld_y2);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
 }
 
 }  // extern "C"

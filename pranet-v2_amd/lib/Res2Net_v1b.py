@@ -51,11 +51,16 @@ class Bottle2neck(nn.Module):
         OH = (out1.H + 2 - 3) // stride + 1
         OW = (out1.W + 2 - 3) // stride + 1
         cat = eng.new_act(out1.N, OH, OW, w * sc, w, wp)
-        sp = None
+        s_in = spx[0]
         for i in range(self.nums):
-            # spx[i] feeds only this sum: its gradient slice of out1 doubles as the sum's gradient buffer (no copy in the backward pass)
-            s_in = spx[i] if (i == 0 or stage) else eng.add(sp, spx[i], grad_alias=True)
-            sp = eng.conv_bn_act(s_in, self.convs[i], self.bns[i], relu=True, out=cat.slice(i * wp, (i + 1) * wp, w, w, wp), out_map=(w, wp))
+            # sp_i = relu(bn(conv(s_in))) goes into the concat buffer; the next branch's input sp_i + spx[i+1] (Res2Net_v1b.py:66-68) is written
+            # by the same pass (spx[i+1] feeds only that sum: its slice of conv1's gradient doubles as the sum's gradient buffer)
+            nxt = spx[i + 1] if (i + 1 < self.nums and not stage) else None
+            r = eng.conv_bn_act(s_in, self.convs[i], self.bns[i], relu=True, out=cat.slice(i * wp, (i + 1) * wp, w, w, wp), out_map=(w, wp), sum_with=nxt)
+            if nxt is not None:
+                s_in = r[1]
+            elif i + 1 < self.nums:
+                s_in = spx[i + 1]
         last = cat.slice(self.nums * wp, sc * wp, w, w, wp)
         if stage:
             eng.avgpool(spx[self.nums], 3, stride, 1, out=last)

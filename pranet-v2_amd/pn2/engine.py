@@ -660,13 +660,15 @@ class Engine:
         return best
 
     # ------------------------------------------------------------------ conv (+BN +ReLU +residual)
-    def conv_bn_act(self, x, conv, bn=None, relu=False, residual=None, out=None, out_map=None, y_dt=None, y_C=None, bias=None):
+    def conv_bn_act(self, x, conv, bn=None, relu=False, residual=None, out=None, out_map=None, y_dt=None, y_C=None, bias=None, sum_with=None):
         """y = act(BN(conv(x)) + residual)   — BasicConv2d / Bottle2neck pieces.
 
         conv: nn.Conv2d (bias-free unless `bias` given), bn: nn.BatchNorm2d or None.
         out: optional destination Act view (writes y into a slice of a concat buffer).
         out_map: (gw, gwp) group-padded layout of the produced channels (default identity).
         y_dt/y_C: fp32 K-channel head outputs (physical raw output stays padded to 8).
+        sum_with: an Act of the output's geometry that has no other consumer; returns (y, y + sum_with) - the second tensor (Bottle2neck's
+                  sp + spx[i+1]) is written by the same pass and keeps its gradient in sum_with's gradient storage.
         """
         w = conv.weight
         Cout, Cin, KH, KW = _w4(w)
@@ -767,15 +769,35 @@ class Engine:
         ncopy = y_C if y_C is not None else Cout_p
         if residual is not None:
             assert residual.Cp == Cout_p and residual.dt == self.dt
-        if not fuse_bias:
+        y2 = None
+        if sum_with is not None and (fuse_bias or residual is not None or y_dt != self.dt or ncopy != Cout_p or sum_with.dt != self.dt
+                                     or (sum_with.N, sum_with.H, sum_with.W, sum_with.Cp) != (N, OH, OW, Cout_p) or out.ld % 8 or sum_with.ld % 8):
+            raise RuntimeError("sum_with needs a plain same-dtype BN/activation output of the same geometry")
+        if sum_with is not None:
+            y2 = Act(self, self.empty(N, OH, OW, Cout_p), Cout, gw_o, gwp_o, self.dt)
+            call.pn2_affine_act_sum(self.dt, _p(raw), Cout_p, out.ptr, out.ld, M, Cout_p, _p(scale), _p(shift), (2 if relu == 2 else 1) if relu else 0,
+                                    sum_with.ptr, sum_with.ld, y2.ptr, y2.ld, st)
+            if self.need_grad and sum_with.requires_grad:
+                y2.galias = sum_with            # d(y + s)/ds = 1 and s has no other consumer: the sum's gradient lives in s's gradient storage
+        elif not fuse_bias:
             call.pn2_affine_act(self.dt, _p(raw), Cout_p, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
                                 residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
 
         if not self.need_grad:
-            return out
+            return out if y2 is None else (out, y2)
 
         def bwd():
             st = _stream()
+            if y2 is not None and y2.grad_written:          # the sum's gradient also flows into y (the other operand holds it already)
+                if y2.galias is not None:
+                    assert not sum_with._written, "sum_with: the aliased operand received another gradient"
+                    sum_with.grad_written = True
+                g2 = y2.grad_buf()
+                go, oacc = out.grad_sink()
+                call.pn2_copy(self.dt, _p(g2), g2.stride(2), self.dt, _p(go), go.stride(2), M, Cout_p, oacc, st)
+                if y2.galias is None and sum_with.requires_grad:
+                    gs, sacc = sum_with.grad_sink()
+                    call.pn2_copy(self.dt, _p(g2), g2.stride(2), self.dt, _p(gs), gs.stride(2), M, Cout_p, sacc, st)
             dy = out.grad_buf()
             assert out.grad_written or out.child_written, "conv output never received a gradient"
             draw = self.empty(N, OH, OW, Cout_p)
@@ -896,7 +918,7 @@ class Engine:
                     call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
 
         self.record(bwd)
-        return out
+        return out if y2 is None else (out, y2)
 
     # ------------------------------------------------------------------ fused 1x1 reducers sharing one input
     def conv_bn_multi(self, x, mods):
