@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void ln_fwd_k(const T* __restrict__ x, int ld_
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ;  partial dgamma / dbeta rows per block
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, int ld_dy, const T* __restrict__ x, int ld_x, int M, int C, const float* __restrict__ gamma,
                                                 const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx, int ld_dx, int acc_dx,
                                                 float* __restrict__ pg, float* __restrict__ pb, int rows_per_blk, int LPR) {
@@ -76,24 +76,53 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, int ld
     const int nslot = 4 * rpw;
     const int r0 = blockIdx.x * rows_per_blk;
     int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
-    float ag[LN_NV][V], ab[LN_NV][V], gm[LN_NV][V];
+    float ag[NV][V], ab[NV][V], gm[NV][V];
 #pragma unroll
-    for (int k = 0; k < LN_NV; ++k)
+    for (int k = 0; k < NV; ++k)
 #pragma unroll
         for (int e = 0; e < V; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; const int c = (lr + k * LPR) * V + e; gm[k][e] = c < C ? gamma[c] : 0.f; }
+    // the next row's vectors are fetched before the current row is reduced: the rows of a slot form a dependent chain (load -> two lane
+    // reductions -> store), and without the prefetch every link pays the full memory latency
+    uint4 nd[NV], nx[NV];
+    float nmu = 0.f, nrs = 0.f;
+    {
+        const int row = r0 + slot;
+        if (row < r1) {
+            nmu = mean[row]; nrs = rstd[row];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int cv = lr + k * LPR;
+                if (cv < CV) { nd[k] = *reinterpret_cast<const uint4*>(dy + (size_t)row * ld_dy + cv * V); nx[k] = *reinterpret_cast<const uint4*>(x + (size_t)row * ld_x + cv * V); }
+            }
+        }
+    }
     for (int rb = r0; rb < r1; rb += nslot) {           // uniform trip count: the shuffles below need every lane
         const int row = rb + slot;
         const bool live = row < r1;
-        float g[LN_NV][V], xh[LN_NV][V];
-        float s1 = 0.f, s2 = 0.f;
-        const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
+        uint4 cd[NV], cx[NV];
 #pragma unroll
-        for (int k = 0; k < LN_NV; ++k) {
+        for (int k = 0; k < NV; ++k) { cd[k] = nd[k]; cx[k] = nx[k]; }
+        const float mu = live ? nmu : 0.f, rs = live ? nrs : 0.f;
+        {
+            const int rown = row + nslot;
+            if (rown < r1) {
+                nmu = mean[rown]; nrs = rstd[rown];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int cv = lr + k * LPR;
+                    if (cv < CV) { nd[k] = *reinterpret_cast<const uint4*>(dy + (size_t)rown * ld_dy + cv * V); nx[k] = *reinterpret_cast<const uint4*>(x + (size_t)rown * ld_x + cv * V); }
+                }
+            }
+        }
+        float g[NV][V], xh[NV][V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
             const int cv = lr + k * LPR;
             if (live && cv < CV) {
                 float d[V], xv[V];
-                ldv<T>(dy + (size_t)row * ld_dy + cv * V, d);
-                ldv<T>(x + (size_t)row * ld_x + cv * V, xv);
+                TT<T>::unpack(cd[k], d);
+                TT<T>::unpack(cx[k], xv);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     xh[k][e] = (xv[e] - mu) * rs; g[k][e] = d[e] * gm[k][e];
@@ -105,7 +134,7 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, int ld
         for (int o = 1; o < LPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
         const float c1 = s1 / (float)C, c2 = s2 / (float)C;
 #pragma unroll
-        for (int k = 0; k < LN_NV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int cv = lr + k * LPR;
             if (live && cv < CV) {
                 float o[V];
@@ -120,7 +149,7 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, int ld
     // block partial of dgamma / dbeta: every slot owns the same channels -> sum the slots in a fixed order through LDS
     float* sg = sh; float* sb = sh + nslot * C;
 #pragma unroll
-    for (int k = 0; k < LN_NV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int cv = lr + k * LPR;
         if (cv < CV) {
 #pragma unroll
@@ -925,7 +954,10 @@ int pn2_layernorm_bwd(int dt, const void* dy, int ld_dy, const void* x, int ld_x
     if ((M + rows - 1) / rows != nblk) return -2;          // nblk must be pn2_rows_blocks(M, pn2_ln_slots(dt, C))
     const size_t lds = (size_t)2 * nslot * C * 4;
     if (lds > 64 * 1024) return -2;
-    VIT_DISPATCH(dt, { hipLaunchKernelGGL(ln_bwd_k<T>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)x, ld_x, M, C, gamma, mean, rstd,
+    const bool nv1 = C / (dt == PN2_F32 ? 4 : 8) <= lpr;          // one channel vector per lane (C <= 512 bf16 / 256 fp32): the lean instantiation
+    VIT_DISPATCH(dt, { if (nv1) hipLaunchKernelGGL((ln_bwd_k<T, 1>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)x, ld_x, M, C, gamma, mean, rstd,
+                                          (T*)dx, ld_dx, accumulate_dx, pg, pb, rows, lpr);
+                       else hipLaunchKernelGGL((ln_bwd_k<T, LN_NV>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)x, ld_x, M, C, gamma, mean, rstd,
                                           (T*)dx, ld_dx, accumulate_dx, pg, pb, rows, lpr); })
     PN2_CHECK_LAUNCH();
     return 0;
