@@ -304,6 +304,9 @@ class GradQueue:
                 raise RuntimeError("unsupported wgrad geometry")
             groups.setdefault((dt, v), []).append((dy, x, slab, wd, ns, fl))
         for (dt, v), js in sorted(groups.items()):
+            # longest workgroups first (pixels per split x taps): the hardware hands out workgroups in index order, so the short jobs fill the
+            # tail of the launch instead of the long ones stretching it
+            js = sorted(js, key=lambda j: -((j[3].N * j[3].OH * j[3].OW + j[4] - 1) // j[4]) * j[3].KH * j[3].KW)
             arr = []
             for dy, x, slab, wd, ns, fl in js:
                 j = capi.WgradJob()
