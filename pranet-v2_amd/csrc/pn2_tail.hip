@@ -176,11 +176,26 @@ __global__ void loss_finalize_k(const float* __restrict__ partial, int P, int N,
     __shared__ float per[64 * 8];                  // per (p,n) loss term
     __shared__ double acc[64 * 8 * 5];             // per (p,n,j) band sums: one thread each (the band loop of one thread per (p,n) took 17 us)
     const int t = threadIdx.x;
-    for (int idx = t; idx < P * N * 5; idx += blockDim.x) {
-        const int pn = idx / 5, j = idx - pn * 5;
+    // 4 adjacent lanes share one (p,n,j) band sum (bands b = q, q+4, ...; 8 loads in flight per lane), combined in a fixed order:
+    // one lane per sum walked the bands in 26 us of dependent-latency loads
+    for (int it = t; it < ((P * N * 5 * 4 + 63) & ~63); it += blockDim.x) {
+        const int idx = it >> 2, q = it & 3;
         double a = 0.0;
-        for (int b = 0; b < nb; ++b) a += (double)partial[((size_t)pn * nb + b) * 5 + j];
-        acc[idx] = a;
+        if (idx < P * N * 5) {
+            const int pn = idx / 5, j = idx - pn * 5;
+            const float* src = partial + (size_t)pn * nb * 5 + j;
+            int b = q;
+            for (; b + 28 < nb; b += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + 4 * u) * 5];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (double)v[u];
+            }
+            for (; b < nb; b += 4) a += (double)src[(size_t)b * 5];
+        }
+        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+        if (q == 0 && idx < P * N * 5) acc[idx] = a;
     }
     __syncthreads();
     if (t < P * N) {
@@ -225,6 +240,7 @@ __global__ __launch_bounds__(256) void loss_bwd_k(const float* __restrict__ pred
 
 // ------------------------------------------------------------------------------------------ fused DSRA tail (K = 1)
 constexpr int TRB = 8;          // output rows per forward block
+__device__ __forceinline__ int pn2_dsra_tail_blocks_dev(int OH) { return (OH + TRB - 1) / TRB; }
 
 // 4 consecutive output pixels (oy, ox..ox+3) of one lateral map from its low-res rows staged in LDS (rows ylo.. of width mp.w);
 // same expression as bilinear_fwd_k
@@ -398,6 +414,281 @@ __global__ __launch_bounds__(256) void tail_bwd_k(pn2_tail_desc d, tail_groups G
     }
 }
 
+// ------------------------------------------------------------------------------------------ fused DSRA tail, band kernels
+// Used when every lateral map is magnified by more than TRB-1 (x8 / x16 / x32 in pranet.py:354,371,393,415): a band of TRB output rows then
+// touches at most 3 low-res rows of a map.  One block = (geometry group, row band, image).  The band's TRB vertically interpolated low-res
+// rows are staged in LDS once ([map][row][w+1], last column duplicated so the right tap is always x0+1); a thread owns 4 output columns, keeps
+// their horizontal taps in registers and walks the band's rows: 2 LDS reads + 2 flops per logit instead of the full 4-tap index math.
+// Backward: the same walk forms dL/dlogit once per pixel (the row-per-block kernel above visits every pixel twice per geometry), folds the
+// vertical adjoint into <= 3 slot accumulators, meets the other row lanes in LDS in a fixed order, applies the horizontal adjoint with the
+// tap weight shared by the group's maps, and leaves one partial row set per band; tail_band_fin_k sums the <= 3 bands that touch a low-res
+// row, again in a fixed order (deterministic, no atomics).
+// single-instruction transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, <= 1 ulp each): __expf / __logf / __frcp_rn expand to 10-instruction
+// denormal-safe / correctly rounded sequences, which made the walk ALU-bound.  Arguments here are e^-|z| in (0, 1] and 1 + e in [1, 2].
+__device__ __forceinline__ float hw_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
+__device__ __forceinline__ float hw_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718f; }
+__device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+struct tail_band_aux { int poff[PN2_TAIL_MAX_MAPS]; int ptot; int R; int nbn; };
+constexpr int TBM = 2;          // maps per band block: 24 slot accumulators in the backward, every block the same weight
+
+template <int CTRL> __device__ __forceinline__ float tdpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a DPP row (row_ror:8/4/2/1 fold into v_add_f32_dpp, no LDS permutes); every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += tdpp<0x128>(v); v += tdpp<0x124>(v); v += tdpp<0x122>(v); v += tdpp<0x121>(v);
+    return v;
+}
+
+// XCD-aware work order: workgroup i runs on XCD i % 8, so the groups of one (band, image) take consecutive slots of ONE XCD and share
+// its L2 for the mask / weit rows.  Returns false for the padding blocks of the last 8-wide stripe.
+__device__ __forceinline__ bool tail_band_ids(int ng, int nbn, int nb, int& g, int& band, int& n) {
+    const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
+    g = k % ng;
+    const int bn = (k / ng) * 8 + xcd;
+    if (bn >= nbn) return false;
+    n = bn / nb; band = bn - n * nb;
+    return true;
+}
+
+// stage v[q][r][0..w] = ly0*src[y0][x] + ly1*src[y1][x] for the rows of the band ([TBM][TRB][w+1]); slot weights of row r towards low-res
+// rows ylo..ylo+2.  A (map, row) pair takes a power-of-two lane segment >= w+1, so the index math is shifts and masks.
+__device__ __forceinline__ void tail_band_stage(const pn2_tail_desc& d, const tail_groups& G, int g, int n, int oyA, int rows, float* v, float* wslot) {
+    const pn2_tail_map& m0 = d.maps[G.idx[g][0]];
+    const int h = m0.h, w = m0.w, wp = w + 1, ac = d.align_corners, nm = G.nm[g];
+    int ylo, t1; float t2, t3;
+    bl_src(oyA, m0.rh, ac, h, ylo, t1, t2, t3);
+    int sh = 2; while ((1 << sh) < wp && sh < 6) ++sh;
+    const int seg = 1 << sh, x0 = threadIdx.x & (seg - 1), item0 = threadIdx.x >> sh, items = blockDim.x >> sh;
+    const float* s0 = d.maps[G.idx[g][0]].src + (size_t)n * h * w;
+    const float* s1 = d.maps[G.idx[g][1]].src + (size_t)n * h * w;
+    for (int it = item0; it < nm * TRB; it += items) {
+        const int q = it >> 3, r = it & (TRB - 1);
+        if (r >= rows) continue;
+        int y0, y1; float l0, l1;
+        bl_src(oyA + r, m0.rh, ac, h, y0, y1, l0, l1);
+        const float* src = q ? s1 : s0;
+        for (int x = x0; x < wp; x += seg) {
+            const int xs = x < w ? x : w - 1;
+            v[it * wp + x] = l0 * src[y0 * w + xs] + l1 * src[y1 * w + xs];
+        }
+    }
+    if (wslot && (int)threadIdx.x < rows) {
+        int y0, y1; float l0, l1;
+        bl_src(oyA + threadIdx.x, m0.rh, ac, h, y0, y1, l0, l1);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) wslot[threadIdx.x * 3 + s] = (y0 - ylo == s ? l0 : 0.f) + (y1 - ylo == s ? l1 : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void tail_band_fwd_k(pn2_tail_desc d, tail_groups G, tail_band_aux A, float* __restrict__ lat, const float* __restrict__ mask,
+                                                       const float* __restrict__ weit, float* __restrict__ partial) {
+    extern __shared__ float lds[];
+    __shared__ float red[3 * TBM + 2][16];
+    const int nb = pn2_dsra_tail_blocks_dev(d.OH), ac = d.align_corners, P = d.P, R = A.R;
+    int g, band, n;
+    if (!tail_band_ids(G.ng, A.nbn, nb, g, band, n)) return;
+    const int nm = G.nm[g];
+    const pn2_tail_map& m0 = d.maps[G.idx[g][0]];
+    const int w = m0.w, wp = w + 1, OW = d.OW, LV = OW >> 2;
+    const int oyA = band * TRB, rows = min(TRB, d.OH - oyA);
+    tail_band_stage(d, G, g, n, oyA, rows, lds, nullptr);
+    __syncthreads();
+    const int rl = threadIdx.x / LV, jv = threadIdx.x - rl * LV;
+    float acc[TBM][3], wacc = 0.f, mwacc = 0.f;
+#pragma unroll
+    for (int q = 0; q < TBM; ++q) { acc[q][0] = 0.f; acc[q][1] = 0.f; acc[q][2] = 0.f; }
+    int isbg[TBM]; size_t mapoff[TBM];
+    const size_t img = (size_t)d.OH * OW;
+#pragma unroll
+    for (int q = 0; q < TBM; ++q) { const int j = G.idx[g][q]; isbg[q] = j >= P; mapoff[q] = (size_t)j * d.N * img; }
+    if (rl < R) {
+        int xo[4]; float lx0[4], lx1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { int x1; bl_src(jv * 4 + e, m0.rw, ac, w, xo[e], x1, lx0[e], lx1[e]); }
+        for (int r = rl; r < rows; r += R) {
+            const size_t pix = (size_t)n * img + (size_t)(oyA + r) * OW + jv * 4;
+            const float4 m4 = *reinterpret_cast<const float4*>(mask + pix), w4 = *reinterpret_cast<const float4*>(weit + pix);
+            const float wt[4] = {w4.x, w4.y, w4.z, w4.w};
+            const float mw[4] = {m4.x * w4.x, m4.y * w4.y, m4.z * w4.z, m4.w * w4.w};
+            wacc += (wt[0] + wt[1]) + (wt[2] + wt[3]); mwacc += (mw[0] + mw[1]) + (mw[2] + mw[3]);
+#pragma unroll
+            for (int q = 0; q < TBM; ++q) {
+                if (q < nm) {
+                    const float* vr = lds + (q * TRB + r) * wp;
+                    float z[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[e] = lx0[e] * vr[xo[e]] + lx1[e] * vr[xo[e] + 1];
+                    *reinterpret_cast<float4*>(lat + mapoff[q] + pix) = make_float4(z[0], z[1], z[2], z[3]);
+                    if (isbg[q]) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {       // w * (softplus(b) - b*(1-m))
+                            const float sp = fmaxf(z[e], 0.f) + hw_log(1.f + hw_exp(-fabsf(z[e])));
+                            acc[q][0] += wt[e] * sp - z[e] * (wt[e] - mw[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float ex = hw_exp(-fabsf(z[e])), rr = hw_rcp(1.f + ex), pr = z[e] >= 0.f ? rr : ex * rr;
+                            const float sp = fmaxf(z[e], 0.f) - hw_log(rr);          // log(1 + ex) = -log(1 / (1 + ex))
+                            acc[q][0] += wt[e] * sp - z[e] * mw[e]; acc[q][1] += pr * mw[e]; acc[q][2] += pr * wt[e];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // 16-lane DPP sums, then the <= 16 row partials of the block meet in LDS (fixed order)
+    const int rrow = threadIdx.x >> 4, nrow = blockDim.x >> 4;
+    const bool rlead = (threadIdx.x & 15) == 0;
+#pragma unroll
+    for (int q = 0; q < TBM; ++q)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float s = row16_sum(acc[q][k]); if (rlead) red[q * 3 + k][rrow] = s; }
+    { const float s = row16_sum(wacc); if (rlead) red[3 * TBM][rrow] = s; }
+    { const float s = row16_sum(mwacc); if (rlead) red[3 * TBM + 1][rrow] = s; }
+    __syncthreads();
+    if (threadIdx.x < 4 * nm) {          // partial[p][n][band][5] = {w*bce_fg, w*bce_bg, p*m*w, (p+m)*w, w}
+        const int q = threadIdx.x >> 2, k = threadIdx.x & 3, j = G.idx[g][q];
+        auto tot = [&](int row) { float s = red[row][0]; for (int i = 1; i < nrow; ++i) s += red[row][i]; return s; };
+        if (j >= P) { if (k == 0) partial[(((size_t)(j - P) * d.N + n) * nb + band) * 5 + 1] = tot(q * 3); }
+        else {
+            float* dst = partial + (((size_t)j * d.N + n) * nb + band) * 5;
+            if (k == 0) dst[0] = tot(q * 3);
+            else if (k == 1) dst[2] = tot(q * 3 + 1);
+            else if (k == 2) dst[3] = tot(q * 3 + 2) + tot(3 * TBM + 1);
+            else dst[4] = tot(3 * TBM);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tail_band_bwd_k(pn2_tail_desc d, tail_groups G, tail_band_aux A, const float* __restrict__ mask,
+                                                       const float* __restrict__ weit, const float* __restrict__ wsum, const float* __restrict__ sums,
+                                                       float gscale, float* __restrict__ pbuf) {
+    extern __shared__ float lds[];          // v[TBM][TRB][w+1] | wslot[TRB][3] | col[nm][3][OW]
+    const int nb = pn2_dsra_tail_blocks_dev(d.OH), ac = d.align_corners, P = d.P, R = A.R;
+    int g, band, n;
+    if (!tail_band_ids(G.ng, A.nbn, nb, g, band, n)) return;
+    const int nm = G.nm[g];
+    const pn2_tail_map& m0 = d.maps[G.idx[g][0]];
+    const int w = m0.w, wp = w + 1, OW = d.OW, LV = OW >> 2;
+    const int oyA = band * TRB, rows = min(TRB, d.OH - oyA);
+    float* wslot = lds + ((TBM * TRB * wp + 3) & ~3);
+    float* col = wslot + TRB * 3;
+    tail_band_stage(d, G, g, n, oyA, rows, lds, wslot);
+    __syncthreads();
+    const int rl = threadIdx.x / LV, jv = threadIdx.x - rl * LV;
+    const size_t img = (size_t)d.OH * OW;
+    const float gs = gscale / (float)d.N, gw = gs / wsum[n];
+    // per-map constants of this image: fg  dl = gw*(wt*pr - mw) + (cA*(wt-mw) - cB*mw) * pr*(1-pr) ;  bg  dl = 0.8*gw*(wt*pb - (wt-mw))
+    float cA[TBM], cB[TBM]; int isbg[TBM];
+#pragma unroll
+    for (int q = 0; q < TBM; ++q) {
+        const int j = G.idx[g][q], p = j >= P ? j - P : j;
+        const float* s = sums + ((size_t)p * d.N + n) * 4;
+        const float I1 = s[2] + 1.f, D = s[3] - s[2] + 1.f, invD2 = 1.f / (D * D);
+        cA[q] = gs * I1 * invD2; cB[q] = gs * D * invD2; isbg[q] = j >= P;
+    }
+    float a[TBM][3][4];
+#pragma unroll
+    for (int q = 0; q < TBM; ++q)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { a[q][s][0] = 0.f; a[q][s][1] = 0.f; a[q][s][2] = 0.f; a[q][s][3] = 0.f; }
+    if (rl < R) {
+        int xo[4]; float lx0[4], lx1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { int x1; bl_src(jv * 4 + e, m0.rw, ac, w, xo[e], x1, lx0[e], lx1[e]); }
+        for (int r = rl; r < rows; r += R) {
+            const size_t pix = (size_t)n * img + (size_t)(oyA + r) * OW + jv * 4;
+            const float4 m4 = *reinterpret_cast<const float4*>(mask + pix), w4 = *reinterpret_cast<const float4*>(weit + pix);
+            const float wt[4] = {w4.x, w4.y, w4.z, w4.w};
+            const float mw[4] = {m4.x * w4.x, m4.y * w4.y, m4.z * w4.z, m4.w * w4.w};
+            const float ws0 = wslot[r * 3], ws1 = wslot[r * 3 + 1], ws2 = wslot[r * 3 + 2];
+#pragma unroll
+            for (int q = 0; q < TBM; ++q) {
+                if (q < nm) {
+                    const float* vr = lds + (q * TRB + r) * wp;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z = lx0[e] * vr[xo[e]] + lx1[e] * vr[xo[e] + 1];
+                        const float ex = hw_exp(-fabsf(z)), rr = hw_rcp(1.f + ex), pr = z >= 0.f ? rr : ex * rr;
+                        const float u = wt[e] - mw[e];
+                        float dl;
+                        if (isbg[q]) dl = 0.8f * gw * (wt[e] * pr - u);
+                        else dl = gw * (wt[e] * pr - mw[e]) + (cA[q] * u - cB[q] * mw[e]) * (pr - pr * pr);
+                        a[q][0][e] += ws0 * dl; a[q][1][e] += ws1 * dl; a[q][2][e] += ws2 * dl;
+                    }
+                }
+            }
+        }
+    }
+    for (int r = 0; r < R; ++r) {              // the row lanes meet in a fixed order
+        if (rl == r) {
+#pragma unroll
+            for (int q = 0; q < TBM; ++q) {
+                if (q < nm) {
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        float4* c4 = reinterpret_cast<float4*>(col + (q * 3 + s) * OW) + jv;
+                        if (r == 0) *c4 = make_float4(a[q][s][0], a[q][s][1], a[q][s][2], a[q][s][3]);
+                        else { float4 o = *c4; o.x += a[q][s][0]; o.y += a[q][s][1]; o.z += a[q][s][2]; o.w += a[q][s][3]; *c4 = o; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // horizontal adjoint: PW lanes share one low-res column, the tap weight of an output column is shared by the block's maps and slots
+    int PW = 1; while (PW * 2 * w <= (int)blockDim.x && PW < 64) PW <<= 1;
+    const int ix = threadIdx.x / PW, part = threadIdx.x - ix * PW;
+    float sacc[TBM][3];
+#pragma unroll
+    for (int q = 0; q < TBM; ++q) { sacc[q][0] = 0.f; sacc[q][1] = 0.f; sacc[q][2] = 0.f; }
+    if (ix < w) {
+        int ox0, ox1;
+        bl_range(ix, m0.rw, ac, OW, ox0, ox1);
+        for (int ox = ox0 + part; ox <= ox1; ox += PW) {
+            int x0, x1; float l0, l1;
+            bl_src(ox, m0.rw, ac, w, x0, x1, l0, l1);
+            const float wx = (x0 == ix ? l0 : 0.f) + (x1 == ix ? l1 : 0.f);
+#pragma unroll
+            for (int q = 0; q < TBM; ++q)
+                if (q < nm) { sacc[q][0] += wx * col[(q * 3) * OW + ox]; sacc[q][1] += wx * col[(q * 3 + 1) * OW + ox]; sacc[q][2] += wx * col[(q * 3 + 2) * OW + ox]; }
+        }
+    }
+    for (int o = PW >> 1; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < TBM; ++q) { sacc[q][0] += __shfl_xor(sacc[q][0], o); sacc[q][1] += __shfl_xor(sacc[q][1], o); sacc[q][2] += __shfl_xor(sacc[q][2], o); }
+    if (ix < w && part == 0) {
+        float* base = pbuf + ((size_t)n * nb + band) * A.ptot;
+#pragma unroll
+        for (int q = 0; q < TBM; ++q)
+            if (q < nm) { float* dst = base + A.poff[G.idx[g][q]] + ix; dst[0] = sacc[q][0]; dst[w] = sacc[q][1]; dst[2 * w] = sacc[q][2]; }
+    }
+}
+
+// dsrc[j][n][y][x] = sum over the bands whose rows touch low-res row y (ascending band order)
+__global__ __launch_bounds__(256) void tail_band_fin_k(pn2_tail_desc d, tail_band_aux A, const float* __restrict__ pbuf, int nb) {
+    const int j = blockIdx.y, local = blockIdx.x * 256 + threadIdx.x;        // the map is uniform per block: its descriptor stays in SGPRs
+    const pn2_tail_map& mp = d.maps[j];
+    const int h = mp.h, w = mp.w, ac = d.align_corners;
+    if (local >= d.N * h * w) return;
+    const int n = local / (h * w), rem = local - n * h * w, y = rem / w, x = rem - y * w;
+    int oy0, oy1;
+    bl_range(y, mp.rh, ac, d.OH, oy0, oy1);
+    float s = 0.f;
+    for (int b = oy0 / TRB; b <= oy1 / TRB; ++b) {
+        const int oyA = b * TRB, oyB = min(oyA + TRB - 1, d.OH - 1);
+        int ylo, yhi, t; float t0, t1;
+        bl_src(oyA, mp.rh, ac, h, ylo, t, t0, t1);
+        bl_src(oyB, mp.rh, ac, h, t, yhi, t0, t1);
+        if (y >= ylo && y <= yhi) s += pbuf[((size_t)n * nb + b) * A.ptot + A.poff[j] + (y - ylo) * w + x];
+    }
+    float* dst = mp.dsrc + local;
+    *dst = mp.accumulate ? *dst + s : s;
+}
+
 // ------------------------------------------------------------------------------------------ clamp + Adam
 __global__ void adam_tick_k(float* bc, float b1, float b2) {
     // bc = {1-b1^t, 1-b2^t, b1^t, b2^t}; host initialises {0,0,1,1}
@@ -537,7 +828,7 @@ int pn2_structure_loss_fwd(const float* preds, long long map_stride, int P, cons
     if (P * N > 512 || P > 8) return -2;
     const int nb = pn2_loss_blocks(HW);
     hipLaunchKernelGGL(loss_fwd_k, dim3(nb, N, P), dim3(256), 0, (hipStream_t)stream, preds, map_stride, P, mask, weit, partial, N, HW);
-    hipLaunchKernelGGL(loss_finalize_k, dim3(1), dim3(512), 0, (hipStream_t)stream, partial, P, N, nb, sums, wsum, loss);
+    hipLaunchKernelGGL(loss_finalize_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, P, N, nb, sums, wsum, loss);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -589,42 +880,17 @@ static int tail_check(const pn2_tail_desc* d) {
     return 0;
 }
 
-int pn2_dsra_tail_fwd(const pn2_tail_desc* d, float* lat, const float* mask, const float* weit, float* partial,
-                      float* sums, float* wsum, float* loss, void* stream) {
-    if (!lat || !mask || !weit || !partial || !sums || !wsum || !loss) return -1;
-    if (int rc = tail_check(d)) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    size_t lds = 0;
-    for (int j = 0; j < 2 * d->P; ++j) lds += (size_t)((int)(TRB * d->maps[j].rh) + 3) * d->maps[j].w * 4;
-    if (lds > 60 * 1024) return -2;
-    const int nb = pn2_dsra_tail_blocks(d->OH);
-    dim3 grid(nb, d->N);
-    switch (d->P) {
-        case 1: hipLaunchKernelGGL(tail_fwd_k<1>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
-        case 2: hipLaunchKernelGGL(tail_fwd_k<2>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
-        case 3: hipLaunchKernelGGL(tail_fwd_k<3>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
-        default: hipLaunchKernelGGL(tail_fwd_k<4>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
-    }
-    hipLaunchKernelGGL(loss_finalize_k, dim3(1), dim3(512), 0, st, partial, d->P, d->N, nb, sums, wsum, loss);
-    PN2_CHECK_LAUNCH();
-    return 0;
-}
-
-int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* weit, const float* wsum, const float* sums,
-                      float gscale, void* stream) {
-    if (!mask || !weit || !wsum || !sums) return -1;
-    if (int rc = tail_check(d)) return rc;
-    tail_groups G;
+// geometry groups (<= 4 maps of equal low-res size and scale); returns the LDS bytes the row-per-block backward needs
+static size_t tail_make_groups(const pn2_tail_desc* d, tail_groups& G, int cap = 4) {
     G.ng = 0; G.start[0] = 0;
     bool used[PN2_TAIL_MAX_MAPS] = {false};
     size_t lds = 0;
     for (int j = 0; j < 2 * d->P; ++j) {
         if (used[j]) continue;
-        if (!d->maps[j].dsrc) return -1;
         const pn2_tail_map& a = d->maps[j];
         int g = G.ng++;
         G.nm[g] = 0;
-        for (int k = j; k < 2 * d->P && G.nm[g] < 4; ++k) {
+        for (int k = j; k < 2 * d->P && G.nm[g] < cap; ++k) {
             const pn2_tail_map& b = d->maps[k];
             if (!used[k] && b.h == a.h && b.w == a.w && b.rh == a.rh && b.rw == a.rw) { used[k] = true; G.idx[g][G.nm[g]++] = k; }
         }
@@ -635,8 +901,100 @@ int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* we
         const size_t need = ((size_t)G.nm[g] * nr * a.w + 4 + (size_t)G.nm[g] * d->OW) * 4;
         if (need > lds) lds = need;
     }
+    return lds;
+}
+
+// band kernels apply when a band of TRB output rows touches <= 3 low-res rows of every map; PN2_TAIL_BAND=0 keeps the row kernels
+static bool tail_band_ok(const pn2_tail_desc* d) {
+    const char* e = getenv("PN2_TAIL_BAND");
+    if ((e && e[0] == '0') || d->N > 65535) return false;
+    for (int j = 0; j < 2 * d->P; ++j) {
+        const pn2_tail_map& m = d->maps[j];
+        if (m.rh * (float)(TRB - 1) >= 0.999f || m.rw * 4.f >= 0.999f) return false;
+    }
+    return true;
+}
+
+static void tail_band_geometry(const pn2_tail_desc* d, const tail_groups& G, tail_band_aux& A, int& threads, int& blocks, size_t& lds_f, size_t& lds_b) {
+    const int LV = d->OW >> 2;
+    int R = 1; while (R * 2 * LV <= 256 && R * 2 <= TRB) R <<= 1;
+    A.R = R; threads = (R * LV + 63) & ~63;
+    A.nbn = pn2_dsra_tail_blocks(d->OH) * d->N;
+    blocks = G.ng * ((A.nbn + 7) & ~7);
+    A.ptot = 0;
+    for (int j = 0; j < 2 * d->P; ++j) { A.poff[j] = A.ptot; A.ptot += 3 * d->maps[j].w; }
+    lds_f = lds_b = 0;
+    for (int g = 0; g < G.ng; ++g) {
+        const size_t v = (((size_t)TBM * TRB * (d->maps[G.idx[g][0]].w + 1) + 3) & ~(size_t)3) * 4;
+        const size_t b = v + (TRB * 3 + (size_t)G.nm[g] * 3 * d->OW) * 4;
+        if (v > lds_f) lds_f = v;
+        if (b > lds_b) lds_b = b;
+    }
+}
+
+long long pn2_dsra_tail_scratch(const pn2_tail_desc* d) {
+    if (tail_check(d) || !tail_band_ok(d)) return 0;
+    long long ptot = 0;
+    for (int j = 0; j < 2 * d->P; ++j) ptot += 3 * d->maps[j].w;
+    return (long long)d->N * pn2_dsra_tail_blocks(d->OH) * ptot;
+}
+
+int pn2_dsra_tail_fwd(const pn2_tail_desc* d, float* lat, const float* mask, const float* weit, float* partial,
+                      float* sums, float* wsum, float* loss, void* stream) {
+    if (!lat || !mask || !weit || !partial || !sums || !wsum || !loss) return -1;
+    if (int rc = tail_check(d)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = pn2_dsra_tail_blocks(d->OH);
+    bool band = tail_band_ok(d);
+    if (band) {
+        tail_groups G; tail_band_aux A; int threads, blocks; size_t lds_f, lds_b;
+        tail_make_groups(d, G, TBM);
+        tail_band_geometry(d, G, A, threads, blocks, lds_f, lds_b);
+        if (lds_f <= 60 * 1024) hipLaunchKernelGGL(tail_band_fwd_k, dim3(blocks), dim3(threads), lds_f, st, *d, G, A, lat, mask, weit, partial);
+        else band = false;
+    }
+    if (!band) {
+        size_t lds = 0;
+        for (int j = 0; j < 2 * d->P; ++j) lds += (size_t)((int)(TRB * d->maps[j].rh) + 3) * d->maps[j].w * 4;
+        if (lds > 60 * 1024) return -2;
+        dim3 grid(nb, d->N);
+        switch (d->P) {
+            case 1: hipLaunchKernelGGL(tail_fwd_k<1>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
+            case 2: hipLaunchKernelGGL(tail_fwd_k<2>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
+            case 3: hipLaunchKernelGGL(tail_fwd_k<3>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
+            default: hipLaunchKernelGGL(tail_fwd_k<4>, grid, dim3(256), lds, st, *d, lat, mask, weit, partial); break;
+        }
+    }
+    hipLaunchKernelGGL(loss_finalize_k, dim3(1), dim3(1024), 0, st, partial, d->P, d->N, nb, sums, wsum, loss);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* weit, const float* wsum, const float* sums,
+                      float gscale, float* scratch, long long scratch_floats, void* stream) {
+    if (!mask || !weit || !wsum || !sums) return -1;
+    if (int rc = tail_check(d)) return rc;
+    for (int j = 0; j < 2 * d->P; ++j) if (!d->maps[j].dsrc) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    tail_groups G;
+    const long long need = pn2_dsra_tail_scratch(d);
+    if (need > 0 && scratch && scratch_floats >= need) {
+        tail_band_aux A; int threads, blocks; size_t lds_f, lds_b;
+        tail_make_groups(d, G, TBM);
+        tail_band_geometry(d, G, A, threads, blocks, lds_f, lds_b);
+        if (lds_b <= 60 * 1024) {
+            const int nb = pn2_dsra_tail_blocks(d->OH);
+            hipLaunchKernelGGL(tail_band_bwd_k, dim3(blocks), dim3(threads), lds_b, st, *d, G, A, mask, weit, wsum, sums, gscale, scratch);
+            int emax = 0;
+            for (int j = 0; j < 2 * d->P; ++j) emax = std::max(emax, d->N * d->maps[j].h * d->maps[j].w);
+            hipLaunchKernelGGL(tail_band_fin_k, dim3((emax + 255) / 256, 2 * d->P), dim3(256), 0, st, *d, A, scratch, nb);
+            PN2_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    const size_t lds = tail_make_groups(d, G);
     if (lds > 60 * 1024) return -2;
-    hipLaunchKernelGGL(tail_bwd_k, dim3(G.start[G.ng]), dim3(256), lds, (hipStream_t)stream, *d, G, mask, weit, wsum, sums, gscale);
+    hipLaunchKernelGGL(tail_bwd_k, dim3(G.start[G.ng]), dim3(256), lds, st, *d, G, mask, weit, wsum, sums, gscale);
     PN2_CHECK_LAUNCH();
     return 0;
 }

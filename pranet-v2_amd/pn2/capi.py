@@ -111,7 +111,8 @@ SIGNATURES = {
     "pn2_structure_loss_bwd": [P, P, LL, I, P, P, P, P, FL, I, I, P],
     "pn2_dsra_tail_blocks": [I],
     "pn2_dsra_tail_fwd": [C.POINTER(TailDesc), P, P, P, P, P, P, P, P],
-    "pn2_dsra_tail_bwd": [C.POINTER(TailDesc), P, P, P, P, FL, P],
+    "pn2_dsra_tail_scratch": [C.POINTER(TailDesc)],
+    "pn2_dsra_tail_bwd": [C.POINTER(TailDesc), P, P, P, P, FL, P, LL, P],
     "pn2_layernorm_fwd": [I, P, I, P, I, I, I, P, P, FL, P, P, P],
     "pn2_ln_slots": [I, I],
     "pn2_rows_blocks": [I, I],
@@ -170,7 +171,7 @@ SIGNATURES = {
 # entry points that return a value rather than a status
 _VALUE_FUNCS = {"pn2_resize_ksize", "pn2_colsum_job_blocks", "pn2_colsum_finalize_blocks", "pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
                 "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
-                "pn2_dsra_tail_blocks", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks", "pn2_mutation_loss_blocks", "pn2_mutation_loss_width",
+                "pn2_dsra_tail_blocks", "pn2_dsra_tail_scratch", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks", "pn2_mutation_loss_blocks", "pn2_mutation_loss_width",
                 "pn2_dwconv_blocks", "pn2_pairconv_blocks", "pn2_gate_blocks"}
 
 _lib = None
@@ -190,6 +191,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export what pn2.h declares
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.pn2_dsra_tail_scratch.restype = C.c_longlong
     _lib = lib
     return lib
 

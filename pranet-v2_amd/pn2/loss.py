@@ -69,7 +69,10 @@ def tail_backward(eng, tail, P, mask, saved, gscale=1.0):
         x = tail[j][0]
         g, acc = x.grad_sink()
         d.maps[j].dsrc, d.maps[j].accumulate = g.data_ptr(), acc
-    call.pn2_dsra_tail_bwd(C.byref(d), _p(mask), _p(weit), _p(wsum), _p(sums), float(gscale), _stream())
+    need = int(call.pn2_dsra_tail_scratch(C.byref(d)))          # band partials of the band-wise backward (0: row kernels)
+    scratch = eng.alloc((need,), torch.float32) if need > 0 else None
+    call.pn2_dsra_tail_bwd(C.byref(d), _p(mask), _p(weit), _p(wsum), _p(sums), float(gscale),
+                           _p(scratch) if scratch is not None else None, need, _stream())
 
 
 class _StructureLoss(torch.autograd.Function):
