@@ -912,24 +912,35 @@ __global__ __launch_bounds__(256) void pack_weight_multi(const pn2_pack_job* __r
     const int co0 = (local / nci) * CO, ci0 = (local - (local / nci) * nci) * CI;
     const int nco_t = min(CO, p.Cout - co0), nci_t = min(CI, p.Cin - ci0);
     const int run = nci_t * taps, rs = CI * taps + 1;     // +1: the transposed read walks LDS with stride rs
-    for (int e = threadIdx.x; e < nco_t * run; e += 256) {
-        const int col = e / run, r = e - col * run;
-        tile[col * rs + r] = w[((size_t)(co0 + col) * p.Cin + ci0) * taps + r];
+    // index math without integer divisions (the flat e / run, e / nci_t, t2 / taps form made this kernel ALU-bound at 1 TB/s):
+    // a wave owns tile rows, its lanes walk (tap, channel) pairs with the power-of-two tile width peeled off by shift / mask
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int col = ty; col < nco_t; col += 4) {
+        const float* src = w + ((size_t)(co0 + col) * p.Cin + ci0) * taps;
+        for (int r = tx; r < run; r += 64) tile[col * rs + r] = src[r];
     }
     __syncthreads();
     const size_t ld = p.ld ? p.ld : p.Kp;
-    const int n = nco_t * run;
+    const float inv_gi = 1.f / (float)p.gw_in, inv_go = 1.f / (float)p.gw_out;
+    auto phys_in = [&](int c) { const int g = (int)(((float)c + 0.5f) * inv_gi); return g * p.gwp_in + (c - g * p.gw_in); };
+    auto phys_out = [&](int c) { const int g = (int)(((float)c + 0.5f) * inv_go); return g * p.gwp_out + (c - g * p.gw_out); };
     if (!p.transposed) {
-        for (int e = threadIdx.x; e < n; e += 256) {
-            const int t2 = e / nci_t, cil = e - t2 * nci_t, col = t2 / taps, tap = t2 - col * taps;
-            TT<T>::st(wp + (size_t)log2phys(co0 + col, p.gw_out, p.gwp_out) * ld + p.koff + tap * p.Cin_p + log2phys(ci0 + cil, p.gw_in, p.gwp_in),
-                      tile[col * rs + cil * taps + tap]);
+        const int sh = 31 - __clz(CI);
+        for (int col = ty; col < nco_t; col += 4) {
+            T* dst = wp + (size_t)phys_out(co0 + col) * ld + p.koff;
+            for (int cb = tx; cb < taps * CI; cb += 64) {
+                const int tap = cb >> sh, cil = cb & (CI - 1);
+                if (cil < nci_t) TT<T>::st(dst + tap * p.Cin_p + phys_in(ci0 + cil), tile[col * rs + cil * taps + tap]);
+            }
         }
     } else {
-        for (int e = threadIdx.x; e < n; e += 256) {
-            const int t2 = e / nco_t, col = e - t2 * nco_t, cil = t2 / taps, tap = t2 - cil * taps;
-            TT<T>::st(wp + (size_t)log2phys(ci0 + cil, p.gw_in, p.gwp_in) * ld + p.koff + tap * p.Cout_p + log2phys(co0 + col, p.gw_out, p.gwp_out),
-                      tile[col * rs + cil * taps + tap]);
+        const int sh = 31 - __clz(CO);
+        for (int cil = ty; cil < nci_t; cil += 4) {
+            T* dst = wp + (size_t)phys_in(ci0 + cil) * ld + p.koff;
+            for (int cb = tx; cb < taps * CO; cb += 64) {
+                const int tap = cb >> sh, col = cb & (CO - 1);
+                if (col < nco_t) TT<T>::st(dst + tap * p.Cout_p + phys_out(co0 + col), tile[col * rs + cil * taps + tap]);
+            }
         }
     }
 }

@@ -364,15 +364,34 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_k(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void bias_grad_k(const float* __restrict__ dy, int M, int K, float* db, int accumulate) {
-    // one block per channel k; deterministic tree reduce
-    __shared__ float sh[256];
-    const int k = blockIdx.x;
+__global__ __launch_bounds__(1024) void bias_grad_k(const float* __restrict__ dy, int M, int K, float* db, int accumulate) {
+    // one block per channel k, 1024 lanes with 8 independent loads in flight each (a 256-lane walk of dependent-latency loads took 56 us on
+    // the 61952-row K = 1 head maps); fixed-order tree reduce -> deterministic
+    __shared__ float sh[1024];
+    const int k = blockIdx.x, t = threadIdx.x;
     float s = 0.f;
-    for (int m = threadIdx.x; m < M; m += 256) s += dy[(size_t)m * K + k];
-    sh[threadIdx.x] = s; __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) db[k] = accumulate ? db[k] + sh[0] : sh[0];
+    if (K == 1 && (M & 3) == 0 && (reinterpret_cast<size_t>(dy) & 15) == 0) {
+        const float4* d4 = reinterpret_cast<const float4*>(dy);
+        const int M4 = M >> 2;
+        int m = t;
+        for (; m + 3 * 1024 < M4; m += 4 * 1024) {
+            const float4 a = d4[m], b = d4[m + 1024], c = d4[m + 2048], d = d4[m + 3072];
+            s += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w));
+        }
+        for (; m < M4; m += 1024) { const float4 a = d4[m]; s += (a.x + a.y) + (a.z + a.w); }
+    } else {
+        int m = t;
+        for (; m + 7 * 1024 < M; m += 8 * 1024) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dy[(size_t)(m + u * 1024) * K + k];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; m < M; m += 1024) s += dy[(size_t)m * K + k];
+    }
+    sh[t] = s; __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (t < o) sh[t] += sh[t + o]; __syncthreads(); }
+    if (t == 0) db[k] = accumulate ? db[k] + sh[0] : sh[0];
 }
 
 template <typename T> bool vec_ok(int C, int a, int b = 0, int c = 0, int d = 0) {
@@ -503,7 +522,7 @@ int pn2_nchw_to_nhwc(int dt_out, const float* x, void* y, int ld_y, int N, int C
 
 int pn2_bias_grad(const float* dy, int M, int K, float* db, int accumulate, void* stream) {
     if (!dy || !db) return -1;
-    hipLaunchKernelGGL(bias_grad_k, dim3(K), dim3(256), 0, (hipStream_t)stream, dy, M, K, db, accumulate);
+    hipLaunchKernelGGL(bias_grad_k, dim3(K), dim3(1024), 0, (hipStream_t)stream, dy, M, K, db, accumulate);
     PN2_CHECK_LAUNCH();
     return 0;
 }
