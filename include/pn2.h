@@ -203,7 +203,7 @@ int pn2_dsra_tail_blocks(int OH);               /* row bands per image of `parti
 int pn2_dsra_tail_fwd(const pn2_tail_desc* d, float* lat, const float* mask, const float* weit, float* partial,
                       float* sums, float* wsum, float* loss, void* stream);
 /* floats of caller-owned scratch the band-wise backward needs ([N][blocks][3 rows of every map]); 0 = geometry served by the row kernels */
-long long pn2_dsra_tail_scratch(const pn2_tail_desc* d);
+int pn2_dsra_tail_scratch(const pn2_tail_desc* d);
 /* scratch may be NULL / short: the backward then runs one block per low-res row (slower, same result up to summation order) */
 int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* weit, const float* wsum, const float* sums,
                       float gscale, float* scratch, long long scratch_floats, void* stream);

@@ -956,11 +956,12 @@ static void tail_band_geometry(const pn2_tail_desc* d, const tail_groups& G, tai
     }
 }
 
-long long pn2_dsra_tail_scratch(const pn2_tail_desc* d) {
+int pn2_dsra_tail_scratch(const pn2_tail_desc* d) {
     if (tail_check(d) || !tail_band_ok(d)) return 0;
     long long ptot = 0;
     for (int j = 0; j < 2 * d->P; ++j) ptot += 3 * d->maps[j].w;
-    return (long long)d->N * pn2_dsra_tail_blocks(d->OH) * ptot;
+    const long long need = (long long)d->N * pn2_dsra_tail_blocks(d->OH) * ptot;
+    return need > 0x7fffffffLL ? 0 : (int)need;          // (never reached with tail_check's limits: N*P <= 512, OW <= 1024)
 }
 
 int pn2_dsra_tail_fwd(const pn2_tail_desc* d, float* lat, const float* mask, const float* weit, float* partial,

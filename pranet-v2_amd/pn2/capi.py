@@ -191,7 +191,6 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export what pn2.h declares
         fn.argtypes = args
         fn.restype = C.c_int
-    lib.pn2_dsra_tail_scratch.restype = C.c_longlong
     _lib = lib
     return lib
 
