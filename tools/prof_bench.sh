@@ -1,0 +1,9 @@
+#!/bin/bash
+# rocprofv3 kernel stats of a bench.py command (GPU box): prof_bench.sh <out.csv> [bench.py args]; the CSV lands in gpurun_out/
+out=$1; shift
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_bench
+rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > /tmp/pb.log 2>&1
+tail -1 /tmp/pb.log | cut -c1-260
+DB=$(find /tmp/prof_bench -name "*.db" | head -1)
+python3 $GRAFT_REPO_ROOT/tools/rocpd_stats.py $DB $GRAFT_REPO_ROOT/gpurun_out/$out
