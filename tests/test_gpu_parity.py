@@ -478,6 +478,77 @@ def test_fused_dsra_tail_matches_unfused_path(monkeypatch):
     assert rell2(g1, g0) < 2e-5 and relmax(g1, g0) < 2e-4
 
 
+TAIL_GEOMS = [  # N, S, align_corners: the three training scales of a 96-pixel fixture, the 1.25x headline scale with align_corners, ragged last band
+    (3, 96, 0), (2, 64, 1), (2, 128, 0), (2, 448, 1), (1, 352, 0), (2, 100, 0),
+]
+
+
+@pytest.mark.parametrize("cfg", TAIL_GEOMS)
+def test_dsra_tail_band_kernels_vs_oracle_and_row_kernels(cfg, monkeypatch):
+    """pn2_dsra_tail_fwd/_bwd called through the C ABI on random low-res logits: band kernels (default) and row kernels (PN2_TAIL_BAND=0) against
+    the oracle's structure_loss (MyTrain_med.py:19-38) on F.interpolate'd maps in float64 with autograd for the low-res gradients; gradients
+    accumulate into pre-filled buffers where `accumulate` is set.  OH = 100 leaves a 4-row last band."""
+    import ctypes as C
+    from pn2 import capi
+    from pn2.capi import call
+    from oracle import pranet_oracle as O
+    N, S, ac = cfg
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(100 + S)
+    sizes = [max(S // 8, 1), max(S // 16, 1), max(S // 32, 1), max(S // 8, 1)]
+    src_cpu = [(torch.randn(N, h, h, generator=g) * 2) for h in sizes + sizes]
+    mask_cpu = (torch.rand(N, 1, S, S, generator=g) < 0.3).float()
+    mask_cpu[:, :, S // 4: S // 2, S // 3: 2 * S // 3] = 1.0
+    # ---- oracle (float64, autograd)
+    leaves = [t.double().requires_grad_(True) for t in src_cpu]
+    ups = [F.interpolate(t[:, None], size=(S, S), mode="bilinear", align_corners=bool(ac)) for t in leaves]
+    ref_losses = [O.structure_loss(ups[j], ups[4 + j], mask_cpu.double(), 1 - mask_cpu.double()) for j in range(4)]
+    sum(ref_losses).backward()
+    ref_grads = [t.grad.float() for t in leaves]
+    # the maps themselves are held to the reference's own fp32 index math (float64 source coordinates differ by ~55 * 2^-24 at 448 px, align_corners)
+    ups32 = [F.interpolate(t[:, None], size=(S, S), mode="bilinear", align_corners=bool(ac)).reshape(N, S, S) for t in src_cpu]
+    res = {}
+    for band in ("1", "0"):
+        monkeypatch.setenv("PN2_TAIL_BAND", band)
+        srcs = [t.to(dev) for t in src_cpu]
+        base = [torch.randn_like(t) * float(ref_grads[j].abs().max()) for j, t in enumerate(srcs)]      # pre-existing gradient of the sinks that accumulate
+        dsrcs = [base[j].clone() if j % 3 == 0 else torch.empty_like(t) for j, t in enumerate(srcs)]
+        mask = mask_cpu.reshape(N, S, S).to(dev).contiguous()
+        weit = torch.empty_like(mask)
+        call.pn2_loss_weights(P(mask), P(weit), N, S, S, 31, st)
+        d = capi.TailDesc()
+        d.N, d.OH, d.OW, d.P, d.align_corners = N, S, S, 4, ac
+        for j, (s_, ds) in enumerate(zip(srcs, dsrcs)):
+            m, h = d.maps[j], s_.shape[1]
+            m.src, m.dsrc, m.h, m.w = s_.data_ptr(), ds.data_ptr(), h, h
+            m.rh = m.rw = ((h - 1) / (S - 1) if S > 1 else 0.0) if ac else h / S
+            m.accumulate = 1 if j % 3 == 0 else 0
+        nb = call.pn2_dsra_tail_blocks(S)
+        lat = torch.empty(8, N, S, S, device=dev)
+        partial = torch.empty(4, N, nb, 5, device=dev)
+        sums, wsum, loss = torch.empty(4, N, 4, device=dev), torch.empty(N, device=dev), torch.empty(5, device=dev)
+        need = int(call.pn2_dsra_tail_scratch(C.byref(d)))
+        assert (need > 0) == (band == "1")
+        scratch = torch.empty(max(need, 1), device=dev)
+        call.pn2_dsra_tail_fwd(C.byref(d), P(lat), P(mask), P(weit), P(partial), P(sums), P(wsum), P(loss), st)
+        call.pn2_dsra_tail_bwd(C.byref(d), P(mask), P(weit), P(wsum), P(sums), 1.0, P(scratch) if need else None, need, st)
+        torch.cuda.synchronize()
+        for j in range(8):
+            assert relmax(lat[j], ups32[j]) < 2e-6, (band, j)
+        for j in range(4):
+            assert abs(float(loss[j]) - float(ref_losses[j].detach())) < 5e-6 * abs(float(ref_losses[j].detach())), (band, j)
+        for j in range(8):
+            got = dsrcs[j] - base[j] if j % 3 == 0 else dsrcs[j]
+            assert relmax(got, ref_grads[j]) < 2e-4 and rell2(got, ref_grads[j]) < 2e-5, (band, j, relmax(got, ref_grads[j]))
+        res[band] = (lat.clone(),)
+    assert relmax(res["1"][0], res["0"][0]) < 1e-6
+    # short / missing scratch: the backward falls back to the row kernels instead of failing
+    monkeypatch.setenv("PN2_TAIL_BAND", "1")
+    call.pn2_dsra_tail_bwd(C.byref(d), P(mask), P(weit), P(wsum), P(sums), 1.0, None, 0, st)
+    torch.cuda.synchronize()
+
+
 def test_pack_weights_multi_matches_single_pack():
     """The one-launch tiled repack (pn2_pack_weights_multi) rewrites every cached panel exactly as pn2_pack_weight builds it."""
     from pn2.trainer import Trainer
