@@ -684,10 +684,15 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
 // SOURCE side and in the ds_read_b64_tr_b16 addresses, which spreads the 8 pixel rows touched by one transpose-read
 // over all 64 banks.  Same k-slot <-> pixel permutation for both operands as conv_wgrad.
 // ------------------------------------------------------------------------------------------------
+#ifndef PN2_WG_PX
+#define PN2_WG_PX 32
+#endif
+// pixels per ring stage of the LDS-DMA wgrad kernel: 32-pixel stages (48 KB ring) leave room for three workgroups per CU
+constexpr int wg_px(int bmc) { return bmc >= 64 ? PN2_WG_PX : 64; }
 template <int BMC, int WM, int WN, bool PW>
 __device__ __forceinline__ void conv_wgrad_dma_body(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ slab,
                                                     const pn2_wgrad_desc& d, int nsplit, int bloc) {
-    constexpr int BNK = 128, PX = 64, NS = 3;
+    constexpr int BNK = 128, PX = wg_px(BMC), NS = 3;
     constexpr int WTM = BMC / WM, WTN = BNK / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int RBY = BMC * 2, RBX = BNK * 2;              // row bytes
     constexpr int CHY = BMC / 8, CHX = BNK / 8;              // 16-byte chunks per row
@@ -795,7 +800,7 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const bf16_t* __restrict__ d
             }
             const unsigned sb = lds0 + (t % NS) * STAGE;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < PX / 32; ++ks) {
                 u32x2_t a0[MT], a1[MT], b0[NT], b1[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
@@ -1137,9 +1142,9 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
 
 template <int BMC, int WM, int WN>
 int launch_wgrad_dma(const void* dy, const void* x, float* slab, const pn2_wgrad_desc& d, int nsplit, hipStream_t st) {
-    constexpr int stage_b = 64 * (BMC * 2 + 256), max_b = 3 * stage_b;
+    constexpr int PX = wg_px(BMC), stage_b = PX * (BMC * 2 + 256), max_b = 3 * stage_b;
     const int M = d.N * d.OH * d.OW;
-    const int total_steps = (M + 63) / 64, spb = (total_steps + nsplit - 1) / nsplit;
+    const int total_steps = (M + PX - 1) / PX, spb = (total_steps + nsplit - 1) / nsplit;
     const int lds = (spb < 3 ? (spb < 1 ? 1 : spb) : 3) * stage_b;
     const int grid = 8 * ((nsplit + 7) / 8) * (d.Rp / BMC) * (d.Kp / 128);
     const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
@@ -1206,7 +1211,7 @@ int launch_wgrad_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, int 
 
 template <int BMC, int WM, int WN>
 int launch_wgrad_dma_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
-    constexpr int max_b = 3 * 64 * (BMC * 2 + 256);
+    constexpr int max_b = 3 * wg_px(BMC) * (BMC * 2 + 256);
     if (max_b > 64 * 1024) {
         static bool done = false;
         if (!done) {

@@ -226,6 +226,7 @@ class StepArena:
         return torch.empty(shape, dtype=dtype, device=dev)
 
 
+WGRAD_SPLIT_DIV = int(os.environ.get("PN2_WGRAD_SPLIT_DIV", "1"))
 TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the conv tuner times every candidate behind a cache-evicting fill
 _THRASH = {}
 
@@ -861,6 +862,10 @@ class Engine:
             rd.Rp = wd.Rp
             wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd, nsplit, w.shape)
             rq = self.grad_queue
+            if rq is not None and rq.defer_wgrad and WGRAD_SPLIT_DIV > 1:
+                # the tuner times a conv alone, where many pixel splits are what fills the chip; inside a table-driven launch the other
+                # convs of the table do that, and longer contractions per workgroup amortise the pipeline fill and write fewer fp32 slabs
+                nsplit = max(1, -(-nsplit // WGRAD_SPLIT_DIV))
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab((id(w), x.M), (nsplit, wd.Rp, wd.Kp), self.dev)
             gwt, gwa = self.pgrads.sink(w)
             # wgrad (+ slab reduce) only feeds the parameter gradient: run it on the side stream so that it overlaps the dgrad /
