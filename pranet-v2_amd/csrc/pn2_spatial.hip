@@ -360,7 +360,15 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_k(const float* __restrict__ 
     PIX_LOOP(total) {
         const int n = (int)(idx / HW), p = (int)(idx % HW);
         To* d = y + idx * ld_y;
-        for (int c = 0; c < Cp; ++c) TT<To>::st(d + c, c < C ? x[((size_t)n * C + c) * HW + p] : 0.f);
+        constexpr int V = TT<To>::VEC;
+        if (Cp == V && (ld_y % V) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {      // the usual case (3 channels in an 8 / 4 slot pixel): one 16-byte store
+            float f[V];
+#pragma unroll
+            for (int c = 0; c < V; ++c) f[c] = c < C ? x[((size_t)n * C + c) * HW + p] : 0.f;
+            *reinterpret_cast<uint4*>(d) = TT<To>::pack(f);
+        } else {
+            for (int c = 0; c < Cp; ++c) TT<To>::st(d + c, c < C ? x[((size_t)n * C + c) * HW + p] : 0.f);
+        }
     }
 }
 
