@@ -67,6 +67,29 @@ int pn2_wgrad_tile_co(int cout_p);      /* co tile of the wgrad kernel */
 int pn2_conv_tile_m(int m, int cout, int dtype);        /* M tile (128 or 64) chosen for m output pixels x cout channels */
 int pn2_conv_stat_blocks(int m, int cout, int dtype);   /* rows of the psum/psq partial buffers = ceil(m / tile_m) */
 int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, void* stream);
+/* pn2_conv_gemm with the BatchNorm-BACKWARD statistics taken in the GEMM epilogue (autograd of nn.BatchNorm2d + ReLU behind a conv,
+ * Res2Net_v1b.py:60-63,70-72,84-89 ; pranet.py:40-43).  A dgrad GEMM whose result completes the gradient dy of a BatchNorm output y = act(BN(raw))
+ * has every dy tile in registers: the epilogue loads the matching `raw` (and, for BN + residual + ReLU, the stored y) tile, forms
+ * dz = dy * [y > 0] and leaves the per-channel partial sums  p1[tile][c] = sum dz,  p2[tile][c] = sum dz * (raw - mean) * invstd  of its rows -
+ * the separate pn2_bn_bwd_reduce pass (three full-tensor reads) disappears.  The stored result stays UNMASKED (pn2_bn_bwd_apply masks).
+ * Target `a` describes the GEMM's own destination `out`; target `b` (optional, b.out != NULL) receives a second copy of the plain result
+ * (never accumulated) with its own statistics: the gradient of Bottle2neck's  sp + spx[i]  (Res2Net_v1b.py:66-68) flows to both operands,
+ * which sit behind two different BatchNorms.  16-byte aligned rows only; excludes PN2_CONV_STATS / PN2_CONV_BIAS / split-K.               */
+#define PN2_BNB_STATS 1      /* emit p1 / p2 */
+#define PN2_BNB_MASK_RAW 2   /* ReLU mask recomputed as fmaf(raw, scale, shift) > 0 (bit-identical to the forward's affine pass) */
+#define PN2_BNB_MASK_Y 4     /* ReLU mask from the stored activation y > 0 (BN + residual + ReLU) */
+typedef struct pn2_bnb_target {
+    void* out; int ld_out;          /* target b only: second destination (same dtype / column range as the GEMM's out) */
+    int mode;                       /* PN2_BNB_* ; 0 = no statistics */
+    const void* raw; int ld_raw;    /* raw conv output behind the BatchNorm, columns aligned with the destination's */
+    const void* y; int ld_y;        /* PN2_BNB_MASK_Y: stored activation */
+    const float* par; int ps;       /* rows scale, shift, mean, invstd of that BatchNorm, row stride ps (elements) */
+    int split;                      /* > 0: columns >= split use raw2 / par2 instead (a concat buffer whose tail belongs to another BatchNorm); */
+    const void* raw2; const float* par2;   /* par2 == NULL: no statistics for those columns (zeros are written) */
+    float* p1; float* p2; int ldp;  /* partial rows [pn2_conv_stat_blocks or ceil(M / tile_m)][ldp] */
+} pn2_bnb_target;
+typedef struct pn2_conv_ep { pn2_bnb_target a, b; } pn2_conv_ep;
+int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const pn2_conv_desc* d, const pn2_conv_ep* ep, void* stream);
 int pn2_conv_splitk_reduce(int dtype, const float* ws, int ksplit, int M, int Cout, void* out, int ld_out, const float* bias, float* psum, float* psq,
                            int accumulate, void* stream);   /* psum / psq: BatchNorm partial rows [ceil(M / 64)][Cout] of the summed result, or NULL */
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream);
@@ -111,6 +134,9 @@ typedef struct pn2_bn_desc {
     float eps, momentum;
     int ldp;                /* row stride of the partial buffers and plane stride of `coef` (0 = Cp): a BN that owns a channel
                                slice [c0, c0+Cp) of a wider fused conv output passes base pointers offset by c0 and ldp = total */
+    int tile_rows;          /* pn2_bn_finalize: 0 = the partial rows hold raw moments (sum x, sum x^2) of their row block; > 0 = they hold
+                               (mean, M2 = sum (x - mean)^2) of blocks of tile_rows rows (the last one shorter), as the GEMM epilogue leaves
+                               them (PN2_CONV_STATS): merged with Chan's formula in double, no E[x^2] - mean^2 cancellation */
 } pn2_bn_desc;
 /* batch statistics from the conv epilogue partials -> scale/shift (physical), saved mean/invstd, running-stat update */
 int pn2_bn_finalize(const float* psum, const float* psq, int nblk, const pn2_bn_desc* d, const float* gamma, const float* beta,
@@ -134,6 +160,12 @@ int pn2_bn_bwd_blocks(int M, int Cp, int dtype);   /* rows of the p1/p2 partial 
 /* pass 1b: dgamma/dbeta (logical, optionally accumulated) + per-channel coefficients for pass 2 */
 int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn_desc* d, const float* gamma, const float* invstd,
                         float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);
+/* pn2_bn_bwd_finalize when the partial rows of the BatchNorm's channels come from up to 4 different producers (GEMM epilogues, pn2_conv_gemm_ep,
+ * or pn2_bn_bwd_reduce on a channel slice): segment s covers physical channels [c0[s], c0[s+1]) (the last one up to d->Cp), p1[s] / p2[s] point at
+ * its first column, nblk[s] rows of stride ldp[s].  d->ldp is the plane stride of `coef` only. */
+typedef struct pn2_bn_segs { int nseg; int c0[4]; int nblk[4]; int ldp[4]; const float* p1[4]; const float* p2[4]; } pn2_bn_segs;
+int pn2_bn_bwd_finalize_seg(const pn2_bn_segs* segs, const pn2_bn_desc* d, const float* gamma, const float* invstd,
+                            float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);
 /* pass 2: dx = g*invstd*(dz - c1 - xhat*c2) ; optional dres (+)= dz.  coef = [gscale|c1|c2] each Cp long.
  * coef==NULL: pure activation backward (dx = dz), used for eval-mode / affine-only layers.                */
 int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,

@@ -68,14 +68,29 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
                                                      float* scale, float* shift, float* mean_o, float* invstd_o, int CPB) {
     __shared__ double sh[2][4][8];
     const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
-    double s1, s2;
-    reduce_partials(psum, psq, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, 256 / CPB, s1, s2);
+    double s1, s2, k0 = 0.0;
+    if (d.tile_rows > 0) {
+        // Chan merge of per-tile (mean_t, M2_t): with K = the mean of tile 0 as a shift,
+        //   mean = K + A / M,  M2 = sum M2_t + B - A^2 / M,   A = sum n_t (mean_t - K),  B = sum n_t (mean_t - K)^2   (all in double)
+        // s1 carries A, s2 carries sum M2_t + B; the A^2 / M term is applied after the block reduction.
+        const int ldp = d.ldp ? d.ldp : d.Cp, RL = 256 / CPB;
+        s1 = 0.0; s2 = 0.0;
+        if (c < d.Cp) {
+            k0 = (double)psum[c];
+            for (int r = rl; r < nblk; r += RL) {
+                const int nt = min(d.tile_rows, d.M - r * d.tile_rows);
+                const double dm = (double)psum[(size_t)r * ldp + c] - k0;
+                s1 += nt * dm; s2 += (double)psq[(size_t)r * ldp + c] + nt * dm * dm;
+            }
+        }
+    } else reduce_partials(psum, psq, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, 256 / CPB, s1, s2);
     block_reduce_rows(sh, CPB, s1, s2);
     if (rl == 0 && c < d.Cp) {
         const int lc = phys2log(c, d.gw, d.gwp, d.C);
         if (lc < 0) { scale[c] = 0.f; shift[c] = 0.f; mean_o[c] = 0.f; invstd_o[c] = 0.f; return; }
-        const double mean = s1 / d.M;
-        double var = s2 / d.M - mean * mean;
+        double mean, var;
+        if (d.tile_rows > 0) { mean = k0 + s1 / d.M; var = (s2 - s1 * s1 / d.M) / d.M; }
+        else { mean = s1 / d.M; var = s2 / d.M - mean * mean; }
         if (var < 0.0) var = 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)d.eps));
         const float sc = gamma[lc] * invstd;
@@ -211,6 +226,30 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
     const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
     double s1, s2;
     reduce_partials(p1, p2, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, 256 / CPB, s1, s2);
+    const int cs = d.ldp ? d.ldp : d.Cp;     // plane stride of coef
+    block_reduce_rows(sh, CPB, s1, s2);
+    if (rl == 0 && c < d.Cp) {
+        const int lc = phys2log(c, d.gw, d.gwp, d.C);
+        if (lc < 0) { coef[c] = 0.f; coef[cs + c] = 0.f; coef[2 * cs + c] = 0.f; return; }
+        if (accumulate) { dbeta[lc] += (float)s1; dgamma[lc] += (float)s2; }
+        else { dbeta[lc] = (float)s1; dgamma[lc] = (float)s2; }
+        coef[c] = gamma[lc] * invstd[c];
+        coef[cs + c] = (float)(s1 / d.M);
+        coef[2 * cs + c] = (float)(s2 / d.M);
+    }
+}
+
+// pn2_bn_bwd_finalize with the partial rows of the channels coming from up to 4 producers (see pn2_bn_segs)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_seg_k(pn2_bn_segs sg, pn2_bn_desc d, const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                             float* dgamma, float* dbeta, int accumulate, float* coef, int CPB) {
+    __shared__ double sh[2][4][8];
+    const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (k < sg.nseg && c >= sg.c0[k]) si = k;
+    const int cc = c - sg.c0[si];
+    double s1, s2;
+    reduce_partials(sg.p1[si], sg.p2[si], sg.nblk[si], c < d.Cp ? cc + 1 : 0, sg.ldp[si], cc, rl, 256 / CPB, s1, s2);
     const int cs = d.ldp ? d.ldp : d.Cp;     // plane stride of coef
     block_reduce_rows(sh, CPB, s1, s2);
     if (rl == 0 && c < d.Cp) {
@@ -505,6 +544,22 @@ int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn
     if (!p1 || !p2 || !d || !gamma || !invstd || !dgamma || !dbeta || !coef) return -1;
     const int cpb = finalize_cpb(nblk);
     hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((d->Cp + cpb - 1) / cpb), dim3(256), 0, (hipStream_t)stream, p1, p2, nblk, *d, gamma, invstd, dgamma, dbeta, accumulate, coef, cpb);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_bn_bwd_finalize_seg(const pn2_bn_segs* segs, const pn2_bn_desc* d, const float* gamma, const float* invstd,
+                            float* dgamma, float* dbeta, int accumulate, float* coef, void* stream) {
+    if (!segs || !d || !gamma || !invstd || !dgamma || !dbeta || !coef) return -1;
+    if (segs->nseg < 1 || segs->nseg > 4 || segs->c0[0] != 0) return -2;
+    int nmax = 1;
+    for (int k = 0; k < segs->nseg; ++k) {
+        if (!segs->p1[k] || !segs->p2[k] || segs->nblk[k] < 1 || segs->ldp[k] < 1) return -1;
+        if (k && segs->c0[k] <= segs->c0[k - 1]) return -2;
+        if (segs->nblk[k] > nmax) nmax = segs->nblk[k];
+    }
+    const int cpb = finalize_cpb(nmax);
+    hipLaunchKernelGGL(bn_bwd_finalize_seg_k, dim3((d->Cp + cpb - 1) / cpb), dim3(256), 0, (hipStream_t)stream, *segs, *d, gamma, invstd, dgamma, dbeta, accumulate, coef, cpb);
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -14,6 +14,7 @@
 //
 // Tiling is for 64-wide wavefronts: 256 threads = 4 waves, each wave owns a (16*MT)x(16*NT) block of
 // v_mfma_f32_16x16x32_bf16 (or v_mfma_f32_16x16x4_f32 for exact-fp32 parity runs) accumulators.
+#include <cstring>
 #include "pn2_common.h"
 #include "../../include/pn2.h"
 
@@ -59,15 +60,281 @@ __device__ __forceinline__ bool tap_pixel(const GatherGeom& g, int iy0, int ix0,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Shared epilogue of the two GEMM kernels: accumulators -> (bias) -> LDS-staged 16-byte stores, with
+//   PN2_CONV_STATS : forward BatchNorm batch statistics of the fp32 accumulators as one (mean, M2) pair per tile and channel.
+//                    A wave shifts its values by its own first row (no cancellation however large |mean| / sigma is), the WM wave
+//                    results of a tile are merged with Chan's formula; pn2_bn_finalize merges the tiles in double.
+//   pn2_conv_ep    : BatchNorm-BACKWARD partial sums of the gradient tile this dgrad GEMM produces (see pn2.h), one or two targets.
+// LDS use: the C tile [BM][CRS] followed by 3*WM*BN floats (STATS); the ep sums reuse the C tile area after it has been drained.
+// ------------------------------------------------------------------------------------------------
+// BatchNorm-backward epilogue (pn2_conv_gemm_ep).  A thread owns ONE channel vector of the C tile (256 % VPR == 0) and RPT of its rows, so its
+// per-channel parameters and sums stay in registers.  This code runs at the GEMM's low occupancy (1-3 workgroups per CU), where every
+// instruction is exposed: a first, straightforward version executed ~1800 instructions per wave and DOUBLED the kernel time.  Hence:
+//   * all global operands of a thread's rows (raw, stored y, the destination for +=) are requested in ONE batch at the top of the epilogue,
+//     before the C tile is staged through LDS (a load -> use -> store walk would pay a full HBM latency per row);
+//   * the ReLU mask is branch-free: keep = fmaf(ms, msc, msh) > 0 with (ms, msc, msh) = (raw, scale, shift) | (stored y, 1, 0) | (raw, 0, 1);
+//   * s2 = invstd * (sum dz*raw - mean * sum dz): one fma per element in the walk;
+//   * bounds checks and the += path are template parameters (full tiles / plain stores take the lean loop);
+//   * the row lanes of a channel meet in LDS (one 16-byte write per lane and sum, column-parallel fixed-order adds) instead of ~100 ds_bpermute.
+template <typename T, int BM, int BN> struct BnbPre {
+    static constexpr int VEC = TT<T>::VEC, VPR = BN / VEC;
+    static constexpr int RPT = BM * VPR / 256 > 0 ? BM * VPR / 256 : 1;
+    static_assert(BM * VPR >= 256 && (BM * VPR) % 256 == 0, "tile rows must split evenly over the 256 / VPR row lanes");
+    uint4 ra[RPT], ma[RPT], rb[RPT], vd[RPT];
+};
+constexpr int ep_lds_bytes(int vec) { return 4 * 256 * vec * 4; }      // [4 sums][256 / VPR row lanes][BN] floats
+
+__device__ __forceinline__ void bnb_select(const pn2_bnb_target& t, int col, const void*& raw, const float*& par, bool& stat) {
+    raw = t.raw; par = t.par;
+    stat = (t.mode & PN2_BNB_STATS) != 0;
+    if (t.split > 0 && col >= t.split) { raw = t.raw2; par = t.par2; if (!par) stat = false; }
+}
+
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void bnb_prefetch(const pn2_conv_desc& d, const pn2_conv_ep& ep, const T* out, int M, int m0, int n0, BnbPre<T, BM, BN>& P) {
+    constexpr int VEC = TT<T>::VEC, VPR = BN / VEC, RPT = BnbPre<T, BM, BN>::RPT;
+    const int tid = threadIdx.x, cv = tid % VPR, col = n0 + cv * VEC, rstep = 256 / VPR;
+    const bool cok = col < d.Cout;
+    const int colc = cok ? col : 0;
+    const void *rawA, *rawB; const float *parA, *parB; bool stA, stB;
+    bnb_select(ep.a, colc, rawA, parA, stA);
+    bnb_select(ep.b, colc, rawB, parB, stB);
+    const bool yA = stA && (ep.a.mode & PN2_BNB_MASK_Y), acc = d.flags & PN2_CONV_ACCUM;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int row = tid / VPR + u * rstep;
+        const size_t mc = (cok && m0 + row < M) ? (size_t)(m0 + row) : 0;      // clamped: the loads are unconditional, results of dead rows are ignored
+        if (stA) P.ra[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(rawA) + mc * ep.a.ld_raw + colc);
+        if (yA) P.ma[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(ep.a.y) + mc * ep.a.ld_y + colc);
+        if (stB) P.rb[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(rawB) + mc * ep.b.ld_raw + colc);
+        if (acc) P.vd[u] = *reinterpret_cast<const uint4*>(out + mc * d.ld_out + colc);
+    }
+}
+
+// mask coefficients + (mean, invstd) of this thread's channel vector
+template <typename T>
+__device__ __forceinline__ void bnb_params(const pn2_bnb_target& t, const float* par, int colc, bool stat, float* msc, float* msh, float* mu, float* is) {
+    constexpr int VEC = TT<T>::VEC;
+    const bool my = (t.mode & PN2_BNB_MASK_Y) != 0, mr = (t.mode & PN2_BNB_MASK_RAW) != 0;
+#pragma unroll
+    for (int e = 0; e < VEC; e += 4) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(1.f, 1.f, 1.f, 1.f), c = a, dd = a;
+        if (stat) {
+            if (mr && !my) { a = *reinterpret_cast<const float4*>(par + colc + e); b = *reinterpret_cast<const float4*>(par + (size_t)t.ps + colc + e); }
+            c = *reinterpret_cast<const float4*>(par + (size_t)2 * t.ps + colc + e); dd = *reinterpret_cast<const float4*>(par + (size_t)3 * t.ps + colc + e);
+        }
+        if (my) { a = make_float4(1.f, 1.f, 1.f, 1.f); b = make_float4(0.f, 0.f, 0.f, 0.f); }
+        msc[e] = a.x; msc[e + 1] = a.y; msc[e + 2] = a.z; msc[e + 3] = a.w; msh[e] = b.x; msh[e + 1] = b.y; msh[e + 2] = b.z; msh[e + 3] = b.w;
+        mu[e] = c.x; mu[e + 1] = c.y; mu[e + 2] = c.z; mu[e + 3] = c.w; is[e] = dd.x; is[e + 1] = dd.y; is[e + 2] = dd.z; is[e + 3] = dd.w;
+    }
+}
+
+// One target: walk this thread's rows of the staged C tile, store them to dst (+= vd when ACC) and accumulate t1 = sum dz, t2 = sum dz * raw
+template <typename T, int BM, int BN, bool ACC, bool FULL>
+__device__ __forceinline__ void bnb_rows(T* __restrict__ dst, int ld_dst, const char* Cs, int M, int m0, int col, int cv, bool cok, bool stat, bool usey,
+                                         const uint4* vr, const uint4* vm, const uint4* vd, const float* msc, const float* msh, float* t1, float* t2) {
+    constexpr int VEC = TT<T>::VEC, VPR = BN / VEC, CRS = BN * (int)sizeof(T) + 16, RPT = BnbPre<T, BM, BN>::RPT;
+    const int r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int row = r0 + u * (256 / VPR);
+        const int m = m0 + row;
+        if constexpr (!FULL) { if (!(cok && m < M)) continue; }
+        uint4 o = *reinterpret_cast<const uint4*>(Cs + row * CRS + cv * 16);
+        float x[VEC];
+        TT<T>::unpack(o, x);
+        if constexpr (ACC) {
+            float y[VEC];
+            TT<T>::unpack(vd[u], y);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) x[e] += y[e];
+            o = TT<T>::pack(x);
+            TT<T>::unpack(o, x);                  // the statistics see the STORED (rounded) gradient, as a separate reduce pass would
+        }
+        *reinterpret_cast<uint4*>(dst + (size_t)m * ld_dst + col) = o;
+        if (stat) {
+            float xr[VEC], ms[VEC];
+            TT<T>::unpack(vr[u], xr);
+            TT<T>::unpack(usey ? vm[u] : vr[u], ms);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float dz = fmaf(ms[e], msc[e], msh[e]) > 0.f ? x[e] : 0.f;
+                t1[e] += dz; t2[e] = fmaf(dz, xr[e], t2[e]);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void bnb_target(const pn2_bnb_target& t, T* __restrict__ dst, int ld_dst, bool accum, const char* Cs, int M, int m0, int n0, int Cout,
+                                           const uint4* vr, const uint4* vm, const uint4* vd, float* s1, float* s2) {
+    constexpr int VEC = TT<T>::VEC, VPR = BN / VEC;
+    const int cv = threadIdx.x % VPR, col = n0 + cv * VEC;
+    const bool cok = col < Cout;
+    const int colc = cok ? col : 0;
+    const void* raw; const float* par; bool stat;
+    bnb_select(t, colc, raw, par, stat);
+    float msc[VEC], msh[VEC], mu[VEC], is[VEC], t1[VEC], t2[VEC];
+    bnb_params<T>(t, par, colc, stat, msc, msh, mu, is);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
+    const bool usey = (t.mode & PN2_BNB_MASK_Y) != 0;
+    const bool full = m0 + BM <= M && n0 + BN <= Cout;
+    if (full) {
+        if (accum) bnb_rows<T, BM, BN, true, true>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, vr, vm, vd, msc, msh, t1, t2);
+        else bnb_rows<T, BM, BN, false, true>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, vr, vm, vd, msc, msh, t1, t2);
+    } else {
+        if (accum) bnb_rows<T, BM, BN, true, false>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, vr, vm, vd, msc, msh, t1, t2);
+        else bnb_rows<T, BM, BN, false, false>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, vr, vm, vd, msc, msh, t1, t2);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1[e] = t1[e]; s2[e] = is[e] * (t2[e] - mu[e] * t1[e]); }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int MT, int NT, bool EP>
+__device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem, const pn2_conv_desc& d, const pn2_conv_ep& ep, T* __restrict__ out,
+                                              float* __restrict__ psum, float* __restrict__ psq, int M, int m0, int n0, int bm, BnbPre<T, BM, BN>& pre) {
+    constexpr int VEC = TT<T>::VEC;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int CRS = BN * (int)sizeof(T) + 16;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
+    char* Cs = smem;
+    float* red = reinterpret_cast<float*>(smem + BM * CRS);   // [3][WM][BN]: shifted sum, shifted sum of squares, shift
+#ifndef PN2_EP_PREFETCH_EARLY
+    if constexpr (EP) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);      // in flight while the C tile is staged
+#endif
+    if (d.flags & PN2_CONV_STATS) {
+        const int rows_w = min(max(M - m0 - wm * WTM, 0), WTM);        // valid rows of this wave's tile (rows are ascending)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float k = __shfl(acc[0][j][0], l15);                   // row 0 of the wave tile, this lane's column
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (i * 16 + g * 4 + r < rows_w) ? acc[i][j][r] - k : 0.f;
+                    s += v; q += v * v;
+                }
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+            if (g == 0) {
+                const int c = wn * WTN + j * 16 + l15;
+                red[wm * BN + c] = s; red[(WM + wm) * BN + c] = q; red[(2 * WM + wm) * BN + c] = k;
+            }
+        }
+    }
+    float bj[NT];                                   // PN2_CONV_BIAS: psum carries a per-output-channel fp32 bias (biased conv / nn.Linear without BN)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int cg = n0 + wn * WTN + j * 16 + l15;
+        bj[j] = ((d.flags & PN2_CONV_BIAS) && cg < d.Cout) ? psum[cg] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
+                TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r] + bj[j]);
+            }
+    __syncthreads();
+    if ((d.flags & PN2_CONV_STATS) && tid < BN) {
+        const int col = n0 + tid;
+        if (col < d.Cout) {
+            float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                const float nw = (float)min(max(M - m0 - w * WTM, 0), WTM);
+                if (nw > 0.f) {
+                    const float s = red[w * BN + tid], q = red[(WM + w) * BN + tid], k = red[(2 * WM + w) * BN + tid];
+                    const float mw = k + s / nw, m2w = q - s * s / nw;
+                    const float delta = mw - mean, nt = n + nw;
+                    mean += delta * (nw / nt);
+                    m2 += m2w + delta * delta * (n * nw / nt);
+                    n = nt;
+                }
+            }
+            psum[(size_t)bm * d.Cout + col] = mean;
+            psq[(size_t)bm * d.Cout + col] = m2;
+        }
+    }
+    constexpr int VPR = BN / VEC;
+    const bool vec_ok = (d.Cout % VEC == 0) && (d.ld_out % VEC == 0);
+    const bool accum = d.flags & PN2_CONV_ACCUM;
+    if constexpr (!EP) {
+        for (int idx = tid; idx < BM * VPR; idx += 256) {
+            const int row = idx / VPR, cv = idx - row * VPR;
+            const int m = m0 + row, col = n0 + cv * VEC;
+            if (m >= M || col >= d.Cout) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CRS + cv * 16);
+            T* dst = out + (size_t)m * d.ld_out + col;
+            if (vec_ok) {
+                if (accum) {
+                    float x[VEC], y[VEC];
+                    TT<T>::unpack(v, x);
+                    TT<T>::unpack(*reinterpret_cast<const uint4*>(dst), y);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) x[e] += y[e];
+                    v = TT<T>::pack(x);
+                }
+                *reinterpret_cast<uint4*>(dst) = v;
+            } else {
+                float x[VEC];
+                TT<T>::unpack(v, x);
+                for (int e = 0; e < VEC && col + e < d.Cout; ++e) TT<T>::st(dst + e, accum ? x[e] + TT<T>::ld(dst + e) : x[e]);
+            }
+        }
+    } else {
+    // ---- BatchNorm-backward statistics of the produced gradient tile (vector path only: the host checks the alignment)
+    float sums[4][VEC];
+    const bool dual = ep.b.out != nullptr;
+    if (dual) bnb_target<T, BM, BN>(ep.b, reinterpret_cast<T*>(ep.b.out), ep.b.ld_out, false, Cs, M, m0, n0, d.Cout, pre.rb, pre.rb, pre.vd, sums[2], sums[3]);
+    bnb_target<T, BM, BN>(ep.a, out, d.ld_out, accum, Cs, M, m0, n0, d.Cout, pre.ra, pre.ma, pre.vd, sums[0], sums[1]);
+    __syncthreads();                                   // everyone has drained the C tile
+    // the 256 / VPR row lanes of a channel vector meet in LDS: rs[sum][row lane][BN], then column-parallel adds in a fixed order
+    constexpr int RL = 256 / VPR;
+    float* rs = reinterpret_cast<float*>(smem);
+    const int cv = tid % VPR, rl = tid / VPR, nsum = dual ? 4 : 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < nsum) {
+            float* w = rs + ((size_t)(k * RL + rl) * BN + cv * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) *reinterpret_cast<float4*>(w + e) = make_float4(sums[k][e], sums[k][e + 1], sums[k][e + 2], sums[k][e + 3]);
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < nsum * BN; o += 256) {
+        const int k = o / BN, c = o - k * BN;
+        const float* r = rs + (size_t)k * RL * BN + c;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll 4
+        for (int q = 0; q < RL; q += 4) { v0 += r[q * BN]; v1 += r[(q + 1) * BN]; v2 += r[(q + 2) * BN]; v3 += r[(q + 3) * BN]; }
+        const float v = (v0 + v1) + (v2 + v3);
+        if (n0 + c < d.Cout) {
+            float* pa = (k & 1) ? ep.a.p2 : ep.a.p1;
+            float* pb = (k & 1) ? ep.b.p2 : ep.b.p1;
+            const bool isb = k >= 2;
+            float* pp = isb ? pb : pa;
+            const int ldp = isb ? ep.b.ldp : ep.a.ldp;
+            if ((isb ? ep.b.mode : ep.a.mode) & PN2_BNB_STATS) pp[(size_t)bm * ldp + n0 + c] = v;
+        }
+    }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward / dgrad gather-GEMM
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, bool PW>
+template <typename T, int BM, int BN, int WM, int WN, bool PW, bool EP = false>
 __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in, const T* __restrict__ wp, T* __restrict__ out,
-                                                        float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d) {
+                                                        float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
     constexpr int VEC = TT<T>::VEC, BK = MMA<T>::BK;
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int STAGE = (BM + BN) * RS;
-    constexpr int CRS = BN * (int)sizeof(T) + 16;
     constexpr int NA = BM / 32, NB = BN / 32;     // 16-byte vectors per thread per step (8 vectors per 128-byte row)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -153,6 +420,10 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
             *reinterpret_cast<uint4*>(Bs_ + ((tid >> 3) + 32 * i) * RS + kv * 16) = rb[i];                            \
     } while (0)
 
+    BnbPre<T, BM, BN> pre;
+#ifdef PN2_EP_PREFETCH_EARLY
+    if constexpr (EP) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);
+#endif
     f32x4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -187,76 +458,7 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
 #undef PN2_GLOAD
 #undef PN2_LSTORE
 
-    // ---- epilogue: stats partials + LDS-staged coalesced store
-    char* Cs = smem;
-    float* red = reinterpret_cast<float*>(smem + BM * CRS);   // [2][WM][BN]
-    if (d.flags & PN2_CONV_STATS) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s += v; q += v * v; }
-            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-            if (g == 0) {
-                red[wm * BN + wn * WTN + j * 16 + l15] = s;
-                red[(WM + wm) * BN + wn * WTN + j * 16 + l15] = q;
-            }
-        }
-    }
-    float bj[NT];                                   // PN2_CONV_BIAS: psum carries a per-output-channel fp32 bias (biased conv / nn.Linear without BN)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int cg = n0 + wn * WTN + j * 16 + l15;
-        bj[j] = ((d.flags & PN2_CONV_BIAS) && cg < d.Cout) ? psum[cg] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
-                TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r] + bj[j]);
-            }
-    __syncthreads();
-    if ((d.flags & PN2_CONV_STATS) && tid < BN) {
-        const int col = n0 + tid;
-        if (col < d.Cout) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) { s += red[w * BN + tid]; q += red[(WM + w) * BN + tid]; }
-            psum[(size_t)bm * d.Cout + col] = s;
-            psq[(size_t)bm * d.Cout + col] = q;
-        }
-    }
-    constexpr int VPR = BN / VEC;
-    const bool vec_ok = (d.Cout % VEC == 0) && (d.ld_out % VEC == 0);
-    const bool accum = d.flags & PN2_CONV_ACCUM;
-    for (int idx = tid; idx < BM * VPR; idx += 256) {
-        const int row = idx / VPR, cv = idx - row * VPR;
-        const int m = m0 + row, col = n0 + cv * VEC;
-        if (m >= M || col >= d.Cout) continue;
-        uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CRS + cv * 16);
-        T* dst = out + (size_t)m * d.ld_out + col;
-        if (vec_ok) {
-            if (accum) {
-                float x[VEC], y[VEC];
-                TT<T>::unpack(v, x);
-                TT<T>::unpack(*reinterpret_cast<const uint4*>(dst), y);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) x[e] += y[e];
-                v = TT<T>::pack(x);
-            }
-            *reinterpret_cast<uint4*>(dst) = v;
-        } else {
-            float x[VEC];
-            TT<T>::unpack(v, x);
-            for (int e = 0; e < VEC && col + e < d.Cout; ++e) TT<T>::st(dst + e, accum ? x[e] + TT<T>::ld(dst + e) : x[e]);
-        }
-    }
+    conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -271,14 +473,13 @@ __device__ __attribute__((aligned(16))) unsigned pn2_zero16[4] = {0u, 0u, 0u, 0u
 
 // NS = 3: two K-steps of loads in flight; NS = 2: one step ahead and a third less LDS, so that three (64x128) instead of two workgroups share
 // a CU - the per-shape tuner picks (the K loop runs at ~27 % of the MFMA rate with two resident workgroups: barrier / wait stalls).
-template <int BM, int BN, int WM, int WN, bool PW, int NS = 3>
+template <int BM, int BN, int WM, int WN, bool PW, int NS = 3, bool EP = false>
 __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
-                                                     float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d) {
+                                                     float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
     using T = bf16_t;
     constexpr int VEC = 8, BK = 64, ROW = 128;
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int STAGE = (BM + BN) * ROW;
-    constexpr int CRS = BN * 2 + 16;
     constexpr int NA = BM / 32, NB = BN / 32, LPS = NA + NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -356,6 +557,10 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
                                              (lptr_t)(sb_ + BM * ROW + (i * 32 + wrow) * ROW), 16, 0, 0);              \
     } while (0)
 
+    BnbPre<T, BM, BN> pre;
+#ifdef PN2_EP_PREFETCH_EARLY
+    if constexpr (EP) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);
+#endif
     f32x4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -430,76 +635,7 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
                 }
         return;
     }
-    // ---- epilogue: stats partials + LDS-staged coalesced store (same as conv_gather_gemm)
-    char* Cs = smem;
-    float* red = reinterpret_cast<float*>(smem + BM * CRS);
-    if (d.flags & PN2_CONV_STATS) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s += v; q += v * v; }
-            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-            if (g == 0) {
-                red[wm * BN + wn * WTN + j * 16 + l15] = s;
-                red[(WM + wm) * BN + wn * WTN + j * 16 + l15] = q;
-            }
-        }
-    }
-    float bj[NT];                                   // PN2_CONV_BIAS: psum carries a per-output-channel fp32 bias (biased conv / nn.Linear without BN)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int cg = n0 + wn * WTN + j * 16 + l15;
-        bj[j] = ((d.flags & PN2_CONV_BIAS) && cg < d.Cout) ? psum[cg] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
-                TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r] + bj[j]);
-            }
-    __syncthreads();
-    if ((d.flags & PN2_CONV_STATS) && tid < BN) {
-        const int col = n0 + tid;
-        if (col < d.Cout) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) { s += red[w * BN + tid]; q += red[(WM + w) * BN + tid]; }
-            psum[(size_t)bm * d.Cout + col] = s;
-            psq[(size_t)bm * d.Cout + col] = q;
-        }
-    }
-    constexpr int VPR = BN / VEC;
-    const bool vec_ok = (d.Cout % VEC == 0) && (d.ld_out % VEC == 0);
-    const bool accum = d.flags & PN2_CONV_ACCUM;
-    for (int idx = tid; idx < BM * VPR; idx += 256) {
-        const int row = idx / VPR, cv = idx - row * VPR;
-        const int m = m0 + row, col = n0 + cv * VEC;
-        if (m >= M || col >= d.Cout) continue;
-        uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CRS + cv * 16);
-        T* dst = out + (size_t)m * d.ld_out + col;
-        if (vec_ok) {
-            if (accum) {
-                float x[VEC], y[VEC];
-                TT<T>::unpack(v, x);
-                TT<T>::unpack(*reinterpret_cast<const uint4*>(dst), y);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) x[e] += y[e];
-                v = TT<T>::pack(x);
-            }
-            *reinterpret_cast<uint4*>(dst) = v;
-        } else {
-            float x[VEC];
-            TT<T>::unpack(v, x);
-            for (int e = 0; e < VEC && col + e < d.Cout; ++e) TT<T>::st(dst + e, accum ? x[e] + TT<T>::ld(dst + e) : x[e]);
-        }
-    }
+    conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1020,49 +1156,51 @@ inline int reduce_blocks(const pn2_pack_desc& p) {
     return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_gemm(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, hipStream_t st) {
+template <typename T, int BM, int BN, int WM, int WN, bool EP>
+int launch_gemm(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
     const int M = d.N * d.OH * d.OW;
     const int grid = ((M + BM - 1) / BM) * ((d.Cout + BN - 1) / BN);
-    constexpr int main_b = 2 * (BM + BN) * RS, epi_b = BM * (BN * (int)sizeof(T) + 16) + 2 * WM * BN * 4;
-    constexpr int lds = main_b > epi_b ? main_b : epi_b;
+    constexpr int main_b = 2 * (BM + BN) * RS, epi_b = BM * (BN * (int)sizeof(T) + 16) + 3 * WM * BN * 4;
+    constexpr int ep_b = EP ? ep_lds_bytes(TT<T>::VEC) : 0;
+    constexpr int lds = (main_b > epi_b ? main_b : epi_b) > ep_b ? (main_b > epi_b ? main_b : epi_b) : ep_b;
     const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
     if (lds > 64 * 1024) {      // opt in to more than 64 KiB of dynamic LDS once per instantiation
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, true, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, false, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             done = true;
         }
     }
-    if (pw) hipLaunchKernelGGL((conv_gather_gemm<T, BM, BN, WM, WN, true>), dim3(grid), dim3(256), lds, st, (const T*)in, (const T*)wp, (T*)out, psum, psq, d);
-    else hipLaunchKernelGGL((conv_gather_gemm<T, BM, BN, WM, WN, false>), dim3(grid), dim3(256), lds, st, (const T*)in, (const T*)wp, (T*)out, psum, psq, d);
+    if (pw) hipLaunchKernelGGL((conv_gather_gemm<T, BM, BN, WM, WN, true, EP>), dim3(grid), dim3(256), lds, st, (const T*)in, (const T*)wp, (T*)out, psum, psq, d, ep);
+    else hipLaunchKernelGGL((conv_gather_gemm<T, BM, BN, WM, WN, false, EP>), dim3(grid), dim3(256), lds, st, (const T*)in, (const T*)wp, (T*)out, psum, psq, d, ep);
     PN2_CHECK_LAUNCH();
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NS = 3>
-int launch_dma(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, hipStream_t st) {
+template <bool EP, int BM, int BN, int WM, int WN, int NS = 3>
+int launch_dma(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
     const int M = d.N * d.OH * d.OW;
     const int grid = ((M + BM - 1) / BM) * ((d.Cout + BN - 1) / BN);
-    constexpr int stage_b = (BM + BN) * 128, max_b = NS * stage_b, epi_b = BM * (BN * 2 + 16) + 2 * WM * BN * 4;
+    constexpr int stage_b = (BM + BN) * 128, max_b = NS * stage_b, epi_b = BM * (BN * 2 + 16) + 3 * WM * BN * 4;
     // short-K convs (1-2 K-steps) only touch 1-2 ring slots: ask for less LDS so that more workgroups share a CU
     const int ksteps = (d.KH * d.KW * d.Cin_p + 63) / 64;
     const int main_b = (ksteps < NS ? ksteps : NS) * stage_b;
-    const int lds = main_b > epi_b ? main_b : epi_b;
+    int lds = main_b > epi_b ? main_b : epi_b;
+    if (EP && lds < ep_lds_bytes(8)) lds = ep_lds_bytes(8);
     const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
     if (max_b > 64 * 1024 || epi_b > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, true, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b > epi_b ? max_b : epi_b);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, false, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b > epi_b ? max_b : epi_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, true, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b > epi_b ? max_b : epi_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, false, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b > epi_b ? max_b : epi_b);
             done = true;
         }
     }
     const int ksplit = (d.flags >> 16) & 15;
     const dim3 g3(grid, ksplit > 1 ? ksplit : 1);
-    if (pw) hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, true, NS>), g3, dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
-    else hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, false, NS>), g3, dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d);
+    if (pw) hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, true, NS, EP>), g3, dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d, ep);
+    else hipLaunchKernelGGL((conv_dma_gemm<BM, BN, WM, WN, false, NS, EP>), g3, dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d, ep);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -1095,8 +1233,8 @@ int launch_wgrad(const void* dy, const void* x, float* slab, const pn2_wgrad_des
     return 0;
 }
 
-template <typename T>
-int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, hipStream_t st) {
+template <typename T, bool EP>
+int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
     int bm, bn;
     pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
     // optional per-shape tuning code in flags bits 8..15 (bf16 only): kernel (1 register-staged, 2 LDS-DMA 3-stage, 3 LDS-DMA 2-stage), BM, BN
@@ -1107,37 +1245,37 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
     if constexpr (sizeof(T) == 2) {
         if (tk_ == 3) {              // LDS-DMA, 2-stage ring (more workgroups per CU)
             if (bm == 128) {
-                if (bn == 128) return launch_dma<128, 128, 2, 2, 2>(in, wp, out, psum, psq, d, st);
-                if (bn == 64) return launch_dma<128, 64, 2, 2, 2>(in, wp, out, psum, psq, d, st);
-                return launch_dma<128, 32, 4, 1, 2>(in, wp, out, psum, psq, d, st);
+                if (bn == 128) return launch_dma<EP, 128, 128, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+                if (bn == 64) return launch_dma<EP, 128, 64, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+                return launch_dma<EP, 128, 32, 4, 1, 2>(in, wp, out, psum, psq, d, ep, st);
             }
-            if (bn == 128) return launch_dma<64, 128, 2, 2, 2>(in, wp, out, psum, psq, d, st);
-            if (bn == 64) return launch_dma<64, 64, 2, 2, 2>(in, wp, out, psum, psq, d, st);
-            return launch_dma<64, 32, 4, 1, 2>(in, wp, out, psum, psq, d, st);
+            if (bn == 128) return launch_dma<EP, 64, 128, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+            if (bn == 64) return launch_dma<EP, 64, 64, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+            return launch_dma<EP, 64, 32, 4, 1, 2>(in, wp, out, psum, psq, d, ep, st);
         }
         if (tk_ ? tk_ == 2 : use_dma_kernel()) {
             if (bm == 128) {
-                if (bn == 128) return launch_dma<128, 128, 2, 2>(in, wp, out, psum, psq, d, st);
-                if (bn == 64) return launch_dma<128, 64, 2, 2>(in, wp, out, psum, psq, d, st);
-                return launch_dma<128, 32, 4, 1>(in, wp, out, psum, psq, d, st);
+                if (bn == 128) return launch_dma<EP, 128, 128, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+                if (bn == 64) return launch_dma<EP, 128, 64, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+                return launch_dma<EP, 128, 32, 4, 1>(in, wp, out, psum, psq, d, ep, st);
             }
-            if (bn == 128) return launch_dma<64, 128, 2, 2>(in, wp, out, psum, psq, d, st);
-            if (bn == 64) return launch_dma<64, 64, 2, 2>(in, wp, out, psum, psq, d, st);
-            return launch_dma<64, 32, 4, 1>(in, wp, out, psum, psq, d, st);
+            if (bn == 128) return launch_dma<EP, 64, 128, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+            if (bn == 64) return launch_dma<EP, 64, 64, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+            return launch_dma<EP, 64, 32, 4, 1>(in, wp, out, psum, psq, d, ep, st);
         }
     }
     if (bm == 128) {
         if (bn == 128) {
-            if constexpr (sizeof(T) == 2) return launch_gemm<T, 128, 128, 2, 2>(in, wp, out, psum, psq, d, st);
+            if constexpr (sizeof(T) == 2) return launch_gemm<T, 128, 128, 2, 2, EP>(in, wp, out, psum, psq, d, ep, st);
         }
-        if (bn == 64) return launch_gemm<T, 128, 64, 2, 2>(in, wp, out, psum, psq, d, st);
-        return launch_gemm<T, 128, 32, 4, 1>(in, wp, out, psum, psq, d, st);
+        if (bn == 64) return launch_gemm<T, 128, 64, 2, 2, EP>(in, wp, out, psum, psq, d, ep, st);
+        return launch_gemm<T, 128, 32, 4, 1, EP>(in, wp, out, psum, psq, d, ep, st);
     }
     if (bn == 128) {
-        if constexpr (sizeof(T) == 2) return launch_gemm<T, 64, 128, 2, 2>(in, wp, out, psum, psq, d, st);
+        if constexpr (sizeof(T) == 2) return launch_gemm<T, 64, 128, 2, 2, EP>(in, wp, out, psum, psq, d, ep, st);
     }
-    if (bn == 64) return launch_gemm<T, 64, 64, 2, 2>(in, wp, out, psum, psq, d, st);
-    return launch_gemm<T, 64, 32, 4, 1>(in, wp, out, psum, psq, d, st);
+    if (bn == 64) return launch_gemm<T, 64, 64, 2, 2, EP>(in, wp, out, psum, psq, d, ep, st);
+    return launch_gemm<T, 64, 32, 4, 1, EP>(in, wp, out, psum, psq, d, ep, st);
 }
 
 template <int BMC, int WM, int WN>
@@ -1397,6 +1535,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__
 
 }  // namespace
 
+static int conv_gemm_impl(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, const pn2_conv_ep& ep, void* stream) {
+    if (!in || !wp || !out || !d) return -1;
+    if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
+    if ((d->flags & PN2_CONV_STATS) && (!psum || !psq)) return -1;
+    if ((d->flags & PN2_CONV_BIAS) && (!psum || (d->flags & PN2_CONV_STATS))) return -1;
+    if (((d->flags >> 16) & 15) > 1 && (dtype != PN2_BF16 || !psum || (d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS | PN2_CONV_ACCUM)) || ((d->flags >> 8) & 3) < 2)) return -2;
+    const bool use_ep = (ep.a.mode | ep.b.mode) != 0 || ep.b.out != nullptr;
+    if (dtype == PN2_BF16) return use_ep ? gemm_dispatch<bf16_t, true>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream) : gemm_dispatch<bf16_t, false>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream);
+    if (dtype == PN2_F32) return use_ep ? gemm_dispatch<float, true>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream) : gemm_dispatch<float, false>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream);
+    return -3;
+}
+
+static int bnb_check(const pn2_bnb_target& t, int vec, bool is_b) {
+    if (is_b && !t.out) return t.mode ? -1 : 0;
+    if (is_b && t.ld_out % vec) return -2;
+    if (!(t.mode & PN2_BNB_STATS)) return 0;
+    if (!t.raw || !t.par || !t.p1 || !t.p2 || t.ldp < 1) return -1;
+    if (t.ld_raw % vec || t.ps < 1) return -2;
+    if ((t.mode & PN2_BNB_MASK_Y) && (!t.y || t.ld_y % vec)) return -1;
+    if (t.split > 0 && (t.split % vec || (t.par2 && !t.raw2))) return -2;
+    return 0;
+}
+
 extern "C" {
 
 int pn2_conv_tile_n(int cout) {
@@ -1415,14 +1576,21 @@ int pn2_conv_tile_m(int m, int cout, int dtype) { int bm, bn; pick_tiles(m, cout
 int pn2_conv_stat_blocks(int m, int cout, int dtype) { const int bm = pn2_conv_tile_m(m, cout, dtype); return (m + bm - 1) / bm; }
 
 int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, void* stream) {
-    if (!in || !wp || !out || !d) return -1;
-    if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
-    if ((d->flags & PN2_CONV_STATS) && (!psum || !psq)) return -1;
-    if ((d->flags & PN2_CONV_BIAS) && (!psum || (d->flags & PN2_CONV_STATS))) return -1;
-    if (((d->flags >> 16) & 15) > 1 && (dtype != PN2_BF16 || !psum || (d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS | PN2_CONV_ACCUM)) || ((d->flags >> 8) & 3) < 2)) return -2;
-    if (dtype == PN2_BF16) return gemm_dispatch<bf16_t>(in, wp, out, psum, psq, *d, (hipStream_t)stream);
-    if (dtype == PN2_F32) return gemm_dispatch<float>(in, wp, out, psum, psq, *d, (hipStream_t)stream);
-    return -3;
+    pn2_conv_ep ep;
+    memset(&ep, 0, sizeof(ep));
+    return conv_gemm_impl(dtype, in, wp, out, psum, psq, d, ep, stream);
+}
+
+int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const pn2_conv_desc* d, const pn2_conv_ep* ep, void* stream) {
+    if (!d || !ep) return -1;
+    const int vec = dtype == PN2_F32 ? 4 : 8;
+    if ((d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS)) || ((d->flags >> 16) & 15) > 1) return -2;
+    if (d->Cout % vec || d->ld_out % vec) return -2;                      // the statistics live in the 16-byte store path
+    int rc = bnb_check(ep->a, vec, false);
+    if (rc) return rc;
+    rc = bnb_check(ep->b, vec, true);
+    if (rc) return rc;
+    return conv_gemm_impl(dtype, in, wp, out, nullptr, nullptr, d, *ep, stream);
 }
 
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream) {

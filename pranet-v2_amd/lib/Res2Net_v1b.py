@@ -46,17 +46,24 @@ class Bottle2neck(nn.Module):
         wp = rup(w, 8)
         stage = self.stype == 'stage'
         stride = self.convs[0].stride[0]
-        out1 = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True, out_map=(w, wp))
+        # x_last: conv1 is the first consumer of the block input, so its data gradient is the last contribution to that gradient - the dgrad
+        # GEMM takes the BatchNorm-backward statistics of the previous block's bn3 in its epilogue (engine.conv_bn_act)
+        out1 = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True, out_map=(w, wp), x_last=True)
         spx = [out1.slice(i * wp, (i + 1) * wp, w, w, wp) for i in range(sc)]
         OH = (out1.H + 2 - 3) // stride + 1
         OW = (out1.W + 2 - 3) // stride + 1
         cat = eng.new_act(out1.N, OH, OW, w * sc, w, wp)
+        # the branch convs leave their raw outputs and BatchNorm rows in channel slices of two shared buffers, so that conv3's dgrad can take
+        # the backward statistics of bns[0..2] (and of bn1's last slice, which the concat buffer copies) in one epilogue
+        rawcat = eng.empty(out1.N, OH, OW, sc * wp)
+        pcat = eng.fbuf(4, sc * wp)
         s_in = spx[0]
         for i in range(self.nums):
             # sp_i = relu(bn(conv(s_in))) goes into the concat buffer; the next branch's input sp_i + spx[i+1] (Res2Net_v1b.py:66-68) is written
             # by the same pass (spx[i+1] feeds only that sum: its slice of conv1's gradient doubles as the sum's gradient buffer)
             nxt = spx[i + 1] if (i + 1 < self.nums and not stage) else None
-            r = eng.conv_bn_act(s_in, self.convs[i], self.bns[i], relu=True, out=cat.slice(i * wp, (i + 1) * wp, w, w, wp), out_map=(w, wp), sum_with=nxt)
+            r = eng.conv_bn_act(s_in, self.convs[i], self.bns[i], relu=True, out=cat.slice(i * wp, (i + 1) * wp, w, w, wp), out_map=(w, wp), sum_with=nxt,
+                                raw_out=rawcat[..., i * wp:(i + 1) * wp], par_out=pcat[:, i * wp:(i + 1) * wp], x_last=True)
             if nxt is not None:
                 s_in = r[1]
             elif i + 1 < self.nums:
@@ -64,8 +71,10 @@ class Bottle2neck(nn.Module):
         last = cat.slice(self.nums * wp, sc * wp, w, w, wp)
         if stage:
             eng.avgpool(spx[self.nums], 3, stride, 1, out=last)
+            eng.concat_bnb(cat, rawcat, pcat, split=self.nums * wp, tail=None)
         else:
             eng.copy_into(spx[self.nums], last)
+            eng.concat_bnb(cat, rawcat, pcat, split=self.nums * wp, tail=spx[self.nums])
         if self.downsample is not None:
             pool, dconv, dbn = self.downsample[0], self.downsample[1], self.downsample[2]
             k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
@@ -73,7 +82,7 @@ class Bottle2neck(nn.Module):
             res = eng.conv_bn_act(r, dconv, dbn, relu=False)
         else:
             res = x
-        return eng.conv_bn_act(cat, self.conv3, self.bn3, relu=True, residual=res)
+        return eng.conv_bn_act(cat, self.conv3, self.bn3, relu=True, residual=res, x_last=True)
 
     def forward(self, x):
         return run_module(lambda e, a: [self._build(e, a)], [x], list(self.parameters()), self.training)[0]
@@ -122,8 +131,8 @@ class Res2Net(nn.Module):
         """stem + maxpool + layer1..4 -> (x1, x2, x3, x4), as PraNet_V2.forward drives the backbone (pranet.py:331-341)."""
         c = self.conv1
         x = eng.conv_bn_act(x, c[0], c[1], relu=True)
-        x = eng.conv_bn_act(x, c[3], c[4], relu=True)
-        x = eng.conv_bn_act(x, c[6], self.bn1, relu=True)
+        x = eng.conv_bn_act(x, c[3], c[4], relu=True, x_last=True)          # single-consumer chain: see Bottle2neck._build
+        x = eng.conv_bn_act(x, c[6], self.bn1, relu=True, x_last=True)
         x = eng.maxpool3x3s2(x)
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):

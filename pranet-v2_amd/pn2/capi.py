@@ -61,7 +61,24 @@ class TailDesc(C.Structure):
 
 class BnDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("Cp", C.c_int), ("C", C.c_int), ("gw", C.c_int), ("gwp", C.c_int),
-                ("eps", C.c_float), ("momentum", C.c_float), ("ldp", C.c_int)]
+                ("eps", C.c_float), ("momentum", C.c_float), ("ldp", C.c_int), ("tile_rows", C.c_int)]
+
+
+BNB_STATS, BNB_MASK_RAW, BNB_MASK_Y = 1, 2, 4
+
+
+class BnbTarget(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("ld_out", C.c_int), ("mode", C.c_int), ("raw", C.c_void_p), ("ld_raw", C.c_int),
+                ("y", C.c_void_p), ("ld_y", C.c_int), ("par", C.c_void_p), ("ps", C.c_int), ("split", C.c_int),
+                ("raw2", C.c_void_p), ("par2", C.c_void_p), ("p1", C.c_void_p), ("p2", C.c_void_p), ("ldp", C.c_int)]
+
+
+class ConvEp(C.Structure):
+    _fields_ = [("a", BnbTarget), ("b", BnbTarget)]
+
+
+class BnSegs(C.Structure):
+    _fields_ = [("nseg", C.c_int), ("c0", C.c_int * 4), ("nblk", C.c_int * 4), ("ldp", C.c_int * 4), ("p1", C.c_void_p * 4), ("p2", C.c_void_p * 4)]
 
 
 P, I, LL, FL = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -73,6 +90,7 @@ SIGNATURES = {
     "pn2_conv_tile_m": [I, I, I],
     "pn2_conv_stat_blocks": [I, I, I],
     "pn2_conv_gemm": [I, P, P, P, P, P, C.POINTER(ConvDesc), P],
+    "pn2_conv_gemm_ep": [I, P, P, P, C.POINTER(ConvDesc), C.POINTER(ConvEp), P],
     "pn2_conv_wgrad": [I, P, P, P, C.POINTER(WgradDesc), I, P],
     "pn2_conv_wgrad_variant": [I, C.POINTER(WgradDesc)],
     "pn2_conv_wgrad_blocks": [C.POINTER(WgradDesc), I],
@@ -94,6 +112,7 @@ SIGNATURES = {
     "pn2_bn_bwd_reduce": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, P, I, P],
     "pn2_bn_bwd_blocks": [I, I, I],
     "pn2_bn_bwd_finalize": [P, P, I, C.POINTER(BnDesc), P, P, P, P, I, P, P],
+    "pn2_bn_bwd_finalize_seg": [C.POINTER(BnSegs), C.POINTER(BnDesc), P, P, P, P, I, P, P],
     "pn2_bn_bwd_apply": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, I, I, P, P, I, P],
     "pn2_maxpool3x3s2_fwd": [I, P, I, P, I, P, I, I, I, I, I, I, P],
     "pn2_maxpool3x3s2_bwd": [I, P, I, P, P, I, I, I, I, I, I, I, P],

@@ -72,7 +72,8 @@ class _LinearAsConv:
 
 class Act:
     """NHWC activation view.  t: torch tensor (N,H,W,Cp) whose last dim is contiguous; ld = pixel stride."""
-    __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0", "lat", "galias")
+    __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0", "lat", "galias",
+                 "bnb", "bstats", "sum_of", "dual_done", "_sealed")
 
     def __init__(self, eng, t, C_, gw=None, gwp=None, dt=None, requires_grad=True):
         self.eng, self.t = eng, t
@@ -85,6 +86,11 @@ class Act:
         self.parent, self.c0 = None, 0
         self.lat = None                 # index of the full-resolution lateral output slot this Act is (Engine.lateral_out)
         self.galias = None              # Act whose gradient storage this one shares (Engine.binary(..., grad_alias=True))
+        self.bnb = None                 # Bnb: the train-mode BatchNorm this activation is the output of (statistics of its gradient can be taken in a dgrad epilogue)
+        self.bstats = None              # [(c0, ncols, p1, p2, nblk, ldp)] BatchNorm-backward partial sums left by dgrad epilogues, by physical column range
+        self.sum_of = None              # (u, v): this Act is u + v written by u's BN-apply pass (conv_bn_act(sum_with=v)); its gradient aliases v's
+        self.dual_done = False          # the sum's consumer wrote the gradient of BOTH operands (dual-target dgrad epilogue)
+        self._sealed = False            # a dgrad that declared itself the last contribution has written this gradient
 
     @property
     def grad_written(self):
@@ -106,7 +112,47 @@ class Act:
         """Channel-slice view (physical channel range); its gradient is the same slice of this grad."""
         a = Act(self.eng, self.t[..., c0:c1], C_ if C_ is not None else c1 - c0, gw, gwp, self.dt, self.requires_grad)
         a.parent, a.c0 = self, c0
+        if self.bnb is not None and self.bnb.split == 0:
+            a.bnb = self.bnb.cols(c0, c1)
         return a
+
+    def root(self):
+        """-> (outermost parent, this view's first physical column inside it)"""
+        a, off = self, 0
+        while a.parent is not None:
+            off += a.c0
+            a = a.parent
+        return a, off
+
+    def add_bstats(self, c0, ncols, p1, p2, nblk, ldp):
+        r, off = self.root()
+        if r.bstats is None:
+            r.bstats = []
+        r.bstats.append((off + c0, ncols, p1, p2, nblk, ldp))
+
+    def find_bstats(self):
+        """Segments [(c0 (relative), ncols, p1, p2, nblk, ldp)] that cover this view's columns, newest entry first; None where nothing covers."""
+        r, off = self.root()
+        segs, c = [], 0
+        have = r.bstats or []
+        while c < self.Cp:
+            hit = None
+            for (s0, n, p1, p2, nblk, ldp) in reversed(have):
+                if s0 <= off + c < s0 + n:
+                    hit = (s0, n, p1, p2, nblk, ldp)
+                    break
+            if hit is None:
+                # uncovered run up to the next covered column
+                nxt = min([s0 - off for (s0, n, *_r) in have if s0 - off > c] + [self.Cp])
+                segs.append((c, nxt - c, None, None, 0, 0))
+                c = nxt
+            else:
+                s0, n, p1, p2, nblk, ldp = hit
+                skip = off + c - s0
+                take = min(n - skip, self.Cp - c)
+                segs.append((c, take, p1[:, skip:], p2[:, skip:], nblk, ldp))
+                c += take
+        return segs
 
     def grad_buf(self):
         """Gradient storage (allocated on first use, uninitialised)."""
@@ -121,10 +167,27 @@ class Act:
 
     def grad_sink(self):
         """-> (tensor, accumulate_flag) for a backward op that contributes to this activation's gradient."""
+        if self._sealed:
+            raise RuntimeError("a gradient contribution arrived after the dgrad that was declared the last one (x_last=True)")
         g = self.grad_buf()
         acc = 1 if self.grad_written else 0
         self.grad_written = True
         return g, acc
+
+
+class Bnb:
+    """What a dgrad epilogue needs to take the BatchNorm-backward statistics of the gradient it produces (pn2_conv_gemm_ep):
+    raw: the BN's input (raw conv output) as a [N,H,W,C] view; par: [4][C] rows scale, shift, mean, invstd (a view: row stride = par.stride(0));
+    relu: the activation behind the BN; ymask: the stored output (tensor view) when the ReLU mask cannot be recomputed from raw (BN + residual + ReLU).
+    split / raw2 / par2 / tail: a concat buffer whose columns >= split are (a copy of) another BatchNorm's output `tail` (raw2 / par2 indexed by the
+    same local column; par2 None = those columns carry no BatchNorm)."""
+    __slots__ = ("raw", "par", "relu", "ymask", "split", "raw2", "par2", "tail")
+
+    def __init__(self, raw, par, relu, ymask=None, split=0, raw2=None, par2=None, tail=None):
+        self.raw, self.par, self.relu, self.ymask, self.split, self.raw2, self.par2, self.tail = raw, par, relu, ymask, split, raw2, par2, tail
+
+    def cols(self, c0, c1):
+        return Bnb(self.raw[..., c0:c1], self.par[:, c0:c1], self.relu, self.ymask[..., c0:c1] if self.ymask is not None else None)
 
 
 class ParamGrads:
@@ -246,6 +309,7 @@ GRAD_ALIAS = os.environ.get("PN2_GRAD_ALIAS", "1") == "1"             # sums who
 SPLITK = os.environ.get("PN2_SPLITK", "1") == "1"                     # split-K for few-row / long-contraction convs
 PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
+BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
 
 
 class GradQueue:
@@ -562,22 +626,47 @@ class Engine:
         return wp, d
 
     # ------------------------------------------------------------------ per-shape kernel / tile selection
-    def _tune_gemm(self, cd, in_ptr, wp, M, Cout):
+    def _tune_gemm(self, cd, in_ptr, wp, M, Cout, ep=None):
         """Pick (kernel, BM, BN) for this forward/dgrad shape by timing every candidate once (first eager step; results are cached in
-        self.tuner and reused under hipGraph capture).  Returns the code for pn2_conv_desc.flags bits 8..15 (0 = library heuristic)."""
+        self.tuner and reused under hipGraph capture).  Returns the code for pn2_conv_desc.flags bits 8..15 (0 = library heuristic).
+        ep: the launch carries a BatchNorm-backward epilogue (pn2_conv_gemm_ep): the candidates are timed WITH it (its extra operand reads and
+        per-tile work favour other tiles than the plain kernel), writing to scratch destinations."""
         t = self.tuner
         if t is None or self.dt != BF16:
             return 0
         key = ("g", cd.N, cd.H, cd.W, cd.OH, cd.OW, cd.Cin_p, cd.ld_in, Cout, cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w, cd.transposed)
+        if ep is not None:
+            key = key + ("ep", ep.a.mode, ep.b.mode, 1 if ep.b.out else 0, cd.flags & capi.CONV_ACCUM)
         if key in t:
             return t[key]
         if torch.cuda.is_current_stream_capturing():
             return 0
         st = _stream()
+        nul = C.c_void_p(0)
         scratch = torch.empty((M, Cout), dtype=torch.bfloat16, device=self.dev)
         d2 = capi.ConvDesc()
         C.memmove(C.byref(d2), C.byref(cd), C.sizeof(capi.ConvDesc))
         d2.ld_out, d2.Cout = Cout, Cout
+        if ep is not None:
+            d2.flags = cd.flags & capi.CONV_ACCUM
+            e2 = capi.ConvEp()
+            C.memmove(C.byref(e2), C.byref(ep), C.sizeof(capi.ConvEp))
+            nb64 = (M + 63) // 64
+            tp = torch.empty((4, nb64, Cout), dtype=torch.float32, device=self.dev)
+            e2.a.p1, e2.a.p2, e2.a.ldp = tp[0].data_ptr(), tp[1].data_ptr(), Cout
+            if ep.b.out:
+                scratch_b = torch.empty((M, Cout), dtype=torch.bfloat16, device=self.dev)
+                e2.b.out, e2.b.ld_out = scratch_b.data_ptr(), Cout
+                e2.b.p1, e2.b.p2, e2.b.ldp = tp[2].data_ptr(), tp[3].data_ptr(), Cout
+            base = d2.flags
+
+            def launch(code):
+                d2.flags = base | (code << 8)
+                call.pn2_conv_gemm_ep(self.dt, in_ptr, _p(wp), _p(scratch), C.byref(d2), C.byref(e2), st)
+        else:
+            def launch(code):
+                d2.flags = code << 8
+                call.pn2_conv_gemm(self.dt, in_ptr, _p(wp), _p(scratch), nul, nul, C.byref(d2), st)
         cands = []
         for kern in (1, 2, 3):             # 1 register-staged, 2 LDS-DMA with a 3-stage ring, 3 LDS-DMA with a 2-stage ring (more workgroups per CU)
             for bm in (1, 2):
@@ -588,18 +677,16 @@ class Engine:
                         continue
                     cands.append(kern | (bm << 2) | (bn << 4))
         evs = []
-        nul = C.c_void_p(0)
         cold = TUNE_COLD
         for code in cands:
-            d2.flags = code << 8
-            call.pn2_conv_gemm(self.dt, in_ptr, _p(wp), _p(scratch), nul, nul, C.byref(d2), st)
+            launch(code)
             per = []
             for _ in range(3):
                 if cold:            # inside a step every conv runs once, on operands the caches have mostly lost: time it that way
                     _thrash()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                call.pn2_conv_gemm(self.dt, in_ptr, _p(wp), _p(scratch), nul, nul, C.byref(d2), st)
+                launch(code)
                 e1.record()
                 per.append((e0, e1))
             evs.append(per)
@@ -664,7 +751,8 @@ class Engine:
         return best
 
     # ------------------------------------------------------------------ conv (+BN +ReLU +residual)
-    def conv_bn_act(self, x, conv, bn=None, relu=False, residual=None, out=None, out_map=None, y_dt=None, y_C=None, bias=None, sum_with=None):
+    def conv_bn_act(self, x, conv, bn=None, relu=False, residual=None, out=None, out_map=None, y_dt=None, y_C=None, bias=None, sum_with=None,
+                    raw_out=None, par_out=None, x_last=False):
         """y = act(BN(conv(x)) + residual)   — BasicConv2d / Bottle2neck pieces.
 
         conv: nn.Conv2d (bias-free unless `bias` given), bn: nn.BatchNorm2d or None.
@@ -673,6 +761,11 @@ class Engine:
         y_dt/y_C: fp32 K-channel head outputs (physical raw output stays padded to 8).
         sum_with: an Act of the output's geometry that has no other consumer; returns (y, y + sum_with) - the second tensor (Bottle2neck's
                   sp + spx[i+1]) is written by the same pass and keeps its gradient in sum_with's gradient storage.
+        raw_out / par_out: where the raw conv output ([N,OH,OW,Cout_p] view) and the BatchNorm's per-channel rows (scale, shift, mean, invstd:
+                  a [4][Cout_p] view) go - channel slices of buffers shared by the convs that write one concat buffer (Engine.concat_bnb).
+        x_last:   the caller guarantees that this conv's data gradient is the LAST contribution to x's gradient (x's first consumer in forward
+                  order).  If x is the output of a train-mode BatchNorm, the dgrad GEMM then takes that BatchNorm's backward statistics in its
+                  epilogue (pn2_conv_gemm_ep) and x's producer skips its pn2_bn_bwd_reduce pass.
         """
         w = conv.weight
         Cout, Cin, KH, KW = _w4(w)
@@ -691,6 +784,7 @@ class Engine:
         M = N * OH * OW
         st = _stream()
         train_bn = bn is not None and self.training
+        V = 4 if self.dt == F32 else 8
 
         wp, pd = self.pack(w, x_map, o_map, False)
         # biased conv / nn.Linear with nothing behind it (no BN, activation, residual or re-layout): the bias goes into the GEMM epilogue and
@@ -705,18 +799,24 @@ class Engine:
             else:
                 bvec = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
                 bvec[:Cout] = bias.detach()
+        elif raw_out is not None:
+            assert tuple(raw_out.shape) == (N, OH, OW, Cout_p) and raw_out.dtype == self.tdt and raw_out.stride(2) % V == 0
+            raw = raw_out
         else:
             raw = self.empty(N, OH, OW, Cout_p)
+        raw_ld = raw.stride(2)
         cd = capi.ConvDesc()
         cd.N, cd.H, cd.W, cd.OH, cd.OW = N, H, W, OH, OW
-        cd.Cin_p, cd.ld_in, cd.Cout, cd.ld_out = x.Cp, x.ld, Cout_p, Cout_p
+        cd.Cin_p, cd.ld_in, cd.Cout, cd.ld_out = x.Cp, x.ld, Cout_p, raw_ld
         cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = KH, KW, sh, ph, pw, dh, dw
         cd.transposed, cd.Kp, cd.flags = 0, pd.Kp, (capi.CONV_STATS if train_bn else 0)
         psum = psq = None
         tune = self._tune_gemm(cd, x.ptr, wp, M, Cout_p)
         cd.flags |= tune << 8
+        tile_rows = 0
         if train_bn:
             nblk = self._stat_blocks(M, Cout_p, tune)
+            tile_rows = self._tile_m(M, Cout_p, tune)
             psum, psq = self.fbuf(nblk, Cout_p), self.fbuf(nblk, Cout_p)
         flops = 2 * M * Cout * Cin * KH * KW
         shape = f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}"
@@ -728,10 +828,10 @@ class Engine:
             ws = self.fbuf(ksplit, M, Cout_p)
             cd.flags = ((2 | (1 << 2) | ((3 if Cout_p > 64 else 2) << 4)) << 8) | (ksplit << 16)
             if train_bn:
-                nblk = (M + 63) // 64
+                nblk, tile_rows = (M + 63) // 64, 0          # the reduce leaves raw moments of 64-row blocks
                 psum, psq = self.fbuf(nblk, Cout_p), self.fbuf(nblk, Cout_p)
             call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(ws), _p(None), C.byref(cd), st)
-            call.pn2_conv_splitk_reduce(self.dt, _p(ws), ksplit, M, Cout_p, _p(raw), Cout_p, _p(bvec) if fuse_bias else _p(None),
+            call.pn2_conv_splitk_reduce(self.dt, _p(ws), ksplit, M, Cout_p, _p(raw), raw_ld, _p(bvec) if fuse_bias else _p(None),
                                         _p(psum) if train_bn else _p(None), _p(psq) if train_bn else _p(None), 0, st)
         elif fuse_bias:
             cd.flags |= capi.CONV_BIAS
@@ -739,14 +839,17 @@ class Engine:
         else:
             call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), st)
 
-        scale = shift = mean = invstd = None
+        scale = shift = mean = invstd = par = None
         bd = None
         if bn is not None:
             bd = capi.BnDesc()
             bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, Cout_p, Cout, gw_o, gwp_o, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
-            scale, shift = self.fbuf(Cout_p), self.fbuf(Cout_p)
+            bd.tile_rows = tile_rows
+            par = par_out if par_out is not None else self.fbuf(4, Cout_p)          # rows: scale, shift, mean, invstd
+            assert tuple(par.shape) == (4, Cout_p) and par.stride(1) == 1
+            scale, shift = par[0], par[1]
             if train_bn:
-                mean, invstd = self.fbuf(Cout_p), self.fbuf(Cout_p)
+                mean, invstd = par[2], par[3]
                 call.pn2_bn_finalize(_p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
                                      _p(scale), _p(shift), _p(mean), _p(invstd), st)
                 self.bn_modules.append(bn)
@@ -779,20 +882,25 @@ class Engine:
             raise RuntimeError("sum_with needs a plain same-dtype BN/activation output of the same geometry")
         if sum_with is not None:
             y2 = Act(self, self.empty(N, OH, OW, Cout_p), Cout, gw_o, gwp_o, self.dt)
-            call.pn2_affine_act_sum(self.dt, _p(raw), Cout_p, out.ptr, out.ld, M, Cout_p, _p(scale), _p(shift), (2 if relu == 2 else 1) if relu else 0,
+            call.pn2_affine_act_sum(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, Cout_p, _p(scale), _p(shift), (2 if relu == 2 else 1) if relu else 0,
                                     sum_with.ptr, sum_with.ld, y2.ptr, y2.ld, st)
             if self.need_grad and sum_with.requires_grad:
                 y2.galias = sum_with            # d(y + s)/ds = 1 and s has no other consumer: the sum's gradient lives in s's gradient storage
+                y2.sum_of = (out, sum_with)
         elif not fuse_bias:
-            call.pn2_affine_act(self.dt, _p(raw), Cout_p, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
+            call.pn2_affine_act(self.dt, _p(raw), raw_ld, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
                                 residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
 
         if not self.need_grad:
             return out if y2 is None else (out, y2)
+        # the BatchNorm-backward statistics of this output's gradient can be taken by the dgrad GEMM that completes it (x_last of the consumer)
+        bnb_ok = BNB_EPILOGUE and train_bn and not fuse_bias and y_C is None and y_dt == self.dt and relu in (False, True) and out.ld % V == 0 and Cout_p % V == 0
+        if bnb_ok:
+            out.bnb = Bnb(raw, par, bool(relu), out.t if residual is not None else None)
 
         def bwd():
             st = _stream()
-            if y2 is not None and y2.grad_written:          # the sum's gradient also flows into y (the other operand holds it already)
+            if y2 is not None and y2.grad_written and not y2.dual_done:          # the sum's gradient also flows into y (the other operand holds it already)
                 if y2.galias is not None:
                     assert not sum_with._written, "sum_with: the aliased operand received another gradient"
                     sum_with.grad_written = True
@@ -809,20 +917,38 @@ class Engine:
             ymask = out if relu else None
             r6 = 1 if relu == 2 else 0          # relu: False / True (ReLU) / 2 (ReLU6: the mask also drops the saturated y == 6)
             msc = msh = None
-            if os.environ.get("PN2_MASK_FROM_X", "0") == "1" and relu and train_bn and residual is None and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) % 8 == 0:
+            if bnb_ok and relu and residual is None and dy.stride(2) % V == 0:
                 # ReLU mask recomputed from the raw conv output (fmaf(x, scale, shift) > 0, bit-identical to the forward):
                 # the backward passes then do not read y at all
                 ymask, msc, msh = None, scale, shift
+            nul = C.c_void_p(0)
             if train_bn:
-                nb = call.pn2_bn_bwd_blocks(M, Cout_p, self.dt)
-                p1, p2 = self.fbuf(nb, Cout_p), self.fbuf(nb, Cout_p)
-                call.pn2_bn_bwd_reduce(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
-                                       _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(p1), _p(p2), nb, _p(msc), _p(msh), r6, st)
                 coef = self.fbuf(3 * Cout_p)
                 gg, ga = self.pgrads.sink(bn.weight)
                 gb, gba = self.pgrads.sink(bn.bias)
                 assert ga == gba
-                call.pn2_bn_bwd_finalize(_p(p1), _p(p2), nb, C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
+                segs = out.find_bstats() if (bnb_ok and dy.stride(2) % V == 0) else None
+                if segs is not None and len(segs) <= 4 and any(s_[2] is not None for s_ in segs):
+                    # (part of) the statistics were left by dgrad epilogues; channel ranges nobody covered get a reduce pass of their own
+                    sg = capi.BnSegs()
+                    sg.nseg = len(segs)
+                    for k_, (c0, nc, p1, p2, nb_, ldp) in enumerate(segs):
+                        if p1 is None:
+                            nb_ = call.pn2_bn_bwd_blocks(M, nc, self.dt)
+                            p1, p2, ldp = self.fbuf(nb_, nc), self.fbuf(nb_, nc), nc
+                            ym = ymask.t[..., c0:c0 + nc] if ymask is not None else None
+                            call.pn2_bn_bwd_reduce(self.dt, out.dt, _p(dy[..., c0:c0 + nc]), dy.stride(2), nc, _p(ym), ym.stride(2) if ym is not None else 0, self.dt,
+                                                   _p(raw[..., c0:c0 + nc]), raw_ld, M, nc, _p(mean[c0:]), _p(invstd[c0:]), _p(p1), _p(p2), nb_,
+                                                   _p(msc[c0:]) if msc is not None else nul, _p(msh[c0:]) if msc is not None else nul, r6, st)
+                        sg.c0[k_], sg.nblk[k_], sg.ldp[k_], sg.p1[k_], sg.p2[k_] = c0, nb_, ldp, p1.data_ptr(), p2.data_ptr()
+                        self._keep.append((p1, p2))
+                    call.pn2_bn_bwd_finalize_seg(C.byref(sg), C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
+                else:
+                    nb = call.pn2_bn_bwd_blocks(M, Cout_p, self.dt)
+                    p1, p2 = self.fbuf(nb, Cout_p), self.fbuf(nb, Cout_p)
+                    call.pn2_bn_bwd_reduce(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
+                                           _p(raw), raw_ld, M, Cout_p, _p(mean), _p(invstd), _p(p1), _p(p2), nb, _p(msc), _p(msh), r6, st)
+                    call.pn2_bn_bwd_finalize(_p(p1), _p(p2), nb, C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
             else:
                 coef = None
                 if bn is not None:
@@ -839,8 +965,8 @@ class Engine:
             if coef is None and ymask is None and rg is None and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) == Cout_p and dy.is_contiguous():
                 draw = dy               # no BN, no activation, no residual (nn.Linear / biased conv): dz IS dy - no copy pass
             else:
-                call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else C.c_void_p(0), ymask.ld if ymask else 0, self.dt,
-                                      _p(raw), Cout_p, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
+                call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
+                                      _p(raw), raw_ld, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
                                       _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), r6, st)
             if train_bn:
                 bias_done = bias is None
@@ -909,24 +1035,111 @@ class Engine:
             elif x.requires_grad:
                 wt, ptd = self.pack(w, x_map, o_map, True)
                 gx, gxa = x.grad_sink()
+                Mx = N * H * W
                 dd = capi.ConvDesc()
                 dd.N, dd.H, dd.W, dd.OH, dd.OW = N, OH, OW, H, W
                 dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Cout_p, Cout_p, x.Cp, gx.stride(2)
                 dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = KH, KW, sh, ph, pw, dh, dw
                 dd.transposed, dd.Kp, dd.flags = 1, ptd.Kp, (capi.CONV_ACCUM if gxa else 0)
-                ks = self._ksplit(N * H * W, KH * KW * Cout_p, x.Cp) if gx.stride(2) == x.Cp else 1
+                ks = self._ksplit(Mx, KH * KW * Cout_p, x.Cp) if gx.stride(2) == x.Cp else 1
                 capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
+                dual = x.sum_of is not None and x.galias is x.sum_of[1] and x.sum_of[0].requires_grad
                 if ks > 1:
-                    ws = self.fbuf(ks, N * H * W, x.Cp)
+                    ws = self.fbuf(ks, Mx, x.Cp)
                     dd.flags = ((2 | (1 << 2) | ((3 if x.Cp > 64 else 2) << 4)) << 8) | (ks << 16)
                     call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), _p(ws), C.c_void_p(0), C.byref(dd), st)
-                    call.pn2_conv_splitk_reduce(self.dt, _p(ws), ks, N * H * W, x.Cp, _p(gx), x.Cp, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), gxa, st)
+                    call.pn2_conv_splitk_reduce(self.dt, _p(ws), ks, Mx, x.Cp, _p(gx), x.Cp, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), gxa, st)
+                elif BNB_EPILOGUE and x_last and x.Cp % V == 0 and gx.stride(2) % V == 0 and (x.bnb is not None or dual):
+                    ep = capi.ConvEp()
+                    if dual and x.sum_of[0].grad_written:
+                        dd.flags |= capi.CONV_ACCUM
+                    for t_, a_ in ((ep.a, x.sum_of[0] if dual else x), (ep.b, x.sum_of[1] if dual else None)):       # what the tuner needs to know
+                        if a_ is not None and a_.bnb is not None:
+                            self._fill_bnb(t_, a_, 0)
+                    if dual:
+                        ep.b.out = 1
+                    tcode = self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, ep)
+                    dd.flags |= tcode << 8
+                    nbx = self._stat_blocks(Mx, x.Cp, tcode)
+                    ep = capi.ConvEp()
+                    if dual:
+                        # x = u + v (Bottle2neck's sp + spx[i]): the gradient goes to BOTH operands - accumulated into u's (the concat buffer slice
+                        # conv3's dgrad wrote), stored as v's (aliased by x) - each with the statistics of its own BatchNorm
+                        u, v = x.sum_of
+                        gu, gua = u.grad_sink()
+                        assert gu.stride(2) % V == 0
+                        dd.ld_out, dd.flags = gu.stride(2), (dd.flags & ~capi.CONV_ACCUM) | (capi.CONV_ACCUM if gua else 0)
+                        self._fill_bnb(ep.a, u, nbx)
+                        ep.b.out, ep.b.ld_out = gx.data_ptr(), gx.stride(2)
+                        self._fill_bnb(ep.b, v, nbx)
+                        v.grad_written = True
+                        x.dual_done = True
+                        u._sealed = v._sealed = True
+                        call.pn2_conv_gemm_ep(self.dt, _p(draw), _p(wt), _p(gu), C.byref(dd), C.byref(ep), st)
+                    else:
+                        self._fill_bnb(ep.a, x, nbx)
+                        call.pn2_conv_gemm_ep(self.dt, _p(draw), _p(wt), _p(gx), C.byref(dd), C.byref(ep), st)
+                    x._sealed = True
                 else:
-                    dd.flags |= self._tune_gemm(dd, _p(draw), wt, N * H * W, x.Cp) << 8
+                    dd.flags |= self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp) << 8
                     call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
 
         self.record(bwd)
         return out if y2 is None else (out, y2)
+
+    def _tile_m(self, M, Cout, tune):
+        bm = (tune >> 2) & 3
+        return (64 if bm == 1 else 128) if bm else call.pn2_conv_tile_m(M, Cout, self.dt)
+
+    def _fill_bnb(self, t, act, nblk):
+        """Describe `act`'s BatchNorm to a dgrad epilogue target and register the partial rows it will leave."""
+        b = act.bnb
+        if b is None:
+            t.mode = 0
+            return
+        t.mode = capi.BNB_STATS | (capi.BNB_MASK_Y if b.ymask is not None else (capi.BNB_MASK_RAW if b.relu else 0))
+        t.raw, t.ld_raw = b.raw.data_ptr(), b.raw.stride(2)
+        if b.ymask is not None:
+            t.y, t.ld_y = b.ymask.data_ptr(), b.ymask.stride(2)
+        t.par, t.ps = b.par.data_ptr(), b.par.stride(0)
+        Cp = act.Cp
+        if b.split:
+            t.split = b.split
+            if b.par2 is not None:
+                t.raw2, t.par2 = b.raw2.data_ptr(), b.par2.data_ptr()
+        if nblk == 0:               # description only (the tuner supplies its own partial rows)
+            return
+        p1, p2 = self.fbuf(nblk, Cp), self.fbuf(nblk, Cp)
+        t.p1, t.p2, t.ldp = p1.data_ptr(), p2.data_ptr(), Cp
+        if b.split:
+            t.split = b.split
+            if b.par2 is not None:
+                assert b.raw2.stride(2) == b.raw.stride(2) and b.par2.stride(0) == b.par.stride(0)
+                t.raw2, t.par2 = b.raw2.data_ptr(), b.par2.data_ptr()
+                b.tail.add_bstats(0, Cp - b.split, p1[:, b.split:], p2[:, b.split:], nblk, Cp)
+            act.add_bstats(0, b.split, p1, p2, nblk, Cp)
+        else:
+            act.add_bstats(0, Cp, p1, p2, nblk, Cp)
+
+    def concat_bnb(self, cat, raw, par, split=0, tail=None):
+        """Declare that the channels [0, split or all) of the concat buffer `cat` were written by train-mode conv+BN(+ReLU) ops whose raw outputs /
+        parameter rows sit in the matching channel slices of `raw` / `par` (conv_bn_act(raw_out=, par_out=)); channels >= split are a copy of the
+        BN+ReLU output `tail` (None: they carry no BatchNorm).  The dgrad that completes cat's gradient can then take all those BatchNorms'
+        backward statistics in one epilogue."""
+        if not (BNB_EPILOGUE and self.need_grad and self.training):
+            return
+        tb = tail.bnb if tail is not None else None
+        if tail is not None and (tb is None or not tb.relu or tb.ymask is not None):
+            return
+        r2 = p2 = None
+        if tb is not None:
+            # raw2 / par2 are indexed with cat's local column: shift the tail's views back by `split` columns
+            tr, off = tail.root()
+            rb = tr.bnb
+            if rb is None or off != split or rb.raw.stride(2) != raw.stride(2) or rb.par.stride(0) != par.stride(0):
+                return
+            r2, p2 = rb.raw, rb.par
+        cat.bnb = Bnb(raw, par, True, None, split, r2, p2, tail)
 
     # ------------------------------------------------------------------ fused 1x1 reducers sharing one input
     def conv_bn_multi(self, x, mods):
@@ -983,8 +1196,10 @@ class Engine:
         psum = psq = None
         tune = self._tune_gemm(cd, x.ptr, wp, M, Ct)
         cd.flags |= tune << 8
+        tile_rows = 0
         if train:
             nblk = self._stat_blocks(M, Ct, tune)
+            tile_rows = self._tile_m(M, Ct, tune)
             psum, psq = self.fbuf(nblk, Ct), self.fbuf(nblk, Ct)
         flops = 2 * M * Ct * x.C
         shape = f"{x.C}->{'+'.join(map(str, couts))} k1x1 s1 d1 {N}x{H}x{W}"
@@ -997,6 +1212,7 @@ class Engine:
             bn = m.bn
             bd = capi.BnDesc()
             bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum, bd.ldp = M, co, co, co, co, bn.eps, (bn.momentum if bn.momentum is not None else 0.1), Ct
+            bd.tile_rows = tile_rows
             bds.append(bd)
             if train:
                 call.pn2_bn_finalize(_p(psum[:, off:]), _p(psq[:, off:]), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),

@@ -116,7 +116,7 @@ class Recorder:
             fn = getattr(lib, name)
 
             def wrapped(*a, _fn=fn, _name=name):
-                if _name in ("pn2_conv_gemm", "pn2_conv_wgrad", "pn2_conv_wgrad_multi"):
+                if _name in ("pn2_conv_gemm", "pn2_conv_gemm_ep", "pn2_conv_wgrad", "pn2_conv_wgrad_multi"):
                     fl, tag, shape = capi.WORK.pop("flops", 0), capi.WORK.pop("tag", ""), capi.WORK.pop("shape", "")
                 else:
                     fl, tag, shape = 0, "", _shape(_name, a)
@@ -126,6 +126,8 @@ class Recorder:
                 e1.record()
                 if rc != 0:
                     raise RuntimeError(f"{_name} failed with status {rc}")
+                if _name == "pn2_conv_gemm_ep":
+                    _name = "pn2_conv_gemm"           # same kernel symbols; the tag (:dgrad) keeps the family together
                 self.rows.append((_name + tag, fl, _bytes(_name, a) if not fl else 0, e0, e1, shape))
             self.saved[name] = capi.call.__dict__.get(name)
             setattr(capi.call, name, wrapped)

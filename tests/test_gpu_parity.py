@@ -94,6 +94,86 @@ def test_conv_bn_act_fwd_bwd(dtn, cfg):
 
 
 @pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ["chain", "residual", "big_mean"])
+def test_bn_backward_statistics_in_dgrad_epilogue(dtn, case, monkeypatch):
+    """conv -> BN -> ReLU -> conv -> BN [-> + residual -> ReLU -> conv]: with x_last=True the second (third) conv's dgrad GEMM takes the
+    BatchNorm-backward sums of the layer below in its epilogue (pn2_conv_gemm_ep) instead of a pn2_bn_bwd_reduce pass; same gradients as
+    torch float64 autograd, and - in fp32 - as the engine's own reduce-pass path.  big_mean: |mean| >> sigma channels (the Chan-merged
+    forward statistics must not cancel)."""
+    from pn2 import F32, BF16, engine
+    from pn2.engine import Engine
+    from pn2.graph import _seed_grad
+    from pn2 import capi
+    dt = F32 if dtn == "fp32" else BF16
+    err, tol = (relmax, 5e-5) if dt == F32 else (rell2, 1e-1)         # bf16: three BatchNorm layers deep
+    torch.manual_seed(5)
+    N, H, Wd, C0, C1, C2 = 3, 13, 17, 24, 40, 56
+    c1 = nn.Conv2d(C0, C1, 3, 1, 1, bias=False).to(dev); b1 = nn.BatchNorm2d(C1).to(dev)
+    c2 = nn.Conv2d(C1, C1 if case == "residual" else C2, 3 if case != "residual" else 1, 1, 1 if case != "residual" else 0, bias=False).to(dev)
+    b2 = nn.BatchNorm2d(c2.out_channels).to(dev)
+    c3 = nn.Conv2d(c2.out_channels, 32, 1, bias=False).to(dev); b3 = nn.BatchNorm2d(32).to(dev)
+    for b in (b1, b2, b3):
+        b.weight.data.uniform_(0.5, 1.5); b.bias.data.normal_(0, 0.3)
+    x = torch.randn(N, C0, H, Wd, device=dev)
+    if case == "big_mean":
+        x = x + 6.0
+        c1.weight.data.abs_()          # conv1's outputs: |mean| ~ 25 sigma in every channel
+
+    def run(x_last):
+        eng = Engine(dt, True, need_grad=True)
+        a = eng.from_nchw(x, requires_grad=True)
+        launched = []
+        real = capi.call.pn2_conv_gemm_ep
+        monkeypatch.setattr(capi.call, "pn2_conv_gemm_ep", lambda *aa: (launched.append(1), real(*aa))[1], raising=False)
+        y1 = eng.conv_bn_act(a, c1, b1, relu=True)
+        if case == "residual":
+            y2 = eng.conv_bn_act(y1, c2, b2, relu=True, residual=y1, x_last=x_last)       # y1 feeds the conv first, then the residual add
+            y3 = eng.conv_bn_act(y2, c3, b3, relu=False, x_last=x_last)
+        else:
+            y2 = eng.conv_bn_act(y1, c2, b2, relu=False, x_last=x_last)
+            y3 = eng.conv_bn_act(y2, c3, b3, relu=True, x_last=x_last)
+        out = eng.to_nchw(y3).clone()
+        gy = torch.randn(out.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+        _seed_grad(y3, gy)
+        eng.backward()
+        grads = [a.grad[..., :C0].float().permute(0, 3, 1, 2).clone()] + [eng.pgrads.get(p_).clone() for m_ in (c1, b1, c2, b2, c3, b3) for p_ in m_.parameters()]
+        return out, gy, grads, len(launched)
+
+    out, gy, grads, n_ep = run(True)
+    assert n_ep == 2, "the epilogue path did not run"
+    xc = x.double().cpu().requires_grad_(True)
+    mods = [m_.double().cpu() for m_ in (nn.Conv2d(C0, C1, 3, 1, 1, bias=False), nn.BatchNorm2d(C1), nn.Conv2d(C1, c2.out_channels, c2.kernel_size, 1, c2.padding, bias=False),
+                                        nn.BatchNorm2d(c2.out_channels), nn.Conv2d(c2.out_channels, 32, 1, bias=False), nn.BatchNorm2d(32))]
+    for m_, src in zip(mods, (c1, b1, c2, b2, c3, b3)):
+        m_.load_state_dict({k: v.double().cpu() for k, v in src.state_dict().items()}); m_.train()
+    r1 = F.relu(mods[1](mods[0](xc)))
+    if case == "residual":
+        r2 = F.relu(mods[3](mods[2](r1)) + r1); r3 = mods[5](mods[4](r2))
+    else:
+        r2 = mods[3](mods[2](r1)); r3 = F.relu(mods[5](mods[4](r2)))
+    r3.backward(gy.double().cpu())
+    ref = [xc.grad] + [p_.grad for m_ in mods for p_ in m_.parameters()]
+    if case == "big_mean":
+        if dt == BF16:
+            return                  # bf16 storage of a tensor with |mean| >> sigma has no meaningful reference; fp32 checks the statistics
+        tol = 2e-3                  # the fp32 rounding of the conv outputs themselves is amplified by |mean| / sigma
+    assert err(out, r3) < tol
+    for i_, (g_, r_) in enumerate(zip(grads, ref)):
+        if float(r_.abs().max()) > 1e-9:          # (the bias of a BatchNorm behind a 1x1 conv + train-mode BatchNorm has an exactly-zero gradient)
+            assert err(g_, r_) < tol, (i_, err(g_, r_))
+    # against the separate reduce pass: same sums up to fp32 summation order (bf16: the epilogue sees the fp32 gradient tile before it is rounded)
+    monkeypatch.setattr(engine, "BNB_EPILOGUE", False)
+    out0, _, grads0, n0 = run(True)
+    assert n0 == 0
+    for g_, r_, f_ in zip(grads, grads0, ref):
+        if float(f_.abs().max()) > 1e-9:
+            if dt == F32:
+                assert relmax(g_, r_) < (2e-5 if case != "big_mean" else 2e-3)
+            else:
+                assert rell2(g_, r_) < 3e-2
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
 def test_pool_and_bilinear_ops(dtn):
     from pn2 import F32, BF16
     from pn2.engine import Engine
