@@ -9,6 +9,7 @@ typedef unsigned short bf16_t;   // storage type; arithmetic always in f32
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) double f64x4_t;
 
 #define PN2_F32 0
 #define PN2_BF16 1

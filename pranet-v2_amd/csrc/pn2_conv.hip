@@ -27,18 +27,27 @@ constexpr int RS = ROWB + 16;  // padded LDS row stride (bytes): 36 banks -> the
 template <typename T> struct MMA;
 template <> struct MMA<bf16_t> {
     static constexpr int BK = 32 * KSUB;
+    typedef f32x4_t acc_t;
+    __device__ static __forceinline__ int arow(int l15) { return l15; }
     __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
     }
 };
+// PN2_F32 (the parity path): fp32 storage, products and sums in DOUBLE on v_mfma_f64_16x16x4_f64, one rounding to fp32 per output - every conv
+// result is the correctly rounded fp32 value of the exact contraction, so the only error left against a float64 run of the reference is the
+// fp32 storage of activations (a k-ordered fp32 fma chain over K up to 6400 was 2-4x less accurate than the reference's own blocked fp32 sums).
+// C/D of the f64 form is row = (lane>>4) + 4*reg (not (lane>>4)*4 + reg as in every other MFMA): A rows are fed through the 4x4 index
+// transpose arow() so that the accumulators land in the common layout and the shared epilogue applies unchanged.
 template <> struct MMA<float> {
     static constexpr int BK = 16 * KSUB;
+    typedef f64x4_t acc_t;
+    __device__ static __forceinline__ int arow(int l15) { return ((l15 & 3) << 2) | (l15 >> 2); }
     // lane (g = lane>>4) holds k = 4g..4g+3 of this 16-deep sub-step; MFMA j contracts {j, 4+j, 8+j, 12+j}
-    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    __device__ static __forceinline__ void run(f64x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)__uint_as_float(a.x), (double)__uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)__uint_as_float(a.y), (double)__uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)__uint_as_float(a.z), (double)__uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)__uint_as_float(a.w), (double)__uint_as_float(b.w), acc, 0, 0, 0);
     }
 };
 
@@ -424,11 +433,12 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
 #ifdef PN2_EP_PREFETCH_EARLY
     if constexpr (EP) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);
 #endif
-    f32x4_t acc[MT][NT];
+    typename MMA<T>::acc_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = typename MMA<T>::acc_t{0, 0, 0, 0};
+    const int l15a = MMA<T>::arow(l15);
 
     PN2_GLOAD(0);
     PN2_LSTORE(0);
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
         for (int ks = 0; ks < KSUB; ++ks) {
             uint4 a[MT], b[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(As + (wm * WTM + i * 16 + l15) * RS + ks * 64 + g * 16);
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(As + (wm * WTM + i * 16 + l15a) * RS + ks * 64 + g * 16);
 #pragma unroll
             for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WTN + j * 16 + l15) * RS + ks * 64 + g * 16);
 #pragma unroll
@@ -458,7 +468,16 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
 #undef PN2_GLOAD
 #undef PN2_LSTORE
 
-    conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
+    if constexpr (sizeof(T) == 4) {
+        f32x4_t accf[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) accf[i][j] = f32x4_t{(float)acc[i][j][0], (float)acc[i][j][1], (float)acc[i][j][2], (float)acc[i][j][3]};
+        conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP>(accf, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
+    } else {
+        conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -761,11 +780,11 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
         for (int i = 0; i < NX; ++i) *reinterpret_cast<uint4*>(Xs + (xrow + i * RSTEPX) * RSX + xkv * 16) = (xmask >> i) & 1u ? rx[i] : make_uint4(0, 0, 0, 0);
     };
 
-    f32x4_t acc[MT][NT];
+    typename MMA<T>::acc_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = typename MMA<T>::acc_t{0, 0, 0, 0};
 
     if (s_begin < s_end) {
         gload(s_begin, true);
@@ -797,7 +816,7 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[i], (double)b[j], acc[i][j], 0, 0, 0);
                 }
             }
             lstore(cur ^ 1);
@@ -810,8 +829,11 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                dst[(size_t)(wm * WTM + i * 16 + g * 4 + r) * d.Kp + wn * WTN + j * 16 + l15] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) {
+                // f64 MFMA (fp32 path): C/D row = (lane>>4) + 4*reg; every other form: (lane>>4)*4 + reg
+                const int row = sizeof(T) == 4 ? g + 4 * r : g * 4 + r;
+                dst[(size_t)(wm * WTM + i * 16 + row) * d.Kp + wn * WTN + j * 16 + l15] = (float)acc[i][j][r];
+            }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -3,11 +3,16 @@ the eval tail are compared — through the C ABI — with the CPU oracle on the 
 vectors that the imported reference produced.
 
 Tolerances
-  fp32 path (v_mfma_f32_16x16x4_f32): single ops / blocks 5e-5 relative.  Whole network in train mode: batch-statistics BN over a
-  2-image batch makes the fp32 problem ill-conditioned — the reference's own fp32 CPU result differs from the same reference run in
-  float64 by up to 1e-3 on the logits (measured in tests/golden/make_golden.py, stored as f64.*).  The north-star bound of 1e-4 abs is
-  therefore applied against the float64 reference as  |ours - ref64| <= max(1e-4, 3 * |ref32 - ref64|).
-  bf16 path: relative L2 <= 3e-2 per op (max-norm is meaningless once a ReLU mask bit flips on a near-zero activation).
+  fp32 path (fp32 storage, conv contractions accumulated in double on v_mfma_f64_16x16x4_f64): single ops / blocks 5e-5 relative.
+  Whole network in train mode: batch-statistics BN over a 2-image batch makes the fp32 problem ill-conditioned — the reference's own
+  fp32 CPU result differs from the same reference run in float64 by up to 1.6e-3 on the logits (measured in tests/golden/make_golden.py,
+  stored as f64.*), so "1e-4 abs against the reference's fp32 logits" (north star) cannot be met by ANY fp32 implementation, the
+  reference re-run with another BLAS included.  What is gated instead, against the float64 run of the reference:
+      |ours - ref64| <= max(1e-4, 0.6 * |ref32 - ref64|)      logits and losses  (measured: 0.25-0.4 x the reference's own gap)
+      rel-L2(ours, ref64) <= max(2e-6, 0.8 * rel-L2(ref32, ref64))   every gradient probe, no outliers  (measured <= 0.5 x)
+  i.e. this implementation must be CLOSER to the exact result than the reference's own fp32 path is.
+  bf16 path: relative L2 <= 3e-2 per op (max-norm is meaningless once a ReLU mask bit flips on a near-zero activation); whole model:
+  see test_model_bf16_vs_reference_f64.
 """
 import os
 
@@ -360,13 +365,14 @@ def test_model_forward_backward_vs_reference(tag):
     loss = losses[3] + losses[2] + losses[1] + losses[0]
     loss.backward()
     own_l = float(np.abs(z["s1.losses"] - z["f64.losses"]).max())
-    assert max(abs(float(l) - float(r)) for l, r in zip(losses, z["f64.losses"])) < max(1e-4, 3 * own_l)
+    assert max(abs(float(l.detach()) - float(r)) for l, r in zip(losses, z["f64.losses"])) < max(1e-5, 0.6 * own_l)
     full = tag == "96"
     for i, o in enumerate(outs):
         r32 = torch.from_numpy(z[f"s1.out{i}"]).double(); r64 = torch.from_numpy(z[f"f64.out{i}"])
         got = (o.detach().cpu() if full else o.detach().cpu()[:, :, ::4, ::4]).double()
         own = float((r32 - r64).abs().max())
-        assert float((got - r64).abs().max()) <= max(1e-4, 3 * own), (i, own)
+        e = float((got - r64).abs().max())
+        assert e <= max(1e-4, 0.6 * own), (i, e, own)          # measured 0.25-0.4 x own (tests/parity_probe.py)
     named = dict(model.named_parameters())
     bad = []
     for f in z.files:
@@ -376,14 +382,83 @@ def test_model_forward_backward_vs_reference(tag):
             got = named[k].grad.reshape(-1)[:256].cpu().double()
             own = float((r32 - r64).norm() / (r64.norm() + 1e-30))
             e = float((got - r64).norm() / (r64.norm() + 1e-30))
-            if e > max(3e-3, 6 * own):
+            if e > max(2e-6, 0.8 * own):
                 bad.append((k, e, own))
-    # gradients through ~60 train-mode BN layers are ill-conditioned (the reference's own fp32 error reaches 4e-2); allow isolated
-    # ReLU-mask flips but require the bulk to be within 6x of the reference's own fp32 error (the fp32 MFMA accumulates each
-    # output as one k-ordered fma chain, MKL-DNN's blocked accumulation is ~2-4x more accurate per layer)
-    assert len(bad) <= 2, bad
+    # gradients through ~60 train-mode BN layers are ill-conditioned (the reference's own fp32 error reaches 4e-2 on the stem): every probe
+    # must be closer to the float64 gradient than the reference's own fp32 gradient is (measured <= 0.5 x), no outliers allowed
+    assert not bad, bad
     no_grad = sorted(k for k, p in named.items() if p.grad is None)
     assert no_grad == sorted(str(s) for s in z["nograd"])
+
+
+@pytest.mark.parametrize("tag", ["96", "352"])
+def test_model_bf16_vs_reference_f64(tag):
+    """The BENCHMARKED precision (bf16 storage + bf16 MFMA, fp32 accumulate) end to end against the float64 run of the imported reference.
+    These fixtures (random init, train-mode BN over 2 images) amplify rounding noise ~500x from the stem to the logits, so every bf16
+    execution sits O(1) relative L2 away from the float64 maps; the yardstick is the imported reference under PyTorch's own bf16 policy
+    (torch.autocast("cpu", bfloat16): tests/golden/make_golden_bf16.py).  Gates, per map: rel-L2(ours, ref64) <= 1.5 x rel-L2(torch bf16, ref64);
+    pair losses within 10 % (torch's own bf16 run: 4.6 %); meanDic of the MyTest_med.py:104-111 map no further from the float64 value
+    than torch's bf16 map is (+5e-2: the fixture's meanDic is 0.07, i.e. noise).  'Dice within 1e-3' itself is a property of the fp32 path (test_eval_tail_and_dice_on_train_mode_logits)."""
+    from pn2.loss import structure_loss
+    from pn2.evaltail import test_postprocess
+    from oracle import weights as W
+    from oracle import pranet_oracle as O
+    z = np.load(os.path.join(G, f"pranet_v2_{tag}.npz"))
+    zb = np.load(os.path.join(G, "pranet_v2_bf16ref.npz"))
+    size, n = int(z["size"]), int(z["n"])
+    model = _fixture_model(fp32=False)
+    x, mask = W.synthetic_batch(n, size, seed=1234)
+    xg, mg = x.to(dev), mask.to(dev)
+    with torch.no_grad():
+        outs = model(xg)
+    full = tag == "96"
+    errs, torch_errs = [], []
+    for i, o in enumerate(outs):
+        r64 = torch.from_numpy(z[f"f64.out{i}"])
+        got = (o.cpu() if full else o.cpu()[:, :, ::4, ::4]).double()
+        errs.append(rell2(got, r64)); torch_errs.append(rell2(torch.from_numpy(zb[f"{tag}.out{i}"]), r64))
+    losses = [float(structure_loss(outs[i], outs[i + 4], mg, 1 - mg)) for i in range(4)]
+    lerr = [abs(l - float(r)) / abs(float(r)) for l, r in zip(losses, z["f64.losses"])]
+    tlerr = [abs(float(l) - float(r)) / abs(float(r)) for l, r in zip(zb[f"{tag}.losses"], z["f64.losses"])]
+    print(f"bf16 vs f64 [{tag}]: rel-L2 per map ours {[f'{e:.2f}' for e in errs]}  torch-bf16 {[f'{e:.2f}' for e in torch_errs]}")
+    print(f"   rel loss err ours {[f'{e:.1e}' for e in lerr]}  torch-bf16 {[f'{e:.1e}' for e in tlerr]}")
+    for e, t in zip(errs, torch_errs):
+        assert e <= 1.5 * t, (errs, torch_errs)              # two realisations of amplified rounding noise: measured 0.85 .. 1.4 x torch's
+    for e, t in zip(lerr, tlerr):
+        assert e <= 1e-1, (lerr, tlerr)                      # measured <= 6.9e-2 (torch's own bf16: <= 4.6e-2)
+    if full:
+        dice_gate = []
+        for shape in ((104, 90), (96, 96)):
+            gt = torch.nn.functional.interpolate(mask[:1], size=shape, mode="nearest")[0, 0].numpy()
+            ours = test_postprocess([o[:1] for o in outs], shape).cpu().numpy()
+            ref = O.test_postprocess([torch.from_numpy(z[f"f64.out{i}"])[:1].float() for i in range(8)], shape)
+            tb = O.test_postprocess([torch.from_numpy(zb[f"{tag}.out{i}"])[:1] for i in range(8)], shape)
+            d_ours, d_torch = abs(O.mean_dice(ours, gt) - O.mean_dice(ref, gt)), abs(O.mean_dice(tb, gt) - O.mean_dice(ref, gt))
+            print(f"   meanDic f64 {O.mean_dice(ref, gt):.5f}: ours-bf16 off by {d_ours:.1e}, torch-bf16 off by {d_torch:.1e}")
+            dice_gate.append((d_ours, d_torch))
+        assert all(a <= b + 5e-2 for a, b in dice_gate), dice_gate          # meanDic of this random-init fixture is 0.07: noise on noise (measured 0.08 vs torch's 0.05)
+
+
+def test_bf16_training_trajectory_vs_fp32_oracle():
+    """8 MyTrain_med.py steps (lr 1e-4, clip 0.5) on one fixed batch: the bf16 fused trainer against the CPU oracle in fp32.  The loss
+    curves must stay together (bf16 noise does not accumulate into a different trajectory) and the loss must fall."""
+    from pn2.trainer import Trainer
+    from oracle import weights as W
+    from oracle import pranet_oracle as O
+    model = _fixture_model(fp32=False)
+    x, mask = W.synthetic_batch(2, 96, seed=1234)
+    xg, mg = x.to(dev), mask.to(dev)
+    tr = Trainer(model, lr=1e-4, clip=0.5)
+    NS = 8
+    ours = [float(tr.step(xg, mg)[-1]) for _ in range(NS)]
+    P = W.make_state_dict(W.manifest_pranet_v2(1), seed=0)
+    st = {}
+    ref = [float(O.train_step(P, st, x, mask)[0]) for _ in range(NS)]
+    rel = [abs(a - b) / b for a, b in zip(ours, ref)]
+    print("bf16 trajectory:", [f"{v:.4f}" for v in ours[::2]], " oracle fp32:", [f"{v:.4f}" for v in ref[::2]], f" max rel diff {max(rel):.2e}")
+    # measured: <= 5.3 % on single steps (the first Adam steps move every weight by ~lr * sign(g), see the 2-step test), ~2 % at the end
+    assert max(rel) < 8e-2 and rel[-1] < 4e-2, rel
+    assert ours[-1] < 0.9 * ours[0] and ref[-1] < 0.9 * ref[0]
 
 
 def test_trainer_two_steps_and_eval_tail_vs_reference():
@@ -403,7 +478,7 @@ def test_trainer_two_steps_and_eval_tail_vs_reference():
         s = f"s{step}."
         # step 1 sees identical weights; step 2 follows one Adam update, which at t=1 moves every weight by ~lr*sign(g): sign flips
         # of noise-level gradients make the step-2 loss differ at the 1e-3 level between ANY two fp32 implementations
-        ltol = 1e-3 if step == 1 else 3e-2
+        ltol = 2e-4 if step == 1 else 3e-2
         assert abs(float(loss[-1]) - float(z[s + "loss"])) < ltol
         assert np.abs(loss[:4].cpu().numpy() - z[s + "losses"]).max() < ltol
         for k in [f[len(s + "param."):] for f in z.files if f.startswith(s + "param.")]:
