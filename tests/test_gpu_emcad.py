@@ -359,3 +359,35 @@ def test_depthwise_kxk_and_pair_conv_kernels_at_edge_geometries(dtn):
         assert rell2(part.sum(0).reshape(Fo, 2, 3, 3), wr.grad) < tol, tag
         zs = z.float().reshape(-1, Fo)
         assert rell2(ps.sum(0), zs.sum(0)) < 1e-4 and rell2(pq.sum(0), (zs * zs).sum(0)) < 1e-4, tag
+
+
+def test_full_size_properties_config5_bs16_512_k9_bf16():
+    """BASELINE config 5 shape (EMCADNet dual, K = 9, bs=16 per GPU, 512x512 1-channel slices, bf16, the 15-subset loss + AdamW): finite,
+    deterministic, output geometry (8 maps of [16, 512, 512, 9]), sample-permutation invariance of the batch-mean loss, hipGraph replay == eager."""
+    from pn2.trainer import Trainer
+    g = torch.Generator(device="cpu").manual_seed(77)
+    N, S, K = 16, 512, 9
+    x = torch.randn(N, 1, S, S, generator=g).to(dev)
+    lab = torch.randint(0, K, (N, S // 16, S // 16), generator=g).to(dev)
+    lab = torch.nn.functional.interpolate(lab[:, None].float(), size=(S, S), mode="nearest")[:, 0].long()
+    bg = torch.stack([(lab != k).float() for k in range(K)], 1)
+
+    def trainer():
+        m = _model(False)
+        return Trainer(m, lr=1e-4, clip=None, weight_decay=1e-4, loss="mutation", hot=m.hot_parameters(True))
+    tr = trainer()
+    l1 = tr.forward_backward(x, (lab, bg)).clone(); g1 = tr.gflat.clone()
+    l2 = tr.forward_backward(x, (lab, bg)).clone(); g2 = tr.gflat.clone()
+    assert torch.isfinite(l1).all() and torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    assert torch.equal(l1, l2) and torch.equal(g1, g2), "kernels must be deterministic (no atomics on the data path)"
+    perm = torch.randperm(N, device=dev)
+    l3 = tr.forward_backward(x[perm], (lab[perm], bg[perm]))
+    assert abs(float(l3[0]) - float(l1[0])) < 2e-2 * abs(float(l1[0]))
+    ref = trainer()
+    for _ in range(3):
+        le = ref.step(x, (lab, bg))
+    cap = trainer()
+    cap.capture(x, (lab, bg), warmup=2)
+    lg = cap.replay(x, (lab, bg))
+    torch.cuda.synchronize()
+    assert torch.equal(le, lg) and torch.equal(ref.flat, cap.flat)

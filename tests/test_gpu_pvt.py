@@ -304,3 +304,33 @@ def test_deferred_column_sums_and_splitk_match_immediate_launches(monkeypatch):
         nt = torch.full((nb, 1), 64.0, device=dev); nt[-1] = M - 64 * (nb - 1)
         s1 = (ps1.double() * nt).sum(0); s2 = (pq1.double() + nt * ps1.double() ** 2).sum(0)
         assert rell2(ps2.double().sum(0), s1) < 1e-5 and rell2(pq2.double().sum(0), s2) < 1e-5
+
+
+def test_full_size_properties_config4_bs16_352_bf16():
+    """BASELINE config 4 shape (PVT-PraNet-V2, bs=16 per GPU, 352x352, bf16, DropPath 0): size-independent properties instead of an oracle run -
+    finite, deterministic (bit for bit across two passes), output geometry, batch-permutation invariance of the batch-mean loss (BatchNorm
+    statistics do not depend on the image order; LayerNorm / attention are per image), total == sum of the pair losses, hipGraph replay == eager."""
+    from pn2.trainer import Trainer
+    from oracle import weights as W
+    x, mask = W.synthetic_batch(16, 352, seed=5)
+    xg, mg = x.to(dev), mask.to(dev)
+    tr = Trainer(_pvt_model(fp32=False), lr=1e-4, clip=0.5)
+    l1 = tr.forward_backward(xg, mg).clone(); g1 = tr.gflat.clone(); o1 = tr.last_outs.clone()
+    l2 = tr.forward_backward(xg, mg).clone(); g2 = tr.gflat.clone()
+    assert torch.isfinite(l1).all() and torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    assert torch.equal(l1, l2) and torch.equal(g1, g2), "kernels must be deterministic (no atomics on the data path)"
+    assert o1.shape == (8, 16, 352, 352, 1)
+    perm = torch.randperm(16, device=dev)
+    l3 = tr.forward_backward(xg[perm], mg[perm])
+    assert abs(float(l3[-1]) - float(l1[-1])) < 2e-2 * abs(float(l1[-1]))
+    assert abs(float(l1[:4].sum()) - float(l1[4])) < 1e-5 * abs(float(l1[4]))
+    # one optimizer step moves the weights and lowers nothing to NaN; replaying the captured step == the eager step, bit for bit
+    tr.optimizer_step()
+    ref = Trainer(_pvt_model(fp32=False), lr=1e-4, clip=0.5)
+    for _ in range(3):
+        le = ref.step(xg, mg)
+    cap = Trainer(_pvt_model(fp32=False), lr=1e-4, clip=0.5)
+    cap.capture(xg, mg, warmup=2)
+    lg = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(le, lg) and torch.equal(ref.flat, cap.flat)
