@@ -244,17 +244,22 @@ def pranet_v2_forward(P, x, training, use_softmax=True, sem_downsample=1, featur
     return lat[2][0], lat[3][0], l4_fg, l5_fg, lat[2][1], lat[3][1], l4_bg, l5_bg
 
 
-def pranet_v1_forward(P, x, training):
+def pvt_pranet_v1_forward(P, x, training):
+    """PVT_PraNet.forward (PraNet_Res2Net.py:226-273): PVTv2-B2 features, then exactly the PraNet reverse-attention heads."""
+    return pranet_v1_forward(P, x, training, features=lambda P_, x_, ctx: pvt_features(P_, "backbone.", x_))
+
+
+def pranet_v1_forward(P, x, training, features=None):
     """PraNet.forward (PraNet_Res2Net.py:130-186): reverse attention = (1 - sigmoid(crop)) gate."""
     ctx = Ctx(training)
-    x1, x2, x3, x4 = res2net_features(P, "resnet.", x, ctx)
+    x1, x2, x3, x4 = features(P, x, ctx) if features is not None else res2net_features(P, "resnet.", x, ctx)
     x2_rfb = rfb(P, "rfb2_1.", x2, ctx)
     x3_rfb = rfb(P, "rfb3_1.", x3, ctx)
     x4_rfb = rfb(P, "rfb4_1.", x4, ctx)
     ra5 = aggregation(P, "agg1.", x4_rfb, x3_rfb, x2_rfb, ctx, v1=True)
     l5 = interp(ra5, 8)
     crop = interp(ra5, 0.25)
-    t = (-1 * torch.sigmoid(crop) + 1).expand(-1, 2048, -1, -1).mul(x4)
+    t = (-1 * torch.sigmoid(crop) + 1).expand(-1, x4.shape[1], -1, -1).mul(x4)
     t = basic_conv(P, "ra4_conv1", t, ctx)
     for i in (2, 3, 4):
         t = F.relu(basic_conv(P, f"ra4_conv{i}", t, ctx, padding=2))

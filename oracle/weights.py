@@ -210,6 +210,23 @@ def _emcad_decoder(m, p, channels=(512, 320, 128, 64), kernel_sizes=(1, 3, 5), e
         _basic(m, p + f"ConvBlock{lvl}_fg", c[i], num_class, k); _basic(m, p + f"ConvBlock{lvl}_bg", c[i], num_class, k)
 
 
+def manifest_pvt_pranet_v1(channel=32):
+    """PVT_PraNet (lib/PraNet_Res2Net.py:188-224): key -> shape in state_dict() order."""
+    m = OrderedDict()
+    _pvt_v2(m, "backbone.")
+    _rfb(m, "rfb2_1.", 128, channel); _rfb(m, "rfb3_1.", 320, channel); _rfb(m, "rfb4_1.", 512, channel)
+    _agg(m, "agg1.", channel, None)
+    _basic(m, "ra4_conv1", 512, 256, 1)
+    for i in (2, 3, 4):
+        _basic(m, f"ra4_conv{i}", 256, 256, 5)
+    _basic(m, "ra4_conv5", 256, 1, 1)
+    for s, cin in ((3, 320), (2, 128)):
+        _basic(m, f"ra{s}_conv1", cin, 64, 1)
+        _basic(m, f"ra{s}_conv2", 64, 64, 3); _basic(m, f"ra{s}_conv3", 64, 64, 3)
+        _basic(m, f"ra{s}_conv4", 64, 1, 3)
+    return m
+
+
 def manifest_emcadnet(num_classes=9):
     """EMCADNet(dual=True, encoder='pvt_v2_b2') (multiclass_seg/EMCAD/lib/networks.py:10-98): key -> shape in state_dict() order."""
     m = OrderedDict()

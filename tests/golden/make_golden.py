@@ -234,22 +234,58 @@ def gen_model(size, n, tag, full_maps):
     save(f"pranet_v2_{tag}.npz", **out)
 
 
+V1_PROBES = ("ra4_conv1.conv.weight", "ra3_conv1.conv.weight", "ra2_conv4.conv.weight", "agg1.conv5.weight", "rfb3_1.branch2.2.conv.weight", "ra4_conv5.bn.weight")
+
+
+def _v1_case(make_model, sd0, x, out, probes):
+    """outputs + gradient probes of a V1 model in fp32 and, from the same weights, in float64 (f64.*: the well-conditioned truth)."""
+    for tag, dt in (("", torch.float32), ("f64.", torch.float64)):
+        model = make_model()
+        model.load_state_dict(sd0, strict=True)
+        model = model.to(dt).train()
+        outs = model(x.to(dt))
+        for i, o in enumerate(outs):
+            out[f"{tag}out{i}"] = npy(o)
+        sum(o.square().mean() for o in outs).backward()
+        names = dict(model.named_parameters())
+        for k in probes:
+            out[tag + "graw." + k] = head(names[k].grad)
+            out[tag + "grawnorm." + k] = npy(names[k].grad.norm())
+
+
 def gen_v1(size=96, n=2):
     man = W.manifest_pranet_v1()
     sd0 = W.make_state_dict(man, seed=1)
-    model = R.v1.PraNet()
-    model.load_state_dict(sd0, strict=True)
-    model.train()
     x, _ = W.synthetic_batch(n, size, seed=77)
-    outs = model(x)
-    out = {f"out{i}": npy(o) for i, o in enumerate(outs)}
-    loss = sum(o.square().mean() for o in outs)
-    loss.backward()
-    names = dict(model.named_parameters())
-    for k in ("resnet.layer4.2.conv3.weight", "ra4_conv1.conv.weight", "ra3_conv1.conv.weight", "ra2_conv4.conv.weight", "agg1.conv5.weight"):
-        out["graw." + k] = head(names[k].grad)
-        out["grawnorm." + k] = npy(names[k].grad.norm())
+    out = {}
+    _v1_case(lambda: R.v1.PraNet(), sd0, x, out, ("resnet.layer4.2.conv3.weight",) + V1_PROBES)
     save("pranet_v1_96.npz", **out)
+
+
+def _ref_pvt_v1_model():
+    """Reference PVT_PraNet (PraNet_Res2Net.py:188-224) without its checkpoint file: torch.load patched to {} around construction; DropPath off."""
+    orig = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        m = R.v1.PVT_PraNet()
+    finally:
+        torch.load = orig
+    m.backbone.reset_drop_path(0.0)
+    return m
+
+
+def gen_pvt_v1(size=96, n=2):
+    man = W.manifest_pvt_pranet_v1()
+    model = _ref_pvt_v1_model()
+    ref = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert list(ref.items()) == [(k, list(v)) for k, v in man.items()], "manifest mismatch (PVT_PraNet)"
+    with open(os.path.join(HERE, "manifest_pvt_v1.json"), "w") as f:
+        json.dump({"pvt_pranet": ref, "n_params": sum(p.numel() for p in model.parameters())}, f)
+    sd0 = W.make_state_dict(man, seed=7)
+    x, _ = W.synthetic_batch(n, size, seed=78)
+    out = {}
+    _v1_case(_ref_pvt_v1_model, sd0, x, out, ("backbone.block4.0.attn.q.weight", "backbone.patch_embed1.proj.weight") + V1_PROBES)
+    save("pvt_pranet_v1_96.npz", **out)
 
 
 PVT_PROBES = [
@@ -350,7 +386,7 @@ def gen_eval_metrics():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["manifest", "loss", "dsra", "blocks", "m96", "m352", "v1", "evalm", "pvt"]
+    which = sys.argv[1:] or ["manifest", "loss", "dsra", "blocks", "m96", "m352", "v1", "pvtv1", "evalm", "pvt"]
     if "evalm" in which: gen_eval_metrics()
     if "pvt" in which: gen_pvt()
     if "manifest" in which: gen_manifest()
@@ -360,3 +396,4 @@ if __name__ == "__main__":
     if "m96" in which: gen_model(96, 2, "96", True)
     if "m352" in which: gen_model(352, 2, "352", False)
     if "v1" in which: gen_v1()
+    if "pvtv1" in which: gen_pvt_v1()

@@ -63,6 +63,15 @@ def test_state_dict_matches_reference_manifest():
     assert len(m.hot_parameters()) == 478 - 6          # conv.0/1 and backbone.fc never receive gradients
     m1 = PraNet()
     assert [(k, list(v.shape)) for k, v in m1.state_dict().items()] == [(k, v) for k, v in ref["pranet_v1"].items()]
+    # all four models MyTest_med.py:58-76 constructs load their checkpoints (V1 strict, :59,64)
+    os.environ["PN2_NO_PRETRAINED"] = "1"
+    from lib.PraNet_Res2Net import PVT_PraNet
+    from oracle import weights as W
+    refp = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest_pvt_v1.json")))
+    mp = PVT_PraNet()
+    assert [(k, list(v.shape)) for k, v in mp.state_dict().items()] == [(k, v) for k, v in refp["pvt_pranet"].items()]
+    assert sum(p.numel() for p in mp.parameters()) == refp["n_params"]
+    mp.load_state_dict(W.make_state_dict(W.manifest_pvt_pranet_v1(), seed=7), strict=True)
     # constructor signature / defaults of the reference (pranet.py:270)
     d = PraNet_V2()
     assert (d.num_class, d.sem_downsample, d.use_softmax) == (3, 1, True)

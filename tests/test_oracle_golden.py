@@ -151,6 +151,19 @@ def test_v1_forward():
         assert (o - T(z[f"out{i}"])).abs().max() < 1e-4, i
 
 
+def test_pvt_v1_forward_and_manifest():
+    """PVT_PraNet (PraNet_Res2Net.py:188-273): the oracle's restatement against the imported reference's vectors; manifest == the reference's state_dict."""
+    import json
+    ref = json.load(open(os.path.join(G, "manifest_pvt_v1.json")))
+    assert [(k, list(v)) for k, v in W.manifest_pvt_pranet_v1().items()] == [(k, v) for k, v in ref["pvt_pranet"].items()]
+    z = np.load(os.path.join(G, "pvt_pranet_v1_96.npz"))
+    P = W.make_state_dict(W.manifest_pvt_pranet_v1(), seed=7)
+    x, _ = W.synthetic_batch(2, 96, seed=78)
+    outs = O.pvt_pranet_v1_forward(P, x, True)
+    for i, o in enumerate(outs):
+        assert (o - T(z[f"out{i}"])).abs().max() < 1e-4, i
+
+
 def test_threshold_metrics_oracle_matches_reference_curves():
     """oracle.threshold_metrics == the imported reference's Fmeasure_calu sweep (tests/golden/make_golden.py evalm), NaNs included."""
     import warnings
