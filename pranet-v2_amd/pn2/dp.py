@@ -32,16 +32,26 @@ class GradBuckets:
         self.pending = list(range(len(self.buckets)))
         self.works = []
         self.order = []          # bucket indices in launch order (for tests)
+        self.launched_keys = set()
 
     def _launch(self, b):
-        a, e, _ = self.buckets[b]
+        a, e, keys = self.buckets[b]
+        self.launched_keys |= keys
         self.works.append(dist.all_reduce(self.gflat[a:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         self.order.append(b)
 
-    def launch_ready(self, written, before_launch=None):
-        """Start the all-reduce of every pending bucket whose parameter keys are all in `written`.
+    def launch_ready(self, written, before_launch=None, expected=None):
+        """Start the all-reduce of every pending bucket whose gradients are COMPLETE.
+        written: the set of keys that have received a gradient, or (with `expected`) a dict key -> contributions received so far this step.
+        expected: dict key -> contributions a full backward pass delivers to that parameter (a weight applied k times per step - CAB's shared
+        fc1 / fc2, EMCAD_dual's single sab conv - receives k of them, in different tape entries): a key is complete only when its count has
+        reached that number; keys missing from `expected` never receive a gradient and do not hold a bucket back... until finish().
         before_launch: called once if anything is about to be launched (e.g. join a side stream that produced the gradients)."""
-        ready = [b for b in self.pending if self.buckets[b][2] <= written]
+        if expected is None:
+            ready = [b for b in self.pending if self.buckets[b][2] <= written]
+        else:
+            ready = [b for b in self.pending if all(written.get(k, 0) >= expected[k] for k in self.buckets[b][2] if k in expected)
+                     and any(k in expected for k in self.buckets[b][2])]
         if ready and before_launch is not None:
             before_launch()
         for b in ready:

@@ -198,6 +198,8 @@ class ParamGrads:
         self.provider = provider
         self.bufs = {}
         self.written = set()
+        self.counts = {}            # id(p) -> contributions received this step (a weight applied k times per step receives k)
+        self.on_sink = None         # optional hook(key, count): the data-parallel trainer checks that no contribution follows a sent bucket
 
     def sink(self, p):
         k = id(p)
@@ -205,6 +207,9 @@ class ParamGrads:
             self.bufs[k] = self.provider(p) if self.provider else torch.empty_like(p, dtype=torch.float32)
         acc = 1 if k in self.written else 0
         self.written.add(k)
+        self.counts[k] = self.counts.get(k, 0) + 1
+        if self.on_sink is not None:
+            self.on_sink(k, self.counts[k])
         return self.bufs[k], acc
 
     def get(self, p):

@@ -63,6 +63,7 @@ class Trainer:
         self.hot = hot
         # gradient buckets in arena order (backward completes them from the tail)
         self.buckets = GradBuckets(self.gflat, [(id(p), self.off[id(p)][0], _r4(self.off[id(p)][1])) for p in hot], bucket_bytes, process_group)
+        self._expected = None           # id(p) -> gradient contributions per step, learned from the first backward pass (see _backward)
         self.last_outs = None
         self.pack_cache = PackCache()
         # Everything shape-dependent (step arena, deferred-launch tables, captured graphs) lives in a per-shape state, so the
@@ -158,13 +159,28 @@ class Trainer:
             eng.flush_colsum()
             if rq is not None:
                 rq.flush()
+        # A bucket may leave as soon as every gradient in it is COMPLETE.  "Has been written" is not enough: a weight applied k times per step
+        # (CAB's shared fc1 / fc2, EMCAD_dual's single sab conv) receives k contributions from different tape entries.  The first backward pass
+        # of a trainer therefore only counts contributions per parameter (its buckets all leave at the end); later passes launch a bucket when
+        # every count has reached that number, and a contribution that arrives after its bucket was sent is an error, not a silent corruption.
+        hook = self.world > 1 and reduce_hook
+        expected = self._expected
+        if hook and expected is not None:
+            def late(k, c, bk=self.buckets):
+                if k in bk.launched_keys:
+                    raise RuntimeError("a gradient contribution arrived after its bucket was all-reduced (the model's use of its parameters changed "
+                                       "between steps): build a new Trainer")
+            eng.pgrads.on_sink = late
         for fn in reversed(eng.tape):
             fn()
-            if self.world > 1 and reduce_hook:
-                self.buckets.launch_ready(eng.pgrads.written, before_launch=grads_complete)
+            if hook and expected is not None:
+                self.buckets.launch_ready(eng.pgrads.counts, before_launch=grads_complete, expected=expected)
         eng.tape = []
+        eng.pgrads.on_sink = None
         grads_complete()
         if self.world > 1:
+            if reduce_hook and expected is None:
+                self._expected = dict(eng.pgrads.counts)
             self.buckets.finish()
         self.last_outs = lat
         if self.tuner is not None and len(self.tuner) != self._tuned and os.environ.get("PN2_TUNE_CACHE"):

@@ -43,7 +43,20 @@ def _worker(rank, world, port, q):
     bk.launch_ready({len(sizes) - 1})
     bk.finish()
     ok_rest = torch.allclose(gflat, sum(allg), atol=1e-6)
-    q.put((rank, order, ok_sum, ok_mean, ok_rest))
+    # third step: parameter 5 is applied twice per step (two contributions from different tape entries): its bucket must not leave
+    # after the first one, and the launch order must still be identical on every rank
+    gflat.copy_(local)
+    bk.reset()
+    expected = {i: (2 if i == 5 else 1) for i in range(len(sizes))}
+    counts, seen5 = {}, []
+    for i in [6, 5, 4, 3, 5, 2, 1, 0]:
+        counts[i] = counts.get(i, 0) + 1
+        bk.launch_ready(counts, expected=expected)
+        if i == 5:
+            seen5.append(any(5 in bk.buckets[b][2] for b in bk.order))
+    bk.finish()
+    ok_multi = seen5 == [False, True] and torch.allclose(gflat, sum(allg), atol=1e-6)
+    q.put((rank, order, ok_sum, ok_mean, ok_rest and ok_multi))
     dist.destroy_process_group()
 
 

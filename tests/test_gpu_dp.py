@@ -13,40 +13,70 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _setup():
+def _setup(kind="res2net", autotune=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "pranet-v2_amd"))
     os.environ["PN2_NO_PRETRAINED"] = "1"
-    os.environ["PN2_AUTOTUNE"] = "0"      # every process must launch the same kernels: per-process tuning would pick different tiles, and this
-                                          # 2-image train-mode-BN problem is ill-conditioned enough to flip gradient signs on a rounding difference
+    # autotune off: every process launches the same kernels, so the 2-rank result can be compared tightly with the single process.  autotune on (the
+    # SHIPPED configuration): every process times its own candidates and may pick other tiles; replicas still stay bit-identical (they apply the
+    # same all-reduced gradient), only the comparison with the separately tuned single process needs slack on this ill-conditioned 2-image problem
+    os.environ["PN2_AUTOTUNE"] = "1" if autotune else "0"
     import pn2
-    from lib.pranet import PraNet_V2
     from oracle import weights as W
     pn2.set_compute_dtype("bf16")
-    model = PraNet_V2(num_class=1)
-    model.load_state_dict(W.make_state_dict(W.manifest_pranet_v2(1), seed=0), strict=True)
+    if kind == "emcad":
+        from lib.networks import EMCADNet
+        model = EMCADNet(num_classes=9, kernel_sizes=[1, 3, 5], expansion_factor=2, dw_parallel=True, add=True, lgag_ks=3, activation="relu6", encoder="pvt_v2_b2",
+                         pretrain=False, dual=True)
+        model.load_state_dict(W.make_state_dict(W.manifest_emcadnet(9), seed=5), strict=True)
+        model.backbone.reset_drop_path(0.0)
+    else:
+        from lib.pranet import PraNet_V2
+        model = PraNet_V2(num_class=1)
+        model.load_state_dict(W.make_state_dict(W.manifest_pranet_v2(1), seed=0), strict=True)
     return model.cuda().train(), W
 
 
-def _worker(rank, world, port, q):
+def _batch(kind, W, rank):
+    if kind == "emcad":
+        g = torch.Generator(device="cpu").manual_seed(900 + rank)
+        x = torch.randn(2, 1, 64, 64, generator=g).cuda()
+        lab = torch.randint(0, 9, (2, 64, 64), generator=g).cuda()
+        return x, (lab, torch.stack([(lab != k).float() for k in range(9)], 1))
+    x, m = W.synthetic_batch(2, 96, seed=50 + rank)
+    return x.cuda(), m.cuda()
+
+
+def _trainer(kind, model, pg):
+    from pn2.trainer import Trainer
+    if kind == "emcad":
+        # weights applied more than once per step (CAB fc1 / fc2, the shared sab conv) + 1 MB buckets: a bucket must wait for the LAST contribution
+        return Trainer(model, lr=1e-4, clip=None, weight_decay=1e-4, loss="mutation", hot=model.hot_parameters(True), process_group=pg, bucket_bytes=1 << 20)
+    return Trainer(model, lr=1e-4, clip=0.5, process_group=pg, bucket_bytes=8 << 20)
+
+
+def _worker(rank, world, port, q, kind, autotune):
     try:
-        _worker_body(rank, world, port, q)
+        _worker_body(rank, world, port, q, kind, autotune)
     except Exception:
         import traceback
         q.put((rank, "ERROR", traceback.format_exc()))
 
 
-def _worker_body(rank, world, port, q):
+def _worker_body(rank, world, port, q, kind, autotune):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    model, W = _setup()
-    from pn2.trainer import Trainer
-    x, m = W.synthetic_batch(2, 96, seed=50 + rank)
-    x, m = x.cuda(), m.cuda()
-    tr = Trainer(model, lr=1e-4, clip=0.5, process_group=dist.group.WORLD, bucket_bytes=8 << 20)
-    loss = tr.step(x, m)                      # eager step with bucket hooks
+    model, W = _setup(kind, autotune)
+    tr = _trainer(kind, model, dist.group.WORLD)
+    x, m = _batch(kind, W, rank)
+    loss = tr.forward_backward(x, m)          # first pass: counts the gradient contributions per parameter, buckets leave at the end
     torch.cuda.synchronize()
-    g1 = tr.gflat.clone(); p1 = tr.flat.clone(); order = list(tr.buckets.order)
+    g1 = tr.gflat.clone()
+    tr.optimizer_step()
+    p1 = tr.flat.clone()
+    tr.step(x, m)                             # second pass: bucket hooks inside backward
+    torch.cuda.synchronize()
+    order = list(tr.buckets.order)
     tr.capture(x, m, warmup=2)                # 2 more eager steps, then the split graphs
     tr.replay(); tr.replay()
     torch.cuda.synchronize()
@@ -55,17 +85,18 @@ def _worker_body(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process_with_averaged_gradients():
+@pytest.mark.parametrize("kind,autotune", [("res2net", False), ("res2net", True), ("emcad", False)])
+def test_two_ranks_match_single_process_with_averaged_gradients(kind, autotune):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 2000
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29600 + (os.getpid() + 7 * len(kind) + int(autotune)) % 2000
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, kind, autotune)) for r in range(world)]
     for p in ps:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda r: r[0])
     for r in res:
         assert r[1] != "ERROR" if isinstance(r[1], str) else True, r[2]
     for p in ps:
@@ -74,20 +105,23 @@ def test_two_ranks_match_single_process_with_averaged_gradients():
     g_a, p_a, pf_a, g_b, p_b, pf_b = (torch.from_numpy(t) for t in (g_a, p_a, pf_a, g_b, p_b, pf_b))
     assert order_a == order_b and len(order_a) >= 3 and order_a[-1] == 0, "ranks must launch the bucket collectives in the same order, head bucket last"
     assert torch.equal(g_a, g_b), "both ranks must hold the same summed gradient"
-    assert torch.equal(p_a, p_b) and torch.equal(pf_a, pf_b), "replicas must stay bit-identical (eager step, then 2 eager + 2 replayed steps)"
+    assert torch.equal(p_a, p_b) and torch.equal(pf_a, pf_b), "replicas must stay bit-identical (eager steps, then 2 eager + 2 replayed steps)"
     # single process: the two shards one after the other, gradients averaged by hand, same clamp+Adam
-    model, W = _setup()
-    from pn2.trainer import Trainer
-    tr = Trainer(model, lr=1e-4, clip=0.5)
+    model, W = _setup(kind, autotune)
+    tr = _trainer(kind, model, None)
     gs = []
     for rank in range(world):
-        x, m = W.synthetic_batch(2, 96, seed=50 + rank)
-        tr.forward_backward(x.cuda(), m.cuda())
+        x, m = _batch(kind, W, rank)
+        tr.forward_backward(x, m)
         gs.append(tr.gflat.clone())
     gsum = gs[0] + gs[1]
     torch.cuda.synchronize()
-    ref = (gsum * 0.5).clamp(-0.5, 0.5).cpu()                   # the fused clamp+Adam kernel leaves grad/world, clamped, in the arena (utils.py:7-17)
-    assert float((g_a - ref).norm() / ref.norm()) < 2e-2        # same kernels in the same order -> normally exact; slack for per-process tuner choices
+    ref = (gsum * 0.5).cpu()
+    g_cmp = g_a * 0.5                                           # before the optimizer kernel the arena holds the plain all-reduced sum
+    if not autotune:            # same kernels in the same order -> normally exact
+        assert float((g_cmp - ref).norm() / ref.norm()) < 2e-2
+    # autotune on: this process tuned its own tiles; on the 2-image fixture bf16 rounding noise is amplified to O(1) in the backbone gradients
+    # (tests/test_gpu_parity.py::test_model_bf16_vs_reference_f64), so only the replica-consistency statements above and the Adam bound below hold
     tr.gflat.copy_(gsum * 0.5)
     tr.optimizer_step()
     torch.cuda.synchronize()
