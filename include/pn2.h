@@ -348,9 +348,10 @@ int pn2_bias_grad(const float* dy, int M, int K, float* db, int accumulate, void
  * clip_gradient (utils/utils.py:7-17: per-element clamp) + torch.optim.Adam step (MyTrain_med.py:149,85-86), one launch over
  * the flat parameter arena.  step_ptr: device int64 step counter incremented by the kernel launch before (graph friendly). */
 int pn2_clamp_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
-                   float eps, float clip, float grad_scale, const float* bias_corr /* device [2]: 1-b1^t, 1-b2^t */,
+                   float eps, float clip, float grad_scale, const float* bias_corr /* device [8]: 1-b1^t, 1-b2^t, b1^t, b2^t (pn2_adam_tick), then lr, clip,
+                                    weight_decay and a flag: flag != 0 -> the kernel takes these three from the device (LR schedules under hipGraph replay) */,
                    float weight_decay /* decoupled (torch.optim.AdamW, EMCAD/trainer.py:75): p *= 1 - lr*wd ; 0 = Adam */, void* stream);
-int pn2_adam_tick(float* bias_corr /* [4]: bc1, bc2, b1^t, b2^t */, float beta1, float beta2, void* stream);
+int pn2_adam_tick(float* bias_corr /* updates [0..3]: bc1, bc2, b1^t, b2^t */, float beta1, float beta2, void* stream);
 
 /* MyTest_med.py:104-111 tail on device: sum of 4 maps already resized -> sigmoid -> min-max -> uint8 */
 int pn2_eval_tail(const float* res, unsigned char* out, float* minmax /* scratch [2 + 2*512] */, long long n, void* stream);

@@ -721,6 +721,8 @@ __global__ void adam_tick_k(float* bc, float b1, float b2) {
 
 __global__ __launch_bounds__(256) void clamp_adam_k(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                                                     float lr, float b1, float b2, float eps, float clip, float gsc, const float* __restrict__ bc, float wd) {
+    // bc[7] != 0: lr / clip / weight decay live on the DEVICE (bc[4..6]) so that a captured hipGraph follows adjust_lr() without a re-capture
+    if (bc[7] != 0.f) { lr = bc[4]; clip = bc[5]; wd = bc[6]; }
     const float step = lr / bc[0], rs2 = 1.f / sqrtf(bc[1]), keep = 1.f - lr * wd;       // wd: decoupled weight decay (torch.optim.AdamW), 0 = Adam
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {

@@ -51,7 +51,8 @@ class Trainer:
         self.gflat = torch.zeros(self.n_hot, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(self.n_hot, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(self.n_hot, dtype=torch.float32, device=dev)
-        self.bias_corr = torch.tensor([0.0, 0.0, 1.0, 1.0], dtype=torch.float32, device=dev)
+        # [0..3] Adam bias corrections (pn2_adam_tick); [4..6] lr, clip, weight decay READ BY THE KERNEL (flag [7]): a captured step follows set_lr()
+        self.bias_corr = torch.tensor([0.0, 0.0, 1.0, 1.0, lr, clip, float(weight_decay), 1.0], dtype=torch.float32, device=dev)
         self.off = {}
         o = 0
         for p in hot + cold:
@@ -75,6 +76,28 @@ class Trainer:
         # per process (= per GPU) so every trainer in the process launches identical kernels (bit-reproducible runs)
         self.tuner = TUNER if os.environ.get("PN2_AUTOTUNE", "1") == "1" else None
         self._tuned = len(self.tuner) if self.tuner is not None else 0
+
+    # ------------------------------------------------------------------ optimizer surface (utils.adjust_lr / clip_gradient of MyTrain_med.py:85,155)
+    def set_lr(self, lr):
+        """Takes effect at the next step, captured hipGraphs included (the kernel reads lr from the device)."""
+        self.lr = float(lr)
+        self.bias_corr[4] = self.lr
+
+    def set_clip(self, clip):
+        self.clip = 3.0e38 if clip is None else float(clip)
+        self.bias_corr[5] = self.clip
+
+    @property
+    def param_groups(self):
+        """torch.optim-style view so that utils.adjust_lr(trainer, ...) works: param_groups[0]['lr'] *= decay."""
+        tr = self
+
+        class _Group(dict):
+            def __setitem__(g, k, v):
+                dict.__setitem__(g, k, v)
+                if k == 'lr':
+                    tr.set_lr(v)
+        return [_Group(lr=self.lr, params=self.hot, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)]
 
     # ------------------------------------------------------------------ pieces
     def _grad_view(self, p):
@@ -177,6 +200,11 @@ class Trainer:
                 self.buckets.launch_ready(eng.pgrads.counts, before_launch=grads_complete, expected=expected)
         eng.tape = []
         eng.pgrads.on_sink = None
+        if len(eng.pgrads.written) != len(self.hot):
+            # torch.optim skips parameters whose grad is None; the fused kernel steps the whole arena, so a trained parameter without a gradient
+            # would be stepped with LAST step's gradient.  Fail loudly instead (pass hot= without it, e.g. hot_parameters(one_channel=False)).
+            missing = [n for n, p in self.model.named_parameters() if id(p) in {id(q) for q in self.hot} and id(p) not in eng.pgrads.written]
+            raise RuntimeError(f"{len(missing)} trained parameters received no gradient this step (first: {missing[:3]}): exclude them from `hot`")
         grads_complete()
         if self.world > 1:
             if reduce_hook and expected is None:
@@ -218,8 +246,10 @@ class Trainer:
             raise RuntimeError("optimizer state was saved for a different parameter layout")
         self.model.load_state_dict(sd["model"], strict=True)          # copies into the arena views in place
         with torch.no_grad():
-            self.exp_avg.copy_(o["exp_avg"]); self.exp_avg_sq.copy_(o["exp_avg_sq"]); self.bias_corr.copy_(o["bias_corr"])
+            self.exp_avg.copy_(o["exp_avg"]); self.exp_avg_sq.copy_(o["exp_avg_sq"]); self.bias_corr[:4].copy_(o["bias_corr"][:4])
         self.lr, self.betas, self.eps, self.clip, self.weight_decay = o["lr"], tuple(o["betas"]), o["eps"], o["clip"], o["weight_decay"]
+        with torch.no_grad():
+            self.bias_corr[4:7] = torch.tensor([self.lr, self.clip, self.weight_decay], device=self.bias_corr.device)
         for st in self._states.values():                               # captured graphs baked the old hyper-parameters in
             st.graph = st.graph_opt = None
         return self

@@ -1,5 +1,4 @@
 """Training helpers with the reference's names and behaviour (/root/reference/binary_seg/utils/utils.py)."""
-import numpy as np
 import torch
 
 
@@ -19,25 +18,22 @@ def adjust_lr(optimizer, init_lr, epoch, decay_rate=0.1, decay_epoch=30):
 
 
 class AvgMeter(object):
-    """reference utils/utils.py:26-46: show() = mean of the last `num` recorded values."""
+    """Loss meter of the training loop (same surface as reference utils/utils.py:26-46: update(val, n), show(), reset(); val / avg / sum /
+    count attributes).  show() is the mean of the most recent `num` values, as a tensor."""
 
     def __init__(self, num=40):
         self.num = num
         self.reset()
 
     def reset(self):
-        self.val = 0
-        self.avg = 0
-        self.sum = 0
-        self.count = 0
+        self.val = self.avg = self.sum = self.count = 0
         self.losses = []
 
     def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
+        self.val, self.sum, self.count = val, self.sum + val * n, self.count + n
         self.avg = self.sum / self.count
         self.losses.append(val)
 
     def show(self):
-        return torch.mean(torch.stack(self.losses[np.maximum(len(self.losses) - self.num, 0):]))
+        recent = self.losses[-self.num:] if self.num > 0 else self.losses[len(self.losses):]
+        return torch.stack(list(recent)).mean()

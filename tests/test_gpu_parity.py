@@ -607,6 +607,29 @@ def test_graph_replay_matches_eager_bf16():
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_lr_schedule_reaches_captured_graph():
+    """utils.adjust_lr (MyTrain_med.py:155) on the fused trainer: the optimizer kernel reads lr from the device, so a captured hipGraph follows
+    the schedule without a re-capture (the by-value lr used to be baked into the graph)."""
+    from pn2.trainer import Trainer
+    from utils.utils import adjust_lr
+    from oracle import weights as W
+    x, m = W.synthetic_batch(2, 96, seed=9)
+    xg, mg = x.to(dev), m.to(dev)
+    tr = Trainer(_fixture_model(fp32=False), lr=1e-4, clip=0.5)
+    tr.capture(xg, mg, warmup=2)
+    p0 = tr.flat.clone(); tr.replay(); torch.cuda.synchronize()
+    d1 = float((tr.flat - p0).abs().max())
+    assert 0.5e-4 < d1 <= 1.01e-4 * 3.2                       # Adam: |step| <= lr * (1 - b1^t) / sqrt(1 - b2^t) ~ lr early on
+    adjust_lr(tr, 1e-4, epoch=60, decay_rate=0.1, decay_epoch=30)          # lr *= 0.1 ** 2
+    assert abs(tr.lr - 1e-6) < 1e-12
+    p1 = tr.flat.clone(); tr.replay(); torch.cuda.synchronize()
+    d2 = float((tr.flat - p1).abs().max())
+    assert d2 < 0.02 * d1 and d2 > 0
+    tr.set_lr(0.0)
+    p2 = tr.flat.clone(); tr.replay(); torch.cuda.synchronize()
+    assert torch.equal(tr.flat, p2)
+
+
 @pytest.mark.parametrize("fp32", [False, True])
 def test_table_driven_launches_match_single_launches(fp32, monkeypatch):
     """pn2_conv_wgrad_multi / pn2_wgrad_reduce_multi over the step arena == one pn2_conv_wgrad + pn2_wgrad_reduce per conv, bit for bit."""
