@@ -26,6 +26,7 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_F64_TFLOPS = 78.6      # v_mfma_f64_16x16x4_f64 (the fp32 parity path accumulates in double)
 PEAK_HBM_GBS = 8000.0
 TRAIN_GFLOP_PER_IMG = 78.02   # 13.004 GMAC fwd x 2 x 3 (fwd + dgrad + wgrad)
 
@@ -43,23 +44,59 @@ def synthetic(n, size, seed, device):
     return x.to(device), m.to(device)
 
 
-def cpu_baseline(size, bs):
-    """The oracle's train step (kind 'port') on the host cores: 1 warm-up + 2 timed steps at a reduced batch."""
+def cpu_baseline(size):
+    """the CPU oracle (kind 'port': oracle/pranet_oracle.py, a torch-CPU restatement of the same step) on this host's cores, fp32:
+    eval forward at bs=1 and bs=32 and one train step at bs=8 (extrapolated per image; bs=32 would take minutes), median after warm-ups.
+    Bounded to ~20-30 s: bs=1 5 timed after 2 warm-ups; bs=32 eval and bs=8 train 3 timed after 1 warm-up."""
+    import statistics
     from oracle import pranet_oracle as O
     from oracle import weights as W
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     P = W.make_state_dict(W.manifest_pranet_v2(1), seed=0)
-    x, mask = W.synthetic_batch(bs, size, seed=1234)
+
+    def med(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+    x1, _ = W.synthetic_batch(1, size, seed=1234)
+    x32, _ = W.synthetic_batch(32, size, seed=1234)
+    x8, m8 = W.synthetic_batch(8, size, seed=1234)
+    with torch.no_grad():
+        t_e1 = med(lambda: O.pranet_v2_forward(O.clone_sd(P), x1, False), 2, 5)
+        t_e32 = med(lambda: O.pranet_v2_forward(O.clone_sd(P), x32, False), 1, 3)
     st = {}
-    O.train_step(P, st, x, mask)
+    t_tr = med(lambda: O.train_step(P, st, x8, m8), 1, 3)
+    return {"value": round(8 / t_tr, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "eval_fwd_bs1_img_s": round(1 / t_e1, 2), "eval_fwd_bs32_img_s": round(32 / t_e32, 2), "train_bs8_s_per_step": round(t_tr, 3),
+            "sample": f"oracle (torch CPU fp32, {cores} threads) at {size}x{size}: value = train step (fwd+4x structure_loss+bwd+clamp+Adam) at bs=8, median of 3 after 1 warm-up "
+                      f"({t_tr:.2f} s/step; bs=32 extrapolates per image); eval forward bs=1 median of 5 after 2 warm-ups ({1e3 * t_e1:.0f} ms), bs=32 median of 3 after 1 ({t_e32:.2f} s)"}
+
+
+def fp32_line(model_ctor, x, m, steps=5):
+    """The same step on the fp32 parity path (fp32 storage, conv contractions accumulated in double on v_mfma_f64_16x16x4_f64), eager + hipGraph:
+    the precision all tight parity evidence is on (tests/test_gpu_parity.py)."""
+    import pn2
+    from pn2.trainer import Trainer
+    pn2.set_compute_dtype("fp32")
+    torch.manual_seed(0)
+    tr = Trainer(model_ctor(), lr=1e-4, clip=0.5)
+    tr.capture(x, m, warmup=2)
+    tr.replay(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    reps = 2
-    for _ in range(reps):
-        O.train_step(P, st, x, mask)
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": round(bs / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle train step (fwd+4x structure_loss+bwd+clamp+Adam) fp32, bs={bs} at {size}x{size}, 1 warm-up + {reps} timed steps, {dt:.2f} s/step"}
+    for _ in range(steps):
+        tr.replay()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    pn2.set_compute_dtype("bf16")
+    del tr
+    torch.cuda.empty_cache()
+    return {"value": round(x.shape[0] / el, 2), "unit": "images/sec", "ms_per_step": round(1e3 * el, 3), "steps": steps, "peak_tf": PEAK_F64_TFLOPS,
+            "mfma_frac_whole_step": round(x.shape[0] / el * TRAIN_GFLOP_PER_IMG / 1e3 / PEAK_F64_TFLOPS, 4),
+            "note": "fp32 storage; conv products / sums in double on v_mfma_f64_16x16x4_f64 (78.6 TF/s dense peak), one rounding per output"}
 
 
 def main():
@@ -75,7 +112,7 @@ def main():
                     help="res2net = BASELINE config 2/3 (headline); pvt = config 4 (PVT_PraNet_V2, use --batch 16); "
                          "emcad = config 5 (EMCADNet dual K=9 + the 15-subset loss + AdamW, use --batch 16 --size 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--no-fp32-line", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,7 +174,21 @@ def main():
 
     # ---- instrumented extra step: per-kernel-family HIP-event timing (not part of the timed region)
     from pn2 import profile as prof
-    roof = prof.measure_step(tr, x, m, args.dtype)
+    roof = prof.measure_step(tr, x, m, args.dtype, config={"model": args.model, "batch": args.batch, "size": args.size, "dtype": args.dtype})
+    # ---- data-parallel exchange: how much of the gradient all-reduce is exposed (time of a step with the collectives minus one without)
+    dp = None
+    if world > 1:
+        def timed(fn, n=5):
+            torch.cuda.synchronize(); dist.barrier(); t0_ = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0_) / n
+        st_ = tr._cur
+        t_all = timed(step)
+        t_noex = timed(lambda: (st_.graph.replay(), st_.graph_opt.replay())) if use_graph and st_.graph_opt is not None else None
+        dp = {"backend": "nccl (RCCL)", "nccl_ranks": world, "buckets": len(tr.buckets.buckets), "bucket_bytes": 32 << 20, "allreduce_bytes_per_step": int(tr.n_hot * 4),
+              "exposed_comm_ms": None if t_noex is None else round(1e3 * (t_all - t_noex), 3)}
     names = {"res2net": "PraNet-V2 Res2Net50", "pvt": "PVT-PraNet-V2 (pvt_v2_b2, DropPath 0.1)", "emcad": "EMCADNet dual K=9 (pvt_v2_b2 encoder, EMCAD decoder)"}
     what = ("fwd+15-subset CE/Dice/BCE loss+bwd+AdamW" if args.model == "emcad" else "fwd+4x structure_loss+bwd+clamp+Adam")
 
@@ -156,8 +207,14 @@ def main():
                                      round(ips / world * (TRAIN_GFLOP_PER_IMG if args.model == "res2net" else 72.3) / 1e3 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4)),
             "roofline": roof["roofline"], "kernels": roof["kernels"],
         }
+        if dp is not None:
+            out["dp"] = dp
+        if world == 1 and not args.no_fp32_line and args.model == "res2net" and args.dtype == "bf16":
+            del tr
+            torch.cuda.empty_cache()
+            out["fp32"] = fp32_line(lambda: PraNet_V2(num_class=1).to(dev).train(), x, m)
         if world == 1 and not args.no_cpu_baseline and args.model != "emcad":
-            out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_batch)
+            out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

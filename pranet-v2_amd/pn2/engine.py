@@ -36,9 +36,14 @@ def load_tuner(path):
 
 
 def save_tuner(path):
+    """Rank 0 only (every DP rank would otherwise race on the same file), through a temporary file + os.replace (no torn reads)."""
     import json
-    with open(path, "w") as f:
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
         json.dump({repr(k): v for k, v in TUNER.items()}, f)
+    os.replace(tmp, path)
 
 
 if os.environ.get("PN2_TUNE_CACHE"):

@@ -12,6 +12,7 @@ from . import capi
 from .capi import F32
 
 _EL = {0: 4, 1: 2}
+ACTUAL = {}     # bytes the fused DSRA tail kernels really move (next to SURVEY's algorithmic 17*S figure)
 
 
 def _bytes(name, a):
@@ -27,6 +28,9 @@ def _bytes(name, a):
         if name == "pn2_bn_bwd_apply":
             dt, dt_dy, Cdy, y, M, Cp, dres = a[0], a[1], a[4], a[5], a[10], a[11], a[17]
             return M * (Cdy * _EL[dt_dy] + Cp * _EL[dt] * (2 + (1 if y.value else 0) + (1 if dres.value else 0)))
+        if name == "pn2_affine_act_sum":
+            dt, M, C = a[0], a[5], a[6]
+            return M * C * _EL[dt] * 4                      # raw + the other operand in, y and y + operand out
         if name in ("pn2_bilinear_fwd", "pn2_bilinear_bwd", "pn2_avgpool_fwd", "pn2_avgpool_bwd"):
             dt, N, H, W, C, OH, OW = a[0], a[5], a[6], a[7], a[8], a[9], a[10]
             return N * C * _EL[dt] * (H * W + OH * OW)
@@ -38,7 +42,8 @@ def _bytes(name, a):
             # backward accounts for re-reading the 2P maps (this implementation recomputes them from the low-res logits instead)
             d = a[0]._obj
             S = d.N * d.OH * d.OW * 4
-            return S * (2 * d.P + 1) if name.endswith("fwd") else S * 2 * d.P
+            ACTUAL["tail"] = ACTUAL.get("tail", 0) + (S * (2 * d.P + 2) if name.endswith("fwd") else S * 2)   # what the kernels really move: fwd writes 2P maps +
+            return S * (2 * d.P + 1) if name.endswith("fwd") else S * 2 * d.P                                  # reads mask, weit; bwd reads mask, weit only
         if name == "pn2_structure_loss_fwd":
             P, N, HW = a[2], a[9], a[10]
             return N * HW * 4 * (2 * P + 2)
@@ -151,24 +156,46 @@ class Recorder:
         return agg
 
 
-def _pmc_traffic(symbols):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary (profiles/, made by tools/pmc_summary.py from
-    separate FETCH_SIZE / WRITE_SIZE passes of this same bench command).  None when the summary is absent."""
+def _pmc_traffic(symbols, config):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary (profiles/, made by tools/pmc_summary.py from separate
+    FETCH_SIZE / WRITE_SIZE passes of `bench.py --no-graph`).  Only reported when that summary was recorded for THIS workload (model, batch,
+    size, dtype); None otherwise - a number measured on another configuration would describe a different run."""
     import json, os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r01_pmc_hbm_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r02_pmc_hbm_traffic.json")
     try:
-        ks = json.load(open(path))["kernels"]
+        doc = json.load(open(path))
+        ks = doc["kernels"]
     except Exception:
+        return None
+    if any(doc.get("config", {}).get(k) != v for k, v in config.items()):
         return None
     rows = [ks[k] for k in symbols if k in ks]
     if not rows:
         return None
     n = sum(r["launches"] for r in rows)
-    return {"bytes_per_launch": int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n), "source": "profiles/r01_pmc_hbm_traffic.json"}
+    return {"bytes_per_launch": int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n), "source": "profiles/r02_pmc_hbm_traffic.json",
+            "commit": doc.get("commit"), "step_total_bytes": doc.get("step_total_bytes")}
 
 
-def measure_step(trainer, x, m, dtype):
+def _conv_class(shape):
+    """layer class of a conv launch from its shape string 'Cin->Cout kHxW sS dD NxHxW' (per-class TF/s)"""
+    try:
+        io, k = shape.split(" ")[0], shape.split(" ")[1]
+        cin = int(io.split("->")[0]); cout = sum(int(v) for v in io.split("->")[1].split("+"))
+        if k == "k1x1":
+            return "1x1 wide (>= 416 ch)" if max(cin, cout) >= 416 else "1x1 narrow (< 416 ch)"
+        if k == "k3x3" and cin == cout and cin in (26, 52, 104, 208):
+            return "3x3 Res2Net branch (26/52/104/208 ch)"
+        if k == "k5x5":
+            return "5x5 (ra4)"
+        return "3x3 / 1xk / kx1 other (stem, RFB, aggregation, heads)"
+    except Exception:
+        return "other"
+
+
+def measure_step(trainer, x, m, dtype, config=None):
     peak_tf = 2500.0 if dtype == "bf16" else 157.3
+    ACTUAL.clear()
     trainer.step(x, m)                       # eager warm-up (allocator, caches)
     # Keep the GPU queue full during the instrumented step: a spin kernel first, so the host runs ahead and every event marker
     # executes back to back with the kernel it brackets (otherwise each elapsed time would include the idle-queue dispatch latency).
@@ -180,6 +207,7 @@ def measure_step(trainer, x, m, dtype):
         torch.cuda._sleep(int(min(1.5 * host_ms + 20.0, 2000.0) / max(per_cycle_ms, 1e-9)))
         trainer.step(x, m)
     agg = rec.summary()
+    detail = rec.summary(detail=True)
     kernels = {}
     for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         e = {"ms": round(d["ms"], 3), "launches": d["launches"]}
@@ -196,10 +224,27 @@ def measure_step(trainer, x, m, dtype):
     roofline = {"kernel": "pn2_conv_gemm (fwd+dgrad; symbols conv_dma_gemm<*>, conv_gather_gemm<*>)", "bound": "mfma", "achieved": round(ach, 2),
                 "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": None, "launches": nl,
                 "avg_launch_us": round(1e3 * ms / nl, 2), "algorithmic_gflop_per_launch": round(fl / nl / 1e9, 3)}
-    traffic = _pmc_traffic(("conv_dma_gemm", "conv_gather_gemm"))
+    traffic = _pmc_traffic(("conv_dma_gemm", "conv_gather_gemm"), config or {})
     if traffic is not None:
         roofline["traffic"] = traffic["bytes_per_launch"]
         roofline["traffic_source"] = traffic["source"]
+        roofline["traffic_commit"] = traffic["commit"]
+        roofline["step_hbm_bytes_pmc"] = traffic["step_total_bytes"]
+    # per layer class (forward + dgrad launches of the conv GEMM family)
+    cls = {}
+    for name, d in detail.items():
+        if name.startswith("pn2_conv_gemm") and d["flops"]:
+            c = cls.setdefault(_conv_class(name.split(" ", 1)[1] if " " in name else ""), [0.0, 0, 0])
+            c[0] += d["ms"]; c[1] += d["launches"]; c[2] += d["flops"]
+    roofline["conv_classes"] = {k: {"ms": round(v[0], 3), "launches": v[1], "TFLOPs": round(v[2] / (v[0] * 1e-3) / 1e12, 1), "frac": round(v[2] / (v[0] * 1e-3) / 1e12 / peak_tf, 4)}
+                                for k, v in sorted(cls.items(), key=lambda kv: -kv[1][0])}
+    # the BatchNorm family: HBM-bound streaming passes + the per-layer finalisation launches
+    bn_names = ("pn2_affine_act", "pn2_affine_act_sum", "pn2_bn_finalize", "pn2_bn_bwd_reduce", "pn2_bn_bwd_finalize", "pn2_bn_bwd_finalize_seg", "pn2_bn_bwd_apply")
+    bn = [agg[k] for k in bn_names if k in agg]
+    if bn:
+        by, ms_, nl_ = sum(t["bytes"] for t in bn), sum(t["ms"] for t in bn), sum(t["launches"] for t in bn)
+        roofline["hbm_batchnorm"] = {"kernels": [k for k in bn_names if k in agg], "bound": "hbm", "achieved": round(by / (ms_ * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                     "frac": round(by / (ms_ * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_MB": round(by / 1e6, 1), "ms": round(ms_, 3), "launches": nl_}
     wg = [d for n, d in agg.items() if n.startswith("pn2_conv_wgrad")]
     if wg:
         wfl, wms, wnl = sum(d["flops"] for d in wg), sum(d["ms"] for d in wg), sum(d["launches"] for d in wg)
@@ -211,5 +256,6 @@ def measure_step(trainer, x, m, dtype):
     if tail:
         by = sum(t["bytes"] for t in tail); ms = sum(t["ms"] for t in tail)
         roofline["hbm_dsra_tail"] = {"kernels": list(names), "bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                                     "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_MB": round(by / 1e6, 1), "us": round(ms * 1e3, 1)}
+                                     "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_MB": round(by / 1e6, 1), "us": round(ms * 1e3, 1),
+                                     "actual_MB": round(ACTUAL.get("tail", 0) / 1e6, 1), "actual_frac": round(ACTUAL.get("tail", 0) / (ms * 1e-3) / 1e9 / 8000.0, 4)}
     return {"roofline": roofline, "kernels": kernels}
