@@ -71,13 +71,16 @@ int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* p
  * Res2Net_v1b.py:60-63,70-72,84-89 ; pranet.py:40-43).  A dgrad GEMM whose result completes the gradient dy of a BatchNorm output y = act(BN(raw))
  * has every dy tile in registers: the epilogue loads the matching `raw` (and, for BN + residual + ReLU, the stored y) tile, forms
  * dz = dy * [y > 0] and leaves the per-channel partial sums  p1[tile][c] = sum dz,  p2[tile][c] = sum dz * (raw - mean) * invstd  of its rows -
- * the separate pn2_bn_bwd_reduce pass (three full-tensor reads) disappears.  The stored result stays UNMASKED (pn2_bn_bwd_apply masks).
+ * the separate pn2_bn_bwd_reduce pass (three full-tensor reads) disappears.  The stored result stays UNMASKED (pn2_bn_bwd_apply masks) unless
+ * PN2_BNB_STORE_MASKED is set.
  * Target `a` describes the GEMM's own destination `out`; target `b` (optional, b.out != NULL) receives a second copy of the plain result
  * (never accumulated) with its own statistics: the gradient of Bottle2neck's  sp + spx[i]  (Res2Net_v1b.py:66-68) flows to both operands,
  * which sit behind two different BatchNorms.  16-byte aligned rows only; excludes PN2_CONV_STATS / PN2_CONV_BIAS / split-K.               */
 #define PN2_BNB_STATS 1      /* emit p1 / p2 */
 #define PN2_BNB_MASK_RAW 2   /* ReLU mask recomputed as fmaf(raw, scale, shift) > 0 (bit-identical to the forward's affine pass) */
 #define PN2_BNB_MASK_Y 4     /* ReLU mask from the stored activation y > 0 (BN + residual + ReLU) */
+#define PN2_BNB_STORE_MASKED 8   /* store dz (the masked gradient) instead of the plain one: it IS the gradient of the residual branch, so the caller
+                                    can alias that buffer and pn2_bn_bwd_apply neither re-reads y nor writes dres */
 typedef struct pn2_bnb_target {
     void* out; int ld_out;          /* target b only: second destination (same dtype / column range as the GEMM's out) */
     int mode;                       /* PN2_BNB_* ; 0 = no statistics */

@@ -68,6 +68,11 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
                                                      float* scale, float* shift, float* mean_o, float* invstd_o, int CPB) {
     __shared__ double sh[2][4][8];
     const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
+    // the per-channel parameters are requested BEFORE the partial rows are walked: loaded after the reduction they would add a second,
+    // fully exposed memory latency to a kernel that is nothing but latency (156 of these per step)
+    const int lc0 = (rl == 0 && c < d.Cp) ? phys2log(c, d.gw, d.gwp, d.C) : -1;
+    float pg = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
+    if (lc0 >= 0) { pg = gamma[lc0]; pb = beta[lc0]; if (running_mean) { prm = running_mean[lc0]; prv = running_var[lc0]; } }
     double s1, s2, k0 = 0.0;
     if (d.tile_rows > 0) {
         // Chan merge of per-tile (mean_t, M2_t): with K = the mean of tile 0 as a shift,
@@ -93,13 +98,13 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
         else { mean = s1 / d.M; var = s2 / d.M - mean * mean; }
         if (var < 0.0) var = 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)d.eps));
-        const float sc = gamma[lc] * invstd;
-        scale[c] = sc; shift[c] = beta[lc] - (float)mean * sc;
+        const float sc = pg * invstd;
+        scale[c] = sc; shift[c] = pb - (float)mean * sc;
         mean_o[c] = (float)mean; invstd_o[c] = invstd;
         if (running_mean) {
             const double unb = d.M > 1 ? var * ((double)d.M / (double)(d.M - 1)) : var;
-            running_mean[lc] = (1.f - d.momentum) * running_mean[lc] + d.momentum * (float)mean;
-            running_var[lc] = (1.f - d.momentum) * running_var[lc] + d.momentum * (float)unb;
+            running_mean[lc] = (1.f - d.momentum) * prm + d.momentum * (float)mean;
+            running_var[lc] = (1.f - d.momentum) * prv + d.momentum * (float)unb;
         }
     }
 }
@@ -224,6 +229,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
                                                          float* dgamma, float* dbeta, int accumulate, float* coef, int CPB) {
     __shared__ double sh[2][4][8];
     const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
+    const int lc0 = (rl == 0 && c < d.Cp) ? phys2log(c, d.gw, d.gwp, d.C) : -1;       // parameters first, see bn_finalize_k
+    float pg = 0.f, pis = 0.f, pdb = 0.f, pdg = 0.f;
+    if (lc0 >= 0) { pg = gamma[lc0]; pis = invstd[c]; if (accumulate) { pdb = dbeta[lc0]; pdg = dgamma[lc0]; } }
     double s1, s2;
     reduce_partials(p1, p2, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, 256 / CPB, s1, s2);
     const int cs = d.ldp ? d.ldp : d.Cp;     // plane stride of coef
@@ -231,9 +239,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
     if (rl == 0 && c < d.Cp) {
         const int lc = phys2log(c, d.gw, d.gwp, d.C);
         if (lc < 0) { coef[c] = 0.f; coef[cs + c] = 0.f; coef[2 * cs + c] = 0.f; return; }
-        if (accumulate) { dbeta[lc] += (float)s1; dgamma[lc] += (float)s2; }
-        else { dbeta[lc] = (float)s1; dgamma[lc] = (float)s2; }
-        coef[c] = gamma[lc] * invstd[c];
+        dbeta[lc] = pdb + (float)s1; dgamma[lc] = pdg + (float)s2;
+        coef[c] = pg * pis;
         coef[cs + c] = (float)(s1 / d.M);
         coef[2 * cs + c] = (float)(s2 / d.M);
     }
@@ -248,6 +255,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_seg_k(pn2_bn_segs sg, pn2
 #pragma unroll
     for (int k = 1; k < 4; ++k) if (k < sg.nseg && c >= sg.c0[k]) si = k;
     const int cc = c - sg.c0[si];
+    const int lc0 = (rl == 0 && c < d.Cp) ? phys2log(c, d.gw, d.gwp, d.C) : -1;       // parameters first, see bn_finalize_k
+    float pg = 0.f, pis = 0.f, pdb = 0.f, pdg = 0.f;
+    if (lc0 >= 0) { pg = gamma[lc0]; pis = invstd[c]; if (accumulate) { pdb = dbeta[lc0]; pdg = dgamma[lc0]; } }
     double s1, s2;
     reduce_partials(sg.p1[si], sg.p2[si], sg.nblk[si], c < d.Cp ? cc + 1 : 0, sg.ldp[si], cc, rl, 256 / CPB, s1, s2);
     const int cs = d.ldp ? d.ldp : d.Cp;     // plane stride of coef
@@ -255,9 +265,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_seg_k(pn2_bn_segs sg, pn2
     if (rl == 0 && c < d.Cp) {
         const int lc = phys2log(c, d.gw, d.gwp, d.C);
         if (lc < 0) { coef[c] = 0.f; coef[cs + c] = 0.f; coef[2 * cs + c] = 0.f; return; }
-        if (accumulate) { dbeta[lc] += (float)s1; dgamma[lc] += (float)s2; }
-        else { dbeta[lc] = (float)s1; dgamma[lc] = (float)s2; }
-        coef[c] = gamma[lc] * invstd[c];
+        dbeta[lc] = pdb + (float)s1; dgamma[lc] = pdg + (float)s2;
+        coef[c] = pg * pis;
         coef[cs + c] = (float)(s1 / d.M);
         coef[2 * cs + c] = (float)(s2 / d.M);
     }

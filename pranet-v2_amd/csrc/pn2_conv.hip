@@ -140,7 +140,7 @@ __device__ __forceinline__ void bnb_params(const pn2_bnb_target& t, const float*
 
 // One target: walk this thread's rows of the staged C tile, store them to dst (+= vd when ACC) and accumulate t1 = sum dz, t2 = sum dz * raw
 template <typename T, int BM, int BN, bool ACC, bool FULL>
-__device__ __forceinline__ void bnb_rows(T* __restrict__ dst, int ld_dst, const char* Cs, int M, int m0, int col, int cv, bool cok, bool stat, bool usey,
+__device__ __forceinline__ void bnb_rows(T* __restrict__ dst, int ld_dst, const char* Cs, int M, int m0, int col, int cv, bool cok, bool stat, bool usey, bool smask,
                                          const uint4* vr, const uint4* vm, const uint4* vd, const float* msc, const float* msh, float* t1, float* t2) {
     constexpr int VEC = TT<T>::VEC, VPR = BN / VEC, CRS = BN * (int)sizeof(T) + 16, RPT = BnbPre<T, BM, BN>::RPT;
     const int r0 = threadIdx.x / VPR;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void bnb_rows(T* __restrict__ dst, int ld_dst, const 
             o = TT<T>::pack(x);
             TT<T>::unpack(o, x);                  // the statistics see the STORED (rounded) gradient, as a separate reduce pass would
         }
-        *reinterpret_cast<uint4*>(dst + (size_t)m * ld_dst + col) = o;
+        if (!smask) *reinterpret_cast<uint4*>(dst + (size_t)m * ld_dst + col) = o;
         if (stat) {
             float xr[VEC], ms[VEC];
             TT<T>::unpack(vr[u], xr);
@@ -169,8 +169,10 @@ __device__ __forceinline__ void bnb_rows(T* __restrict__ dst, int ld_dst, const 
             for (int e = 0; e < VEC; ++e) {
                 const float dz = fmaf(ms[e], msc[e], msh[e]) > 0.f ? x[e] : 0.f;
                 t1[e] += dz; t2[e] = fmaf(dz, xr[e], t2[e]);
+                x[e] = dz;
             }
         }
+        if (smask) *reinterpret_cast<uint4*>(dst + (size_t)m * ld_dst + col) = TT<T>::pack(x);      // PN2_BNB_STORE_MASKED (only set together with statistics)
     }
 }
 
@@ -188,13 +190,14 @@ __device__ __forceinline__ void bnb_target(const pn2_bnb_target& t, T* __restric
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
     const bool usey = (t.mode & PN2_BNB_MASK_Y) != 0;
+    const bool smask = stat && (t.mode & PN2_BNB_STORE_MASKED) != 0;
     const bool full = m0 + BM <= M && n0 + BN <= Cout;
     if (full) {
-        if (accum) bnb_rows<T, BM, BN, true, true>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, vr, vm, vd, msc, msh, t1, t2);
-        else bnb_rows<T, BM, BN, false, true>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, vr, vm, vd, msc, msh, t1, t2);
+        if (accum) bnb_rows<T, BM, BN, true, true>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2);
+        else bnb_rows<T, BM, BN, false, true>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2);
     } else {
-        if (accum) bnb_rows<T, BM, BN, true, false>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, vr, vm, vd, msc, msh, t1, t2);
-        else bnb_rows<T, BM, BN, false, false>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, vr, vm, vd, msc, msh, t1, t2);
+        if (accum) bnb_rows<T, BM, BN, true, false>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2);
+        else bnb_rows<T, BM, BN, false, false>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2);
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s1[e] = t1[e]; s2[e] = is[e] * (t2[e] - mu[e] * t1[e]); }

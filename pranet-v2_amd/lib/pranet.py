@@ -36,11 +36,12 @@ class BasicConv2d(nn.Module):
         self.bn = nn.BatchNorm2d(out_planes)
         self.relu = nn.ReLU(inplace=True)
 
-    def _build(self, eng, x, relu=False, residual=None, out=None, head=False):
+    def _build(self, eng, x, relu=False, residual=None, out=None, head=False, x_last=False):
+        """x_last: this conv is x's first consumer in forward order, so its data gradient completes x's gradient (engine.conv_bn_act)."""
         if head:      # K-channel fp32 head map; raw conv output keeps 8-channel padded rows
             K = self.conv.out_channels
-            return eng.conv_bn_act(x, self.conv, self.bn, relu=relu, out_map=(K, rup(K, 8)), y_dt=F32, y_C=K)
-        return eng.conv_bn_act(x, self.conv, self.bn, relu=relu, residual=residual, out=out)
+            return eng.conv_bn_act(x, self.conv, self.bn, relu=relu, out_map=(K, rup(K, 8)), y_dt=F32, y_C=K, x_last=x_last)
+        return eng.conv_bn_act(x, self.conv, self.bn, relu=relu, residual=residual, out=out, x_last=x_last)
 
     def forward(self, x):
         return run_module(lambda e, a: [self._build(e, a)], [x], list(self.parameters()), self.training)[0]
@@ -73,8 +74,8 @@ class RFB_modified(nn.Module):
         eng.copy_into(heads[0], cat.slice(0, c))
         for bi, br in enumerate((self.branch1, self.branch2, self.branch3), start=1):
             t = br[1]._build(eng, heads[bi])
-            t = br[2]._build(eng, t)
-            br[3]._build(eng, t, out=cat.slice(bi * c, (bi + 1) * c))
+            t = br[2]._build(eng, t, x_last=True)                  # single-consumer chain
+            br[3]._build(eng, t, out=cat.slice(bi * c, (bi + 1) * c), x_last=True)
         y = self.conv_cat._build(eng, cat, relu=True, residual=heads[4])
         return (y, heads[5:]) if extra else y
 
@@ -112,14 +113,14 @@ class aggregation(nn.Module):
         x2_2 = self.conv_concat2._build(eng, cat2)
         self.conv_upsample5._build(eng, up(x2_2), out=cat3.slice(c, 3 * c))
         x3_2 = self.conv_concat3._build(eng, cat3)
-        return self.conv4._build(eng, x3_2)
+        return self.conv4._build(eng, x3_2, x_last=True)
 
     def _build(self, eng, x1, x2, x3):
         x = self._build_trunk(eng, x1, x2, x3)
         heads = []
-        for conv in (self.conv5_fg, self.conv5_bg):
+        for j, conv in enumerate((self.conv5_fg, self.conv5_bg)):
             K = conv.out_channels
-            heads.append(eng.conv_bn_act(x, conv, None, out_map=(K, rup(K, 8)), y_dt=F32, y_C=K, bias=conv.bias))
+            heads.append(eng.conv_bn_act(x, conv, None, out_map=(K, rup(K, 8)), y_dt=F32, y_C=K, bias=conv.bias, x_last=(j == 0)))   # fg: x's first consumer
         return heads
 
     def forward(self, x1, x2, x3):
@@ -140,9 +141,9 @@ def _dsra_tail(m, eng, t1, ra5_fg, ra5_bg):
     c_fg, c_bg = up(ra5_fg, 0.25), up(ra5_bg, 0.25)
     t = t1[4]
     t = m.ra4_conv2._build(eng, t, relu=True)
-    t = m.ra4_conv3._build(eng, t, relu=True)
-    t = m.ra4_conv4._build(eng, t, relu=True)
-    f = m.ra4_conv5_fg._build(eng, t, head=True)
+    t = m.ra4_conv3._build(eng, t, relu=True, x_last=True)
+    t = m.ra4_conv4._build(eng, t, relu=True, x_last=True)
+    f = m.ra4_conv5_fg._build(eng, t, head=True, x_last=True)      # fg head: t's first consumer (the bg head's gradient arrives first in backward)
     b = m.ra4_conv5_bg._build(eng, t, head=True)
     f = eng.dsra_fuse(f, c_fg, c_bg, m.use_softmax)
     l4_fg, l4_bg = final(f, 32 / sd, 2), final(b, 32 / sd, 6)
@@ -151,8 +152,8 @@ def _dsra_tail(m, eng, t1, ra5_fg, ra5_bg):
         c_fg, c_bg = up(f, 2), up(b, 2)
         t = t1[s]
         t = getattr(m, f"ra{s}_conv2")._build(eng, t, relu=True)
-        t = getattr(m, f"ra{s}_conv3")._build(eng, t, relu=True)
-        f = getattr(m, f"ra{s}_conv4_fg")._build(eng, t, head=True)
+        t = getattr(m, f"ra{s}_conv3")._build(eng, t, relu=True, x_last=True)
+        f = getattr(m, f"ra{s}_conv4_fg")._build(eng, t, head=True, x_last=True)
         b = getattr(m, f"ra{s}_conv4_bg")._build(eng, t, head=True)
         f = eng.dsra_fuse(f, c_fg, c_bg, m.use_softmax)
         lat[s] = (final(f, u / sd, s - 2), final(b, u / sd, s + 2))     # slot = position in the returned 8-tuple

@@ -64,7 +64,7 @@ class BnDesc(C.Structure):
                 ("eps", C.c_float), ("momentum", C.c_float), ("ldp", C.c_int), ("tile_rows", C.c_int)]
 
 
-BNB_STATS, BNB_MASK_RAW, BNB_MASK_Y = 1, 2, 4
+BNB_STATS, BNB_MASK_RAW, BNB_MASK_Y, BNB_STORE_MASKED = 1, 2, 4, 8
 
 
 class BnbTarget(C.Structure):

@@ -9,6 +9,7 @@ groups of `gw` (Res2Net's 26/52-wide splits, K-channel heads) stores each group 
 up to 8 slots, the pad slots holding exact zeros; weights are packed with matching zero rows/columns,
 so the arithmetic is unchanged while every pixel row stays 16-byte aligned.
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -78,7 +79,7 @@ class _LinearAsConv:
 class Act:
     """NHWC activation view.  t: torch tensor (N,H,W,Cp) whose last dim is contiguous; ld = pixel stride."""
     __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0", "lat", "galias",
-                 "bnb", "bstats", "sum_of", "dual_done", "_sealed")
+                 "bnb", "bstats", "sum_of", "dual_done", "_sealed", "grad_masked")
 
     def __init__(self, eng, t, C_, gw=None, gwp=None, dt=None, requires_grad=True):
         self.eng, self.t = eng, t
@@ -96,6 +97,7 @@ class Act:
         self.sum_of = None              # (u, v): this Act is u + v written by u's BN-apply pass (conv_bn_act(sum_with=v)); its gradient aliases v's
         self.dual_done = False          # the sum's consumer wrote the gradient of BOTH operands (dual-target dgrad epilogue)
         self._sealed = False            # a dgrad that declared itself the last contribution has written this gradient
+        self.grad_masked = False        # that dgrad stored dz = dy * [y > 0] (PN2_BNB_STORE_MASKED): the gradient buffer already carries the ReLU mask
 
     @property
     def grad_written(self):
@@ -320,6 +322,7 @@ SPLITK = os.environ.get("PN2_SPLITK", "1") == "1"                     # split-K 
 PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
+MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
 
 
 class GradQueue:
@@ -333,6 +336,8 @@ class GradQueue:
         self.slabs = {}
         self.cache = {}                   # segment index -> (signature, launches)
         self.ccache = {}                  # same for the engine's queued column-sum finalisations
+        self.side = None                  # torch.cuda.Stream: when set, EVERY flush runs there (ordered after the work issued so far on the current stream)
+        self.side_used = False
         self.begin_step()
 
     def begin_step(self):
@@ -413,13 +418,20 @@ class GradQueue:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("run two eager steps before capturing (the deferred-launch tables are built then)")
             hit = self.cache[self.seg] = (sig, self._build())
-        st = _stream()
-        for kind, dt, v, table, bstart, njobs, nblocks, flops in hit[1]:
-            if kind == "w":
-                capi.WORK.update(flops=flops, tag="", shape=f"variant{v} jobs{njobs}")
-                call.pn2_conv_wgrad_multi(dt, v, _p(table), _p(bstart), njobs, nblocks, st)
-            else:
-                call.pn2_wgrad_reduce_multi(_p(table), _p(bstart), njobs, nblocks, st)
+        side = self.side
+        if side is not None:              # the weight-gradient launches overlap the backward chain that continues on the current stream
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            self.side_used = True
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            st = _stream()
+            for kind, dt, v, table, bstart, njobs, nblocks, flops in hit[1]:
+                if kind == "w":
+                    capi.WORK.update(flops=flops, tag="", shape=f"variant{v} jobs{njobs}")
+                    call.pn2_conv_wgrad_multi(dt, v, _p(table), _p(bstart), njobs, nblocks, st)
+                else:
+                    call.pn2_wgrad_reduce_multi(_p(table), _p(bstart), njobs, nblocks, st)
         self.seg += 1
         self.wjobs, self.rjobs, self.keep = [], [], []
         self.levels = {}
@@ -970,8 +982,17 @@ class Engine:
                 else:
                     bias_done = bias is None
             rg, racc = (None, 0)
+            if out.grad_masked:
+                ymask = None                  # dy already carries the ReLU mask (PN2_BNB_STORE_MASKED)
             if residual is not None and residual.requires_grad:
-                rg, racc = residual.grad_sink()
+                if (out.grad_masked and residual.grad is None and residual.galias is None and residual.parent is None and not residual.grad_written
+                        and tuple(dy.shape) == tuple(residual.t.shape) and dy.dtype == residual.t.dtype and dy.is_contiguous()):
+                    # d(out)/d(residual) = the ReLU mask: the masked dy IS the residual's gradient - share the buffer (it is dead here once dz
+                    # has been formed; later contributions to the residual's gradient accumulate into it in place)
+                    residual.grad = dy
+                    residual.grad_written = True
+                else:
+                    rg, racc = residual.grad_sink()
             if coef is None and ymask is None and rg is None and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) == Cout_p and dy.is_contiguous():
                 draw = dy               # no BN, no activation, no residual (nn.Linear / biased conv): dz IS dy - no copy pass
             else:
@@ -1108,6 +1129,10 @@ class Engine:
             t.mode = 0
             return
         t.mode = capi.BNB_STATS | (capi.BNB_MASK_Y if b.ymask is not None else (capi.BNB_MASK_RAW if b.relu else 0))
+        if b.ymask is not None and MASKED_STORE and nblk and b.split == 0 and act.parent is None:
+            # BN + residual + ReLU: the masked gradient is also the residual branch's gradient - store it masked, the producer aliases it
+            t.mode |= capi.BNB_STORE_MASKED
+            act.grad_masked = True
         t.raw, t.ld_raw = b.raw.data_ptr(), b.raw.stride(2)
         if b.ymask is not None:
             t.y, t.ld_y = b.ymask.data_ptr(), b.ymask.stride(2)

@@ -7,6 +7,7 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("PN2_TUNE_COLD", "0")        # tests do not need cold-operand tile tuning (a 512 MB cache-evicting fill per timed candidate)
 
 
 def pytest_configure(config):
