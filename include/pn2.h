@@ -93,6 +93,15 @@ typedef struct pn2_bnb_target {
 } pn2_bnb_target;
 typedef struct pn2_conv_ep { pn2_bnb_target a, b; } pn2_conv_ep;
 int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const pn2_conv_desc* d, const pn2_conv_ep* ep, void* stream);
+/* Many conv GEMMs (forward / dgrad, with or without the epilogue above) of ONE tile shape in one launch, from a DEVICE job table: the convs at the same
+ * position of independent chains (the RFB branches of the three RFB modules, pranet.py:46-83; the parallel 3x3 convs of a Res2Net stage block,
+ * Res2Net_v1b.py:66-69) run in lock step.  pn2_conv_gemm_tile = (bm << 8 | bn) pn2_conv_gemm would pick for a desc (the partial-row counts of its
+ * statistics depend on bm, so a job must run on its own tile); jobs of equal tile and equal `ep` use (any target mode / b.out set) share a launch.
+ * The general (not pointwise-specialised) kernels serve every job; split-K jobs cannot join.  Bit-identical to the single launches. */
+typedef struct pn2_conv_job { const void* in; const void* wp; void* out; float* psum; float* psq; pn2_conv_desc d; int pad_; pn2_conv_ep ep; } pn2_conv_job;
+int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d);
+int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn);
+int pn2_conv_gemm_multi(int dtype, int bm, int bn, int ep, const pn2_conv_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
 int pn2_conv_splitk_reduce(int dtype, const float* ws, int ksplit, int M, int Cout, void* out, int ld_out, const float* bias, float* psum, float* psq,
                            int accumulate, void* stream);   /* psum / psq: BatchNorm partial rows [ceil(M / 64)][Cout] of the summed result, or NULL */
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream);
@@ -169,6 +178,30 @@ int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn
 typedef struct pn2_bn_segs { int nseg; int c0[4]; int nblk[4]; int ldp[4]; const float* p1[4]; const float* p2[4]; } pn2_bn_segs;
 int pn2_bn_bwd_finalize_seg(const pn2_bn_segs* segs, const pn2_bn_desc* d, const float* gamma, const float* invstd,
                             float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);
+/* ---- table-driven launches of the BatchNorm family.  Independent chains of a model (the three RFB modules and their three branches each, pranet.py:46-83;
+ * the three parallel 3x3 convs of a Res2Net stage block, Res2Net_v1b.py:66-69) advance in LOCK STEP: one launch per kernel kind and position in the
+ * chain instead of one per chain.  pn2_*_job_blocks (host) fills the derived geometry of a job and returns its workgroup count (< 0: not batchable,
+ * launch it on its own); pn2_*_multi runs the jobs from a DEVICE table (block_start_dev: njobs + 1 prefix sums).  Bit-identical to the single launches. */
+typedef struct pn2_bnfin_job { const float* psum; const float* psq; const float* gamma; const float* beta; float* running_mean; float* running_var;
+                               float* scale; float* shift; float* mean; float* invstd; pn2_bn_desc d; int nblk; int cpb; int pad_; } pn2_bnfin_job;
+int pn2_bn_finalize_job_blocks(pn2_bnfin_job* j);
+int pn2_bn_finalize_multi(const pn2_bnfin_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
+typedef struct pn2_affine_job { const void* x; void* y; const float* scale; const float* shift; const void* res; const void* add; void* y2;
+                                int ld_x, ld_y, ld_res, ld_add, ld_y2, M, C, relu, rows_per_blk, cvp; } pn2_affine_job;     /* pn2_affine_act / _sum, 16-byte rows */
+int pn2_affine_job_blocks(int dt, pn2_affine_job* j);
+int pn2_affine_multi(int dt, const pn2_affine_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
+typedef struct pn2_bnbfin_job { pn2_bn_segs sg; const float* gamma; const float* invstd; float* dgamma; float* dbeta; float* coef; pn2_bn_desc d;
+                                int accumulate; int cpb; int pad_; } pn2_bnbfin_job;   /* pn2_bn_bwd_finalize(_seg): plain = one segment */
+int pn2_bn_bwd_finalize_job_blocks(pn2_bnbfin_job* j);
+int pn2_bn_bwd_finalize_multi(const pn2_bnbfin_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
+typedef struct pn2_bnapply_job { const void* dy; const void* y; const void* x; const float* mean; const float* invstd; const float* coef; void* dx; void* dres;
+                                 const float* msc; const float* msh; int ld_dy, ld_y, ld_x, ld_dx, ld_dres, M, Cp, dres_accum, r6, rows_per_blk, cvp, pad_; } pn2_bnapply_job;
+int pn2_bn_bwd_apply_job_blocks(int dt, pn2_bnapply_job* j);
+int pn2_bn_bwd_apply_multi(int dt, const pn2_bnapply_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
+typedef struct pn2_bnreduce_job { const void* dy; const void* y; const void* x; const float* mean; const float* invstd; float* p1; float* p2;
+                                  const float* msc; const float* msh; int ld_dy, ld_y, ld_x, M, Cp, nblk, rows_per_blk, cvp, r6, pad_; } pn2_bnreduce_job;
+int pn2_bn_bwd_reduce_job_blocks(int dt, pn2_bnreduce_job* j);
+int pn2_bn_bwd_reduce_multi(int dt, const pn2_bnreduce_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
 /* pass 2: dx = g*invstd*(dz - c1 - xhat*c2) ; optional dres (+)= dz.  coef = [gscale|c1|c2] each Cp long.
  * coef==NULL: pure activation backward (dx = dz), used for eval-mode / affine-only layers.                */
 int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,

@@ -63,11 +63,10 @@ inline int finalize_cpb(int nblk) {
     return cpb;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ psum, const float* __restrict__ psq, int nblk, pn2_bn_desc d,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
-                                                     float* scale, float* shift, float* mean_o, float* invstd_o, int CPB) {
-    __shared__ double sh[2][4][8];
-    const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
+__device__ __forceinline__ void bn_finalize_body(const float* __restrict__ psum, const float* __restrict__ psq, int nblk, const pn2_bn_desc& d,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                 float* scale, float* shift, float* mean_o, float* invstd_o, int CPB, int bid, double (*sh)[4][8]) {
+    const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = bid * CPB + cl;
     // the per-channel parameters are requested BEFORE the partial rows are walked: loaded after the reduction they would add a second,
     // fully exposed memory latency to a kernel that is nothing but latency (156 of these per step)
     const int lc0 = (rl == 0 && c < d.Cp) ? phys2log(c, d.gw, d.gwp, d.C) : -1;
@@ -107,6 +106,21 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
             running_var[lc] = (1.f - d.momentum) * prv + d.momentum * (float)unb;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ psum, const float* __restrict__ psq, int nblk, pn2_bn_desc d,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                     float* scale, float* shift, float* mean_o, float* invstd_o, int CPB) {
+    __shared__ double sh[2][4][8];
+    bn_finalize_body(psum, psq, nblk, d, gamma, beta, running_mean, running_var, scale, shift, mean_o, invstd_o, CPB, blockIdx.x, sh);
+}
+// table-driven launches (pn2_*_multi): the same bodies over a DEVICE job table - the independent chains of a model (the three RFB modules and
+// their three branches each, the three parallel 3x3 convs of a Res2Net stage block) advance in lock step, one launch per kernel kind and position
+__global__ __launch_bounds__(256) void bn_finalize_tab(const pn2_bnfin_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    __shared__ double sh[2][4][8];
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_bnfin_job j = jobs[jb];
+    bn_finalize_body(j.psum, j.psq, j.nblk, j.d, j.gamma, j.beta, j.running_mean, j.running_var, j.scale, j.shift, j.mean, j.invstd, j.cpb, blockIdx.x - bstart[jb], sh);
 }
 
 __global__ void bn_eval_prepare_k(pn2_bn_desc d, const float* gamma, const float* beta, const float* rm, const float* rv, float* scale, float* shift) {
@@ -152,15 +166,15 @@ __global__ __launch_bounds__(256) void affine_act_k(const Ti* __restrict__ x, in
 // backward pass 1: partial sums of dz and dz*xhat over row chunks
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename Tdy, int W>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
-                                                       const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd, float* __restrict__ p1, float* __restrict__ p2,
-                                                       int rows_per_blk, int CVP, const float* __restrict__ msc, const float* __restrict__ msh, int r6) {
+__device__ __forceinline__ void bn_bwd_reduce_body(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
+                                                   const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
+                                                   const float* __restrict__ invstd, float* __restrict__ p1, float* __restrict__ p2,
+                                                   int rows_per_blk, int CVP, const float* __restrict__ msc, const float* __restrict__ msh, int r6, int bid) {
     extern __shared__ __attribute__((aligned(16))) float shf[];   // [2][R][CVP*W]
     const int CV = Cp / W;
     const int R = 256 / CVP;
     const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int r0 = blockIdx.x * rows_per_blk;
+    const int r0 = bid * rows_per_blk;
     int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
     for (int cvb = 0; cvb < CV; cvb += CVP) {
         const int cv = cvb + cvl, c = cv * W;
@@ -217,11 +231,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ d
             for (int e = 0; e < W; ++e) {
                 float s1 = 0.f, s2 = 0.f;
                 for (int r = 0; r < NR; ++r) { s1 += shf[(r * CVP + cvl) * W + e]; s2 += shf[((NR + r) * CVP + cvl) * W + e]; }
-                p1[(size_t)blockIdx.x * Cp + c + e] = s1; p2[(size_t)blockIdx.x * Cp + c + e] = s2;
+                p1[(size_t)bid * Cp + c + e] = s1; p2[(size_t)bid * Cp + c + e] = s2;
             }
         }
         __syncthreads();
     }
+}
+
+template <typename T, typename Tdy, int W>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
+                                                       const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, float* __restrict__ p1, float* __restrict__ p2,
+                                                       int rows_per_blk, int CVP, const float* __restrict__ msc, const float* __restrict__ msh, int r6) {
+    bn_bwd_reduce_body<T, Tdy, W>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, rows_per_blk, CVP, msc, msh, r6, blockIdx.x);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_tab(const pn2_bnreduce_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_bnreduce_job j = jobs[jb];
+    bn_bwd_reduce_body<T, T, TT<T>::VEC>((const T*)j.dy, j.ld_dy, j.Cp, (const T*)j.y, j.ld_y, (const T*)j.x, j.ld_x, j.M, j.Cp, j.mean, j.invstd, j.p1, j.p2,
+                                         j.rows_per_blk, j.cvp, j.msc, j.msh, j.r6, blockIdx.x - bstart[jb]);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ p1, const float* __restrict__ p2, int nblk, pn2_bn_desc d,
@@ -247,10 +276,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict
 }
 
 // pn2_bn_bwd_finalize with the partial rows of the channels coming from up to 4 producers (see pn2_bn_segs)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_seg_k(pn2_bn_segs sg, pn2_bn_desc d, const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                             float* dgamma, float* dbeta, int accumulate, float* coef, int CPB) {
-    __shared__ double sh[2][4][8];
-    const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = blockIdx.x * CPB + cl;
+__device__ __forceinline__ void bn_bwd_finalize_seg_body(const pn2_bn_segs& sg, const pn2_bn_desc& d, const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                         float* dgamma, float* dbeta, int accumulate, float* coef, int CPB, int bid, double (*sh)[4][8]) {
+    const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB, c = bid * CPB + cl;
     int si = 0;
 #pragma unroll
     for (int k = 1; k < 4; ++k) if (k < sg.nseg && c >= sg.c0[k]) si = k;
@@ -270,6 +298,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_seg_k(pn2_bn_segs sg, pn2
         coef[cs + c] = (float)(s1 / d.M);
         coef[2 * cs + c] = (float)(s2 / d.M);
     }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_seg_k(pn2_bn_segs sg, pn2_bn_desc d, const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                             float* dgamma, float* dbeta, int accumulate, float* coef, int CPB) {
+    __shared__ double sh[2][4][8];
+    bn_bwd_finalize_seg_body(sg, d, gamma, invstd, dgamma, dbeta, accumulate, coef, CPB, blockIdx.x, sh);
+}
+__global__ __launch_bounds__(256) void bn_bwd_finalize_tab(const pn2_bnbfin_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    __shared__ double sh[2][4][8];
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_bnbfin_job j = jobs[jb];
+    bn_bwd_finalize_seg_body(j.sg, j.d, j.gamma, j.invstd, j.dgamma, j.dbeta, j.accumulate, j.coef, j.cpb, blockIdx.x - bstart[jb], sh);
 }
 
 template <typename T, typename Tdy, int W>
@@ -308,16 +348,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const Tdy* __restrict__ dy
 constexpr int RU = 4;   // rows in flight per thread
 
 template <typename T>
-__global__ __launch_bounds__(256) void affine_rows_k(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int M, int C,
-                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                     const T* __restrict__ res, int ld_res, int relu, int rows_per_blk, int CVP,
-                                                     const T* __restrict__ add = nullptr, int ld_add = 0, T* __restrict__ y2 = nullptr, int ld_y2 = 0) {
+__device__ __forceinline__ void affine_rows_body(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int M, int C,
+                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                 const T* __restrict__ res, int ld_res, int relu, int rows_per_blk, int CVP,
+                                                 const T* __restrict__ add, int ld_add, T* __restrict__ y2, int ld_y2, int bid) {
     // add / y2 (optional): second output y2 = y + add - the "sp + spx[i+1]" of Bottle2neck.forward (Res2Net_v1b.py:68) written by the pass
     // that produces sp instead of by a separate element-wise launch
     constexpr int V = TT<T>::VEC;
     const int CV = C / V, R = 256 / CVP;
     const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int r0 = blockIdx.x * rows_per_blk;
+    const int r0 = bid * rows_per_blk;
     int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
     for (int cv = cvl; cv < CV; cv += CVP) {
         const int c = cv * V;
@@ -364,15 +404,30 @@ __global__ __launch_bounds__(256) void affine_rows_k(const T* __restrict__ x, in
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__ dy, int ld_dy, const T* __restrict__ y, int ld_y,
-                                                           const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
-                                                           T* __restrict__ dres, int ld_dres, int dres_accum, int rows_per_blk, int CVP,
-                                                           const float* __restrict__ msc, const float* __restrict__ msh, int r6) {
+__global__ __launch_bounds__(256) void affine_rows_k(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int M, int C,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const T* __restrict__ res, int ld_res, int relu, int rows_per_blk, int CVP,
+                                                     const T* __restrict__ add = nullptr, int ld_add = 0, T* __restrict__ y2 = nullptr, int ld_y2 = 0) {
+    affine_rows_body<T>(x, ld_x, y, ld_y, M, C, scale, shift, res, ld_res, relu, rows_per_blk, CVP, add, ld_add, y2, ld_y2, blockIdx.x);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void affine_rows_tab(const pn2_affine_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_affine_job j = jobs[jb];
+    affine_rows_body<T>((const T*)j.x, j.ld_x, (T*)j.y, j.ld_y, j.M, j.C, j.scale, j.shift, (const T*)j.res, j.ld_res, j.relu, j.rows_per_blk, j.cvp,
+                        (const T*)j.add, j.ld_add, (T*)j.y2, j.ld_y2, blockIdx.x - bstart[jb]);
+}
+
+template <typename T>
+__device__ __forceinline__ void bn_bwd_apply_rows_body(const T* __restrict__ dy, int ld_dy, const T* __restrict__ y, int ld_y,
+                                                       const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
+                                                       T* __restrict__ dres, int ld_dres, int dres_accum, int rows_per_blk, int CVP,
+                                                       const float* __restrict__ msc, const float* __restrict__ msh, int r6, int bid) {
     constexpr int V = TT<T>::VEC;
     const int CV = Cp / V, R = 256 / CVP;
     const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int r0 = blockIdx.x * rows_per_blk;
+    const int r0 = bid * rows_per_blk;
     int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
     for (int cv = cvl; cv < CV; cv += CVP) {
         const int c = cv * V;
@@ -420,6 +475,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
             }
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__ dy, int ld_dy, const T* __restrict__ y, int ld_y,
+                                                           const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
+                                                           T* __restrict__ dres, int ld_dres, int dres_accum, int rows_per_blk, int CVP,
+                                                           const float* __restrict__ msc, const float* __restrict__ msh, int r6) {
+    bn_bwd_apply_rows_body<T>(dy, ld_dy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, rows_per_blk, CVP, msc, msh, r6, blockIdx.x);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_tab(const pn2_bnapply_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_bnapply_job j = jobs[jb];
+    bn_bwd_apply_rows_body<T>((const T*)j.dy, j.ld_dy, (const T*)j.y, j.ld_y, (const T*)j.x, j.ld_x, j.M, j.Cp, j.mean, j.invstd, j.coef, (T*)j.dx, j.ld_dx,
+                              (T*)j.dres, j.ld_dres, j.dres_accum, j.rows_per_blk, j.cvp, j.msc, j.msh, j.r6, blockIdx.x - bstart[jb]);
 }
 
 inline void rows_geometry(int M, int CV, int& cvp, int& rows_per_blk, int& nblk) {
@@ -601,6 +672,93 @@ int pn2_affine_act_sum(int dt, const void* x, int ld_x, void* y, int ld_y, int M
                                            (const bf16_t*)add, ld_add, (bf16_t*)y2, ld_y2);
     else if (dt == PN2_F32) hipLaunchKernelGGL((affine_rows_k<float>), dim3(nblk), dim3(256), 0, st, (const float*)x, ld_x, (float*)y, ld_y, M, C, scale, shift, (const float*)nullptr, 0, relu, rpb, cvp,
                                                (const float*)add, ld_add, (float*)y2, ld_y2);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+
+/* ------------------------------------------------------------------------------------------------ table-driven launches
+ * pn2_*_job_blocks fill the derived geometry of a job (host side) and return its workgroup count (< 0: this call cannot be batched - launch it on
+ * its own); pn2_*_multi run many jobs of one kind in ONE launch from a DEVICE job table (block_start_dev: njobs + 1 prefix sums).  Same arithmetic,
+ * bit for bit, as the single launches. */
+int pn2_bn_finalize_job_blocks(pn2_bnfin_job* j) {
+    if (!j || !j->psum || !j->psq || !j->gamma || !j->beta || !j->scale || !j->shift || !j->mean || !j->invstd || j->nblk < 1) return -1;
+    j->cpb = finalize_cpb(j->nblk);
+    return (j->d.Cp + j->cpb - 1) / j->cpb;
+}
+int pn2_bn_finalize_multi(const pn2_bnfin_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    hipLaunchKernelGGL(bn_finalize_tab, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_affine_job_blocks(int dt, pn2_affine_job* j) {
+    if (!j || !j->x || !j->y) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (j->C % V || j->ld_x % V || j->ld_y % V || (j->res && j->ld_res % V) || (j->y2 && (!j->add || j->ld_add % V || j->ld_y2 % V))) return -2;
+    int nblk;
+    rows_geometry(j->M, j->C / V, j->cvp, j->rows_per_blk, nblk);
+    return nblk;
+}
+int pn2_affine_multi(int dt, const pn2_affine_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((affine_rows_tab<bf16_t>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((affine_rows_tab<float>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_bn_bwd_finalize_job_blocks(pn2_bnbfin_job* j) {
+    if (!j || !j->gamma || !j->invstd || !j->dgamma || !j->dbeta || !j->coef) return -1;
+    if (j->sg.nseg < 1 || j->sg.nseg > 4 || j->sg.c0[0] != 0) return -2;
+    int nmax = 1;
+    for (int k = 0; k < j->sg.nseg; ++k) {
+        if (!j->sg.p1[k] || !j->sg.p2[k] || j->sg.nblk[k] < 1 || j->sg.ldp[k] < 1) return -1;
+        if (j->sg.nblk[k] > nmax) nmax = j->sg.nblk[k];
+    }
+    j->cpb = finalize_cpb(nmax);
+    return (j->d.Cp + j->cpb - 1) / j->cpb;
+}
+int pn2_bn_bwd_finalize_multi(const pn2_bnbfin_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    hipLaunchKernelGGL(bn_bwd_finalize_tab, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_bn_bwd_apply_job_blocks(int dt, pn2_bnapply_job* j) {
+    if (!j || !j->dy || !j->dx) return -1;
+    if (j->coef && (!j->x || !j->mean || !j->invstd)) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (j->Cp % V || j->ld_dy % V || j->ld_dx % V || (j->coef && j->ld_x % V) || (j->y && j->ld_y % V) || (j->dres && j->ld_dres % V)) return -2;
+    int nblk;
+    rows_geometry(j->M, j->Cp / V, j->cvp, j->rows_per_blk, nblk);
+    return nblk;
+}
+int pn2_bn_bwd_apply_multi(int dt, const pn2_bnapply_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<bf16_t>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<float>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_bn_bwd_reduce_job_blocks(int dt, pn2_bnreduce_job* j) {
+    if (!j || !j->dy || !j->x || !j->mean || !j->invstd || !j->p1 || !j->p2 || j->nblk < 1) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (j->Cp % V || j->ld_dy % V || j->ld_x % V || (j->y && j->ld_y % V)) return -2;
+    int cvp = pow2ceil(j->Cp / V); if (cvp > 256) cvp = 256;
+    j->cvp = cvp; j->rows_per_blk = (j->M + j->nblk - 1) / j->nblk;
+    return j->nblk;
+}
+int pn2_bn_bwd_reduce_multi(int dt, const pn2_bnreduce_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((bn_bwd_reduce_tab<bf16_t>), dim3(total_blocks), dim3(256), 2 * 256 * 8 * 4, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((bn_bwd_reduce_tab<float>), dim3(total_blocks), dim3(256), 2 * 256 * 4 * 4, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
     else return -3;
     PN2_CHECK_LAUNCH();
     return 0;

@@ -341,9 +341,9 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad gather-GEMM
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, bool PW, bool EP = false>
-__global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in, const T* __restrict__ wp, T* __restrict__ out,
-                                                        float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
+template <typename T, int BM, int BN, int WM, int WN, bool PW, bool EP>
+__device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const T* __restrict__ wp, T* __restrict__ out,
+                                                 float* __restrict__ psum, float* __restrict__ psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, int lbid, int lgrid) {
     constexpr int VEC = TT<T>::VEC, BK = MMA<T>::BK;
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int STAGE = (BM + BN) * RS;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
     const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
     const int M = d.N * d.OH * d.OW;
     const int nbn = (d.Cout + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = xcd_remap(lbid, lgrid);
     const int bn = bid % nbn, bm = bid / nbn;
     const int m0 = bm * BM, n0 = bn * BN;
     const int taps = d.KH * d.KW;
@@ -483,6 +483,19 @@ __global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in
     }
 }
 
+template <typename T, int BM, int BN, int WM, int WN, bool PW, bool EP = false>
+__global__ __launch_bounds__(256) void conv_gather_gemm(const T* __restrict__ in, const T* __restrict__ wp, T* __restrict__ out,
+                                                        float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
+    conv_gather_body<T, BM, BN, WM, WN, PW, EP>(in, wp, out, psum, psq, d, ep, blockIdx.x, gridDim.x);
+}
+// table-driven launch: many convs of one kernel instantiation from a DEVICE job table (see pn2_conv_gemm_multi)
+template <typename T, int BM, int BN, int WM, int WN, bool PW, bool EP>
+__global__ __launch_bounds__(256) void conv_gather_gemm_tab(const pn2_conv_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_conv_job j = jobs[jb];
+    conv_gather_body<T, BM, BN, WM, WN, PW, EP>((const T*)j.in, (const T*)j.wp, (T*)j.out, j.psum, j.psq, j.d, j.ep, blockIdx.x - bstart[jb], bstart[jb + 1] - bstart[jb]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad gather-GEMM, LDS-DMA pipeline (bf16): both operands go global -> LDS with
 // global_load_lds_dwordx4 (no register staging), NS stages deep, counted vmcnt + raw s_barrier so that
@@ -495,9 +508,9 @@ __device__ __attribute__((aligned(16))) unsigned pn2_zero16[4] = {0u, 0u, 0u, 0u
 
 // NS = 3: two K-steps of loads in flight; NS = 2: one step ahead and a third less LDS, so that three (64x128) instead of two workgroups share
 // a CU - the per-shape tuner picks (the K loop runs at ~27 % of the MFMA rate with two resident workgroups: barrier / wait stalls).
-template <int BM, int BN, int WM, int WN, bool PW, int NS = 3, bool EP = false>
-__global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
-                                                     float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
+template <int BM, int BN, int WM, int WN, bool PW, int NS, bool EP>
+__device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
+                                              float* __restrict__ psum, float* __restrict__ psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, int lbid, int lgrid, int by) {
     using T = bf16_t;
     constexpr int VEC = 8, BK = 64, ROW = 128;
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
     const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
     const int M = d.N * d.OH * d.OW;
     const int nbn = (d.Cout + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = xcd_remap(lbid, lgrid);
     const int bn = bid % nbn, bm = bid / nbn;
     const int m0 = bm * BM, n0 = bn * BN;
     const int taps = d.KH * d.KW;
@@ -520,7 +533,7 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
     // split-K (PN2_CONV_SPLITK, small-M long-K convs): blockIdx.y owns the K-steps [kt0, kt0 + ksteps) and leaves an fp32 partial tile
     const int ksplit = (d.flags >> 16) & 15;
     const int kper = ksplit > 1 ? (ksteps_all + ksplit - 1) / ksplit : ksteps_all;
-    const int kt0 = ksplit > 1 ? (int)blockIdx.y * kper : 0;
+    const int kt0 = ksplit > 1 ? by * kper : 0;
     const int ksteps = max(0, min(ksteps_all - kt0, kper));
 
     GatherGeom gg;
@@ -645,7 +658,7 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
     __syncthreads();
 
     if (ksplit > 1) {            // fp32 partial tile -> workspace [ksplit][M][Cout] (psum); pn2_conv_splitk_reduce finishes (sum, stats, bias, store)
-        float* ws = psum + (size_t)blockIdx.y * M * d.Cout;
+        float* ws = psum + (size_t)by * M * d.Cout;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -658,6 +671,18 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
         return;
     }
     conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
+}
+
+template <int BM, int BN, int WM, int WN, bool PW, int NS = 3, bool EP = false>
+__global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
+                                                     float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
+    conv_dma_body<BM, BN, WM, WN, PW, NS, EP>(in, wp, out, psum, psq, d, ep, blockIdx.x, gridDim.x, blockIdx.y);
+}
+template <int BM, int BN, int WM, int WN, bool PW, int NS, bool EP>
+__global__ __launch_bounds__(256) void conv_dma_gemm_tab(const pn2_conv_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_conv_job j = jobs[jb];
+    conv_dma_body<BM, BN, WM, WN, PW, NS, EP>((const bf16_t*)j.in, (const bf16_t*)j.wp, (bf16_t*)j.out, j.psum, j.psq, j.d, j.ep, blockIdx.x - bstart[jb], bstart[jb + 1] - bstart[jb], 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1303,6 +1328,74 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
     return launch_gemm<T, 64, 32, 4, 1, EP>(in, wp, out, psum, psq, d, ep, st);
 }
 
+// (kernel, BM, BN) gemm_dispatch would run for this desc: kern 0 register-staged, 2 LDS-DMA 3-stage, 3 LDS-DMA 2-stage
+template <typename T>
+void gemm_select(const pn2_conv_desc& d, int& kern, int& bm, int& bn) {
+    pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
+    const int tune = sizeof(T) == 2 ? (d.flags >> 8) & 0xff : 0;
+    const int tk_ = tune & 3, tbm = (tune >> 2) & 3, tbn = (tune >> 4) & 3;
+    if (tbm) bm = tbm == 1 ? 64 : 128;
+    if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
+    kern = 0;
+    if (sizeof(T) == 2) kern = tk_ == 3 ? 3 : ((tk_ ? tk_ == 2 : use_dma_kernel()) ? 2 : 0);
+    if (sizeof(T) == 4 && bn == 128) bn = 64;
+}
+
+// table-driven conv GEMM launches: general (non-pointwise-specialised) kernels, LDS-DMA 3-stage for bf16, register-staged for fp32
+template <bool EP, int BM, int BN, int WM, int WN>
+int launch_dma_tab(const pn2_conv_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
+    constexpr int stage_b = (BM + BN) * 128, max_b = 3 * stage_b, epi_b = BM * (BN * 2 + 16) + 3 * WM * BN * 4;
+    int lds = max_b > epi_b ? max_b : epi_b;
+    if (EP && lds < ep_lds_bytes(8)) lds = ep_lds_bytes(8);
+    static bool done = false;
+    if (!done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_tab<BM, BN, WM, WN, false, 3, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        done = true;
+    }
+    hipLaunchKernelGGL((conv_dma_gemm_tab<BM, BN, WM, WN, false, 3, EP>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+template <bool EP, int BM, int BN, int WM, int WN>
+int launch_gather_tab_f32(const pn2_conv_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
+    constexpr int main_b = 2 * (BM + BN) * RS, epi_b = BM * (BN * 4 + 16) + 3 * WM * BN * 4, ep_b = EP ? ep_lds_bytes(4) : 0;
+    constexpr int lds = (main_b > epi_b ? main_b : epi_b) > ep_b ? (main_b > epi_b ? main_b : epi_b) : ep_b;
+    static bool done = false;
+    if (!done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm_tab<float, BM, BN, WM, WN, false, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        done = true;
+    }
+    hipLaunchKernelGGL((conv_gather_gemm_tab<float, BM, BN, WM, WN, false, EP>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+template <bool EP>
+int gemm_multi_dispatch(int dtype, int bm, int bn, const pn2_conv_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
+    if (dtype == PN2_BF16) {
+        if (bm == 128) {
+            if (bn == 128) return launch_dma_tab<EP, 128, 128, 2, 2>(jobs, bstart, njobs, total, st);
+            if (bn == 64) return launch_dma_tab<EP, 128, 64, 2, 2>(jobs, bstart, njobs, total, st);
+            if (bn == 32) return launch_dma_tab<EP, 128, 32, 4, 1>(jobs, bstart, njobs, total, st);
+        } else if (bm == 64) {
+            if (bn == 128) return launch_dma_tab<EP, 64, 128, 2, 2>(jobs, bstart, njobs, total, st);
+            if (bn == 64) return launch_dma_tab<EP, 64, 64, 2, 2>(jobs, bstart, njobs, total, st);
+            if (bn == 32) return launch_dma_tab<EP, 64, 32, 4, 1>(jobs, bstart, njobs, total, st);
+        }
+        return -2;
+    }
+    if (dtype == PN2_F32) {
+        if (bm == 128) {
+            if (bn == 64) return launch_gather_tab_f32<EP, 128, 64, 2, 2>(jobs, bstart, njobs, total, st);
+            if (bn == 32) return launch_gather_tab_f32<EP, 128, 32, 4, 1>(jobs, bstart, njobs, total, st);
+        } else if (bm == 64) {
+            if (bn == 64) return launch_gather_tab_f32<EP, 64, 64, 2, 2>(jobs, bstart, njobs, total, st);
+            if (bn == 32) return launch_gather_tab_f32<EP, 64, 32, 4, 1>(jobs, bstart, njobs, total, st);
+        }
+        return -2;
+    }
+    return -3;
+}
+
 template <int BMC, int WM, int WN>
 int launch_wgrad_dma(const void* dy, const void* x, float* slab, const pn2_wgrad_desc& d, int nsplit, hipStream_t st) {
     constexpr int PX = wg_px(BMC), stage_b = PX * (BMC * 2 + 256), max_b = 3 * stage_b;
@@ -1616,6 +1709,35 @@ int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const
     rc = bnb_check(ep->b, vec, true);
     if (rc) return rc;
     return conv_gemm_impl(dtype, in, wp, out, nullptr, nullptr, d, *ep, stream);
+}
+
+/* tile (bm << 8 | bn) pn2_conv_gemm would run this desc on (its tuning bits included); < 0: the launch cannot join a table (split-K, alignment) */
+int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d) {
+    if (!d) return -1;
+    if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
+    if (((d->flags >> 16) & 15) > 1) return -2;
+    int kern, bm, bn;
+    if (dtype == PN2_BF16) { gemm_select<bf16_t>(*d, kern, bm, bn); if (kern == 0 && !use_dma_kernel()) return -2; }
+    else if (dtype == PN2_F32) gemm_select<float>(*d, kern, bm, bn);
+    else return -3;
+    return (bm << 8) | bn;
+}
+
+int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn) {
+    if (!j || !j->in || !j->wp || !j->out || bm < 1 || bn < 1) return -1;
+    const pn2_conv_desc& d = j->d;
+    if ((d.flags & PN2_CONV_STATS) && (!j->psum || !j->psq)) return -1;
+    if ((d.flags & PN2_CONV_BIAS) && !j->psum) return -1;
+    const bool use_ep = (j->ep.a.mode | j->ep.b.mode) != 0 || j->ep.b.out != nullptr;
+    const int vec = dtype == PN2_F32 ? 4 : 8;
+    if (use_ep && (d.Cout % vec || d.ld_out % vec || (d.flags & (PN2_CONV_STATS | PN2_CONV_BIAS)))) return -2;
+    return ((d.N * d.OH * d.OW + bm - 1) / bm) * ((d.Cout + bn - 1) / bn);
+}
+
+int pn2_conv_gemm_multi(int dtype, int bm, int bn, int ep, const pn2_conv_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    return ep ? gemm_multi_dispatch<true>(dtype, bm, bn, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream)
+              : gemm_multi_dispatch<false>(dtype, bm, bn, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
 }
 
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream) {

@@ -57,22 +57,24 @@ class Bottle2neck(nn.Module):
         # the backward statistics of bns[0..2] (and of bn1's last slice, which the concat buffer copies) in one epilogue
         rawcat = eng.empty(out1.N, OH, OW, sc * wp)
         pcat = eng.fbuf(4, sc * wp)
-        s_in = spx[0]
-        for i in range(self.nums):
-            # sp_i = relu(bn(conv(s_in))) goes into the concat buffer; the next branch's input sp_i + spx[i+1] (Res2Net_v1b.py:66-68) is written
-            # by the same pass (spx[i+1] feeds only that sum: its slice of conv1's gradient doubles as the sum's gradient buffer)
-            nxt = spx[i + 1] if (i + 1 < self.nums and not stage) else None
-            r = eng.conv_bn_act(s_in, self.convs[i], self.bns[i], relu=True, out=cat.slice(i * wp, (i + 1) * wp, w, w, wp), out_map=(w, wp), sum_with=nxt,
-                                raw_out=rawcat[..., i * wp:(i + 1) * wp], par_out=pcat[:, i * wp:(i + 1) * wp], x_last=True)
-            if nxt is not None:
-                s_in = r[1]
-            elif i + 1 < self.nums:
-                s_in = spx[i + 1]
+        def branch(i, s_in, nxt):
+            return eng.conv_bn_act(s_in, self.convs[i], self.bns[i], relu=True, out=cat.slice(i * wp, (i + 1) * wp, w, w, wp), out_map=(w, wp), sum_with=nxt,
+                                   raw_out=rawcat[..., i * wp:(i + 1) * wp], par_out=pcat[:, i * wp:(i + 1) * wp], x_last=True)
         last = cat.slice(self.nums * wp, sc * wp, w, w, wp)
         if stage:
-            eng.avgpool(spx[self.nums], 3, stride, 1, out=last)
+            # the branches of a stage block are independent (sp = spx[i], Res2Net_v1b.py:66-69): they advance in lock step, one table-driven
+            # launch per kernel kind (conv, finalize, BN-apply; and their backward) for all three, next to the pooled pass-through slice
+            eng.lockstep("b2n.stage", [lambda i=i: branch(i, spx[i], None) for i in range(self.nums)] + [lambda: eng.avgpool(spx[self.nums], 3, stride, 1, out=last)])
             eng.concat_bnb(cat, rawcat, pcat, split=self.nums * wp, tail=None)
         else:
+            s_in = spx[0]
+            for i in range(self.nums):
+                # sp_i = relu(bn(conv(s_in))) goes into the concat buffer; the next branch's input sp_i + spx[i+1] (Res2Net_v1b.py:66-68) is written
+                # by the same pass (spx[i+1] feeds only that sum: its slice of conv1's gradient doubles as the sum's gradient buffer)
+                nxt = spx[i + 1] if i + 1 < self.nums else None
+                r = branch(i, s_in, nxt)
+                if nxt is not None:
+                    s_in = r[1]
             eng.copy_into(spx[self.nums], last)
             eng.concat_bnb(cat, rawcat, pcat, split=self.nums * wp, tail=spx[self.nums])
         if self.downsample is not None:

@@ -83,6 +83,28 @@ class RFB_modified(nn.Module):
         return run_module(lambda e, a: [self._build(e, a)], [x], list(self.parameters()), self.training)[0]
 
 
+def rfb_group(eng, rfbs, xs, extras):
+    """The RFB modules of a model (reference :75-83, three per model) in LOCK STEP: they do not depend on each other, nor do the three branch tails
+    inside each.  Phase A: the fused 1x1 reducer GEMM of every module; phase B: the 9 branch tails (1xk -> kx1 -> 3x3 dilated, k = 3, 5, 7) and the
+    branch0 pass-through copies; phase C: conv_cat + residual + ReLU.  Each phase advances position by position with one table-driven launch per
+    kernel kind (Engine.lockstep), forward and backward.  -> [(y, extra outputs)] like RFB_modified._build(extra=...)."""
+    c = rfbs[0].conv_cat.conv.out_channels
+    heads = eng.lockstep("rfb.heads", [lambda r=r, x=x, e=e: eng.conv_bn_multi(x, [r.branch0[0], r.branch1[0], r.branch2[0], r.branch3[0], r.conv_res] + list(e))
+                                       for r, x, e in zip(rfbs, xs, extras)])
+    cats = [eng.new_act(x.N, x.H, x.W, 4 * c) for x in xs]
+
+    def tail(r, h, cat, bi):
+        br = (r.branch1, r.branch2, r.branch3)[bi - 1]
+        t = br[1]._build(eng, h[bi])
+        t = br[2]._build(eng, t, x_last=True)
+        br[3]._build(eng, t, out=cat.slice(bi * c, (bi + 1) * c), x_last=True)
+    fns = [lambda r=r, h=h, cat=cat, bi=bi: tail(r, h, cat, bi) for r, h, cat in zip(rfbs, heads, cats) for bi in (1, 2, 3)]
+    fns += [lambda h=h, cat=cat: eng.copy_into(h[0], cat.slice(0, c)) for h, cat in zip(heads, cats)]
+    eng.lockstep("rfb.tails", fns)
+    ys = eng.lockstep("rfb.cat", [lambda r=r, h=h, cat=cat: r.conv_cat._build(eng, cat, relu=True, residual=h[4]) for r, h, cat in zip(rfbs, heads, cats)])
+    return [(y, h[5:]) for y, h in zip(ys, heads)]
+
+
 class aggregation(nn.Module):
     def __init__(self, channel, num_class):
         super().__init__()
@@ -105,10 +127,16 @@ class aggregation(nn.Module):
         up = lambda a: eng.bilinear(a, 2, align_corners=True)
         u1 = up(x1)                                   # reference recomputes upsample(x1) three times; same values
         cat2 = eng.new_act(x2.N, x2.H, x2.W, 2 * c)
-        eng.mul(self.conv_upsample1._build(eng, u1), x2, out=cat2.slice(0, c))                       # x2_1
-        self.conv_upsample4._build(eng, u1, out=cat2.slice(c, 2 * c))
         cat3 = eng.new_act(x3.N, x3.H, x3.W, 3 * c)
-        t = eng.mul(self.conv_upsample2._build(eng, up(u1)), self.conv_upsample3._build(eng, up(x2)))
+        # three independent conv+BN chains (conv_upsample1 on u1, conv_upsample2 on up(u1), conv_upsample3 on up(x2)) in lock step; conv_upsample4
+        # also reads u1 - its data gradient accumulates into the same buffer as conv_upsample1's, so it cannot share their launches
+        uu1, ux2 = up(u1), up(x2)
+        cu1, cu2, cu3 = eng.lockstep("agg.up", [lambda: self.conv_upsample1._build(eng, u1),
+                                                lambda: self.conv_upsample2._build(eng, uu1),
+                                                lambda: self.conv_upsample3._build(eng, ux2)])
+        self.conv_upsample4._build(eng, u1, out=cat2.slice(c, 2 * c))
+        eng.mul(cu1, x2, out=cat2.slice(0, c))                                                       # x2_1
+        t = eng.mul(cu2, cu3)
         eng.mul(t, x3, out=cat3.slice(0, c))                                                         # x3_1
         x2_2 = self.conv_concat2._build(eng, cat2)
         self.conv_upsample5._build(eng, up(x2_2), out=cat3.slice(c, 3 * c))
@@ -117,11 +145,10 @@ class aggregation(nn.Module):
 
     def _build(self, eng, x1, x2, x3):
         x = self._build_trunk(eng, x1, x2, x3)
-        heads = []
-        for j, conv in enumerate((self.conv5_fg, self.conv5_bg)):
+        def head(conv):
             K = conv.out_channels
-            heads.append(eng.conv_bn_act(x, conv, None, out_map=(K, rup(K, 8)), y_dt=F32, y_C=K, bias=conv.bias, x_last=(j == 0)))   # fg: x's first consumer
-        return heads
+            return eng.conv_bn_act(x, conv, None, out_map=(K, rup(K, 8)), y_dt=F32, y_C=K, bias=conv.bias, x_last=conv is self.conv5_fg)   # fg: x's first consumer
+        return [head(self.conv5_fg), head(self.conv5_bg)]
 
     def forward(self, x1, x2, x3):
         return run_module(lambda e, a, b, c: self._build(e, a, b, c), [x1, x2, x3], list(self.parameters()), self.training)
@@ -137,25 +164,28 @@ def _dsra_tail(m, eng, t1, ra5_fg, ra5_bg):
         OH, OW = int(math.floor(a.H * s)), int(math.floor(a.W * s))
         return eng.bilinear(a, s, out=eng.lateral_out(j, 8, a.N, OH, OW, a.C))
     l5_fg, l5_bg = final(ra5_fg, 8 / sd, 3), final(ra5_bg, 8 / sd, 7)
-    # ---- DSRA3
-    c_fg, c_bg = up(ra5_fg, 0.25), up(ra5_bg, 0.25)
-    t = t1[4]
-    t = m.ra4_conv2._build(eng, t, relu=True)
-    t = m.ra4_conv3._build(eng, t, relu=True, x_last=True)
-    t = m.ra4_conv4._build(eng, t, relu=True, x_last=True)
-    f = m.ra4_conv5_fg._build(eng, t, head=True, x_last=True)      # fg head: t's first consumer (the bg head's gradient arrives first in backward)
-    b = m.ra4_conv5_bg._build(eng, t, head=True)
-    f = eng.dsra_fuse(f, c_fg, c_bg, m.use_softmax)
-    l4_fg, l4_bg = final(f, 32 / sd, 2), final(b, 32 / sd, 6)
-    lat = {}
-    for s, u in ((3, 16), (2, 8)):
-        c_fg, c_bg = up(f, 2), up(b, 2)
+    # The conv stacks of DSRA3/2/1 only depend on the encoder (t1[s]); the stages meet in the fusion with the up-sampled maps of the stage below.
+    # So the three stacks - ra4: 3 x (5x5 + ReLU) + two 1x1 heads; ra3 / ra2: 2 x (3x3 + ReLU) + two 3x3 heads - advance in lock step, then the
+    # cheap sequential chain crop -> fg + fg * softmax(crop_fg - crop_bg) -> up-sample follows.
+    def stack(s):
         t = t1[s]
+        if s == 4:
+            t = m.ra4_conv2._build(eng, t, relu=True)
+            t = m.ra4_conv3._build(eng, t, relu=True, x_last=True)
+            t = m.ra4_conv4._build(eng, t, relu=True, x_last=True)
+            return m.ra4_conv5_fg._build(eng, t, head=True, x_last=True), m.ra4_conv5_bg._build(eng, t, head=True)      # fg head: t's first consumer
         t = getattr(m, f"ra{s}_conv2")._build(eng, t, relu=True)
         t = getattr(m, f"ra{s}_conv3")._build(eng, t, relu=True, x_last=True)
-        f = getattr(m, f"ra{s}_conv4_fg")._build(eng, t, head=True, x_last=True)
-        b = getattr(m, f"ra{s}_conv4_bg")._build(eng, t, head=True)
-        f = eng.dsra_fuse(f, c_fg, c_bg, m.use_softmax)
+        return getattr(m, f"ra{s}_conv4_fg")._build(eng, t, head=True, x_last=True), getattr(m, f"ra{s}_conv4_bg")._build(eng, t, head=True)
+    (f4, b4), (f3, b3), (f2, b2) = eng.lockstep("dsra.stacks", [lambda: stack(4), lambda: stack(3), lambda: stack(2)])
+    # ---- DSRA3
+    f = eng.dsra_fuse(f4, up(ra5_fg, 0.25), up(ra5_bg, 0.25), m.use_softmax)
+    b = b4
+    l4_fg, l4_bg = final(f, 32 / sd, 2), final(b, 32 / sd, 6)
+    lat = {}
+    for s, u, fs, bs in ((3, 16, f3, b3), (2, 8, f2, b2)):
+        f = eng.dsra_fuse(fs, up(f, 2), up(b, 2), m.use_softmax)
+        b = bs
         lat[s] = (final(f, u / sd, s - 2), final(b, u / sd, s + 2))     # slot = position in the returned 8-tuple
     return [lat[2][0], lat[3][0], l4_fg, l5_fg, lat[2][1], lat[3][1], l4_bg, l5_bg]
 
@@ -198,11 +228,9 @@ class PraNet_V2(nn.Module):
 
     def _build(self, eng, x):
         x1, x2, x3, x4 = self.backbone._build_features(eng, x)
-        # the three RFB modules are independent of each other: one lane (HIP stream) each
-        (x2_rfb, (t2,)), (x3_rfb, (t3,)), (x4_rfb, (t4,)) = eng.lanes([
-            lambda: self.rfb2_1._build(eng, x2, extra=[self.ra2_conv1]),
-            lambda: self.rfb3_1._build(eng, x3, extra=[self.ra3_conv1]),
-            lambda: self.rfb4_1._build(eng, x4, extra=[self.ra4_conv1])])
+        # the three RFB modules are independent of each other: they advance in lock step (table-driven launches, rfb_group)
+        (x2_rfb, (t2,)), (x3_rfb, (t3,)), (x4_rfb, (t4,)) = rfb_group(eng, [self.rfb2_1, self.rfb3_1, self.rfb4_1], [x2, x3, x4],
+                                                                  [[self.ra2_conv1], [self.ra3_conv1], [self.ra4_conv1]])
         ra5_fg, ra5_bg = self.agg1._build(eng, x4_rfb, x3_rfb, x2_rfb)
         return _dsra_tail(self, eng, {2: t2, 3: t3, 4: t4}, ra5_fg, ra5_bg)
 

@@ -81,6 +81,35 @@ class BnSegs(C.Structure):
     _fields_ = [("nseg", C.c_int), ("c0", C.c_int * 4), ("nblk", C.c_int * 4), ("ldp", C.c_int * 4), ("p1", C.c_void_p * 4), ("p2", C.c_void_p * 4)]
 
 
+class ConvJob(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("wp", C.c_void_p), ("out", C.c_void_p), ("psum", C.c_void_p), ("psq", C.c_void_p), ("d", ConvDesc), ("pad_", C.c_int), ("ep", ConvEp)]
+
+
+class BnFinJob(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("psum", "psq", "gamma", "beta", "running_mean", "running_var", "scale", "shift", "mean", "invstd")] + \
+               [("d", BnDesc), ("nblk", C.c_int), ("cpb", C.c_int), ("pad_", C.c_int)]
+
+
+class AffineJob(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "y", "scale", "shift", "res", "add", "y2")] + \
+               [(n, C.c_int) for n in ("ld_x", "ld_y", "ld_res", "ld_add", "ld_y2", "M", "C", "relu", "rows_per_blk", "cvp")]
+
+
+class BnBFinJob(C.Structure):
+    _fields_ = [("sg", BnSegs)] + [(n, C.c_void_p) for n in ("gamma", "invstd", "dgamma", "dbeta", "coef")] + \
+               [("d", BnDesc), ("accumulate", C.c_int), ("cpb", C.c_int), ("pad_", C.c_int)]
+
+
+class BnApplyJob(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dy", "y", "x", "mean", "invstd", "coef", "dx", "dres", "msc", "msh")] + \
+               [(n, C.c_int) for n in ("ld_dy", "ld_y", "ld_x", "ld_dx", "ld_dres", "M", "Cp", "dres_accum", "r6", "rows_per_blk", "cvp", "pad_")]
+
+
+class BnReduceJob(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dy", "y", "x", "mean", "invstd", "p1", "p2", "msc", "msh")] + \
+               [(n, C.c_int) for n in ("ld_dy", "ld_y", "ld_x", "M", "Cp", "nblk", "rows_per_blk", "cvp", "r6", "pad_")]
+
+
 P, I, LL, FL = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
 # name -> argtypes ; every function returns int (0 = ok)
@@ -91,6 +120,19 @@ SIGNATURES = {
     "pn2_conv_stat_blocks": [I, I, I],
     "pn2_conv_gemm": [I, P, P, P, P, P, C.POINTER(ConvDesc), P],
     "pn2_conv_gemm_ep": [I, P, P, P, C.POINTER(ConvDesc), C.POINTER(ConvEp), P],
+    "pn2_conv_gemm_tile": [I, C.POINTER(ConvDesc)],
+    "pn2_conv_gemm_job_blocks": [I, C.POINTER(ConvJob), I, I],
+    "pn2_conv_gemm_multi": [I, I, I, I, P, P, I, I, P],
+    "pn2_bn_finalize_job_blocks": [C.POINTER(BnFinJob)],
+    "pn2_bn_finalize_multi": [P, P, I, I, P],
+    "pn2_affine_job_blocks": [I, C.POINTER(AffineJob)],
+    "pn2_affine_multi": [I, P, P, I, I, P],
+    "pn2_bn_bwd_finalize_job_blocks": [C.POINTER(BnBFinJob)],
+    "pn2_bn_bwd_finalize_multi": [P, P, I, I, P],
+    "pn2_bn_bwd_apply_job_blocks": [I, C.POINTER(BnApplyJob)],
+    "pn2_bn_bwd_apply_multi": [I, P, P, I, I, P],
+    "pn2_bn_bwd_reduce_job_blocks": [I, C.POINTER(BnReduceJob)],
+    "pn2_bn_bwd_reduce_multi": [I, P, P, I, I, P],
     "pn2_conv_wgrad": [I, P, P, P, C.POINTER(WgradDesc), I, P],
     "pn2_conv_wgrad_variant": [I, C.POINTER(WgradDesc)],
     "pn2_conv_wgrad_blocks": [C.POINTER(WgradDesc), I],
@@ -188,7 +230,8 @@ SIGNATURES = {
     "pn2_eval_hist": [P, P, LL, P, P],
 }
 # entry points that return a value rather than a status
-_VALUE_FUNCS = {"pn2_resize_ksize", "pn2_colsum_job_blocks", "pn2_colsum_finalize_blocks", "pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
+_VALUE_FUNCS = {"pn2_conv_gemm_tile", "pn2_conv_gemm_job_blocks", "pn2_bn_finalize_job_blocks", "pn2_affine_job_blocks", "pn2_bn_bwd_finalize_job_blocks",
+                "pn2_bn_bwd_apply_job_blocks", "pn2_bn_bwd_reduce_job_blocks", "pn2_resize_ksize", "pn2_colsum_job_blocks", "pn2_colsum_finalize_blocks", "pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
                 "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
                 "pn2_dsra_tail_blocks", "pn2_dsra_tail_scratch", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks", "pn2_mutation_loss_blocks", "pn2_mutation_loss_width",
                 "pn2_dwconv_blocks", "pn2_pairconv_blocks", "pn2_gate_blocks"}

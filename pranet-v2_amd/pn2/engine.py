@@ -322,6 +322,8 @@ SPLITK = os.environ.get("PN2_SPLITK", "1") == "1"                     # split-K 
 PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
+LOCKSTEP_TILES = os.environ.get("PN2_LOCKSTEP_TILES", "0") == "1"   # opt-in: canonical conv tiles inside lock-step regions (measured: no more shared launches, same speed)
+LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
 
 
@@ -438,7 +440,8 @@ class GradQueue:
 
 
 class Engine:
-    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None, grad_queue=None, arena=None):
+    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None, grad_queue=None, arena=None, lock_cache=None):
+        self.lock_cache = lock_cache    # dict shared across steps: device job tables of the lock-step regions (Engine.lockstep); None = no lock-step batching
         self.pack_cache = pack_cache
         self.grad_queue = grad_queue
         self.arena = arena
@@ -536,6 +539,52 @@ class Engine:
         self.tape = []
         self.flush_colsum()
         self.join_side()
+
+    # ------------------------------------------------------------------ lock step: independent chains share table-driven launches
+    def lockstep(self, key, fns):
+        """[f() for f in fns] for chains that do not depend on each other: their launches are issued position by position, the launches of equal
+        kind at a position as ONE table-driven launch (pn2/lockstep.py) - forward and backward.  `key` names the region (stable across steps).
+        Needs a persistent table cache (the trainer's); without one, or inside another lock-step region, the chains simply run one after the other."""
+        from . import lockstep as LS
+        if not LOCKSTEP or self.lock_cache is None or LS._ACTIVE or len(fns) < 2 or key in os.environ.get("PN2_LOCKSTEP_SKIP", "").split(","):
+            self._in_region = getattr(self, "_in_region", 0) + 1
+            try:
+                return [f() for f in fns]
+            finally:
+                self._in_region -= 1
+        self._in_region = getattr(self, "_in_region", 0) + 1
+        try:
+            return self._lockstep_run(LS, key, fns)
+        finally:
+            self._in_region -= 1
+
+    def _lockstep_run(self, LS, key, fns):
+        self._nregion = getattr(self, "_nregion", 0) + 1          # regions are entered in the same order every step: a stable cache key
+        key = f"{key}#{self._nregion}"
+        rec = LS.Lockstep(key + ":f", self.lock_cache)
+        outs, segs = [], []
+        for f in fns:
+            t0 = len(self.tape)
+            with rec.lane():
+                outs.append(f())
+            segs.append(self.tape[t0:])
+            del self.tape[t0:]
+        rec.emit()
+        if self.need_grad and any(segs):
+            def bwd():
+                if LS._ACTIVE:                     # inside an outer region's backward: plain order
+                    for seg in reversed(segs):
+                        for fn in reversed(seg):
+                            fn()
+                    return
+                r = LS.Lockstep(key + ":b", self.lock_cache)
+                for seg in reversed(segs):
+                    with r.lane():
+                        for fn in reversed(seg):
+                            fn()
+                r.emit()
+            self.record(bwd)
+        return outs
 
     # ------------------------------------------------------------------ lanes: independent sub-graphs on their own HIP streams
     _LANE_STREAMS = []
@@ -648,7 +697,7 @@ class Engine:
         return wp, d
 
     # ------------------------------------------------------------------ per-shape kernel / tile selection
-    def _tune_gemm(self, cd, in_ptr, wp, M, Cout, ep=None):
+    def _tune_gemm(self, cd, in_ptr, wp, M, Cout, ep=None, canon=False):
         """Pick (kernel, BM, BN) for this forward/dgrad shape by timing every candidate once (first eager step; results are cached in
         self.tuner and reused under hipGraph capture).  Returns the code for pn2_conv_desc.flags bits 8..15 (0 = library heuristic).
         ep: the launch carries a BatchNorm-backward epilogue (pn2_conv_gemm_ep): the candidates are timed WITH it (its extra operand reads and
@@ -656,6 +705,11 @@ class Engine:
         t = self.tuner
         if t is None or self.dt != BF16:
             return 0
+        if canon:
+            # inside a lock-step region the convs at one position share a launch only if they run on the same tile: one canonical tile per
+            # output width (LDS-DMA 3-stage kernel, 64-row tiles - these are the small maps of the heads) instead of per-shape tuning.  Decided
+            # when the conv is built, identically in every step (the partial-row buffers of the statistics depend on the tile)
+            return 2 | (1 << 2) | ((1 if Cout <= 32 else (2 if Cout <= 64 else 3)) << 4)
         key = ("g", cd.N, cd.H, cd.W, cd.OH, cd.OW, cd.Cin_p, cd.ld_in, Cout, cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w, cd.transposed)
         if ep is not None:
             key = key + ("ep", ep.a.mode, ep.b.mode, 1 if ep.b.out else 0, cd.flags & capi.CONV_ACCUM)
@@ -663,6 +717,11 @@ class Engine:
             return t[key]
         if torch.cuda.is_current_stream_capturing():
             return 0
+        from . import lockstep as LS
+        with LS.pause():                 # the candidates are timed with real launches even inside a lock-step region
+            return self._tune_gemm_run(t, key, cd, in_ptr, wp, M, Cout, ep)
+
+    def _tune_gemm_run(self, t, key, cd, in_ptr, wp, M, Cout, ep):
         st = _stream()
         nul = C.c_void_p(0)
         scratch = torch.empty((M, Cout), dtype=torch.bfloat16, device=self.dev)
@@ -744,6 +803,11 @@ class Engine:
             return t[key]
         if torch.cuda.is_current_stream_capturing():
             return 0, nsplit
+        from . import lockstep as LS
+        with LS.pause():
+            return self._tune_wgrad_run(t, key, wd, dy_ptr, x_ptr, rd, nsplit, wshape)
+
+    def _tune_wgrad_run(self, t, key, wd, dy_ptr, x_ptr, rd, nsplit, wshape):
         st = _stream()
         slab = torch.empty((nsplit, wd.Rp, wd.Kp), dtype=torch.float32, device=self.dev)
         gw = torch.empty(tuple(wshape), dtype=torch.float32, device=self.dev)
@@ -833,7 +897,8 @@ class Engine:
         cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = KH, KW, sh, ph, pw, dh, dw
         cd.transposed, cd.Kp, cd.flags = 0, pd.Kp, (capi.CONV_STATS if train_bn else 0)
         psum = psq = None
-        tune = self._tune_gemm(cd, x.ptr, wp, M, Cout_p)
+        canon = LOCKSTEP and LOCKSTEP_TILES and getattr(self, "_in_region", 0) > 0      # canonical tiles for convs of a lock-step region (fwd and dgrad)
+        tune = self._tune_gemm(cd, x.ptr, wp, M, Cout_p, canon=canon)
         cd.flags |= tune << 8
         tile_rows = 0
         if train_bn:
@@ -1089,7 +1154,7 @@ class Engine:
                             self._fill_bnb(t_, a_, 0)
                     if dual:
                         ep.b.out = 1
-                    tcode = self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, ep)
+                    tcode = self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, ep, canon=canon)
                     dd.flags |= tcode << 8
                     nbx = self._stat_blocks(Mx, x.Cp, tcode)
                     ep = capi.ConvEp()
@@ -1112,7 +1177,7 @@ class Engine:
                         call.pn2_conv_gemm_ep(self.dt, _p(draw), _p(wt), _p(gx), C.byref(dd), C.byref(ep), st)
                     x._sealed = True
                 else:
-                    dd.flags |= self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp) << 8
+                    dd.flags |= self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, canon=canon) << 8
                     call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
 
         self.record(bwd)
@@ -1229,7 +1294,8 @@ class Engine:
         cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = 1, 1, 1, 0, 0, 1, 1
         cd.transposed, cd.Kp, cd.flags = 0, Kp, (capi.CONV_STATS if train else 0)
         psum = psq = None
-        tune = self._tune_gemm(cd, x.ptr, wp, M, Ct)
+        canon = LOCKSTEP and LOCKSTEP_TILES and getattr(self, "_in_region", 0) > 0
+        tune = self._tune_gemm(cd, x.ptr, wp, M, Ct, canon=canon)
         cd.flags |= tune << 8
         tile_rows = 0
         if train:
@@ -1313,7 +1379,7 @@ class Engine:
                 dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Ct, Ct, x.Cp, gx.stride(2)
                 dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = 1, 1, 1, 0, 0, 1, 1
                 dd.transposed, dd.Kp, dd.flags = 1, Kt, (capi.CONV_ACCUM if gxa else 0)
-                dd.flags |= self._tune_gemm(dd, _p(draw), wt, M, x.Cp) << 8
+                dd.flags |= self._tune_gemm(dd, _p(draw), wt, M, x.Cp, canon=canon) << 8
                 capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
                 call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), nul, nul, C.byref(dd), st)
         self.record(bwd)

@@ -119,6 +119,7 @@ class Trainer:
             mode = os.environ.get("PN2_DEFER_WGRAD", "2")
             st = self._states[key] = SimpleNamespace(
                 key=key, steps_run=0, graph=None, graph_opt=None, s_images=None, s_gts=None, s_loss=None,
+                lock_cache={},
                 grad_queue=GradQueue(defer_wgrad=mode == "2") if mode in ("1", "2") else None,
                 arena=StepArena() if os.environ.get("PN2_STEP_ARENA", "1") == "1" else None)
         self._cur = st
@@ -138,7 +139,9 @@ class Trainer:
         if st.arena is not None:
             st.arena.begin_step(self.flat.device)
         st.steps_run += 1
-        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, grad_queue=st.grad_queue, arena=st.arena)
+        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, grad_queue=st.grad_queue, arena=st.arena,
+                     lock_cache=st.lock_cache if (st.arena is not None and st.arena.buf is not None) else None)    # recorded launches hold raw pointers:
+        # only with the bump arena (nothing is recycled inside a step) do the buffers of a lane outlive the deferred emission
         eng.fuse_tail = self.fuse_tail and self.loss_kind == "structure"
         if size is not None and (size != images.shape[2] or size != images.shape[3]):
             x = eng.cast(eng.resize_to(eng.from_nchw(images, dt=F32), size, size, align_corners=True), self.dtype)

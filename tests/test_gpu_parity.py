@@ -652,6 +652,41 @@ def test_table_driven_launches_match_single_launches(fp32, monkeypatch):
         assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
 
 
+@pytest.mark.parametrize("fp32", [False, True])
+@pytest.mark.parametrize("size", [96, 224])
+def test_lockstep_launches_match_plain_launches(fp32, size, monkeypatch):
+    """Engine.lockstep (pn2/lockstep.py): the three RFB modules and their branch tails, and the three parallel 3x3 convs of every Res2Net stage
+    block, advance position by position on table-driven launches (pn2_conv_gemm_multi, pn2_bn_finalize_multi, pn2_affine_multi,
+    pn2_bn_bwd_finalize_multi, pn2_bn_bwd_apply_multi, pn2_bn_bwd_reduce_multi) - against one launch per chain: loss, every gradient and the
+    parameters after three optimizer steps, bit for bit; and the launch count drops."""
+    from pn2 import engine, capi
+    from pn2.trainer import Trainer
+    from oracle import weights as W
+    x, mask = W.synthetic_batch(2, size, seed=6)
+    xg, mg = x.to(dev), mask.to(dev)
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(engine, "LOCKSTEP", on)
+        tr = Trainer(_fixture_model(fp32=fp32))
+        for _ in range(3):          # step 1 torch allocator (no lock step), step 2 builds the tables on arena addresses, step 3 replays them
+            loss = tr.step(xg, mg)
+        counts = {}
+        real = {n: getattr(capi.call, n) for n in ("pn2_conv_gemm", "pn2_conv_gemm_ep", "pn2_conv_gemm_multi", "pn2_bn_finalize", "pn2_bn_finalize_multi")}
+        for n, f in real.items():
+            monkeypatch.setattr(capi.call, n, lambda *a, _f=f, _n=n: (counts.__setitem__(_n, counts.get(_n, 0) + 1), _f(*a))[1], raising=False)
+        loss = tr.forward_backward(xg, mg)
+        for n in real:
+            monkeypatch.setattr(capi.call, n, real[n], raising=False)
+        torch.cuda.synchronize()
+        res.append((loss.clone(), tr.gflat.clone(), tr.flat.clone(), counts))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    plain, ls = res[0][3], res[1][3]
+    print("launch counts plain", plain, "lock step", ls)
+    assert plain.get("pn2_conv_gemm_multi", 0) == 0 and ls["pn2_conv_gemm_multi"] >= 12
+    assert ls.get("pn2_conv_gemm", 0) + ls.get("pn2_conv_gemm_ep", 0) + ls["pn2_conv_gemm_multi"] <= plain["pn2_conv_gemm"] + plain["pn2_conv_gemm_ep"] - 50
+    assert ls["pn2_bn_finalize_multi"] >= 8 and ls.get("pn2_bn_finalize", 0) + ls["pn2_bn_finalize_multi"] <= plain["pn2_bn_finalize"] - 30
+
+
 def test_fused_dsra_tail_matches_unfused_path(monkeypatch):
     """pn2_dsra_tail_fwd/_bwd (up-sampling + structure loss + adjoint in two kernels) against the op-by-op path
     (pn2_bilinear_fwd -> pn2_structure_loss_fwd/_bwd -> pn2_bilinear_bwd), fp32 compute, same weights and batch."""
