@@ -238,6 +238,12 @@ class Trainer:
                 self._expected = dict(eng.pgrads.counts)
             self.buckets.finish()
         self.last_outs = lat
+        # break the reference cycles engine <-> activations <-> closures now: the engine holds this trainer (grad_provider), and a trainer that only
+        # dies when the cyclic collector gets to it would destroy its hipGraphs at an arbitrary later time - e.g. inside another graph's capture
+        eng.tail.clear()
+        eng._lat = None
+        eng.pgrads.provider = None
+        eng.lock_cache = eng.grad_queue = eng.arena = eng.pack_cache = None
         if self.tuner is not None and len(self.tuner) != self._tuned and os.environ.get("PN2_TUNE_CACHE"):
             from .engine import save_tuner
             save_tuner(os.environ["PN2_TUNE_CACHE"])
@@ -301,17 +307,25 @@ class Trainer:
                 self.forward_backward_local(st.s_images, st.s_gts, size=size)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        import gc
         st.graph = torch.cuda.CUDAGraph()
-        if self.world == 1:
-            with torch.cuda.graph(st.graph):
-                st.s_loss = self.step(st.s_images, st.s_gts, size=size)
-            st.graph_opt = None
-        else:
-            with torch.cuda.graph(st.graph):
-                st.s_loss = self.forward_backward_local(st.s_images, st.s_gts, size=size)
-            st.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st.graph_opt):
-                self.optimizer_step()
+        gc_was = gc.isenabled()
+        gc.collect()
+        gc.disable()                   # no collector runs inside a capture: a destructor that touches the HIP runtime there aborts the process
+        try:
+            if self.world == 1:
+                with torch.cuda.graph(st.graph):
+                    st.s_loss = self.step(st.s_images, st.s_gts, size=size)
+                st.graph_opt = None
+            else:
+                with torch.cuda.graph(st.graph):
+                    st.s_loss = self.forward_backward_local(st.s_images, st.s_gts, size=size)
+                st.graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(st.graph_opt):
+                    self.optimizer_step()
+        finally:
+            if gc_was:
+                gc.enable()
         return self
 
     def forward_backward_local(self, images, gts, size=None):
