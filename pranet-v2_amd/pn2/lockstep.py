@@ -211,7 +211,7 @@ class Lockstep:
                 if job is None:
                     singles.append((a, orig, work))
                 else:
-                    groups.setdefault(job[0], []).append((job[1], job[2], a, orig, work))
+                    groups.setdefault(job[0], []).append((job[1], job[2], a, orig, work, name))
             for a, orig, work in singles:
                 capi.WORK.clear(); capi.WORK.update(work)
                 orig(*a)
@@ -235,7 +235,10 @@ class Lockstep:
                     capi.WORK.clear()
                     capi.WORK.update(flops=sum(j[4].get("flops", 0) for j in jobs), tag=jobs[0][4].get("tag", ""), shape=f"lockstep x{n} tile {kind[2]}x{kind[3]}")
                     call.pn2_conv_gemm_multi(kind[1], kind[2], kind[3], kind[4], _p(table), _p(bstart), n, total, st)
-                elif kind[0] == "bnfin":
+                    continue
+                capi.WORK.clear()
+                capi.WORK.update(bytes=self._bytes(jobs))
+                if kind[0] == "bnfin":
                     call.pn2_bn_finalize_multi(_p(table), _p(bstart), n, total, st)
                 elif kind[0] == "affine":
                     call.pn2_affine_multi(kind[1], _p(table), _p(bstart), n, total, st)
@@ -246,3 +249,8 @@ class Lockstep:
                 elif kind[0] == "bnreduce":
                     call.pn2_bn_bwd_reduce_multi(kind[1], _p(table), _p(bstart), n, total, st)
         self.lanes = []
+
+    def _bytes(self, jobs):
+        """minimum HBM bytes of a batched streaming launch for the profiler (sum over its jobs, same accounting as pn2.profile._bytes)"""
+        from .profile import _bytes
+        return sum(_bytes(name, a) for _j, _nb, a, _orig, _w, name in jobs)

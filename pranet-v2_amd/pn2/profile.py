@@ -121,10 +121,12 @@ class Recorder:
             fn = getattr(lib, name)
 
             def wrapped(*a, _fn=fn, _name=name):
-                if _name in ("pn2_conv_gemm", "pn2_conv_gemm_ep", "pn2_conv_wgrad", "pn2_conv_wgrad_multi"):
+                by_ = 0
+                if _name in ("pn2_conv_gemm", "pn2_conv_gemm_ep", "pn2_conv_gemm_multi", "pn2_conv_wgrad", "pn2_conv_wgrad_multi"):
                     fl, tag, shape = capi.WORK.pop("flops", 0), capi.WORK.pop("tag", ""), capi.WORK.pop("shape", "")
                 else:
                     fl, tag, shape = 0, "", _shape(_name, a)
+                    by_ = capi.WORK.pop("bytes", 0) if _name.endswith("_multi") else _bytes(_name, a)      # lock-step launches: summed over their jobs
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _fn(*a)
@@ -133,7 +135,7 @@ class Recorder:
                     raise RuntimeError(f"{_name} failed with status {rc}")
                 if _name == "pn2_conv_gemm_ep":
                     _name = "pn2_conv_gemm"           # same kernel symbols; the tag (:dgrad) keeps the family together
-                self.rows.append((_name + tag, fl, _bytes(_name, a) if not fl else 0, e0, e1, shape))
+                self.rows.append((_name + tag, fl, by_ if not fl else 0, e0, e1, shape))
             self.saved[name] = capi.call.__dict__.get(name)
             setattr(capi.call, name, wrapped)
         return self
@@ -221,10 +223,10 @@ def measure_step(trainer, x, m, dtype, config=None):
     fam = [d for n, d in agg.items() if n.startswith("pn2_conv_gemm")]
     fl, ms, nl = sum(d["flops"] for d in fam), sum(d["ms"] for d in fam), sum(d["launches"] for d in fam)
     ach = fl / (ms * 1e-3) / 1e12
-    roofline = {"kernel": "pn2_conv_gemm (fwd+dgrad; symbols conv_dma_gemm<*>, conv_gather_gemm<*>)", "bound": "mfma", "achieved": round(ach, 2),
+    roofline = {"kernel": "pn2_conv_gemm + pn2_conv_gemm_multi (fwd+dgrad incl. the BatchNorm-backward statistics epilogues; symbols conv_dma_gemm[_tab]<*>, conv_gather_gemm[_tab]<*>)", "bound": "mfma", "achieved": round(ach, 2),
                 "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": None, "launches": nl,
                 "avg_launch_us": round(1e3 * ms / nl, 2), "algorithmic_gflop_per_launch": round(fl / nl / 1e9, 3)}
-    traffic = _pmc_traffic(("conv_dma_gemm", "conv_gather_gemm"), config or {})
+    traffic = _pmc_traffic(("conv_dma_gemm", "conv_gather_gemm", "conv_dma_gemm_tab", "conv_gather_gemm_tab"), config or {})
     if traffic is not None:
         roofline["traffic"] = traffic["bytes_per_launch"]
         roofline["traffic_source"] = traffic["source"]
@@ -239,7 +241,8 @@ def measure_step(trainer, x, m, dtype, config=None):
     roofline["conv_classes"] = {k: {"ms": round(v[0], 3), "launches": v[1], "TFLOPs": round(v[2] / (v[0] * 1e-3) / 1e12, 1), "frac": round(v[2] / (v[0] * 1e-3) / 1e12 / peak_tf, 4)}
                                 for k, v in sorted(cls.items(), key=lambda kv: -kv[1][0])}
     # the BatchNorm family: HBM-bound streaming passes + the per-layer finalisation launches
-    bn_names = ("pn2_affine_act", "pn2_affine_act_sum", "pn2_bn_finalize", "pn2_bn_bwd_reduce", "pn2_bn_bwd_finalize", "pn2_bn_bwd_finalize_seg", "pn2_bn_bwd_apply")
+    bn_names = ("pn2_affine_act", "pn2_affine_act_sum", "pn2_affine_multi", "pn2_bn_finalize", "pn2_bn_finalize_multi", "pn2_bn_bwd_reduce", "pn2_bn_bwd_reduce_multi",
+                "pn2_bn_bwd_finalize", "pn2_bn_bwd_finalize_seg", "pn2_bn_bwd_finalize_multi", "pn2_bn_bwd_apply", "pn2_bn_bwd_apply_multi")
     bn = [agg[k] for k in bn_names if k in agg]
     if bn:
         by, ms_, nl_ = sum(t["bytes"] for t in bn), sum(t["ms"] for t in bn), sum(t["launches"] for t in bn)
