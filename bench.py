@@ -186,8 +186,13 @@ def main():
             return (time.perf_counter() - t0_) / n
         st_ = tr._cur
         t_all = timed(step)
-        t_noex = timed(lambda: (st_.graph.replay(), st_.graph_opt.replay())) if use_graph and st_.graph_opt is not None else None
+        def no_exchange():          # the same graphs without the collectives
+            for g_ in ([g for g, _ in st_.segments] if st_.segments else [st_.graph]):
+                g_.replay()
+            st_.graph_opt.replay()
+        t_noex = timed(no_exchange) if use_graph and st_.graph_opt is not None else None
         dp = {"backend": "nccl (RCCL)", "nccl_ranks": world, "buckets": len(tr.buckets.buckets), "bucket_bytes": 32 << 20, "allreduce_bytes_per_step": int(tr.n_hot * 4),
+              "graph_segments": len(st_.segments) if st_.segments else 1,
               "exposed_comm_ms": None if t_noex is None else round(1e3 * (t_all - t_noex), 3)}
     names = {"res2net": "PraNet-V2 Res2Net50", "pvt": "PVT-PraNet-V2 (pvt_v2_b2, DropPath 0.1)", "emcad": "EMCADNet dual K=9 (pvt_v2_b2 encoder, EMCAD decoder)"}
     what = ("fwd+15-subset CE/Dice/BCE loss+bwd+AdamW" if args.model == "emcad" else "fwd+4x structure_loss+bwd+clamp+Adam")

@@ -206,7 +206,11 @@ def pvt_features(P, p, x, cfg=None):
 
 def pvt_pranet_v2_forward(P, x, training, use_softmax=True, sem_downsample=1):
     """PVT_PraNet_V2.forward (pranet.py:205-263): PVTv2-B2 features, then exactly the PraNet_V2 heads."""
-    return pranet_v2_forward(P, x, training, use_softmax, sem_downsample, features=lambda P_, x_, ctx: pvt_features(P_, "backbone.", x_))
+    def features(P_, x_, ctx):
+        if x_.shape[1] == 1:            # pranet.py:190-191 + :139-143: conv(1->3, k1, bias) + BN + ReLU for 1-channel slices
+            x_ = F.relu(bn(P_, "conv.1", F.conv2d(x_, P_["conv.0.weight"], P_["conv.0.bias"]), ctx))
+        return pvt_features(P_, "backbone.", x_)
+    return pranet_v2_forward(P, x, training, use_softmax, sem_downsample, features=features)
 
 
 def pranet_v2_forward(P, x, training, use_softmax=True, sem_downsample=1, features=None):

@@ -277,11 +277,17 @@ class PVT_PraNet_V2(nn.Module):
         self.ra2_conv4_fg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
         self.ra2_conv4_bg = BasicConv2d(64, num_class, kernel_size=3, padding=1)
 
-    def hot_parameters(self):
+    def hot_parameters(self, gray=False):
         """Parameters that forward() touches (self.conv only serves 1-channel inputs — reference :190-191)."""
-        return [p for n, p in self.named_parameters() if not n.startswith('conv.')]
+        return [p for n, p in self.named_parameters() if gray or not n.startswith('conv.')]
 
-    _build = PraNet_V2._build           # backbone._build_features -> RFBs -> aggregation -> DSRA tail: identical head code (:193-263)
+    def _build(self, eng, x):
+        """1-channel inputs go through conv(1->3)+BN+ReLU first (reference :190-191); then backbone._build_features -> RFBs -> aggregation ->
+        DSRA tail: identical head code (:193-263)"""
+        if x.C == 1:
+            x = eng.conv_bn_act(x, self.conv[0], self.conv[1], relu=True, bias=self.conv[0].bias)
+        return PraNet_V2._build(self, eng, x)
 
     def forward(self, x, segSize=None):
-        return run_module(self._build, [x], self.hot_parameters(), self.training)
+        """segSize is accepted and unused, as in the reference (:189)."""
+        return run_module(self._build, [x], self.hot_parameters(x.shape[1] == 1), self.training)

@@ -26,6 +26,7 @@ class GradBuckets:
         if cur:
             self.buckets.append((start, end, frozenset(cur)))
         self.total = end
+        self.record = None       # a list while a step is being CAPTURED: launches are noted (bucket indices), not issued (Trainer.capture)
         self.reset()
 
     def reset(self):
@@ -37,8 +38,23 @@ class GradBuckets:
     def _launch(self, b):
         a, e, keys = self.buckets[b]
         self.launched_keys |= keys
-        self.works.append(dist.all_reduce(self.gflat[a:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        if self.record is not None:
+            self.record.append(b)
+        else:
+            self.works.append(dist.all_reduce(self.gflat[a:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         self.order.append(b)
+
+    def launch_async(self, bs):
+        """Replay side of a captured step: start the all-reduce of buckets `bs` now (the graph segment that completed them was just enqueued on
+        the current stream; the collective's stream waits for it and then runs next to the following segment)."""
+        for b in bs:
+            a, e, _ = self.buckets[b]
+            self.works.append(dist.all_reduce(self.gflat[a:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
 
     def launch_ready(self, written, before_launch=None, expected=None):
         """Start the all-reduce of every pending bucket whose gradients are COMPLETE.
@@ -63,9 +79,7 @@ class GradBuckets:
         for b in list(self.pending):
             self._launch(b)
         self.pending = []
-        for w in self.works:
-            w.wait()
-        self.works = []
+        self.wait()
 
     def reduce_all(self):
         self.reset()

@@ -25,6 +25,7 @@ def _r4(n):
 
 WGRAD_OVERLAP = os.environ.get("PN2_WGRAD_OVERLAP", "0") == "1"      # deferred wgrad tables on a side stream, next to the backward chain (measured: 19.2 -> 20.3 ms, see DESIGN)
 WGRAD_SEG = int(os.environ.get("PN2_WGRAD_SEG", "24"))              # convs per flush segment
+DP_SEGMENTS = os.environ.get("PN2_DP_SEGMENTS", "1") == "1"          # data-parallel replay: one hipGraph per gradient-bucket boundary, all-reduce overlapped (0: one graph, reduce after it)
 
 
 class Trainer:
@@ -68,6 +69,7 @@ class Trainer:
         self.hot = hot
         # gradient buckets in arena order (backward completes them from the tail)
         self.buckets = GradBuckets(self.gflat, [(id(p), self.off[id(p)][0], _r4(self.off[id(p)][1])) for p in hot], bucket_bytes, process_group)
+        self._seg = None                # capture of a data-parallel step in progress (see _capture_segments)
         self._side = None               # side HIP stream of the overlapped wgrad segments (see _backward)
         self._expected = None           # id(p) -> gradient contributions per step, learned from the first backward pass (see _backward)
         self.last_outs = None
@@ -118,7 +120,7 @@ class Trainer:
             # PN2_DEFER_WGRAD: 2 (default) wgrad + slab reduction deferred into table-driven launches, 1 only the reductions, 0 neither
             mode = os.environ.get("PN2_DEFER_WGRAD", "2")
             st = self._states[key] = SimpleNamespace(
-                key=key, steps_run=0, graph=None, graph_opt=None, s_images=None, s_gts=None, s_loss=None,
+                key=key, steps_run=0, graph=None, graph_opt=None, segments=None, s_images=None, s_gts=None, s_loss=None,
                 lock_cache={},
                 grad_queue=GradQueue(defer_wgrad=mode == "2") if mode in ("1", "2") else None,
                 arena=StepArena() if os.environ.get("PN2_STEP_ARENA", "1") == "1" else None)
@@ -225,6 +227,8 @@ class Trainer:
                 rq.flush()
             if hook and expected is not None:
                 self.buckets.launch_ready(eng.pgrads.counts, before_launch=grads_complete, expected=expected)
+                if self._seg is not None and self.buckets.record:
+                    self._cut_segment()
         eng.tape = []
         eng.pgrads.on_sink = None
         if len(eng.pgrads.written) != len(self.hot):
@@ -284,7 +288,7 @@ class Trainer:
         with torch.no_grad():
             self.bias_corr[4:7] = torch.tensor([self.lr, self.clip, self.weight_decay], device=self.bias_corr.device)
         for st in self._states.values():                               # captured graphs baked the old hyper-parameters in
-            st.graph = st.graph_opt = None
+            st.graph = st.graph_opt = st.segments = None
         return self
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
@@ -303,7 +307,7 @@ class Trainer:
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.step(st.s_images, st.s_gts, size=size)
-            if self.world > 1:      # the captured pass has no bucket hooks: let it build its own (single) reduce table eagerly
+            if self.world > 1 and not DP_SEGMENTS:      # that captured pass has no bucket hooks: let it build its own (single) reduce table eagerly
                 self.forward_backward_local(st.s_images, st.s_gts, size=size)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -318,8 +322,13 @@ class Trainer:
                     st.s_loss = self.step(st.s_images, st.s_gts, size=size)
                 st.graph_opt = None
             else:
-                with torch.cuda.graph(st.graph):
-                    st.s_loss = self.forward_backward_local(st.s_images, st.s_gts, size=size)
+                if DP_SEGMENTS and self._expected is not None:
+                    st.segments = self._capture_segments(st, size)
+                    st.graph = st.segments[0][0]
+                else:
+                    st.segments = None
+                    with torch.cuda.graph(st.graph):
+                        st.s_loss = self.forward_backward_local(st.s_images, st.s_gts, size=size)
                 st.graph_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(st.graph_opt):
                     self.optimizer_step()
@@ -327,6 +336,40 @@ class Trainer:
             if gc_was:
                 gc.enable()
         return self
+
+    def _cut_segment(self):
+        """Capture of a data-parallel step: one or more gradient buckets just became complete - close the hipGraph segment that produced them
+        and open the next one; replay() starts their all-reduce right after enqueueing this segment, next to the segments that follow."""
+        seg = self._seg
+        seg["g"].capture_end()
+        seg["list"].append((seg["g"], list(self.buckets.record)))
+        del self.buckets.record[:]
+        seg["g"] = torch.cuda.CUDAGraph()
+        seg["g"].capture_begin(pool=seg["pool"])
+
+    def _capture_segments(self, st, size):
+        """forward+loss+backward of a data-parallel rank as a CHAIN of hipGraphs cut where buckets leave (same places as in the eager step, so
+        the deferred weight-gradient tables are the ones the eager steps built).  All segments share one memory pool and are replayed in capture
+        order.  Returns [(graph, [bucket, ...]), ...]."""
+        segs = []
+        cs = torch.cuda.Stream()
+        cs.wait_stream(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        with torch.cuda.stream(cs):
+            g = torch.cuda.CUDAGraph()
+            self._seg = {"g": g, "pool": torch.cuda.graph_pool_handle(), "list": segs}
+            self.buckets.record = []
+            g.capture_begin(pool=self._seg["pool"])
+            try:
+                st.s_loss = self.forward_backward(st.s_images, st.s_gts, size=size)
+                self._seg["g"].capture_end()
+                segs.append((self._seg["g"], list(self.buckets.record)))
+            finally:
+                self._seg = None
+                self.buckets.record = None
+        torch.cuda.current_stream().wait_stream(cs)
+        torch.cuda.synchronize()
+        return segs
 
     def forward_backward_local(self, images, gts, size=None):
         w, self.world = self.world, 1
@@ -347,8 +390,18 @@ class Trainer:
                     d_.copy_(s_, non_blocking=True)
             else:
                 st.s_gts.copy_(gts, non_blocking=True)
-        st.graph.replay()
-        if st.graph_opt is not None:
+        if st.graph_opt is None:
+            st.graph.replay()
+        elif st.segments:
+            # data parallel: every segment ends where gradient buckets are complete; their all-reduce runs next to the segments that follow
+            self.buckets.reset()
+            for g, bs in st.segments:
+                g.replay()
+                self.buckets.launch_async(bs)
+            self.buckets.wait()
+            st.graph_opt.replay()
+        else:
+            st.graph.replay()
             self.buckets.reduce_all()
             st.graph_opt.replay()
         return st.s_loss

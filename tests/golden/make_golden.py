@@ -357,6 +357,33 @@ def gen_pvt(size=96, n=2):
     save("pvt_pranet_v2_96.npz", **out)
 
 
+def gen_pvt_gray(size=64, n=2):
+    """PVT_PraNet_V2 on 1-channel input: the conv(1->3)+BN+ReLU stem of pranet.py:190-191 in front of the backbone (fp32 + float64)."""
+    man = W.manifest_pvt_pranet_v2(1)
+    sd0 = W.make_state_dict(man, seed=11)
+    x, mask = W.synthetic_batch(n, size, seed=777)
+    x = x[:, :1].contiguous()
+    out = {"size": np.array(size), "n": np.array(n)}
+    probes = ["conv.0.weight", "conv.1.weight", "conv.1.bias", "backbone.patch_embed1.proj.weight", "ra2_conv4_fg.conv.weight"]
+    for tag, dt in (("", torch.float32), ("f64.", torch.float64)):
+        model = _ref_pvt_model()
+        model.load_state_dict(sd0, strict=True)
+        model = model.to(dt).train()
+        outs = model(x.to(dt))
+        m = mask.to(dt)
+        losses = [R.train.structure_loss(outs[i], outs[i + 4], m, 1 - m) for i in range(4)]
+        (losses[3] + losses[2] + losses[1] + losses[0]).backward()
+        names = dict(model.named_parameters())
+        out[tag + "losses"] = np.array([float(l) for l in losses])
+        for i, o in enumerate(outs):
+            out[tag + f"out{i}"] = npy(o).astype(np.float64 if tag else np.float32)
+        for k in probes:
+            out[tag + "graw." + k] = head(names[k].grad)
+            out[tag + "grawnorm." + k] = npy(names[k].grad.norm())
+        out[tag + "rm.conv.1"] = npy(model.conv[1].running_mean); out[tag + "rv.conv.1"] = npy(model.conv[1].running_var)
+    save("pvt_pranet_v2_gray_64.npz", **out)
+
+
 def gen_eval_metrics():
     """Threshold-sweep metrics of eval.py:22-50 (Fmeasure_calu, eval_functions.py:131-166) + MAE on small synthetic maps."""
     import importlib
@@ -386,7 +413,7 @@ def gen_eval_metrics():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["manifest", "loss", "dsra", "blocks", "m96", "m352", "v1", "pvtv1", "evalm", "pvt"]
+    which = sys.argv[1:] or ["manifest", "loss", "dsra", "blocks", "m96", "m352", "v1", "pvtv1", "evalm", "pvt", "pvtgray"]
     if "evalm" in which: gen_eval_metrics()
     if "pvt" in which: gen_pvt()
     if "manifest" in which: gen_manifest()
@@ -397,3 +424,4 @@ if __name__ == "__main__":
     if "m352" in which: gen_model(352, 2, "352", False)
     if "v1" in which: gen_v1()
     if "pvtv1" in which: gen_pvt_v1()
+    if "pvtgray" in which: gen_pvt_gray()

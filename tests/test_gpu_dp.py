@@ -80,6 +80,8 @@ def _worker_body(rank, world, port, q, kind, autotune):
     tr.capture(x, m, warmup=2)                # 2 more eager steps, then the split graphs
     tr.replay(); tr.replay()
     torch.cuda.synchronize()
+    segs = [bs for _, bs in tr._cur.segments]      # the captured step is a chain of hipGraphs cut where buckets leave
+    assert len(segs) >= 3 and [b for bs in segs for b in bs] == order, (segs, order)
     q.put((rank, g1.cpu().numpy(), p1.cpu().numpy(), tr.flat.clone().cpu().numpy(), order, float(loss[-1])))     # numpy: no fd passing
     dist.barrier()
     dist.destroy_process_group()

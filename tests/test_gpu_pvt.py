@@ -130,13 +130,13 @@ def test_attention(dtn, cfg):
     assert err(kva.grad.float().permute(0, 3, 1, 2), kv64.grad) < tol
 
 
-def _pvt_model(fp32=True):
+def _pvt_model(fp32=True, seed=3):
     import pn2
     from lib.pranet import PVT_PraNet_V2
     from oracle import weights as W
     pn2.set_compute_dtype("fp32" if fp32 else "bf16")
     model = PVT_PraNet_V2(num_class=1)
-    model.load_state_dict(W.make_state_dict(W.manifest_pvt_pranet_v2(1), seed=3), strict=True)
+    model.load_state_dict(W.make_state_dict(W.manifest_pvt_pranet_v2(1), seed=seed), strict=True)
     model.backbone.reset_drop_path(0.0)
     return model.to(dev).train()
 
@@ -201,6 +201,37 @@ def test_pvt_pranet_v2_forward_backward_vs_reference(fp32):
             if k.startswith("f64.grawnorm."):
                 name = k[len("f64.grawnorm."):]
                 assert abs(float(names[name].grad.norm()) - float(z[k])) < 0.3 * float(z[k]) + 5e-3, name      # (norm4.bias: exactly 0 analytically, BN cancels it)
+
+
+def test_pvt_pranet_v2_one_channel_input_vs_reference():
+    """1-channel slices take the conv(1->3)+BN+ReLU stem of pranet.py:190-191 first (its three parameters train; its bias gradient is ~0 under
+    the train-mode BN); fp32 path against the float64 reference, gates relative to the reference's own fp32 error."""
+    from pn2.loss import structure_loss
+    from oracle import weights as W
+    z = np.load(os.path.join(G, "pvt_pranet_v2_gray_64.npz"))
+    model = _pvt_model(fp32=True, seed=11)
+    x, mask = W.synthetic_batch(2, 64, seed=777)
+    xg, mg = x[:, :1].contiguous().to(dev), mask.to(dev)
+    outs = model(xg, segSize=None)
+    losses = [structure_loss(outs[i], outs[i + 4], mg, 1 - mg) for i in range(4)]
+    (losses[3] + losses[2] + losses[1] + losses[0]).backward()
+    for i, o in enumerate(outs):
+        ref64 = torch.from_numpy(z[f"f64.out{i}"])
+        own = float((torch.from_numpy(z[f"out{i}"]).double() - ref64).abs().max())
+        assert float((o.detach().double().cpu() - ref64).abs().max()) <= max(1e-4, 3 * own), i
+    names = dict(model.named_parameters())
+    for k in z.files:
+        if k.startswith("f64.grawnorm."):
+            name = k[len("f64.grawnorm."):]
+            g = names[name].grad
+            assert g is not None, name
+            h64 = torch.from_numpy(z["f64.graw." + name]).double()
+            h32 = torch.from_numpy(z["graw." + name]).double()
+            ours = g.detach().reshape(-1)[:h64.numel()].double().cpu()
+            assert float((ours - h64).norm()) <= max(2e-4 * float(h64.norm()), 3 * float((h32 - h64).norm())) + 1e-7, name
+    assert float((model.conv[1].running_mean.double().cpu() - torch.from_numpy(z["f64.rm.conv.1"]).double()).abs().max()) < 1e-5
+    assert float((model.conv[1].running_var.double().cpu() - torch.from_numpy(z["f64.rv.conv.1"]).double()).abs().max()) < 1e-5
+    assert names["conv.0.bias"].grad is not None and float(names["conv.0.bias"].grad.abs().max()) < 1e-4
 
 
 def test_pvt_trainer_step_and_graph_replay():

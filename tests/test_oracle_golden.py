@@ -205,6 +205,28 @@ def test_pvt_manifest_and_oracle_match_reference():
             assert abs(float(g.norm()) - float(z[k])) <= 2e-3 * float(z[k]) + 1e-6, k
 
 
+def test_pvt_one_channel_stem_oracle_matches_reference():
+    """1-channel input: conv(1->3)+BN+ReLU stem (pranet.py:190-191) in front of PVT_PraNet_V2 - outputs, loss and the stem's gradient probes."""
+    z = np.load(os.path.join(G, "pvt_pranet_v2_gray_64.npz"))
+    sd = W.make_state_dict(W.manifest_pvt_pranet_v2(1), seed=11)
+    x, mask = W.synthetic_batch(2, 64, seed=777)
+    P = O.clone_sd(sd)
+    for k, v in P.items():
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    outs = O.pvt_pranet_v2_forward(P, x[:, :1].contiguous(), True)
+    for i, o in enumerate(outs):
+        assert float((o.detach() - torch.from_numpy(z[f"out{i}"])).abs().max()) < 1e-4
+    loss = O.total_loss(outs, mask)
+    assert abs(float(loss) - float(z["losses"].sum())) < 1e-4
+    loss.backward()
+    for k in z.files:
+        if k.startswith("grawnorm."):
+            g = P[k[len("grawnorm."):]].grad
+            assert abs(float(g.norm()) - float(z[k])) <= 2e-3 * float(z[k]) + 1e-6, k
+    assert float((P["conv.1.running_mean"] - torch.from_numpy(z["rm.conv.1"])).abs().max()) < 1e-6
+
+
 def test_emcad_manifest_and_oracle_match_reference():
     """BASELINE config 5: EMCADNet(dual, K=9, pvt_v2_b2) manifest + oracle/emcad_oracle.py (8 outputs, the 15-subset CE+Dice+BCE loss, gradient
     probes) against the imported reference's vectors (tests/golden/make_golden_emcad.py)."""
