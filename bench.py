@@ -192,7 +192,7 @@ def main():
             st_.graph_opt.replay()
         t_noex = timed(no_exchange) if use_graph and st_.graph_opt is not None else None
         dp = {"backend": "nccl (RCCL)", "nccl_ranks": world, "buckets": len(tr.buckets.buckets), "bucket_bytes": 32 << 20, "allreduce_bytes_per_step": int(tr.n_hot * 4),
-              "graph_segments": len(st_.segments) if st_.segments else 1,
+              "graph_segments": len(st_.segments) if st_.segments else 1, "wire_dtype": os.environ.get("PN2_DP_WIRE", "fp32"),
               "exposed_comm_ms": None if t_noex is None else round(1e3 * (t_all - t_noex), 3)}
     names = {"res2net": "PraNet-V2 Res2Net50", "pvt": "PVT-PraNet-V2 (pvt_v2_b2, DropPath 0.1)", "emcad": "EMCADNet dual K=9 (pvt_v2_b2 encoder, EMCAD decoder)"}
     what = ("fwd+15-subset CE/Dice/BCE loss+bwd+AdamW" if args.model == "emcad" else "fwd+4x structure_loss+bwd+clamp+Adam")

@@ -10,9 +10,12 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, gflat, spans, bucket_bytes=32 << 20, process_group=None):
-        """spans: ordered list of (key, offset, length) of the parameters inside `gflat` (elements)."""
-        self.gflat, self.pg = gflat, process_group
+    def __init__(self, gflat, spans, bucket_bytes=32 << 20, process_group=None, wire_dtype=None):
+        """spans: ordered list of (key, offset, length) of the parameters inside `gflat` (elements).
+        wire_dtype: None = the buckets travel as they are (fp32, what the reference's DDP does); torch.bfloat16 = each bucket is rounded to bf16
+        for the exchange (half the bytes on xGMI) and widened back into the fp32 arena after it - the sum itself is then a bf16 sum, so this is
+        a bandwidth / precision trade the caller has to ask for (PN2_DP_WIRE=bf16)."""
+        self.gflat, self.pg, self.wire = gflat, process_group, wire_dtype
         self.buckets = []        # (start, end, frozenset(keys))
         cur, start, nbytes = [], 0, 0
         end = 0
@@ -41,19 +44,28 @@ class GradBuckets:
         if self.record is not None:
             self.record.append(b)
         else:
-            self.works.append(dist.all_reduce(self.gflat[a:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._issue(a, e)
         self.order.append(b)
+
+    def _issue(self, a, e):
+        if self.wire is None:
+            self.works.append((dist.all_reduce(self.gflat[a:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None, a, e))
+        else:
+            buf = self.gflat[a:e].to(self.wire)
+            self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), buf, a, e))
 
     def launch_async(self, bs):
         """Replay side of a captured step: start the all-reduce of buckets `bs` now (the graph segment that completed them was just enqueued on
         the current stream; the collective's stream waits for it and then runs next to the following segment)."""
         for b in bs:
             a, e, _ = self.buckets[b]
-            self.works.append(dist.all_reduce(self.gflat[a:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._issue(a, e)
 
     def wait(self):
-        for w in self.works:
+        for w, buf, a, e in self.works:
             w.wait()
+            if buf is not None:
+                self.gflat[a:e].copy_(buf)
         self.works = []
 
     def launch_ready(self, written, before_launch=None, expected=None):

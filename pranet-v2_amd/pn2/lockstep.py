@@ -233,7 +233,8 @@ class Lockstep:
                 n = len(jobs)
                 if kind[0] == "conv":
                     capi.WORK.clear()
-                    capi.WORK.update(flops=sum(j[4].get("flops", 0) for j in jobs), tag=jobs[0][4].get("tag", ""), shape=f"lockstep x{n} tile {kind[2]}x{kind[3]}")
+                    capi.WORK.update(flops=sum(j[4].get("flops", 0) for j in jobs), tag=jobs[0][4].get("tag", ""), shape=f"lockstep x{n} tile {kind[2]}x{kind[3]}",
+                                     shapes=[j[4].get("shape", "") for j in jobs])
                     call.pn2_conv_gemm_multi(kind[1], kind[2], kind[3], kind[4], _p(table), _p(bstart), n, total, st)
                     continue
                 capi.WORK.clear()

@@ -124,6 +124,8 @@ class Recorder:
                 by_ = 0
                 if _name in ("pn2_conv_gemm", "pn2_conv_gemm_ep", "pn2_conv_gemm_multi", "pn2_conv_wgrad", "pn2_conv_wgrad_multi"):
                     fl, tag, shape = capi.WORK.pop("flops", 0), capi.WORK.pop("tag", ""), capi.WORK.pop("shape", "")
+                    es = 4 if int(a[0]) == capi.F32 else 2
+                    by_ = sum(_conv_bytes(s_, es) for s_ in (capi.WORK.pop("shapes", None) or [shape]))
                 else:
                     fl, tag, shape = 0, "", _shape(_name, a)
                     by_ = capi.WORK.pop("bytes", 0) if _name.endswith("_multi") else _bytes(_name, a)      # lock-step launches: summed over their jobs
@@ -135,7 +137,7 @@ class Recorder:
                     raise RuntimeError(f"{_name} failed with status {rc}")
                 if _name == "pn2_conv_gemm_ep":
                     _name = "pn2_conv_gemm"           # same kernel symbols; the tag (:dgrad) keeps the family together
-                self.rows.append((_name + tag, fl, by_ if not fl else 0, e0, e1, shape))
+                self.rows.append((_name + tag, fl, by_, e0, e1, shape))
             self.saved[name] = capi.call.__dict__.get(name)
             setattr(capi.call, name, wrapped)
         return self
@@ -154,8 +156,21 @@ class Recorder:
             if detail and shape:
                 name = name + " " + shape
             d = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0, "bytes": 0})
-            d["ms"] += e0.elapsed_time(e1); d["launches"] += 1; d["flops"] += fl; d["bytes"] += by
+            d["ms"] += e0.elapsed_time(e1); d["launches"] += 1; d["flops"] += fl; d["bytes"] += by if not fl else 0
         return agg
+
+
+def _conv_bytes(shape, es):
+    """algorithmic bytes of one conv GEMM launch from its shape string 'Cin->Cout kHxW sS dD NxOHxOW': input + output activations + weights, each
+    moved once (the dgrad of the same conv moves the same tensors the other way)"""
+    try:
+        io, k, s_, _, dims = shape.split(" ")[:5]
+        cin = int(io.split("->")[0]); cout = sum(int(v) for v in io.split("->")[1].split("+"))
+        kh, kw = (int(v) for v in k[1:].split("x")); st = int(s_[1:])
+        n, oh, ow = (int(v) for v in dims.split("x"))
+        return es * (n * oh * st * ow * st * cin + n * oh * ow * cout + cin * cout * kh * kw)
+    except Exception:
+        return 0
 
 
 def _pmc_traffic(symbols, config):
@@ -226,6 +241,18 @@ def measure_step(trainer, x, m, dtype, config=None):
     roofline = {"kernel": "pn2_conv_gemm + pn2_conv_gemm_multi (fwd+dgrad incl. the BatchNorm-backward statistics epilogues; symbols conv_dma_gemm[_tab]<*>, conv_gather_gemm[_tab]<*>)", "bound": "mfma", "achieved": round(ach, 2),
                 "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": None, "launches": nl,
                 "avg_launch_us": round(1e3 * ms / nl, 2), "algorithmic_gflop_per_launch": round(fl / nl / 1e9, 3)}
+    # the same family against the roofline of EACH launch: a launch cannot finish before max(flops / MFMA peak, algorithmic bytes / HBM peak) - the
+    # 1x1 convs of the stem / layer1 / layer2 (247 808 .. 991 232 rows, <= 256 channels: 30-80 flop per byte against a machine balance of 312) are
+    # bound by HBM, not by the matrix cores, so the MFMA fraction alone understates how close those launches are to what the chip allows
+    t_floor = t_mfma = t_hbm = 0.0
+    n_hbm = 0
+    for name, fl_, by_, _e0, _e1, _shape in rec.rows:
+        if name.startswith("pn2_conv_gemm") and fl_:
+            a_, b_ = fl_ / (peak_tf * 1e12), by_ / 8e12
+            t_floor += max(a_, b_); t_mfma += a_; t_hbm += b_; n_hbm += b_ > a_
+    roofline["per_launch_roofline"] = {"frac": round(t_floor / (ms * 1e-3), 4), "floor_ms": round(t_floor * 1e3, 3), "mfma_floor_ms": round(t_mfma * 1e3, 3),
+                                       "hbm_floor_ms": round(t_hbm * 1e3, 3), "hbm_bound_launches": n_hbm, "measured_ms": round(ms, 3),
+                                       "note": "sum over launches of max(flops/2.5 PFLOP/s, (in+out+weights bytes)/8 TB/s) / measured time"}
     traffic = _pmc_traffic(("conv_dma_gemm", "conv_gather_gemm", "conv_dma_gemm_tab", "conv_gather_gemm_tab"), config or {})
     if traffic is not None:
         roofline["traffic"] = traffic["bytes_per_launch"]

@@ -68,7 +68,8 @@ class Trainer:
             o += _r4(n)
         self.hot = hot
         # gradient buckets in arena order (backward completes them from the tail)
-        self.buckets = GradBuckets(self.gflat, [(id(p), self.off[id(p)][0], _r4(self.off[id(p)][1])) for p in hot], bucket_bytes, process_group)
+        self.buckets = GradBuckets(self.gflat, [(id(p), self.off[id(p)][0], _r4(self.off[id(p)][1])) for p in hot], bucket_bytes, process_group,
+                                   wire_dtype=torch.bfloat16 if os.environ.get("PN2_DP_WIRE", "fp32") == "bf16" else None)
         self._seg = None                # capture of a data-parallel step in progress (see _capture_segments)
         self._side = None               # side HIP stream of the overlapped wgrad segments (see _backward)
         self._expected = None           # id(p) -> gradient contributions per step, learned from the first backward pass (see _backward)

@@ -56,7 +56,27 @@ def _worker(rank, world, port, q):
             seen5.append(any(5 in bk.buckets[b][2] for b in bk.order))
     bk.finish()
     ok_multi = seen5 == [False, True] and torch.allclose(gflat, sum(allg), atol=1e-6)
-    q.put((rank, order, ok_sum, ok_mean, ok_rest and ok_multi))
+    # fourth step: the record / replay flow of a captured step (Trainer._capture_segments): launches are noted while recording, issued by launch_async
+    gflat.copy_(local)
+    bk.reset()
+    bk.record = []
+    for i in reversed(range(len(sizes))):
+        bk.launch_ready(set(range(i, len(sizes))))
+    bk.finish()
+    recorded, bk.record = list(bk.record), None
+    ok_rec = recorded == order and torch.equal(gflat, local)            # nothing was sent while recording
+    bk.reset()
+    for b in recorded:
+        bk.launch_async([b])
+    bk.wait()
+    ok_rec = ok_rec and torch.allclose(gflat, sum(allg), atol=1e-6)
+    # fifth step: bf16 on the wire (PN2_DP_WIRE=bf16): half the bytes, a bf16 sum widened back into the fp32 arena
+    g16 = local.clone()
+    bw = GradBuckets(g16, spans, bucket_bytes=4 * 4000, wire_dtype=torch.bfloat16)
+    bw.reduce_all()
+    ref16 = sum(a.bfloat16().float() for a in allg)
+    ok_wire = float((g16 - ref16).abs().max()) <= 2 ** -7 * float(ref16.abs().max()) and g16.dtype == torch.float32
+    q.put((rank, order, ok_sum, ok_mean, ok_rest and ok_multi and ok_rec and ok_wire))
     dist.destroy_process_group()
 
 
