@@ -26,6 +26,7 @@ extern "C" {
 #define PN2_CONV_SPLITK(n) ((n) << 16)   /* bf16 LDS-DMA kernels only (tuning code kernel 2 / 3): n = 2..15 workgroups share the K loop of a tile and
                                             write fp32 partial tiles to `psum` = workspace [n][M][Cout]; finish with pn2_conv_splitk_reduce.  For convs with
                                             few output rows and a long contraction (5x5 on 11x11 maps).  Excludes STATS / BIAS / ACCUM (the reduce does those). */
+#define PN2_CONV_ROWGATE 8 /* set by pn2_conv_gemm_gated: accumulator rows are scaled by 1 - sigmoid(gate[m]) before statistics / store */
 #define PN2_CONV_BIAS 4    /* `psum` is a [Cout] fp32 bias (physical columns) added in the epilogue; excludes PN2_CONV_STATS */
 
 /* ---------------------------------------------------------------------------------------------- conv
@@ -81,6 +82,11 @@ int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* p
 #define PN2_BNB_MASK_Y 4     /* ReLU mask from the stored activation y > 0 (BN + residual + ReLU) */
 #define PN2_BNB_STORE_MASKED 8   /* store dz (the masked gradient) instead of the plain one: it IS the gradient of the residual branch, so the caller
                                     can alias that buffer and pn2_bn_bwd_apply neither re-reads y nor writes dres */
+/* V1 reverse attention fused into the 1x1 conv behind it (PraNet_Res2Net.py:153-155,166-168,177-179:  x = -1*sigmoid(crop)+1 ; x = x.expand(-1, C, -1, -1).mul(x_l) ;
+ * x = ra*_conv1(x)).  The gate is one number per pixel and ra*_conv1 is 1x1, so conv(gate * x_l) = gate * conv(x_l): out[m][:] = (1 - sigmoid(gate[m])) * conv(in)[m][:],
+ * applied to the accumulator rows in the GEMM epilogue; PN2_CONV_STATS statistics are those of the gated result.  The gated copy of x_l (512..2048 channels)
+ * is never materialised.  Not with PN2_CONV_BIAS / split-K.  Backward: pn2_ra_gate_post_bwd on (out, d out), then plain dgrad / wgrad.                         */
+int pn2_conv_gemm_gated(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, const float* gate, void* stream);
 typedef struct pn2_bnb_target {
     void* out; int ld_out;          /* target b only: second destination (same dtype / column range as the GEMM's out) */
     int mode;                       /* PN2_BNB_* ; 0 = no statistics */
@@ -234,6 +240,10 @@ int pn2_dsra_fuse_bwd(const float* fg, const float* crop_fg, const float* crop_b
 int pn2_ra_gate_fwd(int dt, const void* x, int ld_x, const float* crop, void* out, int ld_out, int M, int C, void* stream);
 int pn2_ra_gate_bwd(int dt, const void* x, int ld_x, const float* crop, const void* dout, int ld_dout, void* dx, int ld_dx, int dx_accum,
                     float* dcrop, int M, int C, void* stream);
+/* backward of the gate applied BEHIND the conv (pn2_conv_gemm_gated): raw = gate * u is the stored (gated) conv output, dz its gradient;
+ * dzg = (1 - s) * dz  (gradient of the un-gated GEMM result, feeds dgrad and wgrad),  dcrop[m] = -s * sum_c raw[m][c] * dz[m][c],  s = sigmoid(crop[m]). */
+int pn2_ra_gate_post_bwd(int dt, const void* raw, int ld_raw, const float* crop, const void* dz, int ld_dz, void* dzg, int ld_dzg, float* dcrop,
+                         int M, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- structure loss
  * MyTrain_med.py:19-38 applied to the P (fg,bg) pairs of :78-82 in one pass.  preds = P fg maps then P bg maps,

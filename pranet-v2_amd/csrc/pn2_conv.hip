@@ -216,6 +216,22 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
 #ifndef PN2_EP_PREFETCH_EARLY
     if constexpr (EP) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);      // in flight while the C tile is staged
 #endif
+    if constexpr (EP) {          // (only in the epilogue-statistics instantiations: in the plain kernels the extra live range costs a wave of occupancy)
+        if (d.flags & PN2_CONV_ROWGATE) {
+            // V1 reverse attention in front of a 1x1 conv (PraNet_Res2Net.py:153-155): conv((1 - sigmoid(crop)) * x) = (1 - sigmoid(crop)) * conv(x),
+            // a per-pixel scale of the accumulator rows - before the statistics and the store, so the gated copy of x is never written
+            const float* __restrict__ gate = ep.a.par;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * WTM + i * 16 + g * 4 + r;
+                    const float gg = m < M ? 1.f - 1.f / (1.f + __expf(-gate[m])) : 0.f;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j][r] *= gg;
+                }
+        }
+    }
     if (d.flags & PN2_CONV_STATS) {
         const int rows_w = min(max(M - m0 - wm * WTM, 0), WTM);        // valid rows of this wave's tile (rows are ascending)
 #pragma unroll
@@ -1659,7 +1675,10 @@ static int conv_gemm_impl(int dtype, const void* in, const void* wp, void* out, 
     if ((d->flags & PN2_CONV_STATS) && (!psum || !psq)) return -1;
     if ((d->flags & PN2_CONV_BIAS) && (!psum || (d->flags & PN2_CONV_STATS))) return -1;
     if (((d->flags >> 16) & 15) > 1 && (dtype != PN2_BF16 || !psum || (d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS | PN2_CONV_ACCUM)) || ((d->flags >> 8) & 3) < 2)) return -2;
-    const bool use_ep = (ep.a.mode | ep.b.mode) != 0 || ep.b.out != nullptr;
+    const bool gated = d->flags & PN2_CONV_ROWGATE;
+    const int vec_ = dtype == PN2_F32 ? 4 : 8;
+    if (gated && (!ep.a.par || (ep.a.mode | ep.b.mode) != 0 || ep.b.out || (d->flags & PN2_CONV_BIAS) || ((d->flags >> 16) & 15) > 1 || d->Cout % vec_ || d->ld_out % vec_)) return -2;
+    const bool use_ep = (ep.a.mode | ep.b.mode) != 0 || ep.b.out != nullptr || gated;      // the gate lives in the epilogue-statistics instantiations
     if (dtype == PN2_BF16) return use_ep ? gemm_dispatch<bf16_t, true>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream) : gemm_dispatch<bf16_t, false>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream);
     if (dtype == PN2_F32) return use_ep ? gemm_dispatch<float, true>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream) : gemm_dispatch<float, false>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream);
     return -3;
@@ -1697,6 +1716,16 @@ int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* p
     pn2_conv_ep ep;
     memset(&ep, 0, sizeof(ep));
     return conv_gemm_impl(dtype, in, wp, out, psum, psq, d, ep, stream);
+}
+
+int pn2_conv_gemm_gated(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, const float* gate, void* stream) {
+    if (!d || !gate) return -1;
+    pn2_conv_desc dg = *d;
+    dg.flags |= PN2_CONV_ROWGATE;
+    pn2_conv_ep ep;
+    memset(&ep, 0, sizeof(ep));
+    ep.a.par = gate;                    // no BatchNorm-backward target (mode 0): the field carries the gate logits
+    return conv_gemm_impl(dtype, in, wp, out, psum, psq, &dg, ep, stream);
 }
 
 int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const pn2_conv_desc* d, const pn2_conv_ep* ep, void* stream) {

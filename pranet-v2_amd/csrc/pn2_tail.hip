@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void ra_gate_fwd_k(const T* __restrict__ x, in
     }
 }
 
-template <typename T>
+// POST: the gate was applied BEHIND the 1x1 conv (pn2_conv_gemm_gated): x is the gated conv output raw = gte * u and dout its gradient dz, so
+// dx = gte * dz is the gradient of the un-gated GEMM result u and dcrop = -s * gte * sum(dz * u) = -s * sum(dz * raw): no division by the gate
+template <typename T, bool POST>
 __global__ __launch_bounds__(256) void ra_gate_bwd_k(const T* __restrict__ x, int ld_x, const float* __restrict__ crop, const T* __restrict__ dout, int ld_do,
                                                      T* __restrict__ dx, int ld_dx, int dx_accum, float* __restrict__ dcrop, int M, int C) {
     // one wave per pixel row: lanes sweep channel vectors, wave-reduce the dot product for dcrop
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void ra_gate_bwd_k(const T* __restrict__ x, in
             *reinterpret_cast<uint4*>(dx + (size_t)m * ld_dx + c) = TT<T>::pack(o);
         }
         dot = wave_sum(dot);
-        if (lane == 0) dcrop[m] = -s * gte * dot;
+        if (lane == 0) dcrop[m] = POST ? -s * dot : -s * gte * dot;
     }
 }
 
@@ -829,8 +831,19 @@ int pn2_ra_gate_bwd(int dt, const void* x, int ld_x, const float* crop, const vo
     if (C % 8 || ld_x % 8 || ld_dout % 8 || ld_dx % 8) return -2;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (M + 3) / 4 > 8192 ? 8192 : (M + 3) / 4;
-    if (dt == PN2_BF16) hipLaunchKernelGGL(ra_gate_bwd_k<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ld_x, crop, (const bf16_t*)dout, ld_dout, (bf16_t*)dx, ld_dx, dx_accum, dcrop, M, C);
-    else if (dt == PN2_F32) hipLaunchKernelGGL(ra_gate_bwd_k<float>, dim3(grid), dim3(256), 0, st, (const float*)x, ld_x, crop, (const float*)dout, ld_dout, (float*)dx, ld_dx, dx_accum, dcrop, M, C);
+    if (dt == PN2_BF16) hipLaunchKernelGGL((ra_gate_bwd_k<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ld_x, crop, (const bf16_t*)dout, ld_dout, (bf16_t*)dx, ld_dx, dx_accum, dcrop, M, C);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((ra_gate_bwd_k<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, ld_x, crop, (const float*)dout, ld_dout, (float*)dx, ld_dx, dx_accum, dcrop, M, C);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+int pn2_ra_gate_post_bwd(int dt, const void* raw, int ld_raw, const float* crop, const void* dz, int ld_dz, void* dzg, int ld_dzg, float* dcrop, int M, int C, void* stream) {
+    if (!raw || !crop || !dz || !dzg || !dcrop) return -1;
+    if (C % 8 || ld_raw % 8 || ld_dz % 8 || ld_dzg % 8) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (M + 3) / 4 > 8192 ? 8192 : (M + 3) / 4;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((ra_gate_bwd_k<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)raw, ld_raw, crop, (const bf16_t*)dz, ld_dz, (bf16_t*)dzg, ld_dzg, 0, dcrop, M, C);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((ra_gate_bwd_k<float, true>), dim3(grid), dim3(256), 0, st, (const float*)raw, ld_raw, crop, (const float*)dz, ld_dz, (float*)dzg, ld_dzg, 0, dcrop, M, C);
     else return -3;
     PN2_CHECK_LAUNCH();
     return 0;

@@ -77,14 +77,17 @@ class PraNet(nn.Module):
 
 def _ra_heads(m, eng, x2, x3, x4):
     """RFBs, partial decoder and the three reverse-attention branches shared by PraNet (:141-186) and PVT_PraNet (:229-273):
-    x = (1 - sigmoid(crop)).expand(C) * x_l  ->  conv stack  ->  + crop  ->  up-sample."""
+    x = (1 - sigmoid(crop)).expand(C) * x_l  ->  conv stack  ->  + crop  ->  up-sample.  The gate sits in front of a 1x1 conv, so it is applied to
+    that GEMM's accumulator rows (conv(g * x) = g * conv(x) for a per-pixel g): the gated copy of x_l is never written."""
     x2_rfb = m.rfb2_1._build(eng, x2)
     x3_rfb = m.rfb3_1._build(eng, x3)
     x4_rfb = m.rfb4_1._build(eng, x4)
     ra5 = m.agg1._build(eng, x4_rfb, x3_rfb, x2_rfb)[0]
     l5 = eng.bilinear(ra5, 8)
     crop = eng.bilinear(ra5, 0.25)
-    t = m.ra4_conv1._build(eng, eng.ra_gate(x4, crop))
+    fuse = os.environ.get("PN2_RA_GATE_FUSED", "1") == "1"           # 0: the gate as its own pass over x_l (pn2_ra_gate_fwd / _bwd)
+    gated = (lambda conv, xl, c: conv._build(eng, xl, gate=c)) if fuse else (lambda conv, xl, c: conv._build(eng, eng.ra_gate(xl, c)))
+    t = gated(m.ra4_conv1, x4, crop)
     t = m.ra4_conv2._build(eng, t, relu=True)
     t = m.ra4_conv3._build(eng, t, relu=True)
     t = m.ra4_conv4._build(eng, t, relu=True)
@@ -93,7 +96,7 @@ def _ra_heads(m, eng, x2, x3, x4):
     lat = {}
     for s, xs, u in ((3, x3, 16), (2, x2, 8)):
         crop = eng.bilinear(x, 2)
-        t = getattr(m, f"ra{s}_conv1")._build(eng, eng.ra_gate(xs, crop))
+        t = gated(getattr(m, f"ra{s}_conv1"), xs, crop)
         t = getattr(m, f"ra{s}_conv2")._build(eng, t, relu=True)
         t = getattr(m, f"ra{s}_conv3")._build(eng, t, relu=True)
         x = eng.add(getattr(m, f"ra{s}_conv4")._build(eng, t, head=True), crop)

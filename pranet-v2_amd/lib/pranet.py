@@ -36,12 +36,13 @@ class BasicConv2d(nn.Module):
         self.bn = nn.BatchNorm2d(out_planes)
         self.relu = nn.ReLU(inplace=True)
 
-    def _build(self, eng, x, relu=False, residual=None, out=None, head=False, x_last=False):
-        """x_last: this conv is x's first consumer in forward order, so its data gradient completes x's gradient (engine.conv_bn_act)."""
+    def _build(self, eng, x, relu=False, residual=None, out=None, head=False, x_last=False, gate=None):
+        """x_last: this conv is x's first consumer in forward order, so its data gradient completes x's gradient (engine.conv_bn_act).
+        gate: V1 reverse-attention logits in front of this (1x1) conv, applied in the GEMM epilogue (engine.conv_bn_act)."""
         if head:      # K-channel fp32 head map; raw conv output keeps 8-channel padded rows
             K = self.conv.out_channels
             return eng.conv_bn_act(x, self.conv, self.bn, relu=relu, out_map=(K, rup(K, 8)), y_dt=F32, y_C=K, x_last=x_last)
-        return eng.conv_bn_act(x, self.conv, self.bn, relu=relu, residual=residual, out=out, x_last=x_last)
+        return eng.conv_bn_act(x, self.conv, self.bn, relu=relu, residual=residual, out=out, x_last=x_last, gate=gate)
 
     def forward(self, x):
         return run_module(lambda e, a: [self._build(e, a)], [x], list(self.parameters()), self.training)[0]

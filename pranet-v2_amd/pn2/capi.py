@@ -166,6 +166,8 @@ SIGNATURES = {
     "pn2_dsra_fuse_bwd": [P, P, P, P, P, P, P, I, I, I, P],
     "pn2_ra_gate_fwd": [I, P, I, P, P, I, I, I, P],
     "pn2_ra_gate_bwd": [I, P, I, P, P, I, P, I, I, P, I, I, P],
+    "pn2_ra_gate_post_bwd": [I, P, I, P, P, I, P, I, P, I, I, P],
+    "pn2_conv_gemm_gated": [I, P, P, P, P, P, P, P, P],
     "pn2_loss_weights": [P, P, I, I, I, I, P],
     "pn2_loss_blocks": [I],
     "pn2_structure_loss_fwd": [P, LL, I, P, P, P, P, P, P, I, I, P],

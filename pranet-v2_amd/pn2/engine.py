@@ -838,7 +838,7 @@ class Engine:
 
     # ------------------------------------------------------------------ conv (+BN +ReLU +residual)
     def conv_bn_act(self, x, conv, bn=None, relu=False, residual=None, out=None, out_map=None, y_dt=None, y_C=None, bias=None, sum_with=None,
-                    raw_out=None, par_out=None, x_last=False):
+                    raw_out=None, par_out=None, x_last=False, gate=None):
         """y = act(BN(conv(x)) + residual)   — BasicConv2d / Bottle2neck pieces.
 
         conv: nn.Conv2d (bias-free unless `bias` given), bn: nn.BatchNorm2d or None.
@@ -849,6 +849,9 @@ class Engine:
                   sp + spx[i+1]) is written by the same pass and keeps its gradient in sum_with's gradient storage.
         raw_out / par_out: where the raw conv output ([N,OH,OW,Cout_p] view) and the BatchNorm's per-channel rows (scale, shift, mean, invstd:
                   a [4][Cout_p] view) go - channel slices of buffers shared by the convs that write one concat buffer (Engine.concat_bnb).
+        gate:     a 1-channel fp32 Act of x's geometry in front of a 1x1 conv: the conv sees (1 - sigmoid(gate)) * x (V1 reverse attention,
+                  PraNet_Res2Net.py:153-155).  The per-pixel factor is applied to the GEMM's accumulator rows (pn2_conv_gemm_gated) - the gated copy
+                  of x is never written; backward: one pass over (raw, dz) of the conv's OUTPUT width, then plain dgrad / wgrad.
         x_last:   the caller guarantees that this conv's data gradient is the LAST contribution to x's gradient (x's first consumer in forward
                   order).  If x is the output of a train-mode BatchNorm, the dgrad GEMM then takes that BatchNorm's backward statistics in its
                   epilogue (pn2_conv_gemm_ep) and x's producer skips its pn2_bn_bwd_reduce pass.
@@ -909,7 +912,11 @@ class Engine:
         shape = f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}"
         capi.WORK.update(flops=flops, tag=":fwd", shape=shape)
         ksplit = self._ksplit(M, KH * KW * x.Cp, Cout_p)
-        if ksplit > 1:
+        if gate is not None:
+            assert (KH, KW, sh) == (1, 1, 1) and gate.dt == F32 and gate.C == 1 and gate.M == M and bias is None, "the fused gate sits in front of a bias-free 1x1 conv"
+            ksplit = 1
+            call.pn2_conv_gemm_gated(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), gate.ptr, st)
+        elif ksplit > 1:
             # few output rows, long contraction (the 5x5 convs of the ra4 branch on 11x11 maps): the K loop of every tile is shared by ksplit
             # workgroups that leave fp32 partial tiles; the reduce sums them and takes the BatchNorm statistics / adds the bias
             ws = self.fbuf(ksplit, M, Cout_p)
@@ -1064,6 +1071,15 @@ class Engine:
                 call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
                                       _p(raw), raw_ld, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
                                       _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), r6, st)
+            if gate is not None:
+                # dz is the gradient of the GATED GEMM result: dzg = (1 - s) * dz feeds dgrad / wgrad, d gate[m] = -s * sum_c raw[m][c] * dz[m][c]
+                gc_, cacc = gate.grad_sink()
+                dc = self.fbuf(M) if cacc else gc_
+                dzg = draw if draw is not dy else self.alloc((N, OH, OW, Cout_p), self.tdt)
+                call.pn2_ra_gate_post_bwd(self.dt, _p(raw), raw_ld, gate.ptr, _p(draw), Cout_p, _p(dzg), Cout_p, _p(dc), M, Cout_p, st)
+                if cacc:
+                    call.pn2_copy(F32, _p(dc), 1, F32, _p(gc_), 1, M, 1, 1, st)
+                draw = dzg
             if train_bn:
                 bias_done = bias is None
             if not bias_done:                                  # biased conv / nn.Linear: db = column sums of dz (~0 under a train-mode BN)

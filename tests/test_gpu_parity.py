@@ -99,6 +99,57 @@ def test_conv_bn_act_fwd_bwd(dtn, cfg):
 
 
 @pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+def test_reverse_attention_gate_in_gemm_epilogue(dtn):
+    """V1 reverse attention (PraNet_Res2Net.py:153-155): ra_conv1((1 - sigmoid(crop)).expand(C) * x_l) with a 1x1 ra_conv1 + train-mode BN.  The fused
+    path scales the GEMM's accumulator rows (pn2_conv_gemm_gated) and never writes the gated copy of x_l; outputs and all four gradients (x_l, crop,
+    conv weight, BN affine) against torch float64 autograd, and against the engine's own materialising path (pn2_ra_gate_fwd / _bwd)."""
+    from pn2 import F32, BF16
+    from pn2.engine import Engine, Act
+    from pn2.graph import _seed_grad
+    dt = F32 if dtn == "fp32" else BF16
+    err, tol = (relmax, 5e-5) if dt == F32 else (rell2, 3e-2)
+    torch.manual_seed(11)
+    N, H, Wd, Cin, Cout = 3, 11, 13, 136, 64
+    conv = nn.Conv2d(Cin, Cout, 1, bias=False).to(dev); bnm = nn.BatchNorm2d(Cout).to(dev)
+    bnm.weight.data.uniform_(0.5, 1.5); bnm.bias.data.normal_(0, 0.3)
+    x = torch.randn(N, Cin, H, Wd, device=dev)
+    crop = 2.0 * torch.randn(N, 1, H, Wd, device=dev)
+    gy = torch.randn(N, Cout, H, Wd, device=dev)
+
+    def run(fused):
+        eng = Engine(dt, True, need_grad=True)
+        a = eng.from_nchw(x, requires_grad=True)
+        c = Act(eng, crop.reshape(N, H, Wd, 1).clone(), 1, 1, 1, F32, requires_grad=True)
+        y = eng.conv_bn_act(a, conv, bnm, gate=c) if fused else eng.conv_bn_act(eng.ra_gate(a, c), conv, bnm)
+        out = eng.to_nchw(y).clone()
+        _seed_grad(y, gy)
+        eng.backward()
+        return out, [a.grad[..., :Cin].float().permute(0, 3, 1, 2).clone(), c.grad.reshape(N, 1, H, Wd).clone()] + \
+            [eng.pgrads.get(p_).clone() for p_ in (conv.weight, bnm.weight, bnm.bias)]
+
+    rm0, rv0 = bnm.running_mean.clone(), bnm.running_var.clone()
+    out, grads = run(True)
+    cast = (lambda t: t.bfloat16().double()) if dt == BF16 else (lambda t: t.double())
+    xc, cc = cast(x).cpu().requires_grad_(True), crop.double().cpu().requires_grad_(True)
+    cr, br = nn.Conv2d(Cin, Cout, 1, bias=False).double(), nn.BatchNorm2d(Cout).double()
+    cr.weight.data.copy_(cast(conv.weight.data).cpu()); br.weight.data.copy_(bnm.weight.data.double().cpu()); br.bias.data.copy_(bnm.bias.data.double().cpu())
+    r = br(cr((1 - torch.sigmoid(cc)).expand(-1, Cin, -1, -1) * xc))
+    r.backward(gy.double().cpu())
+    ref = [xc.grad, cc.grad, cr.weight.grad, br.weight.grad, br.bias.grad]
+    assert err(out, r) < tol
+    for i_, (g_, r_) in enumerate(zip(grads, ref)):
+        if float(r_.abs().max()) > 1e-9:
+            assert err(g_, r_) < tol, (i_, err(g_, r_))
+    assert relmax(bnm.running_var, br.running_var) < (1e-5 if dt == F32 else 2e-2)
+    bnm.running_mean.copy_(rm0); bnm.running_var.copy_(rv0)
+    out0, grads0 = run(False)
+    assert err(out, out0) < (1e-5 if dt == F32 else 2e-2)
+    for g_, g0 in zip(grads, grads0):
+        if float(g0.abs().max()) > 1e-9:
+            assert err(g_, g0) < (2e-5 if dt == F32 else 3e-2)
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", ["chain", "residual", "big_mean"])
 def test_bn_backward_statistics_in_dgrad_epilogue(dtn, case, monkeypatch):
     """conv -> BN -> ReLU -> conv -> BN [-> + residual -> ReLU -> conv]: with x_last=True the second (third) conv's dgrad GEMM takes the
