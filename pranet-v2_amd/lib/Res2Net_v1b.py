@@ -18,6 +18,9 @@ from pn2.graph import run_module
 __all__ = ['Res2Net', 'res2net50_v1b', 'res2net101_v1b', 'res2net50_v1b_26w_4s']
 
 
+ALIAS_CAT_GRAD = os.environ.get("PN2_ALIAS_CAT_GRAD", "1") == "1"
+
+
 class Bottle2neck(nn.Module):
     expansion = 4
 
@@ -77,6 +80,10 @@ class Bottle2neck(nn.Module):
                     s_in = r[1]
             eng.copy_into(spx[self.nums], last)
             eng.concat_bnb(cat, rawcat, pcat, split=self.nums * wp, tail=spx[self.nums])
+            if ALIAS_CAT_GRAD and cat.t.shape == out1.t.shape:
+                # d(cat) and d(out1) share ONE buffer: slice i of d(cat) (the gradient of sp_i) is dead once bns[i]'s backward has formed dz_i, which is
+                # before conv_i's dgrad writes slice i of d(out1); the last slice IS d(spx[3]) - the copy's backward has nothing left to move
+                cat.galias = out1
         if self.downsample is not None:
             pool, dconv, dbn = self.downsample[0], self.downsample[1], self.downsample[2]
             k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]

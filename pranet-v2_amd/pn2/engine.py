@@ -1960,6 +1960,9 @@ class Engine:
                 return
             gd = dst.grad_buf()
             gs, acc = src.grad_sink()
+            if gd.data_ptr() == gs.data_ptr() and gd.stride() == gs.stride() and dst.dt == src.dt:
+                assert not acc, "aliased gradient buffers: the copy must be the only contribution"
+                return              # the two gradients share storage (Bottle2neck: d(cat) lives in d(out1)): nothing to move
             call.pn2_copy(dst.dt, _p(gd), gd.stride(2), src.dt, _p(gs), gs.stride(2), src.M, src.Cp, acc, _stream())
         self.record(bwd)
         return dst
