@@ -582,6 +582,12 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     // wave-uniform LDS row offset of this wave inside a 32-row DMA group
     const int wrow = __builtin_amdgcn_readfirstlane(wid * 8);
 
+// Cache policy of the activation operand's DMA (aux): 0 = default.  Non-temporal (aux = 2) wins 14-24 % on COLD operands (tools/loop_ab.py: 256->104 x
+// 247808 rows 60.4 -> 46.2 us, 512->208 x 61952 39.9 -> 31.5) but loses inside the step (17.87 -> 18.05 ms): there the operand was written by the
+// previous kernel and is still resident in L2 / MALL, which the non-temporal path does not use.  Kept as a build knob (-DPN2_A_AUX=2).
+#ifndef PN2_A_AUX
+#define PN2_A_AUX 0
+#endif
 #define PN2_ISSUE(step_, buf_)                                                                                         \
     do {                                                                                                               \
         char* sb_ = smem + (buf_) * STAGE;                                                                             \
@@ -590,7 +596,7 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
             const bool kok_ = k_ < d.Cin_p;                                                                            \
             _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
                 const char* s_ = (rok[i] && kok_) ? reinterpret_cast<const char*>(in + (size_t)rbase[i] * d.ld_in + k_) : zsrc; \
-                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, 0, 0);         \
+                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, 0, PN2_A_AUX); \
             }                                                                                                          \
         } else {                                                                                                       \
             const int r_ = tap / d.KW, c_ = tap - r_ * d.KW;                                                           \
@@ -598,7 +604,7 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
                 int iy_, ix_;                                                                                          \
                 const bool ok_ = rok[i] && tap < taps && tap_pixel(gg, riy0[i], rix0[i], r_, c_, iy_, ix_);            \
                 const char* s_ = ok_ ? reinterpret_cast<const char*>(in + (size_t)(rbase[i] + iy_ * d.W + ix_) * d.ld_in + ci) : zsrc; \
-                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, 0, 0);         \
+                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, 0, PN2_A_AUX); \
             }                                                                                                          \
             ci += BK;                                                                                                  \
             while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; }                                                            \
