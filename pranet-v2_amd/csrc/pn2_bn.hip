@@ -165,6 +165,17 @@ __global__ __launch_bounds__(256) void affine_act_k(const Ti* __restrict__ x, in
 // ---------------------------------------------------------------------------------------------
 // backward pass 1: partial sums of dz and dz*xhat over row chunks
 // ---------------------------------------------------------------------------------------------
+// V consecutive per-channel fp32 parameters as 16-byte loads (c is a multiple of V; slices start at multiples of 8 channels).  As scalar loads
+// they were 56 of the 72 vector-memory instructions a thread of the BatchNorm-backward pass issued.
+template <int V>
+__device__ __forceinline__ void ldpar(const float* __restrict__ p, float (&v)[V]) {
+#pragma unroll
+    for (int e = 0; e < V; e += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + e);
+        v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+    }
+}
+
 template <typename T, typename Tdy, int W>
 __device__ __forceinline__ void bn_bwd_reduce_body(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
                                                    const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
@@ -183,7 +194,8 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const Tdy* __restrict__ dy, i
         for (int e = 0; e < W; ++e) { a1[e] = 0.f; a2[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; ks[e] = 0.f; kh[e] = 1.f; }
         if (cv < CV) {
 #pragma unroll
-            for (int e = 0; e < W; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; if (msc) { ks[e] = msc[c + e]; kh[e] = msh[c + e]; } }
+            for (int e = 0; e < W; ++e) { if constexpr (W % 4 != 0) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; if (msc) { ks[e] = msc[c + e]; kh[e] = msh[c + e]; } } }
+            if constexpr (W % 4 == 0) { ldpar<W>(mean + c, mu); ldpar<W>(invstd + c, is); if (msc) { ldpar<W>(msc + c, ks); ldpar<W>(msh + c, kh); } }
             for (int m = r0 + rl; m < r1; m += R * 4) {
                 float g[4][W], xv[4][W], yv[4][W];
 #pragma unroll
@@ -363,7 +375,9 @@ __device__ __forceinline__ void affine_rows_body(const T* __restrict__ x, int ld
         const int c = cv * V;
         float sc[V], sh[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = shift ? shift[c + e] : 0.f; }
+        for (int e = 0; e < V; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+        if (scale) ldpar<V>(scale + c, sc);
+        if (shift) ldpar<V>(shift + c, sh);
         for (int m = r0 + rl; m < r1; m += R * RU) {
             uint4 vx[RU], vr[RU];
 #pragma unroll
@@ -418,13 +432,17 @@ __global__ __launch_bounds__(256) void affine_rows_tab(const pn2_affine_job* __r
                         (const T*)j.add, j.ld_add, (T*)j.y2, j.ld_y2, blockIdx.x - bstart[jb]);
 }
 
-template <typename T>
-__device__ __forceinline__ void bn_bwd_apply_rows_body(const T* __restrict__ dy, int ld_dy, const T* __restrict__ y, int ld_y,
+// LEAN: the common form inside a training step - ReLU mask recomputed from the raw conv output (or none), no stored y, no residual gradient: the
+// y / dres staging registers disappear (183 -> ~100 VGPRs, twice the resident waves of a kernel that lives on memory-level parallelism)
+template <typename T, bool LEAN>
+__device__ __forceinline__ void bn_bwd_apply_rows_body(const T* __restrict__ dy, int ld_dy, const T* __restrict__ y_, int ld_y,
                                                        const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
-                                                       T* __restrict__ dres, int ld_dres, int dres_accum, int rows_per_blk, int CVP,
+                                                       T* __restrict__ dres_, int ld_dres, int dres_accum, int rows_per_blk, int CVP,
                                                        const float* __restrict__ msc, const float* __restrict__ msh, int r6, int bid) {
     constexpr int V = TT<T>::VEC;
+    const T* __restrict__ y = LEAN ? nullptr : y_;
+    T* __restrict__ dres = LEAN ? nullptr : dres_;
     const int CV = Cp / V, R = 256 / CVP;
     const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
     const int r0 = bid * rows_per_blk;
@@ -434,12 +452,13 @@ __device__ __forceinline__ void bn_bwd_apply_rows_body(const T* __restrict__ dy,
         // dx = a*dz + b*(x - mu) + d  with  a = g, b = -g*c2*invstd, d = -g*c1   (g = gamma*invstd)
         float ka[V], kb[V], kd[V], kmu[V], ks[V], kh[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            ks[e] = msc ? msc[c + e] : 0.f; kh[e] = msc ? msh[c + e] : 1.f;
-            if (coef) {
-                const float g = coef[c + e], c1 = coef[Cp + c + e], c2 = coef[2 * Cp + c + e];
-                ka[e] = g; kb[e] = -g * c2 * invstd[c + e]; kd[e] = -g * c1; kmu[e] = mean[c + e];
-            } else { ka[e] = 1.f; kb[e] = 0.f; kd[e] = 0.f; kmu[e] = 0.f; }
+        for (int e = 0; e < V; ++e) { ks[e] = 0.f; kh[e] = 1.f; ka[e] = 1.f; kb[e] = 0.f; kd[e] = 0.f; kmu[e] = 0.f; }
+        if (msc) { ldpar<V>(msc + c, ks); ldpar<V>(msh + c, kh); }
+        if (coef) {
+            float c1[V], c2[V], is[V];
+            ldpar<V>(coef + c, ka); ldpar<V>(coef + Cp + c, c1); ldpar<V>(coef + 2 * Cp + c, c2); ldpar<V>(invstd + c, is); ldpar<V>(mean + c, kmu);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { kb[e] = __fmul_rn(__fmul_rn(-ka[e], c2[e]), is[e]); kd[e] = __fmul_rn(-ka[e], c1[e]); }
         }
         for (int m = r0 + rl; m < r1; m += R * RU) {
             uint4 vg[RU], vx[RU], vy[RU], vr[RU];
@@ -466,7 +485,8 @@ __device__ __forceinline__ void bn_bwd_apply_rows_body(const T* __restrict__ dy,
                     for (int e = 0; e < V; ++e) {
                         const bool off = y ? (!(yv[e] > 0.f) || (r6 && yv[e] >= 6.f)) : (msc && !(fmaf(xv[e], ks[e], kh[e]) > 0.f));
                         const float dz = off ? 0.f : g[e];
-                        o[e] = coef ? ka[e] * dz + kb[e] * (xv[e] - kmu[e]) + kd[e] : dz;
+                        // explicit fused ops: every instantiation (lean / general / table-driven) rounds the same way, bit for bit
+                        o[e] = coef ? __fmaf_rn(ka[e], dz, __fmaf_rn(kb[e], xv[e] - kmu[e], kd[e])) : dz;
                         rr[e] = (dres && dres_accum) ? rr[e] + dz : dz;
                     }
                     *reinterpret_cast<uint4*>(dx + (size_t)mm * ld_dx + c) = TT<T>::pack(o);
@@ -477,19 +497,19 @@ __device__ __forceinline__ void bn_bwd_apply_rows_body(const T* __restrict__ dy,
     }
 }
 
-template <typename T>
+template <typename T, bool LEAN>
 __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__ dy, int ld_dy, const T* __restrict__ y, int ld_y,
                                                            const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
                                                            T* __restrict__ dres, int ld_dres, int dres_accum, int rows_per_blk, int CVP,
                                                            const float* __restrict__ msc, const float* __restrict__ msh, int r6) {
-    bn_bwd_apply_rows_body<T>(dy, ld_dy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, rows_per_blk, CVP, msc, msh, r6, blockIdx.x);
+    bn_bwd_apply_rows_body<T, LEAN>(dy, ld_dy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, rows_per_blk, CVP, msc, msh, r6, blockIdx.x);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_rows_tab(const pn2_bnapply_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
     const int jb = find_job(bstart, njobs, blockIdx.x);
     const pn2_bnapply_job j = jobs[jb];
-    bn_bwd_apply_rows_body<T>((const T*)j.dy, j.ld_dy, (const T*)j.y, j.ld_y, (const T*)j.x, j.ld_x, j.M, j.Cp, j.mean, j.invstd, j.coef, (T*)j.dx, j.ld_dx,
+    bn_bwd_apply_rows_body<T, false>((const T*)j.dy, j.ld_dy, (const T*)j.y, j.ld_y, (const T*)j.x, j.ld_x, j.M, j.Cp, j.mean, j.invstd, j.coef, (T*)j.dx, j.ld_dx,
                               (T*)j.dres, j.ld_dres, j.dres_accum, j.rows_per_blk, j.cvp, j.msc, j.msh, j.r6, blockIdx.x - bstart[jb]);
 }
 
@@ -555,7 +575,8 @@ int bwd_apply_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int ld
         if (vec) {
             int cvp, rpb, nblk;
             rows_geometry(M, Cp / V, cvp, rpb, nblk);
-            hipLaunchKernelGGL((bn_bwd_apply_rows_k<T>), dim3(nblk), dim3(256), 0, st, (const T*)dy, ld_dy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, rpb, cvp, msc, msh, r6);
+            if (!y && !dres) hipLaunchKernelGGL((bn_bwd_apply_rows_k<T, true>), dim3(nblk), dim3(256), 0, st, (const T*)dy, ld_dy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, rpb, cvp, msc, msh, r6);
+            else hipLaunchKernelGGL((bn_bwd_apply_rows_k<T, false>), dim3(nblk), dim3(256), 0, st, (const T*)dy, ld_dy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, coef, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, rpb, cvp, msc, msh, r6);
             PN2_CHECK_LAUNCH();
             return 0;
         }

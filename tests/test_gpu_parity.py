@@ -443,7 +443,7 @@ def test_model_forward_backward_vs_reference(tag):
 
 
 @pytest.mark.parametrize("tag", ["96", "352"])
-def test_model_bf16_vs_reference_f64(tag):
+def test_model_bf16_vs_reference_f64(tag, monkeypatch):
     """The BENCHMARKED precision (bf16 storage + bf16 MFMA, fp32 accumulate) end to end against the float64 run of the imported reference.
     These fixtures (random init, train-mode BN over 2 images) amplify rounding noise ~500x from the stem to the logits, so every bf16
     execution sits O(1) relative L2 away from the float64 maps; the yardstick is the imported reference under PyTorch's own bf16 policy
@@ -457,6 +457,9 @@ def test_model_bf16_vs_reference_f64(tag):
     z = np.load(os.path.join(G, f"pranet_v2_{tag}.npz"))
     zb = np.load(os.path.join(G, "pranet_v2_bf16ref.npz"))
     size, n = int(z["size"]), int(z["n"])
+    # heuristic tiles: the tuner's choice depends on what it timed (and on the tests that ran before), the tile size decides how the BatchNorm partial
+    # statistics are grouped, and this fixture amplifies a last-bit difference ~500x - with the tuner on the numbers below move from run to run
+    monkeypatch.setenv("PN2_AUTOTUNE", "0")
     model = _fixture_model(fp32=False)
     x, mask = W.synthetic_batch(n, size, seed=1234)
     xg, mg = x.to(dev), mask.to(dev)
