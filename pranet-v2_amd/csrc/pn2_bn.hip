@@ -176,12 +176,13 @@ __device__ __forceinline__ void ldpar(const float* __restrict__ p, float (&v)[V]
     }
 }
 
-template <typename T, typename Tdy, int W>
-__device__ __forceinline__ void bn_bwd_reduce_body(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
+template <typename T, typename Tdy, int W, bool LEAN = false>       // LEAN: no stored-activation mask (y) - its staging registers disappear
+__device__ __forceinline__ void bn_bwd_reduce_body(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y_, int ld_y,
                                                    const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
                                                    const float* __restrict__ invstd, float* __restrict__ p1, float* __restrict__ p2,
                                                    int rows_per_blk, int CVP, const float* __restrict__ msc, const float* __restrict__ msh, int r6, int bid) {
     extern __shared__ __attribute__((aligned(16))) float shf[];   // [2][R][CVP*W]
+    const T* __restrict__ y = LEAN ? nullptr : y_;
     const int CV = Cp / W;
     const int R = 256 / CVP;
     const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
@@ -250,12 +251,12 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const Tdy* __restrict__ dy, i
     }
 }
 
-template <typename T, typename Tdy, int W>
+template <typename T, typename Tdy, int W, bool LEAN = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
                                                        const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, float* __restrict__ p1, float* __restrict__ p2,
                                                        int rows_per_blk, int CVP, const float* __restrict__ msc, const float* __restrict__ msh, int r6) {
-    bn_bwd_reduce_body<T, Tdy, W>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, rows_per_blk, CVP, msc, msh, r6, blockIdx.x);
+    bn_bwd_reduce_body<T, Tdy, W, LEAN>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, p1, p2, rows_per_blk, CVP, msc, msh, r6, blockIdx.x);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_tab(const pn2_bnreduce_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
@@ -505,11 +506,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
                                                            const float* __restrict__ msc, const float* __restrict__ msh, int r6) {
     bn_bwd_apply_rows_body<T, LEAN>(dy, ld_dy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, rows_per_blk, CVP, msc, msh, r6, blockIdx.x);
 }
-template <typename T>
+template <typename T, bool LEAN>
 __global__ __launch_bounds__(256) void bn_bwd_apply_rows_tab(const pn2_bnapply_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
     const int jb = find_job(bstart, njobs, blockIdx.x);
     const pn2_bnapply_job j = jobs[jb];
-    bn_bwd_apply_rows_body<T, false>((const T*)j.dy, j.ld_dy, (const T*)j.y, j.ld_y, (const T*)j.x, j.ld_x, j.M, j.Cp, j.mean, j.invstd, j.coef, (T*)j.dx, j.ld_dx,
+    bn_bwd_apply_rows_body<T, LEAN>((const T*)j.dy, j.ld_dy, (const T*)j.y, j.ld_y, (const T*)j.x, j.ld_x, j.M, j.Cp, j.mean, j.invstd, j.coef, (T*)j.dx, j.ld_dx,
                               (T*)j.dres, j.ld_dres, j.dres_accum, j.rows_per_blk, j.cvp, j.msc, j.msh, j.r6, blockIdx.x - bstart[jb]);
 }
 
@@ -556,7 +557,8 @@ int bwd_reduce_dispatch(const void* dy, int ld_dy, int Cdy, const void* y, int l
     const int rows = (M + nblk - 1) / nblk;
     if (vec) {
         int cvp = pow2ceil(Cp / V); if (cvp > 256) cvp = 256;
-        hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, V>), dim3(nblk), dim3(256), 2 * 256 * V * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp, msc, msh, r6);
+        if (!y) hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, V, true>), dim3(nblk), dim3(256), 2 * 256 * V * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp, msc, msh, r6);
+        else hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, V>), dim3(nblk), dim3(256), 2 * 256 * V * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp, msc, msh, r6);
     } else {
         int cvp = pow2ceil(Cp); if (cvp > 256) cvp = 256;
         hipLaunchKernelGGL((bn_bwd_reduce_k<T, Tdy, 1>), dim3(nblk), dim3(256), 2 * 256 * 4, st, (const Tdy*)dy, ld_dy, Cdy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, p1, p2, rows, cvp, msc, msh, r6);
@@ -761,8 +763,13 @@ int pn2_bn_bwd_apply_job_blocks(int dt, pn2_bnapply_job* j) {
 }
 int pn2_bn_bwd_apply_multi(int dt, const pn2_bnapply_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
     if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
-    if (dt == PN2_BF16) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<bf16_t>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
-    else if (dt == PN2_F32) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<float>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    const bool lean = dt & PN2_MULTI_LEAN;
+    dt &= ~PN2_MULTI_LEAN;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16 && lean) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<bf16_t, true>), dim3(total_blocks), dim3(256), 0, st, jobs_dev, block_start_dev, njobs);
+    else if (dt == PN2_BF16) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<bf16_t, false>), dim3(total_blocks), dim3(256), 0, st, jobs_dev, block_start_dev, njobs);
+    else if (dt == PN2_F32 && lean) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<float, true>), dim3(total_blocks), dim3(256), 0, st, jobs_dev, block_start_dev, njobs);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<float, false>), dim3(total_blocks), dim3(256), 0, st, jobs_dev, block_start_dev, njobs);
     else return -3;
     PN2_CHECK_LAUNCH();
     return 0;

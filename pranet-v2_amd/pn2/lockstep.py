@@ -102,7 +102,8 @@ def _bnapply_job(a):
     j.mean, j.invstd, j.coef, j.dx, j.ld_dx, j.dres, j.ld_dres, j.dres_accum = _v(mean), _v(invstd), _v(coef), _v(dx), ld_dx, _v(dres), ld_dres, dres_accum
     j.msc, j.msh, j.r6 = _v(msc), _v(msh), r6
     nb = call.pn2_bn_bwd_apply_job_blocks(dt, C.byref(j))
-    return (("bnapply", dt), j, nb) if nb >= 1 else None
+    lean = not j.y and not j.dres           # jobs without a stored-activation mask / residual gradient share the register-lean launch (PN2_MULTI_LEAN)
+    return (("bnapply", dt | (0x100 if lean else 0)), j, nb) if nb >= 1 else None
 
 
 def _bnreduce_job(a):
