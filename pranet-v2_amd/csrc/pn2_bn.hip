@@ -39,7 +39,18 @@ __device__ __forceinline__ void reduce_partials(const float* p1, const float* p2
             s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
             s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
         }
-        for (; r < nblk; r += RL) { s1 += (double)p1[(size_t)r * Cp + c]; s2 += (double)p2[(size_t)r * Cp + c]; }
+        if (r < nblk) {         // <= 3 rows left: one more batch of loads (absent rows add an exact +0.0), summed in row order
+            float a[3], b[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const bool ok = r + u * RL < nblk;
+                const size_t rr = ok ? (size_t)(r + u * RL) : (size_t)r;
+                a[u] = p1[rr * Cp + c]; b[u] = p2[rr * Cp + c];
+                if (!ok) { a[u] = 0.f; b[u] = 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
+        }
     }
 }
 
@@ -80,11 +91,23 @@ __device__ __forceinline__ void bn_finalize_body(const float* __restrict__ psum,
         const int ldp = d.ldp ? d.ldp : d.Cp, RL = 256 / CPB;
         s1 = 0.0; s2 = 0.0;
         if (c < d.Cp) {
-            k0 = (double)psum[c];
-            for (int r = rl; r < nblk; r += RL) {
-                const int nt = min(d.tile_rows, d.M - r * d.tile_rows);
-                const double dm = (double)psum[(size_t)r * ldp + c] - k0;
-                s1 += nt * dm; s2 += (double)psq[(size_t)r * ldp + c] + nt * dm * dm;
+            const float k0f = psum[c];
+            k0 = (double)k0f;
+            for (int r = rl; r < nblk; r += 4 * RL) {          // the 8 loads of four tiles are in flight together: the walk is latency, not arithmetic
+                float pm[4], pq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = min(r + u * RL, nblk - 1);
+                    pm[u] = psum[(size_t)rr * ldp + c]; pq[u] = psq[(size_t)rr * ldp + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (r + u * RL < nblk) {
+                        const int nt = min(d.tile_rows, d.M - (r + u * RL) * d.tile_rows);
+                        const double dm = (double)pm[u] - k0;
+                        s1 += nt * dm; s2 += (double)pq[u] + nt * dm * dm;
+                    }
+                }
             }
         }
     } else reduce_partials(psum, psq, nblk, d.Cp, d.ldp ? d.ldp : d.Cp, c, rl, 256 / CPB, s1, s2);
