@@ -68,6 +68,18 @@ __device__ __forceinline__ bool tap_pixel(const GatherGeom& g, int iy0, int ix0,
     return ty >= 0 && tx >= 0 && !(ty & msk) && !(tx & msk) && iy < g.H && ix < g.W;
 }
 
+// the same with the tap's dilated offsets (r * dil_h, s * dil_w) carried by the caller (the LDS-DMA kernel steps them instead of dividing the tap index)
+__device__ __forceinline__ bool tap_pixel_off(const GatherGeom& g, int iy0, int ix0, int dr, int dc, int& iy, int& ix) {
+    if (!g.transposed) {
+        iy = iy0 + dr; ix = ix0 + dc;
+        return (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+    }
+    const int ty = iy0 - dr, tx = ix0 - dc;
+    const int msk = g.stride - 1;
+    iy = ty >> g.sshift; ix = tx >> g.sshift;
+    return ty >= 0 && tx >= 0 && !(ty & msk) && !(tx & msk) && iy < g.H && ix < g.W;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Shared epilogue of the two GEMM kernels: accumulators -> (bias) -> LDS-staged 16-byte stores, with
 //   PN2_CONV_STATS : forward BatchNorm batch statistics of the fp32 accumulators as one (mean, M2) pair per tile and channel.
@@ -402,6 +414,8 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
     }
     int ci = kv * VEC, tap = 0;
     if (!PW) { while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; } }
+    int tcol = 0, tdr = 0, tdc = 0;          // tap column and dilated offsets, stepped with the tap (no division per K-step)
+    if (!PW) { const int r0_ = tap / d.KW; tcol = tap - r0_ * d.KW; tdr = r0_ * d.dil_h; tdc = tcol * d.dil_w; }
     const T* bptr = wp + (size_t)(n0 + (tid >> 3)) * d.Kp + kv * VEC;
 
     // Loads are UNCONDITIONAL (out-of-range vectors read a clamped, valid address) and the zero fill is applied when the
@@ -422,16 +436,18 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
                 ra[i] = *reinterpret_cast<const uint4*>(in + (size_t)rbase[i] * d.ld_in + kc_);                        \
             }                                                                                                          \
         } else {                                                                                                       \
-            const int r_ = tap / d.KW, s_ = tap - r_ * d.KW;                                                           \
             _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
                 int iy_, ix_;                                                                                          \
-                const bool ok_ = rok[i] && tap < taps && tap_pixel(gg, riy0[i], rix0[i], r_, s_, iy_, ix_);            \
+                const bool ok_ = rok[i] && tap < taps && tap_pixel_off(gg, riy0[i], rix0[i], tdr, tdc, iy_, ix_);      \
                 const size_t off_ = ok_ ? (size_t)(rbase[i] + iy_ * d.W + ix_) * d.ld_in + ci : 0;                     \
                 if (ok_) amask |= 1u << i;                                                                             \
                 ra[i] = *reinterpret_cast<const uint4*>(in + off_);                                                    \
             }                                                                                                          \
             ci += BK;                                                                                                  \
-            while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; }                                                            \
+            while (ci >= d.Cin_p) {                                                                                    \
+                ci -= d.Cin_p; ++tap; ++tcol; tdc += d.dil_w;                                                          \
+                if (tcol == d.KW) { tcol = 0; tdc = 0; tdr += d.dil_h; }                                               \
+            }                                                                                                          \
         }                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                 \
             rb[i] = *reinterpret_cast<const uint4*>(bptr + (size_t)(32 * i) * d.Kp + (size_t)(step_) * BK);            \
@@ -577,6 +593,9 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     }
     int ci = cg * VEC + kt0 * BK, tap = 0;
     if (!PW) { while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; } }
+    // the tap's column index and dilated offsets are stepped with the tap (one division here instead of one per K-step and lane)
+    int tcol = 0, tdr = 0, tdc = 0;
+    if (!PW) { const int r0_ = tap / d.KW; tcol = tap - r0_ * d.KW; tdr = r0_ * d.dil_h; tdc = tcol * d.dil_w; }
     const T* bptr = wp + (size_t)(n0 + (tid >> 3)) * d.Kp + cg * VEC;
     const char* zsrc = reinterpret_cast<const char*>(pn2_zero16);
     // wave-uniform LDS row offset of this wave inside a 32-row DMA group
@@ -599,15 +618,17 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
                 __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, 0, PN2_A_AUX); \
             }                                                                                                          \
         } else {                                                                                                       \
-            const int r_ = tap / d.KW, c_ = tap - r_ * d.KW;                                                           \
             _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
                 int iy_, ix_;                                                                                          \
-                const bool ok_ = rok[i] && tap < taps && tap_pixel(gg, riy0[i], rix0[i], r_, c_, iy_, ix_);            \
+                const bool ok_ = rok[i] && tap < taps && tap_pixel_off(gg, riy0[i], rix0[i], tdr, tdc, iy_, ix_);      \
                 const char* s_ = ok_ ? reinterpret_cast<const char*>(in + (size_t)(rbase[i] + iy_ * d.W + ix_) * d.ld_in + ci) : zsrc; \
                 __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, 0, PN2_A_AUX); \
             }                                                                                                          \
             ci += BK;                                                                                                  \
-            while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; }                                                            \
+            while (ci >= d.Cin_p) {                                                                                    \
+                ci -= d.Cin_p; ++tap; ++tcol; tdc += d.dil_w;                                                          \
+                if (tcol == d.KW) { tcol = 0; tdc = 0; tdr += d.dil_h; }                                               \
+            }                                                                                                          \
         }                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                 \
             __builtin_amdgcn_global_load_lds((gptr_t)(bptr + (size_t)(32 * i) * d.Kp + (size_t)(step_) * BK),         \
