@@ -593,11 +593,27 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     }
     int ci = cg * VEC + kt0 * BK, tap = 0;
     if (!PW) { while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; } }
-    // the tap's column index and dilated offsets are stepped with the tap (one division here instead of one per K-step and lane)
+    // The activation operand goes through a BUFFER descriptor: a 32-bit byte offset per lane, and a lane whose tap falls into the padding (or
+    // whose row / channel chunk does not exist) gets an offset beyond num_records - the hardware then writes zeros into the LDS slot.  No 64-bit
+    // address arithmetic, no select against a zero page and, above all, no branches: with flat addresses the compiler guarded every
+    // address computation with exec-mask branches (~35 vector + ~40 scalar instructions per row and K-step around 8..32 MFMAs).
+    // The tap's column and its signed, dilated offsets are stepped with the tap; validity is one branch-free expression for the forward
+    // gather (shift 0, mask 0) and the transposed one (offsets negated; stride-divisibility through `tmsk`, source pixel through `tsh`).
+    // Host side: the tensor's extent from `in` stays below 2 GB (conv_gemm_impl falls back to the register-staged kernel otherwise).
+    const unsigned INV = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)in >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)in)), 0, (int)INV, 0x00020000);
+    const int sgn = d.transposed ? -1 : 1;
+    const int sdil_h = sgn * d.dil_h, sdil_w = sgn * d.dil_w;
+    const int tsh = d.transposed ? gg.sshift : 0, tmsk = d.transposed ? d.stride - 1 : 0;
     int tcol = 0, tdr = 0, tdc = 0;
-    if (!PW) { const int r0_ = tap / d.KW; tcol = tap - r0_ * d.KW; tdr = r0_ * d.dil_h; tdc = tcol * d.dil_w; }
+    if (!PW) { const int r0_ = tap / d.KW; tcol = tap - r0_ * d.KW; tdr = r0_ * sdil_h; tdc = tcol * sdil_w; }
+    const int ldb = d.ld_in * 2;                       // row pitch in bytes
+    unsigned rowoff[NA];                               // PW: byte offset of the row; else: pixel index of the image origin
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rowoff[i] = PW ? (unsigned)rbase[i] * (unsigned)ldb : (unsigned)rbase[i];
     const T* bptr = wp + (size_t)(n0 + (tid >> 3)) * d.Kp + cg * VEC;
-    const char* zsrc = reinterpret_cast<const char*>(pn2_zero16);
     // wave-uniform LDS row offset of this wave inside a 32-row DMA group
     const int wrow = __builtin_amdgcn_readfirstlane(wid * 8);
 
@@ -614,20 +630,22 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
             const int k_ = (step_) * BK + cg * VEC;                                                                    \
             const bool kok_ = k_ < d.Cin_p;                                                                            \
             _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
-                const char* s_ = (rok[i] && kok_) ? reinterpret_cast<const char*>(in + (size_t)rbase[i] * d.ld_in + k_) : zsrc; \
-                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, 0, PN2_A_AUX); \
+                const unsigned vo_ = (rok[i] && kok_) ? rowoff[i] + (unsigned)k_ * 2u : INV;                           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, (int)vo_, 0, 0, PN2_A_AUX); \
             }                                                                                                          \
         } else {                                                                                                       \
+            const bool tok_ = tap < taps;                                                                              \
             _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
-                int iy_, ix_;                                                                                          \
-                const bool ok_ = rok[i] && tap < taps && tap_pixel_off(gg, riy0[i], rix0[i], tdr, tdc, iy_, ix_);      \
-                const char* s_ = ok_ ? reinterpret_cast<const char*>(in + (size_t)(rbase[i] + iy_ * d.W + ix_) * d.ld_in + ci) : zsrc; \
-                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, 0, PN2_A_AUX); \
+                const int ty_ = riy0[i] + tdr, tx_ = rix0[i] + tdc;                                                    \
+                const int iy_ = ty_ >> tsh, ix_ = tx_ >> tsh;                                                          \
+                const bool ok_ = rok[i] & tok_ & ((unsigned)iy_ < (unsigned)d.H) & ((unsigned)ix_ < (unsigned)d.W) & (((ty_ | tx_) & tmsk) == 0); \
+                const unsigned vo_ = ok_ ? (rowoff[i] + (unsigned)(iy_ * d.W + ix_)) * (unsigned)ldb + (unsigned)ci * 2u : INV; \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, (int)vo_, 0, 0, PN2_A_AUX); \
             }                                                                                                          \
             ci += BK;                                                                                                  \
             while (ci >= d.Cin_p) {                                                                                    \
-                ci -= d.Cin_p; ++tap; ++tcol; tdc += d.dil_w;                                                          \
-                if (tcol == d.KW) { tcol = 0; tdc = 0; tdr += d.dil_h; }                                               \
+                ci -= d.Cin_p; ++tap; ++tcol; tdc += sdil_w;                                                           \
+                if (tcol == d.KW) { tcol = 0; tdc = 0; tdr += sdil_h; }                                                \
             }                                                                                                          \
         }                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                 \
@@ -1298,6 +1316,10 @@ int launch_dma(const void* in, const void* wp, void* out, float* psum, float* ps
     return 0;
 }
 
+// the LDS-DMA kernel addresses the activation operand with 32-bit byte offsets behind a buffer descriptor (conv_dma_body): its extent must stay below 2 GB
+inline bool dma_extent_ok(const pn2_conv_desc& d) {
+    return ((size_t)d.N * d.H * d.W - 1) * (size_t)d.ld_in * 2 + (size_t)d.Cin_p * 2 < 0x80000000ull;
+}
 inline bool use_dma_kernel() {
     static const bool on = [] { const char* e = getenv("PN2_CONV_DMA"); return !(e && e[0] == '0'); }();
     return on;
@@ -1332,7 +1354,7 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
     pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
     // optional per-shape tuning code in flags bits 8..15 (bf16 only): kernel (1 register-staged, 2 LDS-DMA 3-stage, 3 LDS-DMA 2-stage), BM, BN
     const int tune = sizeof(T) == 2 ? (d.flags >> 8) & 0xff : 0;
-    const int tk_ = tune & 3, tbm = (tune >> 2) & 3, tbn = (tune >> 4) & 3;
+    const int tk_ = dma_extent_ok(d) ? (tune & 3) : 1, tbm = (tune >> 2) & 3, tbn = (tune >> 4) & 3;     // > 2 GB operand: register-staged kernel (64-bit addresses)
     if (tbm) bm = tbm == 1 ? 64 : 128;
     if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
     if constexpr (sizeof(T) == 2) {
@@ -1376,7 +1398,7 @@ template <typename T>
 void gemm_select(const pn2_conv_desc& d, int& kern, int& bm, int& bn) {
     pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
     const int tune = sizeof(T) == 2 ? (d.flags >> 8) & 0xff : 0;
-    const int tk_ = tune & 3, tbm = (tune >> 2) & 3, tbn = (tune >> 4) & 3;
+    const int tk_ = dma_extent_ok(d) ? (tune & 3) : 1, tbm = (tune >> 2) & 3, tbn = (tune >> 4) & 3;     // > 2 GB operand: register-staged kernel (64-bit addresses)
     if (tbm) bm = tbm == 1 ? 64 : 128;
     if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
     kern = 0;
@@ -1773,7 +1795,7 @@ int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d) {
     if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
     if (((d->flags >> 16) & 15) > 1) return -2;
     int kern, bm, bn;
-    if (dtype == PN2_BF16) { gemm_select<bf16_t>(*d, kern, bm, bn); if (kern == 0 && !use_dma_kernel()) return -2; }
+    if (dtype == PN2_BF16) { gemm_select<bf16_t>(*d, kern, bm, bn); if ((kern == 0 && !use_dma_kernel()) || !dma_extent_ok(*d)) return -2; }
     else if (dtype == PN2_F32) gemm_select<float>(*d, kern, bm, bn);
     else return -3;
     return (bm << 8) | bn;
