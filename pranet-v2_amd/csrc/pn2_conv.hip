@@ -992,29 +992,46 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const bf16_t* __restrict__ d
     }
     const int wch = __builtin_amdgcn_readfirstlane(wid * 64);      // this wave's first chunk inside a 256-chunk DMA instruction
 
+    // Both operands go through buffer descriptors (see conv_dma_body): 32-bit byte offsets that advance by a constant per step, zeros from the
+    // hardware for rows past M / padding taps / channel chunks past the tensor - no 64-bit address arithmetic, no zero page, no branches.
+    const unsigned INV = 0x80000000u;
+    auto mkrs = [&](const void* p_) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)p_ >> 32)) << 32) |
+                                                         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)p_)), 0, (int)INV, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_y = mkrs(dy), rs_x = mkrs(x);
+    const unsigned ldyb = (unsigned)d.ld_dy * 2u, ldxb = (unsigned)d.ld_x * 2u;
+    unsigned yoff[NYI], xoff[NXI];                     // byte offsets of this lane's loads at the current step (PW x: too)
+    int ym[NYI], xm[NXI];                              // their pixel rows
+#pragma unroll
+    for (int i = 0; i < NYI; ++i) { ym[i] = s_begin * PX + yrow + i * (256 / CHY); yoff[i] = (unsigned)ym[i] * ldyb + (unsigned)(co0 + gy * 8) * 2u; }
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) { xm[i] = s_begin * PX + xrow + i * (256 / CHX); xoff[i] = (unsigned)xm[i] * ldxb + (unsigned)kk * 2u; }
+    const int tdy = xr * d.dil_h - d.pad_h, tdx = xs * d.dil_w - d.pad_w;      // this lane's tap offset (its k chunk never changes)
+
 #define PN2_WISSUE(step_, buf_)                                                                                        \
     do {                                                                                                               \
         char* sb_ = smem + (buf_) * STAGE;                                                                             \
-        const int mb_ = (step_) * PX;                                                                                  \
         _Pragma("unroll") for (int i = 0; i < NYI; ++i) {                                                              \
-            const int m_ = mb_ + yrow + i * (256 / CHY);                                                               \
-            const char* s_ = (yc_ok && m_ < M) ? reinterpret_cast<const char*>(ysrc + (size_t)m_ * d.ld_dy) : zsrc;    \
-            __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + (i * 256 + wch) * 16), 16, 0, 0);              \
+            const unsigned vo_ = (yc_ok && ym[i] < M) ? yoff[i] : INV;                                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lptr_t)(sb_ + (i * 256 + wch) * 16), 16, (int)vo_, 0, 0, 0); \
+            ym[i] += PX; yoff[i] += PX * ldyb;                                                                         \
         }                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                              \
-            const int m_ = mb_ + xrow + i * (256 / CHX);                                                               \
-            const char* s_ = zsrc;                                                                                     \
+            unsigned vo_ = INV;                                                                                        \
             if (PW) {                                                                                                  \
-                if (xk_ok && m_ < M) s_ = reinterpret_cast<const char*>(x + (size_t)m_ * d.ld_x + kk);                 \
+                if (xk_ok && xm[i] < M) vo_ = xoff[i];                                                                 \
+                xoff[i] += PX * ldxb;                                                                                  \
             } else {                                                                                                   \
-                const int iy_ = poy[i] * d.stride - d.pad_h + xr * d.dil_h, ix_ = pox[i] * d.stride - d.pad_w + xs * d.dil_w; \
-                if (xk_ok && m_ < M && (unsigned)iy_ < (unsigned)d.H && (unsigned)ix_ < (unsigned)d.W)                 \
-                    s_ = reinterpret_cast<const char*>(x + ((size_t)(pn[i] * d.H + iy_) * d.W + ix_) * d.ld_x + xci);  \
+                const int iy_ = poy[i] * d.stride + tdy, ix_ = pox[i] * d.stride + tdx;                                \
+                const bool ok_ = xk_ok & (xm[i] < M) & ((unsigned)iy_ < (unsigned)d.H) & ((unsigned)ix_ < (unsigned)d.W); \
+                vo_ = ok_ ? (unsigned)((pn[i] * d.H + iy_) * d.W + ix_) * ldxb + (unsigned)xci * 2u : INV;             \
                 pox[i] += PX;                                                                                          \
                 while (pox[i] >= d.OW) { pox[i] -= d.OW; ++poy[i]; }                                                   \
                 while (poy[i] >= d.OH) { poy[i] -= d.OH; ++pn[i]; }                                                    \
             }                                                                                                          \
-            __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(sb_ + PX * RBY + (i * 256 + wch) * 16), 16, 0, 0);   \
+            xm[i] += PX;                                                                                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr_t)(sb_ + PX * RBY + (i * 256 + wch) * 16), 16, (int)vo_, 0, 0, 0); \
         }                                                                                                              \
     } while (0)
 
@@ -1494,6 +1511,8 @@ int wgrad_variant(const pn2_wgrad_desc& d) {
         static const bool on = [] { const char* e = getenv("PN2_WGRAD_DMA"); return !(e && e[0] == '0'); }();
         // default: the DMA pipeline pays off for pointwise convs with many pixels; d.tune (1 register-staged, 2 DMA) overrides
         dma = d.tune ? d.tune == 2 : (on && wgrad_pw(d) && d.N * d.OH * d.OW >= 8192);
+        // the DMA kernel addresses both operands with 32-bit byte offsets (buffer descriptors): extents below 2 GB
+        if ((size_t)d.N * d.OH * d.OW * d.ld_dy * 2 >= 0x80000000ull || (size_t)d.N * d.H * d.W * d.ld_x * 2 >= 0x80000000ull) dma = false;
     }
     return (dma ? 6 : 0) + (bmc == 128 ? 2 : (bmc == 64 ? 1 : 0)) * 2 + (wgrad_pw(d) ? 1 : 0);
 }
