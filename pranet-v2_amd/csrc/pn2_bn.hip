@@ -540,9 +540,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_tab(const pn2_bnapply_j
 inline void rows_geometry(int M, int CV, int& cvp, int& rows_per_blk, int& nblk) {
     cvp = 1; while (cvp < CV && cvp < 256) cvp <<= 1;
     const int R = 256 / cvp;
-    // aim at ~512 workgroups (2 per CU): measured on MI355X (tools/bn_micro.py), more and shorter blocks lose 1.5-2x because
-    // every block pays the per-channel parameter prologue; large tensors get up to RU*4 rows per thread
-    static const int target = getenv("PN2_BN_BLOCKS") ? atoi(getenv("PN2_BN_BLOCKS")) : 512;   // experiment knob
+    // aim at ~1024 workgroups (4 per CU).  With scalar parameter loads every block paid a ~60-instruction prologue and 512 was the optimum; with the
+    // 16-byte parameter loads the step time is flat from 768 up (15.59 / 15.57 / 15.51 / 15.51 / 15.49 ms at 384 / 512 / 768 / 1024 / 2048)
+    static const int target = getenv("PN2_BN_BLOCKS") ? atoi(getenv("PN2_BN_BLOCKS")) : 1024;   // experiment knob
     int want = (M + target - 1) / target;
     rows_per_blk = ((want + R - 1) / R) * R;
     if (rows_per_blk < R) rows_per_blk = R;
