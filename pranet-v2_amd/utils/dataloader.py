@@ -1,50 +1,60 @@
-"""Mirror of binary_seg/utils/dataloader.py (get_loader / PolypDataset / test_dataset) with the per-image transform moved to the GPU:
-worker processes only decode files (PIL -> uint8), `pn2.input.DeviceTransform` does Resize -> ToTensor -> Normalize on the device, bit-exact with
-the reference's torchvision-on-PIL pipeline.  Batches come back as GPU tensors (the `.cuda()` calls of MyTrain_med.py:62-63 become no-ops)."""
+"""Host side of the input path: the names MyTrain_med.py / MyTest_med.py import (`get_loader`, `test_dataset`) in front of the device-side transform.
+
+Only the hand-over matters here: files are decoded to uint8 pixels on the host and `pn2.input.DeviceTransform` does Resize -> ToTensor ->
+Normalize on the GPU, bit-exact with torchvision-on-PIL (tests/test_gpu_input.py); batches arrive as GPU tensors, so the `.cuda()` calls of
+MyTrain_med.py:62-63 are no-ops.  File discovery keeps the reference's observable behaviour (dataloader.py:92-150, 165-205): sorted listing of
+.jpg / .png images and .png (test: .tif / .png) masks, training pairs whose two files differ in size are skipped."""
 import os
 
 import numpy as np
 import torch
-import torch.utils.data as data
 from PIL import Image
+from torch.utils.data import DataLoader, Dataset
 
 from pn2.input import DeviceTransform
 
 
-class PolypDataset(data.Dataset):
-    """dataloader.py:92-150: same file discovery, sorting and size filter; __getitem__ returns the decoded uint8 pixels."""
+def _listing(root, suffixes):
+    return sorted(root + name for name in os.listdir(root) if name.endswith(suffixes))
+
+
+def _pixels(path, mode):
+    """decoded file as a uint8 tensor: HxWx3 for mode 'RGB', HxW for 'L'"""
+    with Image.open(path) as im:
+        return torch.from_numpy(np.array(im.convert(mode), dtype=np.uint8))
+
+
+def _same_size(a, b):
+    with Image.open(a) as ia, Image.open(b) as ib:
+        return ia.size == ib.size
+
+
+class PolypDataset(Dataset):
+    """(image uint8 HxWx3, mask uint8 HxW) pairs of a training directory."""
 
     def __init__(self, image_root, gt_root, trainsize):
+        images, masks = _listing(image_root, ('.jpg', '.png')), _listing(gt_root, ('.png',))
+        assert len(images) == len(masks), f"{len(images)} images but {len(masks)} masks"          # (the reference asserts too)
+        pairs = [(i, m) for i, m in zip(images, masks) if _same_size(i, m)]
         self.trainsize = trainsize
-        self.images = sorted(image_root + f for f in os.listdir(image_root) if f.endswith('.jpg') or f.endswith('.png'))
-        self.gts = sorted(gt_root + f for f in os.listdir(gt_root) if f.endswith('.png'))
-        self.filter_files()
-        self.size = len(self.images)
-
-    def __getitem__(self, index):
-        return torch.from_numpy(np.asarray(self.rgb_loader(self.images[index])).copy()), torch.from_numpy(np.asarray(self.binary_loader(self.gts[index])).copy())
-
-    def filter_files(self):
-        assert len(self.images) == len(self.gts)
-        images, gts = [], []
-        for img_path, gt_path in zip(self.images, self.gts):
-            if Image.open(img_path).size == Image.open(gt_path).size:
-                images.append(img_path); gts.append(gt_path)
-        self.images, self.gts = images, gts
-
-    def rgb_loader(self, path):
-        with open(path, 'rb') as f:
-            return Image.open(f).convert('RGB')
-
-    def binary_loader(self, path):
-        with open(path, 'rb') as f:
-            return Image.open(f).convert('L')
+        self.images, self.gts = [p[0] for p in pairs], [p[1] for p in pairs]
+        self.size = len(pairs)
 
     def __len__(self):
         return self.size
 
+    def __getitem__(self, index):
+        return _pixels(self.images[index], 'RGB'), _pixels(self.gts[index], 'L')
+
+
+def _keep_separate(items):
+    # images of one batch differ in size until the device transform has resized them: no stacking on the host
+    return [it[0] for it in items], [it[1] for it in items]
+
 
 class _DeviceBatches:
+    """iterates a host DataLoader and hands every batch through the device transform"""
+
     def __init__(self, loader, transform):
         self.loader, self.transform = loader, transform
 
@@ -52,46 +62,35 @@ class _DeviceBatches:
         return len(self.loader)
 
     def __iter__(self):
-        for images, gts in self.loader:
-            yield self.transform([im.cuda(non_blocking=True) for im in images], [g.cuda(non_blocking=True) for g in gts])
+        for images, masks in self.loader:
+            yield self.transform([t.cuda(non_blocking=True) for t in images], [t.cuda(non_blocking=True) for t in masks])
 
 
 def get_loader(image_root, gt_root, batchsize, trainsize, shuffle=True, num_workers=4, pin_memory=True):
-    """dataloader.py:153-161; iterating yields (images [N][3][S][S], gts [N][1][S][S]) fp32 GPU tensors."""
-    dataset = PolypDataset(image_root, gt_root, trainsize)
-    loader = data.DataLoader(dataset=dataset, batch_size=batchsize, shuffle=shuffle, num_workers=num_workers, pin_memory=pin_memory,
-                             collate_fn=lambda items: ([i for i, _ in items], [g for _, g in items]))
-    return _DeviceBatches(loader, DeviceTransform(trainsize))
+    """Same signature as the reference's; iterating yields (images [N][3][S][S], gts [N][1][S][S]) fp32 GPU tensors."""
+    host = DataLoader(PolypDataset(image_root, gt_root, trainsize), batch_size=batchsize, shuffle=shuffle, num_workers=num_workers,
+                      pin_memory=pin_memory, collate_fn=_keep_separate)
+    return _DeviceBatches(host, DeviceTransform(trainsize))
 
 
 class test_dataset:
-    """dataloader.py:165-205: load_data() -> (image [1][3][S][S] normalised, on the GPU; gt as the PIL 'L' image; name)."""
+    """load_data() -> (image [1][3][S][S] normalised, on the GPU; the mask as a PIL 'L' image; output file name), one image per call."""
 
     def __init__(self, image_root, gt_root, testsize):
         self.testsize = testsize
-        self.images = sorted(image_root + f for f in os.listdir(image_root) if f.endswith('.jpg') or f.endswith('.png'))
-        self.gts = sorted(gt_root + f for f in os.listdir(gt_root) if f.endswith('.tif') or f.endswith('.png'))
+        self.images, self.gts = _listing(image_root, ('.jpg', '.png')), _listing(gt_root, ('.tif', '.png'))
         self.transform = DeviceTransform(testsize)
         self.size = len(self.images)
         self.index = 0
 
-    def load_data(self):
-        image = torch.from_numpy(np.asarray(self.rgb_loader(self.images[self.index])).copy()).cuda()
-        image = self.transform([image])
-        gt = self.binary_loader(self.gts[self.index])
-        name = self.images[self.index].split('/')[-1]
-        if name.endswith('.jpg'):
-            name = name.split('.jpg')[0] + '.png'
-        self.index += 1
-        return image, gt, name
-
-    def rgb_loader(self, path):
-        with open(path, 'rb') as f:
-            return Image.open(f).convert('RGB')
-
-    def binary_loader(self, path):
-        with open(path, 'rb') as f:
-            return Image.open(f).convert('L')
-
     def __len__(self):
         return self.size
+
+    def load_data(self):
+        path = self.images[self.index]
+        image = self.transform([_pixels(path, 'RGB').cuda()])
+        with Image.open(self.gts[self.index]) as im:
+            gt = im.convert('L')
+        stem, ext = os.path.splitext(os.path.basename(path))
+        self.index += 1
+        return image, gt, (stem + '.png' if ext == '.jpg' else stem + ext)
