@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void affine_act_k(const Ti* __restrict__ x, in
     const int CV = C / W;
     const size_t total = (size_t)M * CV;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int m = (int)(idx / CV), c = (int)(idx - (size_t)m * CV) * W;
+        int c; const int m = (int)divmod_idx(idx, CV, c); c *= W;
         float v[W], r[W];
         VL<Ti, W>::load(x + (size_t)m * ld_x + c, v);
         if (res) VL<Ti, W>::load(res + (size_t)m * ld_res + c, r);
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const Tdy* __restrict__ dy
     const int CV = Cp / W;
     const size_t total = (size_t)M * CV;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int m = (int)(idx / CV), c = (int)(idx - (size_t)m * CV) * W;
+        int c; const int m = (int)divmod_idx(idx, CV, c); c *= W;
         float g[W], xv[W], yv[W], o[W], rr[W];
         if (W > 1 || c < Cdy) VL<Tdy, W>::load(dy + (size_t)m * ld_dy + c, g); else g[0] = 0.f;
         if (coef) VL<T, W>::load(x + (size_t)m * ld_x + c, xv);

@@ -71,6 +71,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// flat 64-bit element index -> quotient / remainder by an int divisor, with 32-bit arithmetic whenever the index fits (a 64-bit division is ~100
+// instructions on this part, and pixel decodes chain three or four of them)
+__device__ __forceinline__ size_t divmod_idx(size_t idx, int d, int& rem) {
+    if (idx >> 32) { const size_t q = idx / (size_t)d; rem = (int)(idx - q * (size_t)d); return q; }
+    const unsigned i = (unsigned)idx, q = i / (unsigned)d;
+    rem = (int)(i - q * (unsigned)d);
+    return q;
+}
+
 // job lookup for the table-driven launches: largest j with bstart[j] <= b   (bstart has njobs + 1 entries)
 __device__ __forceinline__ int find_job(const int* __restrict__ bstart, int njobs, int b) {
     int lo = 0, hi = njobs;

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void gate_mul_k(const T* __restrict__ x, const
     const int CV = C / V;
     const size_t total = (size_t)N * HW * CV;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int cv = (int)(idx % CV); const size_t p = idx / CV; const int n = (int)(p / HW);
+        int cv, pp_; const size_t p = divmod_idx(idx, CV, cv); const int n = (int)divmod_idx(p, HW, pp_);
         float v[V], o[V];
         ldv<T>(x + p * C + cv * V, v);
         if (accumulate) ldv<T>(y + p * C + cv * V, o);
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void global_pool_bwd_k(const T* __restrict__ d
                                                          int N, int HW, int C, int accumulate) {
     const size_t total = (size_t)N * HW * C;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int c = (int)(idx % C); const size_t p = idx / C; const int n = (int)(p / HW), pp = (int)(p % HW);
+        int c, pp; const size_t p = divmod_idx(idx, C, c); const int n = (int)divmod_idx(p, HW, pp);
         float v = TT<T>::ld(davg + (size_t)n * C + c) / (float)HW;
         if (arg[(size_t)n * C + c] == pp) v += TT<T>::ld(dmax + (size_t)n * C + c);
         if (accumulate) v += TT<T>::ld(dx + idx);
@@ -536,7 +536,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void chan_stats_bwd_k(const T* __restrict__ dout, const int* __restrict__ arg, T* __restrict__ dx, size_t NP, int C, int accumulate) {
     const size_t total = NP * C;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int c = (int)(idx % C); const size_t p = idx / C;
+        int c; const size_t p = divmod_idx(idx, C, c);
         float v = TT<T>::ld(dout + p * 8) / (float)C;
         if (arg[p] == c) v += TT<T>::ld(dout + p * 8 + 1);
         if (accumulate) v += TT<T>::ld(dx + idx);
@@ -551,8 +551,8 @@ __global__ __launch_bounds__(256) void up2_k(const T* __restrict__ x, T* __restr
     const int CV = C / V, OH = 2 * H, OW = 2 * W;
     const size_t total = (size_t)N * OH * OW * CV;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int cv = (int)(idx % CV); size_t p = idx / CV;
-        const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int n = (int)(p / OH);
+        int cv, ox, oy; size_t p = divmod_idx(idx, CV, cv);
+        p = divmod_idx(p, OW, ox); const int n = (int)divmod_idx(p, OH, oy);
         *reinterpret_cast<uint4*>(y + (((size_t)n * OH + oy) * OW + ox) * C + cv * V) =
             *reinterpret_cast<const uint4*>(x + (((size_t)n * H + (oy >> 1)) * W + (ox >> 1)) * C + cv * V);
     }
@@ -564,8 +564,8 @@ __global__ __launch_bounds__(256) void up2_bwd_k(const T* __restrict__ dy, T* __
     const int CV = C / V, OW = 2 * W;
     const size_t total = (size_t)N * H * W * CV;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int cv = (int)(idx % CV); size_t p = idx / CV;
-        const int ix = (int)(p % W); p /= W; const int iy = (int)(p % H); const int n = (int)(p / H);
+        int cv, ix, iy; size_t p = divmod_idx(idx, CV, cv);
+        p = divmod_idx(p, W, ix); const int n = (int)divmod_idx(p, H, iy);
         float a[V], b[V];
         const T* base = dy + (((size_t)n * 2 * H + 2 * iy) * OW + 2 * ix) * C + cv * V;
         ldv<T>(base, a);
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void gather_sum_k(const T* __restrict__ a, con
                                                     T* __restrict__ y, size_t M, int C) {
     const size_t total = M * C;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int c = (int)(idx % C); const size_t p = idx / C;
+        int c; const size_t p = divmod_idx(idx, C, c);
         const size_t s = p * C + perm[c];
         float v = TT<T>::ld(a + s);
         if (b) v += TT<T>::ld(b + s);

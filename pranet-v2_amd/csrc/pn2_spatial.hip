@@ -28,9 +28,12 @@ template <typename T, int W> struct VL {
     }
 };
 
-inline int grid_for(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g)); }
+// (>= 2^32 elements: the kernels index with 32 bits - an impossible grid makes the launch fail, and PN2_CHECK_LAUNCH report it, instead of wrapping around)
+inline int grid_for(size_t total) { if (total >> 32) return -1; size_t g = (total + 255) / 256; return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g)); }
 
-#define PIX_LOOP(total) for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (total); idx += (size_t)gridDim.x * 256)
+// 32-bit element index (the C entry points refuse tensors of 2^32 or more vectors): the 64-bit `idx % CV`, `p % W`, `p / H` chains of a pixel decode were
+// ~100 instructions each - most of what these streaming kernels executed
+#define PIX_LOOP(total) for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < (total); idx += gridDim.x * 256u)
 
 // ------------------------------------------------------------------------------------------ max pool
 template <typename T, int W>
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_k(const T* __restrict__ x, in
     const int CV = C / W;
     const size_t total = (size_t)N * OH * OW * CV;
     PIX_LOOP(total) {
-        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int cv = (int)(idx % CV); unsigned p = idx / CV;
         const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int n = (int)(p / OH);
         float best[W]; int bi[W];
 #pragma unroll
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k(const T* __restrict__ dy, i
     const int CV = C / W;
     const size_t total = (size_t)N * H * Wd * CV;
     PIX_LOOP(total) {
-        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int cv = (int)(idx % CV); unsigned p = idx / CV;
         const int ix = (int)(p % Wd); p /= Wd; const int iy = (int)(p % H); const int n = (int)(p / H);
         float acc[W];
 #pragma unroll
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_k(const T* __restrict__ x, in
     const int CV = C / W;
     const size_t total = (size_t)N * OH * OW * CV;
     PIX_LOOP(total) {
-        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int cv = (int)(idx % CV); unsigned p = idx / CV;
         const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int n = (int)(p / OH);
         int y0, y1, x0, x1;
         const float dh = avg_div(oy, k, stride, pad, H, inc, y0, y1), dw = avg_div(ox, k, stride, pad, Wd, inc, x0, x1);
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_k(const T* __restrict__ dy, i
     const int CV = C / W;
     const size_t total = (size_t)N * H * Wd * CV;
     PIX_LOOP(total) {
-        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int cv = (int)(idx % CV); unsigned p = idx / CV;
         const int ix = (int)(p % Wd); p /= Wd; const int iy = (int)(p % H); const int n = (int)(p / H);
         float acc[W];
 #pragma unroll
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_k(const T* __restrict__ x, i
     const int CV = C / W;
     const size_t total = (size_t)N * OH * OW * CV;
     PIX_LOOP(total) {
-        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int cv = (int)(idx % CV); unsigned p = idx / CV;
         const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int n = (int)(p / OH);
         int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
         bl_src(oy, rh, ac, H, y0, y1, ly0, ly1); bl_src(ox, rw, ac, Wd, x0, x1, lx0, lx1);
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const T* __restrict__ dy, 
     const int CV = C / W;
     const size_t total = (size_t)N * H * Wd * CV;
     PIX_LOOP(total) {
-        const int cv = (int)(idx % CV); size_t p = idx / CV;
+        const int cv = (int)(idx % CV); unsigned p = idx / CV;
         const int ix = (int)(p % Wd); p /= Wd; const int iy = (int)(p % H); const int n = (int)(p / H);
         int oy0, oy1, ox0, ox1;
         bl_range(iy, rh, ac, OH, oy0, oy1); bl_range(ix, rw, ac, OW, ox0, ox1);
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_k(const float* __restrict__ 
     const size_t total = (size_t)N * HW;
     PIX_LOOP(total) {
         const int n = (int)(idx / HW), p = (int)(idx % HW);
-        To* d = y + idx * ld_y;
+        To* d = y + (size_t)idx * ld_y;
         constexpr int V = TT<To>::VEC;
         if (Cp == V && (ld_y % V) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {      // the usual case (3 channels in an 8 / 4 slot pixel): one 16-byte store
             float f[V];

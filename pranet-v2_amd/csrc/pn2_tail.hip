@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void ra_gate_fwd_k(const T* __restrict__ x, in
     const int CV = C / V;
     const size_t total = (size_t)M * CV;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int m = (int)(idx / CV), c = (int)(idx % CV) * V;
+        int c; const int m = (int)divmod_idx(idx, CV, c); c *= V;
         const float gte = 1.f - sigmoidf_(crop[m]);
         float v[V];
         TT<T>::unpack(*reinterpret_cast<const uint4*>(x + (size_t)m * ld_x + c), v);

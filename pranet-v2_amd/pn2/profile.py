@@ -253,6 +253,15 @@ def measure_step(trainer, x, m, dtype, config=None):
     roofline["per_launch_roofline"] = {"frac": round(t_floor / (ms * 1e-3), 4), "floor_ms": round(t_floor * 1e3, 3), "mfma_floor_ms": round(t_mfma * 1e3, 3),
                                        "hbm_floor_ms": round(t_hbm * 1e3, 3), "hbm_bound_launches": n_hbm, "measured_ms": round(ms, 3),
                                        "note": "sum over launches of max(flops/2.5 PFLOP/s, (in+out+weights bytes)/8 TB/s) / measured time"}
+    # forward and dgrad launches apart: the dgrad launches carry the BatchNorm-backward statistics (extra operand reads, epilogue arithmetic) that
+    # used to be separate pn2_bn_bwd_reduce passes, so the family's combined rate is not comparable with a round in which they did not
+    for tag_ in (":fwd", ":dgrad"):
+        sel = [d_ for n_, d_ in agg.items() if n_.startswith("pn2_conv_gemm") and n_.endswith(tag_)]
+        if sel:
+            fl_, ms_ = sum(d_["flops"] for d_ in sel), sum(d_["ms"] for d_ in sel)
+            roofline["forward" if tag_ == ":fwd" else "dgrad_with_bn_statistics"] = {
+                "achieved": round(fl_ / (ms_ * 1e-3) / 1e12, 2), "frac": round(fl_ / (ms_ * 1e-3) / 1e12 / peak_tf, 4), "ms": round(ms_, 3),
+                "launches": sum(d_["launches"] for d_ in sel)}
     traffic = _pmc_traffic(("conv_dma_gemm", "conv_gather_gemm", "conv_dma_gemm_tab", "conv_gather_gemm_tab"), config or {})
     if traffic is not None:
         roofline["traffic"] = traffic["bytes_per_launch"]
