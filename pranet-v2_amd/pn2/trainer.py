@@ -25,6 +25,8 @@ def _r4(n):
 
 WGRAD_OVERLAP = os.environ.get("PN2_WGRAD_OVERLAP", "0") == "1"      # deferred wgrad tables on a side stream, next to the backward chain (measured: 19.2 -> 20.3 ms, see DESIGN)
 WGRAD_SEG = int(os.environ.get("PN2_WGRAD_SEG", "24"))              # convs per flush segment
+# "thread_local": other threads of the process (RCCL's watchdog polls events while a rank captures) do not invalidate the capture
+CAPTURE_MODE = os.environ.get("PN2_CAPTURE_MODE", "thread_local")
 DP_SEGMENTS = os.environ.get("PN2_DP_SEGMENTS", "1") == "1"          # data-parallel replay: one hipGraph per gradient-bucket boundary, all-reduce overlapped (0: one graph, reduce after it)
 
 
@@ -319,7 +321,7 @@ class Trainer:
         gc.disable()                   # no collector runs inside a capture: a destructor that touches the HIP runtime there aborts the process
         try:
             if self.world == 1:
-                with torch.cuda.graph(st.graph):
+                with torch.cuda.graph(st.graph, capture_error_mode=CAPTURE_MODE):
                     st.s_loss = self.step(st.s_images, st.s_gts, size=size)
                 st.graph_opt = None
             else:
@@ -328,10 +330,10 @@ class Trainer:
                     st.graph = st.segments[0][0]
                 else:
                     st.segments = None
-                    with torch.cuda.graph(st.graph):
+                    with torch.cuda.graph(st.graph, capture_error_mode=CAPTURE_MODE):
                         st.s_loss = self.forward_backward_local(st.s_images, st.s_gts, size=size)
                 st.graph_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(st.graph_opt):
+                with torch.cuda.graph(st.graph_opt, capture_error_mode=CAPTURE_MODE):
                     self.optimizer_step()
         finally:
             if gc_was:
@@ -346,7 +348,7 @@ class Trainer:
         seg["list"].append((seg["g"], list(self.buckets.record)))
         del self.buckets.record[:]
         seg["g"] = torch.cuda.CUDAGraph()
-        seg["g"].capture_begin(pool=seg["pool"])
+        seg["g"].capture_begin(pool=seg["pool"], capture_error_mode=CAPTURE_MODE)
 
     def _capture_segments(self, st, size):
         """forward+loss+backward of a data-parallel rank as a CHAIN of hipGraphs cut where buckets leave (same places as in the eager step, so
@@ -360,7 +362,7 @@ class Trainer:
             g = torch.cuda.CUDAGraph()
             self._seg = {"g": g, "pool": torch.cuda.graph_pool_handle(), "list": segs}
             self.buckets.record = []
-            g.capture_begin(pool=self._seg["pool"])
+            g.capture_begin(pool=self._seg["pool"], capture_error_mode=CAPTURE_MODE)
             try:
                 st.s_loss = self.forward_backward(st.s_images, st.s_gts, size=size)
                 self._seg["g"].capture_end()
