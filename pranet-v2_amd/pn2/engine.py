@@ -322,6 +322,7 @@ SPLITK = os.environ.get("PN2_SPLITK", "1") == "1"                     # split-K 
 PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
+BNB_MIN_COLS = int(os.environ.get("PN2_BNB_MIN_COLS", "0"))          # experiment: narrower gradients take the separate reduce pass instead of the dgrad epilogue
 LOCKSTEP_TILES = os.environ.get("PN2_LOCKSTEP_TILES", "0") == "1"   # opt-in: canonical conv tiles inside lock-step regions (measured: no more shared launches, same speed)
 LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
@@ -1161,7 +1162,7 @@ class Engine:
                     dd.flags = ((2 | (1 << 2) | ((3 if x.Cp > 64 else 2) << 4)) << 8) | (ks << 16)
                     call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), _p(ws), C.c_void_p(0), C.byref(dd), st)
                     call.pn2_conv_splitk_reduce(self.dt, _p(ws), ks, Mx, x.Cp, _p(gx), x.Cp, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), gxa, st)
-                elif BNB_EPILOGUE and x_last and x.Cp % V == 0 and gx.stride(2) % V == 0 and (x.bnb is not None or dual):
+                elif BNB_EPILOGUE and x_last and x.Cp % V == 0 and gx.stride(2) % V == 0 and (x.bnb is not None or dual) and x.Cp >= BNB_MIN_COLS:
                     ep = capi.ConvEp()
                     if dual and x.sum_of[0].grad_written:
                         dd.flags |= capi.CONV_ACCUM

@@ -24,6 +24,7 @@ def _r4(n):
 
 
 WGRAD_OVERLAP = os.environ.get("PN2_WGRAD_OVERLAP", "0") == "1"      # deferred wgrad tables on a side stream, next to the backward chain (measured: 19.2 -> 20.3 ms, see DESIGN)
+WGRAD_INLINE = os.environ.get("PN2_WGRAD_INLINE", "0") == "1"        # experiment: flush the wgrad tables every WGRAD_SEG convs on the MAIN stream (operands still warm in L2 / MALL)
 WGRAD_SEG = int(os.environ.get("PN2_WGRAD_SEG", "24"))              # convs per flush segment
 # "thread_local": other threads of the process (RCCL's watchdog polls events while a rank captures) do not invalidate the capture
 CAPTURE_MODE = os.environ.get("PN2_CAPTURE_MODE", "thread_local")
@@ -226,7 +227,7 @@ class Trainer:
             eng.pgrads.on_sink = late
         for fn in reversed(eng.tape):
             fn()
-            if overlap and len(rq.wjobs) >= WGRAD_SEG:
+            if (overlap or WGRAD_INLINE) and rq is not None and rq.defer_wgrad and len(rq.wjobs) >= WGRAD_SEG:
                 rq.flush()
             if hook and expected is not None:
                 self.buckets.launch_ready(eng.pgrads.counts, before_launch=grads_complete, expected=expected)
