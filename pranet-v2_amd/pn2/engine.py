@@ -47,8 +47,14 @@ def save_tuner(path):
     os.replace(tmp, path)
 
 
+TUNE_REPS = int(os.environ.get("PN2_TUNE_REPS", "3"))            # timed repetitions per tuning candidate (the minimum counts)
+# Shipped tuning table: the (kernel, tile) and wgrad (kernel, pixel splits) choices for the conv shapes of the BASELINE configurations on an MI355X,
+# produced by the tuner itself (PN2_TUNE_REPS=7 PN2_TUNE_CACHE=... python bench.py per configuration).  Keys carry the complete shape, so a table
+# entry only ever applies to exactly the launch it was timed for; shapes not in the table are tuned at first use as before.  PN2_TUNE_TABLE=0 ignores it.
 if os.environ.get("PN2_TUNE_CACHE"):
-    load_tuner(os.environ["PN2_TUNE_CACHE"])
+    load_tuner(os.environ["PN2_TUNE_CACHE"])          # (first entry wins: an explicit cache overrides the shipped table)
+if os.environ.get("PN2_TUNE_TABLE", "1") == "1":
+    load_tuner(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json"))
 
 
 def rup(v, m):
@@ -763,7 +769,7 @@ class Engine:
         for code in cands:
             launch(code)
             per = []
-            for _ in range(3):
+            for _ in range(TUNE_REPS):
                 if cold:            # inside a step every conv runs once, on operands the caches have mostly lost: time it that way
                     _thrash()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -822,7 +828,7 @@ class Engine:
         for code, ns in cands:
             run(code, ns)
             per = []
-            for _ in range(3):
+            for _ in range(TUNE_REPS):
                 if TUNE_COLD:       # the deferred wgrads run long after dy / x were produced: cold operands
                     _thrash()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
