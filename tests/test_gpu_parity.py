@@ -494,7 +494,7 @@ def test_model_bf16_vs_reference_f64(tag, monkeypatch):
 
 
 def test_bf16_training_trajectory_vs_fp32_oracle():
-    """8 MyTrain_med.py steps (lr 1e-4, clip 0.5) on one fixed batch: the bf16 fused trainer against the CPU oracle in fp32.  The loss
+    """20 MyTrain_med.py steps (lr 1e-4, clip 0.5) on one fixed batch: the bf16 fused trainer against the CPU oracle in fp32.  The loss
     curves must stay together (bf16 noise does not accumulate into a different trajectory) and the loss must fall."""
     from pn2.trainer import Trainer
     from oracle import weights as W
@@ -503,14 +503,15 @@ def test_bf16_training_trajectory_vs_fp32_oracle():
     x, mask = W.synthetic_batch(2, 96, seed=1234)
     xg, mg = x.to(dev), mask.to(dev)
     tr = Trainer(model, lr=1e-4, clip=0.5)
-    NS = 8
+    NS = 20
     ours = [float(tr.step(xg, mg)[-1]) for _ in range(NS)]
     P = W.make_state_dict(W.manifest_pranet_v2(1), seed=0)
     st = {}
     ref = [float(O.train_step(P, st, x, mask)[0]) for _ in range(NS)]
     rel = [abs(a - b) / b for a, b in zip(ours, ref)]
-    print("bf16 trajectory:", [f"{v:.4f}" for v in ours[::2]], " oracle fp32:", [f"{v:.4f}" for v in ref[::2]], f" max rel diff {max(rel):.2e}")
-    # measured: <= 5.3 % on single steps (the first Adam steps move every weight by ~lr * sign(g), see the 2-step test), ~2 % at the end
+    print("bf16 trajectory:", [f"{v:.4f}" for v in ours[::4]], " oracle fp32:", [f"{v:.4f}" for v in ref[::4]], f" max rel diff {max(rel):.2e}, last {rel[-1]:.2e}")
+    # measured over 20 steps: <= 2.7 % .. 5.3 % on single steps depending on the tiles the tuner picked (the first Adam steps move every weight by
+    # ~lr * sign(g), see the 2-step test), 0.75 % .. 2 % at the end; loss 9.39 -> 5.88 (oracle 9.55 -> 5.85)
     assert max(rel) < 8e-2 and rel[-1] < 4e-2, rel
     assert ours[-1] < 0.9 * ours[0] and ref[-1] < 0.9 * ref[0]
 
