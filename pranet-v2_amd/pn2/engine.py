@@ -308,6 +308,7 @@ class StepArena:
 
 
 WGRAD_SPLIT_DIV = int(os.environ.get("PN2_WGRAD_SPLIT_DIV", "1"))
+SLAB_RATIO = float(os.environ.get("PN2_SLAB_RATIO", "0"))           # > 0: cap a deferred wgrad's fp32 slab bytes at this multiple of its operand bytes
 TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the conv tuner times every candidate behind a cache-evicting fill
 _THRASH = {}
 
@@ -1107,6 +1108,11 @@ class Engine:
             rd.Rp = wd.Rp
             wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd, nsplit, w.shape)
             rq = self.grad_queue
+            if rq is not None and rq.defer_wgrad and SLAB_RATIO > 0:
+                # inside a table-driven launch the other convs fill the chip; what a conv's pixel splits cost there is fp32 slab traffic (written, then
+                # re-read by the reduce): keep it within SLAB_RATIO x the bytes of the conv's own operands (small-M 3x3 convs: 25 MB of slabs for 6 MB of dz + x)
+                op_bytes = (M * Cout_p + N * H * W * x.Cp) * 2
+                nsplit = max(1, min(nsplit, int(SLAB_RATIO * op_bytes / (wd.Rp * wd.Kp * 4))))
             if rq is not None and rq.defer_wgrad and WGRAD_SPLIT_DIV > 1:
                 # the tuner times a conv alone, where many pixel splits are what fills the chip; inside a table-driven launch the other
                 # convs of the table do that, and longer contractions per workgroup amortise the pipeline fill and write fewer fp32 slabs
