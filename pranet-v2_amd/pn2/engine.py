@@ -308,6 +308,8 @@ class StepArena:
 
 
 WGRAD_SPLIT_DIV = int(os.environ.get("PN2_WGRAD_SPLIT_DIV", "1"))
+WGRAD_WGS = int(os.environ.get("PN2_WGRAD_WGS", "640"))             # pixel splits: workgroups a single wgrad aims at ...
+WGRAD_SLAB_MB = int(os.environ.get("PN2_WGRAD_SLAB_MB", "24"))      # ... within this many MB of fp32 slabs
 SLAB_RATIO = float(os.environ.get("PN2_SLAB_RATIO", "0"))           # > 0: cap a deferred wgrad's fp32 slab bytes at this multiple of its operand bytes
 TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the conv tuner times every candidate behind a cache-evicting fill
 _THRASH = {}
@@ -1103,7 +1105,7 @@ class Engine:
             tiles = (wd.Rp // tco) * (pd.Kp // 128)
             steps = (M + 31) // 32
             # pixel splits: enough workgroups to fill 256 CUs twice, >= 4 steps each, slabs capped at 24 MB
-            nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (640 + tiles - 1) // tiles, (24 << 20) // (wd.Rp * wd.Kp * 4) or 1))
+            nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (WGRAD_WGS + tiles - 1) // tiles, (WGRAD_SLAB_MB << 20) // (wd.Rp * wd.Kp * 4) or 1))
             rd = self._pack_desc(w, x_map, o_map, False)
             rd.Rp = wd.Rp
             wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd, nsplit, w.shape)
@@ -1381,7 +1383,7 @@ class Engine:
             wd.Rp, wd.Kp = rup(Ct, tco), Kp
             tiles = (wd.Rp // tco) * (Kp // 128)
             steps = (M + 31) // 32
-            nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (640 + tiles - 1) // tiles, (24 << 20) // (wd.Rp * wd.Kp * 4) or 1))
+            nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (WGRAD_WGS + tiles - 1) // tiles, (WGRAD_SLAB_MB << 20) // (wd.Rp * wd.Kp * 4) or 1))
             rd0 = self._pack_desc(convs[0].weight, x_map, (couts[0], couts[0], couts[0]), False)
             rd0.Rp, rd0.Kp = wd.Rp, Kp
             wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd0, nsplit, convs[0].weight.shape)
