@@ -35,13 +35,14 @@ def bench(M, Cc, ld_dy, ld_x):
     nb = call.pn2_bn_bwd_blocks(M, Cc, BF16)
     p1 = torch.empty(nb, Cc, device=dev); p2 = torch.empty(nb, Cc, device=dev)
     t_aff = timeit(lambda: call.pn2_affine_act(BF16, P(x), ld_x, BF16, P(y), ld_dy, M, Cc, P(sc), P(sh), C.c_void_p(0), 0, 1, st))
-    t_red = timeit(lambda: call.pn2_bn_bwd_reduce(BF16, BF16, P(dy), ld_dy, Cc, P(y), ld_dy, BF16, P(x), ld_x, M, Cc, P(mean), P(invstd), P(p1), P(p2), nb,
-                                                  C.c_void_p(0), C.c_void_p(0), 0, st))
+    # (the step's form: mask recomputed from the raw conv output, no stored y)
+    t_red = timeit(lambda: call.pn2_bn_bwd_reduce(BF16, BF16, P(dy), ld_dy, Cc, C.c_void_p(0), 0, BF16, P(x), ld_x, M, Cc, P(mean), P(invstd), P(p1), P(p2), nb,
+                                                  P(sc), P(sh), 0, st))
     # the step's dominant form: ReLU mask recomputed from the raw conv output (msc / msh), no stored y
     t_app = timeit(lambda: call.pn2_bn_bwd_apply(BF16, BF16, P(dy), ld_dy, Cc, C.c_void_p(0), 0, BF16, P(x), ld_x, M, Cc, P(mean), P(invstd), P(coef), P(dx), ld_x,
                                                  C.c_void_p(0), 0, 0, P(sc), P(sh), 0, st))
     b = M * Cc * 2
-    print(f"M{M:7d} C{Cc:5d} lddy{ld_dy:5d}: affine {t_aff:6.1f} us {2*b/t_aff/1e3:6.0f} GB/s | reduce(nb{nb:4d}) {t_red:6.1f} us {3*b/t_red/1e3:6.0f} GB/s | apply {t_app:6.1f} us {3*b/t_app/1e3:6.0f} GB/s")
+    print(f"M{M:7d} C{Cc:5d} lddy{ld_dy:5d}: affine {t_aff:6.1f} us {2*b/t_aff/1e3:6.0f} GB/s | reduce(nb{nb:4d}) {t_red:6.1f} us {2*b/t_red/1e3:6.0f} GB/s | apply {t_app:6.1f} us {3*b/t_app/1e3:6.0f} GB/s")
 
 
 if __name__ == "__main__":
