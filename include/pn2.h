@@ -67,6 +67,9 @@ int pn2_conv_tile_n(int cout);          /* N tile the forward/dgrad kernel will 
 int pn2_wgrad_tile_co(int cout_p);      /* co tile of the wgrad kernel */
 int pn2_conv_tile_m(int m, int cout, int dtype);        /* M tile (128 or 64) chosen for m output pixels x cout channels */
 int pn2_conv_stat_blocks(int m, int cout, int dtype);   /* rows of the psum/psq partial buffers = ceil(m / tile_m) */
+/* bf16: the LDS-DMA kernels (tuning code kernel 2 / 3, and the default choice) address `in` through a buffer descriptor with 32-bit byte offsets - padding taps,
+ * rows past M and channel chunks past Cin_p are zero-filled by the hardware's out-of-range rule.  A gathered tensor whose extent from `in` reaches 2 GB is served by
+ * the register-staged kernel instead (64-bit addresses; same results bit for bit, tests/test_gpu_convkernels.py). */
 int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, void* stream);
 /* pn2_conv_gemm with the BatchNorm-BACKWARD statistics taken in the GEMM epilogue (autograd of nn.BatchNorm2d + ReLU behind a conv,
  * Res2Net_v1b.py:60-63,70-72,84-89 ; pranet.py:40-43).  A dgrad GEMM whose result completes the gradient dy of a BatchNorm output y = act(BN(raw))
