@@ -56,19 +56,8 @@ struct GatherGeom {
     int H, W, OH, OW, KH, KW, stride, sshift, pad_h, pad_w, dil_h, dil_w, transposed;
 };
 
-// resolve tap (r,s) of output pixel (oy0, ox0 precomputed) to an input pixel; returns false if padding
-__device__ __forceinline__ bool tap_pixel(const GatherGeom& g, int iy0, int ix0, int r, int s, int& iy, int& ix) {
-    if (!g.transposed) {
-        iy = iy0 + r * g.dil_h; ix = ix0 + s * g.dil_w;
-        return (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-    }
-    const int ty = iy0 - r * g.dil_h, tx = ix0 - s * g.dil_w;
-    const int msk = g.stride - 1;
-    iy = ty >> g.sshift; ix = tx >> g.sshift;
-    return ty >= 0 && tx >= 0 && !(ty & msk) && !(tx & msk) && iy < g.H && ix < g.W;
-}
-
-// the same with the tap's dilated offsets (r * dil_h, s * dil_w) carried by the caller (the LDS-DMA kernel steps them instead of dividing the tap index)
+// resolve a tap of an output pixel (iy0 / ix0 precomputed) to an input pixel; returns false if padding.  The tap's dilated offsets (r * dil_h, s * dil_w)
+// are carried by the caller, which steps them with the tap instead of dividing the tap index
 __device__ __forceinline__ bool tap_pixel_off(const GatherGeom& g, int iy0, int ix0, int dr, int dc, int& iy, int& ix) {
     if (!g.transposed) {
         iy = iy0 + dr; ix = ix0 + dc;
@@ -529,14 +518,13 @@ __global__ __launch_bounds__(256) void conv_gather_gemm_tab(const pn2_conv_job* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward / dgrad gather-GEMM, LDS-DMA pipeline (bf16): both operands go global -> LDS with
-// global_load_lds_dwordx4 (no register staging), NS stages deep, counted vmcnt + raw s_barrier so that
-// up to NS-1 K-steps of loads stay in flight across the MFMAs.  The LDS image written by the DMA is
-// lane-linear (128-byte rows, no padding); bank conflicts are removed by an XOR swizzle of the 16-byte
-// chunk index with ((row>>1)&7), applied to the per-lane SOURCE address and to the fragment reads.
-// Padding taps / out-of-range rows read a 16-byte zero vector in global memory instead of branching.
+// forward / dgrad gather-GEMM, LDS-DMA pipeline (bf16): both operands go global -> LDS with 16-byte LDS-DMA loads
+// (no register staging), NS stages deep, counted vmcnt + raw s_barrier so that up to NS-1 K-steps of loads stay in
+// flight across the MFMAs.  The LDS image written by the DMA is lane-linear (128-byte rows, no padding); bank
+// conflicts are removed by an XOR swizzle of the 16-byte chunk index with ((row>>1)&7), applied to the per-lane SOURCE
+// address and to the fragment reads.  The activation operand is addressed through a buffer descriptor: padding taps /
+// out-of-range rows get an offset past num_records and the hardware writes zeros (no zero page, no branches).
 // ------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) unsigned pn2_zero16[4] = {0u, 0u, 0u, 0u};
 
 // NS = 3: two K-steps of loads in flight; NS = 2: one step ahead and a third less LDS, so that three (64x128) instead of two workgroups share
 // a CU - the per-shape tuner picks (the K loop runs at ~27 % of the MFMA rate with two resident workgroups: barrier / wait stalls).
@@ -967,12 +955,10 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const bf16_t* __restrict__ d
     int s_end = s_begin + spb; if (s_end > total_steps) s_end = total_steps;
     const int nsteps = s_end > s_begin ? s_end - s_begin : 0;
     const int taps = d.KH * d.KW;
-    const char* zsrc = reinterpret_cast<const char*>(pn2_zero16);
 
     // ---- DMA lanes.  dy: row (tid / CHY) of each group of 256/CHY rows, LDS slot tid % CHY holding global chunk gy
     const int yrow = tid / CHY, gy = (tid % CHY) ^ ((yrow & KMY) << 1);
     const bool yc_ok = co0 + gy * 8 < d.Cout_p;
-    const bf16_t* ysrc = dy + co0 + gy * 8;
     const int xrow = tid / CHX, gx = (tid % CHX) ^ ((xrow & KMX) << 1);
     const int kk = k0 + gx * 8;
     int xtap = 0, xci = kk;
