@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--model", default="res2net", choices=["res2net", "pvt", "emcad"],
                     help="res2net = BASELINE config 2/3 (headline); pvt = config 4 (PVT_PraNet_V2, use --batch 16); "
                          "emcad = config 5 (EMCADNet dual K=9 + the 15-subset loss + AdamW, use --batch 16 --size 512)")
+    ap.add_argument("--dp1", action="store_true", help="single GPU, but through the data-parallel path on a ONE-rank RCCL communicator (bucket hooks, graph "
+                                                       "segments, ncclAllReduce between them): validates the RCCL plumbing where only one GPU is available")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-line", action="store_true")
     args = ap.parse_args()
@@ -121,9 +123,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    use_dist = world > 1 or args.dp1
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:          # --dp1 without torchrun: a one-rank rendezvous on the loopback
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
 
     import pn2
@@ -135,7 +142,7 @@ def main():
         # EMCAD/trainer.py: 1-channel Synapse slices, 9 classes, AdamW(lr 1e-4, wd 1e-4), supervision='mutation' on the dual heads
         from lib.networks import EMCADNet
         model = EMCADNet(num_classes=9, kernel_sizes=[1, 3, 5], expansion_factor=2, activation="relu6", encoder="pvt_v2_b2", pretrain=False, dual=True).to(dev).train()
-        tr = Trainer(model, lr=1e-4, clip=None, weight_decay=1e-4, loss="mutation", hot=model.hot_parameters(True), process_group=pg)
+        tr = Trainer(model, lr=1e-4, clip=None, weight_decay=1e-4, loss="mutation", hot=model.hot_parameters(True), process_group=pg, force_dp=args.dp1)
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         x = torch.randn(args.batch, 1, args.size, args.size, generator=g).to(dev)
         lab = torch.randint(0, 9, (args.batch, args.size // 16, args.size // 16), generator=g).to(dev)
@@ -143,7 +150,7 @@ def main():
         m = (lab, torch.stack([(lab != k).float() for k in range(9)], 1))
     else:
         model = (PraNet_V2 if args.model == "res2net" else PVT_PraNet_V2)(num_class=1).to(dev).train()
-        tr = Trainer(model, lr=1e-4, clip=0.5, process_group=pg)
+        tr = Trainer(model, lr=1e-4, clip=0.5, process_group=pg, force_dp=args.dp1)
         x, m = synthetic(args.batch, args.size, 1234 + rank, dev)
 
     use_graph = not args.no_graph
@@ -155,14 +162,14 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
@@ -177,7 +184,7 @@ def main():
     roof = prof.measure_step(tr, x, m, args.dtype, config={"model": args.model, "batch": args.batch, "size": args.size, "dtype": args.dtype})
     # ---- data-parallel exchange: how much of the gradient all-reduce is exposed (time of a step with the collectives minus one without)
     dp = None
-    if world > 1:
+    if use_dist:
         def timed(fn, n=5):
             torch.cuda.synchronize(); dist.barrier(); t0_ = time.perf_counter()
             for _ in range(n):
@@ -190,9 +197,17 @@ def main():
             for g_ in ([g for g, _ in st_.segments] if st_.segments else [st_.graph]):
                 g_.replay()
             st_.graph_opt.replay()
-        t_noex = timed(no_exchange) if use_graph and st_.graph_opt is not None else None
+        t_noex = None
+        if use_graph and st_.graph_opt is not None:
+            # the probe steps the optimizer on UNREDUCED local gradients: replicas would silently diverge - restore weights and Adam state after it
+            keep = [t_.clone() for t_ in (tr.flat, tr.exp_avg, tr.exp_avg_sq, tr.bias_corr)]
+            t_noex = timed(no_exchange)
+            for d_, s_ in zip((tr.flat, tr.exp_avg, tr.exp_avg_sq, tr.bias_corr), keep):
+                d_.copy_(s_)
+            del keep
         dp = {"backend": "nccl (RCCL)", "nccl_ranks": world, "buckets": len(tr.buckets.buckets), "bucket_bytes": 32 << 20, "allreduce_bytes_per_step": int(tr.n_hot * 4),
               "graph_segments": len(st_.segments) if st_.segments else 1, "wire_dtype": os.environ.get("PN2_DP_WIRE", "fp32"),
+              "mode": "one-rank communicator on one GPU (--dp1)" if args.dp1 and world == 1 else "one process per GPU",
               "exposed_comm_ms": None if t_noex is None else round(1e3 * (t_all - t_noex), 3)}
     names = {"res2net": "PraNet-V2 Res2Net50", "pvt": "PVT-PraNet-V2 (pvt_v2_b2, DropPath 0.1)", "emcad": "EMCADNet dual K=9 (pvt_v2_b2 encoder, EMCAD decoder)"}
     what = ("fwd+15-subset CE/Dice/BCE loss+bwd+AdamW" if args.model == "emcad" else "fwd+4x structure_loss+bwd+clamp+Adam")
@@ -221,7 +236,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model != "emcad":
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

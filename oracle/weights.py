@@ -14,6 +14,7 @@ Key names / shapes restate what the reference classes register:
   PraNet (V1)          /root/reference/binary_seg/lib/PraNet_Res2Net.py:101-128
 """
 import math
+import re
 from collections import OrderedDict
 
 import torch
@@ -238,12 +239,23 @@ def manifest_emcadnet(num_classes=9):
     return m
 
 
-def make_state_dict(manifest, seed=0):
+_BN3 = re.compile(r"layer\d\.\d+\.bn3\.weight$")
+
+
+def make_state_dict(manifest, seed=0, bn3_gamma=None):
     """Deterministic non-trivial weights: every tensor from its own CPU generator.
 
     conv/linear: N(0, sqrt(2/fan_in))·0.9 ; BN gamma U(0.6,1.4), beta N(0,0.1),
     running_mean N(0,0.1), running_var U(0.6,1.4).  Values are chosen so that
     activations stay O(1) through ~60 layers in both train and eval mode.
+
+    bn3_gamma (the CONDITIONED fixtures, tests/golden/make_golden_cond.py): the gamma of the last BatchNorm of every
+    Bottle2neck (`layerL.B.bn3.weight`, Res2Net_v1b.py:50,84) is multiplied by this factor.  A random-init BN-ReLU
+    residual network is chaotic - each block multiplies a perturbation by ~1.2, so fp32 rounding noise reaches 1e-3 on
+    O(1) logits after 16 blocks, in eval mode with calibrated statistics just as in train mode (measured on the imported
+    reference).  Trained checkpoints do not behave like that: their residual branches are small corrections (the usual
+    zero-init-residual regime).  With bn3 gamma x 0.05 the reference's own fp32 run agrees with its float64 run to
+    ~2e-5 on the logits, which is what lets a test gate north_star's literal "1e-4 abs on fp32 logits".
     """
     sd = OrderedDict()
     for idx, (k, shape) in enumerate(manifest.items()):
@@ -256,6 +268,8 @@ def make_state_dict(manifest, seed=0):
             sd[k] = torch.randn(shape, generator=g) * 0.1
         elif len(shape) == 1 and k.endswith(".weight"):      # BN gamma
             sd[k] = torch.rand(shape, generator=g) * 0.8 + 0.6
+            if bn3_gamma is not None and _BN3.search(k):
+                sd[k] = sd[k] * bn3_gamma
         elif len(shape) == 1:                                  # biases (BN beta, conv/fc bias)
             sd[k] = torch.randn(shape, generator=g) * 0.1
         else:

@@ -37,6 +37,32 @@ class GradBuckets:
         self.works = []
         self.order = []          # bucket indices in launch order (for tests)
         self.launched_keys = set()
+        self._remaining = None   # per-bucket outstanding contributions (expect() / contribution()), None: launch_ready() scans
+        self._ready = []
+
+    def expect(self, expected):
+        """Arm the O(1) bookkeeping of a backward pass: `expected` maps key -> contributions a full pass delivers (learned by the trainer's first
+        pass).  Every ParamGrads.sink then calls contribution(key); a bucket whose outstanding count reaches 0 is queued for the next
+        launch_ready() - instead of rescanning every key of every pending bucket after every tape entry (~500 x ~500 dictionary look-ups per
+        eager step).  Buckets none of whose keys is expected stay pending until finish(), as in the scanning form."""
+        self._key_bucket = {}
+        self._remaining = []
+        for b, (_, _, keys) in enumerate(self.buckets):
+            n = 0
+            for k in keys:
+                if k in expected:
+                    self._key_bucket[k] = b
+                    n += expected[k]
+            self._remaining.append(n if n > 0 else -1)
+        self._ready = []
+
+    def contribution(self, key):
+        b = self._key_bucket.get(key)
+        if b is None:
+            return
+        self._remaining[b] -= 1
+        if self._remaining[b] == 0:
+            self._ready.append(b)
 
     def _launch(self, b):
         a, e, keys = self.buckets[b]
@@ -75,7 +101,9 @@ class GradBuckets:
         fc1 / fc2, EMCAD_dual's single sab conv - receives k of them, in different tape entries): a key is complete only when its count has
         reached that number; keys missing from `expected` never receive a gradient and do not hold a bucket back... until finish().
         before_launch: called once if anything is about to be launched (e.g. join a side stream that produced the gradients)."""
-        if expected is None:
+        if self._remaining is not None and expected is not None:
+            ready, self._ready = sorted(self._ready), []          # armed by expect(): O(1) per call; same launch order as the scan below
+        elif expected is None:
             ready = [b for b in self.pending if self.buckets[b][2] <= written]
         else:
             ready = [b for b in self.pending if all(written.get(k, 0) >= expected[k] for k in self.buckets[b][2] if k in expected)

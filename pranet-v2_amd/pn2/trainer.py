@@ -33,11 +33,13 @@ DP_SEGMENTS = os.environ.get("PN2_DP_SEGMENTS", "1") == "1"          # data-para
 
 class Trainer:
     def __init__(self, model, lr=1e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8, dtype=None, process_group=None, bucket_bytes=32 << 20,
-                 loss="structure", loss_weights=(0.5, 0.7, 0.3), weight_decay=0.0, hot=None):
+                 loss="structure", loss_weights=(0.5, 0.7, 0.3), weight_decay=0.0, hot=None, force_dp=False):
         """loss: "structure" - the 4-pair structure loss of MyTrain_med.py:78-82 on (images, masks), Adam + clip_gradient (binary_seg);
                  "mutation"  - the 15-subset CE + Dice + BCE loss of EMCAD/trainer.py:106-140 on (images, (label, bg_mask)) with the 8 maps of a
                                dual EMCADNet; pass clip=None and weight_decay=1e-4 for its AdamW (trainer.py:75).
-        hot: the parameters the step trains (default model.hot_parameters())."""
+        hot: the parameters the step trains (default model.hot_parameters()).
+        force_dp: run the data-parallel machinery (bucket hooks, graph segments, asynchronous all-reduce) even on a 1-rank process group - how the
+                 RCCL path is exercised on a single GPU (tests/test_gpu_dp.py, bench.py --dp1; also PN2_DP_FORCE=1)."""
         self.model = model
         self.loss_kind, self.loss_weights, self.weight_decay = loss, tuple(float(v) for v in loss_weights), float(weight_decay)
         if loss not in ("structure", "mutation"):
@@ -47,6 +49,7 @@ class Trainer:
         self.dtype = get_compute_dtype() if dtype is None else dtype
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.dp = process_group is not None and (self.world > 1 or force_dp or os.environ.get("PN2_DP_FORCE", "0") == "1")
         hot = list(model.hot_parameters()) if hot is None else list(hot)
         hot_ids = {id(p) for p in hot}
         cold = [p for p in model.parameters() if id(p) not in hot_ids]
@@ -185,7 +188,7 @@ class Trainer:
         return self._backward(eng, st, loss, lat, reduce_hook)
 
     def _backward(self, eng, st, loss, lat, reduce_hook):
-        if self.world > 1:
+        if self.dp:
             self.buckets.reset()
         rq = st.grad_queue
         if rq is not None:
@@ -217,13 +220,16 @@ class Trainer:
         # (CAB's shared fc1 / fc2, EMCAD_dual's single sab conv) receives k contributions from different tape entries.  The first backward pass
         # of a trainer therefore only counts contributions per parameter (its buckets all leave at the end); later passes launch a bucket when
         # every count has reached that number, and a contribution that arrives after its bucket was sent is an error, not a silent corruption.
-        hook = self.world > 1 and reduce_hook
+        hook = self.dp and reduce_hook
         expected = self._expected
         if hook and expected is not None:
+            self.buckets.expect(expected)
+
             def late(k, c, bk=self.buckets):
                 if k in bk.launched_keys:
                     raise RuntimeError("a gradient contribution arrived after its bucket was all-reduced (the model's use of its parameters changed "
                                        "between steps): build a new Trainer")
+                bk.contribution(k)
             eng.pgrads.on_sink = late
         for fn in reversed(eng.tape):
             fn()
@@ -241,7 +247,7 @@ class Trainer:
             missing = [n for n, p in self.model.named_parameters() if id(p) in {id(q) for q in self.hot} and id(p) not in eng.pgrads.written]
             raise RuntimeError(f"{len(missing)} trained parameters received no gradient this step (first: {missing[:3]}): exclude them from `hot`")
         grads_complete()
-        if self.world > 1:
+        if self.dp:
             if reduce_hook and expected is None:
                 self._expected = dict(eng.pgrads.counts)
             self.buckets.finish()
@@ -311,7 +317,7 @@ class Trainer:
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.step(st.s_images, st.s_gts, size=size)
-            if self.world > 1 and not DP_SEGMENTS:      # that captured pass has no bucket hooks: let it build its own (single) reduce table eagerly
+            if self.dp and not DP_SEGMENTS:      # that captured pass has no bucket hooks: let it build its own (single) reduce table eagerly
                 self.forward_backward_local(st.s_images, st.s_gts, size=size)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -321,7 +327,7 @@ class Trainer:
         gc.collect()
         gc.disable()                   # no collector runs inside a capture: a destructor that touches the HIP runtime there aborts the process
         try:
-            if self.world == 1:
+            if not self.dp:
                 with torch.cuda.graph(st.graph, capture_error_mode=CAPTURE_MODE):
                     st.s_loss = self.step(st.s_images, st.s_gts, size=size)
                 st.graph_opt = None
@@ -368,6 +374,16 @@ class Trainer:
                 st.s_loss = self.forward_backward(st.s_images, st.s_gts, size=size)
                 self._seg["g"].capture_end()
                 segs.append((self._seg["g"], list(self.buckets.record)))
+            except BaseException:
+                # an error inside the hooked backward (late contribution, a kernel status, ...) must not leave the stream in capture mode: every
+                # later HIP call of the process would fail with an unrelated capture-invalidated error.  End the open segment, drop the partial chain.
+                try:
+                    self._seg["g"].capture_end()
+                except Exception:
+                    pass
+                del segs[:]
+                st.segments = st.graph = None
+                raise
             finally:
                 self._seg = None
                 self.buckets.record = None
@@ -376,11 +392,11 @@ class Trainer:
         return segs
 
     def forward_backward_local(self, images, gts, size=None):
-        w, self.world = self.world, 1
+        w, self.dp = self.dp, False
         try:
             return self.forward_backward(images, gts, size=size)
         finally:
-            self.world = w
+            self.dp = w
 
     def replay(self, images=None, gts=None, size=None):
         """Replay the graphs captured for this batch shape / train size (the most recently used state when called without arguments)."""

@@ -56,6 +56,21 @@ def _worker(rank, world, port, q):
             seen5.append(any(5 in bk.buckets[b][2] for b in bk.order))
     bk.finish()
     ok_multi = seen5 == [False, True] and torch.allclose(gflat, sum(allg), atol=1e-6)
+    # third step again through the O(1) form the trainer uses (expect() arms per-bucket counters, every gradient sink reports contribution()):
+    # same launch order as the scan, nothing leaves early, every element summed once
+    order_scan = list(bk.order)
+    gflat.copy_(local)
+    bk.reset()
+    bk.expect(expected)
+    counts, seen5 = {}, []
+    for i in [6, 5, 4, 3, 5, 2, 1, 0]:
+        counts[i] = counts.get(i, 0) + 1
+        bk.contribution(i)
+        bk.launch_ready(counts, expected=expected)
+        if i == 5:
+            seen5.append(any(5 in bk.buckets[b][2] for b in bk.order))
+    bk.finish()
+    ok_multi = ok_multi and seen5 == [False, True] and list(bk.order) == order_scan and torch.allclose(gflat, sum(allg), atol=1e-6)
     # fourth step: the record / replay flow of a captured step (Trainer._capture_segments): launches are noted while recording, issued by launch_async
     gflat.copy_(local)
     bk.reset()

@@ -1,0 +1,162 @@
+"""GPU parity on the CONDITIONED fixtures (tests/golden/pranet_v2_cond.npz, made by tests/golden/make_golden_cond.py from the imported reference).
+
+The plain random-init fixtures of test_gpu_parity.py are chaotic networks: the reference's own fp32 run sits 1e-3 from its float64 run and every
+bf16 execution is O(1) relative L2 away, so those tests can only carry relative gates.  With the residual branches scaled down (bn3 gamma x 0.05,
+the regime of a trained checkpoint) the reference agrees with itself to ~2e-5 on the logits in train AND eval mode and torch's own bf16 policy
+lands 3e-2 .. 6e-2 from float64 - here north_star's numbers are asserted LITERALLY on the fp32 path:
+
+    |logit - reference fp32 logit| <= 1e-4        (train mode 8 x 96^2 and 2 x 352^2; eval mode with calibrated BatchNorm statistics 1 x 352^2, 2 x 96^2)
+    MyTest_med.py:104-111 uint8 map within 1 level, |meanDic - reference meanDic| <= 1e-3
+
+and the bf16 path (the benchmarked precision) is gated against an informative yardstick: rel-L2 per map <= 1.25 x the imported reference under
+torch.autocast(bfloat16), losses, gradient probes and meanDic no further off than 1.25 x torch's own bf16 deviations.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("PN2_NO_PRETRAINED", "1")
+dev = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pn2
+    pn2.load_library()      # fails loudly if the HIP extension is missing
+    yield
+    pn2.set_compute_dtype("bf16")
+
+
+def rell2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def z():
+    return np.load(os.path.join(G, "pranet_v2_cond.npz"))
+
+
+def _model(z, fp32, calibrated):
+    import pn2
+    from lib.pranet import PraNet_V2
+    from oracle import weights as W
+    pn2.set_compute_dtype("fp32" if fp32 else "bf16")
+    sd = W.make_state_dict(W.manifest_pranet_v2(1), seed=0, bn3_gamma=float(z["bn3_gamma"]))
+    if calibrated:
+        for f in z.files:
+            if f.startswith("calib."):
+                sd[f[6:]] = T(z[f]).clone()
+    model = PraNet_V2(num_class=1)
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev)
+
+
+def _train_case(z, tag, fp32):
+    from pn2.loss import structure_loss
+    from oracle import weights as W
+    n, size = int(z[f"{tag}.n"]), int(z[f"{tag}.size"])
+    model = _model(z, fp32, False).train()
+    x, mask = W.synthetic_batch(n, size, seed=4242)
+    x, mask = x.to(dev), mask.to(dev)
+    outs = model(x)                                                                             # MyTrain_med.py:76
+    losses = [structure_loss(outs[i], outs[i + 4], mask, 1 - mask) for i in range(4)]          # :78-81
+    (losses[3] + losses[2] + losses[1] + losses[0]).backward()                                 # :82-84
+    return model, [o.detach().cpu() for o in outs], [float(l.detach()) for l in losses]
+
+
+@pytest.mark.parametrize("tag", ["t96", "t352"])
+def test_conditioned_train_fp32_literal_tolerance(z, tag):
+    """north_star, literally: fp32 logits within 1e-4 abs of the reference's fp32 logits (train mode, nn.Module surface + torch autograd);
+    losses within 1e-5; every gradient probe at least as close to the float64 gradient as the reference's own fp32 gradient is."""
+    model, outs, losses = _train_case(z, tag, True)
+    s32, s64 = int(z[f"{tag}.stride32"]), int(z[f"{tag}.stride64"])
+    e32 = [float((o[:, :, ::s32, ::s32] - T(z[f"{tag}.out{i}"])).abs().max()) for i, o in enumerate(outs)]
+    e64 = [float((o[:, :, ::s64, ::s64].double() - T(z[f"{tag}.f64.out{i}"])).abs().max()) for i, o in enumerate(outs)]
+    print(f"[{tag}] max |logit - ref fp32| {max(e32):.2e}   max |logit - ref f64| {max(e64):.2e}   (reference fp32 vs its f64: {float(z[tag + '.own_abs'].max()):.2e})")
+    assert max(e32) <= 1e-4, e32
+    assert max(e64) <= 1e-4, e64
+    assert np.abs(np.array(losses) - z[f"{tag}.losses"]).max() < 1e-5
+    named = dict(model.named_parameters())
+    rows = []
+    for f in z.files:
+        if f.startswith(f"{tag}.graw."):
+            k = f[len(tag) + 6:]
+            r32, r64 = T(z[f]).double(), T(z[f"{tag}.f64.graw." + k]).double()
+            own = float((r32 - r64).norm() / (r64.norm() + 1e-30))
+            rows.append((k, rell2(named[k].grad.reshape(-1)[:256], r64), own))
+    worst = max(rows, key=lambda r: r[1] / max(r[2], 1e-5))
+    print(f"[{tag}] gradient probes: worst rel-L2 vs f64 {worst[1]:.2e} (reference's own {worst[2]:.2e}) at {worst[0]}")
+    bad = [r for r in rows if r[1] > max(1e-5, 1.0 * r[2])]
+    assert not bad, bad
+    assert sorted(k for k, p in named.items() if p.grad is None) == sorted(str(s) for s in z[f"{tag}.nograd"])
+
+
+@pytest.mark.parametrize("tag", ["t96", "t352"])
+def test_conditioned_train_bf16_vs_torch_bf16_yardstick(z, tag):
+    """The benchmarked precision on a fixture where bf16 is informative (torch-autocast rel-L2 3e-2 .. 5e-2 per map, not 0.2 .. 1.0):
+    per map rel-L2(ours, ref f64) <= 1.25 x torch's; losses and gradient probes no further off than 1.25 x torch's own bf16 run."""
+    model, outs, losses = _train_case(z, tag, False)
+    s64 = int(z[f"{tag}.stride64"])
+    ours = [rell2(o[:, :, ::s64, ::s64], T(z[f"{tag}.f64.out{i}"])) for i, o in enumerate(outs)]
+    tb = [float(v) for v in z[f"{tag}.bf16.rel"]]
+    print(f"[{tag}] bf16 rel-L2 per map: ours {[f'{e:.3f}' for e in ours]}   torch-autocast {[f'{e:.3f}' for e in tb]}")
+    for e, t in zip(ours, tb):
+        assert e <= 1.25 * t, (ours, tb)
+    l64 = z[f"{tag}.f64.losses"]
+    lerr = np.abs(np.array(losses) - l64) / l64
+    terr = np.abs(z[f"{tag}.bf16.losses"] - l64) / l64
+    print(f"[{tag}] rel loss error: ours {[f'{e:.1e}' for e in lerr]}   torch-autocast {[f'{e:.1e}' for e in terr]}")
+    assert float(lerr.max()) <= max(3e-3, 1.25 * float(terr.max())), (lerr, terr)
+    named = dict(model.named_parameters())
+    PROBE_PARAMS = [f[len(tag) + 6:] for f in z.files if f.startswith(f"{tag}.graw.")]      # file order == the generator's probe order (that of bf16.grel)
+    g_ours = np.array([rell2(named[k].grad.reshape(-1)[:256], T(z[f"{tag}.f64.graw." + k])) for k in PROBE_PARAMS])
+    g_tb = z[f"{tag}.bf16.grel"]
+    print(f"[{tag}] gradient probes rel-L2 vs f64: ours median {np.median(g_ours):.3f} max {g_ours.max():.3f}   torch-autocast median {np.median(g_tb):.3f} max {g_tb.max():.3f}")
+    assert float(np.median(g_ours)) <= 1.25 * float(np.median(g_tb))
+    assert float(g_ours.max()) <= 1.25 * float(g_tb.max())
+
+
+@pytest.mark.parametrize("tag", ["e96", "e352"])
+@pytest.mark.parametrize("fp32", [True, False])
+def test_conditioned_eval_calibrated_bn(z, tag, fp32):
+    """MyTest_med.py:98-111 with realistic (calibrated) BatchNorm running statistics: eval-mode logits, the uint8 map and its meanDic.
+    fp32: |logit - ref fp32| <= 1e-4 literal, uint8 within 1 level, |d meanDic| <= 1e-3.  bf16: rel-L2 per map <= 1.25 x torch-autocast's,
+    meanDic no further from the reference than 1.25 x torch's own bf16 map (floor 1e-3)."""
+    from pn2.evaltail import test_postprocess
+    from oracle import weights as W
+    from oracle import pranet_oracle as O
+    n, size = int(z[f"{tag}.n"]), int(z[f"{tag}.size"])
+    s32, s64 = int(z[f"{tag}.stride32"]), int(z[f"{tag}.stride64"])
+    model = _model(z, fp32, True).eval()
+    x, _ = W.synthetic_batch(n, size, seed=4242)
+    with torch.no_grad():
+        outs = model(x.to(dev))
+    u8 = test_postprocess([o[:1] for o in outs], tuple(z[f"{tag}.u8"].shape)).cpu().numpy()
+    dice, ref_dice = O.mean_dice(u8, z[f"{tag}.gt"]), float(z[f"{tag}.meanDic"])
+    outs = [o.cpu() for o in outs]
+    if fp32:
+        e32 = [float((o[:, :, ::s32, ::s32] - T(z[f"{tag}.out{i}"])).abs().max()) for i, o in enumerate(outs)]
+        print(f"[{tag} fp32] max |logit - ref fp32| {max(e32):.2e} (reference fp32 vs its f64: {float(z[tag + '.own_abs'].max()):.2e}); meanDic {dice:.5f} vs {ref_dice:.5f}")
+        assert max(e32) <= 1e-4, e32
+        assert np.abs(u8.astype(int) - z[f"{tag}.u8"].astype(int)).max() <= 1
+        assert abs(dice - ref_dice) <= 1e-3
+    else:
+        ours = [rell2(o[:, :, ::s64, ::s64], T(z[f"{tag}.f64.out{i}"])) for i, o in enumerate(outs)]
+        tb = [float(v) for v in z[f"{tag}.bf16.rel"]]
+        d_t = abs(float(z[f"{tag}.bf16.meanDic"]) - ref_dice)
+        print(f"[{tag} bf16] rel-L2 per map: ours {[f'{e:.3f}' for e in ours]}   torch-autocast {[f'{e:.3f}' for e in tb]};  meanDic off by {abs(dice - ref_dice):.1e} (torch-autocast {d_t:.1e})")
+        for e, t in zip(ours, tb):
+            assert e <= 1.25 * t, (ours, tb)
+        assert abs(dice - ref_dice) <= max(1e-3, 1.25 * d_t)

@@ -128,3 +128,79 @@ def test_two_ranks_match_single_process_with_averaged_gradients(kind, autotune):
     tr.optimizer_step()
     torch.cuda.synchronize()
     assert float((p_a - tr.flat.cpu()).abs().max()) < 3e-4      # one Adam step of size lr=1e-4: sign flips of ~0 gradients move a weight by <= 2e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# RCCL itself (torch.distributed backend "nccl" IS RCCL on ROCm).  Two ranks cannot share one GPU under RCCL ("duplicate GPU"), so the real
+# backend is exercised with a ONE-rank communicator and Trainer(force_dp=True): eager bucket hooks issuing ncclAllReduce on RCCL's stream next to
+# the backward kernels, _capture_segments under the thread-local capture mode with RCCL's watchdog thread alive, segment replay with
+# launch_async between hipGraph segments, PN2_DP_WIRE=bf16 (temporary bf16 buffers), two trainers in one process.  A 1-rank sum is the
+# identity, so the result must be BIT-IDENTICAL to the trainer without a process group - any ordering bug between RCCL's stream and the compute
+# stream (a bucket sent before its gradients are complete, an optimizer replay that does not wait for the collective) shows as a difference.
+def _rccl_worker(port, q, wire):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ["PN2_DP_WIRE"] = wire
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from pn2.trainer import Trainer
+        model, W = _setup("res2net", False)
+        x, m = _batch("res2net", W, 0)
+        tr = Trainer(model, lr=1e-4, clip=0.5, process_group=dist.group.WORLD, bucket_bytes=8 << 20, force_dp=True)
+        assert tr.dp and tr.world == 1
+        tr.step(x, m); tr.step(x, m)                  # pass 1 counts contributions, pass 2 sends buckets from inside backward (eager RCCL calls)
+        torch.cuda.synchronize()
+        order = list(tr.buckets.order)
+        tr.capture(x, m, warmup=2)
+        tr.replay(); loss = tr.replay()
+        torch.cuda.synchronize()
+        segs = [bs for _, bs in tr._cur.segments]
+        assert len(segs) >= 3 and [b for bs in segs for b in bs] == order, (segs, order)
+        dp_flat = tr.flat.clone(); dp_loss = loss.clone()
+        # the same six steps without a process group
+        model2, _ = _setup("res2net", False)
+        tr2 = Trainer(model2, lr=1e-4, clip=0.5)
+        assert not tr2.dp
+        tr2.step(x, m); tr2.step(x, m)
+        tr2.capture(x, m, warmup=2)
+        tr2.replay(); loss2 = tr2.replay()
+        torch.cuda.synchronize()
+        if wire == "fp32":
+            same = bool(torch.equal(dp_flat, tr2.flat)) and bool(torch.equal(dp_loss, loss2))
+            info = float((dp_flat - tr2.flat).abs().max())
+        else:           # gradients rounded to bf16 on the wire: Adam's update direction is (almost) unchanged, weights agree to ~lr per step
+            info = float((dp_flat - tr2.flat).abs().max())
+            same = info < 6 * 2e-4 and abs(float(dp_loss[-1]) - float(loss2[-1])) < 5e-2 * abs(float(loss2[-1]))
+        # a second data-parallel trainer in the same process (its own buckets, segments and collectives on the same communicator)
+        model3, _ = _setup("res2net", False)
+        tr3 = Trainer(model3, lr=1e-4, clip=0.5, process_group=dist.group.WORLD, bucket_bytes=8 << 20, force_dp=True)
+        tr3.step(x, m); tr3.step(x, m)
+        tr3.capture(x, m, warmup=2)
+        tr3.replay(); tr3.replay(); tr.replay()
+        torch.cuda.synchronize()
+        same3 = bool(torch.equal(tr3.flat, dp_flat)) if wire == "fp32" else True
+        q.put(("OK", same, same3, info, len(segs), len(tr.buckets.buckets), dist.get_backend()))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(("ERROR", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_rccl_one_rank_dp_path_is_bit_identical_to_local(wire):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31600 + (os.getpid() + (3 if wire == "bf16" else 0)) % 2000
+    p = ctx.Process(target=_rccl_worker, args=(port, q, wire))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(60)
+    assert res[0] == "OK", res[1]
+    _, same, same3, info, nseg, nb, backend = res
+    print(f"RCCL 1-rank [{wire}]: backend {backend}, {nb} buckets, {nseg} graph segments, max |w_dp - w_local| {info:.2e}")
+    assert backend == "nccl"
+    assert same, f"data-parallel path over RCCL differs from the local trainer (max weight difference {info:.3e})"
+    assert same3, "a second data-parallel trainer in the same process diverged"

@@ -266,3 +266,53 @@ def test_input_transform_oracle_matches_pillow_vectors():
             assert np.array_equal(t, z[n + ".tensor"]), n
     _, g = I.train_transform(z["down.in"], z["gt.in"], 96)
     assert np.array_equal(g, z["gt.tensor"])
+
+
+def _cond_weights(z, calibrated):
+    """Conditioned weights of tests/golden/make_golden_cond.py (bn3 gamma x 0.05), optionally with the calibrated running statistics."""
+    P = W.make_state_dict(W.manifest_pranet_v2(1), seed=0, bn3_gamma=float(z["bn3_gamma"]))
+    if calibrated:
+        for f in z.files:
+            if f.startswith("calib."):
+                P[f[6:]] = T(z[f]).clone()
+    return P
+
+
+def test_conditioned_fixture_oracle_train_and_eval():
+    """The oracle against the CONDITIONED reference vectors (pranet_v2_cond.npz): there the reference's own fp32 and float64 runs agree to
+    ~2e-5 on the logits, so north_star's literal '1e-4 abs on fp32 logits / Dice within 1e-3' is what is asserted - train mode (8 x 96^2:
+    logits, losses, gradient probes) and eval mode with calibrated BatchNorm statistics (1 x 352^2, 2 x 96^2: logits, uint8 map, meanDic)."""
+    z = np.load(os.path.join(G, "pranet_v2_cond.npz"))
+    assert float(np.max(z["t96.own_abs"])) < 3e-5 and float(np.max(z["e352.own_abs"])) < 5e-5      # the fixture is well-conditioned (reference vs itself)
+    P = _cond_weights(z, False)
+    x, mask = W.synthetic_batch(int(z["t96.n"]), int(z["t96.size"]), seed=4242)
+    for k in O.params_of(P):
+        P[k].requires_grad_(True)
+    outs = O.pranet_v2_forward(P, x, True)
+    losses = [O.structure_loss(outs[i], outs[i + 4], mask, 1 - mask) for i in range(4)]
+    (losses[3] + losses[2] + losses[1] + losses[0]).backward()
+    assert np.abs(np.array([float(l) for l in losses]) - z["t96.losses"]).max() < 1e-5
+    for i, o in enumerate(outs):
+        assert float((o.detach() - T(z[f"t96.out{i}"])).abs().max()) < 1e-4, i              # LITERAL north_star bound, against the reference's fp32 logits
+        assert float((o.detach()[:, :, ::2, ::2].double() - T(z[f"t96.f64.out{i}"])).abs().max()) < 1e-4, i
+    for f in z.files:
+        if f.startswith("t96.graw."):
+            k = f[9:]
+            r32, r64 = T(z[f]).double(), T(z["t96.f64.graw." + k]).double()
+            got = P[k].grad.reshape(-1)[:256].double()
+            own = float((r32 - r64).norm() / (r64.norm() + 1e-30))
+            e = float((got - r64).norm() / (r64.norm() + 1e-30))
+            assert e <= max(1e-5, 3 * own), (k, e, own)                                      # two fp32 evaluations of the same graph
+    assert sorted(k for k in O.params_of(P) if P[k].grad is None) == sorted(str(s) for s in z["t96.nograd"])
+    # eval mode, calibrated running statistics (MyTest_med.py:98-111)
+    Pc = _cond_weights(z, True)
+    for tag in ("e96", "e352"):
+        n, size, s32 = int(z[f"{tag}.n"]), int(z[f"{tag}.size"]), int(z[f"{tag}.stride32"])
+        x, mask = W.synthetic_batch(n, size, seed=4242)
+        with torch.no_grad():
+            outs = O.pranet_v2_forward(Pc, x, False)
+        for i, o in enumerate(outs):
+            assert float((o[:, :, ::s32, ::s32] - T(z[f"{tag}.out{i}"])).abs().max()) < 1e-4, (tag, i)
+        u8 = O.test_postprocess([o[:1] for o in outs], tuple(z[f"{tag}.u8"].shape))
+        assert np.abs(u8.astype(int) - z[f"{tag}.u8"].astype(int)).max() <= 1
+        assert abs(O.mean_dice(u8, z[f"{tag}.gt"]) - float(z[f"{tag}.meanDic"])) < 1e-3
