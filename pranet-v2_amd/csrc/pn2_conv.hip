@@ -1088,11 +1088,18 @@ template <typename T, int BMC, int BNK, int WM, int WN, bool PW>
 __global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ slab, pn2_wgrad_desc d, int nsplit) {
     conv_wgrad_body<T, BMC, BNK, WM, WN, PW>(dy, x, slab, d, nsplit, blockIdx.x);
 }
+// Table launches walk the job table with a grid stride: with gridDim.x == total blocks every workgroup runs one (job, block) pair as before; a
+// NARROWER grid (wgrad_grid(): a multiple of 8, so that b % 8 stays the XCD the workgroup runs on) makes the launch persistent - it then occupies
+// a bounded share of every CU and can run on a side stream next to the latency-bound backward chain without starving it (Trainer WGRAD_OVERLAP).
 template <typename T, int BMC, int BNK, int WM, int WN, bool PW>
 __global__ __launch_bounds__(256) void conv_wgrad_tab(const pn2_wgrad_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
-    const int jb = find_job(bstart, njobs, blockIdx.x);
-    const pn2_wgrad_job j = jobs[jb];
-    conv_wgrad_body<T, BMC, BNK, WM, WN, PW>((const T*)j.dy, (const T*)j.x, j.slab, j.d, j.nsplit, blockIdx.x - bstart[jb]);
+    const int total = bstart[njobs];
+    for (int b = blockIdx.x; b < total; b += gridDim.x) {
+        const int jb = find_job(bstart, njobs, b);
+        const pn2_wgrad_job j = jobs[jb];
+        conv_wgrad_body<T, BMC, BNK, WM, WN, PW>((const T*)j.dy, (const T*)j.x, j.slab, j.d, j.nsplit, b - bstart[jb]);
+        __syncthreads();            // the next pair restages LDS
+    }
 }
 template <int BMC, int WM, int WN, bool PW>
 __global__ __launch_bounds__(256) void conv_wgrad_dma(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ slab, pn2_wgrad_desc d, int nsplit) {
@@ -1100,9 +1107,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const bf16_t* __restrict__
 }
 template <int BMC, int WM, int WN, bool PW>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_tab(const pn2_wgrad_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
-    const int jb = find_job(bstart, njobs, blockIdx.x);
-    const pn2_wgrad_job j = jobs[jb];
-    conv_wgrad_dma_body<BMC, WM, WN, PW>((const bf16_t*)j.dy, (const bf16_t*)j.x, j.slab, j.d, j.nsplit, blockIdx.x - bstart[jb]);
+    const int total = bstart[njobs];
+    for (int b = blockIdx.x; b < total; b += gridDim.x) {
+        const int jb = find_job(bstart, njobs, b);
+        const pn2_wgrad_job j = jobs[jb];
+        conv_wgrad_dma_body<BMC, WM, WN, PW>((const bf16_t*)j.dy, (const bf16_t*)j.x, j.slab, j.d, j.nsplit, b - bstart[jb]);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1525,12 +1536,19 @@ int wgrad_dispatch(const void* dy, const void* x, float* slab, const pn2_wgrad_d
     return launch_wgrad<T, 32, 1, 4>(dy, x, slab, d, nsplit, st);
 }
 
+// PN2_WGRAD_GRID=<n>: cap the grid of the table-driven wgrad launches at n workgroups (rounded up to a multiple of 8); 0 = one workgroup per block
+inline int wgrad_grid(int total) {
+    static const int cap = [] { const char* e = getenv("PN2_WGRAD_GRID"); return e ? atoi(e) : 0; }();
+    if (cap <= 0 || total <= cap) return total;
+    return (cap + 7) / 8 * 8;
+}
+
 template <typename T, int BMC, int WM, int WN>
 int launch_wgrad_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
     constexpr int BNK = 128;
     constexpr int lds = 2 * WGP * (BMC * (int)sizeof(T) + WG<T>::PAD + BNK * (int)sizeof(T) + WG<T>::PAD);
-    if (pw) hipLaunchKernelGGL((conv_wgrad_tab<T, BMC, BNK, WM, WN, true>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
-    else hipLaunchKernelGGL((conv_wgrad_tab<T, BMC, BNK, WM, WN, false>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
+    if (pw) hipLaunchKernelGGL((conv_wgrad_tab<T, BMC, BNK, WM, WN, true>), dim3(wgrad_grid(total)), dim3(256), lds, st, jobs, bstart, njobs);
+    else hipLaunchKernelGGL((conv_wgrad_tab<T, BMC, BNK, WM, WN, false>), dim3(wgrad_grid(total)), dim3(256), lds, st, jobs, bstart, njobs);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -1546,8 +1564,8 @@ int launch_wgrad_dma_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, 
             done = true;
         }
     }
-    if (pw) hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, true>), dim3(total), dim3(256), max_b, st, jobs, bstart, njobs);
-    else hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, false>), dim3(total), dim3(256), max_b, st, jobs, bstart, njobs);
+    if (pw) hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, true>), dim3(wgrad_grid(total)), dim3(256), max_b, st, jobs, bstart, njobs);
+    else hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, false>), dim3(wgrad_grid(total)), dim3(256), max_b, st, jobs, bstart, njobs);
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -328,6 +328,8 @@ DEFER_COLSUM = os.environ.get("PN2_DEFER_COLSUM", "1") == "1"
 SMALL_CIN_DGRAD = os.environ.get("PN2_SMALL_CIN_DGRAD", "1") == "1"  # strided convs with <= 4 input channels: per-pixel data gradient
 GRAD_ALIAS = os.environ.get("PN2_GRAD_ALIAS", "1") == "1"             # sums whose second operand has no other consumer share its gradient storage
 SPLITK = os.environ.get("PN2_SPLITK", "1") == "1"                     # split-K for few-row / long-contraction convs
+KSPLIT_MINK = int(os.environ.get("PN2_KSPLIT_MINK", "4096"))         # shortest contraction that is split (M <= 4096 rows)
+KSPLIT_MID = int(os.environ.get("PN2_KSPLIT_MID", "2"))              # split factor for contractions below 4096
 PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
@@ -791,9 +793,9 @@ class Engine:
         """Split-K factor for a conv GEMM with M output rows and contraction K (bf16 LDS-DMA kernels only).  Measured on cold operands
         (tools/splitk_micro.py): 4 pays for K >= 4096 with M <= 4096 (5x5, 256 channels, 11x11 maps: 66 -> 49 us); shorter contractions lose
         to the partial-tile traffic."""
-        if not SPLITK or self.dt != BF16 or K < 4096 or M > 4096 or Cout_p % 8:
+        if not SPLITK or self.dt != BF16 or K < KSPLIT_MINK or M > 4096 or Cout_p % 8:
             return 1
-        return 4
+        return 4 if K >= 4096 else KSPLIT_MID
 
     def _stat_blocks(self, M, Cout, tune):
         bm = (tune >> 2) & 3
