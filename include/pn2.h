@@ -172,6 +172,14 @@ int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int 
  * written by the pass that produces sp.  16-byte aligned rows only (-2 otherwise). */
 int pn2_affine_act_sum(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* scale, const float* shift, int relu,
                        const void* add, int ld_add, void* y2, int ld_y2, void* stream);
+/* pn2_bn_finalize + pn2_affine_act (+ the second output of pn2_affine_act_sum when add / y2 are given) in ONE launch: the train-mode forward of
+ * nn.BatchNorm2d + ReLU (+ residual) behind a conv (Res2Net_v1b.py:60-63,70-72,84-89 ; pranet.py:40-43) for layers whose statistics arrive as few
+ * partial rows.  A workgroup owns 64 channels x a row block, merges only its channels' partial rows and then normalises its rows; the
+ * (scale, shift, mean, invstd) rows and the running statistics are written exactly as pn2_bn_finalize writes them.  Same dtype in / out, 16-byte
+ * aligned rows, per-tile (mean, M2) partials (d->tile_rows > 0): -2 otherwise. */
+int pn2_bn_finalize_affine(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* psum, const float* psq, int nblk, const pn2_bn_desc* d,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd,
+                           const void* res, int ld_res, int relu, const void* add, int ld_add, void* y2, int ld_y2, void* stream);
 /* backward pass 1: per-channel partials of sum(dz) and sum(dz*xhat), dz = dy*(relu mask) ; dy has Cdy valid channels.
  * ReLU mask: y>0 when y is given; else recomputed as fmaf(x,mask_scale,mask_shift)>0 when mask_scale is given (saves reading y). */
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,

@@ -924,10 +924,13 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
 #endif
 // pixels per ring stage of the LDS-DMA wgrad kernel: 32-pixel stages (48 KB ring) leave room for three workgroups per CU
 constexpr int wg_px(int bmc) { return bmc >= 64 ? PN2_WG_PX : 64; }
-template <int BMC, int WM, int WN, bool PW>
+// BNK = 256 (co tile 128 only): every dy tile is staged once per 256 instead of once per 128 contraction columns.  The kernel runs at the
+// throughput of the L2 -> LDS DMA path (~14 TB/s over the chip: 16 GB of tile traffic for 2.7 GB of operands in the pointwise launch of a step), so
+// what helps is fewer bytes per flop: (BMC + BNK) / (BMC * BNK) = 1/64 -> 1/85.  The wave tile becomes 64 x 128 (128 accumulator registers).
+template <int BMC, int WM, int WN, bool PW, int BNK = 128>
 __device__ __forceinline__ void conv_wgrad_dma_body(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ slab,
                                                     const pn2_wgrad_desc& d, int nsplit, int bloc) {
-    constexpr int BNK = 128, PX = wg_px(BMC), NS = 3;
+    constexpr int PX = wg_px(BMC), NS = 3;
     constexpr int WTM = BMC / WM, WTN = BNK / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int RBY = BMC * 2, RBX = BNK * 2;              // row bytes
     constexpr int CHY = BMC / 8, CHX = BNK / 8;              // 16-byte chunks per row
@@ -942,7 +945,7 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const bf16_t* __restrict__ d
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
     const int M = d.N * d.OH * d.OW;
-    const int tk = d.Kp / BNK;
+    const int tk = (d.Kp + BNK - 1) / BNK;
     const int ntile = (d.Rp / BMC) * tk;
     const int xcd = bloc & 7, jx = bloc >> 3;
     const int split = xcd + 8 * (jx / ntile), tile = jx % ntile;
@@ -1077,10 +1080,12 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const bf16_t* __restrict__ d
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+            if (BNK > 128 && k0 + wn * WTN + j * 16 >= d.Kp) continue;          // Kp is a multiple of 128: the last 256-wide tile may be half empty
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 dst[(size_t)(wm * WTM + i * 16 + g * 4 + r) * d.Kp + wn * WTN + j * 16 + l15] = acc[i][j][r];
+        }
 }
 
 // single-conv and table-driven (many convs, one launch) entry points of the two wgrad kernels
@@ -1101,17 +1106,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_tab(const pn2_wgrad_job* __res
         __syncthreads();            // the next pair restages LDS
     }
 }
-template <int BMC, int WM, int WN, bool PW>
+template <int BMC, int WM, int WN, bool PW, int BNK = 128>
 __global__ __launch_bounds__(256) void conv_wgrad_dma(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ slab, pn2_wgrad_desc d, int nsplit) {
-    conv_wgrad_dma_body<BMC, WM, WN, PW>(dy, x, slab, d, nsplit, blockIdx.x);
+    conv_wgrad_dma_body<BMC, WM, WN, PW, BNK>(dy, x, slab, d, nsplit, blockIdx.x);
 }
-template <int BMC, int WM, int WN, bool PW>
+template <int BMC, int WM, int WN, bool PW, int BNK = 128>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_tab(const pn2_wgrad_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
     const int total = bstart[njobs];
     for (int b = blockIdx.x; b < total; b += gridDim.x) {
         const int jb = find_job(bstart, njobs, b);
         const pn2_wgrad_job j = jobs[jb];
-        conv_wgrad_dma_body<BMC, WM, WN, PW>((const bf16_t*)j.dy, (const bf16_t*)j.x, j.slab, j.d, j.nsplit, b - bstart[jb]);
+        conv_wgrad_dma_body<BMC, WM, WN, PW, BNK>((const bf16_t*)j.dy, (const bf16_t*)j.x, j.slab, j.d, j.nsplit, b - bstart[jb]);
         __syncthreads();
     }
 }
@@ -1475,48 +1480,55 @@ int gemm_multi_dispatch(int dtype, int bm, int bn, const pn2_conv_job* jobs, con
     return -3;
 }
 
-template <int BMC, int WM, int WN>
+template <int BMC, int WM, int WN, int BNK = 128>
 int launch_wgrad_dma(const void* dy, const void* x, float* slab, const pn2_wgrad_desc& d, int nsplit, hipStream_t st) {
-    constexpr int PX = wg_px(BMC), stage_b = PX * (BMC * 2 + 256), max_b = 3 * stage_b;
+    constexpr int PX = wg_px(BMC), stage_b = PX * (BMC * 2 + BNK * 2), max_b = 3 * stage_b;
     const int M = d.N * d.OH * d.OW;
     const int total_steps = (M + PX - 1) / PX, spb = (total_steps + nsplit - 1) / nsplit;
     const int lds = (spb < 3 ? (spb < 1 ? 1 : spb) : 3) * stage_b;
-    const int grid = 8 * ((nsplit + 7) / 8) * (d.Rp / BMC) * (d.Kp / 128);
+    const int grid = 8 * ((nsplit + 7) / 8) * (d.Rp / BMC) * ((d.Kp + BNK - 1) / BNK);
     const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
     if (max_b > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma<BMC, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma<BMC, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma<BMC, WM, WN, true, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma<BMC, WM, WN, false, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
             done = true;
         }
     }
-    if (pw) hipLaunchKernelGGL((conv_wgrad_dma<BMC, WM, WN, true>), dim3(grid), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, slab, d, nsplit);
-    else hipLaunchKernelGGL((conv_wgrad_dma<BMC, WM, WN, false>), dim3(grid), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, slab, d, nsplit);
+    if (pw) hipLaunchKernelGGL((conv_wgrad_dma<BMC, WM, WN, true, BNK>), dim3(grid), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, slab, d, nsplit);
+    else hipLaunchKernelGGL((conv_wgrad_dma<BMC, WM, WN, false, BNK>), dim3(grid), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, slab, d, nsplit);
     PN2_CHECK_LAUNCH();
     return 0;
 }
 
 inline bool wgrad_pw(const pn2_wgrad_desc& d) { return d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0; }
 
-// kernel instantiation a wgrad job runs on: dma * 6 + (co tile 32/64/128 -> 0/1/2) * 2 + pointwise
+// kernel instantiation a wgrad job runs on: dma * 6 + (co tile 32/64/128 -> 0/1/2) * 2 + pointwise; 12 + pointwise: the DMA kernel with 128 x 256 tiles
+// (d.tune == 3, and d.tune == 2 too unless PN2_WGRAD_BNK256=0: the per-shape tuner times a wgrad alone, where its pixel splits fill the chip and the
+// narrower tile wins; inside the table-driven launch of a step the chip is full anyway and the wide tile's smaller L2 -> LDS traffic wins: 15.62 -> 15.52 ms)
 template <typename T>
 int wgrad_variant(const pn2_wgrad_desc& d) {
     const int bmc = pn2_wgrad_tile_co(d.Cout_p);
-    bool dma = false;
+    bool dma = false, wide = false;
     if constexpr (sizeof(T) == 2) {
         static const bool on = [] { const char* e = getenv("PN2_WGRAD_DMA"); return !(e && e[0] == '0'); }();
-        // default: the DMA pipeline pays off for pointwise convs with many pixels; d.tune (1 register-staged, 2 DMA) overrides
-        dma = d.tune ? d.tune == 2 : (on && wgrad_pw(d) && d.N * d.OH * d.OW >= 8192);
+        static const bool force256 = [] { const char* e = getenv("PN2_WGRAD_BNK256"); return !(e && e[0] == '0'); }();
+        // default: the DMA pipeline pays off for pointwise convs with many pixels; d.tune (1 register-staged, 2 DMA, 3 DMA with 256-wide K tiles) overrides
+        dma = d.tune ? d.tune >= 2 : (on && wgrad_pw(d) && d.N * d.OH * d.OW >= 8192);
         // the DMA kernel addresses both operands with 32-bit byte offsets (buffer descriptors): extents below 2 GB
         if ((size_t)d.N * d.OH * d.OW * d.ld_dy * 2 >= 0x80000000ull || (size_t)d.N * d.H * d.W * d.ld_x * 2 >= 0x80000000ull) dma = false;
+        wide = dma && bmc == 128 && d.Kp >= 256 && (d.tune == 3 || (force256 && d.tune == 2));
     }
+    if (wide) return 12 + (wgrad_pw(d) ? 1 : 0);
     return (dma ? 6 : 0) + (bmc == 128 ? 2 : (bmc == 64 ? 1 : 0)) * 2 + (wgrad_pw(d) ? 1 : 0);
 }
 
-inline int wgrad_blocks(const pn2_wgrad_desc& d, int nsplit) {
+template <typename T>
+inline int wgrad_blocks_t(const pn2_wgrad_desc& d, int nsplit) {
     const int bmc = pn2_wgrad_tile_co(d.Cout_p);
-    return 8 * ((nsplit + 7) / 8) * (d.Rp / bmc) * (d.Kp / 128);
+    const int bnk = wgrad_variant<T>(d) >= 12 ? 256 : 128;
+    return 8 * ((nsplit + 7) / 8) * (d.Rp / bmc) * ((d.Kp + bnk - 1) / bnk);
 }
 
 template <typename T>
@@ -1525,6 +1537,7 @@ int wgrad_dispatch(const void* dy, const void* x, float* slab, const pn2_wgrad_d
     if (d.Rp % bmc || d.Kp % 128) return -2;
     const int v = wgrad_variant<T>(d);
     if constexpr (sizeof(T) == 2) {
+        if (v >= 12) return launch_wgrad_dma<128, 2, 2, 256>(dy, x, slab, d, nsplit, st);
         if (v >= 6) {
             if (bmc == 128) return launch_wgrad_dma<128, 2, 2>(dy, x, slab, d, nsplit, st);
             if (bmc == 64) return launch_wgrad_dma<64, 2, 2>(dy, x, slab, d, nsplit, st);
@@ -1553,19 +1566,19 @@ int launch_wgrad_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, int 
     return 0;
 }
 
-template <int BMC, int WM, int WN>
+template <int BMC, int WM, int WN, int BNK = 128>
 int launch_wgrad_dma_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
-    constexpr int max_b = 3 * wg_px(BMC) * (BMC * 2 + 256);
+    constexpr int max_b = 3 * wg_px(BMC) * (BMC * 2 + BNK * 2);
     if (max_b > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab<BMC, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab<BMC, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab<BMC, WM, WN, true, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab<BMC, WM, WN, false, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
             done = true;
         }
     }
-    if (pw) hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, true>), dim3(wgrad_grid(total)), dim3(256), max_b, st, jobs, bstart, njobs);
-    else hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, false>), dim3(wgrad_grid(total)), dim3(256), max_b, st, jobs, bstart, njobs);
+    if (pw) hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, true, BNK>), dim3(wgrad_grid(total)), dim3(256), max_b, st, jobs, bstart, njobs);
+    else hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, false, BNK>), dim3(wgrad_grid(total)), dim3(256), max_b, st, jobs, bstart, njobs);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -1574,6 +1587,10 @@ template <typename T>
 int wgrad_multi_dispatch(int v, const pn2_wgrad_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
     const bool pw = v & 1;
     const int bi = (v % 6) >> 1;
+    if (v >= 12) {
+        if constexpr (sizeof(T) == 2) return launch_wgrad_dma_tab<128, 2, 2, 256>(pw, jobs, bstart, njobs, total, st);
+        return -3;
+    }
     if (v >= 6) {
         if constexpr (sizeof(T) == 2) {
             if (bi == 2) return launch_wgrad_dma_tab<128, 2, 2>(pw, jobs, bstart, njobs, total, st);
@@ -1858,11 +1875,11 @@ int pn2_conv_wgrad_blocks(const pn2_wgrad_desc* d, int nsplit) {
     if (!d || nsplit < 1) return -1;
     const int bmc = pn2_wgrad_tile_co(d->Cout_p);
     if (d->Rp % bmc || d->Kp % 128) return -2;
-    return wgrad_blocks(*d, nsplit);
+    return wgrad_blocks_t<bf16_t>(*d, nsplit);      // (d->tune 2 / 3 only ever come from the bf16 tuner: an fp32 desc never selects the wide tile)
 }
 
 int pn2_conv_wgrad_multi(int dtype, int variant, const pn2_wgrad_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
-    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1 || variant < 0 || variant >= 12) return -1;
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1 || variant < 0 || variant >= 14) return -1;
     if (dtype == PN2_BF16) return wgrad_multi_dispatch<bf16_t>(variant, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
     if (dtype == PN2_F32) return wgrad_multi_dispatch<float>(variant, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
     return -3;

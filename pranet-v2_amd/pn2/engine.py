@@ -337,6 +337,7 @@ BNB_MIN_COLS = int(os.environ.get("PN2_BNB_MIN_COLS", "0"))          # experimen
 LOCKSTEP_TILES = os.environ.get("PN2_LOCKSTEP_TILES", "0") == "1"   # opt-in: canonical conv tiles inside lock-step regions (measured: no more shared launches, same speed)
 LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
+FUSE_FIN = int(os.environ.get("PN2_FUSE_FIN", "256"))               # BatchNorm finalisation inside the normalise pass (pn2_bn_finalize_affine) for layers with <= this many partial rows; 0: off
 
 
 class GradQueue:
@@ -805,8 +806,8 @@ class Engine:
         return call.pn2_conv_stat_blocks(M, Cout, self.dt)
 
     def _tune_wgrad(self, wd, dy_ptr, x_ptr, rd, nsplit, wshape):
-        """-> (kernel code, pixel splits) for this wgrad shape.  Candidates: register-staged / LDS-DMA kernel x {1, 1/2, 1/4, 1/8} of
-        the heuristic split count; each is timed together with the slab reduction its split count implies."""
+        """-> (kernel code, pixel splits) for this wgrad shape.  Candidates: register-staged / LDS-DMA / LDS-DMA with 128 x 256 tiles x
+        {1, 1/2, 1/4, 1/8} of the heuristic split count; each is timed together with the slab reduction its split count implies."""
         t = self.tuner
         if t is None or self.dt != BF16:
             return 0, nsplit
@@ -823,7 +824,8 @@ class Engine:
         st = _stream()
         slab = torch.empty((nsplit, wd.Rp, wd.Kp), dtype=torch.float32, device=self.dev)
         gw = torch.empty(tuple(wshape), dtype=torch.float32, device=self.dev)
-        cands = [(code, ns) for ns in sorted({max(1, nsplit >> k) for k in range(4)}, reverse=True) for code in (1, 2)]
+        codes = (1, 2, 3) if (call.pn2_wgrad_tile_co(wd.Cout_p) == 128 and wd.Kp >= 256) else (1, 2)      # 3: LDS-DMA kernel with 128 x 256 tiles
+        cands = [(code, ns) for ns in sorted({max(1, nsplit >> k) for k in range(4)}, reverse=True) for code in codes]
         evs = []
 
         def run(code, ns):
@@ -947,6 +949,7 @@ class Engine:
 
         scale = shift = mean = invstd = par = None
         bd = None
+        fuse_fin = False
         if bn is not None:
             bd = capi.BnDesc()
             bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, Cout_p, Cout, gw_o, gwp_o, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
@@ -956,8 +959,15 @@ class Engine:
             scale, shift = par[0], par[1]
             if train_bn:
                 mean, invstd = par[2], par[3]
-                call.pn2_bn_finalize(_p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
-                                     _p(scale), _p(shift), _p(mean), _p(invstd), st)
+                # few partial rows (everything from layer3 down): the finalisation runs inside the normalise pass below - one launch instead of two.
+                # Not inside a lock-step region (its finalisations / normalise passes are already shared table-driven launches).
+                from . import lockstep as LS_
+                fuse_fin = (0 < nblk <= FUSE_FIN and tile_rows > 0 and ksplit == 1 and not fuse_bias and bias is None and y_C is None
+                            and (y_dt is None or y_dt == self.dt) and Cout_p % V == 0 and raw_ld % V == 0 and not LS_._ACTIVE
+                            and (out is None or out.ld % V == 0) and (residual is None or residual.ld % V == 0))
+                if not fuse_fin:
+                    call.pn2_bn_finalize(_p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+                                         _p(scale), _p(shift), _p(mean), _p(invstd), st)
                 self.bn_modules.append(bn)
                 if bias is not None:          # biased conv followed by train-mode BN: the output is unchanged, only the running mean sees the bias
                     with torch.no_grad():
@@ -986,13 +996,24 @@ class Engine:
         if sum_with is not None and (fuse_bias or residual is not None or y_dt != self.dt or ncopy != Cout_p or sum_with.dt != self.dt
                                      or (sum_with.N, sum_with.H, sum_with.W, sum_with.Cp) != (N, OH, OW, Cout_p) or out.ld % 8 or sum_with.ld % 8):
             raise RuntimeError("sum_with needs a plain same-dtype BN/activation output of the same geometry")
+        nul_ = C.c_void_p(0)
         if sum_with is not None:
             y2 = Act(self, self.empty(N, OH, OW, Cout_p), Cout, gw_o, gwp_o, self.dt)
-            call.pn2_affine_act_sum(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, Cout_p, _p(scale), _p(shift), (2 if relu == 2 else 1) if relu else 0,
-                                    sum_with.ptr, sum_with.ld, y2.ptr, y2.ld, st)
+            if fuse_fin:
+                call.pn2_bn_finalize_affine(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, Cout_p, _p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias),
+                                            _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), _p(mean), _p(invstd), nul_, 0,
+                                            (2 if relu == 2 else 1) if relu else 0, sum_with.ptr, sum_with.ld, y2.ptr, y2.ld, st)
+            else:
+                call.pn2_affine_act_sum(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, Cout_p, _p(scale), _p(shift), (2 if relu == 2 else 1) if relu else 0,
+                                        sum_with.ptr, sum_with.ld, y2.ptr, y2.ld, st)
             if self.need_grad and sum_with.requires_grad:
                 y2.galias = sum_with            # d(y + s)/ds = 1 and s has no other consumer: the sum's gradient lives in s's gradient storage
                 y2.sum_of = (out, sum_with)
+        elif fuse_fin:
+            call.pn2_bn_finalize_affine(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, ncopy, _p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias),
+                                        _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), _p(mean), _p(invstd),
+                                        residual.ptr if residual is not None else nul_, residual.ld if residual is not None else 0,
+                                        (2 if relu == 2 else 1) if relu else 0, nul_, 0, nul_, 0, st)
         elif not fuse_bias:
             call.pn2_affine_act(self.dt, _p(raw), raw_ld, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
                                 residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)

@@ -95,6 +95,8 @@ def test_conv_kernels_agree_and_match_float64(geom, transposed):
 
 
 WGEOMS = [
+    (2, 11, 13, 272, 136, 1, 1, 1, 0, 0, 1),        # co tile 128 x 2, Kp = 384: a full and a half-empty 256-wide contraction tile
+    (2, 9, 10, 40, 200, 3, 3, 1, 1, 1, 1),          # 3x3, co tile 128, Kp = 384
     (2, 11, 13, 72, 40, 1, 1, 1, 0, 0, 1),
     (2, 11, 13, 104, 104, 3, 3, 1, 1, 1, 1),
     (2, 12, 12, 32, 32, 3, 3, 1, 3, 3, 3),
@@ -135,7 +137,7 @@ def test_wgrad_kernels_agree_and_match_float64(geom):
     rd.Rp, rd.Kp, rd.transposed = wd.Rp, wd.Kp, 0
     xg, dyg = x.to(dev), dy.to(dev)
     res = {}
-    for tune in (1, 2):
+    for tune in (1, 2, 3):          # 3: the LDS-DMA kernel with 128 x 256 tiles (co tile 128 and >= 256 contraction columns; otherwise it IS kernel 2)
         for ns in (1, 3):
             wd.tune = tune
             slab = torch.full((ns, wd.Rp, wd.Kp), float("nan"), dtype=torch.float32, device=dev)
