@@ -480,6 +480,29 @@ __global__ __launch_bounds__(256) void bn_fin_affine_k(const T* __restrict__ x, 
     __shared__ __attribute__((aligned(16))) float par[2][FCG];
     const int cg = blockIdx.x % ngroups, rb = blockIdx.x / ngroups;
     const int c0 = cg * FCG;
+    // geometry of the normalise pass; its first batch of rows is requested BEFORE the statistics are merged, so that the two memory round trips of
+    // this kernel (partial rows, activation rows) overlap instead of following each other
+    constexpr int CVP = FCG / V, R = 256 / CVP;
+    const int CV = C / V;
+    const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int cv = cg * CVP + cvl;
+    const bool act = cv < CV;
+    const int c = cv * V;
+    const int r0 = rb * rows_per_blk;
+    int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
+    uint4 vx[RU], vr[RU], va[RU];
+#define PN2_FA_LOAD(m_)                                                                                                \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < RU; ++u) {                                                               \
+            const int mm_ = (m_) + u * R;                                                                              \
+            if (mm_ < r1) {                                                                                            \
+                vx[u] = *reinterpret_cast<const uint4*>(x + (size_t)mm_ * ld_x + c);                                   \
+                if (res) vr[u] = *reinterpret_cast<const uint4*>(res + (size_t)mm_ * ld_res + c);                      \
+                if (y2) va[u] = *reinterpret_cast<const uint4*>(add + (size_t)mm_ * ld_add + c);                       \
+            }                                                                                                          \
+        }                                                                                                              \
+    } while (0)
+    if (act) { PN2_FA_LOAD(r0 + rl); }
     // ---- phase 1: (mean, var) of this group's channels from the conv epilogue's per-tile (mean, M2) rows
     {
         const int q = threadIdx.x & 15, rl = threadIdx.x >> 4, cq = c0 + q * 4;
@@ -551,28 +574,12 @@ __global__ __launch_bounds__(256) void bn_fin_affine_k(const T* __restrict__ x, 
         __syncthreads();
     }
     // ---- phase 2: y = act(x * scale + shift + res) over this workgroup's rows of the group (affine_rows_body restricted to one channel group)
-    constexpr int CVP = FCG / V, R = 256 / CVP;
-    const int CV = C / V;
-    const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int cv = cg * CVP + cvl;
-    if (cv >= CV) return;
-    const int c = cv * V;
-    const int r0 = rb * rows_per_blk;
-    int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
+    if (!act) return;
     float sc[V], sh[V];
     ldpar<V>(&par[0][cvl * V], sc);
     ldpar<V>(&par[1][cvl * V], sh);
     for (int m = r0 + rl; m < r1; m += R * RU) {
-        uint4 vx[RU], vr[RU], va[RU];
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const int mm = m + u * R;
-            if (mm < r1) {
-                vx[u] = *reinterpret_cast<const uint4*>(x + (size_t)mm * ld_x + c);
-                if (res) vr[u] = *reinterpret_cast<const uint4*>(res + (size_t)mm * ld_res + c);
-                if (y2) va[u] = *reinterpret_cast<const uint4*>(add + (size_t)mm * ld_add + c);
-            }
-        }
+        if (m != r0 + rl) { PN2_FA_LOAD(m); }          // (the first batch was requested before the statistics were merged)
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const int mm = m + u * R;
@@ -599,6 +606,7 @@ __global__ __launch_bounds__(256) void bn_fin_affine_k(const T* __restrict__ x, 
             }
         }
     }
+#undef PN2_FA_LOAD
 }
 
 // LEAN: the common form inside a training step - ReLU mask recomputed from the raw conv output (or none), no stored y, no residual gradient: the

@@ -337,7 +337,11 @@ BNB_MIN_COLS = int(os.environ.get("PN2_BNB_MIN_COLS", "0"))          # experimen
 LOCKSTEP_TILES = os.environ.get("PN2_LOCKSTEP_TILES", "0") == "1"   # opt-in: canonical conv tiles inside lock-step regions (measured: no more shared launches, same speed)
 LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
-FUSE_FIN = int(os.environ.get("PN2_FUSE_FIN", "256"))               # BatchNorm finalisation inside the normalise pass (pn2_bn_finalize_affine) for layers with <= this many partial rows; 0: off
+# BatchNorm finalisation inside the normalise pass (pn2_bn_finalize_affine) for layers with <= this many partial rows; 0: off (default).  MEASURED NULL
+# (round 3): with 256, 42 of the 84 pn2_bn_finalize launches of a step disappear (739 -> 697 graph nodes) and the step time does not move (15.456 vs
+# 15.456 ms, rocprof: finalize 532 -> 322 us, normalise passes 1258 -> 1415 us): the ~5 us of a finalize launch are the dependent read of partial rows that
+# another XCD just wrote plus the merge arithmetic, and the fused pass pays exactly the same chain in front of its rows.  Kept as an opt-in.
+FUSE_FIN = int(os.environ.get("PN2_FUSE_FIN", "0"))
 
 
 class GradQueue:
