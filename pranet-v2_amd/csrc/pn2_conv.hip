@@ -735,6 +735,184 @@ __global__ __launch_bounds__(256) void conv_dma_gemm_tab(const pn2_conv_job* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward / dgrad gather-GEMM, PERSISTENT with the weight panel RESIDENT in LDS (bf16, tuning-code bit 6).
+// The LDS-DMA kernel above re-stages its B tile (BN x 64 weights) in every K-step of every M-tile, and pays row decode, descriptor set-up and the
+// first DMA latency once per 128 x 128 tile.  For the layers with a SHORT contraction and MANY rows - the 1x1 convs of layer1 / layer2 (K = 64 .. 256
+// over 61 952 .. 247 808 rows: 4 K-steps per tile, 3 872 tiles), the 26- / 52-wide 3x3 branches and the stem - that per-tile overhead and the B
+// traffic through the L2 -> LDS path are most of the kernel.  Here a workgroup owns ONE N-tile for its whole life: it stages the complete
+// [BN x Kp] panel of that tile once (ksteps x BN x 128 B, <= ~100 KB), then walks M-tiles bm = slot, slot + P, ... and streams only the activation
+// operand through the DMA ring (NA instead of NA + NB requests per K-step).  Same fragment layout, same MFMA order and the same shared epilogue as
+// conv_dma_body: results are bit-identical.  Grid = N-tiles x P slots, about as many workgroups as the CUs hold.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NS, bool EP>
+constexpr int bres_ring_bytes() {
+    constexpr int ring = NS * BM * 128, epi = BM * (BN * 2 + 16) + 3 * WM * BN * 4, epb = EP ? ep_lds_bytes(8) : 0;
+    constexpr int m = ring > epi ? (ring > epb ? ring : epb) : (epi > epb ? epi : epb);
+    return (m + 127) / 128 * 128;
+}
+
+template <int BM, int BN, int WM, int WN, bool PW, int NS, bool EP>
+__global__ __launch_bounds__(256) void conv_bres_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
+                                                      float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep, int P) {
+    using T = bf16_t;
+    constexpr int VEC = 8, BK = 64, ROW = 128;
+    constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
+    constexpr int ASTAGE = BM * ROW;
+    constexpr int NA = BM / 32, NB = BN / 32;
+    constexpr int RING = bres_ring_bytes<BM, BN, WM, WN, NS, EP>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
+    const int M = d.N * d.OH * d.OW;
+    const int nbn = (d.Cout + BN - 1) / BN, nbm = (M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);        // neighbours on one XCD: the N-tiles of one slot, walking the same rows
+    const int bn = bid % nbn, slot = bid / nbn;
+    const int n0 = bn * BN;
+    const int taps = d.KH * d.KW;
+    const int ktot = taps * d.Cin_p;
+    const int ksteps = (ktot + BK - 1) / BK;
+
+    GatherGeom gg;
+    gg.H = d.H; gg.W = d.W; gg.OH = d.OH; gg.OW = d.OW; gg.KH = d.KH; gg.KW = d.KW; gg.stride = d.stride;
+    gg.sshift = __builtin_ctz(d.stride); gg.pad_h = d.pad_h; gg.pad_w = d.pad_w; gg.dil_h = d.dil_h; gg.dil_w = d.dil_w;
+    gg.transposed = d.transposed;
+
+    const int cg = (tid & 7) ^ ((tid >> 4) & 7);
+    const unsigned INV = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)in >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)in)), 0, (int)INV, 0x00020000);
+    const int sgn = d.transposed ? -1 : 1;
+    const int sdil_h = sgn * d.dil_h, sdil_w = sgn * d.dil_w;
+    const int tsh = d.transposed ? gg.sshift : 0, tmsk = d.transposed ? d.stride - 1 : 0;
+    const int ldb = d.ld_in * 2;
+    const int wrow = __builtin_amdgcn_readfirstlane(wid * 8);
+    char* bpanel = smem + RING;
+
+    // ---- the weight panel of this N-tile, once: [kstep][BN rows][128 B], same swizzled chunk order as a ring stage of conv_dma_body
+    {
+        const T* bptr = wp + (size_t)(n0 + (tid >> 3)) * d.Kp + cg * VEC;
+        for (int kt = 0; kt < ksteps; ++kt)
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(bptr + (size_t)(32 * i) * d.Kp + (size_t)kt * BK),
+                                                 (lptr_t)(bpanel + ((kt * BN) + i * 32 + wrow) * ROW), 16, 0, 0);
+    }
+
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const int key = (l15 >> 1) & 7;
+    const unsigned so0 = ((g) ^ key) * 16, so1 = ((4 + g) ^ key) * 16;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+
+    for (int bm = slot; bm < nbm; bm += P) {
+        const int m0 = bm * BM;
+        int rbase[NA], riy0[NA], rix0[NA]; bool rok[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + (tid >> 3) + 32 * i;
+            rok[i] = m < M;
+            const int mm = rok[i] ? m : 0;
+            if (PW) { rbase[i] = mm; riy0[i] = 0; rix0[i] = 0; }
+            else {
+                const int hw = d.OH * d.OW;
+                const int n = mm / hw, rem = mm - n * hw;
+                const int oy = rem / d.OW, ox = rem - oy * d.OW;
+                rbase[i] = n * d.H * d.W;
+                if (!d.transposed) { riy0[i] = oy * d.stride - d.pad_h; rix0[i] = ox * d.stride - d.pad_w; }
+                else { riy0[i] = oy + d.pad_h; rix0[i] = ox + d.pad_w; }
+            }
+        }
+        int ci = cg * VEC, tap = 0;
+        if (!PW) { while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; } }
+        int tcol = 0, tdr = 0, tdc = 0;
+        if (!PW) { const int r0_ = tap / d.KW; tcol = tap - r0_ * d.KW; tdr = r0_ * sdil_h; tdc = tcol * sdil_w; }
+        unsigned rowoff[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) rowoff[i] = PW ? (unsigned)rbase[i] * (unsigned)ldb : (unsigned)rbase[i];
+
+#define PN2_AISSUE(step_, buf_)                                                                                        \
+    do {                                                                                                               \
+        char* sb_ = smem + (buf_) * ASTAGE;                                                                            \
+        if (PW) {                                                                                                      \
+            const int k_ = (step_) * BK + cg * VEC;                                                                    \
+            const bool kok_ = k_ < d.Cin_p;                                                                            \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+                const unsigned vo_ = (rok[i] && kok_) ? rowoff[i] + (unsigned)k_ * 2u : INV;                           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, (int)vo_, 0, 0, PN2_A_AUX); \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            const bool tok_ = tap < taps;                                                                              \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+                const int ty_ = riy0[i] + tdr, tx_ = rix0[i] + tdc;                                                    \
+                const int iy_ = ty_ >> tsh, ix_ = tx_ >> tsh;                                                          \
+                const bool ok_ = rok[i] & tok_ & ((unsigned)iy_ < (unsigned)d.H) & ((unsigned)ix_ < (unsigned)d.W) & (((ty_ | tx_) & tmsk) == 0); \
+                const unsigned vo_ = ok_ ? (rowoff[i] + (unsigned)(iy_ * d.W + ix_)) * (unsigned)ldb + (unsigned)ci * 2u : INV; \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, (int)vo_, 0, 0, PN2_A_AUX); \
+            }                                                                                                          \
+            ci += BK;                                                                                                  \
+            while (ci >= d.Cin_p) {                                                                                    \
+                ci -= d.Cin_p; ++tap; ++tcol; tdc += sdil_w;                                                           \
+                if (tcol == d.KW) { tcol = 0; tdc = 0; tdr += sdil_h; }                                                \
+            }                                                                                                          \
+        }                                                                                                              \
+    } while (0)
+
+        BnbPre<T, BM, BN> pre;
+        f32x4_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        PN2_AISSUE(0, 0);
+        if (NS == 3 && ksteps > 1) PN2_AISSUE(1, 1);
+        for (int t = 0; t < ksteps; ++t) {
+            if constexpr (NS == 3) {
+                // (the panel's requests are older than every ring request: the first counted wait also covers them)
+                if (t + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 2 < ksteps) { const int nb_ = (t + 2) % NS; PN2_AISSUE(t + 2, nb_); }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 1 < ksteps) { const int nb_ = (t + 1) % NS; PN2_AISSUE(t + 1, nb_); }
+            }
+            const unsigned As = lds0 + (t % NS) * ASTAGE + (wm * WTM + l15) * ROW;
+            const unsigned Bs = lds0 + RING + (t * BN) * ROW + (wn * WTN + l15) * ROW;
+            u32x4_t a0[MT], a1[MT], b0[NT], b1[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a0[i]) : "v"(As + i * 16 * ROW + so0));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b0[j]) : "v"(Bs + j * 16 * ROW + so0));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a1[i]) : "v"(As + i * 16 * ROW + so1));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b1[j]) : "v"(Bs + j * 16 * ROW + so1));
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, a0[i]), __builtin_bit_cast(uint4, b0[j]));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, a1[i]), __builtin_bit_cast(uint4, b1[j]));
+        }
+#undef PN2_AISSUE
+        __syncthreads();            // the ring is free: the epilogue stages the C tile there
+        conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
+        __syncthreads();            // ... and is done with it before the next tile's DMA lands
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient: slab[s][co][k] = sum over this split's pixels of dy[m][co] * gather(x, m, k)
 // ------------------------------------------------------------------------------------------------
 constexpr int WGP = 32;   // pixels (contraction) per step
@@ -1335,6 +1513,41 @@ int launch_dma(const void* in, const void* wp, void* out, float* psum, float* ps
     return 0;
 }
 
+// persistent, B-resident launch (tuning-code bit 6); returns -100 when the panel does not fit so that the caller takes the plain LDS-DMA kernel
+template <bool EP, int BM, int BN, int WM, int WN, int NS = 3>
+int launch_bres(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
+    const int M = d.N * d.OH * d.OW;
+    const int ksteps = (d.KH * d.KW * d.Cin_p + 63) / 64;
+    constexpr int ring = bres_ring_bytes<BM, BN, WM, WN, NS, EP>();
+    const int lds = ring + ksteps * BN * 128;
+    if (lds > 160 * 1024 || ((d.flags >> 16) & 15) > 1) return -100;
+    const int nbn = (d.Cout + BN - 1) / BN, nbm = (M + BM - 1) / BM;
+    int occ = (160 * 1024) / lds; if (occ > 3) occ = 3; if (occ < 1) occ = 1;
+    int P = (256 * occ) / nbn; if (P < 1) P = 1; if (P > nbm) P = nbm;
+    const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
+    static bool done = false;
+    if (!done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bres_gemm<BM, BN, WM, WN, true, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bres_gemm<BM, BN, WM, WN, false, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+    if (pw) hipLaunchKernelGGL((conv_bres_gemm<BM, BN, WM, WN, true, NS, EP>), dim3(nbn * P), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d, ep, P);
+    else hipLaunchKernelGGL((conv_bres_gemm<BM, BN, WM, WN, false, NS, EP>), dim3(nbn * P), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d, ep, P);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+template <bool EP, int NS>
+int bres_dispatch(int bm, int bn, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
+    if (bm == 128) {
+        if (bn == 128) return launch_bres<EP, 128, 128, 2, 2, NS>(in, wp, out, psum, psq, d, ep, st);
+        if (bn == 64) return launch_bres<EP, 128, 64, 2, 2, NS>(in, wp, out, psum, psq, d, ep, st);
+        return launch_bres<EP, 128, 32, 4, 1, NS>(in, wp, out, psum, psq, d, ep, st);
+    }
+    if (bn == 128) return launch_bres<EP, 64, 128, 2, 2, NS>(in, wp, out, psum, psq, d, ep, st);
+    if (bn == 64) return launch_bres<EP, 64, 64, 2, 2, NS>(in, wp, out, psum, psq, d, ep, st);
+    return launch_bres<EP, 64, 32, 4, 1, NS>(in, wp, out, psum, psq, d, ep, st);
+}
+
 // the LDS-DMA kernel addresses the activation operand with 32-bit byte offsets behind a buffer descriptor (conv_dma_body): its extent must stay below 2 GB
 inline bool dma_extent_ok(const pn2_conv_desc& d) {
     return ((size_t)d.N * d.H * d.W - 1) * (size_t)d.ld_in * 2 + (size_t)d.Cin_p * 2 < 0x80000000ull;
@@ -1377,6 +1590,10 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
     if (tbm) bm = tbm == 1 ? 64 : 128;
     if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
     if constexpr (sizeof(T) == 2) {
+        if ((tune & 0x40) && (tk_ == 2 || tk_ == 3) && !(d.flags & PN2_CONV_ROWGATE)) {      // persistent, weight panel resident in LDS (when it fits)
+            const int rc = tk_ == 3 ? bres_dispatch<EP, 2>(bm, bn, in, wp, out, psum, psq, d, ep, st) : bres_dispatch<EP, 3>(bm, bn, in, wp, out, psum, psq, d, ep, st);
+            if (rc != -100) return rc;
+        }
         if (tk_ == 3) {              // LDS-DMA, 2-stage ring (more workgroups per CU)
             if (bm == 128) {
                 if (bn == 128) return launch_dma<EP, 128, 128, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st);

@@ -342,6 +342,7 @@ MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which 
 # 15.456 ms, rocprof: finalize 532 -> 322 us, normalise passes 1258 -> 1415 us): the ~5 us of a finalize launch are the dependent read of partial rows that
 # another XCD just wrote plus the merge arithmetic, and the fused pass pays exactly the same chain in front of its rows.  Kept as an opt-in.
 FUSE_FIN = int(os.environ.get("PN2_FUSE_FIN", "0"))
+ZERO_CROP_SKIP = os.environ.get("PN2_ZERO_CROP_SKIP", "1") == "1"   # K = 1 DSRA: the crop maps' gradient is identically zero - skip the adjoints of the resamples that made them
 
 
 class GradQueue:
@@ -1946,6 +1947,8 @@ class Engine:
         def bwd():
             if not x.requires_grad:
                 return
+            if not (y.grad_written or y.child_written):
+                return              # nothing ever contributed to this output's gradient (e.g. the K = 1 DSRA crop maps): its adjoint is exactly zero
             gy = y.grad_buf()
             gx, acc = x.grad_sink()
             st = _stream()
@@ -2019,8 +2022,20 @@ class Engine:
         sm = 1 if use_softmax else 0
         call.pn2_dsra_fuse_fwd(fg.ptr, crop_fg.ptr, crop_bg.ptr, y.ptr, M, K, sm, _stream())
 
+        # softmax over ONE channel is identically 1 (num_class = 1, the only value the binary scripts use): y = 2 * fg and the gradient into both crop
+        # maps is exactly zero - they receive no contribution at all, so the resamples that produced them skip their adjoints
+        zero_crop = bool(K == 1 and sm and ZERO_CROP_SKIP)
+
         def bwd():
             gy = y.grad_buf()
+            if zero_crop:
+                g, acc = fg.grad_sink()
+                dfg = self.fbuf(M, K) if acc else g
+                scratch = self.fbuf(2, M, K)
+                call.pn2_dsra_fuse_bwd(fg.ptr, crop_fg.ptr, crop_bg.ptr, _p(gy), _p(dfg), _p(scratch[0]), _p(scratch[1]), M, K, sm, _stream())
+                if acc:
+                    call.pn2_copy(F32, _p(dfg), K, F32, _p(g), g.stride(2), M, K, 1, _stream())
+                return
             gs = [a.grad_sink() for a in (fg, crop_fg, crop_bg)]
             tmp = [self.fbuf(M, K) if acc else None for (_, acc) in gs]
             dst = [t if t is not None else g for t, (g, _) in zip(tmp, gs)]

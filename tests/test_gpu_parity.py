@@ -270,18 +270,26 @@ def test_dsra_fusion_k9_golden():
             assert relmax(a.grad.permute(0, 3, 1, 2), torch.from_numpy(z[f"{tag}_{k}"])) < 1e-5
 
 
-def test_dsra_k1_degenerates_to_doubling():
-    """num_class=1: softmax over one channel is 1.0, so fg <- 2*fg and d/dcrop == 0 exactly (SURVEY 'three facts' #2)."""
-    from pn2 import F32
+@pytest.mark.parametrize("skip", [True, False])
+def test_dsra_k1_degenerates_to_doubling(skip, monkeypatch):
+    """num_class=1: softmax over one channel is 1.0, so fg <- 2*fg and d/dcrop == 0 exactly (SURVEY 'three facts' #2).  The engine uses that:
+    the crop maps receive NO gradient contribution (ZERO_CROP_SKIP), so the resamples that produced them skip their adjoints; with the switch off
+    the kernel writes the (exactly zero) crop gradients."""
+    from pn2 import F32, engine
     from pn2.engine import Engine, Act
     from pn2.graph import _seed_grad
+    monkeypatch.setattr(engine, "ZERO_CROP_SKIP", skip)
     eng = Engine(F32, True, need_grad=True)
     mk = lambda: Act(eng, torch.randn(2, 7, 7, 1, device=dev), 1, 1, 1, F32)
-    fg, cf, cb = mk(), mk(), mk()
-    y = eng.dsra_fuse(fg, cf, cb, True)
-    _seed_grad(y, torch.randn(2, 1, 7, 7, device=dev)); eng.backward()
+    fg, src_f, src_b = mk(), Act(eng, torch.randn(2, 14, 14, 1, device=dev), 1, 1, 1, F32), mk()
+    cf = eng.bilinear(src_f, 0.5)               # a crop made by a resample, as in pranet.py:353
+    y = eng.dsra_fuse(fg, cf, src_b, True)
+    gy = torch.randn(2, 1, 7, 7, device=dev)
+    _seed_grad(y, gy); eng.backward()
     assert torch.equal(y.t, 2 * fg.t)
-    assert float(cf.grad.abs().max()) == 0.0 and float(cb.grad.abs().max()) == 0.0
+    assert torch.equal(fg.grad, 2 * gy.permute(0, 2, 3, 1))
+    for a in (cf, src_b, src_f):
+        assert (a.grad is None or not a.grad_written) if skip else float(a.grad.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("tag", ["rand", "zeros", "ones"])
