@@ -233,19 +233,35 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
                 }
         }
     }
+    // Everything below runs once per tile at the GEMM's low occupancy, where every instruction is exposed (the 1x1 convs of layer1 / layer2 have 4
+    // K-steps per tile: ~1000 epilogue instructions per wave next to 32 MFMAs; ablating the statistics alone makes those launches 5-17 % faster).
+    // FULL tiles - all but the last row block of a conv - take paths without per-element row masks, without the bias add when there is no bias and
+    // with a straight LDS -> global copy of the C tile (no bounds checks, no read-modify-write).
+    const bool full_m = m0 + BM <= M;
     if (d.flags & PN2_CONV_STATS) {
         const int rows_w = min(max(M - m0 - wm * WTM, 0), WTM);        // valid rows of this wave's tile (rows are ascending)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const float k = __shfl(acc[0][j][0], l15);                   // row 0 of the wave tile, this lane's column
             float s = 0.f, q = 0.f;
+            if (full_m) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = (i * 16 + g * 4 + r < rows_w) ? acc[i][j][r] - k : 0.f;
-                    s += v; q += v * v;
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[i][j][r] - k;
+                        s += v; q = fmaf(v, v, q);
+                        asm volatile("" : "+v"(s), "+v"(q));      // keeps the two chains scalar: packed-math pairing of s / q (SLP) gave run-to-run different q here
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = (i * 16 + g * 4 + r < rows_w) ? acc[i][j][r] - k : 0.f;
+                        s += v; q += v * v;
+                    }
+            }
             s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
             q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
             if (g == 0) {
@@ -254,21 +270,33 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
             }
         }
     }
-    float bj[NT];                                   // PN2_CONV_BIAS: psum carries a per-output-channel fp32 bias (biased conv / nn.Linear without BN)
+    if (d.flags & PN2_CONV_BIAS) {                  // psum carries a per-output-channel fp32 bias (biased conv / nn.Linear without BN)
+        float bj[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int cg = n0 + wn * WTN + j * 16 + l15;
-        bj[j] = ((d.flags & PN2_CONV_BIAS) && cg < d.Cout) ? psum[cg] : 0.f;
+        for (int j = 0; j < NT; ++j) {
+            const int cg = n0 + wn * WTN + j * 16 + l15;
+            bj[j] = cg < d.Cout ? psum[cg] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
+                    TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r] + bj[j]);
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
+                    TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r]);
+                }
     }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
-                TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r] + bj[j]);
-            }
     __syncthreads();
     if ((d.flags & PN2_CONV_STATS) && tid < BN) {
         const int col = n0 + tid;
@@ -294,6 +322,15 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
     const bool vec_ok = (d.Cout % VEC == 0) && (d.ld_out % VEC == 0);
     const bool accum = d.flags & PN2_CONV_ACCUM;
     if constexpr (!EP) {
+        if (full_m && vec_ok && !accum && n0 + BN <= d.Cout) {         // the common tile: no bounds, no read-modify-write
+            T* obase = out + (size_t)m0 * d.ld_out + n0;
+#pragma unroll
+            for (int u = 0; u < BM * VPR / 256; ++u) {
+                const int idx = tid + u * 256;
+                const int row = idx / VPR, cv = idx - row * VPR;
+                *reinterpret_cast<uint4*>(obase + (size_t)row * d.ld_out + cv * VEC) = *reinterpret_cast<const uint4*>(Cs + row * CRS + cv * 16);
+            }
+        } else
         for (int idx = tid; idx < BM * VPR; idx += 256) {
             const int row = idx / VPR, cv = idx - row * VPR;
             const int m = m0 + row, col = n0 + cv * VEC;
