@@ -63,23 +63,32 @@ def _worker(rank, world, port, q, kind, autotune):
 
 
 def _worker_body(rank, world, port, q, kind, autotune):
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=False)          # a rank that hangs says where (the parent shows the workers' stderr)
+    say = lambda msg: print(f"[dp worker {rank}] {msg}", file=sys.stderr, flush=True)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     model, W = _setup(kind, autotune)
     tr = _trainer(kind, model, dist.group.WORLD)
     x, m = _batch(kind, W, rank)
+    say("first pass")
     loss = tr.forward_backward(x, m)          # first pass: counts the gradient contributions per parameter, buckets leave at the end
     torch.cuda.synchronize()
     g1 = tr.gflat.clone()
     tr.optimizer_step()
     p1 = tr.flat.clone()
+    say("second pass")
     tr.step(x, m)                             # second pass: bucket hooks inside backward
     torch.cuda.synchronize()
     order = list(tr.buckets.order)
+    say("capture")
     tr.capture(x, m, warmup=2)                # 2 more eager steps, then the split graphs
+    say("replay")
     tr.replay(); tr.replay()
     torch.cuda.synchronize()
+    say("done")
+    faulthandler.cancel_dump_traceback_later()
     segs = [bs for _, bs in tr._cur.segments]      # the captured step is a chain of hipGraphs cut where buckets leave
     assert len(segs) >= 3 and [b for bs in segs for b in bs] == order, (segs, order)
     q.put((rank, g1.cpu().numpy(), p1.cpu().numpy(), tr.flat.clone().cpu().numpy(), order, float(loss[-1])))     # numpy: no fd passing
@@ -98,11 +107,19 @@ def test_two_ranks_match_single_process_with_averaged_gradients(kind, autotune):
     ps = [ctx.Process(target=_worker, args=(r, world, port, q, kind, autotune)) for r in range(world)]
     for p in ps:
         p.start()
-    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda r: r[0])
-    for r in res:
-        assert r[1] != "ERROR" if isinstance(r[1], str) else True, r[2]
-    for p in ps:
-        p.join(60)
+    res = []
+    try:
+        for _ in range(world):
+            r = q.get(timeout=int(os.environ.get("PN2_TEST_DP_TIMEOUT", "300")))
+            if isinstance(r[1], str) and r[1] == "ERROR":          # fail fast with the worker's traceback: the other rank is waiting in a collective that will never complete
+                raise AssertionError(f"rank {r[0]} failed:\n{r[2]}")
+            res.append(r)
+    finally:
+        for p in ps:
+            p.join(5 if len(res) < world else 60)
+            if p.is_alive():
+                p.kill()
+    res.sort(key=lambda r: r[0])
     (_, g_a, p_a, pf_a, order_a, _), (_, g_b, p_b, pf_b, order_b, _) = res
     g_a, p_a, pf_a, g_b, p_b, pf_b = (torch.from_numpy(t) for t in (g_a, p_a, pf_a, g_b, p_b, pf_b))
     assert order_a == order_b and len(order_a) >= 3 and order_a[-1] == 0, "ranks must launch the bucket collectives in the same order, head bucket last"
