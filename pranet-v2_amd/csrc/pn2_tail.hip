@@ -533,37 +533,67 @@ __global__ __launch_bounds__(256) void tail_band_fwd_k(pn2_tail_desc d, tail_gro
         int xo[4]; float lx0[4], lx1[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { int x1; bl_src(jv * 4 + e, m0.rw, ac, w, xo[e], x1, lx0[e], lx1[e]); }
-        for (int r = rl; r < rows; r += R) {
-            const size_t pix = (size_t)n * img + (size_t)(oyA + r) * OW + jv * 4;
-            const float4 m4 = *reinterpret_cast<const float4*>(mask + pix), w4 = *reinterpret_cast<const float4*>(weit + pix);
-            const float wt[4] = {w4.x, w4.y, w4.z, w4.w};
-            const float mw[4] = {m4.x * w4.x, m4.y * w4.y, m4.z * w4.z, m4.w * w4.w};
-            wacc += (wt[0] + wt[1]) + (wt[2] + wt[3]); mwacc += (mw[0] + mw[1]) + (mw[2] + mw[3]);
+        const bool same = xo[0] == xo[1] && xo[0] == xo[2] && xo[0] == xo[3];
+#define PN2_TAIL_FWD_ROW(r, m4, w4)                                                                                                                   \
+        do {                                                                                                                                          \
+            const size_t pix = (size_t)n * img + (size_t)(oyA + (r)) * OW + jv * 4;                                                                   \
+            const float wt[4] = {w4.x, w4.y, w4.z, w4.w};                                                                                             \
+            const float mw[4] = {m4.x * w4.x, m4.y * w4.y, m4.z * w4.z, m4.w * w4.w};                                                                 \
+            wacc += (wt[0] + wt[1]) + (wt[2] + wt[3]); mwacc += (mw[0] + mw[1]) + (mw[2] + mw[3]);                                                    \
+_Pragma("unroll")                                                                                                                                     \
+            for (int q = 0; q < TBM; ++q) {                                                                                                           \
+                if (q < nm) {                                                                                                                         \
+                    const float* vr = lds + (q * TRB + (r)) * wp;                                                                                     \
+                    float z[4];                                                                                                                       \
+                    if (same) {                                                                                                                       \
+                        const float ta = vr[xo[0]], tb = vr[xo[0] + 1];                                                                               \
+_Pragma("unroll")                                                                                                                                     \
+                        for (int e = 0; e < 4; ++e) z[e] = lx0[e] * ta + lx1[e] * tb;                                                                 \
+                    } else {                                                                                                                          \
+_Pragma("unroll")                                                                                                                                     \
+                        for (int e = 0; e < 4; ++e) z[e] = lx0[e] * vr[xo[e]] + lx1[e] * vr[xo[e] + 1];                                               \
+                    }                                                                                                                                 \
+                    *reinterpret_cast<float4*>(lat + mapoff[q] + pix) = make_float4(z[0], z[1], z[2], z[3]);                                          \
+                    if (isbg[q]) {                                                                                                                    \
+_Pragma("unroll")                                                                                                                                     \
+                        for (int e = 0; e < 4; ++e) {                                                                                                 \
+                            const float sp = fmaxf(z[e], 0.f) + hw_log(1.f + hw_exp(-fabsf(z[e])));                                                   \
+                            acc[q][0] += wt[e] * sp - z[e] * (wt[e] - mw[e]);                                                                         \
+                        }                                                                                                                             \
+                    } else {                                                                                                                          \
+_Pragma("unroll")                                                                                                                                     \
+                        for (int e = 0; e < 4; ++e) {                                                                                                 \
+                            const float ex = hw_exp(-fabsf(z[e])), rr = hw_rcp(1.f + ex), pr = z[e] >= 0.f ? rr : ex * rr;                            \
+                            const float sp = fmaxf(z[e], 0.f) - hw_log(rr);                                                                           \
+                            acc[q][0] += wt[e] * sp - z[e] * mw[e]; acc[q][1] += pr * mw[e]; acc[q][2] += pr * wt[e];                                 \
+                        }                                                                                                                             \
+                    }                                                                                                                                 \
+                }                                                                                                                                     \
+            }                                                                                                                                         \
+        } while (0)
+        if (R * 4 >= TRB) {
+            // <= 4 rows per thread: every row's mask / weit vector is requested BEFORE the first one is used - a load -> use walk pays a full
+            // memory latency per row (4 per block, on top of the staging round trip)
+            float4 mq[4], wq[4];
 #pragma unroll
-            for (int q = 0; q < TBM; ++q) {
-                if (q < nm) {
-                    const float* vr = lds + (q * TRB + r) * wp;
-                    float z[4];
+            for (int t = 0; t < 4; ++t) {
+                const int r = rl + t * R, rc = r < rows ? r : rl;
+                const size_t px_ = (size_t)n * img + (size_t)(oyA + rc) * OW + jv * 4;
+                mq[t] = *reinterpret_cast<const float4*>(mask + px_); wq[t] = *reinterpret_cast<const float4*>(weit + px_);
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) z[e] = lx0[e] * vr[xo[e]] + lx1[e] * vr[xo[e] + 1];
-                    *reinterpret_cast<float4*>(lat + mapoff[q] + pix) = make_float4(z[0], z[1], z[2], z[3]);
-                    if (isbg[q]) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {       // w * (softplus(b) - b*(1-m))
-                            const float sp = fmaxf(z[e], 0.f) + hw_log(1.f + hw_exp(-fabsf(z[e])));
-                            acc[q][0] += wt[e] * sp - z[e] * (wt[e] - mw[e]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float ex = hw_exp(-fabsf(z[e])), rr = hw_rcp(1.f + ex), pr = z[e] >= 0.f ? rr : ex * rr;
-                            const float sp = fmaxf(z[e], 0.f) - hw_log(rr);          // log(1 + ex) = -log(1 / (1 + ex))
-                            acc[q][0] += wt[e] * sp - z[e] * mw[e]; acc[q][1] += pr * mw[e]; acc[q][2] += pr * wt[e];
-                        }
-                    }
-                }
+            for (int t = 0; t < 4; ++t) {
+                const int r = rl + t * R;
+                if (r < rows) { const float4 m4 = mq[t], w4 = wq[t]; PN2_TAIL_FWD_ROW(r, m4, w4); }
+            }
+        } else {
+            for (int r = rl; r < rows; r += R) {
+                const size_t px_ = (size_t)n * img + (size_t)(oyA + r) * OW + jv * 4;
+                const float4 m4 = *reinterpret_cast<const float4*>(mask + px_), w4 = *reinterpret_cast<const float4*>(weit + px_);
+                PN2_TAIL_FWD_ROW(r, m4, w4);
             }
         }
+#undef PN2_TAIL_FWD_ROW
     }
     // 16-lane DPP sums, then the <= 16 row partials of the block meet in LDS (fixed order)
     const int rrow = threadIdx.x >> 4, nrow = blockDim.x >> 4;
@@ -625,6 +655,7 @@ __global__ __launch_bounds__(256) void tail_band_bwd_k(pn2_tail_desc d, tail_gro
         int xo[4]; float lx0[4], lx1[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { int x1; bl_src(jv * 4 + e, m0.rw, ac, w, xo[e], x1, lx0[e], lx1[e]); }
+        const bool same = xo[0] == xo[1] && xo[0] == xo[2] && xo[0] == xo[3];
         for (int r = rl; r < rows; r += R) {
             const size_t pix = (size_t)n * img + (size_t)(oyA + r) * OW + jv * 4;
             const float4 m4 = *reinterpret_cast<const float4*>(mask + pix), w4 = *reinterpret_cast<const float4*>(weit + pix);
@@ -635,9 +666,10 @@ __global__ __launch_bounds__(256) void tail_band_bwd_k(pn2_tail_desc d, tail_gro
             for (int q = 0; q < TBM; ++q) {
                 if (q < nm) {
                     const float* vr = lds + (q * TRB + r) * wp;
+                    const float ta = vr[xo[0]], tb = vr[xo[0] + 1];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float z = lx0[e] * vr[xo[e]] + lx1[e] * vr[xo[e] + 1];
+                        const float z = same ? lx0[e] * ta + lx1[e] * tb : lx0[e] * vr[xo[e]] + lx1[e] * vr[xo[e] + 1];
                         const float ex = hw_exp(-fabsf(z)), rr = hw_rcp(1.f + ex), pr = z >= 0.f ? rr : ex * rr;
                         const float u = wt[e] - mw[e];
                         float dl;
