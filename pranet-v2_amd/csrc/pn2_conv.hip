@@ -601,19 +601,29 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     // this thread's DMA lanes: row (tid>>3) of every 32-row group, LDS chunk slot (tid&7) which holds GLOBAL chunk cg
     const int cg = (tid & 7) ^ ((tid >> 4) & 7);
     int rbase[NA], riy0[NA], rix0[NA]; bool rok[NA];
+    {
+        // pixel decode of the thread's rows m, m + 32, m + 64, ...: ONE pair of integer divisions (~60 instructions on this part), the other rows
+        // are stepped from it (32 pixels further: a few wrap-arounds of the column / row counters) - the decode was ~240 of the ~400 prologue instructions
+        const int mf = m0 + (tid >> 3);
+        int n_ = 0, oy_ = 0, ox_ = 0;
+        if (!PW) {
+            const unsigned hw = (unsigned)(d.OH * d.OW), mu = (unsigned)mf;
+            const unsigned nq = mu / hw, rem = mu - nq * hw, oq = rem / (unsigned)d.OW;
+            n_ = (int)nq; oy_ = (int)oq; ox_ = (int)(rem - oq * (unsigned)d.OW);
+        }
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int m = m0 + (tid >> 3) + 32 * i;
-        rok[i] = m < M;
-        const int mm = rok[i] ? m : 0;
-        if (PW) { rbase[i] = mm; riy0[i] = 0; rix0[i] = 0; }
-        else {
-            const int hw = d.OH * d.OW;
-            const int n = mm / hw, rem = mm - n * hw;
-            const int oy = rem / d.OW, ox = rem - oy * d.OW;
-            rbase[i] = n * d.H * d.W;
-            if (!d.transposed) { riy0[i] = oy * d.stride - d.pad_h; rix0[i] = ox * d.stride - d.pad_w; }
-            else { riy0[i] = oy + d.pad_h; rix0[i] = ox + d.pad_w; }
+        for (int i = 0; i < NA; ++i) {
+            const int m = mf + 32 * i;
+            rok[i] = m < M;
+            if (PW) { rbase[i] = rok[i] ? m : 0; riy0[i] = 0; rix0[i] = 0; }
+            else {
+                rbase[i] = n_ * d.H * d.W;          // (rows past M: the decode runs on, the loads are masked by rok)
+                if (!d.transposed) { riy0[i] = oy_ * d.stride - d.pad_h; rix0[i] = ox_ * d.stride - d.pad_w; }
+                else { riy0[i] = oy_ + d.pad_h; rix0[i] = ox_ + d.pad_w; }
+                ox_ += 32;
+                while (ox_ >= d.OW) { ox_ -= d.OW; ++oy_; }
+                while (oy_ >= d.OH) { oy_ -= d.OH; ++n_; }
+            }
         }
     }
     int ci = cg * VEC + kt0 * BK, tap = 0;
@@ -847,19 +857,27 @@ __global__ __launch_bounds__(256) void conv_bres_gemm(const bf16_t* __restrict__
     for (int bm = slot; bm < nbm; bm += P) {
         const int m0 = bm * BM;
         int rbase[NA], riy0[NA], rix0[NA]; bool rok[NA];
+        {
+            const int mf = m0 + (tid >> 3);
+            int n_ = 0, oy_ = 0, ox_ = 0;
+            if (!PW) {
+                const unsigned hw = (unsigned)(d.OH * d.OW), mu = (unsigned)mf;
+                const unsigned nq = mu / hw, rem = mu - nq * hw, oq = rem / (unsigned)d.OW;
+                n_ = (int)nq; oy_ = (int)oq; ox_ = (int)(rem - oq * (unsigned)d.OW);
+            }
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int m = m0 + (tid >> 3) + 32 * i;
-            rok[i] = m < M;
-            const int mm = rok[i] ? m : 0;
-            if (PW) { rbase[i] = mm; riy0[i] = 0; rix0[i] = 0; }
-            else {
-                const int hw = d.OH * d.OW;
-                const int n = mm / hw, rem = mm - n * hw;
-                const int oy = rem / d.OW, ox = rem - oy * d.OW;
-                rbase[i] = n * d.H * d.W;
-                if (!d.transposed) { riy0[i] = oy * d.stride - d.pad_h; rix0[i] = ox * d.stride - d.pad_w; }
-                else { riy0[i] = oy + d.pad_h; rix0[i] = ox + d.pad_w; }
+            for (int i = 0; i < NA; ++i) {
+                const int m = mf + 32 * i;
+                rok[i] = m < M;
+                if (PW) { rbase[i] = rok[i] ? m : 0; riy0[i] = 0; rix0[i] = 0; }
+                else {
+                    rbase[i] = n_ * d.H * d.W;
+                    if (!d.transposed) { riy0[i] = oy_ * d.stride - d.pad_h; rix0[i] = ox_ * d.stride - d.pad_w; }
+                    else { riy0[i] = oy_ + d.pad_h; rix0[i] = ox_ + d.pad_w; }
+                    ox_ += 32;
+                    while (ox_ >= d.OW) { ox_ -= d.OW; ++oy_; }
+                    while (oy_ >= d.OH) { oy_ -= d.OH; ++n_; }
+                }
             }
         }
         int ci = cg * VEC, tap = 0;

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpn2_hip.so")
+LIB_PATH = os.environ.get("PN2_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libpn2_hip.so")      # PN2_LIB: another build of the same library (A/B of build flags)
 
 F32, BF16 = 0, 1
 CONV_STATS, CONV_ACCUM, CONV_BIAS = 1, 2, 4
