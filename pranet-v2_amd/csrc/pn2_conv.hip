@@ -24,6 +24,25 @@ constexpr int ROWB = 128;      // bytes of K per LDS row per step (64 bf16 or 32
 constexpr int KSUB = ROWB / 64;
 constexpr int RS = ROWB + 16;  // padded LDS row stride (bytes): 36 banks -> the 16 rows of a fragment read hit 16 distinct 16-B slots
 
+// Phase stamps of the conv kernels (debug build only: make stamp -> libpn2_stamp.so, read by tools/stamp_micro.py): thread 0 of every workgroup
+// leaves s_memtime at the phase boundaries, so that a launch can be taken apart into prologue / first DMA landing / K loop / C staging / stores.
+#ifdef PN2_STAMP
+constexpr int PN2_STAMP_SLOTS = 16, PN2_STAMP_BLOCKS = 1 << 16;
+__device__ unsigned long long pn2_stamp_buf[PN2_STAMP_BLOCKS * PN2_STAMP_SLOTS];
+__device__ __forceinline__ void pn2_stamp(int i) {
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < PN2_STAMP_BLOCKS) pn2_stamp_buf[blockIdx.x * PN2_STAMP_SLOTS + i] = __builtin_amdgcn_s_memtime();
+}
+__device__ __forceinline__ void pn2_stamp_hw() {
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < PN2_STAMP_BLOCKS) {
+        pn2_stamp_buf[blockIdx.x * PN2_STAMP_SLOTS + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+        pn2_stamp_buf[blockIdx.x * PN2_STAMP_SLOTS + 11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+    }
+}
+#define PN2_STAMP_AT(i) pn2_stamp(i)
+#else
+#define PN2_STAMP_AT(i)
+#endif
+
 template <typename T> struct MMA;
 template <> struct MMA<bf16_t> {
     static constexpr int BK = 32 * KSUB;
@@ -51,6 +70,18 @@ template <> struct MMA<float> {
     }
 };
 
+
+// 16 channels x 32 rows of a row-major bf16 tile in LDS as an MFMA operand (lane: channel l15, k-slots (g, e) <-> row (e>>2)*16 + g*4 + (e&3)):
+// two transposing reads.  Used by the statistics of the swapped epilogue and by the weight-gradient kernels (same k-slot order on both operands).
+typedef short s16x4_t_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 tr_frag_bf16(const char* tile, int rs, int chan0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const char* p = tile + (g * 4 + (i >> 2)) * rs + (chan0 + (i & 3) * 4) * 2;
+    s16x4_t_ v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t_ __attribute__((address_space(3)))*)(p));
+    s16x4_t_ v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t_ __attribute__((address_space(3)))*)(p + 16 * rs));
+    uint2 lo = __builtin_bit_cast(uint2, v0), hi = __builtin_bit_cast(uint2, v1);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
 
 struct GatherGeom {
     int H, W, OH, OW, KH, KW, stride, sshift, pad_h, pad_w, dil_h, dil_w, transposed;
@@ -204,7 +235,46 @@ __device__ __forceinline__ void bnb_target(const pn2_bnb_target& t, T* __restric
     for (int e = 0; e < VEC; ++e) { s1[e] = t1[e]; s2[e] = is[e] * (t2[e] - mu[e] * t1[e]); }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MT, int NT, bool EP>
+// BatchNorm batch statistics of a staged bf16 C tile [BM][BN] (row stride crs bytes) on the matrix cores; rows >= nrow are zeros.
+// Wave w takes the 16-channel blocks w, w + 4, ...; writes (mean, M2) of the tile per channel to psum / psq [bm][Cout].
+template <int BM, int BN>
+__device__ __forceinline__ void mfma_stats(const char* Cs, int crs, int nrow, int Cout, int n0, int bm, float* __restrict__ psum, float* __restrict__ psq) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    const double rn = nrow == BM ? 1.0 / BM : 1.0 / (double)nrow;      // (uniform branch: the division runs in the last row block only)
+#pragma unroll
+    for (int cb = wid; cb < BN / 16; cb += 4) {
+        f32x4_t aS = {0.f, 0.f, 0.f, 0.f}, aQ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < BM / 32; ++kc) {
+            const uint4 F = tr_frag_bf16(Cs + kc * 32 * crs, crs, cb * 16, lane);
+            MMA<bf16_t>::run(aQ, F, F);
+            MMA<bf16_t>::run(aS, ones, F);
+        }
+        // column l15: its sum is every row of aS; its sum of squares is the diagonal element of aQ, held by the lane with g == l15 >> 2
+        const int rr = l15 & 3;
+        float qd = rr == 0 ? aQ[0] : (rr == 1 ? aQ[1] : (rr == 2 ? aQ[2] : aQ[3]));
+        qd = (l15 >> 2) == g ? qd : 0.f;
+        qd += __shfl_xor(qd, 16); qd += __shfl_xor(qd, 32);
+        const int col = n0 + cb * 16 + l15;
+        if (g == 0 && col < Cout) {
+            const double S = (double)aS[0], mean = S * rn, m2 = (double)qd - S * mean;
+            psum[(size_t)bm * Cout + col] = (float)mean;
+            psq[(size_t)bm * Cout + col] = (float)(m2 > 0.0 ? m2 : 0.0);
+        }
+    }
+}
+
+// SWP (bf16 LDS-DMA kernels): the MFMAs ran with the operands exchanged, so a lane holds FOUR CONSECUTIVE CHANNELS of one pixel
+// (acc[i][j][r] = C[pixel wm*WTM + i*16 + l15][channel wn*WTN + j*16 + g*4 + r]) instead of four pixels of one channel.  Measured with in-kernel
+// stamps (tools/stamp_micro.py, 64->256 1x1 conv of layer1, 128 x 128 tile): of a workgroup's 6.5 us, 1.6 us were the in-register statistics
+// (192 dependent VALU ops per wave at two waves per SIMD), 1.1 us the 64 cvt + ds_write_b16 per lane (LDS store issue), 0.5 us the merge.  Here
+//   - staging is 2 v_cvt_pk_bf16_f32 + ONE ds_write_b64 per 16 x 16 block (16 stores per lane instead of 64),
+//   - the BatchNorm statistics come from the matrix cores: for a 16-channel block F (rows x 16, read back transposed from the staged tile),
+//     ones x F gives the column sums and the diagonal of F^T F the sums of squares - 2 x BM/32 MFMAs per block, no VALU reduction, no second
+//     barrier, no merge step.  They are the statistics of the bf16-ROUNDED outputs, i.e. of the tensor that is normalised afterwards (what
+//     torch.autocast computes too); mean and M2 of the tile are formed in double from the two fp32 sums.
+template <typename T, int BM, int BN, int WM, int WN, int MT, int NT, bool EP, bool SWP = false>
 __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem, const pn2_conv_desc& d, const pn2_conv_ep& ep, T* __restrict__ out,
                                               float* __restrict__ psum, float* __restrict__ psq, int M, int m0, int n0, int bm, BnbPre<T, BM, BN>& pre) {
     constexpr int VEC = TT<T>::VEC;
@@ -217,6 +287,59 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
 #ifndef PN2_EP_PREFETCH_EARLY
     if constexpr (EP) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);      // in flight while the C tile is staged
 #endif
+    const bool full_m = m0 + BM <= M;
+    if constexpr (SWP) {
+        static_assert(sizeof(T) == 2, "swapped epilogue: bf16 only");
+        if constexpr (EP) {
+            if (d.flags & PN2_CONV_ROWGATE) {          // per-pixel gate (see below): pixel = l15 of block i
+                const float* __restrict__ gate = ep.a.par;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int m = m0 + wm * WTM + i * 16 + l15;
+                    const float gg = m < M ? 1.f - 1.f / (1.f + __expf(-gate[m])) : 0.f;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] *= gg;
+                }
+            }
+        }
+        PN2_STAMP_AT(5);
+        const int rows_ok = M - m0;                    // rows of the tile that exist (>= BM for all but the last row block)
+        const bool has_bias = d.flags & PN2_CONV_BIAS;
+        if (full_m && !has_bias) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    *reinterpret_cast<uint2*>(Cs + (wm * WTM + i * 16 + l15) * CRS + (wn * WTN + j * 16 + g * 4) * 2) =
+                        make_uint2(TT<T>::cvt2(acc[i][j][0], acc[i][j][1]), TT<T>::cvt2(acc[i][j][2], acc[i][j][3]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (has_bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cg = n0 + wn * WTN + j * 16 + g * 4 + r;
+                        b4[r] = cg < d.Cout ? psum[cg] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = wm * WTM + i * 16 + l15;
+                    const bool live = row < rows_ok;       // rows past M are staged as zeros: they drop out of the statistics
+                    const float v0 = live ? acc[i][j][0] + b4[0] : 0.f, v1 = live ? acc[i][j][1] + b4[1] : 0.f;
+                    const float v2 = live ? acc[i][j][2] + b4[2] : 0.f, v3 = live ? acc[i][j][3] + b4[3] : 0.f;
+                    *reinterpret_cast<uint2*>(Cs + row * CRS + (wn * WTN + j * 16 + g * 4) * 2) = make_uint2(TT<T>::cvt2(v0, v1), TT<T>::cvt2(v2, v3));
+                }
+            }
+        }
+        PN2_STAMP_AT(13);
+        __syncthreads();
+        PN2_STAMP_AT(6);
+        if constexpr (EP) { if (d.flags & PN2_CONV_STATS) mfma_stats<BM, BN>(Cs, CRS, min(M - m0, BM), d.Cout, n0, bm, psum, psq); }
+    } else {
     if constexpr (EP) {          // (only in the epilogue-statistics instantiations: in the plain kernels the extra live range costs a wave of occupancy)
         if (d.flags & PN2_CONV_ROWGATE) {
             // V1 reverse attention in front of a 1x1 conv (PraNet_Res2Net.py:153-155): conv((1 - sigmoid(crop)) * x) = (1 - sigmoid(crop)) * conv(x),
@@ -237,8 +360,12 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
     // K-steps per tile: ~1000 epilogue instructions per wave next to 32 MFMAs; ablating the statistics alone makes those launches 5-17 % faster).
     // FULL tiles - all but the last row block of a conv - take paths without per-element row masks, without the bias add when there is no bias and
     // with a straight LDS -> global copy of the C tile (no bounds checks, no read-modify-write).
-    const bool full_m = m0 + BM <= M;
-    if (d.flags & PN2_CONV_STATS) {
+    PN2_STAMP_AT(5);
+    // bf16 instantiations (the register-staged fallback of the LDS-DMA kernels): statistics from the staged, ROUNDED tile on the matrix cores like the
+    // swapped epilogue - one definition of the batch statistics for every bf16 kernel (bit-identical between the kernels); fp32 stores unrounded values
+    // and keeps the in-register shifted sums.
+    constexpr bool MST = sizeof(T) == 2;
+    if (!MST && (d.flags & PN2_CONV_STATS)) {
         const int rows_w = min(max(M - m0 - wm * WTM, 0), WTM);        // valid rows of this wave's tile (rows are ascending)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -270,6 +397,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
             }
         }
     }
+    PN2_STAMP_AT(12);
     if (d.flags & PN2_CONV_BIAS) {                  // psum carries a per-output-channel fp32 bias (biased conv / nn.Linear without BN)
         float bj[NT];
 #pragma unroll
@@ -284,7 +412,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
-                    TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r] + bj[j]);
+                    TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, (!MST || row < M - m0) ? acc[i][j][r] + bj[j] : 0.f);
                 }
     } else {
 #pragma unroll
@@ -294,11 +422,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
-                    TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, acc[i][j][r]);
+                    TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, (!MST || full_m || row < M - m0) ? acc[i][j][r] : 0.f);
                 }
     }
+    PN2_STAMP_AT(13);
     __syncthreads();
-    if ((d.flags & PN2_CONV_STATS) && tid < BN) {
+    PN2_STAMP_AT(6);
+    if constexpr (MST && EP) { if (d.flags & PN2_CONV_STATS) mfma_stats<BM, BN>(Cs, CRS, min(M - m0, BM), d.Cout, n0, bm, psum, psq); }
+    if (!MST && (d.flags & PN2_CONV_STATS) && tid < BN) {
         const int col = n0 + tid;
         if (col < d.Cout) {
             float n = 0.f, mean = 0.f, m2 = 0.f;
@@ -318,9 +449,11 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
             psq[(size_t)bm * d.Cout + col] = m2;
         }
     }
+    }      // !SWP
     constexpr int VPR = BN / VEC;
     const bool vec_ok = (d.Cout % VEC == 0) && (d.ld_out % VEC == 0);
     const bool accum = d.flags & PN2_CONV_ACCUM;
+    PN2_STAMP_AT(7);
     if constexpr (!EP) {
         if (full_m && vec_ok && !accum && n0 + BN <= d.Cout) {         // the common tile: no bounds, no read-modify-write
             T* obase = out + (size_t)m0 * d.ld_out + n0;
@@ -353,12 +486,15 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
                 for (int e = 0; e < VEC && col + e < d.Cout; ++e) TT<T>::st(dst + e, accum ? x[e] + TT<T>::ld(dst + e) : x[e]);
             }
         }
+        // (swapped epilogue) statistics AFTER the stores have been issued: they drain while the matrix cores reduce the staged tile
+        if constexpr (SWP || sizeof(T) == 2) { if (d.flags & PN2_CONV_STATS) mfma_stats<BM, BN>(Cs, CRS, min(M - m0, BM), d.Cout, n0, bm, psum, psq); }
     } else {
     // ---- BatchNorm-backward statistics of the produced gradient tile (vector path only: the host checks the alignment)
     float sums[4][VEC];
     const bool dual = ep.b.out != nullptr;
     if (dual) bnb_target<T, BM, BN>(ep.b, reinterpret_cast<T*>(ep.b.out), ep.b.ld_out, false, Cs, M, m0, n0, d.Cout, pre.rb, pre.rb, pre.vd, sums[2], sums[3]);
     bnb_target<T, BM, BN>(ep.a, out, d.ld_out, accum, Cs, M, m0, n0, d.Cout, pre.ra, pre.ma, pre.vd, sums[0], sums[1]);
+    PN2_STAMP_AT(14);
     __syncthreads();                                   // everyone has drained the C tile
     // the 256 / VPR row lanes of a channel vector meet in LDS: rs[sum][row lane][BN], then column-parallel adds in a fixed order
     constexpr int RL = 256 / VPR;
@@ -373,6 +509,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
         }
     }
     __syncthreads();
+    PN2_STAMP_AT(15);
     for (int o = tid; o < nsum * BN; o += 256) {
         const int k = o / BN, c = o - k * BN;
         const float* r = rs + (size_t)k * RL * BN + c;
@@ -577,6 +714,7 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
+    PN2_STAMP_AT(0);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
     const int M = d.N * d.OH * d.OW;
@@ -704,14 +842,19 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     const unsigned so0 = ((g) ^ key) * 16, so1 = ((4 + g) ^ key) * 16;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;     // LDS byte address of the dynamic segment
 
+    PN2_STAMP_AT(1);
     if (ksteps > 0) PN2_ISSUE(kt0, 0);
     if (NS == 3 && ksteps > 1) PN2_ISSUE(kt0 + 1, 1);
+    PN2_STAMP_AT(2);
     for (int t = 0; t < ksteps; ++t) {
         if constexpr (NS == 3) {
             // my own DMA of step t has landed once at most one later step (LPS loads) is still outstanding
             if (t + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();              // everyone's step-t data is in LDS; everyone finished reading step t-1
+#ifdef PN2_STAMP
+            if (t == 0) PN2_STAMP_AT(3);
+#endif
             if (t + 2 < ksteps) {
                 const int nb_ = (t + 2) % NS;
                 PN2_ISSUE(kt0 + t + 2, nb_);
@@ -719,6 +862,9 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // only step t is outstanding
             __builtin_amdgcn_s_barrier();              // step t is in LDS for everyone; everyone finished reading the other buffer (step t-1)
+#ifdef PN2_STAMP
+            if (t == 0) PN2_STAMP_AT(3);
+#endif
             if (t + 1 < ksteps) {
                 const int nb_ = (t + 1) % NS;
                 PN2_ISSUE(kt0 + t + 1, nb_);
@@ -742,16 +888,17 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, a0[i]), __builtin_bit_cast(uint4, b0[j]));
+            for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, b0[j]), __builtin_bit_cast(uint4, a0[i]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, a1[i]), __builtin_bit_cast(uint4, b1[j]));
+            for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, b1[j]), __builtin_bit_cast(uint4, a1[i]));
     }
 #undef PN2_ISSUE
     __syncthreads();
+    PN2_STAMP_AT(4);
 
     if (ksplit > 1) {            // fp32 partial tile -> workspace [ksplit][M][Cout] (psum); pn2_conv_splitk_reduce finishes (sum, stats, bias, store)
         float* ws = psum + (size_t)by * M * d.Cout;
@@ -761,12 +908,18 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * WTM + i * 16 + g * 4 + r, col = n0 + wn * WTN + j * 16 + l15;
+                    const int m = m0 + wm * WTM + i * 16 + l15, col = n0 + wn * WTN + j * 16 + g * 4 + r;      // (operands exchanged: see conv_epilogue<SWP>)
                     if (m < M && col < d.Cout) ws[(size_t)m * d.Cout + col] = acc[i][j][r];
                 }
         return;
     }
-    conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
+    conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP, true>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
+#ifdef PN2_STAMP
+    PN2_STAMP_AT(8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PN2_STAMP_AT(9);
+    pn2_stamp_hw();
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, bool PW, int NS = 3, bool EP = false>
@@ -952,17 +1105,17 @@ __global__ __launch_bounds__(256) void conv_bres_gemm(const bf16_t* __restrict__
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, a0[i]), __builtin_bit_cast(uint4, b0[j]));
+                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, b0[j]), __builtin_bit_cast(uint4, a0[i]));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, a1[i]), __builtin_bit_cast(uint4, b1[j]));
+                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, b1[j]), __builtin_bit_cast(uint4, a1[i]));
         }
 #undef PN2_AISSUE
         __syncthreads();            // the ring is free: the epilogue stages the C tile there
-        conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
+        conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP, true>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
         __syncthreads();            // ... and is done with it before the next tile's DMA lands
     }
 }
@@ -978,12 +1131,7 @@ template <> struct WG<bf16_t> {
     static constexpr int PAD = 32;   // row stride == 32 B (mod 256 B): conflict-free ds_read_b64_tr_b16
     // A/B fragment of one 16-wide channel block: k-slot (g, j) <-> pixel (j>>2)*16 + g*4 + (j&3)
     __device__ static __forceinline__ uint4 frag(const char* tile, int rs, int chan0, int lane) {
-        const int g = lane >> 4, i = lane & 15;
-        const char* p = tile + (g * 4 + (i >> 2)) * rs + (chan0 + (i & 3) * 4) * 2;
-        s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
-        s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p + 16 * rs));
-        uint2 lo = __builtin_bit_cast(uint2, v0), hi = __builtin_bit_cast(uint2, v1);
-        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        return tr_frag_bf16(tile, rs, chan0, lane);
     }
     __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) { MMA<bf16_t>::run(acc, a, b); }
     static constexpr int NFRAG = 1;
@@ -2262,3 +2410,10 @@ int pn2_conv_splitk_reduce(int dtype, const float* ws, int ksplit, int M, int Co
 }
 
 }  // extern "C"
+
+#ifdef PN2_STAMP
+extern "C" int pn2_debug_stamps(unsigned long long* dst_host, int nblk) {
+    if (nblk > PN2_STAMP_BLOCKS) nblk = PN2_STAMP_BLOCKS;
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(pn2_stamp_buf), (size_t)nblk * PN2_STAMP_SLOTS * sizeof(unsigned long long));
+}
+#endif

@@ -159,10 +159,16 @@ def test_forward_and_dgrad_launches_of_the_benchmark_with_shipped_tiles(name, ke
         mean_t, m2_t = psum.double().cpu(), psq.double().cpu()
         mean = (mean_t * n_t[:, None]).sum(0) / M
         var = (m2_t.sum(0) + (n_t[:, None] * (mean_t - mean) ** 2).sum(0)) / M
+        # the LDS-DMA kernels take the statistics of the STORED (bf16-rounded) tensor - the one pn2_affine_act normalises, and what torch.autocast's
+        # batch_norm sees: tight against the stored output, within the rounding noise (2^-9 / sqrt(M)-ish) of the float64 reference
+        o = out.double().cpu()
+        smean, svar = o.mean(0), o.var(0, unbiased=False)
+        sd = svar.sqrt()
+        assert float(((mean - smean).abs() / sd).max()) < 2e-5, float(((mean - smean).abs() / sd).max())
+        assert float(((var - svar).abs() / svar).max()) < 5e-5, float(((var - svar).abs() / svar).max())
         rmean, rvar = ref.mean(0), ref.var(0, unbiased=False)
-        sd = rvar.sqrt()
-        assert float(((mean - rmean).abs() / sd).max()) < 1e-4, float(((mean - rmean).abs() / sd).max())
-        assert float(((var - rvar).abs() / rvar).max()) < 1e-4, float(((var - rvar).abs() / rvar).max())
+        assert float(((mean - rmean).abs() / sd).max()) < 1e-3, float(((mean - rmean).abs() / sd).max())
+        assert float(((var - rvar).abs() / rvar).max()) < 2e-3, float(((var - rvar).abs() / rvar).max())
     if key == FWD[-1][1]:
         # the step runs this conv's forward and dgrad as split-K (Engine._ksplit: K = 6400, M = 3872): 4 K-slices leave fp32 partial tiles, the reduce sums them
         ks = 4

@@ -73,21 +73,44 @@ def test_conv_kernels_agree_and_match_float64(geom, transposed):
         src, n_out, M = dy, Cin, N * H * W
     d.transposed, d.Kp = transposed, Kp
     src_g, wp_g = src.to(dev), wp.to(dev)
-    outs = {}
+    outs, stats = {}, {}
     for kern in (1, 2, 3, 2 | 0x40, 3 | 0x40):          # 0x40: persistent workgroups with the weight panel resident in LDS (conv_bres_gemm)
         for bm in (1, 2):
             for bn in (1, 2, 3):
                 if (bn == 3 and n_out <= 64) or (bn == 2 and n_out <= 32):
                     continue
                 code = kern | (bm << 2) | (bn << 4)
-                d.flags = code << 8
+                d.flags = (code << 8) | (0 if transposed else capi.CONV_STATS)
                 out = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device=dev)
-                call.pn2_conv_gemm(BF16, P(src_g), P(wp_g), P(out), C.c_void_p(0), C.c_void_p(0), C.byref(d), st)
+                if transposed:
+                    call.pn2_conv_gemm(BF16, P(src_g), P(wp_g), P(out), C.c_void_p(0), C.c_void_p(0), C.byref(d), st)
+                else:
+                    nblk = (M + 64 * bm - 1) // (64 * bm)
+                    ps = torch.full((nblk, n_out), float("nan"), device=dev); pq = torch.full((nblk, n_out), float("nan"), device=dev)
+                    call.pn2_conv_gemm(BF16, P(src_g), P(wp_g), P(out), P(ps), P(pq), C.byref(d), st)
+                    stats.setdefault(bm, {})[code] = (ps, pq)
                 outs[code] = out
     torch.cuda.synchronize()
     first = next(iter(outs.values()))
     for code, o in outs.items():
         assert torch.equal(o.view(torch.int16), first.view(torch.int16)), f"kernel/tile code {code:#x} differs from code {next(iter(outs)):#x}"
+    # BatchNorm partials (mean, M2 per row block and channel): every bf16 kernel takes them from the STORED tile on the matrix cores, so kernels with
+    # the same row-block height agree bit for bit (the table-driven launches swap kernels under the engine), and their Chan merge is the
+    # mean / biased variance of the stored tensor
+    o64 = first.double().cpu()
+    for bm, per in stats.items():
+        c0, (ps0, pq0) = next(iter(per.items()))
+        for code, (ps, pq) in per.items():
+            assert torch.equal(ps, ps0) and torch.equal(pq, pq0), f"statistics of code {code:#x} differ from code {c0:#x}"
+        tm = 64 * bm
+        nblk = ps0.shape[0]
+        n_t = torch.full((nblk,), float(tm), dtype=torch.float64); n_t[-1] = M - (nblk - 1) * tm
+        mean_t, m2_t = ps0.double().cpu(), pq0.double().cpu()
+        mean = (mean_t * n_t[:, None]).sum(0) / M
+        var = (m2_t.sum(0) + (n_t[:, None] * (mean_t - mean) ** 2).sum(0)) / M
+        smean, svar = o64.mean(0), o64.var(0, unbiased=False)
+        assert float(((mean - smean).abs() / svar.sqrt()).max()) < 2e-5
+        assert float(((var - svar).abs() / svar).max()) < 5e-5
     got = first.double().cpu().reshape(ref.shape)
     # fp32 accumulation of exact bf16 products, one bf16 rounding of the result: within one output ulp of the float64 convolution
     tol = ref.abs() * 2.0 ** -8 + 1e-3 * float(ref.abs().max())
@@ -148,3 +171,56 @@ def test_wgrad_kernels_agree_and_match_float64(geom):
     scale = float(ref.abs().max())
     for k, v in res.items():
         assert float((v - ref).abs().max()) <= 2e-5 * scale, (k, float((v - ref).abs().max()) / scale)
+
+
+def test_table_driven_conv_launch_matches_single_launches_bitwise():
+    """pn2_conv_gemm_multi (the lock-step launches of Engine.lockstep: one LDS-DMA kernel for every job of a tile shape) against one pn2_conv_gemm per job
+    with each job's OWN kernel code (register-staged, 2- and 3-stage LDS-DMA): outputs and BatchNorm partials bit for bit.  Jobs as in the RFB tails:
+    1xk / kx1 / dilated 3x3, inputs and outputs that are channel slices of wider buffers, row counts far below a tile."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pn2 import capi
+    from pn2.capi import call, BF16
+    from pn2.engine import _job_table, _p
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(77)
+
+    def mk(N, H, W, Cin_p, Cout, KH, KW, ph, pw, code, dil=1, ld_in=None, ld_out=None, off_in=0, off_out=0):
+        d = capi.ConvDesc()
+        ld_in, ld_out = ld_in or Cin_p, ld_out or Cout
+        d.N, d.H, d.W, d.OH, d.OW = N, H, W, H, W
+        d.Cin_p, d.ld_in, d.Cout, d.ld_out = Cin_p, ld_in, Cout, ld_out
+        d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.dil_h, d.dil_w = KH, KW, 1, ph, pw, dil, dil
+        d.transposed, d.Kp = 0, _rup(KH * KW * Cin_p, 128)
+        d.flags = capi.CONV_STATS | (code << 8)
+        M = N * H * W
+        x = torch.randn(M, ld_in, generator=g).bfloat16().to(dev)[:, off_in:]
+        wp = (torch.randn(_rup(Cout, 128), d.Kp, generator=g) * 0.1).bfloat16().to(dev)
+        return d, x, wp, M, ld_out, off_out
+
+    for bmc, bnc, bm in ((1, 1, 64), (2, 1, 128), (1, 2, 64)):
+        codes = [k | (bmc << 2) | (bnc << 4) for k in (1, 2, 3)]
+        co = 32 if bnc == 1 else 64
+        jobs = [mk(2, 12, 12, 32, co, 1, 3, 0, 1, codes[0], ld_in=224, off_in=32), mk(2, 12, 12, 32, co, 3, 3, 3, 3, codes[1], dil=3, ld_out=256, off_out=64),
+                mk(2, 6, 6, 32, co, 3, 3, 5, 5, codes[2], dil=5, ld_out=256, off_out=128), mk(2, 3, 3, 32, co, 1, 7, 0, 3, codes[0], ld_in=416, off_in=96),
+                mk(2, 6, 6, 64, co, 5, 1, 2, 0, codes[0]), mk(3, 24, 24, 64, co, 1, 1, 0, 0, codes[1])]
+        single, multi, structs, nbs = [], [], [], []
+        for d, x, wp, M, ld_out, off_out in jobs:
+            nb = (M + bm - 1) // bm
+            o = torch.zeros(M, ld_out, dtype=torch.bfloat16, device=dev)[:, off_out:]; ps = torch.zeros(nb, d.Cout, device=dev); pq = torch.zeros(nb, d.Cout, device=dev)
+            call.pn2_conv_gemm(BF16, P(x), P(wp), P(o), P(ps), P(pq), C.byref(d), st)
+            single.append((o, ps, pq))
+            o2 = torch.zeros(M, ld_out, dtype=torch.bfloat16, device=dev)[:, off_out:]; ps2 = torch.zeros_like(ps); pq2 = torch.zeros_like(pq)
+            j = capi.ConvJob()
+            j.in_, j.wp, j.out, j.psum, j.psq = x.data_ptr(), wp.data_ptr(), o2.data_ptr(), ps2.data_ptr(), pq2.data_ptr()
+            C.memmove(C.byref(j.d), C.byref(d), C.sizeof(d))
+            tile = call.pn2_conv_gemm_tile(BF16, C.byref(j.d))
+            assert tile >> 8 == bm
+            structs.append(j); nbs.append(call.pn2_conv_gemm_job_blocks(BF16, C.byref(j), tile >> 8, tile & 255)); multi.append((o2, ps2, pq2))
+        table, bstart, total = _job_table(capi.ConvJob, structs, nbs)
+        call.pn2_conv_gemm_multi(BF16, tile >> 8, tile & 255, 0, _p(table), _p(bstart), len(structs), total, st)
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(single, multi)):
+            assert torch.equal(a[0], b[0]), (bm, i, "output")
+            assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (bm, i, "statistics")
