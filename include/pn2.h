@@ -106,7 +106,10 @@ int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const
  * position of independent chains (the RFB branches of the three RFB modules, pranet.py:46-83; the parallel 3x3 convs of a Res2Net stage block,
  * Res2Net_v1b.py:66-69) run in lock step.  pn2_conv_gemm_tile = (bm << 8 | bn) pn2_conv_gemm would pick for a desc (the partial-row counts of its
  * statistics depend on bm, so a job must run on its own tile); jobs of equal tile and equal `ep` use (any target mode / b.out set) share a launch.
- * The general (not pointwise-specialised) kernels serve every job; split-K jobs cannot join.  Bit-identical to the single launches. */
+ * The general (not pointwise-specialised) kernels serve every job; split-K jobs cannot join.  Bit-identical to the single launches.
+ * `ep`: bit 0 = the jobs carry a pn2_conv_ep; for bf16 its operand tiles are staged in LDS and the launch is sized for what the jobs need -
+ * bit 1: a.mode has PN2_BNB_STATS, bit 2: ... and PN2_BNB_MASK_Y, bit 3: PN2_CONV_ACCUM, bit 4: b.out with PN2_BNB_STATS (OR over the jobs; no
+ * bits = all four, which does not fit 160 KB for a 128 x 128 tile: returns -4). */
 typedef struct pn2_conv_job { const void* in; const void* wp; void* out; float* psum; float* psq; pn2_conv_desc d; int pad_; pn2_conv_ep ep; } pn2_conv_job;
 int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d);
 int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn);

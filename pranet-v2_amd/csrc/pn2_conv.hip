@@ -235,6 +235,214 @@ __device__ __forceinline__ void bnb_target(const pn2_bnb_target& t, T* __restric
     for (int e = 0; e < VEC; ++e) { s1[e] = t1[e]; s2[e] = is[e] * (t2[e] - mu[e] * t1[e]); }
 }
 
+// The same fragment by inline asm.  hipcc orders every compiler-visible LDS access behind ALL outstanding vector-memory operations of a kernel
+// that uses LDS-DMA (s_waitcnt vmcnt(0): it cannot tell a DMA landing from a global store in flight), so an LDS read after a global store costs a
+// full store round trip (measured: 4 x ~2 us in a walk of 4 rows).  The epilogues therefore read LDS through asm (waits are counted by hand) and
+// issue their global stores last.
+typedef unsigned u32x2_t_ __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
+__device__ __forceinline__ void tr_frag_issue(unsigned tile, int rs, int chan0, int lane, u32x2_t_& lo, u32x2_t_& hi) {
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned a = tile + (g * 4 + (i >> 2)) * rs + (chan0 + (i & 3) * 4) * 2;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a + 16 * rs));
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm-backward epilogue of the bf16 kernels (pn2_conv_gemm_ep), second form.  Phase stamps of the first form (tools/stamp_micro.py ep; one
+// thread owns a channel vector and walks its rows with every operand prefetched into registers, sums carried in registers and met in LDS) on the
+// 1x1 dgrads of layer1: of a workgroup's 8.6 us, 1.2 us issuing the register prefetch, 2.3 us the walk (~100 VALU ops per 8 elements at two waves per
+// SIMD), 1.3 us meeting the sums in LDS and writing them - and 184-344 registers.  Here
+//   * the operand tiles (raw conv output, stored activation for the mask, the destination's prior content for +=) come by LDS-DMA into dense
+//     [BM][BN] tiles behind the C tile - no registers, no 64-bit address arithmetic per row;
+//   * the walk works on PACKED bf16 pairs: stored = C (+ prior), keep-mask from the sign of fmaf(m, scale, shift) as a bit mask, dz = stored & mask,
+//     written back over the C tile (~45 ops per 8 elements);
+//   * sum dz and sum dz * raw come from the matrix cores, from the dz tile and the raw tile read back transposed: ones x F_dz and the diagonal of
+//     F_raw^T F_dz - exact products of bf16 values summed in fp32; no per-thread sums, no LDS meeting, one barrier less.
+// Same definition of the sums as before (they see the STORED, rounded gradient); fp32 keeps the register form below.
+// ------------------------------------------------------------------------------------------------
+// Which tiles take this form: measured per launch (tools/stamp_micro.py ep, same box) it wins on the narrow tiles of the 3x3 dgrads (128 x 32 tile,
+// 64 -> 32 channels at 176^2: 137.7 -> 115.7 us; registers 158 -> 118, one more workgroup per CU) and loses on the wide tiles of the 1x1 dgrads
+// with += (64 x 128: 142 -> 154 us, 90.8 -> 100.3 us: three operand tiles cost ~1 us of LDS-DMA issue per workgroup and the sums + stores tail
+// 2.3 us against 1.3 us of the register form).  Tiles of at most 4096 elements use it, the others keep the register form.
+constexpr bool ep2_tile(int bm, int bn) { return bm * bn <= 4096; }
+struct Ep2Layout { int raw_a, y_a, prior, raw_b, dz_b, total; };
+template <int BM, int BN>
+__host__ __device__ inline Ep2Layout ep2_layout(bool stat_a, bool y_a, bool acc, bool stat_b) {
+    constexpr int CT = BM * (BN * 2 + 16), TB = BM * BN * 2;
+    Ep2Layout L; int off = CT;
+    L.raw_a = off; if (stat_a) off += TB;
+    L.y_a = off; if (y_a) off += TB;
+    L.prior = off; if (acc) off += TB;
+    L.raw_b = off; if (stat_b) off += TB;
+    L.dz_b = off; if (stat_b) off += CT;
+    L.total = off;
+    return L;
+}
+__host__ __device__ inline void ep2_needs(const pn2_conv_desc& d, const pn2_conv_ep& ep, bool& stat_a, bool& y_a, bool& acc, bool& stat_b) {
+    stat_a = (ep.a.mode & PN2_BNB_STATS) != 0;
+    y_a = stat_a && (ep.a.mode & PN2_BNB_MASK_Y) != 0;
+    acc = (d.flags & PN2_CONV_ACCUM) != 0;
+    stat_b = ep.b.out != nullptr && (ep.b.mode & PN2_BNB_STATS) != 0;
+}
+
+// one [BM][BN] bf16 operand tile -> LDS, dense rows, by LDS-DMA.  Tensors below 2 GB without a column split go through a buffer descriptor: one
+// 32-bit offset per lane, stepped by a constant per request, rows past M read as zeros (out of range); otherwise flat 64-bit addresses, rows clamped.
+// Columns past Cout are clamped to the tile's first chunk.  None of the clamped / zero values ever counts: their dz is zero or their column is not written.
+template <int BM, int BN>
+__device__ __forceinline__ void ep2_dma_tile(char* region, const bf16_t* base, int ld, const bf16_t* base2, int split, int M, int m0, int n0, int Cout) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int CPR = BN / 8, NCH = BM * CPR, RPK = 256 / CPR;       // chunks per row / per tile, rows per round of the 4 waves
+    static_assert(NCH % 256 == 0 && 256 % CPR == 0, "tile must split over 4 waves x 64 lanes");
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = wid * 64 + lane, row0 = p0 / CPR, ch = p0 - row0 * CPR;
+    int col = n0 + ch * 8;
+    if (col >= Cout) col = n0;
+    const size_t extent = (size_t)M * (size_t)ld * 2;
+    if (split <= 0 && extent < 0x7fffffffull) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)base >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)base)), 0, (int)extent, 0x00020000);
+        unsigned vo = ((unsigned)(m0 + row0) * (unsigned)ld + (unsigned)col) * 2u;
+        const unsigned step = (unsigned)RPK * (unsigned)ld * 2u;
+#pragma unroll
+        for (int k = 0; k < NCH / 256; ++k) {
+            // (an offset that wrapped past 2^32 cannot occur: (m0 + BM) * ld * 2 < extent + BM * ld * 2 < 2^32)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(region + (k * 4 + wid) * 1024), 16, (int)vo, 0, 0, 0);
+            vo += step;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NCH / 256; ++k) {
+            const int m = min(m0 + row0 + k * RPK, M - 1);
+            const bf16_t* b = (split > 0 && col >= split && base2) ? base2 : base;
+            __builtin_amdgcn_global_load_lds((gptr_t)(b + (size_t)m * ld + col), (lptr_t)(region + (k * 4 + wid) * 1024), 16, 0, 0);
+        }
+    }
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void ep2_issue(char* smem, const pn2_conv_desc& d, const pn2_conv_ep& ep, const bf16_t* out, int M, int m0, int n0) {
+    bool stat_a, y_a, acc, stat_b;
+    ep2_needs(d, ep, stat_a, y_a, acc, stat_b);
+    const Ep2Layout L = ep2_layout<BM, BN>(stat_a, y_a, acc, stat_b);
+    if (stat_a) ep2_dma_tile<BM, BN>(smem + L.raw_a, (const bf16_t*)ep.a.raw, ep.a.ld_raw, (const bf16_t*)ep.a.raw2, ep.a.split, M, m0, n0, d.Cout);
+    if (y_a) ep2_dma_tile<BM, BN>(smem + L.y_a, (const bf16_t*)ep.a.y, ep.a.ld_y, nullptr, 0, M, m0, n0, d.Cout);
+    if (acc) ep2_dma_tile<BM, BN>(smem + L.prior, out, d.ld_out, nullptr, 0, M, m0, n0, d.Cout);
+    if (stat_b) ep2_dma_tile<BM, BN>(smem + L.raw_b, (const bf16_t*)ep.b.raw, ep.b.ld_raw, (const bf16_t*)ep.b.raw2, ep.b.split, M, m0, n0, d.Cout);
+}
+
+// keep-mask of 8 packed bf16 values: element e is kept when fmaf(m_e, sc_e, sh_e) > 0  (m = raw with (scale, shift), or the stored activation with (1, 0))
+// component-wise select on VALUES (a ?: between uint4 lvalues becomes a select between stack slots: scratch traffic with a vmcnt(0) wait each)
+__device__ __forceinline__ uint4 sel4(bool c, uint4 a, uint4 b) { return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
+__device__ __forceinline__ unsigned ep2_keep2(unsigned v, unsigned m, float sc0, float sh0, float sc1, float sh1) {
+    const bool k0 = fmaf(__uint_as_float(m << 16), sc0, sh0) > 0.f;
+    const bool k1 = fmaf(__uint_as_float(m & 0xffff0000u), sc1, sh1) > 0.f;
+    return v & ((k0 ? 0x0000ffffu : 0u) | (k1 ? 0xffff0000u : 0u));
+}
+__device__ __forceinline__ uint4 ep2_masked(const uint4& v, const uint4& m, const float (&sc)[8], const float (&sh)[8]) {
+    return make_uint4(ep2_keep2(v.x, m.x, sc[0], sh[0], sc[1], sh[1]), ep2_keep2(v.y, m.y, sc[2], sh[2], sc[3], sh[3]),
+                      ep2_keep2(v.z, m.z, sc[4], sh[4], sc[5], sh[5]), ep2_keep2(v.w, m.w, sc[6], sh[6], sc[7], sh[7]));
+}
+
+// mask coefficients of this thread's channel vector for one target (statistics columns only)
+__device__ __forceinline__ void ep2_mask_params(const pn2_bnb_target& t, const float* par, int colc, bool stat, int& kind, float (&sc)[8], float (&sh)[8]) {
+    kind = 0;                                        // 0: keep everything, 1: mask from raw, 2: mask from the stored activation
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    if (!stat) return;
+    if (t.mode & PN2_BNB_MASK_Y) kind = 2;
+    else if (t.mode & PN2_BNB_MASK_RAW) {
+        kind = 1;
+        const float4 a0 = *reinterpret_cast<const float4*>(par + colc), a1 = *reinterpret_cast<const float4*>(par + colc + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(par + (size_t)t.ps + colc), b1 = *reinterpret_cast<const float4*>(par + (size_t)t.ps + colc + 4);
+        sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+        sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+    }
+}
+
+// the walk: every thread owns one channel vector (8 channels) and RPT rows of the tile.  All LDS reads first (asm), then the arithmetic, then the dz
+// tiles back to LDS; what goes to global memory is handed back in registers and stored after the sums (see tr_frag_issue)
+template <int BM, int BN> struct Ep2Out {
+    static constexpr int RPT = BM * (BN / 8) / 256;
+    uint4 a[RPT], b[RPT];
+};
+template <int BM, int BN>
+__device__ __forceinline__ void ep2_apply(char* smem, const pn2_conv_desc& d, const pn2_conv_ep& ep, int M, int m0, int n0, Ep2Out<BM, BN>& O) {
+    using T = bf16_t;
+    constexpr int VPR = BN / 8, CRS = BN * 2 + 16, RPT = BM * VPR / 256, RSTEP = 256 / VPR;
+    bool stat_a, y_a, acc, stat_b;
+    ep2_needs(d, ep, stat_a, y_a, acc, stat_b);
+    const Ep2Layout L = ep2_layout<BM, BN>(stat_a, y_a, acc, stat_b);
+    const int tid = threadIdx.x, cv = tid % VPR, r0 = tid / VPR, col = n0 + cv * 8;
+    const bool cok = col < d.Cout, dual = ep.b.out != nullptr;
+    const int colc = cok ? col : n0;
+    const void* rawp; const float *parA, *parB = nullptr; bool stA, stB = false;
+    bnb_select(ep.a, colc, rawp, parA, stA);
+    if (dual) bnb_select(ep.b, colc, rawp, parB, stB);
+    int kindA, kindB;
+    float scA[8], shA[8], scB[8], shB[8];
+    ep2_mask_params(ep.a, parA, colc, stA, kindA, scA, shA);
+    ep2_mask_params(ep.b, parB, colc, stB, kindB, scB, shB);          // (stB is false without a second target)
+    const bool smA = stA && (ep.a.mode & PN2_BNB_STORE_MASKED), smB = stB && (ep.b.mode & PN2_BNB_STORE_MASKED);
+    const unsigned base = lds_addr(smem);
+    u32x4_t_ c[RPT], pr[RPT], ma[RPT], mb[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int row = r0 + u * RSTEP;
+        const unsigned tslot = (unsigned)(row * VPR + cv) * 16u;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(c[u]) : "v"(base + row * CRS + cv * 16));
+        if (acc) asm volatile("ds_read_b128 %0, %1" : "=v"(pr[u]) : "v"(base + L.prior + tslot));
+        if (kindA) asm volatile("ds_read_b128 %0, %1" : "=v"(ma[u]) : "v"(base + (kindA == 2 ? L.y_a : L.raw_a) + tslot));
+        if (kindB) asm volatile("ds_read_b128 %0, %1" : "=v"(mb[u]) : "v"(base + L.raw_b + tslot));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int row = r0 + u * RSTEP, m = m0 + row;
+        const bool live = cok && m < M;
+        const uint4 cc = __builtin_bit_cast(uint4, c[u]);
+        uint4 o = cc;
+        if (acc) {
+            float x[8], y[8];
+            TT<T>::unpack(cc, x);
+            TT<T>::unpack(__builtin_bit_cast(uint4, pr[u]), y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += y[e];
+            o = TT<T>::pack(x);                      // the statistics see the STORED (rounded) gradient, as a separate reduce pass would
+        }
+        uint4 dz = o;
+        if (kindA) dz = ep2_masked(o, __builtin_bit_cast(uint4, ma[u]), scA, shA);
+        O.a[u] = sel4(smA, dz, o);
+        if (stat_a) *reinterpret_cast<uint4*>(smem + row * CRS + cv * 16) = sel4(live && stA, dz, zero);      // dz tile of target a, in place
+        if (dual) {
+            uint4 dzb = cc;                           // the second target takes the GEMM's own tile (never +=)
+            if (kindB) dzb = ep2_masked(cc, __builtin_bit_cast(uint4, mb[u]), scB, shB);
+            O.b[u] = sel4(smB, dzb, cc);
+            if (stat_b) *reinterpret_cast<uint4*>(smem + L.dz_b + row * CRS + cv * 16) = sel4(live && stB, dzb, zero);
+        }
+    }
+}
+template <int BM, int BN>
+__device__ __forceinline__ void ep2_store(const pn2_conv_desc& d, const pn2_conv_ep& ep, bf16_t* __restrict__ out, int M, int m0, int n0, const Ep2Out<BM, BN>& O) {
+    constexpr int VPR = BN / 8, RPT = BM * VPR / 256, RSTEP = 256 / VPR;
+    const int tid = threadIdx.x, cv = tid % VPR, r0 = tid / VPR, col = n0 + cv * 8;
+    const bool cok = col < d.Cout, dual = ep.b.out != nullptr;
+    bf16_t* outb = reinterpret_cast<bf16_t*>(ep.b.out);
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int m = m0 + r0 + u * RSTEP;
+        if (cok && m < M) {
+            *reinterpret_cast<uint4*>(out + (size_t)m * d.ld_out + col) = O.a[u];
+            if (dual) *reinterpret_cast<uint4*>(outb + (size_t)m * ep.b.ld_out + col) = O.b[u];
+        }
+    }
+}
+
 // BatchNorm batch statistics of a staged bf16 C tile [BM][BN] (row stride crs bytes) on the matrix cores; rows >= nrow are zeros.
 // Wave w takes the 16-channel blocks w, w + 4, ...; writes (mean, M2) of the tile per channel to psum / psq [bm][Cout].
 template <int BM, int BN>
@@ -242,25 +450,99 @@ __device__ __forceinline__ void mfma_stats(const char* Cs, int crs, int nrow, in
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
     const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
     const double rn = nrow == BM ? 1.0 / BM : 1.0 / (double)nrow;      // (uniform branch: the division runs in the last row block only)
+    constexpr int NCB = (BN / 16 + 3) / 4, KC = BM / 32;
+    const unsigned cs = lds_addr(Cs);
+    float S[NCB], Q[NCB];
 #pragma unroll
-    for (int cb = wid; cb < BN / 16; cb += 4) {
-        f32x4_t aS = {0.f, 0.f, 0.f, 0.f}, aQ = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NCB; ++c) {
+        const int cb = wid + 4 * c;
+        S[c] = 0.f; Q[c] = 0.f;
+        if (cb < BN / 16) {
+            u32x2_t_ lo[KC], hi[KC];
 #pragma unroll
-        for (int kc = 0; kc < BM / 32; ++kc) {
-            const uint4 F = tr_frag_bf16(Cs + kc * 32 * crs, crs, cb * 16, lane);
-            MMA<bf16_t>::run(aQ, F, F);
-            MMA<bf16_t>::run(aS, ones, F);
+            for (int kc = 0; kc < KC; ++kc) tr_frag_issue(cs + kc * 32 * crs, crs, cb * 16, lane, lo[kc], hi[kc]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4_t aS = {0.f, 0.f, 0.f, 0.f}, aQ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const uint4 F = make_uint4(lo[kc].x, lo[kc].y, hi[kc].x, hi[kc].y);
+                MMA<bf16_t>::run(aQ, F, F);
+                MMA<bf16_t>::run(aS, ones, F);
+            }
+            // column l15: its sum is every row of aS; its sum of squares is the diagonal element of aQ, held by the lane with g == l15 >> 2
+            const int rr = l15 & 3;
+            float qd = rr == 0 ? aQ[0] : (rr == 1 ? aQ[1] : (rr == 2 ? aQ[2] : aQ[3]));
+            qd = (l15 >> 2) == g ? qd : 0.f;
+            qd += __shfl_xor(qd, 16); qd += __shfl_xor(qd, 32);
+            S[c] = aS[0]; Q[c] = qd;
         }
-        // column l15: its sum is every row of aS; its sum of squares is the diagonal element of aQ, held by the lane with g == l15 >> 2
-        const int rr = l15 & 3;
-        float qd = rr == 0 ? aQ[0] : (rr == 1 ? aQ[1] : (rr == 2 ? aQ[2] : aQ[3]));
-        qd = (l15 >> 2) == g ? qd : 0.f;
-        qd += __shfl_xor(qd, 16); qd += __shfl_xor(qd, 32);
-        const int col = n0 + cb * 16 + l15;
-        if (g == 0 && col < Cout) {
-            const double S = (double)aS[0], mean = S * rn, m2 = (double)qd - S * mean;
+    }
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int cb = wid + 4 * c, col = n0 + cb * 16 + l15;
+        if (cb < BN / 16 && g == 0 && col < Cout) {
+            const double Sd = (double)S[c], mean = Sd * rn, m2 = (double)Q[c] - Sd * mean;
             psum[(size_t)bm * Cout + col] = (float)mean;
             psq[(size_t)bm * Cout + col] = (float)(m2 > 0.0 ? m2 : 0.0);
+        }
+    }
+}
+
+// p1 = sum dz, p2 = invstd * (sum dz * raw - mean * sum dz) per channel of the tile, on the matrix cores; wave w takes the 16-channel blocks w, w + 4, ...
+template <int BM, int BN>
+__device__ __forceinline__ void ep2_sums(const char* dz, const char* raw, const pn2_bnb_target& t, int Cout, int n0, int bm) {
+    constexpr int CRS = BN * 2 + 16, NCB = (BN / 16 + 3) / 4, KC = BM / 32;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    const unsigned dza = lds_addr(dz), rawa = lds_addr(raw);
+    float T1[NCB], T2[NCB], MU[NCB], IS[NCB];
+    bool ST[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {                  // this lane's (mean, invstd): requested now, needed after the MFMAs
+        const int cb = wid + 4 * c, col = n0 + cb * 16 + l15;
+        MU[c] = 0.f; IS[c] = 0.f; ST[c] = false;
+        if (cb < BN / 16 && g == 0 && col < Cout) {
+            const void* rw; const float* par;
+            bnb_select(t, col, rw, par, ST[c]);
+            if (ST[c]) { MU[c] = par[(size_t)2 * t.ps + col]; IS[c] = par[(size_t)3 * t.ps + col]; }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int cb = wid + 4 * c;
+        T1[c] = 0.f; T2[c] = 0.f;
+        if (cb < BN / 16) {
+            u32x2_t_ dl[KC], dh[KC], rl[KC], rh[KC];
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                tr_frag_issue(dza + kc * 32 * CRS, CRS, cb * 16, lane, dl[kc], dh[kc]);
+                tr_frag_issue(rawa + kc * 32 * BN * 2, BN * 2, cb * 16, lane, rl[kc], rh[kc]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4_t a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const uint4 Fd = make_uint4(dl[kc].x, dl[kc].y, dh[kc].x, dh[kc].y), Fr = make_uint4(rl[kc].x, rl[kc].y, rh[kc].x, rh[kc].y);
+                MMA<bf16_t>::run(a1, ones, Fd);
+                MMA<bf16_t>::run(a2, Fr, Fd);
+            }
+            const int rr = l15 & 3;
+            float q = rr == 0 ? a2[0] : (rr == 1 ? a2[1] : (rr == 2 ? a2[2] : a2[3]));
+            q = (l15 >> 2) == g ? q : 0.f;
+            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+            T1[c] = a1[0]; T2[c] = q;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int cb = wid + 4 * c, col = n0 + cb * 16 + l15;
+        if (cb < BN / 16 && g == 0 && col < Cout) {
+            float s1 = 0.f, s2 = 0.f;
+            if (ST[c]) { s1 = T1[c]; s2 = IS[c] * (T2[c] - MU[c] * s1); }
+            t.p1[(size_t)bm * t.ldp + col] = s1;
+            t.p2[(size_t)bm * t.ldp + col] = s2;
         }
     }
 }
@@ -284,8 +566,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
     const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
     char* Cs = smem;
     float* red = reinterpret_cast<float*>(smem + BM * CRS);   // [3][WM][BN]: shifted sum, shifted sum of squares, shift
+    constexpr bool EP2 = EP && sizeof(T) == 2 && ep2_tile(BM, BN);          // bf16, narrow tiles: operand tiles by LDS-DMA, sums on the matrix cores (ep2_*)
+    if constexpr (EP2) ep2_issue<BM, BN>(smem, d, ep, reinterpret_cast<const bf16_t*>(out), M, m0, n0);
 #ifndef PN2_EP_PREFETCH_EARLY
-    if constexpr (EP) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);      // in flight while the C tile is staged
+    if constexpr (EP && !EP2) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);      // in flight while the C tile is staged
 #endif
     const bool full_m = m0 + BM <= M;
     if constexpr (SWP) {
@@ -336,6 +620,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
             }
         }
         PN2_STAMP_AT(13);
+        if constexpr (EP2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's operand-tile DMA has landed; the barrier publishes everyone's
         __syncthreads();
         PN2_STAMP_AT(6);
         if constexpr (EP) { if (d.flags & PN2_CONV_STATS) mfma_stats<BM, BN>(Cs, CRS, min(M - m0, BM), d.Cout, n0, bm, psum, psq); }
@@ -426,6 +711,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
                 }
     }
     PN2_STAMP_AT(13);
+    if constexpr (EP2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PN2_STAMP_AT(6);
     if constexpr (MST && EP) { if (d.flags & PN2_CONV_STATS) mfma_stats<BM, BN>(Cs, CRS, min(M - m0, BM), d.Cout, n0, bm, psum, psq); }
@@ -488,6 +774,18 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
         }
         // (swapped epilogue) statistics AFTER the stores have been issued: they drain while the matrix cores reduce the staged tile
         if constexpr (SWP || sizeof(T) == 2) { if (d.flags & PN2_CONV_STATS) mfma_stats<BM, BN>(Cs, CRS, min(M - m0, BM), d.Cout, n0, bm, psum, psq); }
+    } else if constexpr (EP2) {
+        Ep2Out<BM, BN> O;
+        ep2_apply<BM, BN>(smem, d, ep, M, m0, n0, O);
+        PN2_STAMP_AT(14);
+        __syncthreads();                               // the dz tiles are complete
+        PN2_STAMP_AT(15);
+        bool stat_a, y_a, acc_, stat_b;
+        ep2_needs(d, ep, stat_a, y_a, acc_, stat_b);
+        const Ep2Layout L = ep2_layout<BM, BN>(stat_a, y_a, acc_, stat_b);
+        if (stat_a) ep2_sums<BM, BN>(smem, smem + L.raw_a, ep.a, d.Cout, n0, bm);
+        if (stat_b) ep2_sums<BM, BN>(smem + L.dz_b, smem + L.raw_b, ep.b, d.Cout, n0, bm);
+        ep2_store<BM, BN>(d, ep, reinterpret_cast<bf16_t*>(out), M, m0, n0, O);      // global stores last
     } else {
     // ---- BatchNorm-backward statistics of the produced gradient tile (vector path only: the host checks the alignment)
     float sums[4][VEC];
@@ -922,8 +1220,11 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
 #endif
 }
 
+#ifndef PN2_EP_WAVES
+#define PN2_EP_WAVES 1
+#endif
 template <int BM, int BN, int WM, int WN, bool PW, int NS = 3, bool EP = false>
-__global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, ((EP && BM * BN <= 8192) ? PN2_EP_WAVES : 1)) void conv_dma_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
                                                      float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
     conv_dma_body<BM, BN, WM, WN, PW, NS, EP>(in, wp, out, psum, psq, d, ep, blockIdx.x, gridDim.x, blockIdx.y);
 }
@@ -1667,19 +1968,38 @@ inline int reduce_blocks(const pn2_pack_desc& p) {
     return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
 }
 
+// dynamic LDS of the bf16 BatchNorm-backward epilogue for this launch (C tile + the operand tiles it needs)
+template <int BM, int BN>
+inline int ep2_lds_for(const pn2_conv_desc& d, const pn2_conv_ep& ep) {
+    bool stat_a, y_a, acc, stat_b;
+    ep2_needs(d, ep, stat_a, y_a, acc, stat_b);
+    return ep2_layout<BM, BN>(stat_a, y_a, acc, stat_b).total;
+}
+// table launches: the caller says what the jobs need (bits 1..4 of `ep`: statistics a, mask-from-activation a, +=, statistics b); no bits = everything
+template <int BM, int BN>
+inline int ep2_lds_bits(int bits) {
+    if (!(bits & 15)) bits = 15;
+    return ep2_layout<BM, BN>(bits & 1, bits & 2, bits & 4, bits & 8).total;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool EP>
 int launch_gemm(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
     const int M = d.N * d.OH * d.OW;
     const int grid = ((M + BM - 1) / BM) * ((d.Cout + BN - 1) / BN);
     constexpr int main_b = 2 * (BM + BN) * RS, epi_b = BM * (BN * (int)sizeof(T) + 16) + 3 * WM * BN * 4;
-    constexpr int ep_b = EP ? ep_lds_bytes(TT<T>::VEC) : 0;
-    constexpr int lds = (main_b > epi_b ? main_b : epi_b) > ep_b ? (main_b > epi_b ? main_b : epi_b) : ep_b;
+    constexpr bool E2 = EP && sizeof(T) == 2 && ep2_tile(BM, BN);
+    constexpr int ep_b = (EP && !E2) ? ep_lds_bytes(TT<T>::VEC) : 0;
+    constexpr int lds0 = (main_b > epi_b ? main_b : epi_b) > ep_b ? (main_b > epi_b ? main_b : epi_b) : ep_b;
+    int lds = lds0;
+    if (E2) { const int e2 = ep2_lds_for<BM, BN>(d, ep); if (e2 > lds) lds = e2; }
+    if (lds > 160 * 1024) return -4;
     const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
-    if (lds > 64 * 1024) {      // opt in to more than 64 KiB of dynamic LDS once per instantiation
+    if (lds0 > 64 * 1024 || E2) {      // opt in to more than 64 KiB of dynamic LDS once per instantiation
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, true, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, false, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            const int cap = E2 ? 160 * 1024 : lds0;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, true, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, false, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
             done = true;
         }
     }
@@ -1698,13 +2018,17 @@ int launch_dma(const void* in, const void* wp, void* out, float* psum, float* ps
     const int ksteps = (d.KH * d.KW * d.Cin_p + 63) / 64;
     const int main_b = (ksteps < NS ? ksteps : NS) * stage_b;
     int lds = main_b > epi_b ? main_b : epi_b;
-    if (EP && lds < ep_lds_bytes(8)) lds = ep_lds_bytes(8);
+    constexpr bool E2 = EP && ep2_tile(BM, BN);
+    if (E2) { const int e2 = ep2_lds_for<BM, BN>(d, ep); if (e2 > lds) lds = e2; }
+    else if (EP && lds < ep_lds_bytes(8)) lds = ep_lds_bytes(8);
+    if (lds > 160 * 1024) return -4;
     const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
-    if (max_b > 64 * 1024 || epi_b > 64 * 1024) {
+    if (max_b > 64 * 1024 || epi_b > 64 * 1024 || E2) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, true, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b > epi_b ? max_b : epi_b);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, false, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b > epi_b ? max_b : epi_b);
+            const int cap = E2 ? 160 * 1024 : (max_b > epi_b ? max_b : epi_b);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, true, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, false, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
             done = true;
         }
     }
@@ -1723,7 +2047,7 @@ int launch_bres(const void* in, const void* wp, void* out, float* psum, float* p
     const int ksteps = (d.KH * d.KW * d.Cin_p + 63) / 64;
     constexpr int ring = bres_ring_bytes<BM, BN, WM, WN, NS, EP>();
     const int lds = ring + ksteps * BN * 128;
-    if (lds > 160 * 1024 || ((d.flags >> 16) & 15) > 1) return -100;
+    if ((EP && ep2_tile(BM, BN)) || lds > 160 * 1024 || ((d.flags >> 16) & 15) > 1) return -100;      // (the operand tiles of the LDS-DMA form of the BatchNorm-backward epilogue would sit on the resident panel)
     const int nbn = (d.Cout + BN - 1) / BN, nbm = (M + BM - 1) / BM;
     int occ = (160 * 1024) / lds; if (occ > 3) occ = 3; if (occ < 1) occ = 1;
     int P = (256 * occ) / nbn; if (P < 1) P = 1; if (P > nbm) P = nbm;
@@ -1847,13 +2171,15 @@ void gemm_select(const pn2_conv_desc& d, int& kern, int& bm, int& bn) {
 
 // table-driven conv GEMM launches: general (non-pointwise-specialised) kernels, LDS-DMA 3-stage for bf16, register-staged for fp32
 template <bool EP, int BM, int BN, int WM, int WN>
-int launch_dma_tab(const pn2_conv_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
+int launch_dma_tab(const pn2_conv_job* jobs, const int* bstart, int njobs, int total, int bits, hipStream_t st) {
     constexpr int stage_b = (BM + BN) * 128, max_b = 3 * stage_b, epi_b = BM * (BN * 2 + 16) + 3 * WM * BN * 4;
     int lds = max_b > epi_b ? max_b : epi_b;
-    if (EP && lds < ep_lds_bytes(8)) lds = ep_lds_bytes(8);
+    if (EP && ep2_tile(BM, BN)) { const int e2 = ep2_lds_bits<BM, BN>(bits); if (e2 > lds) lds = e2; }
+    else if (EP && lds < ep_lds_bytes(8)) lds = ep_lds_bytes(8);
+    if (lds > 160 * 1024) return -4;
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_tab<BM, BN, WM, WN, false, 3, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_tab<BM, BN, WM, WN, false, 3, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, EP ? 160 * 1024 : lds);
         done = true;
     }
     hipLaunchKernelGGL((conv_dma_gemm_tab<BM, BN, WM, WN, false, 3, EP>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
@@ -1874,16 +2200,16 @@ int launch_gather_tab_f32(const pn2_conv_job* jobs, const int* bstart, int njobs
     return 0;
 }
 template <bool EP>
-int gemm_multi_dispatch(int dtype, int bm, int bn, const pn2_conv_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
+int gemm_multi_dispatch(int dtype, int bm, int bn, int bits, const pn2_conv_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
     if (dtype == PN2_BF16) {
         if (bm == 128) {
-            if (bn == 128) return launch_dma_tab<EP, 128, 128, 2, 2>(jobs, bstart, njobs, total, st);
-            if (bn == 64) return launch_dma_tab<EP, 128, 64, 2, 2>(jobs, bstart, njobs, total, st);
-            if (bn == 32) return launch_dma_tab<EP, 128, 32, 4, 1>(jobs, bstart, njobs, total, st);
+            if (bn == 128) return launch_dma_tab<EP, 128, 128, 2, 2>(jobs, bstart, njobs, total, bits, st);
+            if (bn == 64) return launch_dma_tab<EP, 128, 64, 2, 2>(jobs, bstart, njobs, total, bits, st);
+            if (bn == 32) return launch_dma_tab<EP, 128, 32, 4, 1>(jobs, bstart, njobs, total, bits, st);
         } else if (bm == 64) {
-            if (bn == 128) return launch_dma_tab<EP, 64, 128, 2, 2>(jobs, bstart, njobs, total, st);
-            if (bn == 64) return launch_dma_tab<EP, 64, 64, 2, 2>(jobs, bstart, njobs, total, st);
-            if (bn == 32) return launch_dma_tab<EP, 64, 32, 4, 1>(jobs, bstart, njobs, total, st);
+            if (bn == 128) return launch_dma_tab<EP, 64, 128, 2, 2>(jobs, bstart, njobs, total, bits, st);
+            if (bn == 64) return launch_dma_tab<EP, 64, 64, 2, 2>(jobs, bstart, njobs, total, bits, st);
+            if (bn == 32) return launch_dma_tab<EP, 64, 32, 4, 1>(jobs, bstart, njobs, total, bits, st);
         }
         return -2;
     }
@@ -2274,8 +2600,8 @@ int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn) {
 
 int pn2_conv_gemm_multi(int dtype, int bm, int bn, int ep, const pn2_conv_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
     if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
-    return ep ? gemm_multi_dispatch<true>(dtype, bm, bn, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream)
-              : gemm_multi_dispatch<false>(dtype, bm, bn, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
+    return (ep & 1) ? gemm_multi_dispatch<true>(dtype, bm, bn, ep >> 1, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream)
+                    : gemm_multi_dispatch<false>(dtype, bm, bn, 0, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
 }
 
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream) {

@@ -777,8 +777,13 @@ class Engine:
                     cands.append(kern | (bm << 2) | (bn << 4))
         evs = []
         cold = TUNE_COLD
+        feasible = []
         for code in cands:
-            launch(code)
+            try:
+                launch(code)
+            except RuntimeError:        # status -4: the epilogue's operand tiles of this tile shape do not fit the LDS (128 x 128 with two targets and +=)
+                continue
+            feasible.append(code)
             per = []
             for _ in range(TUNE_REPS):
                 if cold:            # inside a step every conv runs once, on operands the caches have mostly lost: time it that way
@@ -791,7 +796,9 @@ class Engine:
             evs.append(per)
         torch.cuda.synchronize()
         times = [min(a.elapsed_time(b) for a, b in per) for per in evs]
-        best = cands[min(range(len(cands)), key=lambda i: times[i])]
+        if not feasible:
+            raise RuntimeError(f"no conv kernel candidate could be launched for {key}")
+        best = feasible[min(range(len(feasible)), key=lambda i: times[i])]
         t[key] = best
         return best
 

@@ -236,7 +236,13 @@ class Lockstep:
                     capi.WORK.clear()
                     capi.WORK.update(flops=sum(j[4].get("flops", 0) for j in jobs), tag=jobs[0][4].get("tag", ""), shape=f"lockstep x{n} tile {kind[2]}x{kind[3]}",
                                      shapes=[j[4].get("shape", "") for j in jobs])
-                    call.pn2_conv_gemm_multi(kind[1], kind[2], kind[3], kind[4], _p(table), _p(bstart), n, total, st)
+                    epbits = kind[4]
+                    if epbits:       # what the BatchNorm-backward epilogues of these jobs need in LDS (pn2.h: bits 1..4 of `ep`)
+                        for s_ in structs:
+                            sa = s_.ep.a.mode & capi.BNB_STATS
+                            epbits |= (2 if sa else 0) | (4 if sa and (s_.ep.a.mode & capi.BNB_MASK_Y) else 0) | (8 if s_.d.flags & capi.CONV_ACCUM else 0) \
+                                      | (16 if s_.ep.b.out and (s_.ep.b.mode & capi.BNB_STATS) else 0)
+                    call.pn2_conv_gemm_multi(kind[1], kind[2], kind[3], epbits, _p(table), _p(bstart), n, total, st)
                     continue
                 capi.WORK.clear()
                 capi.WORK.update(bytes=self._bytes(jobs))
