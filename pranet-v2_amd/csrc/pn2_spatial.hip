@@ -28,8 +28,11 @@ template <typename T, int W> struct VL {
     }
 };
 
-// (>= 2^32 elements: the kernels index with 32 bits - an impossible grid makes the launch fail, and PN2_CHECK_LAUNCH report it, instead of wrapping around)
-inline int grid_for(size_t total) { if (total >> 32) return -1; size_t g = (total + 255) / 256; return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g)); }
+// The kernels index with 32 bits and step by gridDim.x * 256 <= 16384 * 256: the C entry points refuse (status -2) element counts within one step
+// of 2^32, where `idx += step` would wrap and the loop never end (PN2_TOO_MANY); grid_for keeps the impossible-grid backstop.
+constexpr size_t PIX_MAX = 0xFFFFFFFFull - 16384ull * 256ull;
+#define PN2_TOO_MANY(total) do { if ((size_t)(total) > PIX_MAX) return -2; } while (0)
+inline int grid_for(size_t total) { if (total > PIX_MAX) return -1; size_t g = (total + 255) / 256; return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g)); }
 
 // 32-bit element index (the C entry points refuse tensors of 2^32 or more vectors): the 64-bit `idx % CV`, `p % W`, `p / H` chains of a pixel decode were
 // ~100 instructions each - most of what these streaming kernels executed
@@ -421,6 +424,7 @@ extern "C" {
 
 int pn2_maxpool3x3s2_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, unsigned char* idx, int N, int H, int W, int C, int OH, int OW, void* stream) {
     if (!x || !y || !idx) return -1;
+    PN2_TOO_MANY((size_t)N * OH * OW * C);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dt, {
         if (vec_ok<T>(C, ld_x, ld_y)) hipLaunchKernelGGL((maxpool_fwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * OH * OW * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, idx, N, H, W, C, OH, OW);
@@ -432,6 +436,7 @@ int pn2_maxpool3x3s2_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, uns
 
 int pn2_maxpool3x3s2_bwd(int dt, const void* dy, int ld_dy, const unsigned char* idx, void* dx, int ld_dx, int N, int H, int W, int C, int OH, int OW, void* stream) {
     if (!dy || !dx || !idx) return -1;
+    PN2_TOO_MANY((size_t)N * H * W * C);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dt, {
         if (vec_ok<T>(C, ld_dy, ld_dx)) hipLaunchKernelGGL((maxpool_bwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * H * W * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)dy, ld_dy, idx, (T*)dx, ld_dx, N, H, W, C, OH, OW);
@@ -443,6 +448,7 @@ int pn2_maxpool3x3s2_bwd(int dt, const void* dy, int ld_dy, const unsigned char*
 
 int pn2_avgpool_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int OH, int OW, int k, int stride, int pad, int inc, void* stream) {
     if (!x || !y) return -1;
+    PN2_TOO_MANY((size_t)N * OH * OW * C);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dt, {
         if (vec_ok<T>(C, ld_x, ld_y)) hipLaunchKernelGGL((avgpool_fwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * OH * OW * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, N, H, W, C, OH, OW, k, stride, pad, inc);
@@ -454,6 +460,7 @@ int pn2_avgpool_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int N, i
 
 int pn2_avgpool_bwd(int dt, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C, int OH, int OW, int k, int stride, int pad, int inc, int accumulate, void* stream) {
     if (!dy || !dx) return -1;
+    PN2_TOO_MANY((size_t)N * H * W * C);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dt, {
         if (vec_ok<T>(C, ld_dy, ld_dx)) hipLaunchKernelGGL((avgpool_bwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * H * W * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)dy, ld_dy, (T*)dx, ld_dx, N, H, W, C, OH, OW, k, stride, pad, inc, accumulate);
@@ -465,6 +472,7 @@ int pn2_avgpool_bwd(int dt, const void* dy, int ld_dy, void* dx, int ld_dx, int 
 
 int pn2_bilinear_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int N, int H, int W, int C, int OH, int OW, int ac, float rh, float rw, void* stream) {
     if (!x || !y) return -1;
+    PN2_TOO_MANY((size_t)N * OH * OW * C);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dt, {
         if (vec_ok<T>(C, ld_x, ld_y)) hipLaunchKernelGGL((bilinear_fwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)N * OH * OW * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)x, ld_x, (T*)y, ld_y, N, H, W, C, OH, OW, ac, rh, rw);
@@ -478,6 +486,7 @@ int pn2_bilinear_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int N, 
 
 int pn2_bilinear_bwd(int dt, const void* dy, int ld_dy, void* dx, int ld_dx, int N, int H, int W, int C, int OH, int OW, int ac, float rh, float rw, int accumulate, void* stream) {
     if (!dy || !dx) return -1;
+    PN2_TOO_MANY((size_t)N * H * W * C);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dt, {
         if ((C < TT<T>::VEC || (sizeof(T) == 4 && C <= 16)) && OH >= 4 * H && OW >= 4 * W && ld_dy == C && OW * C <= 8192)      // K-channel fp32 maps (K = 1 .. 9)
@@ -495,6 +504,7 @@ int pn2_bilinear_bwd(int dt, const void* dy, int ld_dy, void* dx, int ld_dx, int
 
 int pn2_binary(int dt, int op, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream) {
     if (!a || !b || !out) return -1;
+    PN2_TOO_MANY((size_t)M * C);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dt, {
         if (vec_ok<T>(C, ld_a, ld_b, ld_out)) hipLaunchKernelGGL((binary_k<T, TT<T>::VEC>), dim3(grid_for((size_t)M * C / TT<T>::VEC)), dim3(256), 0, st, op, (const T*)a, ld_a, (const T*)b, ld_b, (T*)out, ld_out, M, C, accumulate);
@@ -506,6 +516,7 @@ int pn2_binary(int dt, int op, const void* a, int ld_a, const void* b, int ld_b,
 
 int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld_d, int M, int C, int accumulate, void* stream) {
     if (!src || !dst) return -1;
+    PN2_TOO_MANY((size_t)M * C);
     hipStream_t st = (hipStream_t)stream;
     if (dt_in == dt_out) {
         DISPATCH_T(dt_in, {
@@ -523,6 +534,7 @@ int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld
 
 int pn2_nchw_to_nhwc(int dt_out, const float* x, void* y, int ld_y, int N, int C, int HW, int Cp, void* stream) {
     if (!x || !y) return -1;
+    PN2_TOO_MANY((size_t)N * HW);
     hipStream_t st = (hipStream_t)stream;
     if (dt_out == PN2_BF16) hipLaunchKernelGGL(nchw_to_nhwc_k<bf16_t>, dim3(grid_for((size_t)N * HW)), dim3(256), 0, st, x, (bf16_t*)y, ld_y, N, C, HW, Cp);
     else if (dt_out == PN2_F32) hipLaunchKernelGGL(nchw_to_nhwc_k<float>, dim3(grid_for((size_t)N * HW)), dim3(256), 0, st, x, (float*)y, ld_y, N, C, HW, Cp);

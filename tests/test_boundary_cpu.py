@@ -51,6 +51,12 @@ def test_argument_errors_are_reported_not_swallowed():
     assert lib.pn2_conv_gemm(capi.BF16, None, None, None, None, None, ctypes.byref(d), None) == -1     # null pointers
     with pytest.raises(RuntimeError):
         capi.call.pn2_dsra_fuse_fwd(None, None, None, None, 1, 1, 1, None)
+    # the streaming kernels index with 32 bits: element counts within one grid step of 2^32 are refused at the boundary (status -2), before any launch
+    one = ctypes.c_void_p(16)
+    assert lib.pn2_copy(capi.BF16, one, 8, capi.BF16, one, 8, 1 << 20, 4096, 0, None) == -2
+    assert lib.pn2_binary(capi.BF16, 0, one, 8, one, 8, one, 8, 1 << 20, 4096, 0, None) == -2
+    assert lib.pn2_nchw_to_nhwc(capi.BF16, one, one, 8, 1 << 16, 3, 1 << 16, 8, None) == -2
+    assert lib.pn2_bilinear_fwd(capi.BF16, one, 8, one, 8, 64, 8, 8, 4096, 128, 128, 0, 1.0, 1.0, None) == -2
 
 
 def test_state_dict_matches_reference_manifest():

@@ -662,7 +662,7 @@ def test_v1_forward_vs_reference(which):
             k = f[5:]
             r32 = torch.from_numpy(z[f]).double(); r64 = torch.from_numpy(z["f64." + f]).double()
             own = rell2(r32, r64); e = rell2(named[k].grad.reshape(-1)[:256], r64)
-            assert e <= max(2e-6, 1.5 * own), (k, e, own)          # measured <= 1.03 x (the gate / sigmoid kernels use the hardware exp)
+            assert e <= max(2e-6, 1.1 * own), (k, e, own)          # measured <= 1.03 x the reference's own fp32 error (the gate / sigmoid kernels use the hardware exp)
 
 
 def test_graph_replay_matches_eager_bf16():
