@@ -178,12 +178,15 @@ def _conv_bytes(shape, es):
         return 0
 
 
+PMC_FILE = "r03_pmc_hbm_traffic.json"       # the current round's summary (tools/prof_pmc.sh)
+
+
 def _pmc_traffic(symbols, config):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary (profiles/, made by tools/pmc_summary.py from separate
     FETCH_SIZE / WRITE_SIZE passes of `bench.py --no-graph`).  Only reported when that summary was recorded for THIS workload (model, batch,
     size, dtype); None otherwise - a number measured on another configuration would describe a different run."""
     import json, os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r02_pmc_hbm_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", PMC_FILE)
     try:
         doc = json.load(open(path))
         ks = doc["kernels"]
@@ -195,7 +198,7 @@ def _pmc_traffic(symbols, config):
     if not rows:
         return None
     n = sum(r["launches"] for r in rows)
-    return {"bytes_per_launch": int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n), "source": "profiles/r02_pmc_hbm_traffic.json",
+    return {"bytes_per_launch": int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n), "source": "profiles/" + PMC_FILE,
             "commit": doc.get("commit"), "step_total_bytes": doc.get("step_total_bytes")}
 
 

@@ -31,8 +31,8 @@ if __name__ == "__main__":
     skip = ("FillFunctor", "elementwise", "spin_kernel", "pack_weight", "pack_patch")
     steps = max(1, res.get("clamp_adam_k", {}).get("launches", 1))
     total = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in res.items() if not any(s_ in k for s_ in skip))
-    json.dump({"note": "FETCH_SIZE doubled (gfx950 half-count of 128-B requests), WRITE_SIZE as reported; bench.py --no-graph --steps 2 --warmup 1, tile tuner pre-filled "
-                       "(profiles/r02_tune_cache.json); per-launch figures are averages over all launches of a kernel family in the traced run",
+    json.dump({"note": "FETCH_SIZE doubled (gfx950 half-count of 128-B requests), WRITE_SIZE as reported; bench.py --no-graph --steps 2 --warmup 1, shipped tile table "
+                       "(pn2/tuned_gfx950.json); per-launch figures are averages over all launches of a kernel family in the traced run",
                "config": {"model": "res2net", "batch": 32, "size": 352, "dtype": "bf16"}, "commit": commit, "traced_steps": steps,
                "step_total_bytes": int(total / steps), "kernels": res}, open(out, "w"), indent=1)
     print(f"steps {steps}  HBM bytes / step {total / steps / 1e9:.2f} GB")

@@ -1,9 +1,8 @@
 #!/bin/bash
 # rocprofv3 kernel stats of a bench.py command (GPU box): prof_bench.sh <out.csv> [bench.py args]; the CSV lands in gpurun_out/.
-# The tile tuner is pre-filled from profiles/r03_tune_cache.json (or $PN2_TUNE_CACHE; made by a plain bench.py run with PN2_TUNE_CACHE pointing at it), so the
-# trace holds no tuner launches and no cache-evicting fills: the per-kernel averages are those of the steady-state step.
+# The shipped tile table (pn2/tuned_gfx950.json) covers every conv shape of the benchmark configurations, so the trace holds no tuner launches and no
+# cache-evicting fills: the per-kernel averages are those of the steady-state step.
 out=$1; shift
-export PN2_TUNE_CACHE=${PN2_TUNE_CACHE:-$GRAFT_REPO_ROOT/profiles/r03_tune_cache.json}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_bench
 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > /tmp/pb.log 2>&1

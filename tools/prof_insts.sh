@@ -1,8 +1,7 @@
 #!/bin/bash
 # Instruction mix / stall counters per kernel and grid (GPU box): prof_insts.sh <out.csv>  -> gpurun_out/<out.csv>
-# Two PMC passes of an eager step (every kernel its own dispatch), tile tuner pre-filled.  No trace domains together with --pmc.
+# Two PMC passes of an eager step (every kernel its own dispatch), tiles from the shipped table.  No trace domains together with --pmc.
 out=$1
-export PN2_TUNE_CACHE=$GRAFT_REPO_ROOT/profiles/r02_tune_cache.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pi_a /tmp/pi_b
 ARGS="--no-graph --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-line"

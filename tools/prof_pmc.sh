@@ -1,9 +1,8 @@
 #!/bin/bash
 # HBM traffic per kernel family from rocprofv3 PMC counters (GPU box): two separate passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, and
-# gpurun refuses --pmc combined with trace domains), eager launches (--no-graph) so that every kernel is its own dispatch, tile tuner pre-filled.
+# gpurun refuses --pmc combined with trace domains), eager launches (--no-graph) so that every kernel is its own dispatch, tiles from the shipped table.
 # prof_pmc.sh <out.json> <commit>   -> gpurun_out/<out.json>
 out=$1; commit=$2
-export PN2_TUNE_CACHE=${PN2_TUNE_CACHE:-$GRAFT_REPO_ROOT/profiles/r03_tune_cache.json}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_f /tmp/pmc_w
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_f -o pmc --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-line > /tmp/pf.log 2>&1
