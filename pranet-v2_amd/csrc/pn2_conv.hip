@@ -2479,7 +2479,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__
                 T* dst = out + (size_t)m * ld_out + c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    s1[e] += vv[e]; s2[e] += vv[e] * vv[e];
+                    // bf16: the moments of the value as it is STORED (rounded), the one definition of the batch statistics for every bf16 conv kernel
+                    float sv = vv[e];
+                    if constexpr (sizeof(T) == 2) sv = bf2f(f2bf(vv[e]));
+                    s1[e] += sv; s2[e] += sv * sv;
                     const float o = vv[e] + b[e];
                     TT<T>::st(dst + e, accumulate ? o + TT<T>::ld(dst + e) : o);
                 }

@@ -334,7 +334,11 @@ def test_deferred_column_sums_and_splitk_match_immediate_launches(monkeypatch):
         # the plain launch leaves (mean, M2) of its 64-row tiles (Chan partials), the split-K reduce raw moments of the same blocks
         nt = torch.full((nb, 1), 64.0, device=dev); nt[-1] = M - 64 * (nb - 1)
         s1 = (ps1.double() * nt).sum(0); s2 = (pq1.double() + nt * ps1.double() ** 2).sum(0)
-        assert rell2(ps2.double().sum(0), s1) < 1e-5 and rell2(pq2.double().sum(0), s2) < 1e-5
+        # both take the moments of the STORED (bf16-rounded) values: exact against the tensor the reduce wrote, and within the few one-ulp
+        # differences between the two outputs of the plain launch's statistics
+        o64 = o2.double()
+        assert rell2(ps2.double().sum(0), o64.sum(0)) < 2e-6 and rell2(pq2.double().sum(0), (o64 * o64).sum(0)) < 2e-6
+        assert rell2(ps2.double().sum(0), s1) < 2e-4 and rell2(pq2.double().sum(0), s2) < 2e-4
 
 
 def test_full_size_properties_config4_bs16_352_bf16():
