@@ -1018,7 +1018,12 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     const int M = d.N * d.OH * d.OW;
     const int nbn = (d.Cout + BN - 1) / BN;
     const int bid = xcd_remap(lbid, lgrid);
-    const int bn = bid % nbn, bm = bid / nbn;
+    // (tile -> (row block, column block): a scalar division costs ~25 dependent instructions with two VALU round trips at the very top of the kernel;
+    //  one column tile - every narrow conv - or a power-of-two count need none)
+    int bn, bm;
+    if (nbn == 1) { bn = 0; bm = bid; }
+    else if ((nbn & (nbn - 1)) == 0) { const int sh_ = __builtin_ctz(nbn); bn = bid & (nbn - 1); bm = bid >> sh_; }
+    else { bn = bid % nbn; bm = bid / nbn; }
     const int m0 = bm * BM, n0 = bn * BN;
     const int taps = d.KH * d.KW;
     const int ktot = taps * d.Cin_p;
@@ -1079,7 +1084,7 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     const int sdil_h = sgn * d.dil_h, sdil_w = sgn * d.dil_w;
     const int tsh = d.transposed ? gg.sshift : 0, tmsk = d.transposed ? d.stride - 1 : 0;
     int tcol = 0, tdr = 0, tdc = 0;
-    if (!PW) { const int r0_ = tap / d.KW; tcol = tap - r0_ * d.KW; tdr = r0_ * sdil_h; tdc = tcol * sdil_w; }
+    if (!PW && tap) { const int r0_ = tap / d.KW; tcol = tap - r0_ * d.KW; tdr = r0_ * sdil_h; tdc = tcol * sdil_w; }      // (tap 0 unless a split-K slice starts later)
     const int ldb = d.ld_in * 2;                       // row pitch in bytes
     unsigned rowoff[NA];                               // PW: byte offset of the row; else: pixel index of the image origin
 #pragma unroll
