@@ -452,37 +452,36 @@ __device__ __forceinline__ void mfma_stats(const char* Cs, int crs, int nrow, in
     const double rn = nrow == BM ? 1.0 / BM : 1.0 / (double)nrow;      // (uniform branch: the division runs in the last row block only)
     constexpr int NCB = (BN / 16 + 3) / 4, KC = BM / 32;
     const unsigned cs = lds_addr(Cs);
-    float S[NCB], Q[NCB];
+    // all of this wave's blocks at once: every transposing read is requested before the one wait, the 2 * NCB accumulator chains interleave
+    u32x2_t_ lo[NCB][KC], hi[NCB][KC];
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
-        const int cb = wid + 4 * c;
-        S[c] = 0.f; Q[c] = 0.f;
-        if (cb < BN / 16) {
-            u32x2_t_ lo[KC], hi[KC];
+        const int cb = min(wid + 4 * c, BN / 16 - 1);                  // (a wave without a block c re-reads its last one; nothing is written for it)
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) tr_frag_issue(cs + kc * 32 * crs, crs, cb * 16, lane, lo[kc], hi[kc]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4_t aS = {0.f, 0.f, 0.f, 0.f}, aQ = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                const uint4 F = make_uint4(lo[kc].x, lo[kc].y, hi[kc].x, hi[kc].y);
-                MMA<bf16_t>::run(aQ, F, F);
-                MMA<bf16_t>::run(aS, ones, F);
-            }
-            // column l15: its sum is every row of aS; its sum of squares is the diagonal element of aQ, held by the lane with g == l15 >> 2
-            const int rr = l15 & 3;
-            float qd = rr == 0 ? aQ[0] : (rr == 1 ? aQ[1] : (rr == 2 ? aQ[2] : aQ[3]));
-            qd = (l15 >> 2) == g ? qd : 0.f;
-            qd += __shfl_xor(qd, 16); qd += __shfl_xor(qd, 32);
-            S[c] = aS[0]; Q[c] = qd;
-        }
+        for (int kc = 0; kc < KC; ++kc) tr_frag_issue(cs + kc * 32 * crs, crs, cb * 16, lane, lo[c][kc], hi[c][kc]);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4_t aS[NCB], aQ[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) { aS[c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; aQ[c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const uint4 F = make_uint4(lo[c][kc].x, lo[c][kc].y, hi[c][kc].x, hi[c][kc].y);
+            MMA<bf16_t>::run(aQ[c], F, F);
+            MMA<bf16_t>::run(aS[c], ones, F);
+        }
+    // column l15: every row of aS holds its sum; its sum of squares is the diagonal element of aQ, in register l15 & 3 of the lane with g == l15 >> 2:
+    // that lane has both and writes the column - no cross-lane traffic
+    const int rr = l15 & 3;
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
         const int cb = wid + 4 * c, col = n0 + cb * 16 + l15;
-        if (cb < BN / 16 && g == 0 && col < Cout) {
-            const double Sd = (double)S[c], mean = Sd * rn, m2 = (double)Q[c] - Sd * mean;
+        const float qd = rr == 0 ? aQ[c][0] : (rr == 1 ? aQ[c][1] : (rr == 2 ? aQ[c][2] : aQ[c][3]));
+        if (cb < BN / 16 && (l15 >> 2) == g && col < Cout) {
+            const double Sd = (double)aS[c][0], mean = Sd * rn, m2 = (double)qd - Sd * mean;
             psum[(size_t)bm * Cout + col] = (float)mean;
             psq[(size_t)bm * Cout + col] = (float)(m2 > 0.0 ? m2 : 0.0);
         }
@@ -496,51 +495,50 @@ __device__ __forceinline__ void ep2_sums(const char* dz, const char* raw, const 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
     const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
     const unsigned dza = lds_addr(dz), rawa = lds_addr(raw);
-    float T1[NCB], T2[NCB], MU[NCB], IS[NCB];
+    const bool holder = (l15 >> 2) == g;             // the lane that holds the diagonal element of its column (and, like every lane of the column, its plain sum)
+    float MU[NCB], IS[NCB];
     bool ST[NCB];
 #pragma unroll
-    for (int c = 0; c < NCB; ++c) {                  // this lane's (mean, invstd): requested now, needed after the MFMAs
+    for (int c = 0; c < NCB; ++c) {                  // the holder's (mean, invstd): requested now, needed after the MFMAs
         const int cb = wid + 4 * c, col = n0 + cb * 16 + l15;
         MU[c] = 0.f; IS[c] = 0.f; ST[c] = false;
-        if (cb < BN / 16 && g == 0 && col < Cout) {
+        if (cb < BN / 16 && holder && col < Cout) {
             const void* rw; const float* par;
             bnb_select(t, col, rw, par, ST[c]);
             if (ST[c]) { MU[c] = par[(size_t)2 * t.ps + col]; IS[c] = par[(size_t)3 * t.ps + col]; }
         }
     }
+    u32x2_t_ dl[NCB][KC], dh[NCB][KC], rl[NCB][KC], rh[NCB][KC];
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
-        const int cb = wid + 4 * c;
-        T1[c] = 0.f; T2[c] = 0.f;
-        if (cb < BN / 16) {
-            u32x2_t_ dl[KC], dh[KC], rl[KC], rh[KC];
+        const int cb = min(wid + 4 * c, BN / 16 - 1);
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                tr_frag_issue(dza + kc * 32 * CRS, CRS, cb * 16, lane, dl[kc], dh[kc]);
-                tr_frag_issue(rawa + kc * 32 * BN * 2, BN * 2, cb * 16, lane, rl[kc], rh[kc]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4_t a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                const uint4 Fd = make_uint4(dl[kc].x, dl[kc].y, dh[kc].x, dh[kc].y), Fr = make_uint4(rl[kc].x, rl[kc].y, rh[kc].x, rh[kc].y);
-                MMA<bf16_t>::run(a1, ones, Fd);
-                MMA<bf16_t>::run(a2, Fr, Fd);
-            }
-            const int rr = l15 & 3;
-            float q = rr == 0 ? a2[0] : (rr == 1 ? a2[1] : (rr == 2 ? a2[2] : a2[3]));
-            q = (l15 >> 2) == g ? q : 0.f;
-            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-            T1[c] = a1[0]; T2[c] = q;
+        for (int kc = 0; kc < KC; ++kc) {
+            tr_frag_issue(dza + kc * 32 * CRS, CRS, cb * 16, lane, dl[c][kc], dh[c][kc]);
+            tr_frag_issue(rawa + kc * 32 * BN * 2, BN * 2, cb * 16, lane, rl[c][kc], rh[c][kc]);
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4_t a1[NCB], a2[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) { a1[c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; a2[c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const uint4 Fd = make_uint4(dl[c][kc].x, dl[c][kc].y, dh[c][kc].x, dh[c][kc].y), Fr = make_uint4(rl[c][kc].x, rl[c][kc].y, rh[c][kc].x, rh[c][kc].y);
+            MMA<bf16_t>::run(a1[c], ones, Fd);
+            MMA<bf16_t>::run(a2[c], Fr, Fd);
+        }
+    const int rr = l15 & 3;
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
         const int cb = wid + 4 * c, col = n0 + cb * 16 + l15;
-        if (cb < BN / 16 && g == 0 && col < Cout) {
+        const float q = rr == 0 ? a2[c][0] : (rr == 1 ? a2[c][1] : (rr == 2 ? a2[c][2] : a2[c][3]));
+        if (cb < BN / 16 && holder && col < Cout) {
             float s1 = 0.f, s2 = 0.f;
-            if (ST[c]) { s1 = T1[c]; s2 = IS[c] * (T2[c] - MU[c] * s1); }
+            if (ST[c]) { s1 = a1[c][0]; s2 = IS[c] * (q - MU[c] * s1); }
             t.p1[(size_t)bm * t.ldp + col] = s1;
             t.p2[(size_t)bm * t.ldp + col] = s2;
         }
@@ -773,6 +771,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
             }
         }
         // (swapped epilogue) statistics AFTER the stores have been issued: they drain while the matrix cores reduce the staged tile
+        PN2_STAMP_AT(14);
         if constexpr (SWP || sizeof(T) == 2) { if (d.flags & PN2_CONV_STATS) mfma_stats<BM, BN>(Cs, CRS, min(M - m0, BM), d.Cout, n0, bm, psum, psq); }
     } else if constexpr (EP2) {
         Ep2Out<BM, BN> O;

@@ -83,7 +83,9 @@ def analyse(us, M, Cout, bm, bn, title, flops, byts):
     print(line + " (median/p90 us)")
     b = buf[keep].astype(np.int64)
     print(f"   inside stats+stage: statistics {np.median(b[:, 12] - b[:, 5]) / tick_per_us:5.2f}  cvt + LDS stores {np.median(b[:, 13] - b[:, 12]) / tick_per_us:5.2f}  barrier {np.median(b[:, 6] - b[:, 13]) / tick_per_us:5.2f}")
-    if b[:, 14].any():
+    if b[:, 14].any() and not b[:, 15].any():
+        print(f"   inside store-issue: copy-out {np.median(b[:, 14] - b[:, 7]) / tick_per_us:5.2f}  statistics on the matrix cores + partial stores {np.median(b[:, 8] - b[:, 14]) / tick_per_us:5.2f}")
+    if b[:, 14].any() and b[:, 15].any():
         print(f"   inside store-issue (BN-backward epilogue): targets {np.median(b[:, 14] - b[:, 7]) / tick_per_us:5.2f}  barrier + LDS sums {np.median(b[:, 15] - b[:, 14]) / tick_per_us:5.2f}  partial stores {np.median(b[:, 8] - b[:, 15]) / tick_per_us:5.2f}")
     drain = phs[:, 8]
     print(f"   store drain (s_waitcnt vmcnt(0) after the last store) {np.median(drain) / tick_per_us:5.2f}/{np.percentile(drain, 90) / tick_per_us:5.2f}")
