@@ -102,11 +102,13 @@ __device__ __forceinline__ bool tap_pixel_off(const GatherGeom& g, int iy0, int 
 
 // ------------------------------------------------------------------------------------------------
 // Shared epilogue of the two GEMM kernels: accumulators -> (bias) -> LDS-staged 16-byte stores, with
-//   PN2_CONV_STATS : forward BatchNorm batch statistics of the fp32 accumulators as one (mean, M2) pair per tile and channel.
-//                    A wave shifts its values by its own first row (no cancellation however large |mean| / sigma is), the WM wave
-//                    results of a tile are merged with Chan's formula; pn2_bn_finalize merges the tiles in double.
-//   pn2_conv_ep    : BatchNorm-BACKWARD partial sums of the gradient tile this dgrad GEMM produces (see pn2.h), one or two targets.
-// LDS use: the C tile [BM][CRS] followed by 3*WM*BN floats (STATS); the ep sums reuse the C tile area after it has been drained.
+//   PN2_CONV_STATS : forward BatchNorm batch statistics as one (mean, M2) pair per tile and channel; pn2_bn_finalize merges the tiles in double (Chan).
+//                    bf16: of the STORED (rounded) tile, on the matrix cores (mfma_stats below) - one definition for every bf16 kernel.
+//                    fp32: of the accumulators; a wave shifts its values by its own first row (no cancellation however large |mean| / sigma is),
+//                    the WM wave results of a tile are merged with Chan's formula.
+//   pn2_conv_ep    : BatchNorm-BACKWARD partial sums of the gradient tile this dgrad GEMM produces (see pn2.h), one or two targets: register form
+//                    (fp32, wide bf16 tiles; next block) or LDS-DMA / matrix-core form (narrow bf16 tiles; ep2_* further down).
+// LDS use: the C tile [BM][CRS]; fp32 statistics: + 3*WM*BN floats; register-form ep sums reuse the C tile area after it has been drained; ep2: see Ep2Layout.
 // ------------------------------------------------------------------------------------------------
 // BatchNorm-backward epilogue (pn2_conv_gemm_ep).  A thread owns ONE channel vector of the C tile (256 % VPR == 0) and RPT of its rows, so its
 // per-channel parameters and sums stay in registers.  This code runs at the GEMM's low occupancy (1-3 workgroups per CU), where every
