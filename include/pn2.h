@@ -41,7 +41,10 @@ typedef struct pn2_conv_desc {
     int KH, KW, stride, pad_h, pad_w, dil_h, dil_w;   /* of the FORWARD convolution */
     int transposed;         /* 0 forward gather, 1 dgrad gather */
     int Kp;                 /* packed-weight row length, multiple of 128 */
-    int flags;              /* PN2_CONV_* ; bits 8..15 optional tuning code (bf16): kernel | BM<<2 | BN<<4, see pn2_conv_tile_m */
+    int flags;              /* PN2_CONV_* ; bits 8..15 optional tuning code (bf16): kernel | BM<<2 | BN<<4 | 0x40, see pn2_conv_tile_m.  kernel: 1 register-staged,
+                               2 / 3 LDS-DMA with a 3- / 2-stage ring; 0x40: DIRECT form - every wave loads its MFMA fragments straight from global memory (no
+                               LDS, no barrier in the K loop; few-channel / many-pixel convs).  All forms give the same bits (tests/test_gpu_convkernels.py);
+                               strided transposed gathers and split-K ignore 0x40 */
 } pn2_conv_desc;
 
 typedef struct pn2_wgrad_desc {
@@ -107,6 +110,7 @@ int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const
  * Res2Net_v1b.py:66-69) run in lock step.  pn2_conv_gemm_tile = (bm << 8 | bn) pn2_conv_gemm would pick for a desc (the partial-row counts of its
  * statistics depend on bm, so a job must run on its own tile); jobs of equal tile and equal `ep` use (any target mode / b.out set) share a launch.
  * The general (not pointwise-specialised) kernels serve every job; split-K jobs cannot join.  Bit-identical to the single launches.
+ * pn2_conv_gemm_tile bit 16 / `ep` bit 8: the jobs' tuned kernel is the direct form (own launch: jobs of equal tile AND equal form share one).
  * `ep`: bit 0 = the jobs carry a pn2_conv_ep; for bf16 its operand tiles are staged in LDS and the launch is sized for what the jobs need -
  * bit 1: a.mode has PN2_BNB_STATS, bit 2: ... and PN2_BNB_MASK_Y, bit 3: PN2_CONV_ACCUM, bit 4: b.out with PN2_BNB_STATS (OR over the jobs; no
  * bits = all four, which does not fit 160 KB for a 128 x 128 tile: returns -4). */

@@ -1242,189 +1242,141 @@ __global__ __launch_bounds__(256) void conv_dma_gemm_tab(const pn2_conv_job* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward / dgrad gather-GEMM, PERSISTENT with the weight panel RESIDENT in LDS (bf16, tuning-code bit 6).
-// The LDS-DMA kernel above re-stages its B tile (BN x 64 weights) in every K-step of every M-tile, and pays row decode, descriptor set-up and the
-// first DMA latency once per 128 x 128 tile.  For the layers with a SHORT contraction and MANY rows - the 1x1 convs of layer1 / layer2 (K = 64 .. 256
-// over 61 952 .. 247 808 rows: 4 K-steps per tile, 3 872 tiles), the 26- / 52-wide 3x3 branches and the stem - that per-tile overhead and the B
-// traffic through the L2 -> LDS path are most of the kernel.  Here a workgroup owns ONE N-tile for its whole life: it stages the complete
-// [BN x Kp] panel of that tile once (ksteps x BN x 128 B, <= ~100 KB), then walks M-tiles bm = slot, slot + P, ... and streams only the activation
-// operand through the DMA ring (NA instead of NA + NB requests per K-step).  Same fragment layout, same MFMA order and the same shared epilogue as
-// conv_dma_body: results are bit-identical.  Grid = N-tiles x P slots, about as many workgroups as the CUs hold.
+// forward / dgrad gather-GEMM, DIRECT form (bf16, tuning-code bit 6): no LDS and no barrier in the K loop.
+// The LDS-DMA kernel above pays 60-185 cycles of issue per 1 KB DMA piece and moves every activation row of a 3x3 conv through the L2 -> LDS path
+// once per tap (9x the tensor; that path tops out near 13-14 TB/s on this part), with two barriers per 64-deep K-step.  For the convs with FEW
+// channels and MANY pixels - the 26/52-wide Res2Net branches (Res2Net_v1b.py:44,66-69), the 32/64-channel stem (:102-108), the RFB / aggregation /
+// head convs (pranet.py:56-72,94-102) - the operands of a wave's MFMAs are tiny and the wave tiles do not share much: here every wave loads its
+// MFMA fragments STRAIGHT from global memory into registers through buffer descriptors (lane (l15, g): the 16 bytes = 8 channels k = 32c + 8g .. + 7
+// of pixel / output-channel row l15; the 16 rows x 64 B of a fragment are one contiguous KB when Cin_p == 32), PD chunks of 32 k-values ahead.
+// Padding taps, rows past M and chunks past the contraction read as zeros by the descriptor's out-of-range rule (same trick as the LDS-DMA
+// kernel), the 9 taps of a pixel row hit L1 / L2, and the four waves of a workgroup only meet in the shared epilogue.  Same k-slot assignment and
+// the same ascending chunk order per accumulator as conv_dma_body -> bit-identical results (tests/test_gpu_convkernels.py).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NS, bool EP>
-constexpr int bres_ring_bytes() {
-    constexpr int ring = NS * BM * 128, epi = BM * (BN * 2 + 16) + 3 * WM * BN * 4, epb = EP ? ep_lds_bytes(8) : 0;
-    constexpr int m = ring > epi ? (ring > epb ? ring : epb) : (epi > epb ? epi : epb);
-    return (m + 127) / 128 * 128;
-}
+constexpr int direct_pd(int mt, int nt) { return mt + nt <= 4 ? 4 : (mt + nt <= 6 ? 3 : 2); }
 
-template <int BM, int BN, int WM, int WN, bool PW, int NS, bool EP>
-__global__ __launch_bounds__(256) void conv_bres_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
-                                                      float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep, int P) {
+template <int BM, int BN, int WM, int WN, bool EP>
+__device__ __forceinline__ void conv_direct_body(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
+                                                 float* __restrict__ psum, float* __restrict__ psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, int lbid, int lgrid) {
     using T = bf16_t;
-    constexpr int VEC = 8, BK = 64, ROW = 128;
-    constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
-    constexpr int ASTAGE = BM * ROW;
-    constexpr int NA = BM / 32, NB = BN / 32;
-    constexpr int RING = bres_ring_bytes<BM, BN, WM, WN, NS, EP>();
+    constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16, PD = direct_pd(MT, NT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
     const int M = d.N * d.OH * d.OW;
-    const int nbn = (d.Cout + BN - 1) / BN, nbm = (M + BM - 1) / BM;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);        // neighbours on one XCD: the N-tiles of one slot, walking the same rows
-    const int bn = bid % nbn, slot = bid / nbn;
-    const int n0 = bn * BN;
+    const int nbn = (d.Cout + BN - 1) / BN;
+    const int bid = xcd_remap(lbid, lgrid);
+    int bn, bm;
+    if (nbn == 1) { bn = 0; bm = bid; }
+    else if ((nbn & (nbn - 1)) == 0) { const int sh_ = __builtin_ctz(nbn); bn = bid & (nbn - 1); bm = bid >> sh_; }
+    else { bn = bid % nbn; bm = bid / nbn; }
+    const int m0 = bm * BM, n0 = bn * BN;
     const int taps = d.KH * d.KW;
-    const int ktot = taps * d.Cin_p;
-    const int ksteps = (ktot + BK - 1) / BK;
+    const int nch = (taps * d.Cin_p + 31) >> 5;          // 32-deep chunks of the contraction
 
-    GatherGeom gg;
-    gg.H = d.H; gg.W = d.W; gg.OH = d.OH; gg.OW = d.OW; gg.KH = d.KH; gg.KW = d.KW; gg.stride = d.stride;
-    gg.sshift = __builtin_ctz(d.stride); gg.pad_h = d.pad_h; gg.pad_w = d.pad_w; gg.dil_h = d.dil_h; gg.dil_w = d.dil_w;
-    gg.transposed = d.transposed;
-
-    const int cg = (tid & 7) ^ ((tid >> 4) & 7);
+    // this lane's pixel rows m0 + wm * WTM + i * 16 + l15 (one division pair, the other blocks are stepped from it): byte offset of the tap-(0,0) source pixel
+    // and which kernel rows / columns fall inside the image (bit r of rmask, bit s of cmask) - the taps' validity is separable
+    int base2[MT]; unsigned rmask[MT], cmask[MT];
+    const unsigned ldb = (unsigned)d.ld_in * 2u;
+    const int sgn = d.transposed ? -1 : 1;                 // (a transposed gather runs with stride 1 here: the host sends strided dgrads to the LDS-DMA kernel)
+    const int sdil_h = sgn * d.dil_h, sdil_w = sgn * d.dil_w;
+    {
+        const int mf = m0 + wm * WTM + l15;
+        const unsigned hw = (unsigned)(d.OH * d.OW), mu = (unsigned)mf;
+        const unsigned nq = mu / hw, rem = mu - nq * hw, oq = rem / (unsigned)d.OW;
+        int n_ = (int)nq, oy_ = (int)oq, ox_ = (int)(rem - oq * (unsigned)d.OW);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const bool rok = mf + 16 * i < M;
+            const int iy0 = d.transposed ? oy_ + d.pad_h : oy_ * d.stride - d.pad_h, ix0 = d.transposed ? ox_ + d.pad_w : ox_ * d.stride - d.pad_w;
+            base2[i] = (n_ * d.H * d.W + iy0 * d.W + ix0) * (int)ldb;
+            unsigned rm = 0, cm = 0;
+            for (int r = 0; r < d.KH; ++r) rm |= ((unsigned)(iy0 + r * sdil_h) < (unsigned)d.H ? 1u : 0u) << r;
+            for (int c = 0; c < d.KW; ++c) cm |= ((unsigned)(ix0 + c * sdil_w) < (unsigned)d.W ? 1u : 0u) << c;
+            rmask[i] = rok ? rm : 0u; cmask[i] = cm;
+            ox_ += 16;
+            while (ox_ >= d.OW) { ox_ -= d.OW; ++oy_; }
+            while (oy_ >= d.OH) { oy_ -= d.OH; ++n_; }
+        }
+    }
     const unsigned INV = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)in >> 32)) << 32) |
                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)in)), 0, (int)INV, 0x00020000);
-    const int sgn = d.transposed ? -1 : 1;
-    const int sdil_h = sgn * d.dil_h, sdil_w = sgn * d.dil_w;
-    const int tsh = d.transposed ? gg.sshift : 0, tmsk = d.transposed ? d.stride - 1 : 0;
-    const int ldb = d.ld_in * 2;
-    const int wrow = __builtin_amdgcn_readfirstlane(wid * 8);
-    char* bpanel = smem + RING;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)wp >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)wp)), 0, 0x7fffffff, 0x00020000);
+    // chunk state of this lane group (k = 32 * chunk + 8 * g): kernel row / column of its tap, and toff = byte offset of (tap, channel) from the tap-(0,0) pixel.
+    // All of it is stepped with adds and selects: no multiply, no division and no branch per chunk (hipcc wraps a v_mul_lo in an exec-mask branch)
+    const int dcol = sdil_w * (int)ldb, drow = sdil_h * d.W * (int)ldb - (d.KW - 1) * dcol, cinb = d.Cin_p * 2;
+    int ci2 = g * 16, tr = 0, tc = 0, toff = g * 16;
+    while (ci2 >= cinb) { ci2 -= cinb; toff -= cinb; const bool cw_ = tc + 1 == d.KW; toff += cw_ ? drow : dcol; tc = cw_ ? 0 : tc + 1; tr += cw_ ? 1 : 0; }
+    const int nwrap = d.Cin_p >= 32 ? 1 : 4;                // tap steps per 32-deep chunk (Cin_p is a multiple of 8)
+    // weight panel: row n0 + wn * WTN + j * 16 + l15, k as above; chunks past the panel row re-read its last one (their A operand is zero)
+    const unsigned boff = ((unsigned)(n0 + wn * WTN + l15) * (unsigned)d.Kp + (unsigned)g * 8u) * 2u;
+    const unsigned bstep = 16u * (unsigned)d.Kp * 2u;
+    const int cbmax = (d.Kp >> 5) - 1;
+    int cnext = 0;
 
-    // ---- the weight panel of this N-tile, once: [kstep][BN rows][128 B], same swizzled chunk order as a ring stage of conv_dma_body
-    {
-        const T* bptr = wp + (size_t)(n0 + (tid >> 3)) * d.Kp + cg * VEC;
-        for (int kt = 0; kt < ksteps; ++kt)
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(bptr + (size_t)(32 * i) * d.Kp + (size_t)kt * BK),
-                                                 (lptr_t)(bpanel + ((kt * BN) + i * 32 + wrow) * ROW), 16, 0, 0);
-    }
-
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-    const int key = (l15 >> 1) & 7;
-    const unsigned so0 = ((g) ^ key) * 16, so1 = ((4 + g) ^ key) * 16;
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-
-    for (int bm = slot; bm < nbm; bm += P) {
-        const int m0 = bm * BM;
-        int rbase[NA], riy0[NA], rix0[NA]; bool rok[NA];
-        {
-            const int mf = m0 + (tid >> 3);
-            int n_ = 0, oy_ = 0, ox_ = 0;
-            if (!PW) {
-                const unsigned hw = (unsigned)(d.OH * d.OW), mu = (unsigned)mf;
-                const unsigned nq = mu / hw, rem = mu - nq * hw, oq = rem / (unsigned)d.OW;
-                n_ = (int)nq; oy_ = (int)oq; ox_ = (int)(rem - oq * (unsigned)d.OW);
-            }
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int m = mf + 32 * i;
-                rok[i] = m < M;
-                if (PW) { rbase[i] = rok[i] ? m : 0; riy0[i] = 0; rix0[i] = 0; }
-                else {
-                    rbase[i] = n_ * d.H * d.W;
-                    if (!d.transposed) { riy0[i] = oy_ * d.stride - d.pad_h; rix0[i] = ox_ * d.stride - d.pad_w; }
-                    else { riy0[i] = oy_ + d.pad_h; rix0[i] = ox_ + d.pad_w; }
-                    ox_ += 32;
-                    while (ox_ >= d.OW) { ox_ -= d.OW; ++oy_; }
-                    while (oy_ >= d.OH) { oy_ -= d.OH; ++n_; }
-                }
-            }
-        }
-        int ci = cg * VEC, tap = 0;
-        if (!PW) { while (ci >= d.Cin_p) { ci -= d.Cin_p; ++tap; } }
-        int tcol = 0, tdr = 0, tdc = 0;
-        if (!PW) { const int r0_ = tap / d.KW; tcol = tap - r0_ * d.KW; tdr = r0_ * sdil_h; tdc = tcol * sdil_w; }
-        unsigned rowoff[NA];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) rowoff[i] = PW ? (unsigned)rbase[i] * (unsigned)ldb : (unsigned)rbase[i];
-
-#define PN2_AISSUE(step_, buf_)                                                                                        \
+    u32x4_t a[PD][MT], b[PD][NT];
+#define PN2_DLOAD(u_)                                                                                                  \
     do {                                                                                                               \
-        char* sb_ = smem + (buf_) * ASTAGE;                                                                            \
-        if (PW) {                                                                                                      \
-            const int k_ = (step_) * BK + cg * VEC;                                                                    \
-            const bool kok_ = k_ < d.Cin_p;                                                                            \
-            _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
-                const unsigned vo_ = (rok[i] && kok_) ? rowoff[i] + (unsigned)k_ * 2u : INV;                           \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, (int)vo_, 0, 0, PN2_A_AUX); \
-            }                                                                                                          \
-        } else {                                                                                                       \
-            const bool tok_ = tap < taps;                                                                              \
-            _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
-                const int ty_ = riy0[i] + tdr, tx_ = rix0[i] + tdc;                                                    \
-                const int iy_ = ty_ >> tsh, ix_ = tx_ >> tsh;                                                          \
-                const bool ok_ = rok[i] & tok_ & ((unsigned)iy_ < (unsigned)d.H) & ((unsigned)ix_ < (unsigned)d.W) & (((ty_ | tx_) & tmsk) == 0); \
-                const unsigned vo_ = ok_ ? (rowoff[i] + (unsigned)(iy_ * d.W + ix_)) * (unsigned)ldb + (unsigned)ci * 2u : INV; \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, (int)vo_, 0, 0, PN2_A_AUX); \
-            }                                                                                                          \
-            ci += BK;                                                                                                  \
-            while (ci >= d.Cin_p) {                                                                                    \
-                ci -= d.Cin_p; ++tap; ++tcol; tdc += sdil_w;                                                           \
-                if (tcol == d.KW) { tcol = 0; tdc = 0; tdr += sdil_h; }                                                \
-            }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                               \
+            const bool ok_ = ((rmask[i] >> tr) & (cmask[i] >> tc) & 1u) != 0;                                          \
+            const unsigned vo_ = ok_ ? (unsigned)(base2[i] + toff) : INV;                                              \
+            a[u_][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)vo_, 0, 0);                                   \
+        }                                                                                                              \
+        const unsigned bo_ = boff + (unsigned)min(cnext, cbmax) * 64u;                                                 \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                 \
+            b[u_][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)bo_, (int)((unsigned)j * bstep), 0);           \
+        ++cnext;                                                                                                       \
+        ci2 += 64; toff += 64;                                                                                         \
+        for (int w_ = 0; w_ < nwrap; ++w_) {                                                                           \
+            const bool wr_ = ci2 >= cinb, cw_ = wr_ & (tc + 1 == d.KW);                                                \
+            ci2 -= wr_ ? cinb : 0;                                                                                     \
+            toff += wr_ ? (cw_ ? drow : dcol) - cinb : 0;                                                              \
+            tc = cw_ ? 0 : tc + (wr_ ? 1 : 0);                                                                         \
+            tr = min(tr + (cw_ ? 1 : 0), 31);                                                                          \
         }                                                                                                              \
     } while (0)
 
-        BnbPre<T, BM, BN> pre;
-        f32x4_t acc[MT][NT];
+    BnbPre<T, BM, BN> pre;
+    f32x4_t acc[MT][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-        PN2_AISSUE(0, 0);
-        if (NS == 3 && ksteps > 1) PN2_AISSUE(1, 1);
-        for (int t = 0; t < ksteps; ++t) {
-            if constexpr (NS == 3) {
-                // (the panel's requests are older than every ring request: the first counted wait also covers them)
-                if (t + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t + 2 < ksteps) { const int nb_ = (t + 2) % NS; PN2_AISSUE(t + 2, nb_); }
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t + 1 < ksteps) { const int nb_ = (t + 1) % NS; PN2_AISSUE(t + 1, nb_); }
-            }
-            const unsigned As = lds0 + (t % NS) * ASTAGE + (wm * WTM + l15) * ROW;
-            const unsigned Bs = lds0 + RING + (t * BN) * ROW + (wn * WTN + l15) * ROW;
-            u32x4_t a0[MT], a1[MT], b0[NT], b1[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a0[i]) : "v"(As + i * 16 * ROW + so0));
+    for (int u = 0; u < PD; ++u) PN2_DLOAD(u);
+    // chunks are consumed in rounds of PD; the chunks past nch of the last round have all-zero A operands (kernel row >= KH): they add exact zeros
+    const int nround = (nch + PD - 1) / PD;
+    for (int r = 0; r < nround; ++r) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b0[j]) : "v"(Bs + j * 16 * ROW + so0));
-#pragma unroll
-            for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a1[i]) : "v"(As + i * 16 * ROW + so1));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b1[j]) : "v"(Bs + j * 16 * ROW + so1));
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < PD; ++u) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, b0[j]), __builtin_bit_cast(uint4, a0[i]));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, b1[j]), __builtin_bit_cast(uint4, a1[i]));
+                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, b[u][j]), __builtin_bit_cast(uint4, a[u][i]));
+            PN2_DLOAD(u);
         }
-#undef PN2_AISSUE
-        __syncthreads();            // the ring is free: the epilogue stages the C tile there
-        conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP, true>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
-        __syncthreads();            // ... and is done with it before the next tile's DMA lands
     }
+#undef PN2_DLOAD
+    conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP, true>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
+}
+
+template <int BM, int BN, int WM, int WN, bool EP>
+__global__ __launch_bounds__(256) void conv_direct_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
+                                                        float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
+    conv_direct_body<BM, BN, WM, WN, EP>(in, wp, out, psum, psq, d, ep, blockIdx.x, gridDim.x);
+}
+template <int BM, int BN, int WM, int WN, bool EP>
+__global__ __launch_bounds__(256) void conv_direct_gemm_tab(const pn2_conv_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_conv_job j = jobs[jb];
+    conv_direct_body<BM, BN, WM, WN, EP>((const bf16_t*)j.in, (const bf16_t*)j.wp, (bf16_t*)j.out, j.psum, j.psq, j.d, j.ep, blockIdx.x - bstart[jb], bstart[jb + 1] - bstart[jb]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2046,44 +1998,47 @@ int launch_dma(const void* in, const void* wp, void* out, float* psum, float* ps
     return 0;
 }
 
-// persistent, B-resident launch (tuning-code bit 6); returns -100 when the panel does not fit so that the caller takes the plain LDS-DMA kernel
-template <bool EP, int BM, int BN, int WM, int WN, int NS = 3>
-int launch_bres(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
+// direct form (tuning-code bit 6): LDS only for the shared epilogue
+template <int BM, int BN, bool EP>
+inline int direct_lds(const pn2_conv_desc& d, const pn2_conv_ep& ep, int bits, bool table) {
+    int lds = BM * (BN * 2 + 16);
+    if (EP && ep2_tile(BM, BN)) { const int e2 = table ? ep2_lds_bits<BM, BN>(bits) : ep2_lds_for<BM, BN>(d, ep); if (e2 > lds) lds = e2; }
+    else if (EP && lds < ep_lds_bytes(8)) lds = ep_lds_bytes(8);
+    return lds;
+}
+template <bool EP, int BM, int BN, int WM, int WN>
+int launch_direct(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
     const int M = d.N * d.OH * d.OW;
-    const int ksteps = (d.KH * d.KW * d.Cin_p + 63) / 64;
-    constexpr int ring = bres_ring_bytes<BM, BN, WM, WN, NS, EP>();
-    const int lds = ring + ksteps * BN * 128;
-    if ((EP && ep2_tile(BM, BN)) || lds > 160 * 1024 || ((d.flags >> 16) & 15) > 1) return -100;      // (the operand tiles of the LDS-DMA form of the BatchNorm-backward epilogue would sit on the resident panel)
-    const int nbn = (d.Cout + BN - 1) / BN, nbm = (M + BM - 1) / BM;
-    int occ = (160 * 1024) / lds; if (occ > 3) occ = 3; if (occ < 1) occ = 1;
-    int P = (256 * occ) / nbn; if (P < 1) P = 1; if (P > nbm) P = nbm;
-    const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
-    static bool done = false;
-    if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bres_gemm<BM, BN, WM, WN, true, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bres_gemm<BM, BN, WM, WN, false, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        done = true;
+    const int grid = ((M + BM - 1) / BM) * ((d.Cout + BN - 1) / BN);
+    const int lds = direct_lds<BM, BN, EP>(d, ep, 0, false);
+    if (lds > 160 * 1024) return -4;
+    if (EP) {
+        static bool done = false;
+        if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_gemm<BM, BN, WM, WN, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
     }
-    if (pw) hipLaunchKernelGGL((conv_bres_gemm<BM, BN, WM, WN, true, NS, EP>), dim3(nbn * P), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d, ep, P);
-    else hipLaunchKernelGGL((conv_bres_gemm<BM, BN, WM, WN, false, NS, EP>), dim3(nbn * P), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d, ep, P);
+    hipLaunchKernelGGL((conv_direct_gemm<BM, BN, WM, WN, EP>), dim3(grid), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d, ep);
     PN2_CHECK_LAUNCH();
     return 0;
 }
-template <bool EP, int NS>
-int bres_dispatch(int bm, int bn, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
+template <bool EP>
+int direct_dispatch(int bm, int bn, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
     if (bm == 128) {
-        if (bn == 128) return launch_bres<EP, 128, 128, 2, 2, NS>(in, wp, out, psum, psq, d, ep, st);
-        if (bn == 64) return launch_bres<EP, 128, 64, 2, 2, NS>(in, wp, out, psum, psq, d, ep, st);
-        return launch_bres<EP, 128, 32, 4, 1, NS>(in, wp, out, psum, psq, d, ep, st);
+        if (bn == 128) return launch_direct<EP, 128, 128, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+        if (bn == 64) return launch_direct<EP, 128, 64, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+        return launch_direct<EP, 128, 32, 4, 1>(in, wp, out, psum, psq, d, ep, st);
     }
-    if (bn == 128) return launch_bres<EP, 64, 128, 2, 2, NS>(in, wp, out, psum, psq, d, ep, st);
-    if (bn == 64) return launch_bres<EP, 64, 64, 2, 2, NS>(in, wp, out, psum, psq, d, ep, st);
-    return launch_bres<EP, 64, 32, 4, 1, NS>(in, wp, out, psum, psq, d, ep, st);
+    if (bn == 128) return launch_direct<EP, 64, 128, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+    if (bn == 64) return launch_direct<EP, 64, 64, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+    return launch_direct<EP, 64, 32, 4, 1>(in, wp, out, psum, psq, d, ep, st);
 }
 
 // the LDS-DMA kernel addresses the activation operand with 32-bit byte offsets behind a buffer descriptor (conv_dma_body): its extent must stay below 2 GB
 inline bool dma_extent_ok(const pn2_conv_desc& d) {
     return ((size_t)d.N * d.H * d.W - 1) * (size_t)d.ld_in * 2 + (size_t)d.Cin_p * 2 < 0x80000000ull;
+}
+// the direct kernel steps linear byte offsets: any forward gather, transposed gathers of stride-1 convs; kernel rows / columns index 32-bit masks; no split-K
+inline bool direct_ok(const pn2_conv_desc& d) {
+    return dma_extent_ok(d) && !(d.transposed && d.stride > 1) && d.KH < 32 && d.KW < 32 && ((d.flags >> 16) & 15) <= 1;
 }
 inline bool use_dma_kernel() {
     static const bool on = [] { const char* e = getenv("PN2_CONV_DMA"); return !(e && e[0] == '0'); }();
@@ -2123,10 +2078,8 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
     if (tbm) bm = tbm == 1 ? 64 : 128;
     if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
     if constexpr (sizeof(T) == 2) {
-        if ((tune & 0x40) && (tk_ == 2 || tk_ == 3) && !(d.flags & PN2_CONV_ROWGATE)) {      // persistent, weight panel resident in LDS (when it fits)
-            const int rc = tk_ == 3 ? bres_dispatch<EP, 2>(bm, bn, in, wp, out, psum, psq, d, ep, st) : bres_dispatch<EP, 3>(bm, bn, in, wp, out, psum, psq, d, ep, st);
-            if (rc != -100) return rc;
-        }
+        if ((tune & 0x40) && direct_ok(d))      // direct form: fragments straight from global memory (no LDS in the K loop)
+            return direct_dispatch<EP>(bm, bn, in, wp, out, psum, psq, d, ep, st);
         if (tk_ == 3) {              // LDS-DMA, 2-stage ring (more workgroups per CU)
             if (bm == 128) {
                 if (bn == 128) return launch_dma<EP, 128, 128, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st);
@@ -2162,7 +2115,7 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
     return launch_gemm<T, 64, 32, 4, 1, EP>(in, wp, out, psum, psq, d, ep, st);
 }
 
-// (kernel, BM, BN) gemm_dispatch would run for this desc: kern 0 register-staged, 2 LDS-DMA 3-stage, 3 LDS-DMA 2-stage
+// (kernel, BM, BN) gemm_dispatch would run for this desc: kern 0 register-staged, 2 LDS-DMA 3-stage, 3 LDS-DMA 2-stage, 4 direct
 template <typename T>
 void gemm_select(const pn2_conv_desc& d, int& kern, int& bm, int& bn) {
     pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
@@ -2172,6 +2125,7 @@ void gemm_select(const pn2_conv_desc& d, int& kern, int& bm, int& bn) {
     if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
     kern = 0;
     if (sizeof(T) == 2) kern = tk_ == 3 ? 3 : ((tk_ ? tk_ == 2 : use_dma_kernel()) ? 2 : 0);
+    if (sizeof(T) == 2 && (tune & 0x40) && direct_ok(d)) kern = 4;      // direct form
     if (sizeof(T) == 4 && bn == 128) bn = 64;
 }
 
@@ -2205,8 +2159,34 @@ int launch_gather_tab_f32(const pn2_conv_job* jobs, const int* bstart, int njobs
     PN2_CHECK_LAUNCH();
     return 0;
 }
+template <bool EP, int BM, int BN, int WM, int WN>
+int launch_direct_tab(const pn2_conv_job* jobs, const int* bstart, int njobs, int total, int bits, hipStream_t st) {
+    pn2_conv_desc d0{}; pn2_conv_ep e0{};
+    const int lds = direct_lds<BM, BN, EP>(d0, e0, bits, true);
+    if (lds > 160 * 1024) return -4;
+    if (EP) {
+        static bool done = false;
+        if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_gemm_tab<BM, BN, WM, WN, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    }
+    hipLaunchKernelGGL((conv_direct_gemm_tab<BM, BN, WM, WN, EP>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
 template <bool EP>
 int gemm_multi_dispatch(int dtype, int bm, int bn, int bits, const pn2_conv_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
+    if (dtype == PN2_BF16 && (bits & 0x80)) {          // direct form (every job of the table carries tuning-code bit 6)
+        bits &= 15;
+        if (bm == 128) {
+            if (bn == 128) return launch_direct_tab<EP, 128, 128, 2, 2>(jobs, bstart, njobs, total, bits, st);
+            if (bn == 64) return launch_direct_tab<EP, 128, 64, 2, 2>(jobs, bstart, njobs, total, bits, st);
+            if (bn == 32) return launch_direct_tab<EP, 128, 32, 4, 1>(jobs, bstart, njobs, total, bits, st);
+        } else if (bm == 64) {
+            if (bn == 128) return launch_direct_tab<EP, 64, 128, 2, 2>(jobs, bstart, njobs, total, bits, st);
+            if (bn == 64) return launch_direct_tab<EP, 64, 64, 2, 2>(jobs, bstart, njobs, total, bits, st);
+            if (bn == 32) return launch_direct_tab<EP, 64, 32, 4, 1>(jobs, bstart, njobs, total, bits, st);
+        }
+        return -2;
+    }
     if (dtype == PN2_BF16) {
         if (bm == 128) {
             if (bn == 128) return launch_dma_tab<EP, 128, 128, 2, 2>(jobs, bstart, njobs, total, bits, st);
@@ -2593,7 +2573,7 @@ int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d) {
     if (dtype == PN2_BF16) { gemm_select<bf16_t>(*d, kern, bm, bn); if ((kern == 0 && !use_dma_kernel()) || !dma_extent_ok(*d)) return -2; }
     else if (dtype == PN2_F32) gemm_select<float>(*d, kern, bm, bn);
     else return -3;
-    return (bm << 8) | bn;
+    return (kern == 4 ? 1 << 16 : 0) | (bm << 8) | bn;
 }
 
 int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn) {
@@ -2609,8 +2589,9 @@ int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn) {
 
 int pn2_conv_gemm_multi(int dtype, int bm, int bn, int ep, const pn2_conv_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
     if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
-    return (ep & 1) ? gemm_multi_dispatch<true>(dtype, bm, bn, ep >> 1, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream)
-                    : gemm_multi_dispatch<false>(dtype, bm, bn, 0, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
+    const int direct = (ep & 0x100) ? 0x80 : 0;      // bit 8: the jobs run on the direct kernel (pn2_conv_gemm_tile bit 16)
+    return (ep & 1) ? gemm_multi_dispatch<true>(dtype, bm, bn, ((ep >> 1) & 15) | direct, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream)
+                    : gemm_multi_dispatch<false>(dtype, bm, bn, direct, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
 }
 
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream) {

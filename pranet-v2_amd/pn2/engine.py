@@ -334,6 +334,7 @@ PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == 
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
 BNB_MIN_COLS = int(os.environ.get("PN2_BNB_MIN_COLS", "0"))          # experiment: narrower gradients take the separate reduce pass instead of the dgrad epilogue
+DIRECT_CONV = os.environ.get("PN2_DIRECT_CONV", "1") == "1"         # the tuner may pick the direct conv kernel (tuning-code bit 6)
 LOCKSTEP_TILES = os.environ.get("PN2_LOCKSTEP_TILES", "0") == "1"   # opt-in: canonical conv tiles inside lock-step regions (measured: no more shared launches, same speed)
 LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
@@ -767,7 +768,10 @@ class Engine:
                 d2.flags = code << 8
                 call.pn2_conv_gemm(self.dt, in_ptr, _p(wp), _p(scratch), nul, nul, C.byref(d2), st)
         cands = []
-        for kern in (1, 2, 3):             # 1 register-staged, 2 LDS-DMA with a 3-stage ring, 3 LDS-DMA with a 2-stage ring (more workgroups per CU)
+        # 1 register-staged, 2 LDS-DMA with a 3-stage ring, 3 LDS-DMA with a 2-stage ring (more workgroups per CU), 0x42 direct (MFMA fragments straight
+        # from global memory, no LDS in the K loop: any forward gather and the transposed gathers of stride-1 convs)
+        kerns = (1, 2, 3) if (cd.transposed and cd.stride > 1) or not DIRECT_CONV else (1, 2, 3, 0x42)
+        for kern in kerns:
             for bm in (1, 2):
                 if bm == 2 and M <= 64:
                     continue

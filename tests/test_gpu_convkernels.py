@@ -1,6 +1,6 @@
 """The conv GEMM kernels one by one (C ABI, forced kernel / tile codes): the register-staged kernel, the LDS-DMA kernel with 3 and 2 ring stages
 (activation operand through a buffer descriptor: 32-bit offsets, hardware zero fill for padding taps and missing rows / channel chunks), the
-persistent kernel with the weight panel resident in LDS, and every tile shape must produce the SAME bf16 tensor bit for bit, forward gather and transposed (dgrad) gather, and that tensor must be the
+direct kernel (MFMA fragments straight from global memory, no LDS in the K loop), and every tile shape must produce the SAME bf16 tensor bit for bit, forward gather and transposed (dgrad) gather, and that tensor must be the
 convolution torch computes in float64 from the same bf16 operands, up to one rounding of the output.  Geometries: 1x1, 3x3, 1xk / kx1, 5x5,
 dilation 3 / 5 / 7, stride 2 (forward and its dgrad), row counts that do not fill a tile, channel counts that straddle a 64-wide K-step."""
 import ctypes as C
@@ -74,7 +74,7 @@ def test_conv_kernels_agree_and_match_float64(geom, transposed):
     d.transposed, d.Kp = transposed, Kp
     src_g, wp_g = src.to(dev), wp.to(dev)
     outs, stats = {}, {}
-    for kern in (1, 2, 3, 2 | 0x40, 3 | 0x40):          # 0x40: persistent workgroups with the weight panel resident in LDS (conv_bres_gemm)
+    for kern in (1, 2, 3, 0x42):          # 0x42: direct form (fragments straight from global memory; strided transposed gathers fall back to the LDS-DMA kernel)
         for bm in (1, 2):
             for bn in (1, 2, 3):
                 if (bn == 3 and n_out <= 64) or (bn == 2 and n_out <= 32):
