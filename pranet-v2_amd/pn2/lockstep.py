@@ -45,11 +45,13 @@ def _conv_job(a, with_ep):
     tile = call.pn2_conv_gemm_tile(dt, C.byref(j.d))
     if tile < 0:
         return None
-    bm, bn, direct = (tile >> 8) & 255, tile & 255, tile >> 16          # bit 16: the tuned choice is the direct kernel (its own table launch)
+    bm, bn = (tile >> 8) & 0x1ff, tile & 255
+    if (tile >> 20) & 1:
+        return None                                                       # the tuned choice is the persistent window-form kernel: no table-driven form, launched on its own
     nb = call.pn2_conv_gemm_job_blocks(dt, C.byref(j), bm, bn)
     if nb < 1:
         return None
-    return ("conv", dt, bm, bn, (1 if with_ep else 0) | (0x100 if direct else 0)), j, nb
+    return ("conv", dt, bm, bn, 1 if with_ep else 0), j, nb
 
 
 def _bnfin_job(a):
@@ -237,7 +239,7 @@ class Lockstep:
                     capi.WORK.update(flops=sum(j[4].get("flops", 0) for j in jobs), tag=jobs[0][4].get("tag", ""), shape=f"lockstep x{n} tile {kind[2]}x{kind[3]}",
                                      shapes=[j[4].get("shape", "") for j in jobs])
                     epbits = kind[4]
-                    if epbits & 1:   # what the BatchNorm-backward epilogues of these jobs need in LDS (pn2.h: bits 1..4 of `ep`)
+                    if epbits:       # what the BatchNorm-backward epilogues of these jobs need in LDS (pn2.h: bits 1..4 of `ep`)
                         for s_ in structs:
                             sa = s_.ep.a.mode & capi.BNB_STATS
                             epbits |= (2 if sa else 0) | (4 if sa and (s_.ep.a.mode & capi.BNB_MASK_Y) else 0) | (8 if s_.d.flags & capi.CONV_ACCUM else 0) \

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the conv GEMM kernels on the real layer shapes of the benchmark step (C ABI, cold operands): the shipped (kernel, tile) of pn2/tuned_gfx950.json against
-the direct kernel (tuning-code bit 6: MFMA fragments straight from global memory) on every tile.  Plain forward / dgrad launches (with the forward BatchNorm
+the window-form kernel (tuning-code bit 6: persistent workgroups, rolling input window + weights resident in LDS) on its tiles.  Plain forward / dgrad launches (with the forward BatchNorm
 statistics); GPU box only.   python tools/direct_micro.py [max shapes]"""
 import ast, ctypes as C, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 nmax = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 keys = [k for k in TABLE if k[0] == "g" and k[1] == 32 and len(k) == 17]
-sel = [k for k in keys if not (k[16] and k[11] > 1)]
+sel = [k for k in keys if k[11] == 1 and k[9] * k[10] > 1 and (k[2], k[3]) == (k[4], k[5])]
 sel.sort(key=lambda k: (-(k[9] * k[10] > 1), -(k[1] * k[4] * k[5] * k[6] * k[8] * k[9] * k[10])))
 tot0 = tot1 = 0.0
 for key in sel[:nmax]:
@@ -35,9 +35,9 @@ for key in sel[:nmax]:
     psum = torch.empty(nb64, Cout, device="cuda"); psq = torch.empty(nb64, Cout, device="cuda")
     base = TABLE[key]
     cands = [base]
-    for bm in (1, 2):
+    for bm in (1, 2, 3):
         for bn in (1, 2, 3):
-            if (bn == 2 and Cout <= 32) or (bn == 3 and Cout <= 64) or (bm == 2 and M <= 64):
+            if (bn == 2 and Cout <= 32) or bn == 3 or bm == 1 or Cin_p > 64:
                 continue
             cands.append(0x42 | (bm << 2) | (bn << 4))
     res = []
@@ -53,9 +53,11 @@ for key in sel[:nmax]:
             ts.append(e0.elapsed_time(e1) * 1e3)
         res.append((min(ts[1:]), code))
     t0 = res[0][0]
+    if len(res) < 2:
+        continue
     best = min(res[1:])
     tot0 += t0; tot1 += min(t0, best[0])
     fl = 2 * M * Cout * Cin_p * taps
-    print(f"{'dgrad' if tr else 'fwd  '} {Cin_p:4d}->{Cout:4d} k{KH}x{KW} s{s} d{dh} M{M:7d} ld{ld_in:4d}: table {base:#04x} {t0:7.1f} us ({fl / t0 / 1e6:5.0f} TF/s) | direct " +
+    print(f"{'dgrad' if tr else 'fwd  '} {Cin_p:4d}->{Cout:4d} k{KH}x{KW} s{s} d{dh} M{M:7d} ld{ld_in:4d}: table {base:#04x} {t0:7.1f} us ({fl / t0 / 1e6:5.0f} TF/s) | window " +
           " ".join(f"{c:#04x}:{t:6.1f}" for t, c in res[1:]) + f" | best x{t0 / best[0]:.2f}", flush=True)
-print(f"sum over shapes: table {tot0:.0f} us, min(table, direct) {tot1:.0f} us")
+print(f"sum over shapes: table {tot0:.0f} us, min(table, window) {tot1:.0f} us")
