@@ -26,7 +26,6 @@ extern "C" {
 #define PN2_CONV_SPLITK(n) ((n) << 16)   /* bf16 LDS-DMA kernels only (tuning code kernel 2 / 3): n = 2..15 workgroups share the K loop of a tile and
                                             write fp32 partial tiles to `psum` = workspace [n][M][Cout]; finish with pn2_conv_splitk_reduce.  For convs with
                                             few output rows and a long contraction (5x5 on 11x11 maps).  Excludes STATS / BIAS / ACCUM (the reduce does those). */
-#define PN2_CONV_WIN_SLOTS(n) ((n) << 20)   /* window form (tuning-code bit 6) only: at most 8 n persistent workgroups per N-tile (n = 1..255; 0 = as many as the CUs hold) */
 #define PN2_CONV_ROWGATE 8 /* set by pn2_conv_gemm_gated: accumulator rows are scaled by 1 - sigmoid(gate[m]) before statistics / store */
 #define PN2_CONV_BIAS 4    /* `psum` is a [Cout] fp32 bias (physical columns) added in the epilogue; excludes PN2_CONV_STATS */
 
@@ -42,11 +41,7 @@ typedef struct pn2_conv_desc {
     int KH, KW, stride, pad_h, pad_w, dil_h, dil_w;   /* of the FORWARD convolution */
     int transposed;         /* 0 forward gather, 1 dgrad gather */
     int Kp;                 /* packed-weight row length, multiple of 128 */
-    int flags;              /* PN2_CONV_* ; bits 8..15 optional tuning code (bf16): kernel | BM<<2 | BN<<4 | 0x40, see pn2_conv_tile_m.  kernel: 1 register-staged,
-                               2 / 3 LDS-DMA with a 3- / 2-stage ring; BM 1: 64, 2: 128, 3: 256 (window form only, else 128); 0x40: WINDOW form for stride-1 "same"
-                               convs with more than one tap and a small weight panel - persistent workgroups keep the weights and a rolling window of input rows
-                               in LDS (every input byte enters LDS once), tiles of 128 / 256 rows x 32 / 64 channels; taken when geometry and LDS allow, else the
-                               LDS-DMA kernel of the code's low bits.  All forms give the same bits (tests/test_gpu_convkernels.py) */
+    int flags;              /* PN2_CONV_* ; bits 8..15 optional tuning code (bf16): kernel | BM<<2 | BN<<4, see pn2_conv_tile_m */
 } pn2_conv_desc;
 
 typedef struct pn2_wgrad_desc {
@@ -112,7 +107,6 @@ int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const
  * Res2Net_v1b.py:66-69) run in lock step.  pn2_conv_gemm_tile = (bm << 8 | bn) pn2_conv_gemm would pick for a desc (the partial-row counts of its
  * statistics depend on bm, so a job must run on its own tile); jobs of equal tile and equal `ep` use (any target mode / b.out set) share a launch.
  * The general (not pointwise-specialised) kernels serve every job; split-K jobs cannot join.  Bit-identical to the single launches.
- * pn2_conv_gemm_tile = window << 20 | bm << 8 | bn; bit 20: the desc runs on the (persistent) window form, which has no table-driven launch.
  * `ep`: bit 0 = the jobs carry a pn2_conv_ep; for bf16 its operand tiles are staged in LDS and the launch is sized for what the jobs need -
  * bit 1: a.mode has PN2_BNB_STATS, bit 2: ... and PN2_BNB_MASK_Y, bit 3: PN2_CONV_ACCUM, bit 4: b.out with PN2_BNB_STATS (OR over the jobs; no
  * bits = all four, which does not fit 160 KB for a 128 x 128 tile: returns -4). */

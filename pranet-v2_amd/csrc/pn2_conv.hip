@@ -1242,244 +1242,6 @@ __global__ __launch_bounds__(256) void conv_dma_gemm_tab(const pn2_conv_job* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward / dgrad gather-GEMM, WINDOW form (bf16, tuning-code bit 6): PERSISTENT workgroups with a ROLLING input window and the weight panel resident in
-// LDS, for stride-1 "same" convolutions with more than one tap and a small weight panel (the 26 / 52-wide 3x3 Res2Net branches Res2Net_v1b.py:44,66-69,
-// the 32 / 64-channel stem :102-108, the RFB / aggregation / DSRA-stack convs pranet.py:56-72,94-102,313-325).
-// What conv_dma_body costs on these layers (tens of MB in, tens of MB out, a few GFLOP): every activation row goes through the L2 -> LDS DMA path once
-// per TAP (9x the tensor; every 1 KB piece costs its wave 60-185 issue cycles), every 128-row tile re-stages the weights, and all workgroups of a launch
-// are resident at once - they all load, then all compute, then all store: neither HBM nor the matrix cores are busy for more than a third of the launch.
-// Here: in NHWC with input and output of equal height / width the source pixel of output pixel m under tap (r, s) is the pixel with linear index
-// m + off(r, s), off = +-(r dil_h W + s dil_w) + const, so the taps of BM consecutive output pixels read ONE contiguous run of BM + |off(KH-1, KW-1)|
-// input pixels.  A workgroup owns a contiguous range of M-tiles of one N-tile for its whole life: it stages the weight panel once ([K-step][BN][128 B],
-// the ring-stage image of conv_dma_body), keeps the input rows in a RING of R pixel rows (R a multiple of 64; row p lives at p mod R, 16-byte
-// chunks XOR-swizzled by the ring row so that fragment reads of 16 consecutive rows are conflict-free for every Cin_p) and per tile only fetches the BM
-// NEW rows - every input byte enters LDS once - while the matrix cores work on the current tile (the new rows are requested before the K loop and waited
-// for at the top of the next tile).  The K loop itself has no barrier and no memory wait: fragment addresses are (ring row of the lane's pixel + row
-// shift of its tap, channel chunk), stepped with adds per K-step; a tap that falls outside the image - the run wraps into the neighbouring image row /
-// image - reads a 16-byte zero piece instead (validity is separable: one bit per kernel row and per kernel column of the lane's pixels).
-// Same k-slot assignment, same K-step order and the same shared epilogue as conv_dma_body: results are bit-identical (tests/test_gpu_convkernels.py).
-// LDS: [epilogue region | zero piece | ring R x Cin_p x 2 B | weight panel].
-// ------------------------------------------------------------------------------------------------
-struct WinGeom { int c0, offmin, span, cpt, R, ksh, kmask; };
-__host__ __device__ inline WinGeom win_geom(const pn2_conv_desc& d, int bm) {
-    WinGeom g;
-    const int sgn = d.transposed ? -1 : 1;
-    g.c0 = -sgn * (d.pad_h * d.W + d.pad_w);                                 // off(0, 0)
-    const int last = sgn * ((d.KH - 1) * d.dil_h * d.W + (d.KW - 1) * d.dil_w);     // off(KH-1, KW-1) - off(0, 0)
-    g.offmin = g.c0 + (last < 0 ? last : 0);
-    g.span = last < 0 ? -last : last;
-    g.cpt = d.Cin_p >> 3;
-    g.R = (2 * bm + g.span + 64 + 63) & ~63;                                  // the current tile's window, 64-row alignment slack and the next tile's BM new rows
-    int a = 0;
-    while (a < 4 && !((g.cpt >> a) & 1)) ++a;                                 // rows whose chunk slots collide modulo the 256-byte bank row: XOR key of `a` bits
-    g.ksh = 4 - a; g.kmask = (1 << a) - 1;
-    return g;
-}
-
-template <int BM, int BN, int WM, int WN, bool EP>
-__global__ __launch_bounds__(256) void conv_win_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
-                                                     float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep, int P, int esz) {
-    using T = bf16_t;
-    constexpr int BK = 64, ROW = 128;
-    constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
-    constexpr int STAGE = BN * ROW, NB = BN / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
-    const int M = d.N * d.OH * d.OW;
-    const int nbn = (d.Cout + BN - 1) / BN, nbm = (M + BM - 1) / BM;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);          // neighbours on one XCD: adjacent tile ranges (their halo rows meet in one L2)
-    const int bn = lid % nbn, slot = lid / nbn;
-    const int n0 = bn * BN;
-    const int t_beg = (int)(((long long)slot * nbm) / P), t_end = (int)(((long long)(slot + 1) * nbm) / P);
-    const int ksteps = (d.KH * d.KW * d.Cin_p + BK - 1) / BK;
-    const WinGeom wg = win_geom(d, BM);
-    const int cinb = d.Cin_p * 2;                       // bytes of a ring row
-    const int R = wg.R;
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-    const int ring0 = esz + 128, bpan = ring0 + wg.R * cinb;
-    const unsigned zaddr = lds0 + (unsigned)esz, ringa = lds0 + (unsigned)ring0;
-    if (tid == 0) *reinterpret_cast<uint4*>(smem + esz) = make_uint4(0, 0, 0, 0);      // (before any DMA is in flight: hipcc drains vmcnt in front of a visible LDS store)
-
-    // ---- the weight panel of this N-tile, once (stage image and lanes of conv_dma_body's B stage)
-    {
-        const int cgc = (tid & 7) ^ ((tid >> 4) & 7);
-        const T* bptr = wp + (size_t)(n0 + (tid >> 3)) * d.Kp + cgc * 8;
-        const int wrow = __builtin_amdgcn_readfirstlane(wid * 8);
-        for (int t = 0; t < ksteps; ++t)
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(bptr + (size_t)(32 * i) * d.Kp + (size_t)t * BK), (lptr_t)(smem + bpan + t * STAGE + (i * 32 + wrow) * ROW), 16, 0, 0);
-    }
-    // ---- input rows [lo, hi) -> ring (lo, hi multiples of 64 rows: a wave's 64 pieces never straddle the ring's end).  Wave w takes the 64-piece groups
-    // w, w + 4, ...; piece q holds (row lo + q / cpt, chunk (q % cpt) ^ key(ring row))
-    const unsigned INV = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)in >> 32)) << 32) |
-                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)in)), 0, (int)INV, 0x00020000);
-    const int Min = d.N * d.H * d.W;
-    const unsigned ldb = (unsigned)d.ld_in * 2u;
-    const int q0row = (wid * 64 + lane) / wg.cpt, q0slot = (wid * 64 + lane) - q0row * wg.cpt, qdrow = 256 / wg.cpt, qdslot = 256 - qdrow * wg.cpt;
-    const int ringbytes = wg.R * cinb;
-#define PN2_RING_LOAD(lo_, hi_, rlo_)                                                                                  \
-    do {                                                                                                               \
-        const int ngrp_ = ((hi_) - (lo_)) * wg.cpt >> 6;                                                               \
-        int row_ = q0row, slot_ = q0slot;                                                                              \
-        int rb_ = (rlo_) * cinb + wid * 1024;                /* (rlo_ = lo_ mod R, carried by the caller) */           \
-        if (rb_ >= ringbytes) rb_ -= ringbytes;                                                                        \
-        for (int j_ = wid; j_ < ngrp_; j_ += 4) {                                                                      \
-            int rr_ = (rlo_) + row_;                                                                                   \
-            if (rr_ >= R) rr_ -= R;                                                                                    \
-            const int p_ = (lo_) + row_, ch_ = slot_ ^ ((rr_ >> wg.ksh) & wg.kmask);                                   \
-            const unsigned vo_ = (unsigned)p_ < (unsigned)Min ? (unsigned)p_ * ldb + (unsigned)ch_ * 16u : INV;        \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(smem + ring0 + __builtin_amdgcn_readfirstlane(rb_)), 16, (int)vo_, 0, 0, PN2_A_AUX); \
-            row_ += qdrow; slot_ += qdslot;                                                                            \
-            if (slot_ >= wg.cpt) { slot_ -= wg.cpt; ++row_; }                                                          \
-            rb_ += 4096;                                                                                               \
-            if (rb_ >= ringbytes) rb_ -= ringbytes;                                                                    \
-        }                                                                                                              \
-    } while (0)
-    const int BIG = 1 << 24;                                 // (multiple of 64 above every |row index|: floor / ceil to 64 rows of possibly negative rows)
-    int front, rfront;                                       // rows below `front` are in the ring (or requested); rfront = front mod R
-    int rbase;                                               // ring row of input pixel (first row of the current tile) + off(0, 0)
-    {
-        const int m0 = t_beg * BM;
-        const int lo = ((m0 + wg.offmin + BIG) & ~63) - BIG;          // lives at ring row 0
-        front = ((m0 + BM + wg.offmin + wg.span + 63 + BIG) & ~63) - BIG;
-        PN2_RING_LOAD(lo, front, 0);
-        rfront = front - lo;                                 // (< R: the first window and its alignment slack fit the ring)
-        rbase = m0 + wg.c0 - lo;                             // in [0, R)
-    }
-
-    // ---- fragment state at K-step 0 of the two 32-deep halves (k = 64 t + 32 h + 8 g): channel byte offset inside the pixel, kernel row / column of
-    // the tap, the tap's row shift - stepped with adds and selects per K-step, no division and no branch
-    const int sgn = d.transposed ? -1 : 1;
-    const int sd_h = sgn * d.dil_h, sd_w = sgn * d.dil_w;
-    const int dcol_r = sd_w, drow_r = sd_h * d.W - (d.KW - 1) * sd_w;
-    const int nw = (63 + d.Cin_p) / d.Cin_p;           // tap steps per 64-deep K-step: ceil(64 / Cin_p)
-    int ci2_0[2], tr_0[2], tc_0[2], tsr_0[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        ci2_0[h] = (32 * h + 8 * g) * 2; tr_0[h] = 0; tc_0[h] = 0; tsr_0[h] = 0;
-        while (ci2_0[h] >= cinb) {
-            ci2_0[h] -= cinb;
-            const bool cw_ = tc_0[h] + 1 == d.KW;
-            tsr_0[h] += cw_ ? drow_r : dcol_r;
-            tc_0[h] = cw_ ? 0 : tc_0[h] + 1; tr_0[h] += cw_ ? 1 : 0;
-        }
-    }
-    const int key = (l15 >> 1) & 7;
-    const unsigned so0 = ((g) ^ key) * 16, so1 = ((4 + g) ^ key) * 16;
-    // pixel coordinates of this lane's first row, stepped from tile to tile
-    int oy0, ox0;
-    {
-        const unsigned mu = (unsigned)(t_beg * BM + wm * WTM + l15), hw = (unsigned)(d.OH * d.OW);
-        const unsigned rem = mu - (mu / hw) * hw, oq = rem / (unsigned)d.OW;
-        oy0 = (int)oq; ox0 = (int)(rem - oq * (unsigned)d.OW);
-    }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // weight panel + first window (this wave's pieces)
-    for (int bm = t_beg; bm < t_end; ++bm) {
-        const int m0 = bm * BM;
-        // this wave's share of the tile's rows (and of the weight panel) has landed - waited for before the previous tile's epilogue / in front of the loop;
-        // the barrier publishes the rows of all four waves and says that everyone is done with the previous tile's K loop and epilogue region.  The
-        // previous tile's global stores are NOT waited for.
-        __builtin_amdgcn_s_barrier();
-        if (bm + 1 < t_end) {                                // the next tile's BM new rows: in flight under this tile's K loop
-            PN2_RING_LOAD(front, front + BM, rfront);
-            front += BM; rfront += BM;
-            if (rfront >= R) rfront -= R;
-        }
-
-        int mrow[MT]; unsigned rmask[MT], cmask[MT];
-        {
-            int oy_ = oy0, ox_ = ox0;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int m = m0 + wm * WTM + i * 16 + l15;
-                const int iy0 = oy_ - sgn * d.pad_h, ix0 = ox_ - sgn * d.pad_w;
-                unsigned rm = 0, cm = 0;
-                for (int r = 0; r < d.KH; ++r) rm |= ((unsigned)(iy0 + r * sd_h) < (unsigned)d.H ? 1u : 0u) << r;
-                for (int c = 0; c < d.KW; ++c) cm |= ((unsigned)(ix0 + c * sd_w) < (unsigned)d.W ? 1u : 0u) << c;
-                rmask[i] = m < M ? rm : 0u; cmask[i] = cm;
-                mrow[i] = rbase + wm * WTM + i * 16 + l15 + R;      // ring row of the tap-(0,0) source pixel + R (the tap shift may be negative), before the reduction mod R
-                ox_ += 16;
-                while (ox_ >= d.OW) { ox_ -= d.OW; ++oy_; }
-                while (oy_ >= d.OH) oy_ -= d.OH;
-            }
-            rbase += BM;
-            if (rbase >= R) rbase -= R;
-            ox0 += BM;                                  // this lane's first row of the next tile
-            while (ox0 >= d.OW) { ox0 -= d.OW; ++oy0; }
-            while (oy0 >= d.OH) oy0 -= d.OH;
-        }
-        int ci2[2] = {ci2_0[0], ci2_0[1]}, tr[2] = {tr_0[0], tr_0[1]}, tc[2] = {tc_0[0], tc_0[1]}, tsr[2] = {tsr_0[0], tsr_0[1]};
-#define PN2_WSTEP(h_)                                                                                                  \
-    do {                                                                                                               \
-        ci2[h_] += 2 * BK;                                                                                             \
-        for (int w_ = 0; w_ < nw; ++w_) {                                                                              \
-            const bool wr_ = ci2[h_] >= cinb, cw_ = wr_ & (tc[h_] + 1 == d.KW);                                        \
-            ci2[h_] -= wr_ ? cinb : 0;                                                                                 \
-            tsr[h_] += wr_ ? (cw_ ? drow_r : dcol_r) : 0;                                                              \
-            tc[h_] = cw_ ? 0 : tc[h_] + (wr_ ? 1 : 0);                                                                 \
-            tr[h_] = min(tr[h_] + (cw_ ? 1 : 0), 31);                                                                  \
-        }                                                                                                              \
-    } while (0)
-        BnbPre<T, BM, BN> pre;
-        f32x4_t acc[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < ksteps; ++t) {
-            const unsigned Bs = lds0 + bpan + t * STAGE + (wn * WTN + l15) * ROW;
-            u32x4_t a0[MT], a1[MT], b0[NT], b1[NT];
-            unsigned ad0[MT], ad1[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                // (mrow + tsr in (0, 3R): two unsigned-min reductions bring it into [0, R))
-                unsigned r0_ = (unsigned)(mrow[i] + tsr[0]), r1_ = (unsigned)(mrow[i] + tsr[1]);
-                r0_ = min(r0_, r0_ - (unsigned)R); r0_ = min(r0_, r0_ - (unsigned)R);
-                r1_ = min(r1_, r1_ - (unsigned)R); r1_ = min(r1_, r1_ - (unsigned)R);
-                const bool ok0_ = ((rmask[i] >> tr[0]) & (cmask[i] >> tc[0]) & 1u) != 0, ok1_ = ((rmask[i] >> tr[1]) & (cmask[i] >> tc[1]) & 1u) != 0;
-                ad0[i] = ok0_ ? ringa + (unsigned)(__umul24(r0_, cinb) + (ci2[0] ^ (((r0_ >> wg.ksh) & wg.kmask) << 4))) : zaddr;
-                ad1[i] = ok1_ ? ringa + (unsigned)(__umul24(r1_, cinb) + (ci2[1] ^ (((r1_ >> wg.ksh) & wg.kmask) << 4))) : zaddr;
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a0[i]) : "v"(ad0[i]));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b0[j]) : "v"(Bs + j * 16 * ROW + so0));
-#pragma unroll
-            for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a1[i]) : "v"(ad1[i]));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b1[j]) : "v"(Bs + j * 16 * ROW + so1));
-            PN2_WSTEP(0);
-            PN2_WSTEP(1);
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, b0[j]), __builtin_bit_cast(uint4, a0[i]));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], __builtin_bit_cast(uint4, b1[j]), __builtin_bit_cast(uint4, a1[i]));
-        }
-#undef PN2_WSTEP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's rows (requested before the K loop) have landed: nothing but stores is in flight in the epilogue
-        conv_epilogue<T, BM, BN, WM, WN, MT, NT, EP, true>(acc, smem, d, ep, out, psum, psq, M, m0, n0, bm, pre);
-    }
-#undef PN2_RING_LOAD
-}
-
-// ------------------------------------------------------------------------------------------------
 // weight gradient: slab[s][co][k] = sum over this split's pixels of dy[m][co] * gather(x, m, k)
 // ------------------------------------------------------------------------------------------------
 constexpr int WGP = 32;   // pixels (contraction) per step
@@ -2098,58 +1860,6 @@ int launch_dma(const void* in, const void* wp, void* out, float* psum, float* ps
     return 0;
 }
 
-// window form (tuning-code bit 6)
-inline bool dma_extent_ok(const pn2_conv_desc& d);
-// LDS of the shared epilogue for a tile (worst case over the epilogue variants, so that the tile a tuning code runs on does not depend on the epilogue)
-inline int win_epi_bytes(int bm, int bn, bool ep) {
-    const int ct = bm * (bn * 2 + 16);
-    if (!ep) return ct;
-    if (ep2_tile(bm, bn)) return 2 * ct + 4 * bm * bn * 2;
-    return ct > ep_lds_bytes(8) ? ct : ep_lds_bytes(8);
-}
-inline int win_lds_bytes(const pn2_conv_desc& d, int bm, int bn, bool ep, int* esz_out = nullptr) {
-    const WinGeom g = win_geom(d, bm);
-    const int ksteps = (d.KH * d.KW * d.Cin_p + 63) / 64;
-    const int esz = (win_epi_bytes(bm, bn, ep) + 127) / 128 * 128;
-    if (esz_out) *esz_out = esz;
-    return esz + 128 + g.R * d.Cin_p * 2 + ksteps * bn * 128;
-}
-// stride-1 "same" convolution with more than one tap, 32-bit operand offsets, no split-K; tiles of 128 / 256 rows x 32 / 64 channels whose ring + weight
-// panel (+ the largest epilogue region) fit the LDS
-inline bool win_ok(const pn2_conv_desc& d, int bm, int bn) {
-    if (d.stride != 1 || d.H != d.OH || d.W != d.OW || d.KH * d.KW < 2 || d.KH > 31 || d.KW > 31 || ((d.flags >> 16) & 15) > 1 || !dma_extent_ok(d)) return false;
-    if (2 * d.pad_h != d.dil_h * (d.KH - 1) || 2 * d.pad_w != d.dil_w * (d.KW - 1) || bm < 128 || bn > 64) return false;
-    return win_lds_bytes(d, bm, bn, true) <= 160 * 1024;
-}
-template <bool EP, int BM, int BN, int WM, int WN>
-int launch_win(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
-    const int M = d.N * d.OH * d.OW;
-    const int nbm = (M + BM - 1) / BM, nbn = (d.Cout + BN - 1) / BN;
-    int esz;
-    const int lds = win_lds_bytes(d, BM, BN, EP, &esz);
-    if (lds > 160 * 1024) return -4;
-    // persistent grid: as many workgroups as the CUs hold (LDS-limited, at most 3 per CU), every one with a contiguous range of M-tiles
-    int occ = (160 * 1024) / lds; if (occ > 3) occ = 3; if (occ < 1) occ = 1;
-    int P = (256 * occ) / nbn;
-    const int cap = ((d.flags >> 20) & 0xff) * 8;          // PN2_CONV_WIN_SLOTS: at most this many workgroups per N-tile (tests: several tiles per workgroup on small inputs)
-    if (cap && P > cap) P = cap;
-    if (P < 1) P = 1; if (P > nbm) P = nbm;
-    static bool done = false;
-    if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_gemm<BM, BN, WM, WN, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-    hipLaunchKernelGGL((conv_win_gemm<BM, BN, WM, WN, EP>), dim3(nbn * P), dim3(256), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d, ep, P, esz);
-    PN2_CHECK_LAUNCH();
-    return 0;
-}
-template <bool EP>
-int win_dispatch(int bm, int bn, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
-    if (bm == 256) {
-        if (bn == 64) return launch_win<EP, 256, 64, 4, 1>(in, wp, out, psum, psq, d, ep, st);
-        return launch_win<EP, 256, 32, 4, 1>(in, wp, out, psum, psq, d, ep, st);
-    }
-    if (bn == 64) return launch_win<EP, 128, 64, 2, 2>(in, wp, out, psum, psq, d, ep, st);
-    return launch_win<EP, 128, 32, 4, 1>(in, wp, out, psum, psq, d, ep, st);
-}
-
 // the LDS-DMA kernel addresses the activation operand with 32-bit byte offsets behind a buffer descriptor (conv_dma_body): its extent must stay below 2 GB
 inline bool dma_extent_ok(const pn2_conv_desc& d) {
     return ((size_t)d.N * d.H * d.W - 1) * (size_t)d.ld_in * 2 + (size_t)d.Cin_p * 2 < 0x80000000ull;
@@ -2182,9 +1892,8 @@ int launch_wgrad(const void* dy, const void* x, float* slab, const pn2_wgrad_des
     return 0;
 }
 
-// (kernel, BM, BN) for this desc: kern 0 register-staged, 2 LDS-DMA 3-stage, 3 LDS-DMA 2-stage, 4 window form.  Optional per-shape tuning code in flags
-// bits 8..15 (bf16 only): kernel (1 register-staged, 2 / 3 LDS-DMA) | BM (1: 64, 2: 128, 3: 256 - window form only, else 128) << 2 | BN << 4 | 0x40 window form
-// (taken when the geometry and the LDS allow it, else the LDS-DMA kernel of the code's low bits)
+// (kernel, BM, BN) for this desc: kern 0 register-staged, 2 LDS-DMA 3-stage, 3 LDS-DMA 2-stage.  Optional per-shape tuning code in flags bits 8..15
+// (bf16 only): kernel (1 register-staged, 2 / 3 LDS-DMA) | BM (1: 64, 2: 128) << 2 | BN (1: 32, 2: 64, 3: 128) << 4
 template <typename T>
 void gemm_select(const pn2_conv_desc& d, int& kern, int& bm, int& bn) {
     pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
@@ -2194,10 +1903,6 @@ void gemm_select(const pn2_conv_desc& d, int& kern, int& bm, int& bn) {
     if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
     kern = 0;
     if (sizeof(T) == 2) kern = tk_ == 3 ? 3 : ((tk_ ? tk_ == 2 : use_dma_kernel()) ? 2 : 0);
-    if (sizeof(T) == 2 && (tune & 0x40) && tk_ != 1) {
-        const int wbm = tbm == 3 ? 256 : bm;
-        if (win_ok(d, wbm, bn)) { kern = 4; bm = wbm; }
-    }
     if (sizeof(T) == 4 && bn == 128) bn = 64;
 }
 
@@ -2206,7 +1911,6 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
     int kern, bm, bn;
     gemm_select<T>(d, kern, bm, bn);
     if constexpr (sizeof(T) == 2) {
-        if (kern == 4) return win_dispatch<EP>(bm, bn, in, wp, out, psum, psq, d, ep, st);
         if (kern == 3) {              // LDS-DMA, 2-stage ring (more workgroups per CU)
             if (bm == 128) {
                 if (bn == 128) return launch_dma<EP, 128, 128, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st);
@@ -2660,7 +2364,7 @@ int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d) {
     if (dtype == PN2_BF16) { gemm_select<bf16_t>(*d, kern, bm, bn); if ((kern == 0 && !use_dma_kernel()) || !dma_extent_ok(*d)) return -2; }
     else if (dtype == PN2_F32) gemm_select<float>(*d, kern, bm, bn);
     else return -3;
-    return (kern == 4 ? 1 << 20 : 0) | (bm << 8) | bn;
+    return (bm << 8) | bn;
 }
 
 int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn) {

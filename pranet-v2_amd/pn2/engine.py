@@ -334,7 +334,6 @@ PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == 
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
 BNB_MIN_COLS = int(os.environ.get("PN2_BNB_MIN_COLS", "0"))          # experiment: narrower gradients take the separate reduce pass instead of the dgrad epilogue
-WINDOW_CONV = os.environ.get("PN2_WINDOW_CONV", "1") == "1"         # the tuner may pick the window-form conv kernel (tuning-code bit 6)
 LOCKSTEP_TILES = os.environ.get("PN2_LOCKSTEP_TILES", "0") == "1"   # opt-in: canonical conv tiles inside lock-step regions (measured: no more shared launches, same speed)
 LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
@@ -768,15 +767,11 @@ class Engine:
                 d2.flags = code << 8
                 call.pn2_conv_gemm(self.dt, in_ptr, _p(wp), _p(scratch), nul, nul, C.byref(d2), st)
         cands = []
-        # 1 register-staged, 2 LDS-DMA with a 3-stage ring, 3 LDS-DMA with a 2-stage ring (more workgroups per CU), 0x42 window form (stride-1 "same" convs
-        # with more than one tap and few channels: persistent workgroups, rolling input window and weight panel resident in LDS; tiles of 128 / 256 rows)
-        win = (WINDOW_CONV and cd.stride == 1 and cd.KH * cd.KW > 1 and (cd.H, cd.W) == (cd.OH, cd.OW)
-               and 2 * cd.pad_h == cd.dil_h * (cd.KH - 1) and 2 * cd.pad_w == cd.dil_w * (cd.KW - 1))
-        for kern in (1, 2, 3) + ((0x42,) if win and cd.Cin_p <= 64 and M > 4096 else ()):
-            for bm in (2, 3) if kern == 0x42 else (1, 2):
+        for kern in (1, 2, 3):             # 1 register-staged, 2 LDS-DMA with a 3-stage ring, 3 LDS-DMA with a 2-stage ring (more workgroups per CU)
+            for bm in (1, 2):
                 if bm == 2 and M <= 64:
                     continue
-                for bn in (1, 2) if kern == 0x42 else (1, 2, 3):
+                for bn in (1, 2, 3):
                     if (bn == 2 and Cout <= 32) or (bn == 3 and Cout <= 64):
                         continue
                     cands.append(kern | (bm << 2) | (bn << 4))
@@ -815,11 +810,12 @@ class Engine:
             return 1
         return 4 if K >= 4096 else KSPLIT_MID
 
-    def _stat_blocks(self, M, Cout, tune, cd=None):
-        """rows of the per-tile partial buffers = ceil(M / tile rows); with a desc the library says which tile its tuning code runs on (the window form has
-        256-row tiles and falls back to 128 where it cannot run)"""
-        b = self._tile_m(M, Cout, tune, cd)
-        return (M + b - 1) // b
+    def _stat_blocks(self, M, Cout, tune):
+        bm = (tune >> 2) & 3
+        if bm:
+            b = 64 if bm == 1 else 128
+            return (M + b - 1) // b
+        return call.pn2_conv_stat_blocks(M, Cout, self.dt)
 
     def _tune_wgrad(self, wd, dy_ptr, x_ptr, rd, nsplit, wshape):
         """-> (kernel code, pixel splits) for this wgrad shape.  Candidates: register-staged / LDS-DMA / LDS-DMA with 128 x 256 tiles x
@@ -935,8 +931,8 @@ class Engine:
         cd.flags |= tune << 8
         tile_rows = 0
         if train_bn:
-            nblk = self._stat_blocks(M, Cout_p, tune, cd)
-            tile_rows = self._tile_m(M, Cout_p, tune, cd)
+            nblk = self._stat_blocks(M, Cout_p, tune)
+            tile_rows = self._tile_m(M, Cout_p, tune)
             psum, psq = self.fbuf(nblk, Cout_p), self.fbuf(nblk, Cout_p)
         flops = 2 * M * Cout * Cin * KH * KW
         shape = f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}"
@@ -1226,7 +1222,7 @@ class Engine:
                         ep.b.out = 1
                     tcode = self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, ep, canon=canon)
                     dd.flags |= tcode << 8
-                    nbx = self._stat_blocks(Mx, x.Cp, tcode, dd)
+                    nbx = self._stat_blocks(Mx, x.Cp, tcode)
                     ep = capi.ConvEp()
                     if dual:
                         # x = u + v (Bottle2neck's sp + spx[i]): the gradient goes to BOTH operands - accumulated into u's (the concat buffer slice
@@ -1253,15 +1249,8 @@ class Engine:
         self.record(bwd)
         return out if y2 is None else (out, y2)
 
-    def _tile_m(self, M, Cout, tune, cd=None):
+    def _tile_m(self, M, Cout, tune):
         bm = (tune >> 2) & 3
-        if bm == 3 and cd is not None:
-            d2 = capi.ConvDesc()
-            C.memmove(C.byref(d2), C.byref(cd), C.sizeof(capi.ConvDesc))
-            d2.flags = (cd.flags & 0xff) | (tune << 8)
-            t = call.pn2_conv_gemm_tile(self.dt, C.byref(d2))
-            if t >= 0:
-                return (t >> 8) & 0x1ff
         return (64 if bm == 1 else 128) if bm else call.pn2_conv_tile_m(M, Cout, self.dt)
 
     def _fill_bnb(self, t, act, nblk):
@@ -1376,8 +1365,8 @@ class Engine:
         cd.flags |= tune << 8
         tile_rows = 0
         if train:
-            nblk = self._stat_blocks(M, Ct, tune, cd)
-            tile_rows = self._tile_m(M, Ct, tune, cd)
+            nblk = self._stat_blocks(M, Ct, tune)
+            tile_rows = self._tile_m(M, Ct, tune)
             psum, psq = self.fbuf(nblk, Ct), self.fbuf(nblk, Ct)
         flops = 2 * M * Ct * x.C
         shape = f"{x.C}->{'+'.join(map(str, couts))} k1x1 s1 d1 {N}x{H}x{W}"

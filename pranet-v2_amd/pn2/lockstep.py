@@ -45,9 +45,7 @@ def _conv_job(a, with_ep):
     tile = call.pn2_conv_gemm_tile(dt, C.byref(j.d))
     if tile < 0:
         return None
-    bm, bn = (tile >> 8) & 0x1ff, tile & 255
-    if (tile >> 20) & 1:
-        return None                                                       # the tuned choice is the persistent window-form kernel: no table-driven form, launched on its own
+    bm, bn = tile >> 8, tile & 255
     nb = call.pn2_conv_gemm_job_blocks(dt, C.byref(j), bm, bn)
     if nb < 1:
         return None

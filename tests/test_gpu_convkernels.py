@@ -1,6 +1,6 @@
 """The conv GEMM kernels one by one (C ABI, forced kernel / tile codes): the register-staged kernel, the LDS-DMA kernel with 3 and 2 ring stages
-(activation operand through a buffer descriptor: 32-bit offsets, hardware zero fill for padding taps and missing rows / channel chunks), the
-window-form kernel (the contiguous input window of a tile staged once), and every tile shape must produce the SAME bf16 tensor bit for bit, forward gather and transposed (dgrad) gather, and that tensor must be the
+(activation operand through a buffer descriptor: 32-bit offsets, hardware zero fill for padding taps and missing rows / channel chunks),
+and every tile shape must produce the SAME bf16 tensor bit for bit, forward gather and transposed (dgrad) gather, and that tensor must be the
 convolution torch computes in float64 from the same bf16 operands, up to one rounding of the output.  Geometries: 1x1, 3x3, 1xk / kx1, 5x5,
 dilation 3 / 5 / 7, stride 2 (forward and its dgrad), row counts that do not fill a tile, channel counts that straddle a 64-wide K-step."""
 import ctypes as C
@@ -28,11 +28,9 @@ GEOMS = [
     (2, 16, 18, 56, 56, 3, 3, 2, 1, 1, 1),
     (2, 17, 15, 8, 32, 3, 3, 2, 1, 1, 1),
     (1, 5, 7, 200, 136, 1, 1, 1, 0, 0, 1),
-    (2, 40, 36, 32, 32, 3, 3, 1, 1, 1, 1),          # window form: several tiles per workgroup and image, 4 chunks per pixel (2-bit XOR key)
-    (2, 24, 20, 64, 32, 3, 3, 1, 1, 1, 1),          # 8 chunks per pixel (3-bit key)
-    (3, 20, 18, 56, 56, 3, 3, 1, 1, 1, 1),          # 7 chunks per pixel (no key), two 64-wide K-steps straddle a tap
-    (3, 20, 18, 48, 40, 3, 3, 1, 1, 1, 1),          # 6 chunks per pixel (1-bit key)
-    (5, 30, 30, 16, 24, 5, 5, 1, 2, 2, 1),          # 2 chunks per pixel, 25 taps: four taps per K-step
+    (2, 40, 36, 32, 32, 3, 3, 1, 1, 1, 1),          # many tiles per image
+    (3, 20, 18, 56, 56, 3, 3, 1, 1, 1, 1),          # a 64-wide K-step straddles two taps
+    (5, 30, 30, 16, 24, 5, 5, 1, 2, 2, 1),          # 25 taps, four taps per K-step
 ]
 
 
@@ -79,23 +77,14 @@ def test_conv_kernels_agree_and_match_float64(geom, transposed):
     d.transposed, d.Kp = transposed, Kp
     src_g, wp_g = src.to(dev), wp.to(dev)
     outs, stats = {}, {}
-    # 0x42: window form (stride-1 "same" convs with more than one tap and a small weight panel: persistent workgroups, rolling input window and weights
-    # resident in LDS; tiles of 128 / 256 rows x 32 / 64 channels); everything else falls back to the LDS-DMA kernel of the same code (256-row code -> 128 rows)
-    win_geo = s == 1 and taps > 1 and (H, W) == (OH, OW) and (Cout if transposed else Cin) <= 64
-    nwin = 0
-    for kern in (1, 2, 3, 0x42):
-        for bm in (1, 2, 3) if kern == 0x42 else (1, 2):
+    for kern in (1, 2, 3):
+        for bm in (1, 2):
             for bn in (1, 2, 3):
                 if (bn == 3 and n_out <= 64) or (bn == 2 and n_out <= 32):
                     continue
                 code = kern | (bm << 2) | (bn << 4)
-                d.flags = (code << 8) | (0 if transposed else capi.CONV_STATS) | (1 << 20)          # PN2_CONV_WIN_SLOTS(1): 8 persistent workgroups -> several tiles each
-                tile = call.pn2_conv_gemm_tile(BF16, C.byref(d))
-                tm = (tile >> 8) & 0x1ff
-                isw = (tile >> 20) & 1                      # the library takes the window form when geometry AND the LDS budget allow it
-                assert tile >= 0 and (not isw or (kern == 0x42 and win_geo and bm >= 2 and bn <= 2)), hex(tile)
-                nwin += isw
-                assert tm == (64 if bm == 1 else (256 if bm == 3 and (tile >> 20) & 1 else 128))
+                d.flags = (code << 8) | (0 if transposed else capi.CONV_STATS)
+                tm = 64 * bm
                 out = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device=dev)
                 if transposed:
                     call.pn2_conv_gemm(BF16, P(src_g), P(wp_g), P(out), C.c_void_p(0), C.c_void_p(0), C.byref(d), st)
@@ -106,7 +95,6 @@ def test_conv_kernels_agree_and_match_float64(geom, transposed):
                     stats.setdefault(tm, {})[code] = (ps, pq)
                 outs[code] = out
     torch.cuda.synchronize()
-    assert nwin > 0 or not (win_geo and KH == 3 and dil == 1), "the 3x3 few-channel geometries must exercise the window form"
     first = next(iter(outs.values()))
     for code, o in outs.items():
         assert torch.equal(o.view(torch.int16), first.view(torch.int16)), f"kernel/tile code {code:#x} differs from code {next(iter(outs)):#x}"
