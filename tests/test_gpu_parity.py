@@ -9,7 +9,7 @@ Tolerances
   stored as f64.*), so "1e-4 abs against the reference's fp32 logits" (north star) cannot be met by ANY fp32 implementation, the
   reference re-run with another BLAS included.  What is gated instead, against the float64 run of the reference:
       |ours - ref64| <= max(1e-4, 0.6 * |ref32 - ref64|)      logits and losses  (measured: 0.25-0.4 x the reference's own gap)
-      rel-L2(ours, ref64) <= max(2e-6, 0.8 * rel-L2(ref32, ref64))   every gradient probe, no outliers  (measured <= 0.5 x)
+      rel-L2(ours, ref64) <= max(2e-6, 1.0 * rel-L2(ref32, ref64))   every gradient probe, no outliers; median <= 0.8 x  (measured 0.23-0.63 x)
   i.e. this implementation must be CLOSER to the exact result than the reference's own fp32 path is.
   bf16 path: relative L2 <= 3e-2 per op (max-norm is meaningless once a ReLU mask bit flips on a near-zero activation); whole model:
   see test_model_bf16_vs_reference_f64.
@@ -331,10 +331,12 @@ def _module_vs_oracle(mod, oracle_fn, inputs, dtn):
     for x, c in zip(xs, xc):
         assert err(x.grad, c.grad) < tol
     named = dict(mod.named_parameters())
-    # bf16: a BatchNorm bias / weight gradient is a CANCELLING sum over a few hundred pixels of this small block (sum of ReLU-masked dy, of dy * xhat);
-    # one element whose normalised value sits next to 0 flips its mask under any rounding change and moves the sum by |dy| - the per-vector relative
-    # error of the deepest branch (bns.2.bias, 6 numbers) swings between 0.1 and 0.45 with the order of bf16 roundings.  Those vectors are judged
-    # together (relative L2 over all 1-D parameter gradients of the block) plus a loose per-vector bound; conv weights keep the per-tensor bound.
+    # Every parameter gradient keeps the per-tensor bound tol * 5 (bf16: measured <= 0.16 on the 1-D BatchNorm vectors, <= 0.1 on conv weights).  ONE vector
+    # is named as an exception: bns.2.bias of a Bottle2neck, the bias gradient of the deepest branch - 4..16 numbers, each a CANCELLING sum of ReLU-masked
+    # dy over a few hundred pixels of this small block; one element whose normalised value sits next to 0 flips its mask under any change in the order of
+    # bf16 roundings and moves the sum by |dy| (measured 0.03 / 0.16 / 0.43 on the three blocks, tools/probe_gates.py).  It gets < 1.0 and is covered by the
+    # pooled bound over all 1-D gradients of the block.
+    UNSTABLE_BF16 = ("bns.2.bias",)
     pool_a, pool_b = [], []
     for k in keys:
         if P[k].grad is not None:
@@ -343,9 +345,7 @@ def _module_vs_oracle(mod, oracle_fn, inputs, dtn):
                 print(f"   grad {k:28s} err {e:.3e}")
             if dtn != "fp32" and P[k].ndim == 1:
                 pool_a.append(named[k].grad.detach().reshape(-1).cpu().double()); pool_b.append(P[k].grad.reshape(-1).double())
-                assert e < 1.0, k
-            else:
-                assert e < tol * 5, k
+            assert e < (1.0 if (dtn != "fp32" and k in UNSTABLE_BF16) else tol * 5), (k, e)
     if pool_a:
         assert err(torch.cat(pool_a), torch.cat(pool_b)) < tol * 5
     sd = mod.state_dict()
@@ -458,13 +458,72 @@ def test_model_forward_backward_vs_reference(tag):
             rows.append((k, e, own))
     # gradients through ~60 train-mode BN layers are ill-conditioned (the reference's own fp32 error reaches 4e-2 on the stem), and an fp32 gradient of
     # a ReLU network is only piecewise continuous: an element within rounding of zero takes the other branch than in float64 and shifts every
-    # gradient upstream of it (tests/test_gpu_cond.py).  Gate on the distribution: the typical probe must be closer to the float64 gradient than the
-    # reference's own fp32 gradient is (median ratio <= 0.8; measured <= 0.5), and no probe may be further than 2 x the reference's own error.
+    # gradient upstream of it (tests/test_gpu_cond.py).  Gates: EVERY probe at least as close to the float64 gradient as the reference's own fp32 gradient is
+    # (ratio <= 1.0; measured 0.23-0.64 on both fixtures, tools/probe_gates.py), and the typical probe clearly closer (median <= 0.8).  ONE probe is a named
+    # exception: layer4.0.convs.1.weight at 96^2, a 3x3 stride-2 conv whose output has 2 x 3 x 3 = 18 pixels per channel in front of a train-mode BatchNorm
+    # (measured 1.17 x the reference's own error; allowed 2 x).
+    OUTLIERS = {("96", "backbone.layer4.0.convs.1.weight"): 2.0}
     ratios = sorted(e / max(own, 2.5e-6) for _k, e, own in rows)
-    bad = [r for r in rows if r[1] > max(2e-6, 2.0 * r[2])]
+    bad = [r for r in rows if r[1] > max(2e-6, OUTLIERS.get((tag, r[0]), 1.0) * r[2])]
     assert ratios[len(ratios) // 2] <= 0.8 and not bad, (ratios[len(ratios) // 2], bad)
     no_grad = sorted(k for k, p in named.items() if p.grad is None)
     assert no_grad == sorted(str(s) for s in z["nograd"])
+
+
+VARIANTS = {"k3": (dict(), "v2", 0, 1234), "k3lin": (dict(num_class=3, use_softmax=False, sem_downsample=2), "v2", 0, 1234), "pvtk3": (dict(num_class=3), "pvt", 3, 4321)}
+
+
+@pytest.mark.parametrize("tag", sorted(VARIANTS))
+def test_constructor_variants_vs_reference(tag):
+    """The constructor paths the binary scripts never take, end to end through the nn.Module surface + torch autograd on the fp32 path, against the
+    reference's own classes (tests/golden/make_golden_variants.py): PraNet_V2() with its DEFAULT arguments (num_class=3: the DSRA softmax is not the
+    identity, pranet.py:270,365-368), PraNet_V2(num_class=3, use_softmax=False, sem_downsample=2) (linear fusion, half-resolution maps, :349-350) and
+    PVT_PraNet_V2(num_class=3).  Backward under fixed cotangents (structure_loss is a one-channel loss).  Gates: every map within
+    max(1e-4, 1.0 x |ref32 - ref64|) of the float64 run - no further from the exact result than the reference's own fp32 run (measured 0.3-0.65 x;
+    PVT, whose own gap is 3e-5: 3 x), every gradient probe at least as close to the
+    float64 gradient as the reference's own fp32 gradient."""
+    import pn2
+    from lib.pranet import PraNet_V2, PVT_PraNet_V2
+    from oracle import weights as W
+    pn2.set_compute_dtype("fp32")
+    z = np.load(os.path.join(G, "pranet_v2_variants.npz"))
+    kw, fam, wseed, xseed = VARIANTS[tag]
+    model = (PraNet_V2 if fam == "v2" else PVT_PraNet_V2)(**kw)
+    if fam == "pvt":
+        model.backbone.reset_drop_path(0.0)
+    model.load_state_dict(W.make_state_dict(W.manifest_pranet_v2(3) if fam == "v2" else W.manifest_pvt_pranet_v2(3), seed=wseed), strict=True)
+    model = model.to(dev).train()
+    x, _ = W.synthetic_batch(2, 96, seed=xseed)
+    outs = model(x.to(dev))
+    assert len(outs) == 8 and all(tuple(o.shape) == tuple(int(v) for v in z[f"{tag}.shape"]) for o in outs)
+    g = torch.Generator().manual_seed(99)
+    gs = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * c.to(dev)).sum() for o, c in zip(outs, gs)).backward()
+    k_own = 1.0 if fam == "v2" else 3.0
+    rows = []
+    for i, o in enumerate(outs):
+        r64 = torch.from_numpy(z[f"{tag}.f64.out{i}"])
+        rows.append((i, float((o.detach().cpu().double()[:, :, ::2, ::2] - r64).abs().max()), float(z[f"{tag}.own_abs"][i])))
+    if os.environ.get("PN2_TEST_VERBOSE"):
+        print(tag, [(i, f"{e:.2e}", f"{own:.2e}") for i, e, own in rows])
+    assert all(e <= max(1e-4, k_own * own) for _i, e, own in rows), (tag, rows)
+    named = dict(model.named_parameters())
+    bad = []
+    for f in z.files:
+        if f.startswith(f"{tag}.f64.graw."):
+            k = f[len(f"{tag}.f64.graw."):]
+            r64 = torch.from_numpy(z[f]).double(); r32 = torch.from_numpy(z[f"{tag}.graw.{k}"]).double()
+            got = named[k].grad.reshape(-1)[:256].cpu().double()
+            own = float((r32 - r64).norm() / (r64.norm() + 1e-30)); e = float((got - r64).norm() / (r64.norm() + 1e-30))
+            if e > max(2e-5 if fam == "pvt" else 2e-6, 1.0 * own):
+                bad.append((k, e, own))
+    assert not bad, bad
+    assert sorted(k for k, p in named.items() if p.grad is None) == sorted(str(s_) for s_ in z[f"{tag}.nograd"])
+    sd = model.state_dict()
+    for f in z.files:
+        if f.startswith(f"{tag}.buf."):
+            k = f[len(f"{tag}.buf."):]
+            assert relmax(sd[k].reshape(-1)[:256].float(), torch.from_numpy(z[f])) < 1e-4, k
 
 
 @pytest.mark.parametrize("tag", ["96", "352"])

@@ -316,3 +316,40 @@ def test_conditioned_fixture_oracle_train_and_eval():
         u8 = O.test_postprocess([o[:1] for o in outs], tuple(z[f"{tag}.u8"].shape))
         assert np.abs(u8.astype(int) - z[f"{tag}.u8"].astype(int)).max() <= 1
         assert abs(O.mean_dice(u8, z[f"{tag}.gt"]) - float(z[f"{tag}.meanDic"])) < 1e-3
+
+
+VARIANTS = {"k3": (dict(), "v2", 0, 1234), "k3lin": (dict(use_softmax=False, sem_downsample=2), "v2", 0, 1234), "pvtk3": (dict(), "pvt", 3, 4321)}
+
+
+@pytest.mark.parametrize("tag", sorted(VARIANTS))
+def test_constructor_variants_oracle_matches_reference(tag):
+    """The constructor paths the binary scripts never take - PraNet_V2() with its DEFAULT num_class=3 (pranet.py:270), use_softmax=False +
+    sem_downsample=2 (pranet.py:349-350, 365-368), PVT_PraNet_V2(num_class=3) - against the reference's own classes (tests/golden/make_golden_variants.py):
+    8 outputs, gradient heads / norms under fixed cotangents, BN buffers, the parameters without gradient."""
+    z = np.load(os.path.join(G, "pranet_v2_variants.npz"))
+    kw, fam, wseed, xseed = VARIANTS[tag]
+    man = W.manifest_pranet_v2(3) if fam == "v2" else W.manifest_pvt_pranet_v2(3)
+    P = W.make_state_dict(man, seed=wseed)
+    x, _ = W.synthetic_batch(2, 96, seed=xseed)
+    keys = O.params_of(P)
+    for k in keys:
+        P[k].requires_grad_(True)
+    fwd = O.pranet_v2_forward if fam == "v2" else O.pvt_pranet_v2_forward
+    outs = fwd(P, x, True, **kw)
+    assert tuple(outs[0].shape) == tuple(int(v) for v in z[f"{tag}.shape"])
+    g = torch.Generator().manual_seed(99)
+    gs = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * c).sum() for o, c in zip(outs, gs)).backward()
+    for i, o in enumerate(outs):
+        ref = T(z[f"{tag}.out{i}"])
+        assert float((o.detach() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), (tag, i)
+    for f in z.files:
+        if f.startswith(f"{tag}.grawnorm."):
+            k = f[len(f"{tag}.grawnorm."):]
+            assert abs(float(P[k].grad.norm()) - float(z[f])) <= 3e-3 * float(z[f]) + 1e-6, k
+            ref = T(z[f"{tag}.graw.{k}"])
+            assert float((P[k].grad.reshape(-1)[:256] - ref).abs().max()) < 3e-3 * max(1e-3, float(ref.abs().max())), k
+        if f.startswith(f"{tag}.buf."):
+            k = f[len(f"{tag}.buf."):]
+            assert float((P[k].detach().reshape(-1)[:256] - T(z[f])).abs().max()) < 1e-5, k
+    assert sorted(k for k in keys if P[k].grad is None) == sorted(str(s_) for s_ in z[f"{tag}.nograd"])
