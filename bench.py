@@ -99,10 +99,141 @@ def fp32_line(model_ctor, x, m, steps=5):
             "note": "fp32 storage; conv products / sums in double on v_mfma_f64_16x16x4_f64 (78.6 TF/s dense peak), one rounding per output"}
 
 
+def _timed_replay(tr, steps):
+    tr.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def other_configs(dev, steps=10):
+    """BASELINE configs 4 and 5 on this GPU (their single-GPU workloads), through the same fused Trainer + hipGraph replay as the headline."""
+    import pn2
+    from pn2.trainer import Trainer
+    from lib.pranet import PVT_PraNet_V2
+    from lib.networks import EMCADNet
+    out = {}
+    pn2.set_compute_dtype("bf16")
+    torch.manual_seed(0)
+    model = PVT_PraNet_V2(num_class=1).to(dev).train()
+    tr = Trainer(model, lr=1e-4, clip=0.5)
+    x, m = synthetic(16, 352, 1234, dev)
+    tr.capture(x, m, warmup=2)
+    el = _timed_replay(tr, steps)
+    out["pvt_bs16_352"] = {"workload": "PVT-PraNet-V2 (pvt_v2_b2, DropPath 0.1) training step, bs=16 352x352 bf16 (config 4, one GPU)", "value": round(16 / el, 1),
+                           "unit": "images/sec", "ms_per_step": round(1e3 * el, 3), "steps": steps}
+    del tr, model
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    model = EMCADNet(num_classes=9, kernel_sizes=[1, 3, 5], expansion_factor=2, activation="relu6", encoder="pvt_v2_b2", pretrain=False, dual=True).to(dev).train()
+    tr = Trainer(model, lr=1e-4, clip=None, weight_decay=1e-4, loss="mutation", hot=model.hot_parameters(True))
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = torch.randn(16, 1, 512, 512, generator=g).to(dev)
+    lab = torch.randint(0, 9, (16, 32, 32), generator=g).to(dev)
+    lab = torch.nn.functional.interpolate(lab[:, None].float(), size=(512, 512), mode="nearest")[:, 0].long()
+    m = (lab, torch.stack([(lab != k).float() for k in range(9)], 1))
+    tr.capture(x, m, warmup=2)
+    el = _timed_replay(tr, steps)
+    out["emcad_k9_bs16_512"] = {"workload": "EMCADNet dual K=9 (pvt_v2_b2 + EMCAD decoder) fwd + 15-subset CE/Dice/BCE loss + bwd + AdamW, bs=16 512x512 bf16 (config 5, one GPU)",
+                                "value": round(16 / el, 1), "unit": "images/sec", "ms_per_step": round(1e3 * el, 3), "steps": steps}
+    del tr, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def module_surface(dev, x, m, steps=10):
+    """The drop-in path: the literal loop of MyTrain_med.py:59-86 on the mirror classes - model(images) -> 4 x structure_loss -> loss.backward() -> clip_gradient ->
+    torch.optim.Adam.step(), eager, torch autograd around one engine pass."""
+    import pn2
+    from lib.pranet import PraNet_V2
+    from pn2.loss import structure_loss
+    from utils.utils import clip_gradient
+    pn2.set_compute_dtype("bf16")
+    torch.manual_seed(0)
+    model = PraNet_V2(num_class=1).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), 1e-4)
+    bg = 1 - m
+
+    def step():
+        opt.zero_grad()
+        o = model(x)
+        loss = structure_loss(o[3], o[7], m, bg) + structure_loss(o[2], o[6], m, bg) + structure_loss(o[1], o[5], m, bg) + structure_loss(o[0], o[4], m, bg)
+        loss.backward()
+        clip_gradient(opt, 0.5)
+        opt.step()
+        return loss
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    del model, opt
+    torch.cuda.empty_cache()
+    return {"what": "nn.Module surface + torch autograd + utils.clip_gradient + torch.optim.Adam (MyTrain_med.py:59-86 verbatim), eager launches", "value": round(x.shape[0] / el, 1),
+            "unit": "images/sec", "ms_per_step": round(1e3 * el, 3), "steps": steps, "loss": round(float(loss), 4)}
+
+
+def inference(dev, reps=50):
+    """BASELINE config 1 on the GPU: eval-mode forward of one 352x352 image (MyTest_med.py:98-104) replayed from a hipGraph (pn2.infer.Predictor; conv + BatchNorm
+    + ReLU + residual in one launch per layer), and at bs=16 (the largest batch of the published FPS table, jittor/README.md:109-117)."""
+    import pn2
+    from pn2.infer import Predictor
+    from lib.pranet import PraNet_V2
+    pn2.set_compute_dtype("bf16")
+    torch.manual_seed(0)
+    model = PraNet_V2(num_class=1).to(dev).eval()
+    out = {}
+    with torch.no_grad():
+        pred = Predictor(model)
+        for bs in (1, 16):
+            x = torch.randn(bs, 3, 352, 352, device=dev)
+            pred(x); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                pred(x)
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / reps
+            out[f"bs{bs}_352"] = {"ms_per_batch": round(1e3 * el, 3), "images_per_sec": round(bs / el, 1)}
+    del pred, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def dp1_line(dev, x, m, steps=10):
+    """The data-parallel path on a ONE-rank RCCL communicator (bucket hooks, graph segments, ncclAllReduce between them) next to the local trainer: what the DP
+    machinery costs with zero bytes on the wire."""
+    import torch.distributed as dist
+    import pn2
+    from pn2.trainer import Trainer
+    from lib.pranet import PraNet_V2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        pn2.set_compute_dtype("bf16")
+        torch.manual_seed(0)
+        model = PraNet_V2(num_class=1).to(dev).train()
+        tr = Trainer(model, lr=1e-4, clip=0.5, process_group=dist.group.WORLD, force_dp=True)
+        tr.capture(x, m, warmup=2)
+        el = _timed_replay(tr, steps)
+        st_ = tr._cur
+        res = {"ms_per_step": round(1e3 * el, 3), "images_per_sec": round(x.shape[0] / el, 1), "graph_segments": len(st_.segments) if st_.segments else 1,
+               "buckets": len(tr.buckets.buckets), "allreduce_bytes_per_step": int(tr.n_hot * 4), "backend": "nccl (RCCL), one-rank communicator"}
+        del tr, model
+    finally:
+        dist.destroy_process_group()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=150, help="timed steps (default: ~2 s of hipGraph replay)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=352)
@@ -115,6 +246,7 @@ def main():
                                                        "segments, ncclAllReduce between them): validates the RCCL plumbing where only one GPU is available")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-line", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra records of the default single-GPU run (configs 4 / 5, module surface, inference, one-rank DP)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,9 +362,22 @@ def main():
         if dp is not None:
             out["dp"] = dp
         if world == 1 and not args.no_fp32_line and args.model == "res2net" and args.dtype == "bf16":
-            del tr
+            tr = None
             torch.cuda.empty_cache()
             out["fp32"] = fp32_line(lambda: PraNet_V2(num_class=1).to(dev).train(), x, m)
+        if world == 1 and not args.no_extras and not args.dp1 and args.model == "res2net" and args.dtype == "bf16" and args.batch == 32 and args.size == 352:
+            # the other numbers of the repository, in the driver's record (each bounded to a few seconds of GPU time; a failure is reported, not fatal)
+            tr = None
+            torch.cuda.empty_cache()
+            for key, fn in (("configs", lambda: other_configs(dev)), ("module_surface", lambda: module_surface(dev, x, m)), ("inference", lambda: inference(dev)),
+                            ("dp1", lambda: dp1_line(dev, x, m))):
+                try:
+                    out[key] = fn()
+                except Exception as e:          # noqa: BLE001
+                    out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if "dp1" in out and "ms_per_step" in out["dp1"]:
+                out["dp1"]["local_ms_per_step"] = out["ms_per_step"]
+                out["dp1"]["overhead_frac"] = round(out["dp1"]["ms_per_step"] / out["ms_per_step"] - 1.0, 4)
         if world == 1 and not args.no_cpu_baseline and args.model != "emcad":
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)

@@ -27,6 +27,9 @@ extern "C" {
                                             write fp32 partial tiles to `psum` = workspace [n][M][Cout]; finish with pn2_conv_splitk_reduce.  For convs with
                                             few output rows and a long contraction (5x5 on 11x11 maps).  Excludes STATS / BIAS / ACCUM (the reduce does those). */
 #define PN2_CONV_ROWGATE 8 /* set by pn2_conv_gemm_gated: accumulator rows are scaled by 1 - sigmoid(gate[m]) before statistics / store */
+#define PN2_CONV_AFFINE 16 /* pn2_conv_gemm_affine: out = act(acc * scale[c] + shift[c] (+ residual)) - eval-mode BatchNorm (+ ReLU / ReLU6) (+ residual add) folded into the GEMM epilogue */
+#define PN2_CONV_RELU 32   /* ... with ReLU */
+#define PN2_CONV_RELU6 64  /* ... with ReLU6 */
 #define PN2_CONV_BIAS 4    /* `psum` is a [Cout] fp32 bias (physical columns) added in the epilogue; excludes PN2_CONV_STATS */
 
 /* ---------------------------------------------------------------------------------------------- conv
@@ -90,6 +93,13 @@ int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* p
  * applied to the accumulator rows in the GEMM epilogue; PN2_CONV_STATS statistics are those of the gated result.  The gated copy of x_l (512..2048 channels)
  * is never materialised.  Not with PN2_CONV_BIAS / split-K.  Backward: pn2_ra_gate_post_bwd on (out, d out), then plain dgrad / wgrad.                         */
 int pn2_conv_gemm_gated(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, const float* gate, void* stream);
+/* Eval-mode conv + BatchNorm (+ ReLU / ReLU6) (+ residual) in ONE launch (MyTest_med.py:98-104, the in-training evaluation MyTrain_med.py:163-164; BasicConv2d
+ * pranet.py:40-43, Bottle2neck Res2Net_v1b.py:60-63,70-72,84-89 with running statistics): scale / shift [Cout] are the folded BatchNorm rows of pn2_bn_eval_prepare
+ * (physical columns), d->flags carries PN2_CONV_AFFINE (| PN2_CONV_RELU | PN2_CONV_RELU6); `res` (optional, same dtype, 16-byte aligned rows) is added before the
+ * activation.  No raw conv output is written and no separate pn2_affine_act pass runs.  fp32: bit-identical to the two launches; bf16: one rounding fewer.  Table-driven
+ * form: a pn2_conv_job with psum = scale, psq = shift, ep.a.y / ep.a.ld_y = res, every other ep field zero. */
+int pn2_conv_gemm_affine(int dtype, const void* in, const void* wp, void* out, const float* scale, const float* shift, const void* res, int ld_res,
+                         const pn2_conv_desc* d, void* stream);
 typedef struct pn2_bnb_target {
     void* out; int ld_out;          /* target b only: second destination (same dtype / column range as the GEMM's out) */
     int mode;                       /* PN2_BNB_* ; 0 = no statistics */
@@ -168,6 +178,10 @@ int pn2_bn_finalize(const float* psum, const float* psq, int nblk, const pn2_bn_
 /* eval mode: scale/shift from running statistics */
 int pn2_bn_eval_prepare(const pn2_bn_desc* d, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float* scale, float* shift, void* stream);
+/* the same for many BatchNorms in one launch, from a DEVICE job table (inference: every BatchNorm of a model folded by one graph node); block_start_dev:
+ * njobs + 1 prefix sums of ceil(Cp / 256) */
+typedef struct pn2_bnprep_job { const float* gamma; const float* beta; const float* running_mean; const float* running_var; float* scale; float* shift; pn2_bn_desc d; int pad_; } pn2_bnprep_job;
+int pn2_bn_eval_prepare_multi(const pn2_bnprep_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
 /* y[m][c] = act(x[m][c]*scale[c] + shift[c] + res[m][c]) for c < Cout ; scale==NULL -> identity affine */
 int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int ld_y, int M, int Cout,
                    const float* scale, const float* shift, const void* res, int ld_res, int relu, void* stream);

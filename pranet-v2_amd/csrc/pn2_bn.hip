@@ -155,6 +155,18 @@ __global__ void bn_eval_prepare_k(pn2_bn_desc d, const float* gamma, const float
     scale[c] = sc; shift[c] = beta[lc] - rm[lc] * sc;
 }
 
+// every eval-mode BatchNorm of a model in one launch (inference graphs: one node instead of one per layer)
+__global__ __launch_bounds__(256) void bn_eval_prepare_tab(const pn2_bnprep_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_bnprep_job j = jobs[jb];
+    const int c = (blockIdx.x - bstart[jb]) * 256 + threadIdx.x;
+    if (c >= j.d.Cp) return;
+    const int lc = phys2log(c, j.d.gw, j.d.gwp, j.d.C);
+    if (lc < 0) { j.scale[c] = 0.f; j.shift[c] = 0.f; return; }
+    const float sc = j.gamma[lc] / sqrtf(j.running_var[lc] + j.d.eps);
+    j.scale[c] = sc; j.shift[c] = j.beta[lc] - j.running_mean[lc] * sc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // y = act(x*scale + shift + res)
 // ---------------------------------------------------------------------------------------------
@@ -781,6 +793,13 @@ int pn2_bn_finalize(const float* psum, const float* psq, int nblk, const pn2_bn_
 int pn2_bn_eval_prepare(const pn2_bn_desc* d, const float* gamma, const float* beta, const float* rm, const float* rv, float* scale, float* shift, void* stream) {
     if (!d || !gamma || !beta || !rm || !rv || !scale || !shift) return -1;
     hipLaunchKernelGGL(bn_eval_prepare_k, dim3((d->Cp + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, gamma, beta, rm, rv, scale, shift);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_bn_eval_prepare_multi(const pn2_bnprep_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    hipLaunchKernelGGL(bn_eval_prepare_tab, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
     PN2_CHECK_LAUNCH();
     return 0;
 }

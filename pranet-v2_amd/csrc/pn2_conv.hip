@@ -591,7 +591,11 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
         PN2_STAMP_AT(5);
         const int rows_ok = M - m0;                    // rows of the tile that exist (>= BM for all but the last row block)
         const bool has_bias = d.flags & PN2_CONV_BIAS;
-        if (full_m && !has_bias) {
+        // PN2_CONV_AFFINE (eval-mode BatchNorm folded into the GEMM, pn2_conv_gemm_affine): y = acc * scale[c] + shift[c] (psum / psq), then the activation -
+        // unless a residual is added first (copy-out below)
+        const bool affine = !EP && (d.flags & PN2_CONV_AFFINE);
+        const int act_pre = (affine && !ep.a.y) ? ((d.flags & PN2_CONV_RELU6) ? 2 : ((d.flags & PN2_CONV_RELU) ? 1 : 0)) : 0;
+        if (full_m && !has_bias && !affine) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -601,21 +605,28 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
         } else {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                float b4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (has_bias) {
+                float b4[4] = {0.f, 0.f, 0.f, 0.f}, s4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (has_bias || affine) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int cg = n0 + wn * WTN + j * 16 + g * 4 + r;
-                        b4[r] = cg < d.Cout ? psum[cg] : 0.f;
+                        if (affine) { s4[r] = cg < d.Cout ? psum[cg] : 0.f; b4[r] = cg < d.Cout ? psq[cg] : 0.f; }
+                        else b4[r] = cg < d.Cout ? psum[cg] : 0.f;
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int row = wm * WTM + i * 16 + l15;
                     const bool live = row < rows_ok;       // rows past M are staged as zeros: they drop out of the statistics
-                    const float v0 = live ? acc[i][j][0] + b4[0] : 0.f, v1 = live ? acc[i][j][1] + b4[1] : 0.f;
-                    const float v2 = live ? acc[i][j][2] + b4[2] : 0.f, v3 = live ? acc[i][j][3] + b4[3] : 0.f;
-                    *reinterpret_cast<uint2*>(Cs + row * CRS + (wn * WTN + j * 16 + g * 4) * 2) = make_uint2(TT<T>::cvt2(v0, v1), TT<T>::cvt2(v2, v3));
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = affine ? fmaf(acc[i][j][r], s4[r], b4[r]) : acc[i][j][r] + b4[r];
+                        if (act_pre) v[r] = fmaxf(v[r], 0.f);
+                        if (act_pre == 2) v[r] = fminf(v[r], 6.f);
+                        v[r] = live ? v[r] : 0.f;
+                    }
+                    *reinterpret_cast<uint2*>(Cs + row * CRS + (wn * WTN + j * 16 + g * 4) * 2) = make_uint2(TT<T>::cvt2(v[0], v[1]), TT<T>::cvt2(v[2], v[3]));
                 }
             }
         }
@@ -683,7 +694,27 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
         }
     }
     PN2_STAMP_AT(12);
-    if (d.flags & PN2_CONV_BIAS) {                  // psum carries a per-output-channel fp32 bias (biased conv / nn.Linear without BN)
+    if (!EP && (d.flags & PN2_CONV_AFFINE)) {       // eval-mode BatchNorm folded into the GEMM: psum / psq carry scale / shift (see the swapped epilogue)
+        const int act_pre = !ep.a.y ? ((d.flags & PN2_CONV_RELU6) ? 2 : ((d.flags & PN2_CONV_RELU) ? 1 : 0)) : 0;
+        float sj[NT], bj[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cg = n0 + wn * WTN + j * 16 + l15;
+            sj[j] = cg < d.Cout ? psum[cg] : 0.f; bj[j] = cg < d.Cout ? psq[cg] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * WTM + i * 16 + g * 4 + r, col = wn * WTN + j * 16 + l15;
+                    float v = fmaf(acc[i][j][r], sj[j], bj[j]);
+                    if (act_pre) v = fmaxf(v, 0.f);
+                    if (act_pre == 2) v = fminf(v, 6.f);
+                    TT<T>::st(reinterpret_cast<T*>(Cs + row * CRS) + col, (!MST || row < M - m0) ? v : 0.f);
+                }
+    } else if (d.flags & PN2_CONV_BIAS) {           // psum carries a per-output-channel fp32 bias (biased conv / nn.Linear without BN)
         float bj[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -741,7 +772,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
     const bool accum = d.flags & PN2_CONV_ACCUM;
     PN2_STAMP_AT(7);
     if constexpr (!EP) {
-        if (full_m && vec_ok && !accum && n0 + BN <= d.Cout) {         // the common tile: no bounds, no read-modify-write
+        // PN2_CONV_AFFINE with a residual (ep.a.y, same dtype): y = act(staged + residual) in the copy-out (vector path: the host checks the alignment)
+        const T* res = (d.flags & PN2_CONV_AFFINE) ? reinterpret_cast<const T*>(ep.a.y) : nullptr;
+        const int act_post = res ? ((d.flags & PN2_CONV_RELU6) ? 2 : ((d.flags & PN2_CONV_RELU) ? 1 : 0)) : 0;
+        if (full_m && vec_ok && !accum && !res && n0 + BN <= d.Cout) {         // the common tile: no bounds, no read-modify-write
             T* obase = out + (size_t)m0 * d.ld_out + n0;
 #pragma unroll
             for (int u = 0; u < BM * VPR / 256; ++u) {
@@ -763,6 +797,18 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
                     TT<T>::unpack(*reinterpret_cast<const uint4*>(dst), y);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) x[e] += y[e];
+                    v = TT<T>::pack(x);
+                }
+                if (res) {
+                    float x[VEC], y[VEC];
+                    TT<T>::unpack(v, x);
+                    TT<T>::unpack(*reinterpret_cast<const uint4*>(res + (size_t)m * ep.a.ld_y + col), y);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        x[e] += y[e];
+                        if (act_post) x[e] = fmaxf(x[e], 0.f);
+                        if (act_post == 2) x[e] = fminf(x[e], 6.f);
+                    }
                     v = TT<T>::pack(x);
                 }
                 *reinterpret_cast<uint4*>(dst) = v;
@@ -2290,6 +2336,7 @@ static int conv_gemm_impl(int dtype, const void* in, const void* wp, void* out, 
     if ((d->flags & PN2_CONV_STATS) && (!psum || !psq)) return -1;
     if ((d->flags & PN2_CONV_BIAS) && (!psum || (d->flags & PN2_CONV_STATS))) return -1;
     if (((d->flags >> 16) & 15) > 1 && (dtype != PN2_BF16 || !psum || (d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS | PN2_CONV_ACCUM)) || ((d->flags >> 8) & 3) < 2)) return -2;
+    if (d->flags & PN2_CONV_AFFINE) return -2;                 // (pn2_conv_gemm_affine owns that flag)
     const bool gated = d->flags & PN2_CONV_ROWGATE;
     const int vec_ = dtype == PN2_F32 ? 4 : 8;
     if (gated && (!ep.a.par || (ep.a.mode | ep.b.mode) != 0 || ep.b.out || (d->flags & PN2_CONV_BIAS) || ((d->flags >> 16) & 15) > 1 || d->Cout % vec_ || d->ld_out % vec_)) return -2;
@@ -2333,6 +2380,22 @@ int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* p
     return conv_gemm_impl(dtype, in, wp, out, psum, psq, d, ep, stream);
 }
 
+int pn2_conv_gemm_affine(int dtype, const void* in, const void* wp, void* out, const float* scale, const float* shift, const void* res, int ld_res, const pn2_conv_desc* d,
+                         void* stream) {
+    if (!d || !scale || !shift) return -1;
+    if (!(d->flags & PN2_CONV_AFFINE) || (d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS | PN2_CONV_ACCUM | PN2_CONV_ROWGATE)) || ((d->flags >> 16) & 15) > 1) return -2;
+    const int vec_ = dtype == PN2_F32 ? 4 : 8;
+    if (res && (d->Cout % vec_ || d->ld_out % vec_ || ld_res % vec_)) return -2;
+    pn2_conv_ep ep;
+    memset(&ep, 0, sizeof(ep));
+    ep.a.y = res; ep.a.ld_y = ld_res;
+    if (!in || !wp || !out) return -1;
+    if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
+    if (dtype == PN2_BF16) return gemm_dispatch<bf16_t, false>(in, wp, out, const_cast<float*>(scale), const_cast<float*>(shift), *d, ep, (hipStream_t)stream);
+    if (dtype == PN2_F32) return gemm_dispatch<float, false>(in, wp, out, const_cast<float*>(scale), const_cast<float*>(shift), *d, ep, (hipStream_t)stream);
+    return -3;
+}
+
 int pn2_conv_gemm_gated(int dtype, const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc* d, const float* gate, void* stream) {
     if (!d || !gate) return -1;
     pn2_conv_desc dg = *d;
@@ -2372,6 +2435,11 @@ int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn) {
     const pn2_conv_desc& d = j->d;
     if ((d.flags & PN2_CONV_STATS) && (!j->psum || !j->psq)) return -1;
     if ((d.flags & PN2_CONV_BIAS) && !j->psum) return -1;
+    if (d.flags & PN2_CONV_AFFINE) {
+        const int v_ = dtype == PN2_F32 ? 4 : 8;
+        if (!j->psum || !j->psq || (d.flags & (PN2_CONV_STATS | PN2_CONV_BIAS | PN2_CONV_ACCUM | PN2_CONV_ROWGATE)) || j->ep.a.mode || j->ep.b.mode || j->ep.b.out) return -1;
+        if (j->ep.a.y && (d.Cout % v_ || d.ld_out % v_ || j->ep.a.ld_y % v_)) return -2;
+    }
     const bool use_ep = (j->ep.a.mode | j->ep.b.mode) != 0 || j->ep.b.out != nullptr;
     const int vec = dtype == PN2_F32 ? 4 : 8;
     if (use_ep && (d.Cout % vec || d.ld_out % vec || (d.flags & (PN2_CONV_STATS | PN2_CONV_BIAS)))) return -2;

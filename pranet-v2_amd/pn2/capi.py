@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("PN2_LIB") or os.path.join(os.path.dirname(_HERE), "cs
 
 F32, BF16 = 0, 1
 CONV_STATS, CONV_ACCUM, CONV_BIAS = 1, 2, 4
+CONV_AFFINE, CONV_RELU, CONV_RELU6 = 16, 32, 64
 
 
 class ConvDesc(C.Structure):
@@ -90,6 +91,10 @@ class BnFinJob(C.Structure):
                [("d", BnDesc), ("nblk", C.c_int), ("cpb", C.c_int), ("pad_", C.c_int)]
 
 
+class BnPrepJob(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("gamma", "beta", "running_mean", "running_var", "scale", "shift")] + [("d", BnDesc), ("pad_", C.c_int)]
+
+
 class AffineJob(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "y", "scale", "shift", "res", "add", "y2")] + \
                [(n, C.c_int) for n in ("ld_x", "ld_y", "ld_res", "ld_add", "ld_y2", "M", "C", "relu", "rows_per_blk", "cvp")]
@@ -149,6 +154,7 @@ SIGNATURES = {
     "pn2_wgrad_reduce_multi": [P, P, I, I, P],
     "pn2_bn_finalize": [P, P, I, C.POINTER(BnDesc), P, P, P, P, P, P, P, P, P],
     "pn2_bn_eval_prepare": [C.POINTER(BnDesc), P, P, P, P, P, P, P],
+    "pn2_bn_eval_prepare_multi": [P, P, I, I, P],
     "pn2_affine_act_sum": [I, P, I, P, I, I, I, P, P, I, P, I, P, I, P],
     "pn2_bn_finalize_affine": [I, P, I, P, I, I, I, P, P, I, C.POINTER(BnDesc), P, P, P, P, P, P, P, P, P, I, I, P, I, P, I, P],
     "pn2_affine_act": [I, P, I, I, P, I, I, I, P, P, P, I, I, P],
@@ -169,6 +175,7 @@ SIGNATURES = {
     "pn2_ra_gate_bwd": [I, P, I, P, P, I, P, I, I, P, I, I, P],
     "pn2_ra_gate_post_bwd": [I, P, I, P, P, I, P, I, P, I, I, P],
     "pn2_conv_gemm_gated": [I, P, P, P, P, P, P, P, P],
+    "pn2_conv_gemm_affine": [I, P, P, P, P, P, P, I, P, P],
     "pn2_loss_weights": [P, P, I, I, I, I, P],
     "pn2_loss_blocks": [I],
     "pn2_structure_loss_fwd": [P, LL, I, P, P, P, P, P, P, I, I, P],

@@ -265,6 +265,42 @@ class PackCache:
         call.pn2_pack_weights_multi(self.dt, _p(self.table), _p(self.bstart), len(self.jobs), self.nblocks, _stream())
 
 
+class BnFoldCache:
+    """Folded eval-mode BatchNorm rows (scale, shift) of a model's layers, persistent across forwards and refreshed from the live gamma / beta / running
+    statistics by ONE table-driven launch per forward (pn2_bn_eval_prepare_multi) - inside a captured inference graph that is one node instead of one per layer."""
+
+    def __init__(self):
+        self.entries = {}          # (id(bn), Cp, gw, gwp) -> [2][Cp] fp32 rows scale, shift
+        self.jobs, self.keep, self.table = [], [], None
+
+    def __reduce__(self):
+        return (BnFoldCache, ())
+
+    def __deepcopy__(self, memo):
+        return BnFoldCache()
+
+    def stale(self):
+        return any(j.gamma != bn.weight.data_ptr() or j.running_mean != bn.running_mean.data_ptr() for j, bn in zip(self.jobs, self.keep))
+
+    def add(self, key, bn, par, bd, off=0):
+        """register `bn` (rows par[0][off:], par[1][off:]); `key` -> par for the lookup (several BatchNorms may share one [2][sum C] block)"""
+        self.entries[key] = par
+        j = capi.BnPrepJob()
+        j.gamma, j.beta, j.running_mean, j.running_var = bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        j.scale, j.shift = par[0][off:].data_ptr(), par[1][off:].data_ptr()
+        C.memmove(C.byref(j.d), C.byref(bd), C.sizeof(capi.BnDesc))
+        self.jobs.append(j)
+        self.keep.append(bn)
+        self.table = None
+
+    def refresh(self):
+        if not self.jobs:
+            return
+        if self.table is None:
+            self.table, self.bstart, self.nblocks = _job_table(capi.BnPrepJob, self.jobs, [(j.d.Cp + 255) // 256 for j in self.jobs])
+        call.pn2_bn_eval_prepare_multi(_p(self.table), _p(self.bstart), len(self.jobs), self.nblocks, _stream())
+
+
 def _job_table(struct, jobs, blocks):
     """-> (device copy of the job array, device prefix sums of the per-job workgroup counts, total workgroups)."""
     if min(blocks) < 1:
@@ -342,6 +378,7 @@ MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which 
 # 15.456 ms, rocprof: finalize 532 -> 322 us, normalise passes 1258 -> 1415 us): the ~5 us of a finalize launch are the dependent read of partial rows that
 # another XCD just wrote plus the merge arithmetic, and the fused pass pays exactly the same chain in front of its rows.  Kept as an opt-in.
 FUSE_FIN = int(os.environ.get("PN2_FUSE_FIN", "0"))
+EVAL_FUSE = True          # eval mode: conv + BatchNorm (+ ReLU) (+ residual) in ONE launch (pn2_conv_gemm_affine); tests switch it off to compare with the two-launch path
 ZERO_CROP_SKIP = os.environ.get("PN2_ZERO_CROP_SKIP", "1") == "1"   # K = 1 DSRA: the crop maps' gradient is identically zero - skip the adjoints of the resamples that made them
 
 
@@ -458,7 +495,9 @@ class GradQueue:
 
 
 class Engine:
-    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None, grad_queue=None, arena=None, lock_cache=None):
+    def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None, grad_queue=None, arena=None, lock_cache=None,
+                 bn_fold=None):
+        self.bn_fold = bn_fold          # BnFoldCache: eval-mode BatchNorm rows kept across forwards (the caller refreshes it once per forward); None = one prepare launch per layer
         self.lock_cache = lock_cache    # dict shared across steps: device job tables of the lock-step regions (Engine.lockstep); None = no lock-step batching
         self.pack_cache = pack_cache
         self.grad_queue = grad_queue
@@ -929,6 +968,22 @@ class Engine:
         canon = LOCKSTEP and LOCKSTEP_TILES and getattr(self, "_in_region", 0) > 0      # canonical tiles for convs of a lock-step region (fwd and dgrad)
         tune = self._tune_gemm(cd, x.ptr, wp, M, Cout_p, canon=canon)
         cd.flags |= tune << 8
+        if (EVAL_FUSE and bn is not None and not self.training and not self.need_grad and gate is None and sum_with is None and y_C is None and not fuse_bias
+                and (y_dt is None or y_dt == self.dt) and self._ksplit(M, KH * KW * x.Cp, Cout_p) == 1 and relu in (False, True, 2)
+                and (residual is None or (residual.dt == self.dt and residual.ld % V == 0 and Cout_p % V == 0 and (out is None or out.ld % V == 0)))):
+            # eval mode (MyTest_med.py:98-104, the in-training evaluation): the folded BatchNorm, the activation and the residual add ride in the GEMM epilogue -
+            # no raw conv output, no separate normalise pass (half the launches and half the activation traffic of the layer)
+            scale, shift = self._bn_eval_rows(bn, M, Cout_p, Cout, gw_o, gwp_o, bias)
+            if out is None:
+                out = Act(self, self.empty(N, OH, OW, Cout_p), Cout, gw_o, gwp_o, self.dt)
+            if residual is not None:
+                assert residual.Cp == Cout_p
+            cd.ld_out = out.ld
+            cd.flags = (tune << 8) | capi.CONV_AFFINE | (capi.CONV_RELU6 if relu == 2 else (capi.CONV_RELU if relu else 0))
+            capi.WORK.update(flops=2 * M * Cout * Cin * KH * KW, tag=":fwd", shape=f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}")
+            call.pn2_conv_gemm_affine(self.dt, x.ptr, _p(wp), out.ptr, _p(scale), _p(shift), residual.ptr if residual is not None else C.c_void_p(0),
+                                      residual.ld if residual is not None else 0, C.byref(cd), st)
+            return out
         tile_rows = 0
         if train_bn:
             nblk = self._stat_blocks(M, Cout_p, tune)
@@ -1249,6 +1304,26 @@ class Engine:
         self.record(bwd)
         return out if y2 is None else (out, y2)
 
+    def _bn_eval_rows(self, bn, M, Cout_p, Cout, gw_o, gwp_o, bias=None):
+        """-> (scale, shift) fp32 [Cout_p] rows of an eval-mode BatchNorm (bias of the conv in front folded into shift).  With a BnFoldCache the rows persist and
+        were refreshed at the start of this forward; a layer seen for the first time is folded here and joins the cache."""
+        bd = capi.BnDesc()
+        bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, Cout_p, Cout, gw_o, gwp_o, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
+        fold = self.bn_fold if bias is None else None
+        key = (id(bn), Cout_p, gw_o, gwp_o)
+        if fold is not None and key in fold.entries:
+            par = fold.entries[key]
+            return par[0], par[1]
+        par = torch.empty((2, Cout_p), dtype=torch.float32, device=self.dev) if fold is not None else self.fbuf(2, Cout_p)
+        call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(par[0]), _p(par[1]), _stream())
+        if bias is not None:
+            par[1][:Cout] += bias.detach() * par[0][:Cout]
+        if fold is not None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("run an eager forward before capturing (the BatchNorm fold table is built then)")
+            fold.add(key, bn, par, bd)
+        return par[0], par[1]
+
     def _tile_m(self, M, Cout, tune):
         bm = (tune >> 2) & 3
         return (64 if bm == 1 else 128) if bm else call.pn2_conv_tile_m(M, Cout, self.dt)
@@ -1353,7 +1428,6 @@ class Engine:
             return wp
 
         wp = panel(False)
-        raw = self.empty(N, H, W, Ct)
         cd = capi.ConvDesc()
         cd.N, cd.H, cd.W, cd.OH, cd.OW = N, H, W, H, W
         cd.Cin_p, cd.ld_in, cd.Cout, cd.ld_out = x.Cp, x.ld, Ct, Ct
@@ -1371,6 +1445,27 @@ class Engine:
         flops = 2 * M * Ct * x.C
         shape = f"{x.C}->{'+'.join(map(str, couts))} k1x1 s1 d1 {N}x{H}x{W}"
         capi.WORK.update(flops=flops, tag=":fwd", shape=shape)
+        if EVAL_FUSE and not train and not self.need_grad:
+            # eval mode: the folded BatchNorms of all the reducers ride in the GEMM epilogue (pn2_conv_gemm_affine) - no raw output, no normalise pass
+            fold = self.bn_fold
+            key = ("multi",) + tuple(id(m.bn) for m in mods)
+            par = fold.entries.get(key) if fold is not None else None
+            if par is None:
+                par = torch.empty((2, Ct), dtype=torch.float32, device=self.dev) if fold is not None else self.fbuf(2, Ct)
+                for m, co, off in zip(mods, couts, offs):
+                    bn = m.bn
+                    bd = capi.BnDesc()
+                    bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, co, co, co, co, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
+                    call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(par[0][off:]), _p(par[1][off:]), st)
+                    if fold is not None:
+                        if torch.cuda.is_current_stream_capturing():
+                            raise RuntimeError("run an eager forward before capturing (the BatchNorm fold table is built then)")
+                        fold.add(key, bn, par, bd, off)
+            out = Act(self, self.empty(N, H, W, Ct), Ct, Ct, Ct, self.dt)
+            cd.flags = (tune << 8) | capi.CONV_AFFINE
+            call.pn2_conv_gemm_affine(self.dt, x.ptr, _p(wp), out.ptr, _p(par[0]), _p(par[1]), C.c_void_p(0), 0, C.byref(cd), st)
+            return [out.slice(off, off + co) for co, off in zip(couts, offs)]
+        raw = self.empty(N, H, W, Ct)
         call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), st)
         scale, shift = self.fbuf(Ct), self.fbuf(Ct)
         mean, invstd = (self.fbuf(Ct), self.fbuf(Ct)) if train else (None, None)

@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from .capi import call, F32
-from .engine import Act, Engine, PackCache, StepArena, TUNER, _p, _stream
+from .engine import Act, BnFoldCache, Engine, PackCache, StepArena, TUNER, _p, _stream
 from .graph import get_compute_dtype
 
 
@@ -19,14 +19,16 @@ class Predictor:
         self.model = model
         self.dtype = get_compute_dtype() if dtype is None else dtype
         self.pack_cache = PackCache()
+        self.bn_fold = BnFoldCache()    # folded BatchNorm rows of every layer: one table-driven launch per forward (inside the graph: the live statistics are used)
         self._states = {}               # input shape -> captured forward (insertion order = LRU order)
         self.max_shapes = 8
 
     def _forward(self, st, x):
         self.pack_cache.refresh()
+        self.bn_fold.refresh()
         if st["arena"] is not None:
             st["arena"].begin_step(x.device)
-        eng = Engine(self.dtype, False, need_grad=False, pack_cache=self.pack_cache, tuner=TUNER, arena=st["arena"])
+        eng = Engine(self.dtype, False, need_grad=False, pack_cache=self.pack_cache, tuner=TUNER, arena=st["arena"], bn_fold=self.bn_fold)
         outs = self.model._build(eng, eng.from_nchw(x))
         eng.finish_forward()
         return eng, outs
@@ -35,8 +37,9 @@ class Predictor:
         """The packed-panel job table and the captured graphs bake raw weight pointers in: if anything re-allocated a parameter since (a Trainer built
         over the same model re-points p.data into its flat arena), start over instead of repacking from freed storage."""
         pc = self.pack_cache
-        if pc.keep and any(j.w != w.data_ptr() for j, w in zip(pc.jobs, pc.keep)):
+        if (pc.keep and any(j.w != w.data_ptr() for j, w in zip(pc.jobs, pc.keep))) or self.bn_fold.stale():
             self.pack_cache = PackCache()
+            self.bn_fold = BnFoldCache()
             self._states = {}
 
     def _state(self, x):

@@ -31,7 +31,11 @@ def _copy_struct(dst, src_byref):
 
 # ---------------------------------------------------------------------------------------------- converters: recorded call -> (kind, job struct) or None
 def _conv_job(a, with_ep):
-    if with_ep:
+    res = None
+    if with_ep == 2:               # pn2_conv_gemm_affine: scale / shift ride in psum / psq, the residual in ep.a.y
+        dt, in_, wp, out, psum, psq, res, ld_res, d, _st = a
+        ep = None
+    elif with_ep:
         dt, in_, wp, out, d, ep, _st = a
         psum = psq = None
     else:
@@ -42,6 +46,9 @@ def _conv_job(a, with_ep):
     _copy_struct(j.d, d)
     if ep is not None:
         _copy_struct(j.ep, ep)
+    if _v(res) is not None:
+        j.ep.a.y, j.ep.a.ld_y = _v(res), ld_res
+    with_ep = 1 if with_ep == 1 else 0
     tile = call.pn2_conv_gemm_tile(dt, C.byref(j.d))
     if tile < 0:
         return None
@@ -120,6 +127,7 @@ def _bnreduce_job(a):
 CONVERT = {
     "pn2_conv_gemm": lambda a: _conv_job(a, False),
     "pn2_conv_gemm_ep": lambda a: _conv_job(a, True),
+    "pn2_conv_gemm_affine": lambda a: _conv_job(a, 2),
     "pn2_bn_finalize": _bnfin_job,
     "pn2_affine_act": lambda a: _affine_job(a, False),
     "pn2_affine_act_sum": lambda a: _affine_job(a, True),

@@ -98,6 +98,58 @@ def test_conv_bn_act_fwd_bwd(dtn, cfg):
         assert err(eng.pgrads.get(bnm.bias), b_.grad) < tol
 
 
+EVAL_CONVS = [  # N, Cin, Cout, k, stride, pad, H, W, relu, residual, out_map
+    (2, 64, 256, 1, 1, 0, 17, 17, True, True, None), (3, 104, 26, 3, 1, 1, 15, 13, True, False, (26, 32)), (2, 32, 64, 3, 2, 1, 19, 21, 2, False, None),
+    (1, 256, 256, 5, 1, 2, 11, 11, False, False, None), (2, 40, 48, 3, 1, 1, 9, 9, 2, True, None), (1, 2048, 832, 1, 1, 0, 11, 11, True, False, None),
+]
+
+
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+@pytest.mark.parametrize("cfg", EVAL_CONVS)
+def test_eval_conv_bn_fused_in_gemm_epilogue(dtn, cfg, monkeypatch):
+    """Eval-mode conv + BatchNorm (+ ReLU / ReLU6) (+ residual) in ONE launch (pn2_conv_gemm_affine, MyTest_med.py:98-104) against the two-launch path
+    (conv -> raw, pn2_affine_act) and against torch float64: fp32 bit-identical to the two launches; bf16 at least as close to float64
+    (one rounding fewer; with a residual: the same two roundings at other places, within 1.25 x).  Covers group-padded outputs (26 channels in 32 slots), partial last tiles, stride 2, a 5x5 and the split between pre- and post-residual
+    activation."""
+    from pn2 import F32, BF16
+    from pn2 import engine as E
+    N, Cin, Cout, k, stride, pad, H, Wd, relu, use_res, omap = cfg
+    dt = F32 if dtn == "fp32" else BF16
+    torch.manual_seed(2)
+    conv = nn.Conv2d(Cin, Cout, k, stride, pad, bias=False).to(dev)
+    bnm = nn.BatchNorm2d(Cout).to(dev).eval()
+    bnm.weight.data.uniform_(0.5, 1.5); bnm.bias.data.normal_(0, 0.3); bnm.running_mean.normal_(0, 0.5); bnm.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(N, Cin, H, Wd, device=dev)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
+    res = torch.randn(N, Cout, OH, OW, device=dev) if use_res else None
+
+    def run(fuse):
+        monkeypatch.setattr(E, "EVAL_FUSE", fuse)
+        eng = E.Engine(dt, False, need_grad=False)
+        a = eng.from_nchw(x)
+        r = eng.from_nchw(res) if use_res else None
+        y = eng.conv_bn_act(a, conv, bnm, relu=relu, residual=r, out_map=omap)
+        torch.cuda.synchronize()
+        return eng.to_nchw(y).clone(), y.t.clone()
+    (y1, t1), (y0, t0) = run(True), run(False)
+    xr = x if dt == F32 else x.bfloat16().float()
+    wr = conv.weight.detach() if dt == F32 else conv.weight.detach().bfloat16().float()
+    ref = F.batch_norm(F.conv2d(xr.double().cpu(), wr.double().cpu(), None, stride, pad), bnm.running_mean.double().cpu(), bnm.running_var.double().cpu(),
+                       bnm.weight.detach().double().cpu(), bnm.bias.detach().double().cpu(), False, 0.1, 1e-5)
+    if use_res:
+        ref = ref + (res if dt == F32 else res.bfloat16().float()).double().cpu()
+    ref = F.relu6(ref) if relu == 2 else (F.relu(ref) if relu else ref)
+    if dt == F32:
+        assert torch.equal(t1, t0)                     # same fma on the same correctly rounded conv result
+        assert relmax(y1, ref) < 3e-5
+    else:
+        # (with a residual the fused form rounds BN(conv) to bf16 before the add - the two-launch form rounds the raw conv output instead: two roundings
+        # either way, the same size of error; without one the fused form saves a rounding)
+        assert rell2(y1, y0) < 6e-3 and rell2(y1, ref) <= rell2(y0, ref) * (1.25 if use_res else 1.02) + 1e-6, (rell2(y1, ref), rell2(y0, ref))
+        if omap is not None:                           # pad slots of a group-padded output stay exact zeros
+            assert float(t1[..., Cout:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtn", ["fp32", "bf16"])
 def test_reverse_attention_gate_in_gemm_epilogue(dtn):
     """V1 reverse attention (PraNet_Res2Net.py:153-155): ra_conv1((1 - sigmoid(crop)).expand(C) * x_l) with a 1x1 ra_conv1 + train-mode BN.  The fused

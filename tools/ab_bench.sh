@@ -4,7 +4,7 @@ out=$1; shift
 mkdir -p $out
 for cfg in "$@"; do
   name=${cfg%%:*}; envs=${cfg#*:}
-  env $envs python bench.py --no-cpu-baseline --no-fp32-line --steps 30 > $out/$name.log 2>&1
+  env $envs python bench.py --no-cpu-baseline --no-fp32-line --no-extras --steps 60 > $out/$name.log 2>&1
   python - "$out/$name.log" "$name" "$envs" <<'PY'
 import json, sys
 line = [l for l in open(sys.argv[1]) if l.startswith('{"metric"')]

@@ -11,9 +11,9 @@ json.dump(keep, open("/tmp/tune_cache.json", "w"))
 print(len(t), "->", len(keep), "entries kept")
 PY
 export PN2_TUNE_TABLE=0 PN2_TUNE_CACHE=/tmp/tune_cache.json PN2_TUNE_REPS=7
-python3 bench.py --no-cpu-baseline --no-fp32-line --steps 5 | tail -1 | cut -c1-200
-python3 bench.py --no-cpu-baseline --no-fp32-line --steps 5 --model pvt --batch 16 | tail -1 | cut -c1-200
-python3 bench.py --no-cpu-baseline --no-fp32-line --steps 5 --model emcad --batch 16 --size 512 | tail -1 | cut -c1-200
+python3 bench.py --no-cpu-baseline --no-fp32-line --no-extras --steps 5 | tail -1 | cut -c1-200
+python3 bench.py --no-cpu-baseline --no-fp32-line --no-extras --steps 5 --model pvt --batch 16 | tail -1 | cut -c1-200
+python3 bench.py --no-cpu-baseline --no-fp32-line --no-extras --steps 5 --model emcad --batch 16 --size 512 | tail -1 | cut -c1-200
 mkdir -p gpurun_out
 cp /tmp/tune_cache.json gpurun_out/tuned_gemm.json
 python3 - <<'PY'
