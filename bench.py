@@ -222,7 +222,9 @@ def dp1_line(dev, x, m, steps=10):
         el = _timed_replay(tr, steps)
         st_ = tr._cur
         res = {"ms_per_step": round(1e3 * el, 3), "images_per_sec": round(x.shape[0] / el, 1), "graph_segments": len(st_.segments) if st_.segments else 1,
-               "buckets": len(tr.buckets.buckets), "allreduce_bytes_per_step": int(tr.n_hot * 4), "backend": "nccl (RCCL), one-rank communicator"}
+               "collectives": "captured in the step graph" if st_.graph_opt is None else "c10d asynchronous, between graph segments",
+               "buckets": len(tr.buckets.buckets), "bucket_mb": [round((e - a) * 4 / 2 ** 20, 1) for a, e, _ in tr.buckets.buckets],
+               "allreduce_bytes_per_step": int(tr.n_hot * 4), "backend": "nccl (RCCL), one-rank communicator"}
         del tr, model
     finally:
         dist.destroy_process_group()
@@ -337,8 +339,9 @@ def main():
             for d_, s_ in zip((tr.flat, tr.exp_avg, tr.exp_avg_sq, tr.bias_corr), keep):
                 d_.copy_(s_)
             del keep
-        dp = {"backend": "nccl (RCCL)", "nccl_ranks": world, "buckets": len(tr.buckets.buckets), "bucket_bytes": 32 << 20, "allreduce_bytes_per_step": int(tr.n_hot * 4),
+        dp = {"backend": "nccl (RCCL)", "nccl_ranks": world, "buckets": len(tr.buckets.buckets), "bucket_mb": [round((e - a) * 4 / 2 ** 20, 1) for a, e, _ in tr.buckets.buckets], "allreduce_bytes_per_step": int(tr.n_hot * 4),
               "graph_segments": len(st_.segments) if st_.segments else 1, "wire_dtype": os.environ.get("PN2_DP_WIRE", "fp32"),
+              "collectives": ("captured in the step graph" if (use_graph and st_.graph_opt is None) else "c10d asynchronous, between graph segments") if use_graph else "eager",
               "mode": "one-rank communicator on one GPU (--dp1)" if args.dp1 and world == 1 else "one process per GPU",
               "exposed_comm_ms": None if t_noex is None else round(1e3 * (t_all - t_noex), 3)}
     names = {"res2net": "PraNet-V2 Res2Net50", "pvt": "PVT-PraNet-V2 (pvt_v2_b2, DropPath 0.1)", "emcad": "EMCADNet dual K=9 (pvt_v2_b2 encoder, EMCAD decoder)"}

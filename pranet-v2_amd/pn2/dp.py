@@ -10,24 +10,35 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, gflat, spans, bucket_bytes=32 << 20, process_group=None, wire_dtype=None):
+    def __init__(self, gflat, spans, bucket_bytes=64 << 20, process_group=None, wire_dtype=None, head_bytes=None):
         """spans: ordered list of (key, offset, length) of the parameters inside `gflat` (elements).
+        Buckets are cut FROM THE TAIL of the arena - the order backward completes gradients in: full buckets of `bucket_bytes`, whose all-reduce overlaps
+        the backward kernels that follow, and the bucket that leaves last (the head of the arena: nothing is left to overlap its all-reduce with) holds at
+        most `head_bytes` (default bucket_bytes / 5).  Every cut costs a flush of the deferred weight-gradient tables (~0.09 ms on an MI355X), every byte of
+        the last bucket is exposed wire time: 64 MB + a 12 MB head gives 3 buckets for PraNet-V2's 122 MB of gradients.
         wire_dtype: None = the buckets travel as they are (fp32, what the reference's DDP does); torch.bfloat16 = each bucket is rounded to bf16
         for the exchange (half the bytes on xGMI) and widened back into the fp32 arena after it - the sum itself is then a bf16 sum, so this is
         a bandwidth / precision trade the caller has to ask for (PN2_DP_WIRE=bf16)."""
         self.gflat, self.pg, self.wire = gflat, process_group, wire_dtype
-        self.buckets = []        # (start, end, frozenset(keys))
-        cur, start, nbytes = [], 0, 0
-        end = 0
-        for key, off, n in spans:
-            cur.append(key)
-            end = off + n
-            nbytes += n * gflat.element_size()
+        es = gflat.element_size()
+        head_bytes = bucket_bytes // 5 if head_bytes is None else head_bytes
+        cuts = []                # bucket boundaries as span indices, from the tail: bucket = spans[i0:i1]
+        i1, nbytes = len(spans), 0
+        for i in range(len(spans) - 1, -1, -1):
+            nbytes += spans[i][2] * es
             if nbytes >= bucket_bytes:
-                self.buckets.append((start, end, frozenset(cur)))
-                cur, start, nbytes = [], end, 0
-        if cur:
-            self.buckets.append((start, end, frozenset(cur)))
+                cuts.append((i, i1)); i1, nbytes = i, 0
+        if i1 > 0:               # what is left at the head of the arena: the last bucket to leave - at most head_bytes, the rest a bucket of its own
+            i0, nb = 0, 0
+            while i0 < i1 and nb + spans[i0][2] * es <= head_bytes:
+                nb += spans[i0][2] * es; i0 += 1
+            if 0 < i0 < i1:
+                cuts.append((i0, i1)); i1 = i0
+            cuts.append((0, i1))
+        self.buckets = []        # (start, end, frozenset(keys)), in arena order
+        for i0, i1 in reversed(cuts):
+            self.buckets.append((spans[i0][1], spans[i1 - 1][1] + spans[i1 - 1][2], frozenset(k for k, _, _ in spans[i0:i1])))
+        end = spans[-1][1] + spans[-1][2] if spans else 0
         self.total = end
         self.record = None       # a list while a step is being CAPTURED: launches are noted (bucket indices), not issued (Trainer.capture)
         self.reset()

@@ -29,10 +29,15 @@ WGRAD_SEG = int(os.environ.get("PN2_WGRAD_SEG", "24"))              # convs per 
 # "thread_local": other threads of the process (RCCL's watchdog polls events while a rank captures) do not invalidate the capture
 CAPTURE_MODE = os.environ.get("PN2_CAPTURE_MODE", "thread_local")
 DP_SEGMENTS = os.environ.get("PN2_DP_SEGMENTS", "1") == "1"          # data-parallel replay: one hipGraph per gradient-bucket boundary, all-reduce overlapped (0: one graph, reduce after it)
+# data-parallel replay on RCCL: the bucket all-reduces are captured INTO the step's hipGraph (forked onto RCCL's stream by the events c10d records, joined before
+# the optimizer) - a replay is ONE hipGraphLaunch.  Measured on a one-rank communicator (tools/dp_probe.py): 14.85 ms local, 15.31 ms with c10d's asynchronous
+# collectives between graph segments (the cross-stream event traffic costs 0.37 ms per step plus ~0.09 ms per cut), back to local speed when captured.  A backend
+# that cannot be captured (gloo) or a failing capture falls back to the chain of graph segments.
+DP_CAPTURE = os.environ.get("PN2_DP_CAPTURE", "1") == "1"
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8, dtype=None, process_group=None, bucket_bytes=32 << 20,
+    def __init__(self, model, lr=1e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8, dtype=None, process_group=None, bucket_bytes=64 << 20,
                  loss="structure", loss_weights=(0.5, 0.7, 0.3), weight_decay=0.0, hot=None, force_dp=False):
         """loss: "structure" - the 4-pair structure loss of MyTrain_med.py:78-82 on (images, masks), Adam + clip_gradient (binary_seg);
                  "mutation"  - the 15-subset CE + Dice + BCE loss of EMCAD/trainer.py:106-140 on (images, (label, bg_mask)) with the 8 maps of a
@@ -74,6 +79,7 @@ class Trainer:
             o += _r4(n)
         self.hot = hot
         # gradient buckets in arena order (backward completes them from the tail)
+        bucket_bytes = int(os.environ.get("PN2_DP_BUCKET_MB", "0")) << 20 or bucket_bytes
         self.buckets = GradBuckets(self.gflat, [(id(p), self.off[id(p)][0], _r4(self.off[id(p)][1])) for p in hot], bucket_bytes, process_group,
                                    wire_dtype=torch.bfloat16 if os.environ.get("PN2_DP_WIRE", "fp32") == "bf16" else None)
         self._seg = None                # capture of a data-parallel step in progress (see _capture_segments)
@@ -331,7 +337,10 @@ class Trainer:
                 with torch.cuda.graph(st.graph, capture_error_mode=CAPTURE_MODE):
                     st.s_loss = self.step(st.s_images, st.s_gts, size=size)
                 st.graph_opt = None
+            elif self._capture_with_collectives(st, size):
+                st.graph_opt, st.segments = None, None
             else:
+                st.graph = torch.cuda.CUDAGraph()
                 if DP_SEGMENTS and self._expected is not None:
                     st.segments = self._capture_segments(st, size)
                     st.graph = st.segments[0][0]
@@ -346,6 +355,27 @@ class Trainer:
             if gc_was:
                 gc.enable()
         return self
+
+    def _capture_with_collectives(self, st, size):
+        """The whole data-parallel step - forward, loss, backward with the bucket all-reduces launched where the eager step launches them, the wait for them,
+        the optimizer - as ONE hipGraph.  c10d runs a collective on its own stream behind an event of the capturing stream and joins it back in Work.wait():
+        inside a capture those become a forked branch of the graph, so the all-reduce of a bucket overlaps the backward kernels that follow it exactly as in
+        the eager step, without any host-side stream traffic at replay.  Returns False (nothing captured) when the backend cannot be captured."""
+        import torch.distributed as dist
+        if not DP_CAPTURE or self._expected is None or dist.get_backend(self.pg) != "nccl":
+            return False
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                st.s_loss = self.step(st.s_images, st.s_gts, size=size)
+        except Exception as e:          # noqa: BLE001   (the context manager has ended the capture; fall back to graph segments)
+            import warnings
+            warnings.warn(f"capturing the RCCL collectives into the step graph failed ({type(e).__name__}: {e}); falling back to graph segments")
+            self.buckets.works = []
+            torch.cuda.synchronize()
+            return False
+        st.graph = g
+        return True
 
     def _cut_segment(self):
         """Capture of a data-parallel step: one or more gradient buckets just became complete - close the hipGraph segment that produced them

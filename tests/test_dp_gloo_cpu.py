@@ -110,3 +110,21 @@ def test_bucketed_allreduce_two_ranks():
         assert ok_sum and ok_mean and ok_rest, (rank, ok_sum, ok_mean, ok_rest)
         assert order == sorted(order, reverse=True), f"buckets must launch tail-first, got {order}"
     assert res[0][1] == res[1][1], "ranks must launch collectives in the same order"
+
+
+def test_buckets_are_cut_from_the_tail_with_a_small_head_bucket():
+    """Bucket layout (no communication): full buckets from the tail of the arena (what backward completes first), the head of the arena - the bucket that
+    leaves last, with nothing left to overlap its all-reduce - at most head_bytes; every element in exactly one bucket, in arena order."""
+    sys.path.insert(0, os.path.join(ROOT, "pranet-v2_amd"))
+    from pn2.dp import GradBuckets
+    sizes = [300, 700, 1000, 2000, 4000, 1000, 3000, 2500, 500]
+    spans, off = [], 0
+    for i, n in enumerate(sizes):
+        spans.append((i, off, n)); off += n
+    bk = GradBuckets(torch.zeros(off), spans, bucket_bytes=4 * 5000, head_bytes=4 * 1200)
+    b = bk.buckets
+    assert b[0][0] == 0 and b[-1][1] == off and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+    assert [sorted(k[2]) for k in b] == [[0, 1], [2, 3], [4, 5], [6, 7, 8]], [sorted(k[2]) for k in b]      # tail: 6000 >= 5000; 5000; rest 4000 -> head 1000 <= 1200 + 3000
+    assert (b[0][1] - b[0][0]) * 4 <= 4 * 1200
+    one = GradBuckets(torch.zeros(off), spans, bucket_bytes=4 * 100000)                                     # everything below one bucket: head + rest
+    assert [len(k[2]) for k in one.buckets] == [len(sizes)] or sum(len(k[2]) for k in one.buckets) == len(sizes)

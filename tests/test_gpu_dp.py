@@ -150,15 +150,16 @@ def test_two_ranks_match_single_process_with_averaged_gradients(kind, autotune):
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # RCCL itself (torch.distributed backend "nccl" IS RCCL on ROCm).  Two ranks cannot share one GPU under RCCL ("duplicate GPU"), so the real
 # backend is exercised with a ONE-rank communicator and Trainer(force_dp=True): eager bucket hooks issuing ncclAllReduce on RCCL's stream next to
-# the backward kernels, _capture_segments under the thread-local capture mode with RCCL's watchdog thread alive, segment replay with
-# launch_async between hipGraph segments, PN2_DP_WIRE=bf16 (temporary bf16 buffers), two trainers in one process.  A 1-rank sum is the
+# the backward kernels, the collectives captured into the step's hipGraph (and, as the fallback, _capture_segments + launch_async between hipGraph
+# segments) under the thread-local capture mode with RCCL's watchdog thread alive, PN2_DP_WIRE=bf16 (temporary bf16 buffers), two trainers in one process.  A 1-rank sum is the
 # identity, so the result must be BIT-IDENTICAL to the trainer without a process group - any ordering bug between RCCL's stream and the compute
 # stream (a bucket sent before its gradients are complete, an optimizer replay that does not wait for the collective) shows as a difference.
-def _rccl_worker(port, q, wire):
+def _rccl_worker(port, q, wire, captured=True):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ["PN2_DP_WIRE"] = wire
+        os.environ["PN2_DP_CAPTURE"] = "1" if captured else "0"      # (read when pn2.trainer is imported, below)
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         from pn2.trainer import Trainer
@@ -172,8 +173,12 @@ def _rccl_worker(port, q, wire):
         tr.capture(x, m, warmup=2)
         tr.replay(); loss = tr.replay()
         torch.cuda.synchronize()
-        segs = [bs for _, bs in tr._cur.segments]
-        assert len(segs) >= 3 and [b for bs in segs for b in bs] == order, (segs, order)
+        if captured:        # ONE graph holds the step, its collectives (issued in the eager order) and the optimizer
+            assert tr._cur.segments is None and tr._cur.graph_opt is None and list(tr.buckets.order) == order, (tr.buckets.order, order)
+            segs = [order]
+        else:
+            segs = [bs for _, bs in tr._cur.segments]
+            assert len(segs) >= 3 and [b for bs in segs for b in bs] == order, (segs, order)
         dp_flat = tr.flat.clone(); dp_loss = loss.clone()
         # the same six steps without a process group
         model2, _ = _setup("res2net", False)
@@ -204,14 +209,17 @@ def _rccl_worker(port, q, wire):
         q.put(("ERROR", traceback.format_exc()))
 
 
+@pytest.mark.parametrize("captured", [True, False])
 @pytest.mark.parametrize("wire", ["fp32", "bf16"])
-def test_rccl_one_rank_dp_path_is_bit_identical_to_local(wire):
+def test_rccl_one_rank_dp_path_is_bit_identical_to_local(wire, captured):
+    """captured: the bucket all-reduces are captured INTO the step's hipGraph (the default on RCCL); else: c10d asynchronous collectives between a chain
+    of graph segments (the fallback, PN2_DP_CAPTURE=0)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31600 + (os.getpid() + (3 if wire == "bf16" else 0)) % 2000
-    p = ctx.Process(target=_rccl_worker, args=(port, q, wire))
+    port = 31600 + (os.getpid() + (3 if wire == "bf16" else 0) + (7 if captured else 0)) % 2000
+    p = ctx.Process(target=_rccl_worker, args=(port, q, wire, captured))
     p.start()
     res = q.get(timeout=900)
     p.join(60)

@@ -10,3 +10,4 @@ tail -1 /tmp/pb.log | cut -c1-260
 DB=$(find /tmp/prof_bench -name "*.db" | head -1)
 python3 $GRAFT_REPO_ROOT/tools/rocpd_stats.py $DB $GRAFT_REPO_ROOT/gpurun_out/$out
 python3 $GRAFT_REPO_ROOT/tools/rocpd_timeline.py $DB $GRAFT_REPO_ROOT/gpurun_out/${out%.csv}_timeline.csv
+python3 $GRAFT_REPO_ROOT/tools/rocpd_stepgaps.py $DB
