@@ -53,7 +53,7 @@ typedef struct pn2_wgrad_desc {
     int Cout_p, ld_dy;      /* dy physical channels / stride */
     int KH, KW, stride, pad_h, pad_w, dil_h, dil_w;
     int Rp, Kp;             /* slab rows (multiple of the co tile, normally 128) and row length (multiple of 128) */
-    int tune;               /* 0 heuristic, 1 register-staged kernel, 2 LDS-DMA kernel (bf16) */
+    int tune;               /* 0 heuristic, 1 register-staged kernel, 2 LDS-DMA kernel (bf16), 3 LDS-DMA kernel with 128 x 256 tiles (bf16; co tile 128 and Kp >= 256, else as 2) */
 } pn2_wgrad_desc;
 
 typedef struct pn2_pack_desc {
@@ -119,7 +119,7 @@ int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const
  * The general (not pointwise-specialised) kernels serve every job; split-K jobs cannot join.  Bit-identical to the single launches.
  * `ep`: bit 0 = the jobs carry a pn2_conv_ep; for bf16 its operand tiles are staged in LDS and the launch is sized for what the jobs need -
  * bit 1: a.mode has PN2_BNB_STATS, bit 2: ... and PN2_BNB_MASK_Y, bit 3: PN2_CONV_ACCUM, bit 4: b.out with PN2_BNB_STATS (OR over the jobs; no
- * bits = all four, which does not fit 160 KB for a 128 x 128 tile: returns -4). */
+ * bits = all four).  Only tiles of at most 4096 elements stage operand tiles (the 3x3 dgrads); wider tiles keep their operands in registers.  -4: LDS exceeded. */
 typedef struct pn2_conv_job { const void* in; const void* wp; void* out; float* psum; float* psq; pn2_conv_desc d; int pad_; pn2_conv_ep ep; } pn2_conv_job;
 int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d);
 int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn);
@@ -189,14 +189,6 @@ int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int 
  * written by the pass that produces sp.  16-byte aligned rows only (-2 otherwise). */
 int pn2_affine_act_sum(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* scale, const float* shift, int relu,
                        const void* add, int ld_add, void* y2, int ld_y2, void* stream);
-/* pn2_bn_finalize + pn2_affine_act (+ the second output of pn2_affine_act_sum when add / y2 are given) in ONE launch: the train-mode forward of
- * nn.BatchNorm2d + ReLU (+ residual) behind a conv (Res2Net_v1b.py:60-63,70-72,84-89 ; pranet.py:40-43) for layers whose statistics arrive as few
- * partial rows.  A workgroup owns 64 channels x a row block, merges only its channels' partial rows and then normalises its rows; the
- * (scale, shift, mean, invstd) rows and the running statistics are written exactly as pn2_bn_finalize writes them.  Same dtype in / out, 16-byte
- * aligned rows, per-tile (mean, M2) partials (d->tile_rows > 0): -2 otherwise. */
-int pn2_bn_finalize_affine(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* psum, const float* psq, int nblk, const pn2_bn_desc* d,
-                           const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd,
-                           const void* res, int ld_res, int relu, const void* add, int ld_add, void* y2, int ld_y2, void* stream);
 /* backward pass 1: per-channel partials of sum(dz) and sum(dz*xhat), dz = dy*(relu mask) ; dy has Cdy valid channels.
  * ReLU mask: y>0 when y is given; else recomputed as fmaf(x,mask_scale,mask_shift)>0 when mask_scale is given (saves reading y). */
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,

@@ -67,8 +67,6 @@ __device__ __forceinline__ void block_reduce_rows(double (*sh)[4][8], int CPB, d
     }
 }
 inline int finalize_cpb(int nblk) {
-    static const int forced = getenv("PN2_BN_FIN_CPB") ? atoi(getenv("PN2_BN_FIN_CPB")) : 0;   // experiment knob (8 = the fixed geometry)
-    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     int cpb = 8;
     while (cpb > 1 && nblk / (256 / cpb) > 8) cpb >>= 1;
     return cpb;
@@ -468,159 +466,6 @@ __global__ __launch_bounds__(256) void affine_rows_tab(const pn2_affine_job* __r
                         (const T*)j.add, j.ld_add, (T*)j.y2, j.ld_y2, blockIdx.x - bstart[jb]);
 }
 
-// ---------------------------------------------------------------------------------------------
-// BatchNorm statistics finalisation FUSED into the normalise + activation pass (pn2_bn_finalize_affine).
-// A separate pn2_bn_finalize launch costs ~5 us for ~1 us of work (kernel boundary + two dependent memory round trips on rows other XCDs just
-// wrote), 84 times per step.  Folding it into the consumer pass with the pass's usual decomposition (a workgroup = a row block x ALL channels)
-// makes every workgroup re-merge every channel's partial rows (tried in round 1: slower).  Here the pass is decomposed the other way: a workgroup
-// owns a GROUP of FCG = 64 channels (one 128-byte line of bf16 per pixel row) x a row block, so it merges only the nblk x 64 partial values of ITS
-// channels (31 KB for a 15 488-row layer, read from L2) - once per row block of the group, not once per workgroup of the whole pass - and then
-// walks its rows.  Used for layers whose partial buffers are short (nblk <= 256: everything from layer3 down); tall ones keep the separate
-// launch.  The merge is the Chan formula of bn_finalize_body with a fixed order (16 row lanes, then a pairwise tree), in double.
-// ---------------------------------------------------------------------------------------------
-constexpr int FCG = 64;
-constexpr int FIN_AFFINE_WGS = 512;
-template <typename T>
-__global__ __launch_bounds__(256) void bn_fin_affine_k(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int M, int C,
-                                                       const float* __restrict__ psum, const float* __restrict__ psq, int nblk, pn2_bn_desc d,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
-                                                       float* scale, float* shift, float* mean_o, float* invstd_o,
-                                                       const T* __restrict__ res, int ld_res, int relu, int rows_per_blk, int ngroups,
-                                                       const T* __restrict__ add, int ld_add, T* __restrict__ y2, int ld_y2) {
-    constexpr int V = TT<T>::VEC;
-    __shared__ double shd[2][16][FCG];
-    __shared__ __attribute__((aligned(16))) float par[2][FCG];
-    const int cg = blockIdx.x % ngroups, rb = blockIdx.x / ngroups;
-    const int c0 = cg * FCG;
-    // geometry of the normalise pass; its first batch of rows is requested BEFORE the statistics are merged, so that the two memory round trips of
-    // this kernel (partial rows, activation rows) overlap instead of following each other
-    constexpr int CVP = FCG / V, R = 256 / CVP;
-    const int CV = C / V;
-    const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
-    const int cv = cg * CVP + cvl;
-    const bool act = cv < CV;
-    const int c = cv * V;
-    const int r0 = rb * rows_per_blk;
-    int r1 = r0 + rows_per_blk; if (r1 > M) r1 = M;
-    uint4 vx[RU], vr[RU], va[RU];
-#define PN2_FA_LOAD(m_)                                                                                                \
-    do {                                                                                                               \
-        _Pragma("unroll") for (int u = 0; u < RU; ++u) {                                                               \
-            const int mm_ = (m_) + u * R;                                                                              \
-            if (mm_ < r1) {                                                                                            \
-                vx[u] = *reinterpret_cast<const uint4*>(x + (size_t)mm_ * ld_x + c);                                   \
-                if (res) vr[u] = *reinterpret_cast<const uint4*>(res + (size_t)mm_ * ld_res + c);                      \
-                if (y2) va[u] = *reinterpret_cast<const uint4*>(add + (size_t)mm_ * ld_add + c);                       \
-            }                                                                                                          \
-        }                                                                                                              \
-    } while (0)
-    if (act) { PN2_FA_LOAD(r0 + rl); }
-    // ---- phase 1: (mean, var) of this group's channels from the conv epilogue's per-tile (mean, M2) rows
-    {
-        const int q = threadIdx.x & 15, rl = threadIdx.x >> 4, cq = c0 + q * 4;
-        const int ldp = d.ldp ? d.ldp : d.Cp;
-        // the channel parameters are requested before the partial rows are walked (see bn_finalize_body)
-        const int cfin = c0 + (int)threadIdx.x;
-        const int lc0 = (threadIdx.x < FCG && cfin < d.Cp) ? phys2log(cfin, d.gw, d.gwp, d.C) : -1;
-        float pg = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
-        if (lc0 >= 0) { pg = gamma[lc0]; pb = beta[lc0]; if (running_mean && rb == 0) { prm = running_mean[lc0]; prv = running_var[lc0]; } }
-        double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-        if (cq < d.Cp) {
-            const float4 k0 = *reinterpret_cast<const float4*>(psum + cq);
-            const float kk[4] = {k0.x, k0.y, k0.z, k0.w};
-            for (int r = rl; r < nblk; r += 16 * 8) {          // 16 loads in flight per thread: the walk is latency, not arithmetic
-                float4 pm[8], pq[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int rr = min(r + u * 16, nblk - 1);
-                    pm[u] = *reinterpret_cast<const float4*>(psum + (size_t)rr * ldp + cq);
-                    pq[u] = *reinterpret_cast<const float4*>(psq + (size_t)rr * ldp + cq);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (r + u * 16 < nblk) {
-                        const int nt = min(d.tile_rows, d.M - (r + u * 16) * d.tile_rows);
-                        const float m4[4] = {pm[u].x, pm[u].y, pm[u].z, pm[u].w}, q4[4] = {pq[u].x, pq[u].y, pq[u].z, pq[u].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const double dm = (double)m4[e] - (double)kk[e];
-                            s1[e] += nt * dm; s2[e] += (double)q4[e] + nt * dm * dm;
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { shd[0][rl][q * 4 + e] = s1[e]; shd[1][rl][q * 4 + e] = s2[e]; }
-        __syncthreads();
-        if (threadIdx.x < FCG) {
-            const int cl = threadIdx.x, c = c0 + cl;
-            float sc = 0.f, sf = 0.f;
-            if (c < d.Cp) {
-                double t1[16], t2[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { t1[i] = shd[0][i][cl]; t2[i] = shd[1][i][cl]; }
-#pragma unroll
-                for (int w = 1; w < 16; w <<= 1)
-#pragma unroll
-                    for (int i = 0; i < 16; i += 2 * w) { t1[i] += t1[i + w]; t2[i] += t2[i + w]; }
-                const int lc = lc0;
-                float mo = 0.f, io = 0.f;
-                if (lc >= 0) {
-                    const double k0d = (double)psum[c];
-                    double mean = k0d + t1[0] / d.M, var = (t2[0] - t1[0] * t1[0] / d.M) / d.M;
-                    if (var < 0.0) var = 0.0;
-                    const float invstd = (float)(1.0 / sqrt(var + (double)d.eps));
-                    sc = pg * invstd; sf = pb - (float)mean * sc;
-                    mo = (float)mean; io = invstd;
-                    if (running_mean && rb == 0) {
-                        const double unb = d.M > 1 ? var * ((double)d.M / (double)(d.M - 1)) : var;
-                        running_mean[lc] = (1.f - d.momentum) * prm + d.momentum * (float)mean;
-                        running_var[lc] = (1.f - d.momentum) * prv + d.momentum * (float)unb;
-                    }
-                }
-                if (rb == 0) { scale[c] = sc; shift[c] = sf; mean_o[c] = mo; invstd_o[c] = io; }     // the backward reads these rows
-            }
-            par[0][cl] = sc; par[1][cl] = sf;
-        }
-        __syncthreads();
-    }
-    // ---- phase 2: y = act(x * scale + shift + res) over this workgroup's rows of the group (affine_rows_body restricted to one channel group)
-    if (!act) return;
-    float sc[V], sh[V];
-    ldpar<V>(&par[0][cvl * V], sc);
-    ldpar<V>(&par[1][cvl * V], sh);
-    for (int m = r0 + rl; m < r1; m += R * RU) {
-        if (m != r0 + rl) { PN2_FA_LOAD(m); }          // (the first batch was requested before the statistics were merged)
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const int mm = m + u * R;
-            if (mm < r1) {
-                float v[V], r[V];
-                TT<T>::unpack(vx[u], v);
-                if (res) TT<T>::unpack(vr[u], r);
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    float t = fmaf(v[e], sc[e], sh[e]);
-                    if (res) t += r[e];
-                    v[e] = relu ? (relu == 2 ? fminf(fmaxf(t, 0.f), 6.f) : fmaxf(t, 0.f)) : t;
-                }
-                const uint4 pk = TT<T>::pack(v);
-                *reinterpret_cast<uint4*>(y + (size_t)mm * ld_y + c) = pk;
-                if (y2) {                     // sum of the STORED (rounded) y and the other operand (see affine_rows_body)
-                    float a[V];
-                    TT<T>::unpack(pk, v);
-                    TT<T>::unpack(va[u], a);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) v[e] += a[e];
-                    *reinterpret_cast<uint4*>(y2 + (size_t)mm * ld_y2 + c) = TT<T>::pack(v);
-                }
-            }
-        }
-    }
-#undef PN2_FA_LOAD
-}
-
 // LEAN: the common form inside a training step - ReLU mask recomputed from the raw conv output (or none), no stored y, no residual gradient: the
 // y / dres staging registers disappear (183 -> ~100 VGPRs, twice the resident waves of a kernel that lives on memory-level parallelism)
 template <typename T, bool LEAN>
@@ -707,7 +552,7 @@ inline void rows_geometry(int M, int CV, int& cvp, int& rows_per_blk, int& nblk)
     const int R = 256 / cvp;
     // aim at ~1024 workgroups (4 per CU).  With scalar parameter loads every block paid a ~60-instruction prologue and 512 was the optimum; with the
     // 16-byte parameter loads the step time is flat from 768 up (15.59 / 15.57 / 15.51 / 15.51 / 15.49 ms at 384 / 512 / 768 / 1024 / 2048)
-    static const int target = getenv("PN2_BN_BLOCKS") ? atoi(getenv("PN2_BN_BLOCKS")) : 1024;   // experiment knob
+    constexpr int target = 1024;         // workgroups of a streaming pass (swept 256 .. 2048: flat up to 512 per pass kind)
     int want = (M + target - 1) / target;
     rows_per_blk = ((want + R - 1) / R) * R;
     if (rows_per_blk < R) rows_per_blk = R;
@@ -821,7 +666,7 @@ int pn2_bn_bwd_blocks(int M, int Cp, int dt) {
     int cvp = 1; while (cvp < cv && cvp < 256) cvp <<= 1;
     const int rows = (256 / cvp) * 2;     // >= 2 rows per thread, at most 512 partial rows for the finalize pass (measured optimum)
     int b = (M + rows - 1) / rows;
-    static const int cap = getenv("PN2_BN_RBLOCKS") ? atoi(getenv("PN2_BN_RBLOCKS")) : 512;   // experiment knob
+    constexpr int cap = 512;
     return b > cap ? cap : (b < 1 ? 1 : b);
 }
 
@@ -890,36 +735,6 @@ int pn2_affine_act_sum(int dt, const void* x, int ld_x, void* y, int ld_y, int M
                                            (const bf16_t*)add, ld_add, (bf16_t*)y2, ld_y2);
     else if (dt == PN2_F32) hipLaunchKernelGGL((affine_rows_k<float>), dim3(nblk), dim3(256), 0, st, (const float*)x, ld_x, (float*)y, ld_y, M, C, scale, shift, (const float*)nullptr, 0, relu, rpb, cvp,
                                                (const float*)add, ld_add, (float*)y2, ld_y2);
-    else return -3;
-    PN2_CHECK_LAUNCH();
-    return 0;
-}
-
-
-/* pn2_bn_finalize + pn2_affine_act (or pn2_affine_act_sum when add / y2 are given) in ONE launch, for layers whose statistics arrive as few partial
- * rows (see bn_fin_affine_k): the (scale, shift, mean, invstd) rows and the running statistics are written as pn2_bn_finalize writes them.
- * Same dtype in / out, 16-byte aligned rows, per-tile (mean, M2) partials (d->tile_rows > 0) only: -2 otherwise. */
-int pn2_bn_finalize_affine(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* psum, const float* psq, int nblk, const pn2_bn_desc* d,
-                           const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd,
-                           const void* res, int ld_res, int relu, const void* add, int ld_add, void* y2, int ld_y2, void* stream) {
-    if (!x || !y || !psum || !psq || !d || !gamma || !beta || !scale || !shift || !mean || !invstd || ((add != nullptr) != (y2 != nullptr))) return -1;
-    const int V = dt == PN2_F32 ? 4 : 8;
-    const int ldp = d->ldp ? d->ldp : d->Cp;
-    if (d->tile_rows <= 0 || nblk < 1 || C % V || C > d->Cp || d->Cp % 4 || ldp % 4 || ld_x % V || ld_y % V || (res && ld_res % V) || (add && (ld_add % V || ld_y2 % V))) return -2;
-    if (((size_t)psum | (size_t)psq) & 15) return -2;
-    const int ngroups = (d->Cp + FCG - 1) / FCG;
-    const int R = 256 / (FCG / V);
-    int want = (FIN_AFFINE_WGS + ngroups - 1) / ngroups;  // ~512 workgroups in all: every row block of a group re-merges the group's partial rows
-    int rpb = (M + want - 1) / want;
-    rpb = ((rpb + R - 1) / R) * R;
-    if (rpb < R) rpb = R;
-    if (rpb > R * RU * 4) rpb = R * RU * 4;
-    const int nrb = (M + rpb - 1) / rpb;
-    hipStream_t st = (hipStream_t)stream;
-    if (dt == PN2_BF16) hipLaunchKernelGGL((bn_fin_affine_k<bf16_t>), dim3(ngroups * nrb), dim3(256), 0, st, (const bf16_t*)x, ld_x, (bf16_t*)y, ld_y, M, C, psum, psq, nblk, *d, gamma, beta,
-                                           running_mean, running_var, scale, shift, mean, invstd, (const bf16_t*)res, ld_res, relu, rpb, ngroups, (const bf16_t*)add, ld_add, (bf16_t*)y2, ld_y2);
-    else if (dt == PN2_F32) hipLaunchKernelGGL((bn_fin_affine_k<float>), dim3(ngroups * nrb), dim3(256), 0, st, (const float*)x, ld_x, (float*)y, ld_y, M, C, psum, psq, nblk, *d, gamma, beta,
-                                               running_mean, running_var, scale, shift, mean, invstd, (const float*)res, ld_res, relu, rpb, ngroups, (const float*)add, ld_add, (float*)y2, ld_y2);
     else return -3;
     PN2_CHECK_LAUNCH();
     return 0;

@@ -301,7 +301,7 @@ __device__ __forceinline__ void ep2_dma_tile(char* region, const bf16_t* base, i
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p0 = wid * 64 + lane, row0 = p0 / CPR, ch = p0 - row0 * CPR;
     int col = n0 + ch * 8;
-    if (col >= Cout) col = n0;
+    if (col >= Cout || (split > 0 && col >= split && !base2)) col = n0;      // columns >= split without a second tensor (no BatchNorm behind them) read the tile's first chunk: `raw` need not be that wide
     const size_t extent = (size_t)M * (size_t)ld * 2;
     if (split <= 0 && extent < 0x7fffffffull) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -568,9 +568,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
     float* red = reinterpret_cast<float*>(smem + BM * CRS);   // [3][WM][BN]: shifted sum, shifted sum of squares, shift
     constexpr bool EP2 = EP && sizeof(T) == 2 && ep2_tile(BM, BN);          // bf16, narrow tiles: operand tiles by LDS-DMA, sums on the matrix cores (ep2_*)
     if constexpr (EP2) ep2_issue<BM, BN>(smem, d, ep, reinterpret_cast<const bf16_t*>(out), M, m0, n0);
-#ifndef PN2_EP_PREFETCH_EARLY
     if constexpr (EP && !EP2) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);      // in flight while the C tile is staged
-#endif
     const bool full_m = m0 + BM <= M;
     if constexpr (SWP) {
         static_assert(sizeof(T) == 2, "swapped epilogue: bf16 only");
@@ -973,9 +971,6 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
     } while (0)
 
     BnbPre<T, BM, BN> pre;
-#ifdef PN2_EP_PREFETCH_EARLY
-    if constexpr (EP) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);
-#endif
     typename MMA<T>::acc_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -1140,12 +1135,7 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     // wave-uniform LDS row offset of this wave inside a 32-row DMA group
     const int wrow = __builtin_amdgcn_readfirstlane(wid * 8);
 
-// Cache policy of the activation operand's DMA (aux): 0 = default.  Non-temporal (aux = 2) wins 14-24 % on COLD operands (tools/loop_ab.py: 256->104 x
-// 247808 rows 60.4 -> 46.2 us, 512->208 x 61952 39.9 -> 31.5) but loses inside the step (17.87 -> 18.05 ms): there the operand was written by the
-// previous kernel and is still resident in L2 / MALL, which the non-temporal path does not use.  Kept as a build knob (-DPN2_A_AUX=2).
-#ifndef PN2_A_AUX
-#define PN2_A_AUX 0
-#endif
+// (a non-temporal policy on the activation operand's DMA wins 14-24 % on cold operands and loses inside the step, where the operand still sits in L2 / MALL: DESIGN 6)
 #define PN2_ISSUE(step_, buf_)                                                                                         \
     do {                                                                                                               \
         char* sb_ = smem + (buf_) * STAGE;                                                                             \
@@ -1154,7 +1144,7 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
             const bool kok_ = k_ < d.Cin_p;                                                                            \
             _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
                 const unsigned vo_ = (rok[i] && kok_) ? rowoff[i] + (unsigned)k_ * 2u : INV;                           \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, (int)vo_, 0, 0, PN2_A_AUX); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, (int)vo_, 0, 0, 0); \
             }                                                                                                          \
         } else {                                                                                                       \
             const bool tok_ = tap < taps;                                                                              \
@@ -1163,7 +1153,7 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
                 const int iy_ = ty_ >> tsh, ix_ = tx_ >> tsh;                                                          \
                 const bool ok_ = rok[i] & tok_ & ((unsigned)iy_ < (unsigned)d.H) & ((unsigned)ix_ < (unsigned)d.W) & (((ty_ | tx_) & tmsk) == 0); \
                 const unsigned vo_ = ok_ ? (rowoff[i] + (unsigned)(iy_ * d.W + ix_)) * (unsigned)ldb + (unsigned)ci * 2u : INV; \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, (int)vo_, 0, 0, PN2_A_AUX); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(sb_ + (i * 32 + wrow) * ROW), 16, (int)vo_, 0, 0, 0); \
             }                                                                                                          \
             ci += BK;                                                                                                  \
             while (ci >= d.Cin_p) {                                                                                    \
@@ -1177,9 +1167,6 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     } while (0)
 
     BnbPre<T, BM, BN> pre;
-#ifdef PN2_EP_PREFETCH_EARLY
-    if constexpr (EP) bnb_prefetch<T, BM, BN>(d, ep, out, M, m0, n0, pre);
-#endif
     f32x4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -1272,11 +1259,8 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
 #endif
 }
 
-#ifndef PN2_EP_WAVES
-#define PN2_EP_WAVES 1
-#endif
 template <int BM, int BN, int WM, int WN, bool PW, int NS = 3, bool EP = false>
-__global__ __launch_bounds__(256, ((EP && BM * BN <= 8192) ? PN2_EP_WAVES : 1)) void conv_dma_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
                                                      float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
     conv_dma_body<BM, BN, WM, WN, PW, NS, EP>(in, wp, out, psum, psq, d, ep, blockIdx.x, gridDim.x, blockIdx.y);
 }
@@ -1641,9 +1625,7 @@ template <typename T, int BMC, int BNK, int WM, int WN, bool PW>
 __global__ __launch_bounds__(256) void conv_wgrad(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ slab, pn2_wgrad_desc d, int nsplit) {
     conv_wgrad_body<T, BMC, BNK, WM, WN, PW>(dy, x, slab, d, nsplit, blockIdx.x);
 }
-// Table launches walk the job table with a grid stride: with gridDim.x == total blocks every workgroup runs one (job, block) pair as before; a
-// NARROWER grid (wgrad_grid(): a multiple of 8, so that b % 8 stays the XCD the workgroup runs on) makes the launch persistent - it then occupies
-// a bounded share of every CU and can run on a side stream next to the latency-bound backward chain without starving it (Trainer WGRAD_OVERLAP).
+// Table launches walk the job table with a grid stride (gridDim.x == total blocks: every workgroup runs one (job, block) pair)
 template <typename T, int BMC, int BNK, int WM, int WN, bool PW>
 __global__ __launch_bounds__(256) void conv_wgrad_tab(const pn2_wgrad_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
     const int total = bstart[njobs];
@@ -1910,11 +1892,6 @@ int launch_dma(const void* in, const void* wp, void* out, float* psum, float* ps
 inline bool dma_extent_ok(const pn2_conv_desc& d) {
     return ((size_t)d.N * d.H * d.W - 1) * (size_t)d.ld_in * 2 + (size_t)d.Cin_p * 2 < 0x80000000ull;
 }
-inline bool use_dma_kernel() {
-    static const bool on = [] { const char* e = getenv("PN2_CONV_DMA"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 // tile choice: widest N tile with the least padding, then shrink tiles until the grid can fill 256 CUs
 inline void pick_tiles(int M, int cout, bool f32, int& bm, int& bn) {
     bn = pn2_conv_tile_n(cout);
@@ -1948,7 +1925,7 @@ void gemm_select(const pn2_conv_desc& d, int& kern, int& bm, int& bn) {
     if (tbm) bm = tbm == 1 ? 64 : 128;
     if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
     kern = 0;
-    if (sizeof(T) == 2) kern = tk_ == 3 ? 3 : ((tk_ ? tk_ == 2 : use_dma_kernel()) ? 2 : 0);
+    if (sizeof(T) == 2) kern = tk_ == 3 ? 3 : ((tk_ ? tk_ == 2 : true) ? 2 : 0);
     if (sizeof(T) == 4 && bn == 128) bn = 64;
 }
 
@@ -2073,21 +2050,17 @@ int launch_wgrad_dma(const void* dy, const void* x, float* slab, const pn2_wgrad
 
 inline bool wgrad_pw(const pn2_wgrad_desc& d) { return d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0; }
 
-// kernel instantiation a wgrad job runs on: dma * 6 + (co tile 32/64/128 -> 0/1/2) * 2 + pointwise; 12 + pointwise: the DMA kernel with 128 x 256 tiles
-// (d.tune == 3, and d.tune == 2 too unless PN2_WGRAD_BNK256=0: the per-shape tuner times a wgrad alone, where its pixel splits fill the chip and the
-// narrower tile wins; inside the table-driven launch of a step the chip is full anyway and the wide tile's smaller L2 -> LDS traffic wins: 15.62 -> 15.52 ms)
+// kernel instantiation a wgrad job runs on: dma * 6 + (co tile 32/64/128 -> 0/1/2) * 2 + pointwise; 12 + pointwise: the DMA kernel with 128 x 256 tiles.
+// d.tune: 0 heuristic, 1 register-staged, 2 LDS-DMA (128-wide contraction tiles), 3 LDS-DMA with 128 x 256 tiles (bf16, co tile 128, Kp >= 256; else as 2)
 template <typename T>
 int wgrad_variant(const pn2_wgrad_desc& d) {
     const int bmc = pn2_wgrad_tile_co(d.Cout_p);
     bool dma = false, wide = false;
     if constexpr (sizeof(T) == 2) {
-        static const bool on = [] { const char* e = getenv("PN2_WGRAD_DMA"); return !(e && e[0] == '0'); }();
-        static const bool force256 = [] { const char* e = getenv("PN2_WGRAD_BNK256"); return !(e && e[0] == '0'); }();
-        // default: the DMA pipeline pays off for pointwise convs with many pixels; d.tune (1 register-staged, 2 DMA, 3 DMA with 256-wide K tiles) overrides
-        dma = d.tune ? d.tune >= 2 : (on && wgrad_pw(d) && d.N * d.OH * d.OW >= 8192);
+        dma = d.tune ? d.tune >= 2 : (wgrad_pw(d) && d.N * d.OH * d.OW >= 8192);      // default: the DMA pipeline pays off for pointwise convs with many pixels
         // the DMA kernel addresses both operands with 32-bit byte offsets (buffer descriptors): extents below 2 GB
         if ((size_t)d.N * d.OH * d.OW * d.ld_dy * 2 >= 0x80000000ull || (size_t)d.N * d.H * d.W * d.ld_x * 2 >= 0x80000000ull) dma = false;
-        wide = dma && bmc == 128 && d.Kp >= 256 && (d.tune == 3 || (force256 && d.tune == 2));
+        wide = dma && bmc == 128 && d.Kp >= 256 && d.tune == 3;
     }
     if (wide) return 12 + (wgrad_pw(d) ? 1 : 0);
     return (dma ? 6 : 0) + (bmc == 128 ? 2 : (bmc == 64 ? 1 : 0)) * 2 + (wgrad_pw(d) ? 1 : 0);
@@ -2118,19 +2091,12 @@ int wgrad_dispatch(const void* dy, const void* x, float* slab, const pn2_wgrad_d
     return launch_wgrad<T, 32, 1, 4>(dy, x, slab, d, nsplit, st);
 }
 
-// PN2_WGRAD_GRID=<n>: cap the grid of the table-driven wgrad launches at n workgroups (rounded up to a multiple of 8); 0 = one workgroup per block
-inline int wgrad_grid(int total) {
-    static const int cap = [] { const char* e = getenv("PN2_WGRAD_GRID"); return e ? atoi(e) : 0; }();
-    if (cap <= 0 || total <= cap) return total;
-    return (cap + 7) / 8 * 8;
-}
-
 template <typename T, int BMC, int WM, int WN>
 int launch_wgrad_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
     constexpr int BNK = 128;
     constexpr int lds = 2 * WGP * (BMC * (int)sizeof(T) + WG<T>::PAD + BNK * (int)sizeof(T) + WG<T>::PAD);
-    if (pw) hipLaunchKernelGGL((conv_wgrad_tab<T, BMC, BNK, WM, WN, true>), dim3(wgrad_grid(total)), dim3(256), lds, st, jobs, bstart, njobs);
-    else hipLaunchKernelGGL((conv_wgrad_tab<T, BMC, BNK, WM, WN, false>), dim3(wgrad_grid(total)), dim3(256), lds, st, jobs, bstart, njobs);
+    if (pw) hipLaunchKernelGGL((conv_wgrad_tab<T, BMC, BNK, WM, WN, true>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
+    else hipLaunchKernelGGL((conv_wgrad_tab<T, BMC, BNK, WM, WN, false>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -2146,8 +2112,8 @@ int launch_wgrad_dma_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, 
             done = true;
         }
     }
-    if (pw) hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, true, BNK>), dim3(wgrad_grid(total)), dim3(256), max_b, st, jobs, bstart, njobs);
-    else hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, false, BNK>), dim3(wgrad_grid(total)), dim3(256), max_b, st, jobs, bstart, njobs);
+    if (pw) hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, true, BNK>), dim3(total), dim3(256), max_b, st, jobs, bstart, njobs);
+    else hipLaunchKernelGGL((conv_wgrad_dma_tab<BMC, WM, WN, false, BNK>), dim3(total), dim3(256), max_b, st, jobs, bstart, njobs);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -2424,7 +2390,7 @@ int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d) {
     if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
     if (((d->flags >> 16) & 15) > 1) return -2;
     int kern, bm, bn;
-    if (dtype == PN2_BF16) { gemm_select<bf16_t>(*d, kern, bm, bn); if ((kern == 0 && !use_dma_kernel()) || !dma_extent_ok(*d)) return -2; }
+    if (dtype == PN2_BF16) { gemm_select<bf16_t>(*d, kern, bm, bn); if (!dma_extent_ok(*d)) return -2; }      // (a register-staged choice joins the table on the LDS-DMA kernel: same bits)
     else if (dtype == PN2_F32) gemm_select<float>(*d, kern, bm, bn);
     else return -3;
     return (bm << 8) | bn;
@@ -2455,6 +2421,7 @@ int pn2_conv_gemm_multi(int dtype, int bm, int bn, int ep, const pn2_conv_job* j
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream) {
     if (!dy || !x || !slab || !d || nsplit < 1) return -1;
     if (d->Cin_p % 8 || d->ld_x % 8 || d->ld_dy % 8 || d->Cout_p % 8) return -2;
+    if (dtype == PN2_F32 && d->tune >= 2) return -2;           // the LDS-DMA kernels (and pn2_conv_wgrad_blocks' tile for them) are bf16 only
     if (dtype == PN2_BF16) return wgrad_dispatch<bf16_t>(dy, x, slab, *d, nsplit, (hipStream_t)stream);
     if (dtype == PN2_F32) return wgrad_dispatch<float>(dy, x, slab, *d, nsplit, (hipStream_t)stream);
     return -3;
@@ -2469,7 +2436,7 @@ int pn2_conv_wgrad_blocks(const pn2_wgrad_desc* d, int nsplit) {
     if (!d || nsplit < 1) return -1;
     const int bmc = pn2_wgrad_tile_co(d->Cout_p);
     if (d->Rp % bmc || d->Kp % 128) return -2;
-    return wgrad_blocks_t<bf16_t>(*d, nsplit);      // (d->tune 2 / 3 only ever come from the bf16 tuner: an fp32 desc never selects the wide tile)
+    return wgrad_blocks_t<bf16_t>(*d, nsplit);      // (d->tune 2 / 3 are bf16 kernels: pn2_conv_wgrad rejects them for fp32, so an fp32 job never has the wide tile)
 }
 
 int pn2_conv_wgrad_multi(int dtype, int variant, const pn2_wgrad_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {

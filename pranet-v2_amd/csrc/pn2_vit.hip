@@ -936,7 +936,7 @@ int pn2_layernorm_fwd(int dt, const void* x, int ld_x, void* y, int ld_y, int M,
 }
 
 static int rows_for(int M, int unit) {          /* rows per block of the column-sum style reductions: ~ROWS_TARGET blocks, a multiple of `unit` */
-    static const int target = [] { const char* e = getenv("PN2_ROWS_TARGET"); const int v = e ? atoi(e) : 512; return v < 1 ? 512 : v; }();   // 2 workgroups per CU measured best (256: -1.7 %, 1024: -1.1 % on config 4)
+    constexpr int target = 512;   // 2 workgroups per CU measured best (256: -1.7 %, 1024: -1.1 % on config 4)
     int rows = (M + target - 1) / target;
     rows = ((rows + unit - 1) / unit) * unit;
     return rows < unit ? unit : rows;
@@ -1012,9 +1012,7 @@ int pn2_colsum_multi(int dt, const pn2_colsum_in_job* jobs_dev, const int* block
 
 int pn2_colsum_unit(int dt, int C) { const int V = dt == PN2_F32 ? 4 : 8; int cvp = pow2ceil(C / V); if (cvp > 256) cvp = 256; return 256 / cvp; }
 
-static int dw_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
-
-// channels per thread (VT) and segment length of the depth-wise walks, from a sweep on MI355X (tools/dw_micro.py; PN2_DW_VT / PN2_DW_SEG override):
+// channels per thread (VT) and segment length of the depth-wise walks, from a sweep on MI355X (tools/dw_micro.py):
 // kind 0 = conv + GELU (ALU-heavier: 8-byte vectors, more waves), 1 = plain conv / data gradient (16-byte vectors while there are threads to
 // spare), 2 = weight gradient (80 accumulators per 8 channels: 2 channels per thread keeps 8 waves per SIMD).  Short segments for small tensors.
 static void dw_row_geometry(int dt, int kind, int N, int H, int W, int C, int& VT, int& SEG, int& SPR) {
@@ -1027,9 +1025,6 @@ static void dw_row_geometry(int dt, int kind, int N, int H, int W, int C, int& V
         while (VT > 2 && ((C % VT) || (VT == vmax && kind == 1 && threads(VT, 16) < 2LL * 256 * 8 * 64))) VT >>= 1;
         if (threads(VT, 16) < 200000) target = 8;
     }
-    static const int evt = dw_env("PN2_DW_VT"), eseg = dw_env("PN2_DW_SEG");
-    if (evt && evt <= vmax && C % evt == 0) VT = evt;
-    if (eseg) target = eseg;
     SPR = (W + target - 1) / target; SEG = (W + SPR - 1) / SPR;
 }
 
@@ -1100,7 +1095,7 @@ int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, i
 static int attn_geom(int Nkv, int heads, int head_dim) { return (head_dim == 64 && Nkv >= 1 && Nkv <= 64 * AT_MAXK && heads >= 1) ? 0 : -2; }
 
 // persistent attention blocks per launch: the blocks of one (b, head) share its K / V and walk the query tiles between them
-static int attn_target_blocks() { static const int v = [] { const char* e = getenv("PN2_ATTN_BLOCKS"); return e ? atoi(e) : 512; }(); return v; }
+static int attn_target_blocks() { return 512; }
 static int attn_bwd_gx(int B, int heads, int Nq) {
     const int ntile = (Nq + 63) / 64;
     // backward: one block per CU measured best (the block state - K, V, two 64-query tiles, dS / P and their transposes - fills the LDS anyway)
@@ -1120,7 +1115,7 @@ int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, voi
 #define PN2_ATTN_FWD(NKV) { if (lds > 64 * 1024) { static bool done = false; if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_k<T, NKV>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; } } \
         hipLaunchKernelGGL((attn_fwd_k<T, NKV>), grid, dim3(256), lds, st, (const T*)q, ld_q, (const T*)kv, ld_kv, (T*)out, ld_o, lse, Nq, Nkv, heads, scale, qpb); }
-    static const bool use_mfma = [] { const char* e = getenv("PN2_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    constexpr bool use_mfma = true;
     if (dt == PN2_BF16 && use_mfma && (ld_q % 8) == 0 && (ld_kv % 8) == 0 && (ld_o % 8) == 0) {
         const int NPK = NK == 3 ? 256 : NP;                        // 129..192 keys run the 256-key instantiation (zero-padded keys are masked)
         const size_t lm = ((size_t)NPK * 72 + (size_t)NPK * ATR + 8 * 16 * (NPK + 8)) * 2;
@@ -1142,7 +1137,7 @@ int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, voi
 }
 
 static bool attn_use_mfma(int dt, int ld_a, int ld_b) {
-    static const bool on = [] { const char* e = getenv("PN2_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    constexpr bool on = true;
     return on && dt == PN2_BF16 && (ld_a % 8) == 0 && (ld_b % 8) == 0;
 }
 

@@ -156,7 +156,6 @@ SIGNATURES = {
     "pn2_bn_eval_prepare": [C.POINTER(BnDesc), P, P, P, P, P, P, P],
     "pn2_bn_eval_prepare_multi": [P, P, I, I, P],
     "pn2_affine_act_sum": [I, P, I, P, I, I, I, P, P, I, P, I, P, I, P],
-    "pn2_bn_finalize_affine": [I, P, I, P, I, I, I, P, P, I, C.POINTER(BnDesc), P, P, P, P, P, P, P, P, P, I, I, P, I, P, I, P],
     "pn2_affine_act": [I, P, I, I, P, I, I, I, P, P, P, I, I, P],
     "pn2_bn_bwd_reduce": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, P, I, P],
     "pn2_bn_bwd_blocks": [I, I, I],

@@ -9,7 +9,6 @@ groups of `gw` (Res2Net's 26/52-wide splits, K-channel heads) stores each group 
 up to 8 slots, the pad slots holding exact zeros; weights are packed with matching zero rows/columns,
 so the arithmetic is unchanged while every pixel row stays 16-byte aligned.
 """
-import contextlib
 import ctypes as C
 import math
 import os
@@ -343,11 +342,9 @@ class StepArena:
         return torch.empty(shape, dtype=dtype, device=dev)
 
 
-WGRAD_SPLIT_DIV = int(os.environ.get("PN2_WGRAD_SPLIT_DIV", "1"))
-WGRAD_WGS = int(os.environ.get("PN2_WGRAD_WGS", "640"))             # pixel splits: workgroups a single wgrad aims at ...
-WGRAD_SLAB_MB = int(os.environ.get("PN2_WGRAD_SLAB_MB", "24"))      # ... within this many MB of fp32 slabs
-SLAB_RATIO = float(os.environ.get("PN2_SLAB_RATIO", "0"))           # > 0: cap a deferred wgrad's fp32 slab bytes at this multiple of its operand bytes
-TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the conv tuner times every candidate behind a cache-evicting fill
+TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the tuners time every candidate behind a cache-evicting fill (tests/conftest.py switches it off)
+WGRAD_WGS = 640               # pixel splits: workgroups a single wgrad aims at ...
+WGRAD_SLAB_MB = 24            # ... within this many MB of fp32 slabs
 _THRASH = {}
 
 
@@ -364,20 +361,12 @@ DEFER_COLSUM = os.environ.get("PN2_DEFER_COLSUM", "1") == "1"
 SMALL_CIN_DGRAD = os.environ.get("PN2_SMALL_CIN_DGRAD", "1") == "1"  # strided convs with <= 4 input channels: per-pixel data gradient
 GRAD_ALIAS = os.environ.get("PN2_GRAD_ALIAS", "1") == "1"             # sums whose second operand has no other consumer share its gradient storage
 SPLITK = os.environ.get("PN2_SPLITK", "1") == "1"                     # split-K for few-row / long-contraction convs
-KSPLIT_MINK = int(os.environ.get("PN2_KSPLIT_MINK", "4096"))         # shortest contraction that is split (M <= 4096 rows)
-KSPLIT_MID = int(os.environ.get("PN2_KSPLIT_MID", "2"))              # split factor for contractions below 4096
+KSPLIT_MINK = 4096            # shortest contraction that is split (M <= 4096 rows; shorter ones lose to the partial-tile traffic)
 PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
-BNB_MIN_COLS = int(os.environ.get("PN2_BNB_MIN_COLS", "0"))          # experiment: narrower gradients take the separate reduce pass instead of the dgrad epilogue
-LOCKSTEP_TILES = os.environ.get("PN2_LOCKSTEP_TILES", "0") == "1"   # opt-in: canonical conv tiles inside lock-step regions (measured: no more shared launches, same speed)
 LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
-# BatchNorm finalisation inside the normalise pass (pn2_bn_finalize_affine) for layers with <= this many partial rows; 0: off (default).  MEASURED NULL
-# (round 3): with 256, 42 of the 84 pn2_bn_finalize launches of a step disappear (739 -> 697 graph nodes) and the step time does not move (15.456 vs
-# 15.456 ms, rocprof: finalize 532 -> 322 us, normalise passes 1258 -> 1415 us): the ~5 us of a finalize launch are the dependent read of partial rows that
-# another XCD just wrote plus the merge arithmetic, and the fused pass pays exactly the same chain in front of its rows.  Kept as an opt-in.
-FUSE_FIN = int(os.environ.get("PN2_FUSE_FIN", "0"))
 EVAL_FUSE = True          # eval mode: conv + BatchNorm (+ ReLU) (+ residual) in ONE launch (pn2_conv_gemm_affine); tests switch it off to compare with the two-launch path
 ZERO_CROP_SKIP = os.environ.get("PN2_ZERO_CROP_SKIP", "1") == "1"   # K = 1 DSRA: the crop maps' gradient is identically zero - skip the adjoints of the resamples that made them
 
@@ -393,8 +382,6 @@ class GradQueue:
         self.slabs = {}
         self.cache = {}                   # segment index -> (signature, launches)
         self.ccache = {}                  # same for the engine's queued column-sum finalisations
-        self.side = None                  # torch.cuda.Stream: when set, EVERY flush runs there (ordered after the work issued so far on the current stream)
-        self.side_used = False
         self.begin_step()
 
     def begin_step(self):
@@ -475,20 +462,13 @@ class GradQueue:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("run two eager steps before capturing (the deferred-launch tables are built then)")
             hit = self.cache[self.seg] = (sig, self._build())
-        side = self.side
-        if side is not None:              # the weight-gradient launches overlap the backward chain that continues on the current stream
-            ev = torch.cuda.Event()
-            ev.record()
-            side.wait_event(ev)
-            self.side_used = True
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            st = _stream()
-            for kind, dt, v, table, bstart, njobs, nblocks, flops in hit[1]:
-                if kind == "w":
-                    capi.WORK.update(flops=flops, tag="", shape=f"variant{v} jobs{njobs}")
-                    call.pn2_conv_wgrad_multi(dt, v, _p(table), _p(bstart), njobs, nblocks, st)
-                else:
-                    call.pn2_wgrad_reduce_multi(_p(table), _p(bstart), njobs, nblocks, st)
+        st = _stream()
+        for kind, dt, v, table, bstart, njobs, nblocks, flops in hit[1]:
+            if kind == "w":
+                capi.WORK.update(flops=flops, tag="", shape=f"variant{v} jobs{njobs}")
+                call.pn2_conv_wgrad_multi(dt, v, _p(table), _p(bstart), njobs, nblocks, st)
+            else:
+                call.pn2_wgrad_reduce_multi(_p(table), _p(bstart), njobs, nblocks, st)
         self.seg += 1
         self.wjobs, self.rjobs, self.keep = [], [], []
         self.levels = {}
@@ -518,9 +498,7 @@ class Engine:
         self._lat = None                # contiguous block of the model's full-resolution output maps
         self.fuse_tail = False          # trainer: leave the lateral up-sampling to the fused DSRA tail kernels (K = 1)
         self.tail = {}                  # lateral slot -> (low-res source Act, align_corners, rh, rw) when fuse_tail
-        self._side, self._keep = None, []
-        # experimental: measured no gain on MI355X (wgrad/dgrad grids already fill the chip) and results were not bit-reproducible
-        self.use_side = os.environ.get("PN2_SIDE_STREAM", "0") == "1"
+        self._keep = []
 
     # ------------------------------------------------------------------ allocation / layout
     def alloc(self, shape, dtype):
@@ -595,7 +573,7 @@ class Engine:
             fn()
         self.tape = []
         self.flush_colsum()
-        self.join_side()
+        self._keep = []
 
     # ------------------------------------------------------------------ lock step: independent chains share table-driven launches
     def lockstep(self, key, fns):
@@ -603,7 +581,7 @@ class Engine:
         kind at a position as ONE table-driven launch (pn2/lockstep.py) - forward and backward.  `key` names the region (stable across steps).
         Needs a persistent table cache (the trainer's); without one, or inside another lock-step region, the chains simply run one after the other."""
         from . import lockstep as LS
-        if not LOCKSTEP or self.lock_cache is None or LS._ACTIVE or len(fns) < 2 or key in os.environ.get("PN2_LOCKSTEP_SKIP", "").split(","):
+        if not LOCKSTEP or self.lock_cache is None or LS._ACTIVE or len(fns) < 2:
             self._in_region = getattr(self, "_in_region", 0) + 1
             try:
                 return [f() for f in fns]
@@ -643,86 +621,6 @@ class Engine:
             self.record(bwd)
         return outs
 
-    # ------------------------------------------------------------------ lanes: independent sub-graphs on their own HIP streams
-    _LANE_STREAMS = []
-
-    def lanes(self, fns):
-        """[f() for f in fns] for sub-graphs that do not depend on each other (e.g. the three RFB modules): each runs on its own
-        HIP stream, forked from and joined back to the current stream, in the forward AND in the backward pass, so their many small
-        launch-bound kernels overlap (inside a captured hipGraph they become parallel branches).  Only with a step arena: buffers
-        are then never recycled inside a step, so cross-stream reuse cannot happen."""
-        # measured on MI355X / ROCm 7.2: parallel hipGraph branches cost more than they overlap (21.3 -> 23.2 ms/step) -> opt-in
-        on = os.environ.get("PN2_LANES", "0") == "1" and self.arena is not None and self.arena.buf is not None and len(fns) > 1
-        if not on:
-            return [f() for f in fns]
-        while len(Engine._LANE_STREAMS) < len(fns):
-            Engine._LANE_STREAMS.append(torch.cuda.Stream())
-        streams = Engine._LANE_STREAMS[:len(fns)]
-        self._lanes_used = streams
-        main = torch.cuda.current_stream()
-
-        def fork():
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            for s_ in streams:
-                s_.wait_event(ev)
-
-        def join():
-            cur = torch.cuda.current_stream()
-            for s_ in streams:
-                cur.wait_stream(s_)
-
-        def on_stream(fn, s_):
-            def run():
-                with torch.cuda.stream(s_):
-                    fn()
-            return run
-        self.record(join)                 # backward: runs last of the region
-        fork()
-        outs = []
-        for f, s_ in zip(fns, streams):
-            t0 = len(self.tape)
-            with torch.cuda.stream(s_):
-                outs.append(f())
-            self.tape[t0:] = [on_stream(fn, s_) for fn in self.tape[t0:]]
-        join()
-        self.record(fork)                 # backward: runs first of the region
-        return outs
-
-    # ------------------------------------------------------------------ side stream (off-critical-path work)
-    def on_side(self, keep=()):
-        """Context manager: run the enclosed launches on the engine's side HIP stream, ordered after everything issued so far
-        on the current stream.  `keep` tensors stay referenced until join_side() so the allocator cannot recycle them early."""
-        eng = self
-
-        class _Side:
-            def __enter__(s):
-                if not eng.use_side:
-                    return _stream()
-                if eng._side is None:
-                    eng._side = torch.cuda.Stream()
-                ev = torch.cuda.Event()
-                ev.record()
-                eng._side.wait_event(ev)
-                eng._keep.extend(keep)
-                s.ctx = torch.cuda.stream(eng._side)
-                s.ctx.__enter__()
-                return C.c_void_p(eng._side.cuda_stream)
-
-            def __exit__(s, *exc):
-                if eng.use_side:
-                    s.ctx.__exit__(*exc)
-                return False
-        return _Side()
-
-    def join_side(self):
-        """Make the current stream wait for everything queued on the side stream (call before consuming parameter gradients)."""
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
-        for s_ in getattr(self, "_lanes_used", ()):
-            torch.cuda.current_stream().wait_stream(s_)
-        self._keep = []
-
     # ------------------------------------------------------------------ weights
     def _pack_desc(self, w, x_map, out_map, transposed):
         Cout, Cin, KH, KW = _w4(w)
@@ -754,7 +652,7 @@ class Engine:
         return wp, d
 
     # ------------------------------------------------------------------ per-shape kernel / tile selection
-    def _tune_gemm(self, cd, in_ptr, wp, M, Cout, ep=None, canon=False):
+    def _tune_gemm(self, cd, in_ptr, wp, M, Cout, ep=None):
         """Pick (kernel, BM, BN) for this forward/dgrad shape by timing every candidate once (first eager step; results are cached in
         self.tuner and reused under hipGraph capture).  Returns the code for pn2_conv_desc.flags bits 8..15 (0 = library heuristic).
         ep: the launch carries a BatchNorm-backward epilogue (pn2_conv_gemm_ep): the candidates are timed WITH it (its extra operand reads and
@@ -762,11 +660,6 @@ class Engine:
         t = self.tuner
         if t is None or self.dt != BF16:
             return 0
-        if canon:
-            # inside a lock-step region the convs at one position share a launch only if they run on the same tile: one canonical tile per
-            # output width (LDS-DMA 3-stage kernel, 64-row tiles - these are the small maps of the heads) instead of per-shape tuning.  Decided
-            # when the conv is built, identically in every step (the partial-row buffers of the statistics depend on the tile)
-            return 2 | (1 << 2) | ((1 if Cout <= 32 else (2 if Cout <= 64 else 3)) << 4)
         key = ("g", cd.N, cd.H, cd.W, cd.OH, cd.OW, cd.Cin_p, cd.ld_in, Cout, cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w, cd.transposed)
         if ep is not None:
             key = key + ("ep", ep.a.mode, ep.b.mode, 1 if ep.b.out else 0, cd.flags & capi.CONV_ACCUM)
@@ -815,17 +708,18 @@ class Engine:
                         continue
                     cands.append(kern | (bm << 2) | (bn << 4))
         evs = []
-        cold = TUNE_COLD
         feasible = []
         for code in cands:
             try:
                 launch(code)
-            except RuntimeError:        # status -4: the epilogue's operand tiles of this tile shape do not fit the LDS (128 x 128 with two targets and +=)
+            except RuntimeError as err:       # status -4 only: the epilogue's operand tiles of this tile shape do not fit the LDS; anything else is a real failure
+                if "status -4" not in str(err):
+                    raise
                 continue
             feasible.append(code)
             per = []
             for _ in range(TUNE_REPS):
-                if cold:            # inside a step every conv runs once, on operands the caches have mostly lost: time it that way
+                if TUNE_COLD:       # inside a step every conv runs once, on operands the caches have mostly lost: time it that way
                     _thrash()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -847,7 +741,7 @@ class Engine:
         to the partial-tile traffic."""
         if not SPLITK or self.dt != BF16 or K < KSPLIT_MINK or M > 4096 or Cout_p % 8:
             return 1
-        return 4 if K >= 4096 else KSPLIT_MID
+        return 4
 
     def _stat_blocks(self, M, Cout, tune):
         bm = (tune >> 2) & 3
@@ -965,8 +859,7 @@ class Engine:
         cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = KH, KW, sh, ph, pw, dh, dw
         cd.transposed, cd.Kp, cd.flags = 0, pd.Kp, (capi.CONV_STATS if train_bn else 0)
         psum = psq = None
-        canon = LOCKSTEP and LOCKSTEP_TILES and getattr(self, "_in_region", 0) > 0      # canonical tiles for convs of a lock-step region (fwd and dgrad)
-        tune = self._tune_gemm(cd, x.ptr, wp, M, Cout_p, canon=canon)
+        tune = self._tune_gemm(cd, x.ptr, wp, M, Cout_p)
         cd.flags |= tune << 8
         if (EVAL_FUSE and bn is not None and not self.training and not self.need_grad and gate is None and sum_with is None and y_C is None and not fuse_bias
                 and (y_dt is None or y_dt == self.dt) and self._ksplit(M, KH * KW * x.Cp, Cout_p) == 1 and relu in (False, True, 2)
@@ -1016,7 +909,6 @@ class Engine:
 
         scale = shift = mean = invstd = par = None
         bd = None
-        fuse_fin = False
         if bn is not None:
             bd = capi.BnDesc()
             bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, Cout_p, Cout, gw_o, gwp_o, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
@@ -1026,15 +918,8 @@ class Engine:
             scale, shift = par[0], par[1]
             if train_bn:
                 mean, invstd = par[2], par[3]
-                # few partial rows (everything from layer3 down): the finalisation runs inside the normalise pass below - one launch instead of two.
-                # Not inside a lock-step region (its finalisations / normalise passes are already shared table-driven launches).
-                from . import lockstep as LS_
-                fuse_fin = (0 < nblk <= FUSE_FIN and tile_rows > 0 and ksplit == 1 and not fuse_bias and bias is None and y_C is None
-                            and (y_dt is None or y_dt == self.dt) and Cout_p % V == 0 and raw_ld % V == 0 and not LS_._ACTIVE
-                            and (out is None or out.ld % V == 0) and (residual is None or residual.ld % V == 0))
-                if not fuse_fin:
-                    call.pn2_bn_finalize(_p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
-                                         _p(scale), _p(shift), _p(mean), _p(invstd), st)
+                call.pn2_bn_finalize(_p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+                                     _p(scale), _p(shift), _p(mean), _p(invstd), st)
                 self.bn_modules.append(bn)
                 if bias is not None:          # biased conv followed by train-mode BN: the output is unchanged, only the running mean sees the bias
                     with torch.no_grad():
@@ -1063,24 +948,13 @@ class Engine:
         if sum_with is not None and (fuse_bias or residual is not None or y_dt != self.dt or ncopy != Cout_p or sum_with.dt != self.dt
                                      or (sum_with.N, sum_with.H, sum_with.W, sum_with.Cp) != (N, OH, OW, Cout_p) or out.ld % 8 or sum_with.ld % 8):
             raise RuntimeError("sum_with needs a plain same-dtype BN/activation output of the same geometry")
-        nul_ = C.c_void_p(0)
         if sum_with is not None:
             y2 = Act(self, self.empty(N, OH, OW, Cout_p), Cout, gw_o, gwp_o, self.dt)
-            if fuse_fin:
-                call.pn2_bn_finalize_affine(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, Cout_p, _p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias),
-                                            _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), _p(mean), _p(invstd), nul_, 0,
-                                            (2 if relu == 2 else 1) if relu else 0, sum_with.ptr, sum_with.ld, y2.ptr, y2.ld, st)
-            else:
-                call.pn2_affine_act_sum(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, Cout_p, _p(scale), _p(shift), (2 if relu == 2 else 1) if relu else 0,
-                                        sum_with.ptr, sum_with.ld, y2.ptr, y2.ld, st)
+            call.pn2_affine_act_sum(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, Cout_p, _p(scale), _p(shift), (2 if relu == 2 else 1) if relu else 0,
+                                    sum_with.ptr, sum_with.ld, y2.ptr, y2.ld, st)
             if self.need_grad and sum_with.requires_grad:
                 y2.galias = sum_with            # d(y + s)/ds = 1 and s has no other consumer: the sum's gradient lives in s's gradient storage
                 y2.sum_of = (out, sum_with)
-        elif fuse_fin:
-            call.pn2_bn_finalize_affine(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, ncopy, _p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias),
-                                        _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), _p(mean), _p(invstd),
-                                        residual.ptr if residual is not None else nul_, residual.ld if residual is not None else 0,
-                                        (2 if relu == 2 else 1) if relu else 0, nul_, 0, nul_, 0, st)
         elif not fuse_bias:
             call.pn2_affine_act(self.dt, _p(raw), raw_ld, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
                                 residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
@@ -1200,30 +1074,19 @@ class Engine:
             rd.Rp = wd.Rp
             wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd, nsplit, w.shape)
             rq = self.grad_queue
-            if rq is not None and rq.defer_wgrad and SLAB_RATIO > 0:
-                # inside a table-driven launch the other convs fill the chip; what a conv's pixel splits cost there is fp32 slab traffic (written, then
-                # re-read by the reduce): keep it within SLAB_RATIO x the bytes of the conv's own operands (small-M 3x3 convs: 25 MB of slabs for 6 MB of dz + x)
-                op_bytes = (M * Cout_p + N * H * W * x.Cp) * 2
-                nsplit = max(1, min(nsplit, int(SLAB_RATIO * op_bytes / (wd.Rp * wd.Kp * 4))))
-            if rq is not None and rq.defer_wgrad and WGRAD_SPLIT_DIV > 1:
-                # the tuner times a conv alone, where many pixel splits are what fills the chip; inside a table-driven launch the other
-                # convs of the table do that, and longer contractions per workgroup amortise the pipeline fill and write fewer fp32 slabs
-                nsplit = max(1, -(-nsplit // WGRAD_SPLIT_DIV))
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab((id(w), x.M), (nsplit, wd.Rp, wd.Kp), self.dev)
             gwt, gwa = self.pgrads.sink(w)
-            # wgrad (+ slab reduce) only feeds the parameter gradient: run it on the side stream so that it overlaps the dgrad /
-            # BN-backward chain of the layers below instead of sitting on the critical path
+            # wgrad (+ slab reduce) only feeds the parameter gradient: with a gradient queue both are deferred into the table-driven launches of its flush
             if rq is not None and rq.defer_wgrad:
                 rq.add_wgrad(self.dt, draw, x.ptr, x.t, slab, wd, nsplit, flops)
                 rq.add_reduce(slab, gwt, rd, nsplit, gwa)
             else:
-                with self.on_side((draw, slab)) as sst:
-                    capi.WORK.update(flops=flops, tag="", shape=shape)
-                    call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, sst)
-                    if rq is None:
-                        call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, sst)
-                    else:
-                        rq.add_reduce(slab, gwt, rd, nsplit, gwa)
+                capi.WORK.update(flops=flops, tag="", shape=shape)
+                call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
+                if rq is None:
+                    call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, st)
+                else:
+                    rq.add_reduce(slab, gwt, rd, nsplit, gwa)
             # ---- data gradient
             if x.requires_grad and PATCH_DGRAD and KH == sh and KW == sw and KH > 1 and ph == 0 and pw == 0 and dh == 1 and dw == 1 \
                     and x.gw == x.gwp and gw_o == gwp_o and x.ld == x.Cp:
@@ -1266,7 +1129,7 @@ class Engine:
                     dd.flags = ((2 | (1 << 2) | ((3 if x.Cp > 64 else 2) << 4)) << 8) | (ks << 16)
                     call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), _p(ws), C.c_void_p(0), C.byref(dd), st)
                     call.pn2_conv_splitk_reduce(self.dt, _p(ws), ks, Mx, x.Cp, _p(gx), x.Cp, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), gxa, st)
-                elif BNB_EPILOGUE and x_last and x.Cp % V == 0 and gx.stride(2) % V == 0 and (x.bnb is not None or dual) and x.Cp >= BNB_MIN_COLS:
+                elif BNB_EPILOGUE and x_last and x.Cp % V == 0 and gx.stride(2) % V == 0 and (x.bnb is not None or dual):
                     ep = capi.ConvEp()
                     if dual and x.sum_of[0].grad_written:
                         dd.flags |= capi.CONV_ACCUM
@@ -1275,7 +1138,7 @@ class Engine:
                             self._fill_bnb(t_, a_, 0)
                     if dual:
                         ep.b.out = 1
-                    tcode = self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, ep, canon=canon)
+                    tcode = self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, ep)
                     dd.flags |= tcode << 8
                     nbx = self._stat_blocks(Mx, x.Cp, tcode)
                     ep = capi.ConvEp()
@@ -1298,7 +1161,7 @@ class Engine:
                         call.pn2_conv_gemm_ep(self.dt, _p(draw), _p(wt), _p(gx), C.byref(dd), C.byref(ep), st)
                     x._sealed = True
                 else:
-                    dd.flags |= self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, canon=canon) << 8
+                    dd.flags |= self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp) << 8
                     call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
 
         self.record(bwd)
@@ -1434,8 +1297,7 @@ class Engine:
         cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = 1, 1, 1, 0, 0, 1, 1
         cd.transposed, cd.Kp, cd.flags = 0, Kp, (capi.CONV_STATS if train else 0)
         psum = psq = None
-        canon = LOCKSTEP and LOCKSTEP_TILES and getattr(self, "_in_region", 0) > 0
-        tune = self._tune_gemm(cd, x.ptr, wp, M, Ct, canon=canon)
+        tune = self._tune_gemm(cd, x.ptr, wp, M, Ct)
         cd.flags |= tune << 8
         tile_rows = 0
         if train:
@@ -1540,7 +1402,7 @@ class Engine:
                 dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Ct, Ct, x.Cp, gx.stride(2)
                 dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = 1, 1, 1, 0, 0, 1, 1
                 dd.transposed, dd.Kp, dd.flags = 1, Kt, (capi.CONV_ACCUM if gxa else 0)
-                dd.flags |= self._tune_gemm(dd, _p(draw), wt, M, x.Cp, canon=canon) << 8
+                dd.flags |= self._tune_gemm(dd, _p(draw), wt, M, x.Cp) << 8
                 capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
                 call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), nul, nul, C.byref(dd), st)
         self.record(bwd)

@@ -31,9 +31,6 @@ def _bytes(name, a):
         if name == "pn2_affine_act_sum":
             dt, M, C = a[0], a[5], a[6]
             return M * C * _EL[dt] * 4                      # raw + the other operand in, y and y + operand out
-        if name == "pn2_bn_finalize_affine":
-            dt, M, C, res, add = a[0], a[5], a[6], a[19], a[22]
-            return M * C * _EL[dt] * (2 + (1 if res.value else 0) + (2 if add.value else 0))
         if name in ("pn2_bilinear_fwd", "pn2_bilinear_bwd", "pn2_avgpool_fwd", "pn2_avgpool_bwd"):
             dt, N, H, W, C, OH, OW = a[0], a[5], a[6], a[7], a[8], a[9], a[10]
             return N * C * _EL[dt] * (H * W + OH * OW)
@@ -71,8 +68,6 @@ def _shape(name, a):
     try:
         if name == "pn2_affine_act":
             return f"M{a[6]} C{a[7]} ldx{a[2]} ldy{a[5]} res{1 if a[10].value else 0}"
-        if name == "pn2_bn_finalize_affine":
-            return f"M{a[5]} C{a[6]} nblk{a[9]} res{1 if a[19].value else 0} sum{1 if a[22].value else 0}"
         if name in ("pn2_bn_bwd_reduce", "pn2_bn_bwd_apply"):
             return f"M{a[10]} C{a[11]} lddy{a[3]} ldx{a[9]} y{1 if a[5].value else 0}"
         if name == "pn2_wgrad_reduce":
@@ -285,7 +280,7 @@ def measure_step(trainer, x, m, dtype, config=None):
     roofline["conv_classes"] = {k: {"ms": round(v[0], 3), "launches": v[1], "TFLOPs": round(v[2] / (v[0] * 1e-3) / 1e12, 1), "frac": round(v[2] / (v[0] * 1e-3) / 1e12 / peak_tf, 4)}
                                 for k, v in sorted(cls.items(), key=lambda kv: -kv[1][0])}
     # the BatchNorm family: HBM-bound streaming passes + the per-layer finalisation launches
-    bn_names = ("pn2_affine_act", "pn2_affine_act_sum", "pn2_bn_finalize_affine", "pn2_affine_multi", "pn2_bn_finalize", "pn2_bn_finalize_multi", "pn2_bn_bwd_reduce", "pn2_bn_bwd_reduce_multi",
+    bn_names = ("pn2_affine_act", "pn2_affine_act_sum", "pn2_affine_multi", "pn2_bn_finalize", "pn2_bn_finalize_multi", "pn2_bn_bwd_reduce", "pn2_bn_bwd_reduce_multi",
                 "pn2_bn_bwd_finalize", "pn2_bn_bwd_finalize_seg", "pn2_bn_bwd_finalize_multi", "pn2_bn_bwd_apply", "pn2_bn_bwd_apply_multi")
     bn = [agg[k] for k in bn_names if k in agg]
     if bn:

@@ -23,9 +23,6 @@ def _r4(n):
     return (n + 3) // 4 * 4
 
 
-WGRAD_OVERLAP = os.environ.get("PN2_WGRAD_OVERLAP", "0") == "1"      # deferred wgrad tables on a side stream, next to the backward chain (measured: 19.2 -> 20.3 ms, see DESIGN)
-WGRAD_INLINE = os.environ.get("PN2_WGRAD_INLINE", "0") == "1"        # experiment: flush the wgrad tables every WGRAD_SEG convs on the MAIN stream (operands still warm in L2 / MALL)
-WGRAD_SEG = int(os.environ.get("PN2_WGRAD_SEG", "24"))              # convs per flush segment
 # "thread_local": other threads of the process (RCCL's watchdog polls events while a rank captures) do not invalidate the capture
 CAPTURE_MODE = os.environ.get("PN2_CAPTURE_MODE", "thread_local")
 DP_SEGMENTS = os.environ.get("PN2_DP_SEGMENTS", "1") == "1"          # data-parallel replay: one hipGraph per gradient-bucket boundary, all-reduce overlapped (0: one graph, reduce after it)
@@ -83,7 +80,6 @@ class Trainer:
         self.buckets = GradBuckets(self.gflat, [(id(p), self.off[id(p)][0], _r4(self.off[id(p)][1])) for p in hot], bucket_bytes, process_group,
                                    wire_dtype=torch.bfloat16 if os.environ.get("PN2_DP_WIRE", "fp32") == "bf16" else None)
         self._seg = None                # capture of a data-parallel step in progress (see _capture_segments)
-        self._side = None               # side HIP stream of the overlapped wgrad segments (see _backward)
         self._expected = None           # id(p) -> gradient contributions per step, learned from the first backward pass (see _backward)
         self.last_outs = None
         self.pack_cache = PackCache()
@@ -200,28 +196,10 @@ class Trainer:
         if rq is not None:
             rq.begin_step()
 
-        # Opt-in experiment (PN2_WGRAD_OVERLAP=1): weight gradients only feed the optimizer, so instead of one set of table-driven launches at the
-        # end of the step the queue is flushed every WGRAD_SEG convs onto a SIDE stream, next to the latency-bound dgrad / BatchNorm chain of
-        # the layers below.  Bit-identical results - and SLOWER on MI355X / ROCm 7.2 (19.2 -> 20.3 ms for 12 / 24 / 48-conv segments alike): the
-        # machine-filling wgrad launches delay the short kernels of the critical chain by more than they hide.  Only with the step arena
-        # (buffers are never recycled inside a step, so the side stream can read dz / x long after the main stream moved on).
-        overlap = WGRAD_OVERLAP and rq is not None and rq.defer_wgrad and st.arena is not None and st.arena.buf is not None
-        if overlap and self._side is None:
-            self._side = torch.cuda.Stream()
-        if rq is not None:
-            rq.side = self._side if overlap else None
-
-        def join_wgrad():
-            if rq is not None and rq.side_used:
-                torch.cuda.current_stream().wait_stream(rq.side if rq.side is not None else self._side)
-                rq.side_used = False
-
-        def grads_complete():       # everything queued / running on the side so far must land before a bucket is sent
-            eng.join_side()
+        def grads_complete():       # everything queued so far must be launched before a bucket is sent
             eng.flush_colsum()
             if rq is not None:
                 rq.flush()
-            join_wgrad()
         # A bucket may leave as soon as every gradient in it is COMPLETE.  "Has been written" is not enough: a weight applied k times per step
         # (CAB's shared fc1 / fc2, EMCAD_dual's single sab conv) receives k contributions from different tape entries.  The first backward pass
         # of a trainer therefore only counts contributions per parameter (its buckets all leave at the end); later passes launch a bucket when
@@ -239,8 +217,6 @@ class Trainer:
             eng.pgrads.on_sink = late
         for fn in reversed(eng.tape):
             fn()
-            if (overlap or WGRAD_INLINE) and rq is not None and rq.defer_wgrad and len(rq.wjobs) >= WGRAD_SEG:
-                rq.flush()
             if hook and expected is not None:
                 self.buckets.launch_ready(eng.pgrads.counts, before_launch=grads_complete, expected=expected)
                 if self._seg is not None and self.buckets.record:
