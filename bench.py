@@ -143,9 +143,9 @@ def other_configs(dev, steps=10):
     return out
 
 
-def module_surface(dev, x, m, steps=10):
+def module_surface(dev, x, m, steps=20):
     """The drop-in path: the literal loop of MyTrain_med.py:59-86 on the mirror classes - model(images) -> 4 x structure_loss -> loss.backward() -> clip_gradient ->
-    torch.optim.Adam.step(), eager, torch autograd around one engine pass."""
+    torch.optim.Adam.step(); torch autograd around one engine pass, which the call site replays from two hipGraphs (forward, backward) after its first calls."""
     import pn2
     from lib.pranet import PraNet_V2
     from pn2.loss import structure_loss
@@ -164,7 +164,7 @@ def module_surface(dev, x, m, steps=10):
         clip_gradient(opt, 0.5)
         opt.step()
         return loss
-    for _ in range(3):
+    for _ in range(6):           # 2 plain calls, 2 on the call site's arena, the capture, one replay (pn2/graph.py)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -174,7 +174,7 @@ def module_surface(dev, x, m, steps=10):
     el = (time.perf_counter() - t0) / steps
     del model, opt
     torch.cuda.empty_cache()
-    return {"what": "nn.Module surface + torch autograd + utils.clip_gradient + torch.optim.Adam (MyTrain_med.py:59-86 verbatim), eager launches", "value": round(x.shape[0] / el, 1),
+    return {"what": "nn.Module surface + torch autograd + utils.clip_gradient + torch.optim.Adam (MyTrain_med.py:59-86 verbatim); the model call replays two hipGraphs, loss / clip / Adam are eager torch", "value": round(x.shape[0] / el, 1),
             "unit": "images/sec", "ms_per_step": round(1e3 * el, 3), "steps": steps, "loss": round(float(loss), 4)}
 
 

@@ -8,8 +8,10 @@ import os
 
 import torch
 
+import weakref
+
 from .capi import F32, BF16
-from .engine import Engine, PackCache, TUNER
+from .engine import Engine, GradQueue, PackCache, StepArena, TUNER
 
 _DT = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "float32": F32, "f32": F32}
 _compute_dtype = _DT[os.environ.get("PN2_DTYPE", "bf16").lower()]
@@ -25,7 +27,7 @@ def get_compute_dtype():
     return _compute_dtype
 
 
-def _pack_cache(dtype, params):
+def _pack_cache(dtype, params, refresh=True):
     """Packed-panel cache of one module call site.  The packed weight panels of a call site persist across calls (the cache hangs off the module's
     first parameter, so it lives and dies with the module) and are ALL rebuilt from the current fp32 weights by one table-driven launch
     at the start of every call - never reused unrefreshed, whatever touched the weights in between.  Conv tiles come from the
@@ -38,7 +40,8 @@ def _pack_cache(dtype, params):
             pc = slot[dtype] = PackCache()
         if pc.keep and any(j.w != w.data_ptr() for j, w in zip(pc.jobs, pc.keep)):
             pc = slot[dtype] = PackCache()            # a weight was re-allocated (p.data = ...): start over
-        pc.refresh()
+        if refresh:
+            pc.refresh()
     return pc
 
 
@@ -98,11 +101,203 @@ class _GraphFn(torch.autograd.Function):
         return (None, None, None, None, None, *gin, *gpar)
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# Training call sites replayed from hipGraphs.  `model(images) ... loss.backward()` of MyTrain_med.py:59-86 launches ~1 900 kernels from Python
+# per step (~57 ms of host time against ~15 ms of GPU work at bs = 32).  A call site - one module called in train mode with one input shape -
+# therefore goes through three stages: its first PLAIN_CALLS calls are the plain eager pass above; the next two run the same pass on the
+# trainer's machinery (step arena, lock-step tables, deferred weight-gradient tables: pn2/trainer.py) so that every buffer and job table has
+# its final address; from then on the forward is ONE hipGraph and the backward another (sharing a memory pool), and a call costs two
+# hipGraphLaunch plus the copies of the inputs, outputs and output gradients.  Calls the graphs cannot serve - an input that requires grad, a
+# second forward before the backward of the previous one, eval mode - fall back to the plain pass, so the semantics of the surface do not change.
+# ------------------------------------------------------------------------------------------------------------------------------------------
+MODULE_GRAPH = os.environ.get("PN2_MODULE_GRAPH", "1") == "1"
+PLAIN_CALLS = 2
+MAX_SITES = 4            # input shapes kept per module (the 0.75x / 1x / 1.25x schedule of MyTrain_med.py:55 needs 3)
+
+
+def set_module_graph(on):
+    global MODULE_GRAPH
+    MODULE_GRAPH = bool(on)
+
+
+class _Token:
+    pass
+
+
+class _Sites(dict):
+    """Hangs off the module's first parameter next to the pack cache: never pickled / deep-copied with it."""
+
+    def __reduce__(self):
+        return (_Sites, ())
+
+    def __deepcopy__(self, memo):
+        return _Sites()
+
+
+class _Site:
+    def __init__(self, params, pc):
+        self.pc, self.calls, self.arena_steps, self.gen = pc, 0, 0, 0
+        self.arena, self.lock, self.rq = StepArena(), {}, GradQueue(defer_wgrad=True)
+        self.off, o = {}, 0
+        for p in params:
+            self.off[id(p)] = (o, p.numel())
+            o += (p.numel() + 3) // 4 * 4
+        self.gflat = torch.zeros(o, dtype=torch.float32, device=params[0].device)     # parameter gradients at fixed addresses (the reduce tables hold them)
+        self.graph_f = self.graph_b = None
+        self.no_graph = False
+        self.live, self.bwd_done = None, True
+
+    def busy(self):
+        """A forward of this site is waiting for its backward: its saved activations live in the arena the next pass would overwrite."""
+        return not self.bwd_done and self.live is not None and self.live() is not None
+
+    def grad_view(self, p):
+        if id(p) not in self.off:
+            return torch.empty_like(p, dtype=torch.float32)
+        o, n = self.off[id(p)]
+        return self.gflat[o:o + n].view(p.shape)
+
+    def begin(self, ctx):
+        self.gen += 1
+        ctx.site, ctx.gen, ctx.token = self, self.gen, _Token()
+        self.live, self.bwd_done = weakref.ref(ctx.token), False
+
+    def check(self, ctx):
+        if ctx.gen != self.gen:
+            raise RuntimeError("this call site ran again before the backward of an earlier call (its activations are gone); set PN2_MODULE_GRAPH=0")
+
+    def forward(self, build, training, dtype, inputs):
+        self.arena.begin_step(inputs[0].device)
+        eng = Engine(dtype, training, grad_provider=self.grad_view, need_grad=True, pack_cache=self.pc, grad_queue=self.rq, arena=self.arena,
+                     tuner=TUNER if os.environ.get("PN2_AUTOTUNE", "1") == "1" else None,
+                     lock_cache=self.lock if self.arena.buf is not None else None)
+        acts = [eng.from_nchw(x, requires_grad=False) for x in inputs]
+        outs = build(eng, *acts)
+        eng.finish_forward()
+        return eng, outs, tuple(eng.to_nchw(o) for o in outs)
+
+    def backward(self, eng, outs, gouts):
+        for o, g in zip(outs, gouts):
+            _seed_grad(o, g)
+        self.rq.begin_step()
+        eng.backward()
+        self.rq.flush()
+
+    def capture(self, build, training, dtype, inputs, params):
+        import gc
+        from .trainer import CAPTURE_MODE
+        self.s_in = [x.detach().clone() for x in inputs]
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        gc_was = gc.isenabled()
+        gc.collect()
+        gc.disable()               # no collector inside a capture (see Trainer.capture)
+        try:
+            with torch.no_grad():
+                with torch.cuda.graph(gf, pool=pool, capture_error_mode=CAPTURE_MODE):
+                    self.pc.refresh()
+                    eng, outs, nchw = self.forward(build, training, dtype, self.s_in)
+                self.s_out = nchw
+                self.s_gout = [torch.zeros_like(o) for o in nchw]
+                with torch.cuda.graph(gb, pool=pool, capture_error_mode=CAPTURE_MODE):
+                    self.backward(eng, outs, self.s_gout)
+            self.s_pgrads = [eng.pgrads.get(p) for p in params]
+            eng.pgrads.provider = None
+            eng.lock_cache = eng.grad_queue = eng.arena = eng.pack_cache = None
+        finally:
+            if gc_was:
+                gc.enable()
+        self.graph_f, self.graph_b = gf, gb
+
+
+class _SiteFn(torch.autograd.Function):
+    """One eager pass of a call site on its arena / tables (the two passes before the capture)."""
+
+    @staticmethod
+    def forward(ctx, site, build, training, dtype, n_in, *tensors):
+        eng, outs, nchw = site.forward(build, training, dtype, tensors[:n_in])
+        site.begin(ctx)
+        ctx.eng, ctx.outs, ctx.params, ctx.n_in = eng, outs, tensors[n_in:], n_in
+        return tuple(o.clone() for o in nchw)         # the arena is reused by the next call: hand out copies
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        site, eng = ctx.site, ctx.eng
+        site.check(ctx)
+        site.backward(eng, ctx.outs, gouts)
+        gpar = [eng.pgrads.get(p) for p in ctx.params]
+        site.keep = gpar                               # a second reference: autograd copies the views of the flat buffer instead of adopting them
+        site.bwd_done = True
+        eng.pgrads.provider = None
+        eng.lock_cache = eng.grad_queue = eng.arena = eng.pack_cache = None
+        ctx.eng = ctx.outs = None
+        return (None, None, None, None, None, *([None] * ctx.n_in), *gpar)
+
+
+class _ReplayFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, site, n_in, *tensors):
+        for s_, x in zip(site.s_in, tensors[:n_in]):
+            s_.copy_(x, non_blocking=True)
+        site.graph_f.replay()
+        site.begin(ctx)
+        ctx.n_in = n_in
+        return tuple(o.clone() for o in site.s_out)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        site = ctx.site
+        site.check(ctx)
+        for s_, g in zip(site.s_gout, gouts):
+            if g is None:
+                s_.zero_()
+            else:
+                s_.copy_(g, non_blocking=True)
+        site.graph_b.replay()
+        site.bwd_done = True
+        return (None, None, *([None] * ctx.n_in), *site.s_pgrads)
+
+
+def _site(build, inputs, params, training, dtype, pc):
+    fn = getattr(build, "__func__", build)
+    key = (fn.__code__, len(params), tuple(tuple(x.shape) for x in inputs), dtype)
+    sites = params[0].__dict__.setdefault("_pn2_sites", _Sites())
+    st = sites.get(key)
+    if st is not None and st.pc is not pc:            # the pack cache was rebuilt (a weight was re-allocated): the graphs hold the old pointers
+        st = None
+    if st is None:
+        sites.pop(key, None)
+        while len(sites) >= MAX_SITES:
+            sites.pop(next(iter(sites)))
+        st = _Site(params, pc)
+    sites[key] = st
+    return st
+
+
 def run_module(build, inputs, params, training, dtype=None):
     """Run `build(eng, *acts) -> [Act]` on NCHW inputs; returns a tuple of NCHW fp32 tensors."""
     dtype = _compute_dtype if dtype is None else dtype
     params = [p for p in params]
     need = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(x.requires_grad for x in inputs))
+    if need and training and MODULE_GRAPH and params and not any(x.requires_grad for x in inputs) and os.environ.get("PN2_MODULE_PACK_CACHE", "1") == "1":
+        pc = _pack_cache(dtype, params, refresh=False)
+        site = _site(build, inputs, params, training, dtype, pc)
+        if site.calls >= PLAIN_CALLS and not site.busy():
+            if site.graph_f is None and site.arena_steps >= 2 and not site.no_graph:
+                try:
+                    site.capture(build, training, dtype, inputs, params)
+                except Exception as e:          # noqa: BLE001   (the context manager has ended the capture: this site stays on eager launches)
+                    import warnings
+                    warnings.warn(f"capturing this call site failed ({type(e).__name__}: {e}); it keeps running eager launches")
+                    site.no_graph, site.graph_f, site.graph_b = True, None, None
+                    torch.cuda.synchronize()
+            if site.graph_f is not None:
+                return _ReplayFn.apply(site, len(inputs), *inputs, *params)
+            pc.refresh()
+            site.arena_steps += 1
+            return _SiteFn.apply(site, build, training, dtype, len(inputs), *inputs, *params)
+        site.calls += 1
     pc = _pack_cache(dtype, params)
     if not need:
         eng = _module_engine(dtype, training, False, pc)

@@ -1,0 +1,153 @@
+"""The nn.Module surface replays a training call site from hipGraphs after its first calls (pn2/graph.py).  The literal loop of MyTrain_med.py:59-86 -
+model(images) -> 4 x structure_loss -> loss.backward() -> clip_gradient -> torch.optim.Adam.step() - must give the same training run with and without them, and the
+calls the graphs cannot serve (a second forward before the backward, eval mode, no_grad) must keep their eager semantics."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+os.environ.setdefault("PN2_NO_PRETRAINED", "1")
+dev = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pn2
+    from pn2 import graph as G
+    pn2.load_library()
+    yield
+    pn2.set_compute_dtype("bf16")
+    G.set_module_graph(True)
+
+
+def _model():
+    from lib.pranet import PraNet_V2
+    from oracle import weights as W
+    model = PraNet_V2(num_class=1)
+    model.load_state_dict(W.make_state_dict(W.manifest_pranet_v2(1), seed=0, bn3_gamma=0.05), strict=True)
+    return model.to(dev).train()
+
+
+def _run(steps, graphs, dtype="fp32"):
+    import pn2
+    from pn2 import graph as G
+    from pn2.loss import structure_loss
+    from utils.utils import clip_gradient
+    from oracle import weights as W
+    pn2.set_compute_dtype(dtype)
+    G.set_module_graph(graphs)
+    model = _model()
+    opt = torch.optim.Adam(model.parameters(), 1e-4)
+    losses = []
+    for i in range(steps):
+        x, m = W.synthetic_batch(2, 96, seed=100 + i)
+        x, m = x.to(dev), m.to(dev)
+        bg = 1 - m
+        opt.zero_grad()
+        o = model(x)
+        loss = structure_loss(o[3], o[7], m, bg) + structure_loss(o[2], o[6], m, bg) + structure_loss(o[1], o[5], m, bg) + structure_loss(o[0], o[4], m, bg)
+        loss.backward()
+        clip_gradient(opt, 0.5)
+        opt.step()
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone().double().cpu() for k, v in model.state_dict().items()}
+    return losses, sd, model
+
+
+def test_training_loop_with_graph_replayed_call_site_matches_eager():
+    l0, sd0, _ = _run(7, False)
+    l1, sd1, model = _run(7, True)
+    sites = next(iter(model.hot_parameters())).__dict__["_pn2_sites"]
+    st = next(iter(sites.values()))
+    assert st.graph_f is not None and st.graph_b is not None and st.arena_steps == 2 and st.calls == 2      # calls 5, 6, 7 were replays
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (l0, l1)
+    for k in sd0:
+        if sd0[k].numel() > 1:
+            d = float((sd0[k] - sd1[k]).abs().max())
+            assert d <= 2e-4 * max(1e-3, float(sd0[k].abs().max())) + 1e-6, (k, d)       # 7 Adam steps of lr 1e-4: a step is +-1e-4, equal up to the sign of ~zero gradients
+
+
+def test_outputs_and_gradients_of_a_replayed_call_match_the_plain_pass():
+    """Same weights, same batch: call 5 of a site (a replay) against the plain pass of a fresh model."""
+    import pn2
+    from pn2 import graph as G
+    from oracle import weights as W
+    pn2.set_compute_dtype("fp32")
+    x, _ = W.synthetic_batch(2, 96, seed=7)
+    x = x.to(dev)
+    gs = [torch.randn(2, 1, 96, 96, device=dev, generator=torch.Generator(device=dev).manual_seed(i)) for i in range(8)]
+
+    def one(model):
+        model.zero_grad()
+        outs = model(x)
+        torch.autograd.backward([o for o in outs], gs)
+        return [o.detach().clone() for o in outs], {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    G.set_module_graph(False)
+    ref_model = _model()
+    G.set_module_graph(True)
+    model = _model()
+    # BatchNorm running statistics differ after 4 warm calls, the train-mode outputs do not depend on them
+    for _ in range(4):
+        one(model)
+    o1, g1 = one(model)
+    st = next(iter(next(iter(model.hot_parameters())).__dict__["_pn2_sites"].values()))
+    assert st.graph_f is not None
+    G.set_module_graph(False)
+    o0, g0 = one(ref_model)
+    for a, b in zip(o0, o1):
+        assert float((a - b).abs().max()) < 2e-5
+    assert set(g0) == set(g1)
+    num = sum(float((g0[k].double() - g1[k].double()).pow(2).sum()) for k in g0) ** 0.5
+    den = sum(float(g0[k].double().pow(2).sum()) for k in g0) ** 0.5
+    assert num / den < 2e-4, num / den
+    # the handed-out outputs are private copies: a later call does not overwrite them
+    keep = o1[0].clone()
+    outs = model(x * 0.5)
+    assert torch.equal(o1[0], keep) and not torch.equal(outs[0], keep)
+    del outs
+
+
+def test_second_forward_before_backward_falls_back_to_the_plain_pass():
+    import pn2
+    from pn2 import graph as G
+    from oracle import weights as W
+    pn2.set_compute_dtype("fp32")
+    G.set_module_graph(True)
+    model = _model()
+    xa, _ = W.synthetic_batch(2, 96, seed=1)
+    xb, _ = W.synthetic_batch(2, 96, seed=2)
+    xa, xb = xa.to(dev), xb.to(dev)
+    for _ in range(5):                         # warm the site up to replay
+        model.zero_grad()
+        sum(o.sum() for o in model(xa)).backward()
+    st = next(iter(next(iter(model.hot_parameters())).__dict__["_pn2_sites"].values()))
+    assert st.graph_f is not None
+    model.zero_grad()
+    oa = model(xa)                              # replay
+    ob = model(xb)                              # the site is busy: plain pass, both graphs stay valid
+    assert st.busy()
+    (sum(o.sum() for o in oa) + sum(o.sum() for o in ob)).backward()
+    g_both = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert not st.busy()
+    G.set_module_graph(False)
+    model.zero_grad()
+    (sum(o.sum() for o in model(xa)) + sum(o.sum() for o in model(xb))).backward()
+    num = sum(float((g_both[n].double() - p.grad.double()).pow(2).sum()) for n, p in model.named_parameters() if p.grad is not None) ** 0.5
+    den = sum(float(p.grad.double().pow(2).sum()) for n, p in model.named_parameters() if p.grad is not None) ** 0.5
+    assert num / den < 5e-4, num / den          # (train-mode BatchNorm: the running statistics moved in between, the gradients do not depend on them)
+    # a forward whose result is dropped without a backward does not block the site
+    model(xa)
+    assert not st.busy()
+    # eval mode and no_grad calls never touch the site
+    n_gen = st.gen
+    with torch.no_grad():
+        model(xa)
+    model.eval()
+    model(xa)
+    model.train()
+    assert st.gen == n_gen
