@@ -1,7 +1,7 @@
 """EMCAD decoder with dual-supervised K-class heads (reference: multiclass_seg/EMCAD/lib/decoders.py) on the gfx950 kernels.
 
 Same class names, constructor signatures and parameter names (state_dict keys) as the reference; the computation is expressed in
-engine ops (pn2/engine.py): 1x1 / 3x3 / 7x7 convs on the implicit-GEMM kernels, BatchNorm on pn2_bn_*, and the depth-wise, grouped,
+engine ops (pn2/engine.py + ops_*.py): 1x1 / 3x3 / 7x7 convs on the implicit-GEMM kernels, BatchNorm on pn2_bn_*, and the depth-wise, grouped,
 gating, pooling, shuffle and up-sampling pieces on csrc/pn2_emcad.hip.  Only the configuration the reference trains (train_synapse.py:
 kernel_sizes [1,3,5], expansion 2, dw_parallel, add, stride 1, lgag_ks 3, relu6 in the MSCBs) is built; other switches raise.
 No PyTorch fallback: forward needs the GPU library.

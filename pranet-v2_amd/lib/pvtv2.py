@@ -1,7 +1,7 @@
 """PVTv2 encoder (reference: lib/pvtv2.py) on the gfx950 kernels.
 
 Same class names, constructor signatures, parameter names (state_dict keys) and init as the reference; the computation is
-expressed in engine ops (pn2/engine.py): the nn.Linear layers run as 1x1 implicit-GEMM convolutions on NHWC tokens, LayerNorm,
+expressed in engine ops (pn2/engine.py + ops_*.py): the nn.Linear layers run as 1x1 implicit-GEMM convolutions on NHWC tokens, LayerNorm,
 the depth-wise conv + GELU and the spatial-reduction attention are the kernels of csrc/pn2_vit.hip.  Tokens [B, N, C] of the
 reference are NHWC pixels here, so the reshapes/permutes of the reference (:92-107, :191, :316-338, :370-372) cost nothing.
 There is no PyTorch fallback: forward needs the GPU library.

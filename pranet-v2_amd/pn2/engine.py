@@ -1,480 +1,26 @@
-"""Host engine: NHWC activations, a reverse-mode tape, and the op set the PraNet models are written in.
+"""Host engine: the Engine class = core state (allocation, tape, lock-step regions) + the op mix-ins.
 
-Everything here is plumbing around the C ABI (capi.py): PyTorch supplies device memory and the
-current HIP stream; every arithmetic pass over an activation is one of the gfx950 kernels in csrc/.
-There is deliberately no CPU implementation: ops raise on non-GPU tensors.
-
-Layout: activations are NHWC with *physical* channels.  A tensor whose logical channels come in
-groups of `gw` (Res2Net's 26/52-wide splits, K-channel heads) stores each group in `gwp` = gw rounded
-up to 8 slots, the pad slots holding exact zeros; weights are packed with matching zero rows/columns,
-so the arithmetic is unchanged while every pixel row stays 16-byte aligned.
-"""
+pn2/core.py       activations, caches, tuning table, behaviour switches, deferred weight-gradient queue
+pn2/ops_conv.py   packing, tuners, conv + BatchNorm ops (forward and backward)
+pn2/ops_encoder.py  PVTv2 / EMCAD ops
+pn2/ops_spatial.py  pooling, resampling, element-wise, DSRA ops
+Everything importable from pn2.engine before the split still is (the switches live in pn2.core: patch them there)."""
 import ctypes as C
-import math
 import os
 
 import torch
 
 from . import capi
+from . import core
 from .capi import call, F32, BF16
+from .core import *            # noqa: F401,F403
+from .core import _p, _stream, _job_table, _thrash, _w4, _LinearAsConv, _PERMS, _THRASH      # noqa: F401
+from .ops_conv import ConvOps
+from .ops_encoder import EncoderOps
+from .ops_spatial import SpatialOps
 
-TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
-_PERMS = {}     # channel_shuffle permutations (device int32 tensors) by (channels, groups)
-TUNER = {}      # process-wide conv shape -> tuned kernel/tile code (see Engine._tune_gemm)
 
-
-def load_tuner(path):
-    """Merge a saved tuning table (PN2_TUNE_CACHE=<file>) so that a run does not have to time the candidates again."""
-    import ast
-    import json
-    try:
-        with open(path) as f:
-            for k, v in json.load(f).items():
-                TUNER.setdefault(ast.literal_eval(k), tuple(v) if isinstance(v, list) else v)
-    except (OSError, ValueError):
-        pass
-
-
-def save_tuner(path):
-    """Rank 0 only (every DP rank would otherwise race on the same file), through a temporary file + os.replace (no torn reads)."""
-    import json
-    if int(os.environ.get("RANK", "0")) != 0:
-        return
-    tmp = f"{path}.{os.getpid()}.tmp"
-    with open(tmp, "w") as f:
-        json.dump({repr(k): v for k, v in TUNER.items()}, f)
-    os.replace(tmp, path)
-
-
-TUNE_REPS = int(os.environ.get("PN2_TUNE_REPS", "3"))            # timed repetitions per tuning candidate (the minimum counts)
-# Shipped tuning table: the (kernel, tile) and wgrad (kernel, pixel splits) choices for the conv shapes of the BASELINE configurations on an MI355X,
-# produced by the tuner itself (PN2_TUNE_REPS=7 PN2_TUNE_CACHE=... python bench.py per configuration).  Keys carry the complete shape, so a table
-# entry only ever applies to exactly the launch it was timed for; shapes not in the table are tuned at first use as before.  PN2_TUNE_TABLE=0 ignores it.
-if os.environ.get("PN2_TUNE_CACHE"):
-    load_tuner(os.environ["PN2_TUNE_CACHE"])          # (first entry wins: an explicit cache overrides the shipped table)
-if os.environ.get("PN2_TUNE_TABLE", "1") == "1":
-    load_tuner(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json"))
-
-
-def rup(v, m):
-    return (v + m - 1) // m * m
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
-def _p(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-
-
-def _w4(w):
-    """OIHW shape of a conv weight; an nn.Linear weight [out, in] is a 1x1 conv weight with the same memory layout."""
-    return tuple(w.shape) if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
-
-
-class _LinearAsConv:
-    """nn.Linear over the channel axis of NHWC tokens == 1x1 convolution (pvtv2.py:19,22,62-65)."""
-    __slots__ = ("weight", "stride", "padding", "dilation", "groups")
-
-    def __init__(self, lin):
-        self.weight, self.stride, self.padding, self.dilation, self.groups = lin.weight, (1, 1), (0, 0), (1, 1), 1
-
-
-class Act:
-    """NHWC activation view.  t: torch tensor (N,H,W,Cp) whose last dim is contiguous; ld = pixel stride."""
-    __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0", "lat", "galias",
-                 "bnb", "bstats", "sum_of", "dual_done", "_sealed", "grad_masked")
-
-    def __init__(self, eng, t, C_, gw=None, gwp=None, dt=None, requires_grad=True):
-        self.eng, self.t = eng, t
-        self.N, self.H, self.W = t.shape[0], t.shape[1], t.shape[2]
-        self.C = C_
-        self.gw = gw if gw is not None else t.shape[3]
-        self.gwp = gwp if gwp is not None else t.shape[3]
-        self.dt = dt if dt is not None else (F32 if t.dtype == torch.float32 else BF16)
-        self.grad, self._written, self.child_written, self.requires_grad = None, False, False, requires_grad
-        self.parent, self.c0 = None, 0
-        self.lat = None                 # index of the full-resolution lateral output slot this Act is (Engine.lateral_out)
-        self.galias = None              # Act whose gradient storage this one shares (Engine.binary(..., grad_alias=True))
-        self.bnb = None                 # Bnb: the train-mode BatchNorm this activation is the output of (statistics of its gradient can be taken in a dgrad epilogue)
-        self.bstats = None              # [(c0, ncols, p1, p2, nblk, ldp)] BatchNorm-backward partial sums left by dgrad epilogues, by physical column range
-        self.sum_of = None              # (u, v): this Act is u + v written by u's BN-apply pass (conv_bn_act(sum_with=v)); its gradient aliases v's
-        self.dual_done = False          # the sum's consumer wrote the gradient of BOTH operands (dual-target dgrad epilogue)
-        self._sealed = False            # a dgrad that declared itself the last contribution has written this gradient
-        self.grad_masked = False        # that dgrad stored dz = dy * [y > 0] (PN2_BNB_STORE_MASKED): the gradient buffer already carries the ReLU mask
-
-    @property
-    def grad_written(self):
-        # a slice of a buffer that was written as a whole (e.g. dgrad into a concat buffer) counts as written
-        return self._written or (self.parent is not None and self.parent.grad_written)
-
-    @grad_written.setter
-    def grad_written(self, v):
-        self._written = v
-        if v and self.parent is not None:
-            self.parent.child_written = True
-
-    Cp = property(lambda s: s.t.shape[3])
-    ld = property(lambda s: s.t.stride(2))
-    M = property(lambda s: s.N * s.H * s.W)
-    ptr = property(lambda s: C.c_void_p(s.t.data_ptr()))
-
-    def slice(self, c0, c1, C_=None, gw=None, gwp=None):
-        """Channel-slice view (physical channel range); its gradient is the same slice of this grad."""
-        a = Act(self.eng, self.t[..., c0:c1], C_ if C_ is not None else c1 - c0, gw, gwp, self.dt, self.requires_grad)
-        a.parent, a.c0 = self, c0
-        if self.bnb is not None and self.bnb.split == 0:
-            a.bnb = self.bnb.cols(c0, c1)
-        return a
-
-    def root(self):
-        """-> (outermost parent, this view's first physical column inside it)"""
-        a, off = self, 0
-        while a.parent is not None:
-            off += a.c0
-            a = a.parent
-        return a, off
-
-    def add_bstats(self, c0, ncols, p1, p2, nblk, ldp):
-        r, off = self.root()
-        if r.bstats is None:
-            r.bstats = []
-        r.bstats.append((off + c0, ncols, p1, p2, nblk, ldp))
-
-    def find_bstats(self):
-        """Segments [(c0 (relative), ncols, p1, p2, nblk, ldp)] that cover this view's columns, newest entry first; None where nothing covers."""
-        r, off = self.root()
-        segs, c = [], 0
-        have = r.bstats or []
-        while c < self.Cp:
-            hit = None
-            for (s0, n, p1, p2, nblk, ldp) in reversed(have):
-                if s0 <= off + c < s0 + n:
-                    hit = (s0, n, p1, p2, nblk, ldp)
-                    break
-            if hit is None:
-                # uncovered run up to the next covered column
-                nxt = min([s0 - off for (s0, n, *_r) in have if s0 - off > c] + [self.Cp])
-                segs.append((c, nxt - c, None, None, 0, 0))
-                c = nxt
-            else:
-                s0, n, p1, p2, nblk, ldp = hit
-                skip = off + c - s0
-                take = min(n - skip, self.Cp - c)
-                segs.append((c, take, p1[:, skip:], p2[:, skip:], nblk, ldp))
-                c += take
-        return segs
-
-    def grad_buf(self):
-        """Gradient storage (allocated on first use, uninitialised)."""
-        if self.grad is None:
-            if self.galias is not None:
-                self.grad = self.galias.grad_buf()
-            elif self.parent is not None:
-                self.grad = self.parent.grad_buf()[..., self.c0:self.c0 + self.Cp]
-            else:
-                self.grad = self.eng.alloc(self.t.shape, self.t.dtype)
-        return self.grad
-
-    def grad_sink(self):
-        """-> (tensor, accumulate_flag) for a backward op that contributes to this activation's gradient."""
-        if self._sealed:
-            raise RuntimeError("a gradient contribution arrived after the dgrad that was declared the last one (x_last=True)")
-        g = self.grad_buf()
-        acc = 1 if self.grad_written else 0
-        self.grad_written = True
-        return g, acc
-
-
-class Bnb:
-    """What a dgrad epilogue needs to take the BatchNorm-backward statistics of the gradient it produces (pn2_conv_gemm_ep):
-    raw: the BN's input (raw conv output) as a [N,H,W,C] view; par: [4][C] rows scale, shift, mean, invstd (a view: row stride = par.stride(0));
-    relu: the activation behind the BN; ymask: the stored output (tensor view) when the ReLU mask cannot be recomputed from raw (BN + residual + ReLU).
-    split / raw2 / par2 / tail: a concat buffer whose columns >= split are (a copy of) another BatchNorm's output `tail` (raw2 / par2 indexed by the
-    same local column; par2 None = those columns carry no BatchNorm)."""
-    __slots__ = ("raw", "par", "relu", "ymask", "split", "raw2", "par2", "tail")
-
-    def __init__(self, raw, par, relu, ymask=None, split=0, raw2=None, par2=None, tail=None):
-        self.raw, self.par, self.relu, self.ymask, self.split, self.raw2, self.par2, self.tail = raw, par, relu, ymask, split, raw2, par2, tail
-
-    def cols(self, c0, c1):
-        return Bnb(self.raw[..., c0:c1], self.par[:, c0:c1], self.relu, self.ymask[..., c0:c1] if self.ymask is not None else None)
-
-
-class ParamGrads:
-    """Where parameter gradients go.  Default: fresh fp32 tensors (autograd mode).  The trainer swaps in
-    views of its flat gradient arena so the fused clamp+Adam kernel sees one contiguous buffer."""
-
-    def __init__(self, provider=None):
-        self.provider = provider
-        self.bufs = {}
-        self.written = set()
-        self.counts = {}            # id(p) -> contributions received this step (a weight applied k times per step receives k)
-        self.on_sink = None         # optional hook(key, count): the data-parallel trainer checks that no contribution follows a sent bucket
-
-    def sink(self, p):
-        k = id(p)
-        if k not in self.bufs:
-            self.bufs[k] = self.provider(p) if self.provider else torch.empty_like(p, dtype=torch.float32)
-        acc = 1 if k in self.written else 0
-        self.written.add(k)
-        self.counts[k] = self.counts.get(k, 0) + 1
-        if self.on_sink is not None:
-            self.on_sink(k, self.counts[k])
-        return self.bufs[k], acc
-
-    def get(self, p):
-        return self.bufs.get(id(p)) if id(p) in self.written else None
-
-
-class PackCache:
-    """Persistent packed weight panels + the device job table that refreshes all of them in one launch."""
-
-    def __init__(self):
-        self.entries = {}          # key -> (panel tensor, PackDesc)
-        self.jobs = []             # capi.PackJob (host copies)
-        self.keep = []             # weights referenced by the table (pointers must stay valid)
-        self.table = None
-        self.dt = None
-
-    # a cache hangs off a module parameter on the nn.Module surface: pickling / deep-copying the module must not drag device job tables along
-    def __reduce__(self):
-        return (PackCache, ())
-
-    def __deepcopy__(self, memo):
-        return PackCache()
-
-    def add(self, key, w, wp, d):
-        self.entries[key] = (wp, d)
-        j = capi.PackJob()
-        j.w, j.wp = w.data_ptr(), wp.data_ptr()
-        C.memmove(C.byref(j.d), C.byref(d), C.sizeof(capi.PackDesc))
-        self.jobs.append(j)
-        self.keep.append(w)
-        self.table = None
-        self.dt = key[4]
-
-    def refresh(self):
-        """Repack every cached panel from the current fp32 master weights (call once per step, before forward)."""
-        if not self.jobs:
-            return
-        if self.table is None:
-            self.table, self.bstart, self.nblocks = _job_table(capi.PackJob, self.jobs, [call.pn2_pack_blocks(C.byref(j.d)) for j in self.jobs])
-        call.pn2_pack_weights_multi(self.dt, _p(self.table), _p(self.bstart), len(self.jobs), self.nblocks, _stream())
-
-
-class BnFoldCache:
-    """Folded eval-mode BatchNorm rows (scale, shift) of a model's layers, persistent across forwards and refreshed from the live gamma / beta / running
-    statistics by ONE table-driven launch per forward (pn2_bn_eval_prepare_multi) - inside a captured inference graph that is one node instead of one per layer."""
-
-    def __init__(self):
-        self.entries = {}          # (id(bn), Cp, gw, gwp) -> [2][Cp] fp32 rows scale, shift
-        self.jobs, self.keep, self.table = [], [], None
-
-    def __reduce__(self):
-        return (BnFoldCache, ())
-
-    def __deepcopy__(self, memo):
-        return BnFoldCache()
-
-    def stale(self):
-        return any(j.gamma != bn.weight.data_ptr() or j.running_mean != bn.running_mean.data_ptr() for j, bn in zip(self.jobs, self.keep))
-
-    def add(self, key, bn, par, bd, off=0):
-        """register `bn` (rows par[0][off:], par[1][off:]); `key` -> par for the lookup (several BatchNorms may share one [2][sum C] block)"""
-        self.entries[key] = par
-        j = capi.BnPrepJob()
-        j.gamma, j.beta, j.running_mean, j.running_var = bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-        j.scale, j.shift = par[0][off:].data_ptr(), par[1][off:].data_ptr()
-        C.memmove(C.byref(j.d), C.byref(bd), C.sizeof(capi.BnDesc))
-        self.jobs.append(j)
-        self.keep.append(bn)
-        self.table = None
-
-    def refresh(self):
-        if not self.jobs:
-            return
-        if self.table is None:
-            self.table, self.bstart, self.nblocks = _job_table(capi.BnPrepJob, self.jobs, [(j.d.Cp + 255) // 256 for j in self.jobs])
-        call.pn2_bn_eval_prepare_multi(_p(self.table), _p(self.bstart), len(self.jobs), self.nblocks, _stream())
-
-
-def _job_table(struct, jobs, blocks):
-    """-> (device copy of the job array, device prefix sums of the per-job workgroup counts, total workgroups)."""
-    if min(blocks) < 1:
-        raise RuntimeError("job with an unsupported geometry in a table-driven launch")
-    arr = (struct * len(jobs))(*jobs)
-    table = torch.frombuffer(bytearray(bytes(memoryview(arr).cast("B"))), dtype=torch.uint8).cuda()
-    start = [0]
-    for b in blocks:
-        start.append(start[-1] + b)
-    return table, torch.tensor(start, dtype=torch.int32).cuda(), start[-1]
-
-
-class StepArena:
-    """Bump allocator for everything an Engine allocates during one training step.  The first step runs on the torch allocator
-    and measures the footprint; later steps carve the same sequence of buffers out of one persistent block, so every activation,
-    gradient and scratch buffer has the SAME address in every step (eager or inside a captured hipGraph).  That is what lets the
-    deferred, table-driven launches (GradQueue) reuse their device job tables, and it takes the allocator off the eager path.
-    Sized for a 288 GB part: nothing is recycled inside a step."""
-
-    def __init__(self):
-        self.buf, self.off, self.need = None, 0, 0
-
-    def begin_step(self, dev):
-        want = self.need
-        if want and (self.buf is None or self.buf.numel() < want) and not torch.cuda.is_current_stream_capturing():
-            self.buf = None
-            self.buf = torch.empty(want, dtype=torch.uint8, device=dev)
-        self.off, self.need = 0, 0
-
-    def alloc(self, shape, dtype, dev):
-        n = dtype.itemsize
-        for d in shape:
-            n *= d
-        na = (n + 255) // 256 * 256
-        self.need += na
-        if self.buf is not None and self.off + na <= self.buf.numel():
-            t = self.buf[self.off:self.off + n].view(dtype).view(shape)
-            self.off += na
-            return t
-        return torch.empty(shape, dtype=dtype, device=dev)
-
-
-TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the tuners time every candidate behind a cache-evicting fill (tests/conftest.py switches it off)
-WGRAD_WGS = 640               # pixel splits: workgroups a single wgrad aims at ...
-WGRAD_SLAB_MB = 24            # ... within this many MB of fp32 slabs
-_THRASH = {}
-
-
-def _thrash():
-    """Overwrite 512 MB (more than the L2s and the 256 MB memory-side cache) so that the next kernel starts from HBM."""
-    dev = torch.cuda.current_device()
-    t = _THRASH.get(dev)
-    if t is None:
-        t = _THRASH[dev] = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
-    t.fill_(1)
-
-
-DEFER_COLSUM = os.environ.get("PN2_DEFER_COLSUM", "1") == "1"
-SMALL_CIN_DGRAD = os.environ.get("PN2_SMALL_CIN_DGRAD", "1") == "1"  # strided convs with <= 4 input channels: per-pixel data gradient
-GRAD_ALIAS = os.environ.get("PN2_GRAD_ALIAS", "1") == "1"             # sums whose second operand has no other consumer share its gradient storage
-SPLITK = os.environ.get("PN2_SPLITK", "1") == "1"                     # split-K for few-row / long-contraction convs
-KSPLIT_MINK = 4096            # shortest contraction that is split (M <= 4096 rows; shorter ones lose to the partial-tile traffic)
-PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space
-FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
-BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
-LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
-MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
-EVAL_FUSE = True          # eval mode: conv + BatchNorm (+ ReLU) (+ residual) in ONE launch (pn2_conv_gemm_affine); tests switch it off to compare with the two-launch path
-ZERO_CROP_SKIP = os.environ.get("PN2_ZERO_CROP_SKIP", "1") == "1"   # K = 1 DSRA: the crop maps' gradient is identically zero - skip the adjoints of the resamples that made them
-
-
-class GradQueue:
-    """Deferred weight-gradient work of one training step.  A conv's wgrad and the split-K slab reduction that follows it only
-    feed the optimizer, so the backward pass queues them (dy / x stay alive in the step arena) and `flush()` runs them as a few
-    table-driven launches: one pn2_conv_wgrad_multi per kernel instantiation, then one pn2_wgrad_reduce_multi.  Device job tables
-    are cached per flush segment and reused for as long as the queued pointers are unchanged (always, with a StepArena)."""
-
-    def __init__(self, defer_wgrad=True):
-        self.defer_wgrad = defer_wgrad
-        self.slabs = {}
-        self.cache = {}                   # segment index -> (signature, launches)
-        self.ccache = {}                  # same for the engine's queued column-sum finalisations
-        self.begin_step()
-
-    def begin_step(self):
-        self.seg = 0
-        self.wjobs, self.rjobs, self.keep = [], [], []
-        self.uses, self.levels = {}, {}
-
-    def slab(self, key, shape, dev):
-        # a weight applied twice in one step (CAB's shared fc1 / fc2 on the average- and max-pooled vectors) needs a slab per use: the
-        # deferred wgrads of both uses run before either reduction
-        n = self.uses.get(key, 0)
-        self.uses[key] = n + 1
-        key = key + (n,)
-        t = self.slabs.get(key)
-        if t is None or tuple(t.shape) != tuple(shape):
-            if t is not None:
-                raise RuntimeError("wgrad slab geometry changed between steps; build a new Trainer for a new input shape")
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("run eager steps before capturing (persistent wgrad slabs are allocated then)")
-            t = self.slabs[key] = torch.empty(shape, dtype=torch.float32, device=dev)
-        return t
-
-    def add_wgrad(self, dt, dy, x_ptr, x_keep, slab, wd, nsplit, flops=0):
-        self.wjobs.append((dt, dy.data_ptr(), x_ptr.value, slab.data_ptr(), wd, nsplit, flops))
-        self.keep.append((dy, x_keep))
-
-    def add_reduce(self, slab, gw, rd, nsplit, accumulate):
-        # a weight applied more than once in a step (CAB's shared fc1 / fc2): the k-th contribution to a gradient goes into reduction level k of
-        # this segment - one pn2_wgrad_reduce_multi per level, launched in order - instead of cutting the segment (the wgrads themselves
-        # write private slabs and need no order)
-        lvl = self.levels.get(gw.data_ptr(), 0)
-        if accumulate and lvl == 0:
-            self.flush()          # the earlier contribution was not queued here (an immediate kernel): it must be finished first
-            lvl = 0
-        self.levels[gw.data_ptr()] = lvl + 1
-        self.rjobs.append((slab.data_ptr(), gw.data_ptr(), rd, nsplit, accumulate, lvl))
-
-    def _build(self):
-        launches = []
-        groups = {}
-        for dt, dy, x, slab, wd, ns, fl in self.wjobs:
-            v = call.pn2_conv_wgrad_variant(dt, C.byref(wd))
-            if v < 0:
-                raise RuntimeError("unsupported wgrad geometry")
-            groups.setdefault((dt, v), []).append((dy, x, slab, wd, ns, fl))
-        for (dt, v), js in sorted(groups.items()):
-            # longest workgroups first (pixels per split x taps): the hardware hands out workgroups in index order, so the short jobs fill the
-            # tail of the launch instead of the long ones stretching it
-            js = sorted(js, key=lambda j: -((j[3].N * j[3].OH * j[3].OW + j[4] - 1) // j[4]) * j[3].KH * j[3].KW)
-            arr = []
-            for dy, x, slab, wd, ns, fl in js:
-                j = capi.WgradJob()
-                j.dy, j.x, j.slab, j.nsplit = dy, x, slab, ns
-                C.memmove(C.byref(j.d), C.byref(wd), C.sizeof(capi.WgradDesc))
-                arr.append(j)
-            table, bstart, nblocks = _job_table(capi.WgradJob, arr, [call.pn2_conv_wgrad_blocks(C.byref(j.d), j.nsplit) for j in arr])
-            launches.append(("w", dt, v, table, bstart, len(arr), nblocks, sum(j[5] for j in js)))
-        for lvl in sorted({j[5] for j in self.rjobs}):
-            arr = []
-            for slab, gw, rd, ns, acc, l_ in self.rjobs:
-                if l_ != lvl:
-                    continue
-                j = capi.ReduceJob()
-                j.slab, j.gw, j.nsplit, j.accumulate = slab, gw, ns, acc
-                C.memmove(C.byref(j.d), C.byref(rd), C.sizeof(capi.PackDesc))
-                arr.append(j)
-            table, bstart, nblocks = _job_table(capi.ReduceJob, arr, [call.pn2_wgrad_reduce_blocks(C.byref(j.d)) for j in arr])
-            launches.append(("r", 0, 0, table, bstart, len(arr), nblocks, 0))
-        return launches
-
-    def flush(self):
-        """Launch what was queued since the previous flush."""
-        if not self.wjobs and not self.rjobs:
-            return
-        sig = (tuple(j[:4] + (j[5],) for j in self.wjobs), tuple(j[:2] + j[3:] for j in self.rjobs))
-        hit = self.cache.get(self.seg)
-        if hit is None or hit[0] != sig:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("run two eager steps before capturing (the deferred-launch tables are built then)")
-            hit = self.cache[self.seg] = (sig, self._build())
-        st = _stream()
-        for kind, dt, v, table, bstart, njobs, nblocks, flops in hit[1]:
-            if kind == "w":
-                capi.WORK.update(flops=flops, tag="", shape=f"variant{v} jobs{njobs}")
-                call.pn2_conv_wgrad_multi(dt, v, _p(table), _p(bstart), njobs, nblocks, st)
-            else:
-                call.pn2_wgrad_reduce_multi(_p(table), _p(bstart), njobs, nblocks, st)
-        self.seg += 1
-        self.wjobs, self.rjobs, self.keep = [], [], []
-        self.levels = {}
-
-
-class Engine:
+class Engine(ConvOps, EncoderOps, SpatialOps):
     def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None, grad_queue=None, arena=None, lock_cache=None,
                  bn_fold=None):
         self.bn_fold = bn_fold          # BnFoldCache: eval-mode BatchNorm rows kept across forwards (the caller refreshes it once per forward); None = one prepare launch per layer
@@ -581,7 +127,7 @@ class Engine:
         kind at a position as ONE table-driven launch (pn2/lockstep.py) - forward and backward.  `key` names the region (stable across steps).
         Needs a persistent table cache (the trainer's); without one, or inside another lock-step region, the chains simply run one after the other."""
         from . import lockstep as LS
-        if not LOCKSTEP or self.lock_cache is None or LS._ACTIVE or len(fns) < 2:
+        if not core.LOCKSTEP or self.lock_cache is None or LS._ACTIVE or len(fns) < 2:
             self._in_region = getattr(self, "_in_region", 0) + 1
             try:
                 return [f() for f in fns]
@@ -620,1412 +166,6 @@ class Engine:
                 r.emit()
             self.record(bwd)
         return outs
-
-    # ------------------------------------------------------------------ weights
-    def _pack_desc(self, w, x_map, out_map, transposed):
-        Cout, Cin, KH, KW = _w4(w)
-        gw_in, gwp_in, Cin_p = x_map
-        gw_out, gwp_out, Cout_p = out_map
-        d = capi.PackDesc()
-        d.Cout, d.Cin, d.KH, d.KW = Cout, Cin, KH, KW
-        d.Cout_p, d.gw_out, d.gwp_out = Cout_p, gw_out, gwp_out
-        d.Cin_p, d.gw_in, d.gwp_in = Cin_p, gw_in, gwp_in
-        d.transposed = 1 if transposed else 0
-        if transposed:
-            d.Rp, d.Kp = rup(Cin_p, 128), rup(KH * KW * Cout_p, 128)
-        else:
-            d.Rp, d.Kp = rup(Cout_p, 128), rup(KH * KW * Cin_p, 128)
-        return d
-
-    def pack(self, w, x_map, out_map, transposed):
-        """K-contiguous weight panel in the compute dtype.  With a pack cache (trainer) the panel is persistent and is
-        refreshed for ALL convs by one pn2_pack_weights_multi launch per step instead of one launch per conv."""
-        cache = self.pack_cache
-        key = (id(w), bool(transposed), x_map, out_map, self.dt)
-        if cache is not None and key in cache.entries:
-            return cache.entries[key]
-        d = self._pack_desc(w, x_map, out_map, transposed)
-        wp = torch.empty((d.Rp, d.Kp), dtype=self.tdt, device=self.dev)
-        call.pn2_pack_weight(self.dt, _p(w), _p(wp), C.byref(d), _stream())
-        if cache is not None:
-            cache.add(key, w, wp, d)
-        return wp, d
-
-    # ------------------------------------------------------------------ per-shape kernel / tile selection
-    def _tune_gemm(self, cd, in_ptr, wp, M, Cout, ep=None):
-        """Pick (kernel, BM, BN) for this forward/dgrad shape by timing every candidate once (first eager step; results are cached in
-        self.tuner and reused under hipGraph capture).  Returns the code for pn2_conv_desc.flags bits 8..15 (0 = library heuristic).
-        ep: the launch carries a BatchNorm-backward epilogue (pn2_conv_gemm_ep): the candidates are timed WITH it (its extra operand reads and
-        per-tile work favour other tiles than the plain kernel), writing to scratch destinations."""
-        t = self.tuner
-        if t is None or self.dt != BF16:
-            return 0
-        key = ("g", cd.N, cd.H, cd.W, cd.OH, cd.OW, cd.Cin_p, cd.ld_in, Cout, cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w, cd.transposed)
-        if ep is not None:
-            key = key + ("ep", ep.a.mode, ep.b.mode, 1 if ep.b.out else 0, cd.flags & capi.CONV_ACCUM)
-        if key in t:
-            return t[key]
-        if torch.cuda.is_current_stream_capturing():
-            return 0
-        from . import lockstep as LS
-        with LS.pause():                 # the candidates are timed with real launches even inside a lock-step region
-            return self._tune_gemm_run(t, key, cd, in_ptr, wp, M, Cout, ep)
-
-    def _tune_gemm_run(self, t, key, cd, in_ptr, wp, M, Cout, ep):
-        st = _stream()
-        nul = C.c_void_p(0)
-        scratch = torch.empty((M, Cout), dtype=torch.bfloat16, device=self.dev)
-        d2 = capi.ConvDesc()
-        C.memmove(C.byref(d2), C.byref(cd), C.sizeof(capi.ConvDesc))
-        d2.ld_out, d2.Cout = Cout, Cout
-        if ep is not None:
-            d2.flags = cd.flags & capi.CONV_ACCUM
-            e2 = capi.ConvEp()
-            C.memmove(C.byref(e2), C.byref(ep), C.sizeof(capi.ConvEp))
-            nb64 = (M + 63) // 64
-            tp = torch.empty((4, nb64, Cout), dtype=torch.float32, device=self.dev)
-            e2.a.p1, e2.a.p2, e2.a.ldp = tp[0].data_ptr(), tp[1].data_ptr(), Cout
-            if ep.b.out:
-                scratch_b = torch.empty((M, Cout), dtype=torch.bfloat16, device=self.dev)
-                e2.b.out, e2.b.ld_out = scratch_b.data_ptr(), Cout
-                e2.b.p1, e2.b.p2, e2.b.ldp = tp[2].data_ptr(), tp[3].data_ptr(), Cout
-            base = d2.flags
-
-            def launch(code):
-                d2.flags = base | (code << 8)
-                call.pn2_conv_gemm_ep(self.dt, in_ptr, _p(wp), _p(scratch), C.byref(d2), C.byref(e2), st)
-        else:
-            def launch(code):
-                d2.flags = code << 8
-                call.pn2_conv_gemm(self.dt, in_ptr, _p(wp), _p(scratch), nul, nul, C.byref(d2), st)
-        cands = []
-        for kern in (1, 2, 3):             # 1 register-staged, 2 LDS-DMA with a 3-stage ring, 3 LDS-DMA with a 2-stage ring (more workgroups per CU)
-            for bm in (1, 2):
-                if bm == 2 and M <= 64:
-                    continue
-                for bn in (1, 2, 3):
-                    if (bn == 2 and Cout <= 32) or (bn == 3 and Cout <= 64):
-                        continue
-                    cands.append(kern | (bm << 2) | (bn << 4))
-        evs = []
-        feasible = []
-        for code in cands:
-            try:
-                launch(code)
-            except RuntimeError as err:       # status -4 only: the epilogue's operand tiles of this tile shape do not fit the LDS; anything else is a real failure
-                if "status -4" not in str(err):
-                    raise
-                continue
-            feasible.append(code)
-            per = []
-            for _ in range(TUNE_REPS):
-                if TUNE_COLD:       # inside a step every conv runs once, on operands the caches have mostly lost: time it that way
-                    _thrash()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                launch(code)
-                e1.record()
-                per.append((e0, e1))
-            evs.append(per)
-        torch.cuda.synchronize()
-        times = [min(a.elapsed_time(b) for a, b in per) for per in evs]
-        if not feasible:
-            raise RuntimeError(f"no conv kernel candidate could be launched for {key}")
-        best = feasible[min(range(len(feasible)), key=lambda i: times[i])]
-        t[key] = best
-        return best
-
-    def _ksplit(self, M, K, Cout_p):
-        """Split-K factor for a conv GEMM with M output rows and contraction K (bf16 LDS-DMA kernels only).  Measured on cold operands
-        (tools/splitk_micro.py): 4 pays for K >= 4096 with M <= 4096 (5x5, 256 channels, 11x11 maps: 66 -> 49 us); shorter contractions lose
-        to the partial-tile traffic."""
-        if not SPLITK or self.dt != BF16 or K < KSPLIT_MINK or M > 4096 or Cout_p % 8:
-            return 1
-        return 4
-
-    def _stat_blocks(self, M, Cout, tune):
-        bm = (tune >> 2) & 3
-        if bm:
-            b = 64 if bm == 1 else 128
-            return (M + b - 1) // b
-        return call.pn2_conv_stat_blocks(M, Cout, self.dt)
-
-    def _tune_wgrad(self, wd, dy_ptr, x_ptr, rd, nsplit, wshape):
-        """-> (kernel code, pixel splits) for this wgrad shape.  Candidates: register-staged / LDS-DMA / LDS-DMA with 128 x 256 tiles x
-        {1, 1/2, 1/4, 1/8} of the heuristic split count; each is timed together with the slab reduction its split count implies."""
-        t = self.tuner
-        if t is None or self.dt != BF16:
-            return 0, nsplit
-        key = ("w", wd.N, wd.H, wd.W, wd.OH, wd.OW, wd.Cin_p, wd.ld_x, wd.Cout_p, wd.ld_dy, wd.KH, wd.KW, wd.stride, wd.pad_h, wd.pad_w, wd.dil_h, wd.dil_w, nsplit)
-        if key in t:
-            return t[key]
-        if torch.cuda.is_current_stream_capturing():
-            return 0, nsplit
-        from . import lockstep as LS
-        with LS.pause():
-            return self._tune_wgrad_run(t, key, wd, dy_ptr, x_ptr, rd, nsplit, wshape)
-
-    def _tune_wgrad_run(self, t, key, wd, dy_ptr, x_ptr, rd, nsplit, wshape):
-        st = _stream()
-        slab = torch.empty((nsplit, wd.Rp, wd.Kp), dtype=torch.float32, device=self.dev)
-        gw = torch.empty(tuple(wshape), dtype=torch.float32, device=self.dev)
-        codes = (1, 2, 3) if (call.pn2_wgrad_tile_co(wd.Cout_p) == 128 and wd.Kp >= 256) else (1, 2)      # 3: LDS-DMA kernel with 128 x 256 tiles
-        cands = [(code, ns) for ns in sorted({max(1, nsplit >> k) for k in range(4)}, reverse=True) for code in codes]
-        evs = []
-
-        def run(code, ns):
-            wd.tune = code
-            call.pn2_conv_wgrad(self.dt, dy_ptr, x_ptr, _p(slab), C.byref(wd), ns, st)
-            call.pn2_wgrad_reduce(_p(slab), _p(gw), C.byref(rd), ns, 0, st)
-        for code, ns in cands:
-            run(code, ns)
-            per = []
-            for _ in range(TUNE_REPS):
-                if TUNE_COLD:       # the deferred wgrads run long after dy / x were produced: cold operands
-                    _thrash()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                run(code, ns)
-                e1.record()
-                per.append((e0, e1))
-            evs.append(per)
-        torch.cuda.synchronize()
-        times = [min(a_.elapsed_time(b_) for a_, b_ in per) for per in evs]
-        best = cands[min(range(len(cands)), key=lambda i: times[i])]
-        t[key] = best
-        return best
-
-    # ------------------------------------------------------------------ conv (+BN +ReLU +residual)
-    def conv_bn_act(self, x, conv, bn=None, relu=False, residual=None, out=None, out_map=None, y_dt=None, y_C=None, bias=None, sum_with=None,
-                    raw_out=None, par_out=None, x_last=False, gate=None):
-        """y = act(BN(conv(x)) + residual)   — BasicConv2d / Bottle2neck pieces.
-
-        conv: nn.Conv2d (bias-free unless `bias` given), bn: nn.BatchNorm2d or None.
-        out: optional destination Act view (writes y into a slice of a concat buffer).
-        out_map: (gw, gwp) group-padded layout of the produced channels (default identity).
-        y_dt/y_C: fp32 K-channel head outputs (physical raw output stays padded to 8).
-        sum_with: an Act of the output's geometry that has no other consumer; returns (y, y + sum_with) - the second tensor (Bottle2neck's
-                  sp + spx[i+1]) is written by the same pass and keeps its gradient in sum_with's gradient storage.
-        raw_out / par_out: where the raw conv output ([N,OH,OW,Cout_p] view) and the BatchNorm's per-channel rows (scale, shift, mean, invstd:
-                  a [4][Cout_p] view) go - channel slices of buffers shared by the convs that write one concat buffer (Engine.concat_bnb).
-        gate:     a 1-channel fp32 Act of x's geometry in front of a 1x1 conv: the conv sees (1 - sigmoid(gate)) * x (V1 reverse attention,
-                  PraNet_Res2Net.py:153-155).  The per-pixel factor is applied to the GEMM's accumulator rows (pn2_conv_gemm_gated) - the gated copy
-                  of x is never written; backward: one pass over (raw, dz) of the conv's OUTPUT width, then plain dgrad / wgrad.
-        x_last:   the caller guarantees that this conv's data gradient is the LAST contribution to x's gradient (x's first consumer in forward
-                  order).  If x is the output of a train-mode BatchNorm, the dgrad GEMM then takes that BatchNorm's backward statistics in its
-                  epilogue (pn2_conv_gemm_ep) and x's producer skips its pn2_bn_bwd_reduce pass.
-        """
-        w = conv.weight
-        Cout, Cin, KH, KW = _w4(w)
-        sh, sw = conv.stride
-        assert sh == sw and conv.groups == 1
-        ph, pw = conv.padding
-        dh, dw = conv.dilation
-        assert x.C == Cin, (x.C, Cin)
-        N, H, W = x.N, x.H, x.W
-        OH = (H + 2 * ph - dh * (KH - 1) - 1) // sh + 1
-        OW = (W + 2 * pw - dw * (KW - 1) - 1) // sw + 1
-        gw_o, gwp_o = out_map if out_map is not None else (Cout, rup(Cout, 8))
-        Cout_p = (Cout + gw_o - 1) // gw_o * gwp_o
-        x_map = (x.gw, x.gwp, x.Cp)
-        o_map = (gw_o, gwp_o, Cout_p)
-        M = N * OH * OW
-        st = _stream()
-        train_bn = bn is not None and self.training
-        V = 4 if self.dt == F32 else 8
-
-        wp, pd = self.pack(w, x_map, o_map, False)
-        # biased conv / nn.Linear with nothing behind it (no BN, activation, residual or re-layout): the bias goes into the GEMM epilogue and
-        # the GEMM writes the output itself - no separate affine pass
-        fuse_bias = (FUSE_BIAS and bn is None and bias is not None and not relu and residual is None and out is None and y_C is None
-                     and (y_dt is None or y_dt == self.dt))
-        if fuse_bias:
-            out = Act(self, self.empty(N, OH, OW, Cout_p), Cout, gw_o, gwp_o, self.dt)
-            raw = out.t
-            if Cout_p == Cout:
-                bvec = bias.detach()
-            else:
-                bvec = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
-                bvec[:Cout] = bias.detach()
-        elif raw_out is not None:
-            assert tuple(raw_out.shape) == (N, OH, OW, Cout_p) and raw_out.dtype == self.tdt and raw_out.stride(2) % V == 0
-            raw = raw_out
-        else:
-            raw = self.empty(N, OH, OW, Cout_p)
-        raw_ld = raw.stride(2)
-        cd = capi.ConvDesc()
-        cd.N, cd.H, cd.W, cd.OH, cd.OW = N, H, W, OH, OW
-        cd.Cin_p, cd.ld_in, cd.Cout, cd.ld_out = x.Cp, x.ld, Cout_p, raw_ld
-        cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = KH, KW, sh, ph, pw, dh, dw
-        cd.transposed, cd.Kp, cd.flags = 0, pd.Kp, (capi.CONV_STATS if train_bn else 0)
-        psum = psq = None
-        tune = self._tune_gemm(cd, x.ptr, wp, M, Cout_p)
-        cd.flags |= tune << 8
-        if (EVAL_FUSE and bn is not None and not self.training and not self.need_grad and gate is None and sum_with is None and y_C is None and not fuse_bias
-                and (y_dt is None or y_dt == self.dt) and self._ksplit(M, KH * KW * x.Cp, Cout_p) == 1 and relu in (False, True, 2)
-                and (residual is None or (residual.dt == self.dt and residual.ld % V == 0 and Cout_p % V == 0 and (out is None or out.ld % V == 0)))):
-            # eval mode (MyTest_med.py:98-104, the in-training evaluation): the folded BatchNorm, the activation and the residual add ride in the GEMM epilogue -
-            # no raw conv output, no separate normalise pass (half the launches and half the activation traffic of the layer)
-            scale, shift = self._bn_eval_rows(bn, M, Cout_p, Cout, gw_o, gwp_o, bias)
-            if out is None:
-                out = Act(self, self.empty(N, OH, OW, Cout_p), Cout, gw_o, gwp_o, self.dt)
-            if residual is not None:
-                assert residual.Cp == Cout_p
-            cd.ld_out = out.ld
-            cd.flags = (tune << 8) | capi.CONV_AFFINE | (capi.CONV_RELU6 if relu == 2 else (capi.CONV_RELU if relu else 0))
-            capi.WORK.update(flops=2 * M * Cout * Cin * KH * KW, tag=":fwd", shape=f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}")
-            call.pn2_conv_gemm_affine(self.dt, x.ptr, _p(wp), out.ptr, _p(scale), _p(shift), residual.ptr if residual is not None else C.c_void_p(0),
-                                      residual.ld if residual is not None else 0, C.byref(cd), st)
-            return out
-        tile_rows = 0
-        if train_bn:
-            nblk = self._stat_blocks(M, Cout_p, tune)
-            tile_rows = self._tile_m(M, Cout_p, tune)
-            psum, psq = self.fbuf(nblk, Cout_p), self.fbuf(nblk, Cout_p)
-        flops = 2 * M * Cout * Cin * KH * KW
-        shape = f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}"
-        capi.WORK.update(flops=flops, tag=":fwd", shape=shape)
-        ksplit = self._ksplit(M, KH * KW * x.Cp, Cout_p)
-        if gate is not None:
-            assert (KH, KW, sh) == (1, 1, 1) and gate.dt == F32 and gate.C == 1 and gate.M == M and bias is None, "the fused gate sits in front of a bias-free 1x1 conv"
-            ksplit = 1
-            call.pn2_conv_gemm_gated(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), gate.ptr, st)
-        elif ksplit > 1:
-            # few output rows, long contraction (the 5x5 convs of the ra4 branch on 11x11 maps): the K loop of every tile is shared by ksplit
-            # workgroups that leave fp32 partial tiles; the reduce sums them and takes the BatchNorm statistics / adds the bias
-            ws = self.fbuf(ksplit, M, Cout_p)
-            cd.flags = ((2 | (1 << 2) | ((3 if Cout_p > 64 else 2) << 4)) << 8) | (ksplit << 16)
-            if train_bn:
-                nblk, tile_rows = (M + 63) // 64, 0          # the reduce leaves raw moments of 64-row blocks
-                psum, psq = self.fbuf(nblk, Cout_p), self.fbuf(nblk, Cout_p)
-            call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(ws), _p(None), C.byref(cd), st)
-            call.pn2_conv_splitk_reduce(self.dt, _p(ws), ksplit, M, Cout_p, _p(raw), raw_ld, _p(bvec) if fuse_bias else _p(None),
-                                        _p(psum) if train_bn else _p(None), _p(psq) if train_bn else _p(None), 0, st)
-        elif fuse_bias:
-            cd.flags |= capi.CONV_BIAS
-            call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(bvec), _p(None), C.byref(cd), st)
-        else:
-            call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), st)
-
-        scale = shift = mean = invstd = par = None
-        bd = None
-        if bn is not None:
-            bd = capi.BnDesc()
-            bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, Cout_p, Cout, gw_o, gwp_o, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
-            bd.tile_rows = tile_rows
-            par = par_out if par_out is not None else self.fbuf(4, Cout_p)          # rows: scale, shift, mean, invstd
-            assert tuple(par.shape) == (4, Cout_p) and par.stride(1) == 1
-            scale, shift = par[0], par[1]
-            if train_bn:
-                mean, invstd = par[2], par[3]
-                call.pn2_bn_finalize(_p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
-                                     _p(scale), _p(shift), _p(mean), _p(invstd), st)
-                self.bn_modules.append(bn)
-                if bias is not None:          # biased conv followed by train-mode BN: the output is unchanged, only the running mean sees the bias
-                    with torch.no_grad():
-                        bn.running_mean.add_(bias.detach(), alpha=bd.momentum)
-            else:
-                call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), st)
-                if bias is not None:
-                    shift[:Cout] += bias.detach() * scale[:Cout]
-        elif bias is not None:
-            if Cout_p == Cout:
-                shift = bias.detach()
-            else:
-                shift = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
-                shift[:Cout] = bias.detach()
-
-        y_dt = self.dt if y_dt is None else y_dt
-        if out is None:
-            if y_C is not None:
-                out = Act(self, self.empty(N, OH, OW, y_C, y_dt), y_C, y_C, y_C, y_dt)
-            else:
-                out = Act(self, self.empty(N, OH, OW, Cout_p, y_dt), Cout, gw_o, gwp_o, y_dt)
-        ncopy = y_C if y_C is not None else Cout_p
-        if residual is not None:
-            assert residual.Cp == Cout_p and residual.dt == self.dt
-        y2 = None
-        if sum_with is not None and (fuse_bias or residual is not None or y_dt != self.dt or ncopy != Cout_p or sum_with.dt != self.dt
-                                     or (sum_with.N, sum_with.H, sum_with.W, sum_with.Cp) != (N, OH, OW, Cout_p) or out.ld % 8 or sum_with.ld % 8):
-            raise RuntimeError("sum_with needs a plain same-dtype BN/activation output of the same geometry")
-        if sum_with is not None:
-            y2 = Act(self, self.empty(N, OH, OW, Cout_p), Cout, gw_o, gwp_o, self.dt)
-            call.pn2_affine_act_sum(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, Cout_p, _p(scale), _p(shift), (2 if relu == 2 else 1) if relu else 0,
-                                    sum_with.ptr, sum_with.ld, y2.ptr, y2.ld, st)
-            if self.need_grad and sum_with.requires_grad:
-                y2.galias = sum_with            # d(y + s)/ds = 1 and s has no other consumer: the sum's gradient lives in s's gradient storage
-                y2.sum_of = (out, sum_with)
-        elif not fuse_bias:
-            call.pn2_affine_act(self.dt, _p(raw), raw_ld, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
-                                residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
-
-        if not self.need_grad:
-            return out if y2 is None else (out, y2)
-        # the BatchNorm-backward statistics of this output's gradient can be taken by the dgrad GEMM that completes it (x_last of the consumer)
-        bnb_ok = BNB_EPILOGUE and train_bn and not fuse_bias and y_C is None and y_dt == self.dt and relu in (False, True) and out.ld % V == 0 and Cout_p % V == 0
-        if bnb_ok:
-            out.bnb = Bnb(raw, par, bool(relu), out.t if residual is not None else None)
-
-        def bwd():
-            st = _stream()
-            if y2 is not None and y2.grad_written and not y2.dual_done:          # the sum's gradient also flows into y (the other operand holds it already)
-                if y2.galias is not None:
-                    assert not sum_with._written, "sum_with: the aliased operand received another gradient"
-                    sum_with.grad_written = True
-                g2 = y2.grad_buf()
-                go, oacc = out.grad_sink()
-                call.pn2_copy(self.dt, _p(g2), g2.stride(2), self.dt, _p(go), go.stride(2), M, Cout_p, oacc, st)
-                if y2.galias is None and sum_with.requires_grad:
-                    gs, sacc = sum_with.grad_sink()
-                    call.pn2_copy(self.dt, _p(g2), g2.stride(2), self.dt, _p(gs), gs.stride(2), M, Cout_p, sacc, st)
-            dy = out.grad_buf()
-            assert out.grad_written or out.child_written, "conv output never received a gradient"
-            draw = self.empty(N, OH, OW, Cout_p)
-            Cdy = ncopy
-            ymask = out if relu else None
-            r6 = 1 if relu == 2 else 0          # relu: False / True (ReLU) / 2 (ReLU6: the mask also drops the saturated y == 6)
-            msc = msh = None
-            if bnb_ok and relu and residual is None and dy.stride(2) % V == 0:
-                # ReLU mask recomputed from the raw conv output (fmaf(x, scale, shift) > 0, bit-identical to the forward):
-                # the backward passes then do not read y at all
-                ymask, msc, msh = None, scale, shift
-            nul = C.c_void_p(0)
-            if train_bn:
-                coef = self.fbuf(3 * Cout_p)
-                gg, ga = self.pgrads.sink(bn.weight)
-                gb, gba = self.pgrads.sink(bn.bias)
-                assert ga == gba
-                segs = out.find_bstats() if (bnb_ok and dy.stride(2) % V == 0) else None
-                if segs is not None and len(segs) <= 4 and any(s_[2] is not None for s_ in segs):
-                    # (part of) the statistics were left by dgrad epilogues; channel ranges nobody covered get a reduce pass of their own
-                    sg = capi.BnSegs()
-                    sg.nseg = len(segs)
-                    for k_, (c0, nc, p1, p2, nb_, ldp) in enumerate(segs):
-                        if p1 is None:
-                            nb_ = call.pn2_bn_bwd_blocks(M, nc, self.dt)
-                            p1, p2, ldp = self.fbuf(nb_, nc), self.fbuf(nb_, nc), nc
-                            ym = ymask.t[..., c0:c0 + nc] if ymask is not None else None
-                            call.pn2_bn_bwd_reduce(self.dt, out.dt, _p(dy[..., c0:c0 + nc]), dy.stride(2), nc, _p(ym), ym.stride(2) if ym is not None else 0, self.dt,
-                                                   _p(raw[..., c0:c0 + nc]), raw_ld, M, nc, _p(mean[c0:]), _p(invstd[c0:]), _p(p1), _p(p2), nb_,
-                                                   _p(msc[c0:]) if msc is not None else nul, _p(msh[c0:]) if msc is not None else nul, r6, st)
-                        sg.c0[k_], sg.nblk[k_], sg.ldp[k_], sg.p1[k_], sg.p2[k_] = c0, nb_, ldp, p1.data_ptr(), p2.data_ptr()
-                        self._keep.append((p1, p2))
-                    call.pn2_bn_bwd_finalize_seg(C.byref(sg), C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
-                else:
-                    nb = call.pn2_bn_bwd_blocks(M, Cout_p, self.dt)
-                    p1, p2 = self.fbuf(nb, Cout_p), self.fbuf(nb, Cout_p)
-                    call.pn2_bn_bwd_reduce(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
-                                           _p(raw), raw_ld, M, Cout_p, _p(mean), _p(invstd), _p(p1), _p(p2), nb, _p(msc), _p(msh), r6, st)
-                    call.pn2_bn_bwd_finalize(_p(p1), _p(p2), nb, C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
-            else:
-                coef = None
-                if bn is not None:
-                    raise RuntimeError("backward through eval-mode BatchNorm is not supported")
-                if bias is not None and out.dt == F32 and self.dt != F32 or (bias is not None and Cdy != Cout_p):
-                    gb, gba = self.pgrads.sink(bias)          # fp32 K-channel head maps: sum the fp32 gradient itself
-                    call.pn2_bias_grad(_p(dy), M, Cdy, _p(gb), gba, st)
-                    bias_done = True
-                else:
-                    bias_done = bias is None
-            rg, racc = (None, 0)
-            if out.grad_masked:
-                ymask = None                  # dy already carries the ReLU mask (PN2_BNB_STORE_MASKED)
-            if residual is not None and residual.requires_grad:
-                if (out.grad_masked and residual.grad is None and residual.galias is None and residual.parent is None and not residual.grad_written
-                        and tuple(dy.shape) == tuple(residual.t.shape) and dy.dtype == residual.t.dtype and dy.is_contiguous()):
-                    # d(out)/d(residual) = the ReLU mask: the masked dy IS the residual's gradient - share the buffer (it is dead here once dz
-                    # has been formed; later contributions to the residual's gradient accumulate into it in place)
-                    residual.grad = dy
-                    residual.grad_written = True
-                else:
-                    rg, racc = residual.grad_sink()
-            if coef is None and ymask is None and rg is None and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) == Cout_p and dy.is_contiguous():
-                draw = dy               # no BN, no activation, no residual (nn.Linear / biased conv): dz IS dy - no copy pass
-            else:
-                call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
-                                      _p(raw), raw_ld, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
-                                      _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), r6, st)
-            if gate is not None:
-                # dz is the gradient of the GATED GEMM result: dzg = (1 - s) * dz feeds dgrad / wgrad, d gate[m] = -s * sum_c raw[m][c] * dz[m][c]
-                gc_, cacc = gate.grad_sink()
-                dc = self.fbuf(M) if cacc else gc_
-                dzg = draw if draw is not dy else self.alloc((N, OH, OW, Cout_p), self.tdt)
-                call.pn2_ra_gate_post_bwd(self.dt, _p(raw), raw_ld, gate.ptr, _p(draw), Cout_p, _p(dzg), Cout_p, _p(dc), M, Cout_p, st)
-                if cacc:
-                    call.pn2_copy(F32, _p(dc), 1, F32, _p(gc_), 1, M, 1, 1, st)
-                draw = dzg
-            if train_bn:
-                bias_done = bias is None
-            if not bias_done:                                  # biased conv / nn.Linear: db = column sums of dz (~0 under a train-mode BN)
-                gb, gba = self.pgrads.sink(bias)
-                self.colsum(draw, M, Cout_p, Cout, gb, gba)
-            # ---- weight gradient
-            wd = capi.WgradDesc()
-            wd.N, wd.H, wd.W, wd.OH, wd.OW = N, H, W, OH, OW
-            wd.Cin_p, wd.ld_x, wd.Cout_p, wd.ld_dy = x.Cp, x.ld, Cout_p, Cout_p
-            wd.KH, wd.KW, wd.stride, wd.pad_h, wd.pad_w, wd.dil_h, wd.dil_w = KH, KW, sh, ph, pw, dh, dw
-            tco = call.pn2_wgrad_tile_co(Cout_p)
-            wd.Rp, wd.Kp = rup(Cout_p, tco), pd.Kp
-            tiles = (wd.Rp // tco) * (pd.Kp // 128)
-            steps = (M + 31) // 32
-            # pixel splits: enough workgroups to fill 256 CUs twice, >= 4 steps each, slabs capped at 24 MB
-            nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (WGRAD_WGS + tiles - 1) // tiles, (WGRAD_SLAB_MB << 20) // (wd.Rp * wd.Kp * 4) or 1))
-            rd = self._pack_desc(w, x_map, o_map, False)
-            rd.Rp = wd.Rp
-            wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd, nsplit, w.shape)
-            rq = self.grad_queue
-            slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab((id(w), x.M), (nsplit, wd.Rp, wd.Kp), self.dev)
-            gwt, gwa = self.pgrads.sink(w)
-            # wgrad (+ slab reduce) only feeds the parameter gradient: with a gradient queue both are deferred into the table-driven launches of its flush
-            if rq is not None and rq.defer_wgrad:
-                rq.add_wgrad(self.dt, draw, x.ptr, x.t, slab, wd, nsplit, flops)
-                rq.add_reduce(slab, gwt, rd, nsplit, gwa)
-            else:
-                capi.WORK.update(flops=flops, tag="", shape=shape)
-                call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
-                if rq is None:
-                    call.pn2_wgrad_reduce(_p(slab), _p(gwt), C.byref(rd), nsplit, gwa, st)
-                else:
-                    rq.add_reduce(slab, gwt, rd, nsplit, gwa)
-            # ---- data gradient
-            if x.requires_grad and PATCH_DGRAD and KH == sh and KW == sw and KH > 1 and ph == 0 and pw == 0 and dh == 1 and dw == 1 \
-                    and x.gw == x.gwp and gw_o == gwp_o and x.ld == x.Cp:
-                # patchify conv (kernel == stride): every input pixel sees exactly one tap -> GEMM over the patches + depth-to-space
-                gx, gxa = x.grad_sink()
-                taps, Ct = KH * KW, KH * KW * x.Cp
-                Rp2, Kp2 = rup(Ct, 128), rup(Cout_p, 128)
-                wp2 = self.alloc((Rp2, Kp2), self.tdt)
-                call.pn2_pack_patch_weight(self.dt, _p(w), _p(wp2), Cout, Cin, KH, KW, x.Cp, Rp2, Kp2, st)
-                tpatch = self.empty(N, OH, OW, Ct)
-                dd = capi.ConvDesc()
-                dd.N, dd.H, dd.W, dd.OH, dd.OW = N, OH, OW, OH, OW
-                dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Cout_p, Cout_p, Ct, Ct
-                dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = 1, 1, 1, 0, 0, 1, 1
-                dd.transposed, dd.Kp, dd.flags = 0, Kp2, 0
-                dd.flags |= self._tune_gemm(dd, _p(draw), wp2, M, Ct) << 8
-                capi.WORK.update(flops=flops, tag=":dgrad", shape=shape + " patch")
-                call.pn2_conv_gemm(self.dt, _p(draw), _p(wp2), _p(tpatch), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
-                call.pn2_depth_to_space(self.dt, _p(tpatch), Ct, _p(gx), gx.stride(2), N, H, W, OH, OW, KH, x.Cp, gxa, st)
-            elif x.requires_grad and SMALL_CIN_DGRAD and Cin <= 4 and sh > 1 and dh == 1 and dw == 1 and ph == pw and (x.gw == x.gwp or x.Cp == x.gwp) and gw_o == gwp_o \
-                    and Cout_p == Cout and KH * KW * Cout * 16 <= 64 * 1024 and x.ld == x.Cp:
-                # few-channel strided conv (EMCADNet's patch embedding behind the 1 -> 3 stem): only the taps that land on an output pixel
-                gx, gxa = x.grad_sink()
-                capi.WORK.update(flops=flops, tag=":dgrad", shape=shape + " small-cin")
-                call.pn2_conv_dgrad_small_cin(self.dt, _p(draw), Cout_p, _p(w), _p(gx), gx.stride(2), N, H, W, OH, OW, Cout, Cin, KH, KW, sh, ph, gxa, st)
-            elif x.requires_grad:
-                wt, ptd = self.pack(w, x_map, o_map, True)
-                gx, gxa = x.grad_sink()
-                Mx = N * H * W
-                dd = capi.ConvDesc()
-                dd.N, dd.H, dd.W, dd.OH, dd.OW = N, OH, OW, H, W
-                dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Cout_p, Cout_p, x.Cp, gx.stride(2)
-                dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = KH, KW, sh, ph, pw, dh, dw
-                dd.transposed, dd.Kp, dd.flags = 1, ptd.Kp, (capi.CONV_ACCUM if gxa else 0)
-                ks = self._ksplit(Mx, KH * KW * Cout_p, x.Cp) if gx.stride(2) == x.Cp else 1
-                capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
-                dual = x.sum_of is not None and x.galias is x.sum_of[1] and x.sum_of[0].requires_grad
-                if ks > 1:
-                    ws = self.fbuf(ks, Mx, x.Cp)
-                    dd.flags = ((2 | (1 << 2) | ((3 if x.Cp > 64 else 2) << 4)) << 8) | (ks << 16)
-                    call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), _p(ws), C.c_void_p(0), C.byref(dd), st)
-                    call.pn2_conv_splitk_reduce(self.dt, _p(ws), ks, Mx, x.Cp, _p(gx), x.Cp, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), gxa, st)
-                elif BNB_EPILOGUE and x_last and x.Cp % V == 0 and gx.stride(2) % V == 0 and (x.bnb is not None or dual):
-                    ep = capi.ConvEp()
-                    if dual and x.sum_of[0].grad_written:
-                        dd.flags |= capi.CONV_ACCUM
-                    for t_, a_ in ((ep.a, x.sum_of[0] if dual else x), (ep.b, x.sum_of[1] if dual else None)):       # what the tuner needs to know
-                        if a_ is not None and a_.bnb is not None:
-                            self._fill_bnb(t_, a_, 0)
-                    if dual:
-                        ep.b.out = 1
-                    tcode = self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, ep)
-                    dd.flags |= tcode << 8
-                    nbx = self._stat_blocks(Mx, x.Cp, tcode)
-                    ep = capi.ConvEp()
-                    if dual:
-                        # x = u + v (Bottle2neck's sp + spx[i]): the gradient goes to BOTH operands - accumulated into u's (the concat buffer slice
-                        # conv3's dgrad wrote), stored as v's (aliased by x) - each with the statistics of its own BatchNorm
-                        u, v = x.sum_of
-                        gu, gua = u.grad_sink()
-                        assert gu.stride(2) % V == 0
-                        dd.ld_out, dd.flags = gu.stride(2), (dd.flags & ~capi.CONV_ACCUM) | (capi.CONV_ACCUM if gua else 0)
-                        self._fill_bnb(ep.a, u, nbx)
-                        ep.b.out, ep.b.ld_out = gx.data_ptr(), gx.stride(2)
-                        self._fill_bnb(ep.b, v, nbx)
-                        v.grad_written = True
-                        x.dual_done = True
-                        u._sealed = v._sealed = True
-                        call.pn2_conv_gemm_ep(self.dt, _p(draw), _p(wt), _p(gu), C.byref(dd), C.byref(ep), st)
-                    else:
-                        self._fill_bnb(ep.a, x, nbx)
-                        call.pn2_conv_gemm_ep(self.dt, _p(draw), _p(wt), _p(gx), C.byref(dd), C.byref(ep), st)
-                    x._sealed = True
-                else:
-                    dd.flags |= self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp) << 8
-                    call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), C.c_void_p(0), C.c_void_p(0), C.byref(dd), st)
-
-        self.record(bwd)
-        return out if y2 is None else (out, y2)
-
-    def _bn_eval_rows(self, bn, M, Cout_p, Cout, gw_o, gwp_o, bias=None):
-        """-> (scale, shift) fp32 [Cout_p] rows of an eval-mode BatchNorm (bias of the conv in front folded into shift).  With a BnFoldCache the rows persist and
-        were refreshed at the start of this forward; a layer seen for the first time is folded here and joins the cache."""
-        bd = capi.BnDesc()
-        bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, Cout_p, Cout, gw_o, gwp_o, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
-        fold = self.bn_fold if bias is None else None
-        key = (id(bn), Cout_p, gw_o, gwp_o)
-        if fold is not None and key in fold.entries:
-            par = fold.entries[key]
-            return par[0], par[1]
-        par = torch.empty((2, Cout_p), dtype=torch.float32, device=self.dev) if fold is not None else self.fbuf(2, Cout_p)
-        call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(par[0]), _p(par[1]), _stream())
-        if bias is not None:
-            par[1][:Cout] += bias.detach() * par[0][:Cout]
-        if fold is not None:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("run an eager forward before capturing (the BatchNorm fold table is built then)")
-            fold.add(key, bn, par, bd)
-        return par[0], par[1]
-
-    def _tile_m(self, M, Cout, tune):
-        bm = (tune >> 2) & 3
-        return (64 if bm == 1 else 128) if bm else call.pn2_conv_tile_m(M, Cout, self.dt)
-
-    def _fill_bnb(self, t, act, nblk):
-        """Describe `act`'s BatchNorm to a dgrad epilogue target and register the partial rows it will leave."""
-        b = act.bnb
-        if b is None:
-            t.mode = 0
-            return
-        t.mode = capi.BNB_STATS | (capi.BNB_MASK_Y if b.ymask is not None else (capi.BNB_MASK_RAW if b.relu else 0))
-        if b.ymask is not None and MASKED_STORE and nblk and b.split == 0 and act.parent is None:
-            # BN + residual + ReLU: the masked gradient is also the residual branch's gradient - store it masked, the producer aliases it
-            t.mode |= capi.BNB_STORE_MASKED
-            act.grad_masked = True
-        t.raw, t.ld_raw = b.raw.data_ptr(), b.raw.stride(2)
-        if b.ymask is not None:
-            t.y, t.ld_y = b.ymask.data_ptr(), b.ymask.stride(2)
-        t.par, t.ps = b.par.data_ptr(), b.par.stride(0)
-        Cp = act.Cp
-        if b.split:
-            t.split = b.split
-            if b.par2 is not None:
-                t.raw2, t.par2 = b.raw2.data_ptr(), b.par2.data_ptr()
-        if nblk == 0:               # description only (the tuner supplies its own partial rows)
-            return
-        p1, p2 = self.fbuf(nblk, Cp), self.fbuf(nblk, Cp)
-        t.p1, t.p2, t.ldp = p1.data_ptr(), p2.data_ptr(), Cp
-        if b.split:
-            t.split = b.split
-            if b.par2 is not None:
-                assert b.raw2.stride(2) == b.raw.stride(2) and b.par2.stride(0) == b.par.stride(0)
-                t.raw2, t.par2 = b.raw2.data_ptr(), b.par2.data_ptr()
-                b.tail.add_bstats(0, Cp - b.split, p1[:, b.split:], p2[:, b.split:], nblk, Cp)
-            act.add_bstats(0, b.split, p1, p2, nblk, Cp)
-        else:
-            act.add_bstats(0, Cp, p1, p2, nblk, Cp)
-
-    def concat_bnb(self, cat, raw, par, split=0, tail=None):
-        """Declare that the channels [0, split or all) of the concat buffer `cat` were written by train-mode conv+BN(+ReLU) ops whose raw outputs /
-        parameter rows sit in the matching channel slices of `raw` / `par` (conv_bn_act(raw_out=, par_out=)); channels >= split are a copy of the
-        BN+ReLU output `tail` (None: they carry no BatchNorm).  The dgrad that completes cat's gradient can then take all those BatchNorms'
-        backward statistics in one epilogue."""
-        if not (BNB_EPILOGUE and self.need_grad and self.training):
-            return
-        tb = tail.bnb if tail is not None else None
-        if tail is not None and (tb is None or not tb.relu or tb.ymask is not None):
-            return
-        r2 = p2 = None
-        if tb is not None:
-            # raw2 / par2 are indexed with cat's local column: shift the tail's views back by `split` columns
-            tr, off = tail.root()
-            rb = tr.bnb
-            if rb is None or off != split or rb.raw.stride(2) != raw.stride(2) or rb.par.stride(0) != par.stride(0):
-                return
-            r2, p2 = rb.raw, rb.par
-        cat.bnb = Bnb(raw, par, True, None, split, r2, p2, tail)
-
-    # ------------------------------------------------------------------ fused 1x1 reducers sharing one input
-    def conv_bn_multi(self, x, mods):
-        """[BN_j(conv_j(x)) for j] for bias-free 1x1 / stride-1 BasicConv2d-style modules `mods` (each has .conv, .bn; no ReLU).
-
-        The RFB branches, conv_res and the RA stage's conv1 all read the same encoder map (pranet.py:52,55,61,67,73,303,312,320):
-        their weights are packed side by side into ONE panel so the map is read once in forward, dx is written once in dgrad
-        (instead of J read-modify-write passes) and wgrad reads it once.  BatchNorm stays per module (own gamma/beta/running stats).
-        Returns the channel-slice views of the fused [M][sum Cout] output."""
-        convs = [m.conv for m in mods]
-        for c in convs:
-            assert c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0) and c.bias is None and c.in_channels == x.C
-        couts = [c.out_channels for c in convs]
-        assert all(co % 8 == 0 for co in couts)
-        offs = [sum(couts[:j]) for j in range(len(couts))]
-        Ct = sum(couts)
-        N, H, W = x.N, x.H, x.W
-        M = N * H * W
-        st = _stream()
-        train = self.training
-        x_map = (x.gw, x.gwp, x.Cp)
-        Kp = rup(x.Cp, 128)
-        Rp = rup(Ct, 128)
-        Rt, Kt = rup(x.Cp, 128), rup(Ct, 128)          # transposed (dgrad) panel
-
-        def panel(transposed):
-            cache = self.pack_cache
-            key = ("multi", tuple(id(c.weight) for c in convs), transposed, x_map, self.dt)
-            if cache is not None and key in cache.entries:
-                return cache.entries[key][0]
-            wp = torch.zeros((Rt, Kt) if transposed else (Rp, Kp), dtype=self.tdt, device=self.dev)
-            for c, co, off in zip(convs, couts, offs):
-                d = self._pack_desc(c.weight, x_map, (co, co, co), transposed)
-                if transposed:
-                    d.Rp, d.Kp, d.ld, d.koff = Rt, co, Kt, off          # columns [off, off+co) of every row
-                    dst = wp
-                else:
-                    d.Rp, d.Kp = co, Kp                                  # rows [off, off+co)
-                    dst = wp[off:]
-                call.pn2_pack_weight(self.dt, _p(c.weight), _p(dst), C.byref(d), st)
-                if cache is not None:
-                    cache.add(key + (off,), c.weight, dst, d)
-            if cache is not None:
-                cache.entries[key] = (wp, None)
-            return wp
-
-        wp = panel(False)
-        cd = capi.ConvDesc()
-        cd.N, cd.H, cd.W, cd.OH, cd.OW = N, H, W, H, W
-        cd.Cin_p, cd.ld_in, cd.Cout, cd.ld_out = x.Cp, x.ld, Ct, Ct
-        cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w = 1, 1, 1, 0, 0, 1, 1
-        cd.transposed, cd.Kp, cd.flags = 0, Kp, (capi.CONV_STATS if train else 0)
-        psum = psq = None
-        tune = self._tune_gemm(cd, x.ptr, wp, M, Ct)
-        cd.flags |= tune << 8
-        tile_rows = 0
-        if train:
-            nblk = self._stat_blocks(M, Ct, tune)
-            tile_rows = self._tile_m(M, Ct, tune)
-            psum, psq = self.fbuf(nblk, Ct), self.fbuf(nblk, Ct)
-        flops = 2 * M * Ct * x.C
-        shape = f"{x.C}->{'+'.join(map(str, couts))} k1x1 s1 d1 {N}x{H}x{W}"
-        capi.WORK.update(flops=flops, tag=":fwd", shape=shape)
-        if EVAL_FUSE and not train and not self.need_grad:
-            # eval mode: the folded BatchNorms of all the reducers ride in the GEMM epilogue (pn2_conv_gemm_affine) - no raw output, no normalise pass
-            fold = self.bn_fold
-            key = ("multi",) + tuple(id(m.bn) for m in mods)
-            par = fold.entries.get(key) if fold is not None else None
-            if par is None:
-                par = torch.empty((2, Ct), dtype=torch.float32, device=self.dev) if fold is not None else self.fbuf(2, Ct)
-                for m, co, off in zip(mods, couts, offs):
-                    bn = m.bn
-                    bd = capi.BnDesc()
-                    bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, co, co, co, co, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
-                    call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(par[0][off:]), _p(par[1][off:]), st)
-                    if fold is not None:
-                        if torch.cuda.is_current_stream_capturing():
-                            raise RuntimeError("run an eager forward before capturing (the BatchNorm fold table is built then)")
-                        fold.add(key, bn, par, bd, off)
-            out = Act(self, self.empty(N, H, W, Ct), Ct, Ct, Ct, self.dt)
-            cd.flags = (tune << 8) | capi.CONV_AFFINE
-            call.pn2_conv_gemm_affine(self.dt, x.ptr, _p(wp), out.ptr, _p(par[0]), _p(par[1]), C.c_void_p(0), 0, C.byref(cd), st)
-            return [out.slice(off, off + co) for co, off in zip(couts, offs)]
-        raw = self.empty(N, H, W, Ct)
-        call.pn2_conv_gemm(self.dt, x.ptr, _p(wp), _p(raw), _p(psum), _p(psq), C.byref(cd), st)
-        scale, shift = self.fbuf(Ct), self.fbuf(Ct)
-        mean, invstd = (self.fbuf(Ct), self.fbuf(Ct)) if train else (None, None)
-        bds = []
-        for m, co, off in zip(mods, couts, offs):
-            bn = m.bn
-            bd = capi.BnDesc()
-            bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum, bd.ldp = M, co, co, co, co, bn.eps, (bn.momentum if bn.momentum is not None else 0.1), Ct
-            bd.tile_rows = tile_rows
-            bds.append(bd)
-            if train:
-                call.pn2_bn_finalize(_p(psum[:, off:]), _p(psq[:, off:]), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
-                                     _p(scale[off:]), _p(shift[off:]), _p(mean[off:]), _p(invstd[off:]), st)
-                self.bn_modules.append(bn)
-            else:
-                call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(scale[off:]), _p(shift[off:]), st)
-        out = Act(self, self.empty(N, H, W, Ct), Ct, Ct, Ct, self.dt)
-        call.pn2_affine_act(self.dt, _p(raw), Ct, self.dt, out.ptr, out.ld, M, Ct, _p(scale), _p(shift), C.c_void_p(0), 0, 0, st)
-        outs = [out.slice(off, off + co) for co, off in zip(couts, offs)]
-        if not self.need_grad:
-            return outs
-
-        def bwd():
-            st = _stream()
-            if not train:
-                raise RuntimeError("backward through eval-mode BatchNorm is not supported")
-            dy = out.grad_buf()
-            assert out.grad_written or out.child_written
-            nb = call.pn2_bn_bwd_blocks(M, Ct, self.dt)
-            p1, p2 = self.fbuf(nb, Ct), self.fbuf(nb, Ct)
-            nul = C.c_void_p(0)
-            call.pn2_bn_bwd_reduce(self.dt, self.dt, _p(dy), Ct, Ct, nul, 0, self.dt, _p(raw), Ct, M, Ct, _p(mean), _p(invstd), _p(p1), _p(p2), nb, nul, nul, 0, st)
-            coef = self.fbuf(3 * Ct)
-            for m, bd, off in zip(mods, bds, offs):
-                gg, ga = self.pgrads.sink(m.bn.weight)
-                gb, gba = self.pgrads.sink(m.bn.bias)
-                call.pn2_bn_bwd_finalize(_p(p1[:, off:]), _p(p2[:, off:]), nb, C.byref(bd), _p(m.bn.weight), _p(invstd[off:]), _p(gg), _p(gb), ga, _p(coef[off:]), st)
-            draw = self.empty(N, H, W, Ct)
-            call.pn2_bn_bwd_apply(self.dt, self.dt, _p(dy), Ct, Ct, nul, 0, self.dt, _p(raw), Ct, M, Ct, _p(mean), _p(invstd), _p(coef), _p(draw), Ct, nul, 0, 0, nul, nul, 0, st)
-            wd = capi.WgradDesc()
-            wd.N, wd.H, wd.W, wd.OH, wd.OW = N, H, W, H, W
-            wd.Cin_p, wd.ld_x, wd.Cout_p, wd.ld_dy = x.Cp, x.ld, Ct, Ct
-            wd.KH, wd.KW, wd.stride, wd.pad_h, wd.pad_w, wd.dil_h, wd.dil_w = 1, 1, 1, 0, 0, 1, 1
-            tco = call.pn2_wgrad_tile_co(Ct)
-            wd.Rp, wd.Kp = rup(Ct, tco), Kp
-            tiles = (wd.Rp // tco) * (Kp // 128)
-            steps = (M + 31) // 32
-            nsplit = max(1, min(steps // 4 if steps >= 8 else 1, (WGRAD_WGS + tiles - 1) // tiles, (WGRAD_SLAB_MB << 20) // (wd.Rp * wd.Kp * 4) or 1))
-            rd0 = self._pack_desc(convs[0].weight, x_map, (couts[0], couts[0], couts[0]), False)
-            rd0.Rp, rd0.Kp = wd.Rp, Kp
-            wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd0, nsplit, convs[0].weight.shape)
-            rq = self.grad_queue
-            slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab(tuple(id(c.weight) for c in convs), (nsplit, wd.Rp, wd.Kp), self.dev)
-            if rq is not None and rq.defer_wgrad:
-                rq.add_wgrad(self.dt, draw, x.ptr, x.t, slab, wd, nsplit, flops)
-            else:
-                capi.WORK.update(flops=flops, tag="", shape=shape)
-                call.pn2_conv_wgrad(self.dt, _p(draw), x.ptr, _p(slab), C.byref(wd), nsplit, st)
-            for c, co, off in zip(convs, couts, offs):
-                gwt, gwa = self.pgrads.sink(c.weight)
-                rd = self._pack_desc(c.weight, x_map, (co, co, co), False)
-                rd.Rp, rd.Kp = wd.Rp, Kp
-                if rq is None:
-                    call.pn2_wgrad_reduce(_p(slab[:, off:]), _p(gwt), C.byref(rd), nsplit, gwa, st)
-                else:
-                    rq.add_reduce(slab[:, off:], gwt, rd, nsplit, gwa)
-            if x.requires_grad:
-                wt = panel(True)
-                gx, gxa = x.grad_sink()
-                dd = capi.ConvDesc()
-                dd.N, dd.H, dd.W, dd.OH, dd.OW = N, H, W, H, W
-                dd.Cin_p, dd.ld_in, dd.Cout, dd.ld_out = Ct, Ct, x.Cp, gx.stride(2)
-                dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = 1, 1, 1, 0, 0, 1, 1
-                dd.transposed, dd.Kp, dd.flags = 1, Kt, (capi.CONV_ACCUM if gxa else 0)
-                dd.flags |= self._tune_gemm(dd, _p(draw), wt, M, x.Cp) << 8
-                capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
-                call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), nul, nul, C.byref(dd), st)
-        self.record(bwd)
-        return outs
-
-    # ------------------------------------------------------------------ PVTv2 encoder ops (lib/pvtv2.py)
-    def colsum_finalize(self, part, nblk, Cc, ld, out, accumulate):
-        """out[:Cc] (+)= sum of the nblk partial rows.  These sums only feed parameter gradients: they are queued and run as ONE
-        table-driven launch per flush (end of backward / before a gradient bucket leaves), not one launch each."""
-        if not DEFER_COLSUM or self.grad_queue is None:      # (without a persistent queue the job table would be rebuilt and uploaded every step)
-            call.pn2_colsum_finalize(_p(part), nblk, Cc, ld, _p(out), accumulate, _stream())
-            return
-        if accumulate:                  # a second contribution to the same gradient must see the first one finished
-            self.flush_colsum()
-        self.cjobs.append((part.data_ptr(), out.data_ptr(), nblk, Cc, ld, accumulate))
-        self.ckeep.append((part, out))  # the partial rows must not be recycled before the launch is queued
-
-    def flush_colsum(self):
-        """Run the queued column sums (one pn2_colsum_multi per dtype) and then their finalisations (one pn2_colsum_finalize_multi)."""
-        if not self.cjobs and not self.cin:
-            return
-        sig = (tuple(self.cin), tuple(self.cjobs))
-        cache = self.grad_queue.ccache if self.grad_queue is not None else None
-        hit = cache.get(self.cseg) if cache is not None else None
-        if hit is None or hit[0] != sig:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("run two eager steps before capturing (the deferred-launch tables are built then)")
-            launches = []
-            for dt in sorted({j[0] for j in self.cin}):
-                arr, blocks = [], []
-                for d_, ptr, part, ld, M, Cc in self.cin:
-                    if d_ != dt:
-                        continue
-                    j = capi.ColsumInJob()
-                    j.dy, j.partial, j.ld, j.M, j.C = ptr, part, ld, M, Cc
-                    nb = call.pn2_colsum_job_blocks(dt, C.byref(j))
-                    if nb < 1:
-                        raise RuntimeError("unsupported column-sum geometry")
-                    arr.append(j); blocks.append(nb)
-                launches.append(("s", dt, len(arr)) + _job_table(capi.ColsumInJob, arr, blocks))
-            if self.cjobs:
-                arr = []
-                for part, out, nblk, Cc, ld, acc in self.cjobs:
-                    j = capi.ColsumJob()
-                    j.partial, j.out, j.nblk, j.C, j.ld, j.accumulate = part, out, nblk, Cc, ld, acc
-                    arr.append(j)
-                launches.append(("f", 0, len(arr)) + _job_table(capi.ColsumJob, arr, [call.pn2_colsum_finalize_blocks(j.C) for j in arr]))
-            hit = (sig, launches)
-            if cache is not None:
-                cache[self.cseg] = hit
-        st = _stream()
-        for kind, dt, n, table, bstart, nblocks in hit[1]:
-            if kind == "s":
-                call.pn2_colsum_multi(dt, _p(table), _p(bstart), n, nblocks, st)
-            else:
-                call.pn2_colsum_finalize_multi(_p(table), _p(bstart), n, nblocks, st)
-        self.ctables.append(hit)        # the tables must outlive the launches
-        self.cseg += 1
-        self.cjobs, self.cin, self.ckeep = [], [], []
-
-    def colsum(self, t, M, Cp, Cc, out, accumulate):
-        """out[:Cc] (+)= column sums of the [M][Cp] tensor t (bias gradients).  With a gradient queue both passes are deferred into the
-        table-driven launches of flush_colsum (t stays alive in the step arena)."""
-        st = _stream()
-        dt = F32 if t.dtype == torch.float32 else BF16
-        nb = call.pn2_rows_blocks(M, call.pn2_colsum_unit(dt, Cp))
-        part = self.fbuf(nb, Cp)
-        if DEFER_COLSUM and self.grad_queue is not None:
-            self.cin.append((dt, t.data_ptr(), part.data_ptr(), Cp, M, Cp))
-            self.ckeep.append(t)
-        else:
-            call.pn2_colsum(dt, _p(t), Cp, M, Cp, _p(part), nb, st)
-        self.colsum_finalize(part, nb, Cc, Cp, out, accumulate)
-
-    def linear(self, x, lin, residual=None):
-        """nn.Linear (+ residual add) over the channels of NHWC tokens."""
-        return self.conv_bn_act(x, _LinearAsConv(lin), None, bias=lin.bias, residual=residual)
-
-    def conv_bias(self, x, conv):
-        """biased nn.Conv2d without BN (patch embedding pvtv2.py:167, spatial reduction :70)."""
-        return self.conv_bn_act(x, conv, None, bias=conv.bias)
-
-    def layernorm(self, x, ln):
-        """nn.LayerNorm over the channel axis (tokens = pixels)."""
-        assert x.Cp == x.C and x.ld == x.Cp and tuple(ln.normalized_shape) == (x.C,)
-        M, Cc, st = x.M, x.C, _stream()
-        y = Act(self, self.empty(x.N, x.H, x.W, Cc), Cc, Cc, Cc, self.dt)
-        mean, rstd = self.fbuf(M), self.fbuf(M)
-        call.pn2_layernorm_fwd(self.dt, x.ptr, x.ld, y.ptr, y.ld, M, Cc, _p(ln.weight), _p(ln.bias), float(ln.eps), _p(mean), _p(rstd), st)
-
-        def bwd():
-            st = _stream()
-            dy = y.grad_buf()
-            assert y.grad_written
-            nb = call.pn2_rows_blocks(M, call.pn2_ln_slots(self.dt, Cc))
-            pg, pb = self.fbuf(nb, Cc), self.fbuf(nb, Cc)
-            gx, acc = x.grad_sink() if x.requires_grad else (self.empty(x.N, x.H, x.W, Cc), 0)
-            call.pn2_layernorm_bwd(self.dt, _p(dy), dy.stride(2), x.ptr, x.ld, M, Cc, _p(ln.weight), _p(mean), _p(rstd), _p(gx), gx.stride(2), acc,
-                                   _p(pg), _p(pb), nb, st)
-            gg, ga = self.pgrads.sink(ln.weight)
-            gb, gba = self.pgrads.sink(ln.bias)
-            self.colsum_finalize(pg, nb, Cc, Cc, gg, ga)
-            self.colsum_finalize(pb, nb, Cc, Cc, gb, gba)
-        self.record(bwd)
-        return y
-
-    def dwconv_gelu(self, x, conv):
-        """gelu(DWConv(x)) of Mlp.forward (pvtv2.py:44-45): depth-wise 3x3, pad 1, bias, exact GELU."""
-        Cc = x.C
-        assert x.Cp == Cc and x.ld == Cc and conv.groups == Cc and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1)
-        N, H, W, st = x.N, x.H, x.W, _stream()
-        z = self.empty(N, H, W, Cc)
-        y = Act(self, self.empty(N, H, W, Cc), Cc, Cc, Cc, self.dt)
-        call.pn2_dwconv3x3(self.dt, x.ptr, _p(conv.weight), _p(conv.bias), _p(z), y.ptr, N, H, W, Cc, 0, 0, st)
-
-        def bwd():
-            st = _stream()
-            dy = y.grad_buf()
-            assert y.grad_written and dy.stride(2) == Cc
-            dz = self.empty(N, H, W, Cc)
-            nb = call.pn2_dwconv3x3_wgrad_blocks(self.dt, N, H, W, Cc)
-            part = self.fbuf(nb, Cc * 10)
-            # dz = dy * gelu'(z) is formed inside the weight-gradient walk (one pass over dy, z, x) and kept for the data gradient
-            call.pn2_dwconv3x3_wgrad(self.dt, _p(dy), x.ptr, _p(part), nb, N, H, W, Cc, _p(z), _p(dz), st)
-            gw, gwa = self.pgrads.sink(conv.weight)
-            gb, gba = self.pgrads.sink(conv.bias)
-            self.colsum_finalize(part, nb, Cc * 9, Cc * 10, gw, gwa)
-            self.colsum_finalize(part[:, Cc * 9:], nb, Cc, Cc * 10, gb, gba)
-            if x.requires_grad:
-                gx, acc = x.grad_sink()
-                assert gx.stride(2) == Cc
-                call.pn2_dwconv3x3(self.dt, _p(dz), _p(conv.weight), C.c_void_p(0), _p(gx), C.c_void_p(0), N, H, W, Cc, 1, acc, st)
-        self.record(bwd)
-        return y
-
-    def drop_path(self, x, drop_prob):
-        """timm DropPath in train mode: every sample is kept with probability 1 - drop_prob and rescaled by 1 / keep."""
-        if drop_prob == 0.0 or not self.training:
-            return x
-        keep = 1.0 - drop_prob
-        sc = torch.empty(x.N, dtype=torch.float32, device=self.dev).bernoulli_(keep).div_(keep)
-        assert x.ld == x.Cp
-        y = Act(self, self.empty(x.N, x.H, x.W, x.Cp), x.C, x.gw, x.gwp, self.dt)
-        per = x.H * x.W * x.Cp
-        call.pn2_scale_samples(self.dt, x.ptr, y.ptr, _p(sc), C.c_void_p(0), x.N, per, _stream())
-
-        def bwd():
-            dy = y.grad_buf()
-            assert y.grad_written and not x.grad_written
-            gx, _ = x.grad_sink()
-            call.pn2_scale_samples(self.dt, _p(dy), _p(gx), _p(sc), C.c_void_p(0), x.N, per, _stream())
-        self.record(bwd)
-        return y
-
-    def drop_path_add(self, res, x, drop_prob):
-        """res + DropPath(x) in one pass (Block.forward pvtv2.py:148-149 in train mode); plain add when nothing is dropped."""
-        if drop_prob == 0.0 or not self.training:
-            return self.add(res, x)
-        keep = 1.0 - drop_prob
-        sc = torch.empty(x.N, dtype=torch.float32, device=self.dev).bernoulli_(keep).div_(keep)
-        assert x.ld == x.Cp and res.ld == res.Cp and (res.N, res.H, res.W, res.Cp) == (x.N, x.H, x.W, x.Cp) and res.dt == x.dt == self.dt
-        y = Act(self, self.empty(x.N, x.H, x.W, x.Cp), x.C, x.gw, x.gwp, self.dt)
-        per = x.H * x.W * x.Cp
-        call.pn2_scale_samples(self.dt, x.ptr, y.ptr, _p(sc), res.ptr, x.N, per, _stream())
-
-        def bwd():
-            st = _stream()
-            dy = y.grad_buf()
-            assert y.grad_written and not x.grad_written and dy.stride(2) == x.Cp
-            gx, _ = x.grad_sink()
-            call.pn2_scale_samples(self.dt, _p(dy), _p(gx), _p(sc), C.c_void_p(0), x.N, per, st)
-            if res.requires_grad:
-                gr, acc = res.grad_sink()
-                call.pn2_copy(self.dt, _p(dy), dy.stride(2), self.dt, _p(gr), gr.stride(2), x.M, x.Cp, acc, st)
-        self.record(bwd)
-        return y
-
-    def attention(self, q, kv, heads):
-        """softmax(q k^T / sqrt(hd)) v with the heads concatenated (Attention.forward pvtv2.py:103-107); kv holds k then v."""
-        Cc = q.C
-        hd = Cc // heads
-        assert q.Cp == Cc and q.ld == Cc and kv.C == 2 * Cc and kv.ld == 2 * Cc and kv.N == q.N
-        B, Nq, Nkv, st = q.N, q.H * q.W, kv.H * kv.W, _stream()
-        scale = hd ** -0.5
-        o = Act(self, self.empty(q.N, q.H, q.W, Cc), Cc, Cc, Cc, self.dt)
-        lse = self.fbuf(B, heads, Nq)
-        call.pn2_attn_fwd(self.dt, q.ptr, Cc, kv.ptr, 2 * Cc, o.ptr, Cc, _p(lse), B, Nq, Nkv, heads, hd, scale, st)
-
-        def bwd():
-            st = _stream()
-            do = o.grad_buf()
-            assert o.grad_written and do.stride(2) == Cc and not q.grad_written and not kv.grad_written
-            part = self.fbuf(B, heads, call.pn2_attn_bwd_blocks(self.dt, B, heads, Nq), 2, rup(Nkv, 64), 64)
-            delta = self.fbuf(B, heads, Nq)
-            gq, _ = q.grad_sink()
-            gkv, _ = kv.grad_sink()
-            call.pn2_attn_bwd(self.dt, q.ptr, Cc, kv.ptr, 2 * Cc, o.ptr, Cc, _p(do), Cc, _p(lse), _p(gq), Cc, _p(gkv), 2 * Cc, _p(part), _p(delta),
-                              B, Nq, Nkv, heads, hd, scale, st)
-        self.record(bwd)
-        return o
-
-    # ------------------------------------------------------------------ EMCAD decoder ops (multiclass_seg/EMCAD/lib/decoders.py)
-    def bn_after(self, N, H, W, Cc, nblk, launch, back, bn, relu=False, residual=None, bias=None):
-        """y = act(BN(raw) + residual) for a producer other than the implicit-GEMM conv: `launch(raw, psum, psq)` writes raw [M][Cc] and
-        nblk partial rows of sum / sum of squares; `back(draw)` receives the gradient w.r.t. raw.  relu: False / True / 2 (ReLU6)."""
-        assert Cc % 8 == 0
-        M, st, train = N * H * W, _stream(), self.training
-        raw = self.empty(N, H, W, Cc)
-        psum, psq = (self.fbuf(nblk, Cc), self.fbuf(nblk, Cc)) if train else (None, None)
-        launch(raw, psum, psq)
-        bd = capi.BnDesc()
-        bd.M, bd.Cp, bd.C, bd.gw, bd.gwp, bd.eps, bd.momentum = M, Cc, Cc, Cc, Cc, bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
-        scale, shift = self.fbuf(Cc), self.fbuf(Cc)
-        mean = invstd = None
-        if train:
-            mean, invstd = self.fbuf(Cc), self.fbuf(Cc)
-            call.pn2_bn_finalize(_p(psum), _p(psq), nblk, C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
-                                 _p(scale), _p(shift), _p(mean), _p(invstd), st)
-            self.bn_modules.append(bn)
-            if bias is not None:
-                with torch.no_grad():
-                    bn.running_mean.add_(bias.detach(), alpha=bd.momentum)
-        else:
-            call.pn2_bn_eval_prepare(C.byref(bd), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), st)
-            if bias is not None:
-                shift += bias.detach() * scale
-        out = Act(self, self.empty(N, H, W, Cc), Cc, Cc, Cc, self.dt)
-        if residual is not None:
-            assert residual.Cp == Cc and residual.dt == self.dt
-        call.pn2_affine_act(self.dt, _p(raw), Cc, self.dt, out.ptr, out.ld, M, Cc, _p(scale), _p(shift),
-                            residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
-        if not self.need_grad:
-            return out
-
-        def bwd():
-            st = _stream()
-            if not train:
-                raise RuntimeError("backward through eval-mode BatchNorm is not supported")
-            dy = out.grad_buf()
-            assert out.grad_written or out.child_written
-            draw = self.empty(N, H, W, Cc)
-            ymask = out if relu else None
-            r6 = 1 if relu == 2 else 0
-            nul = C.c_void_p(0)
-            nb = call.pn2_bn_bwd_blocks(M, Cc, self.dt)
-            p1, p2 = self.fbuf(nb, Cc), self.fbuf(nb, Cc)
-            call.pn2_bn_bwd_reduce(self.dt, self.dt, _p(dy), dy.stride(2), Cc, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
-                                   _p(raw), Cc, M, Cc, _p(mean), _p(invstd), _p(p1), _p(p2), nb, nul, nul, r6, st)
-            coef = self.fbuf(3 * Cc)
-            gg, ga = self.pgrads.sink(bn.weight)
-            gb, gba = self.pgrads.sink(bn.bias)
-            call.pn2_bn_bwd_finalize(_p(p1), _p(p2), nb, C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
-            rg, racc = (None, 0)
-            if residual is not None and residual.requires_grad:
-                rg, racc = residual.grad_sink()
-            call.pn2_bn_bwd_apply(self.dt, self.dt, _p(dy), dy.stride(2), Cc, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
-                                  _p(raw), Cc, M, Cc, _p(mean), _p(invstd), _p(coef), _p(draw), Cc,
-                                  _p(rg), rg.stride(2) if rg is not None else 0, racc, nul, nul, r6, st)
-            if bias is not None:
-                gbi, gbia = self.pgrads.sink(bias)
-                self.colsum(draw, M, Cc, Cc, gbi, gbia)
-            back(draw)
-        self.record(bwd)
-        return out
-
-    def dwconv_bn_act(self, x, conv, bn, relu=False):
-        """act(BN(depth-wise KxK conv(x))), K in (1, 3, 5), stride 1, pad K/2, bias-free (MSDC decoders.py:90-96, EUCB :172-174)."""
-        Cc, K = x.C, conv.kernel_size[0]
-        assert x.Cp == Cc and x.ld == Cc and conv.groups == Cc and conv.bias is None and conv.stride == (1, 1) and conv.padding == (K // 2, K // 2)
-        N, H, W = x.N, x.H, x.W
-        nblk = call.pn2_dwconv_blocks(self.dt, N, H, W, Cc, K, 0)
-        w = conv.weight
-
-        def launch(raw, psum, psq):
-            call.pn2_dwconv(self.dt, x.ptr, _p(w), _p(raw), N, H, W, Cc, K, 0, 0, _p(psum), _p(psq), _stream())
-
-        def back(draw):
-            st = _stream()
-            nbw = call.pn2_dwconv_blocks(self.dt, N, H, W, Cc, K, 1)
-            part = self.fbuf(nbw, Cc * K * K)
-            call.pn2_dwconv_wgrad(self.dt, _p(draw), x.ptr, _p(part), N, H, W, Cc, K, st)
-            gw, gwa = self.pgrads.sink(w)
-            self.colsum_finalize(part, nbw, Cc * K * K, Cc * K * K, gw, gwa)
-            if x.requires_grad:
-                gx, acc = x.grad_sink()
-                assert gx.stride(2) == Cc
-                call.pn2_dwconv(self.dt, _p(draw), _p(w), _p(gx), N, H, W, Cc, K, 1, acc, C.c_void_p(0), C.c_void_p(0), st)
-        return self.bn_after(N, H, W, Cc, nblk, launch, back, bn, relu=relu)
-
-    def pairconv_bn(self, x, conv, bn, relu=False, residual=None):
-        """act(BN(grouped 3x3 conv with two input channels per group (+bias)) + residual)   (LGAG.W_g / W_x, decoders.py:193-200)."""
-        F_ = conv.out_channels
-        assert x.C == 2 * F_ and x.Cp == x.C and x.ld == x.C and conv.groups == F_ and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
-        N, H, W = x.N, x.H, x.W
-        nblk = call.pn2_pairconv_blocks(self.dt, N, H, W, F_)
-        w = conv.weight
-
-        def launch(raw, psum, psq):
-            if psum is None:
-                psum, psq = self.fbuf(nblk, F_), self.fbuf(nblk, F_)
-            call.pn2_pairconv3x3_fwd(self.dt, x.ptr, _p(w), _p(raw), N, H, W, F_, _p(psum), _p(psq), _stream())
-
-        def back(draw):
-            st = _stream()
-            part = self.fbuf(nblk, F_ * 18)
-            call.pn2_pairconv3x3_wgrad(self.dt, _p(draw), x.ptr, _p(part), N, H, W, F_, st)
-            gw, gwa = self.pgrads.sink(w)
-            self.colsum_finalize(part, nblk, F_ * 18, F_ * 18, gw, gwa)
-            if x.requires_grad:
-                gx, acc = x.grad_sink()
-                assert gx.stride(2) == 2 * F_
-                call.pn2_pairconv3x3_dgrad(self.dt, _p(draw), _p(w), _p(gx), N, H, W, F_, acc, st)
-        return self.bn_after(N, H, W, F_, nblk, launch, back, bn, relu=relu, residual=residual, bias=conv.bias)
-
-    def upsample2x(self, x):
-        """nn.Upsample(scale_factor=2), nearest (EUCB decoders.py:171)."""
-        assert x.ld == x.Cp
-        y = Act(self, self.empty(x.N, 2 * x.H, 2 * x.W, x.Cp), x.C, x.gw, x.gwp, x.dt)
-        call.pn2_upsample_nearest2x(x.dt, x.ptr, y.ptr, x.N, x.H, x.W, x.Cp, _stream())
-
-        def bwd():
-            if x.requires_grad:
-                gy = y.grad_buf()
-                gx, acc = x.grad_sink()
-                assert gx.stride(2) == x.Cp
-                call.pn2_upsample_nearest2x_bwd(x.dt, _p(gy), _p(gx), x.N, x.H, x.W, x.Cp, acc, _stream())
-        self.record(bwd)
-        return y
-
-    def shuffled_sum(self, parts, groups):
-        """channel_shuffle(sum(parts), groups)  (MSCB.forward decoders.py:147-154, channel_shuffle :69-77) in one pass; the backward is one gather whose
-        result is the gradient of every part."""
-        a = parts[0]
-        Cc, M = a.C, a.M
-        assert all(p.C == Cc and p.Cp == Cc and p.ld == Cc for p in parts) and 1 <= len(parts) <= 3 and Cc % groups == 0
-        cpg = Cc // groups
-        key = ("perm", Cc, groups)
-        if key not in _PERMS:
-            fwd = torch.tensor([(j % groups) * cpg + j // groups for j in range(Cc)], dtype=torch.int32)
-            inv = torch.empty_like(fwd); inv[fwd.long()] = torch.arange(Cc, dtype=torch.int32)
-            _PERMS[key] = (fwd.to(self.dev), inv.to(self.dev))
-        fwd, inv = _PERMS[key]
-        y = Act(self, self.empty(a.N, a.H, a.W, Cc), Cc, Cc, Cc, self.dt)
-        ps = [p.ptr for p in parts] + [C.c_void_p(0)] * (3 - len(parts))
-        call.pn2_gather_sum(self.dt, ps[0], ps[1], ps[2], _p(fwd), y.ptr, M, Cc, _stream())
-
-        def bwd():
-            gy = y.grad_buf()
-            assert y.grad_written and gy.stride(2) == Cc
-            g = self.empty(a.N, a.H, a.W, Cc)
-            call.pn2_gather_sum(self.dt, _p(gy), C.c_void_p(0), C.c_void_p(0), _p(inv), _p(g), M, Cc, _stream())
-            for p in parts:         # single-consumer BN outputs: the shared tensor is only read
-                assert not p.grad_written
-                p.grad = g
-                p.grad_written = True
-        self.record(bwd)
-        return y
-
-    def sigmoid_gate(self, x, pre, mode):
-        """x * sigmoid(pre): mode 0 channel gate, pre = [N,1,1,C] (CAB decoders.py:241,442); mode 1 pixel gate, pre = [N,H,W,1] (SAB :258,443; LGAG :213-214)."""
-        N, HW, Cc = x.N, x.H * x.W, x.C
-        assert x.Cp == Cc and x.ld == Cc
-        n = N * Cc if mode == 0 else N * HW
-        usedC = Cc if mode == 0 else 1
-        assert pre.M * usedC == n and pre.C >= usedC
-        st = _stream()
-        g = self.fbuf(n)
-        call.pn2_sigmoid(pre.dt, pre.ptr, pre.ld, usedC, _p(g), n, st)
-        y = Act(self, self.empty(x.N, x.H, x.W, Cc), Cc, Cc, Cc, self.dt)
-        call.pn2_gate_mul(self.dt, x.ptr, _p(g), y.ptr, N, HW, Cc, mode, 0, st)
-
-        def bwd():
-            st = _stream()
-            gy = y.grad_buf()
-            assert y.grad_written and gy.stride(2) == Cc
-            dg = self.fbuf(n)
-            if mode == 1:
-                call.pn2_gate_bwd(self.dt, _p(gy), x.ptr, _p(dg), N, HW, Cc, 1, st)
-            else:
-                nb = call.pn2_gate_blocks(self.dt, HW, Cc)
-                part = self.fbuf(nb, N * Cc)
-                call.pn2_gate_bwd(self.dt, _p(gy), x.ptr, _p(part), N, HW, Cc, 0, st)
-                call.pn2_colsum_finalize(_p(part), nb, N * Cc, N * Cc, _p(dg), 0, st)
-            gp, pacc = pre.grad_sink()
-            call.pn2_sigmoid_bwd(pre.dt, _p(dg), _p(g), _p(gp), gp.stride(2), usedC, n, pacc, st)
-            if x.requires_grad:
-                gx, acc = x.grad_sink()
-                assert gx.stride(2) == Cc
-                call.pn2_gate_mul(self.dt, _p(gy), _p(g), _p(gx), N, HW, Cc, mode, acc, st)
-        self.record(bwd)
-        return y
-
-    def global_pool(self, x):
-        """(AdaptiveAvgPool2d(1)(x), AdaptiveMaxPool2d(1)(x)) as two [N,1,1,C] maps (CAB decoders.py:234-237)."""
-        N, HW, Cc = x.N, x.H * x.W, x.C
-        assert x.Cp == Cc and x.ld == Cc
-        avg = Act(self, self.empty(N, 1, 1, Cc), Cc, Cc, Cc, self.dt)
-        mx = Act(self, self.empty(N, 1, 1, Cc), Cc, Cc, Cc, self.dt)
-        arg = self.alloc((N, Cc), torch.int32)
-        call.pn2_global_pool(self.dt, x.ptr, avg.ptr, mx.ptr, _p(arg), N, HW, Cc, _stream())
-
-        def bwd():
-            if not x.requires_grad:
-                return
-            ga, gm = avg.grad_buf(), mx.grad_buf()
-            if not avg.grad_written:
-                ga.zero_()
-            if not mx.grad_written:
-                gm.zero_()
-            gx, acc = x.grad_sink()
-            assert gx.stride(2) == Cc
-            call.pn2_global_pool_bwd(self.dt, _p(ga), _p(gm), _p(arg), _p(gx), N, HW, Cc, acc, _stream())
-        self.record(bwd)
-        return avg, mx
-
-    def chan_stats(self, x):
-        """cat([mean over channels, max over channels]) as a 2-channel map (8 physical slots)   (SAB decoders.py:253-255)."""
-        Cc = x.C
-        assert x.Cp == Cc and x.ld == Cc
-        y = Act(self, self.empty(x.N, x.H, x.W, 8), 2, 2, 8, self.dt)
-        arg = self.alloc((x.M,), torch.int32)
-        call.pn2_chan_stats(self.dt, x.ptr, y.ptr, _p(arg), x.M, Cc, _stream())
-
-        def bwd():
-            if not x.requires_grad:
-                return
-            gy = y.grad_buf()
-            assert y.grad_written and gy.stride(2) == 8
-            gx, acc = x.grad_sink()
-            assert gx.stride(2) == Cc
-            call.pn2_chan_stats_bwd(self.dt, _p(gy), _p(arg), _p(gx), x.M, Cc, acc, _stream())
-        self.record(bwd)
-        return y
-
-    # ------------------------------------------------------------------ pooling
-    def maxpool3x3s2(self, x):
-        N, H, W = x.N, x.H, x.W
-        OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-        y = Act(self, self.empty(N, OH, OW, x.Cp), x.C, x.gw, x.gwp, x.dt)
-        idx = torch.empty((N, OH, OW, x.Cp), dtype=torch.uint8, device=self.dev)
-        call.pn2_maxpool3x3s2_fwd(x.dt, x.ptr, x.ld, y.ptr, y.ld, _p(idx), N, H, W, x.Cp, OH, OW, _stream())
-
-        def bwd():
-            if not x.requires_grad:
-                return
-            gx, acc = x.grad_sink()
-            assert not acc
-            call.pn2_maxpool3x3s2_bwd(x.dt, _p(y.grad_buf()), y.grad_buf().stride(2), _p(idx), _p(gx), gx.stride(2), N, H, W, x.Cp, OH, OW, _stream())
-        self.record(bwd)
-        return y
-
-    def avgpool(self, x, k, stride, pad, ceil_mode=False, count_include_pad=True, out=None):
-        N, H, W = x.N, x.H, x.W
-
-        def osz(i):
-            o = (i + 2 * pad - k + (stride - 1 if ceil_mode else 0)) // stride + 1
-            if ceil_mode and (o - 1) * stride >= i + pad:
-                o -= 1
-            return o
-        OH, OW = osz(H), osz(W)
-        y = out if out is not None else Act(self, self.empty(N, OH, OW, x.Cp), x.C, x.gw, x.gwp, x.dt)
-        assert (y.H, y.W, y.Cp) == (OH, OW, x.Cp)
-        inc = 1 if count_include_pad else 0
-        call.pn2_avgpool_fwd(x.dt, x.ptr, x.ld, y.ptr, y.ld, N, H, W, x.Cp, OH, OW, k, stride, pad, inc, _stream())
-
-        def bwd():
-            if not x.requires_grad:
-                return
-            gy = y.grad_buf()
-            gx, acc = x.grad_sink()
-            call.pn2_avgpool_bwd(x.dt, _p(gy), gy.stride(2), _p(gx), gx.stride(2), N, H, W, x.Cp, OH, OW, k, stride, pad, inc, acc, _stream())
-        self.record(bwd)
-        return y
-
-    # ------------------------------------------------------------------ bilinear
-    def bilinear(self, x, scale=None, align_corners=False, out=None):
-        """F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=...) — the given scale is used
-        for the source-index map when align_corners is False (PyTorch default recompute_scale_factor=None)."""
-        N, H, W = x.N, x.H, x.W
-        OH, OW = int(math.floor(H * scale)), int(math.floor(W * scale))
-        if align_corners:
-            rh = (H - 1) / (OH - 1) if OH > 1 else 0.0
-            rw = (W - 1) / (OW - 1) if OW > 1 else 0.0
-        else:
-            rh = rw = 1.0 / scale
-        return self._resize(x, OH, OW, align_corners, rh, rw, out)
-
-    def resize_to(self, x, OH, OW, align_corners=False):
-        """F.interpolate(x, size=(OH,OW), mode='bilinear')"""
-        if align_corners:
-            rh = (x.H - 1) / (OH - 1) if OH > 1 else 0.0
-            rw = (x.W - 1) / (OW - 1) if OW > 1 else 0.0
-        else:
-            rh, rw = x.H / OH, x.W / OW
-        return self._resize(x, OH, OW, align_corners, rh, rw, None)
-
-    def _resize(self, x, OH, OW, ac, rh, rw, out):
-        N, H, W = x.N, x.H, x.W
-        y = out if out is not None else Act(self, self.empty(N, OH, OW, x.Cp, x.dt), x.C, x.gw, x.gwp, x.dt)
-        ac = 1 if ac else 0
-        if self.fuse_tail and out is not None and out.lat is not None and x.dt == F32 and x.Cp == 1 and x.ld == 1 and OW % 4 == 0 and OW <= 1024:
-            self.tail[out.lat] = (x, ac, rh, rw)      # produced (and differentiated) by pn2_dsra_tail_fwd / _bwd
-            return y
-        call.pn2_bilinear_fwd(x.dt, x.ptr, x.ld, y.ptr, y.ld, N, H, W, x.Cp, OH, OW, ac, rh, rw, _stream())
-
-        def bwd():
-            if not x.requires_grad:
-                return
-            if not (y.grad_written or y.child_written):
-                return              # nothing ever contributed to this output's gradient (e.g. the K = 1 DSRA crop maps): its adjoint is exactly zero
-            gy = y.grad_buf()
-            gx, acc = x.grad_sink()
-            st = _stream()
-            if OH >= 4 * H and OW >= 4 * W and x.Cp >= (4 if x.dt == F32 else 8):
-                # separable adjoint: reduce along x first, then along y (keeps per-thread loops short)
-                tmp = self.empty(N, OH, W, x.Cp, x.dt)
-                call.pn2_bilinear_bwd(x.dt, _p(gy), gy.stride(2), _p(tmp), x.Cp, N, OH, W, x.Cp, OH, OW, ac, 1.0, rw, 0, st)
-                call.pn2_bilinear_bwd(x.dt, _p(tmp), x.Cp, _p(gx), gx.stride(2), N, H, W, x.Cp, OH, W, ac, rh, 1.0, acc, st)
-            else:
-                call.pn2_bilinear_bwd(x.dt, _p(gy), gy.stride(2), _p(gx), gx.stride(2), N, H, W, x.Cp, OH, OW, ac, rh, rw, acc, st)
-        self.record(bwd)
-        return y
-
-    # ------------------------------------------------------------------ element-wise
-    def binary(self, op, a, b, out=None, grad_alias=False):
-        """op 0: a+b ; op 1: a*b (same geometry).  Gradients flow to both operands.
-        grad_alias (op 0 only): the caller guarantees that `b` has no other consumer - the sum then keeps its gradient IN b's gradient
-        storage (d(a+b)/db = 1), so the backward pass is one accumulate into a's gradient instead of two copies."""
-        assert (a.N, a.H, a.W, a.Cp) == (b.N, b.H, b.W, b.Cp) and a.dt == b.dt
-        y = out if out is not None else Act(self, self.empty(a.N, a.H, a.W, a.Cp, a.dt), a.C, a.gw, a.gwp, a.dt)
-        call.pn2_binary(a.dt, op, a.ptr, a.ld, b.ptr, b.ld, y.ptr, y.ld, a.M, a.Cp, 0, _stream())
-        alias = GRAD_ALIAS and bool(grad_alias) and op == 0 and out is None and b.requires_grad and self.need_grad
-        if alias:
-            y.galias = b
-
-        def bwd():
-            gy = y.grad_buf()
-            st = _stream()
-            if alias:
-                assert not b._written, "grad_alias: the aliased operand received another gradient"
-                b.grad_written = True
-            for u, v in ((a, b), (b, a)):
-                if not u.requires_grad or (alias and u is b):
-                    continue
-                gu, acc = u.grad_sink()
-                if op == 0:
-                    call.pn2_copy(a.dt, _p(gy), gy.stride(2), a.dt, _p(gu), gu.stride(2), a.M, a.Cp, acc, st)
-                else:
-                    call.pn2_binary(a.dt, 1, _p(gy), gy.stride(2), v.ptr, v.ld, _p(gu), gu.stride(2), a.M, a.Cp, acc, st)
-        self.record(bwd)
-        return y
-
-    def add(self, a, b, out=None, grad_alias=False):
-        return self.binary(0, a, b, out, grad_alias)
-
-    def mul(self, a, b, out=None):
-        return self.binary(1, a, b, out)
-
-    def copy_into(self, src, dst):
-        call.pn2_copy(src.dt, src.ptr, src.ld, dst.dt, dst.ptr, dst.ld, src.M, src.Cp, 0, _stream())
-
-        def bwd():
-            if not src.requires_grad:
-                return
-            gd = dst.grad_buf()
-            gs, acc = src.grad_sink()
-            if gd.data_ptr() == gs.data_ptr() and gd.stride() == gs.stride() and dst.dt == src.dt:
-                assert not acc, "aliased gradient buffers: the copy must be the only contribution"
-                return              # the two gradients share storage (Bottle2neck: d(cat) lives in d(out1)): nothing to move
-            call.pn2_copy(dst.dt, _p(gd), gd.stride(2), src.dt, _p(gs), gs.stride(2), src.M, src.Cp, acc, _stream())
-        self.record(bwd)
-        return dst
-
-    # ------------------------------------------------------------------ DSRA / RA
-    def dsra_fuse(self, fg, crop_fg, crop_bg, use_softmax=True):
-        """fg + fg * softmax(crop_fg - crop_bg, dim=C)   (fp32 K-channel maps)"""
-        for a in (fg, crop_fg, crop_bg):
-            assert a.dt == F32 and a.ld == a.C
-        K, M = fg.C, fg.M
-        y = Act(self, self.empty(fg.N, fg.H, fg.W, K, F32), K, K, K, F32)
-        sm = 1 if use_softmax else 0
-        call.pn2_dsra_fuse_fwd(fg.ptr, crop_fg.ptr, crop_bg.ptr, y.ptr, M, K, sm, _stream())
-
-        # softmax over ONE channel is identically 1 (num_class = 1, the only value the binary scripts use): y = 2 * fg and the gradient into both crop
-        # maps is exactly zero (SURVEY fact 2) - they receive no contribution at all, so the resamples that produced them skip their adjoints
-        zero_crop = bool(K == 1 and sm and ZERO_CROP_SKIP)
-
-        def bwd():
-            gy = y.grad_buf()
-            if zero_crop:
-                g, acc = fg.grad_sink()
-                dfg = self.fbuf(M, K) if acc else g
-                scratch = self.fbuf(2, M, K)
-                call.pn2_dsra_fuse_bwd(fg.ptr, crop_fg.ptr, crop_bg.ptr, _p(gy), _p(dfg), _p(scratch[0]), _p(scratch[1]), M, K, sm, _stream())
-                if acc:
-                    call.pn2_copy(F32, _p(dfg), K, F32, _p(g), g.stride(2), M, K, 1, _stream())
-                return
-            gs = [a.grad_sink() for a in (fg, crop_fg, crop_bg)]
-            tmp = [self.fbuf(M, K) if acc else None for (_, acc) in gs]
-            dst = [t if t is not None else g for t, (g, _) in zip(tmp, gs)]
-            call.pn2_dsra_fuse_bwd(fg.ptr, crop_fg.ptr, crop_bg.ptr, _p(gy), _p(dst[0]), _p(dst[1]), _p(dst[2]), M, K, sm, _stream())
-            for t, (g, acc) in zip(tmp, gs):
-                if t is not None:
-                    call.pn2_copy(F32, _p(t), K, F32, _p(g), g.stride(2), M, K, 1, _stream())
-        self.record(bwd)
-        return y
-
-    def ra_gate(self, x, crop):
-        """(1 - sigmoid(crop)).expand(C) * x      (PraNet V1 reverse attention)"""
-        assert crop.dt == F32 and crop.C == 1
-        y = Act(self, self.empty(x.N, x.H, x.W, x.Cp, x.dt), x.C, x.gw, x.gwp, x.dt)
-        call.pn2_ra_gate_fwd(x.dt, x.ptr, x.ld, crop.ptr, y.ptr, y.ld, x.M, x.Cp, _stream())
-
-        def bwd():
-            gy = y.grad_buf()
-            gx, acc = x.grad_sink()
-            gc, cacc = crop.grad_sink()
-            dc = self.fbuf(x.M) if cacc else gc
-            call.pn2_ra_gate_bwd(x.dt, x.ptr, x.ld, crop.ptr, _p(gy), gy.stride(2), _p(gx), gx.stride(2), acc, _p(dc), x.M, x.Cp, _stream())
-            if cacc:
-                call.pn2_copy(F32, _p(dc), 1, F32, _p(gc), 1, x.M, 1, 1, _stream())
-        self.record(bwd)
-        return y
 
     # ------------------------------------------------------------------ bookkeeping
     def finish_forward(self):

@@ -112,7 +112,7 @@ def test_eval_conv_bn_fused_in_gemm_epilogue(dtn, cfg, monkeypatch):
     (one rounding fewer; with a residual: the same two roundings at other places, within 1.25 x).  Covers group-padded outputs (26 channels in 32 slots), partial last tiles, stride 2, a 5x5 and the split between pre- and post-residual
     activation."""
     from pn2 import F32, BF16
-    from pn2 import engine as E
+    from pn2 import engine as E, core
     N, Cin, Cout, k, stride, pad, H, Wd, relu, use_res, omap = cfg
     dt = F32 if dtn == "fp32" else BF16
     torch.manual_seed(2)
@@ -124,7 +124,7 @@ def test_eval_conv_bn_fused_in_gemm_epilogue(dtn, cfg, monkeypatch):
     res = torch.randn(N, Cout, OH, OW, device=dev) if use_res else None
 
     def run(fuse):
-        monkeypatch.setattr(E, "EVAL_FUSE", fuse)
+        monkeypatch.setattr(core, "EVAL_FUSE", fuse)
         eng = E.Engine(dt, False, need_grad=False)
         a = eng.from_nchw(x)
         r = eng.from_nchw(res) if use_res else None
@@ -208,7 +208,7 @@ def test_bn_backward_statistics_in_dgrad_epilogue(dtn, case, monkeypatch):
     BatchNorm-backward sums of the layer below in its epilogue (pn2_conv_gemm_ep) instead of a pn2_bn_bwd_reduce pass; same gradients as
     torch float64 autograd, and - in fp32 - as the engine's own reduce-pass path.  big_mean: |mean| >> sigma channels (the Chan-merged
     forward statistics must not cancel)."""
-    from pn2 import F32, BF16, engine
+    from pn2 import F32, BF16, engine, core
     from pn2.engine import Engine
     from pn2.graph import _seed_grad
     from pn2 import capi
@@ -270,7 +270,7 @@ def test_bn_backward_statistics_in_dgrad_epilogue(dtn, case, monkeypatch):
         if float(r_.abs().max()) > 1e-9:          # (the bias of a BatchNorm behind a 1x1 conv + train-mode BatchNorm has an exactly-zero gradient)
             assert err(g_, r_) < tol, (i_, err(g_, r_))
     # against the separate reduce pass: same sums up to fp32 summation order (bf16: the epilogue sees the fp32 gradient tile before it is rounded)
-    monkeypatch.setattr(engine, "BNB_EPILOGUE", False)
+    monkeypatch.setattr(core, "BNB_EPILOGUE", False)
     out0, _, grads0, n0 = run(True)
     assert n0 == 0
     for g_, r_, f_ in zip(grads, grads0, ref):
@@ -327,10 +327,10 @@ def test_dsra_k1_degenerates_to_doubling(skip, monkeypatch):
     """num_class=1: softmax over one channel is 1.0, so fg <- 2*fg and d/dcrop == 0 exactly (SURVEY 'three facts' #2).  The engine uses that:
     the crop maps receive NO gradient contribution (ZERO_CROP_SKIP), so the resamples that produced them skip their adjoints; with the switch off
     the kernel writes the (exactly zero) crop gradients."""
-    from pn2 import F32, engine
+    from pn2 import F32, engine, core
     from pn2.engine import Engine, Act
     from pn2.graph import _seed_grad
-    monkeypatch.setattr(engine, "ZERO_CROP_SKIP", skip)
+    monkeypatch.setattr(core, "ZERO_CROP_SKIP", skip)
     eng = Engine(F32, True, need_grad=True)
     mk = lambda: Act(eng, torch.randn(2, 7, 7, 1, device=dev), 1, 1, 1, F32)
     fg, src_f, src_b = mk(), Act(eng, torch.randn(2, 14, 14, 1, device=dev), 1, 1, 1, F32), mk()
@@ -850,14 +850,14 @@ def test_lockstep_launches_match_plain_launches(fp32, size, monkeypatch):
     block, advance position by position on table-driven launches (pn2_conv_gemm_multi, pn2_bn_finalize_multi, pn2_affine_multi,
     pn2_bn_bwd_finalize_multi, pn2_bn_bwd_apply_multi, pn2_bn_bwd_reduce_multi) - against one launch per chain: loss, every gradient and the
     parameters after three optimizer steps, bit for bit; and the launch count drops."""
-    from pn2 import engine, capi
+    from pn2 import engine, capi, core
     from pn2.trainer import Trainer
     from oracle import weights as W
     x, mask = W.synthetic_batch(2, size, seed=6)
     xg, mg = x.to(dev), mask.to(dev)
     res = []
     for on in (False, True):
-        monkeypatch.setattr(engine, "LOCKSTEP", on)
+        monkeypatch.setattr(core, "LOCKSTEP", on)
         tr = Trainer(_fixture_model(fp32=fp32))
         for _ in range(3):          # step 1 torch allocator (no lock step), step 2 builds the tables on arena addresses, step 3 replays them
             loss = tr.step(xg, mg)

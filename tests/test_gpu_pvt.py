@@ -288,7 +288,7 @@ def test_deferred_column_sums_and_splitk_match_immediate_launches(monkeypatch):
     bias, LayerNorm and depth-wise parameter: bit for bit over a PVT-PraNet-V2 training step; and the split-K launch of a few-row / long-
     contraction conv (fp32 partial tiles + reduce with the BatchNorm statistics) against the plain launch."""
     import ctypes as C
-    from pn2 import engine, capi
+    from pn2 import engine, capi, core
     from pn2.capi import call, BF16
     from pn2.trainer import Trainer
     from oracle import weights as W
@@ -296,7 +296,7 @@ def test_deferred_column_sums_and_splitk_match_immediate_launches(monkeypatch):
     x, m = x.to(dev), m.to(dev)
     res = []
     for defer in (False, True):
-        monkeypatch.setattr(engine, "DEFER_COLSUM", defer)
+        monkeypatch.setattr(core, "DEFER_COLSUM", defer)
         tr = Trainer(_pvt_model(fp32=False))
         for _ in range(3):
             loss = tr.forward_backward(x, m)

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 os.environ.setdefault("PN2_NO_PRETRAINED", "1")
 dev = "cuda"
 
-# (where, name, value): "engine" / "res2net" = module constant, "env" = environment variable read by Trainer / run_module at construction
+# (where, name, value): "engine" (pn2/core.py) / "res2net" = module constant, "env" = environment variable read by Trainer / run_module at construction
 SWITCHES = [
     ("engine", "BNB_EPILOGUE", False), ("engine", "MASKED_STORE", False), ("engine", "LOCKSTEP", False), ("engine", "GRAD_ALIAS", False),
     ("engine", "SPLITK", False), ("engine", "FUSE_BIAS", False), ("engine", "DEFER_COLSUM", False), ("engine", "ZERO_CROP_SKIP", False),
@@ -58,7 +58,7 @@ def test_step_under_switch_matches_default(where, name, value, monkeypatch):
         monkeypatch.setenv(name, value)
     else:
         import importlib
-        mod = importlib.import_module("pn2.engine" if where == "engine" else "lib.Res2Net_v1b")
+        mod = importlib.import_module("pn2.core" if where == "engine" else "lib.Res2Net_v1b")
         assert hasattr(mod, name), name
         monkeypatch.setattr(mod, name, value)
     l1, g1, o1 = _step()
