@@ -157,6 +157,21 @@ class _Site:
         o, n = self.off[id(p)]
         return self.gflat[o:o + n].view(p.shape)
 
+    def hand_out(self, grads):
+        """The parameter gradients of a pass as autograd gets them: views of ONE fresh copy of the flat buffer (one launch instead of one clone per parameter;
+        nothing else references the views, so autograd adopts them as .grad where a parameter has none).  Gradients that do not live in the flat buffer are cloned."""
+        flat = self.gflat.clone()
+        out = []
+        for g in grads:
+            if g is None:
+                out.append(None)
+            elif g.untyped_storage().data_ptr() == self.gflat.untyped_storage().data_ptr():
+                o = g.storage_offset()
+                out.append(flat[o:o + g.numel()].view(g.shape))
+            else:
+                out.append(g.clone())
+        return out
+
     def begin(self, ctx):
         self.gen += 1
         ctx.site, ctx.gen, ctx.token = self, self.gen, _Token()
@@ -226,8 +241,7 @@ class _SiteFn(torch.autograd.Function):
         site, eng = ctx.site, ctx.eng
         site.check(ctx)
         site.backward(eng, ctx.outs, gouts)
-        gpar = [eng.pgrads.get(p) for p in ctx.params]
-        site.keep = gpar                               # a second reference: autograd copies the views of the flat buffer instead of adopting them
+        gpar = site.hand_out([eng.pgrads.get(p) for p in ctx.params])
         site.bwd_done = True
         eng.pgrads.provider = None
         eng.lock_cache = eng.grad_queue = eng.arena = eng.pack_cache = None
@@ -256,7 +270,7 @@ class _ReplayFn(torch.autograd.Function):
                 s_.copy_(g, non_blocking=True)
         site.graph_b.replay()
         site.bwd_done = True
-        return (None, None, *([None] * ctx.n_in), *site.s_pgrads)
+        return (None, None, *([None] * ctx.n_in), *site.hand_out(site.s_pgrads))
 
 
 def _site(build, inputs, params, training, dtype, pc):

@@ -151,3 +151,16 @@ def test_second_forward_before_backward_falls_back_to_the_plain_pass():
     model(xa)
     model.train()
     assert st.gen == n_gen
+
+
+def test_clip_gradient_multi_tensor_form_is_the_per_tensor_clamp():
+    """utils.clip_gradient (reference utils/utils.py:7-17) clamps GPU gradients with two multi-tensor launches: same values as the reference's per-parameter loop."""
+    from utils.utils import clip_gradient
+    g = torch.Generator(device=dev).manual_seed(0)
+    ps = [torch.nn.Parameter(torch.zeros(s, device=dev)) for s in ((3, 5), (7,), (2, 3, 4, 5), (1,))] + [torch.nn.Parameter(torch.zeros(4, device=dev))]
+    for p in ps[:-1]:
+        p.grad = torch.randn(p.shape, device=dev, generator=g) * 2
+    want = [None if p.grad is None else p.grad.clone().clamp_(-0.5, 0.5) for p in ps]
+    clip_gradient(torch.optim.SGD(ps, 0.1), 0.5)
+    for p, w in zip(ps, want):
+        assert (p.grad is None and w is None) or torch.equal(p.grad, w)
