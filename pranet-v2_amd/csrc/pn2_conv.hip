@@ -2249,47 +2249,57 @@ __global__ __launch_bounds__(256) void dgrad_small_cin_k(const T* __restrict__ d
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ ws, int S, int M, int C, T* __restrict__ out, int ld_out, const float* __restrict__ bias,
                                                        float* __restrict__ psum, float* __restrict__ psq, int accumulate, int LANES) {
+    // grid = (64-row blocks, groups of LANES column vectors): a few-row tensor (the 11 x 11 maps this is used for have 61 row blocks) still fills the chip
     __shared__ float sh[2][256][4];
     const int CV = C >> 2, R = 256 / LANES, cl = threadIdx.x % LANES, rl = threadIdx.x / LANES;
     const int m0 = blockIdx.x * 64;
-    for (int cb = 0; cb < CV; cb += LANES) {
-        const int cv = cb + cl, c = cv * 4;
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        if (cv < CV) {
-            float b[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) { b[0] = bias[c]; b[1] = bias[c + 1]; b[2] = bias[c + 2]; b[3] = bias[c + 3]; }
-            for (int m = m0 + rl; m < m0 + 64 && m < M; m += R) {
-                float4 v = *reinterpret_cast<const float4*>(ws + (size_t)m * C + c);
-                for (int s = 1; s < S; ++s) {
-                    const float4 u = *reinterpret_cast<const float4*>(ws + ((size_t)s * M + m) * C + c);
-                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                }
-                const float vv[4] = {v.x, v.y, v.z, v.w};
-                T* dst = out + (size_t)m * ld_out + c;
+    const int cv = blockIdx.y * LANES + cl, c = cv * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cv < CV) {
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) { b[0] = bias[c]; b[1] = bias[c + 1]; b[2] = bias[c + 2]; b[3] = bias[c + 3]; }
+        for (int m = m0 + rl; m < m0 + 64 && m < M; m += R) {
+            float4 v = *reinterpret_cast<const float4*>(ws + (size_t)m * C + c);
+            for (int s = 1; s < S; ++s) {
+                const float4 u = *reinterpret_cast<const float4*>(ws + ((size_t)s * M + m) * C + c);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            T* dst = out + (size_t)m * ld_out + c;
+            float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // bf16: the moments of the value as it is STORED (rounded), the one definition of the batch statistics for every bf16 conv kernel
-                    float sv = vv[e];
-                    if constexpr (sizeof(T) == 2) sv = bf2f(f2bf(vv[e]));
-                    s1[e] += sv; s2[e] += sv * sv;
-                    const float o = vv[e] + b[e];
-                    TT<T>::st(dst + e, accumulate ? o + TT<T>::ld(dst + e) : o);
+            for (int e = 0; e < 4; ++e) {
+                // bf16: the moments of the value as it is STORED (rounded), the one definition of the batch statistics for every bf16 conv kernel
+                float sv = vv[e];
+                if constexpr (sizeof(T) == 2) sv = bf2f(f2bf(vv[e]));
+                s1[e] += sv; s2[e] += sv * sv;
+                o[e] = vv[e] + b[e];
+            }
+            if constexpr (sizeof(T) == 2) {          // one 8-byte access per direction (ld_out and c are multiples of 4)
+                if (accumulate) {
+                    const uint2 p = *reinterpret_cast<const uint2*>(dst);
+                    o[0] += bf2f((bf16_t)(p.x & 0xffffu)); o[1] += bf2f((bf16_t)(p.x >> 16)); o[2] += bf2f((bf16_t)(p.y & 0xffffu)); o[3] += bf2f((bf16_t)(p.y >> 16));
                 }
+                uint2 q;
+                q.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16); q.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+                *reinterpret_cast<uint2*>(dst) = q;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) TT<T>::st(dst + e, accumulate ? o[e] + TT<T>::ld(dst + e) : o[e]);
             }
         }
-        if (psum) {
+    }
+    if (psum) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { sh[0][threadIdx.x][e] = s1[e]; sh[1][threadIdx.x][e] = s2[e]; }
-            __syncthreads();
-            if (rl == 0 && cv < CV) {
+        for (int e = 0; e < 4; ++e) { sh[0][threadIdx.x][e] = s1[e]; sh[1][threadIdx.x][e] = s2[e]; }
+        __syncthreads();
+        if (rl == 0 && cv < CV) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float a = 0.f, q = 0.f;
-                    for (int r = 0; r < R; ++r) { a += sh[0][r * LANES + cl][e]; q += sh[1][r * LANES + cl][e]; }
-                    psum[(size_t)blockIdx.x * C + c + e] = a; psq[(size_t)blockIdx.x * C + c + e] = q;
-                }
+            for (int e = 0; e < 4; ++e) {
+                float a = 0.f, q = 0.f;
+                for (int r = 0; r < R; ++r) { a += sh[0][r * LANES + cl][e]; q += sh[1][r * LANES + cl][e]; }
+                psum[(size_t)blockIdx.x * C + c + e] = a; psq[(size_t)blockIdx.x * C + c + e] = q;
             }
-            __syncthreads();
         }
     }
 }
@@ -2541,8 +2551,9 @@ int pn2_conv_splitk_reduce(int dtype, const float* ws, int ksplit, int M, int Co
                            void* stream) {
     if (!ws || !out || ksplit < 1 || M < 1 || Cout < 1 || ((psum == nullptr) != (psq == nullptr))) return -1;
     if (Cout % 4) return -2;
-    const dim3 grid((M + 63) / 64);
-    int lanes = 1; while (lanes < Cout / 4 && lanes < 64) lanes <<= 1;          // <= 64 column lanes -> >= 4 row lanes
+    int lanes = 1; while (lanes < Cout / 4 && lanes < 16) lanes <<= 1;          // <= 16 column lanes (64 channels) per workgroup -> >= 16 row lanes
+    if (dtype == PN2_BF16 && ld_out % 4) return -2;
+    const dim3 grid((M + 63) / 64, (Cout / 4 + lanes - 1) / lanes);
     if (dtype == PN2_BF16) hipLaunchKernelGGL(splitk_reduce_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, ws, ksplit, M, Cout, (bf16_t*)out, ld_out, bias, psum, psq, accumulate, lanes);
     else if (dtype == PN2_F32) hipLaunchKernelGGL(splitk_reduce_k<float>, grid, dim3(256), 0, (hipStream_t)stream, ws, ksplit, M, Cout, (float*)out, ld_out, bias, psum, psq, accumulate, lanes);
     else return -3;
