@@ -147,6 +147,8 @@ want = [("pw64-256", lambda k: k[9] == 1 and k[6] == 64 and k[8] == 256 and k[16
         ("stem32-64", lambda k: k[9] == 3 and k[6] == 32 and k[8] == 64 and k[4] == 176)]
 if any(a.startswith("ep") for a in flt):
     eps = [k for k in TABLE if k[0] == "g" and len(k) == 22]
+    if os.environ.get("K3"):                       # only the 3x3 dgrads (the Res2Net branch convs)
+        eps = [k for k in eps if k[9] == 3]
     eps.sort(key=lambda k: -(k[1] * k[4] * k[5] * k[8]))
     for key in eps[:int(os.environ.get("NEP", "10"))]:
         print(f"==== ep {key}")
