@@ -131,7 +131,10 @@ int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const 
  * and run all convs that share a kernel instantiation (pn2_conv_wgrad_variant) together, from a DEVICE job table.
  * block_start_dev: njobs + 1 prefix sums of pn2_conv_wgrad_blocks(&job.d, job.nsplit).  Same arithmetic, bit for bit, as
  * pn2_conv_wgrad on each job. */
-typedef struct pn2_wgrad_job { const void* dy; const void* x; float* slab; pn2_wgrad_desc d; int nsplit; } pn2_wgrad_job;
+typedef struct pn2_wgrad_job { const void* dy; const void* x; float* slab; pn2_wgrad_desc d; int nsplit;
+    int rot;      /* 0..7: XCD rotation of this job's pixel splits (split s runs on XCD (s + rot) % 8): the caller advances it by nsplit % 8 from job to job, so the
+                   * partial split groups of a table (nsplit = 3, 6, 12 ... on the long-contraction layers) spread over the 8 XCDs instead of piling onto the first ones */
+} pn2_wgrad_job;
 int pn2_conv_wgrad_variant(int dtype, const pn2_wgrad_desc* d);
 int pn2_conv_wgrad_blocks(const pn2_wgrad_desc* d, int nsplit);
 int pn2_conv_wgrad_multi(int dtype, int variant, const pn2_wgrad_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);

@@ -1632,7 +1632,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_tab(const pn2_wgrad_job* __res
     for (int b = blockIdx.x; b < total; b += gridDim.x) {
         const int jb = find_job(bstart, njobs, b);
         const pn2_wgrad_job j = jobs[jb];
-        conv_wgrad_body<T, BMC, BNK, WM, WN, PW>((const T*)j.dy, (const T*)j.x, j.slab, j.d, j.nsplit, b - bstart[jb]);
+        const int bl = b - bstart[jb];          // (the job's XCD rotation relabels the low three bits: the body reads the split's XCD slot from them)
+        conv_wgrad_body<T, BMC, BNK, WM, WN, PW>((const T*)j.dy, (const T*)j.x, j.slab, j.d, j.nsplit, (bl & ~7) | ((bl - j.rot) & 7));
         __syncthreads();            // the next pair restages LDS
     }
 }
@@ -1646,7 +1647,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_tab(const pn2_wgrad_job* _
     for (int b = blockIdx.x; b < total; b += gridDim.x) {
         const int jb = find_job(bstart, njobs, b);
         const pn2_wgrad_job j = jobs[jb];
-        conv_wgrad_dma_body<BMC, WM, WN, PW, BNK>((const bf16_t*)j.dy, (const bf16_t*)j.x, j.slab, j.d, j.nsplit, b - bstart[jb]);
+        const int bl = b - bstart[jb];
+        conv_wgrad_dma_body<BMC, WM, WN, PW, BNK>((const bf16_t*)j.dy, (const bf16_t*)j.x, j.slab, j.d, j.nsplit, (bl & ~7) | ((bl - j.rot) & 7));
         __syncthreads();
     }
 }

@@ -35,7 +35,7 @@ class PackJob(C.Structure):
 
 
 class WgradJob(C.Structure):
-    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("slab", C.c_void_p), ("d", WgradDesc), ("nsplit", C.c_int)]
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("slab", C.c_void_p), ("d", WgradDesc), ("nsplit", C.c_int), ("rot", C.c_int)]
 
 
 class ReduceJob(C.Structure):

@@ -349,6 +349,7 @@ class StepArena:
 TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the tuners time every candidate behind a cache-evicting fill (tests/conftest.py switches it off)
 WGRAD_WGS = 640               # pixel splits: workgroups a single wgrad aims at ...
 WGRAD_SLAB_MB = 24            # ... within this many MB of fp32 slabs
+WGRAD_ROTATE = os.environ.get("PN2_WGRAD_ROTATE", "1") == "1"      # table-driven wgrad: a job's pixel splits start on the XCD after the previous job's last one
 _THRASH = {}
 
 
@@ -435,10 +436,12 @@ class GradQueue:
             # longest workgroups first (pixels per split x taps): the hardware hands out workgroups in index order, so the short jobs fill the
             # tail of the launch instead of the long ones stretching it
             js = sorted(js, key=lambda j: -((j[3].N * j[3].OH * j[3].OW + j[4] - 1) // j[4]) * j[3].KH * j[3].KW)
-            arr = []
+            arr, rot = [], 0
             for dy, x, slab, wd, ns, fl in js:
                 j = capi.WgradJob()
                 j.dy, j.x, j.slab, j.nsplit = dy, x, slab, ns
+                if WGRAD_ROTATE:
+                    j.rot, rot = rot, (rot + ns) & 7        # the next job's splits continue on the XCD after this job's last one
                 C.memmove(C.byref(j.d), C.byref(wd), C.sizeof(capi.WgradDesc))
                 arr.append(j)
             table, bstart, nblocks = _job_table(capi.WgradJob, arr, [call.pn2_conv_wgrad_blocks(C.byref(j.d), j.nsplit) for j in arr])
