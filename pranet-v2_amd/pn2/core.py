@@ -349,6 +349,7 @@ class StepArena:
 TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the tuners time every candidate behind a cache-evicting fill (tests/conftest.py switches it off)
 WGRAD_WGS = 640               # pixel splits: workgroups a single wgrad aims at ...
 WGRAD_SLAB_MB = 24            # ... within this many MB of fp32 slabs
+WGRAD_SLAB_CAP = float(os.environ.get("PN2_WGRAD_SLAB_CAP", "0.25"))   # table-driven wgrad: fp32 slab bytes of a job <= this x its operand bytes (GradQueue.table_splits; 0: off)
 WGRAD_ROTATE = os.environ.get("PN2_WGRAD_ROTATE", "1") == "1"      # table-driven wgrad: a job's pixel splits start on the XCD after the previous job's last one
 _THRASH = {}
 
@@ -382,8 +383,9 @@ class GradQueue:
     table-driven launches: one pn2_conv_wgrad_multi per kernel instantiation, then one pn2_wgrad_reduce_multi.  Device job tables
     are cached per flush segment and reused for as long as the queued pointers are unchanged (always, with a StepArena)."""
 
-    def __init__(self, defer_wgrad=True):
+    def __init__(self, defer_wgrad=True, slab_cap=None):
         self.defer_wgrad = defer_wgrad
+        self.slab_cap = slab_cap          # None: WGRAD_SLAB_CAP; 0: the tuner's split counts
         self.slabs = {}
         self.cache = {}                   # segment index -> (signature, launches)
         self.ccache = {}                  # same for the engine's queued column-sum finalisations
@@ -408,6 +410,17 @@ class GradQueue:
                 raise RuntimeError("run eager steps before capturing (persistent wgrad slabs are allocated then)")
             t = self.slabs[key] = torch.empty(shape, dtype=torch.float32, device=dev)
         return t
+
+    def table_splits(self, nsplit, M, chans, wd):
+        """Pixel splits of a wgrad that runs inside a table-driven launch.  The tuner times a conv ALONE, where splits are what fills the chip; inside a table the
+        other jobs do that, and every split costs a fp32 slab (Rp x Kp x 4 B written, then re-read by the reduce: 3.9 GB of the step's 46 GB with the tuned counts).
+        The slabs of a job are therefore capped at WGRAD_SLAB_CAP x the bytes of its own operands (dy + x): the long-contraction / few-pixel layers go from
+        3..16 splits to 1..2, the many-pixel layers keep theirs.  Sweep at bs = 32 (ms per step): no cap 14.51, 1: 14.27, 0.5: 14.22, 0.35: 14.19, 0.25: 14.19, 0.18: 14.18,
+        0.125: 14.53 (the greedy XCD rotation of _build is what makes few splits pay: without it they pile onto the first XCDs)."""
+        cap = self.slab_cap if self.slab_cap is not None else WGRAD_SLAB_CAP
+        if cap <= 0:
+            return nsplit
+        return min(nsplit, max(1, int(cap * M * chans * 2 // (wd.Rp * wd.Kp * 4))))
 
     def add_wgrad(self, dt, dy, x_ptr, x_keep, slab, wd, nsplit, flops=0):
         self.wjobs.append((dt, dy.data_ptr(), x_ptr.value, slab.data_ptr(), wd, nsplit, flops))
@@ -436,12 +449,19 @@ class GradQueue:
             # longest workgroups first (pixels per split x taps): the hardware hands out workgroups in index order, so the short jobs fill the
             # tail of the launch instead of the long ones stretching it
             js = sorted(js, key=lambda j: -((j[3].N * j[3].OH * j[3].OW + j[4] - 1) // j[4]) * j[3].KH * j[3].KW)
-            arr, rot = [], 0
+            arr, load = [], [0] * 8
             for dy, x, slab, wd, ns, fl in js:
                 j = capi.WgradJob()
                 j.dy, j.x, j.slab, j.nsplit = dy, x, slab, ns
                 if WGRAD_ROTATE:
-                    j.rot, rot = rot, (rot + ns) & 7        # the next job's splits continue on the XCD after this job's last one
+                    # split s of a job runs on XCD (s + rot) % 8 (all its tiles: one L2 fetches that split's dy / x slice once).  Jobs arrive longest first; each takes
+                    # the rotation that keeps the most loaded XCD lowest (work of a split ~ its steps x the job's tiles; equal tile shape inside one table)
+                    w = ((wd.N * wd.OH * wd.OW + 31) // 32 + ns - 1) // ns * (call.pn2_conv_wgrad_blocks(C.byref(wd), ns) // (8 * ((ns + 7) // 8)))
+                    per = [(ns - x_ + 7) // 8 for x_ in range(8)]              # splits on logical XCD slot x_
+                    best = min(range(8), key=lambda r: (max(load[(x_ + r) & 7] + per[x_] * w for x_ in range(8)), r))
+                    for x_ in range(8):
+                        load[(x_ + best) & 7] += per[x_] * w
+                    j.rot = best
                 C.memmove(C.byref(j.d), C.byref(wd), C.sizeof(capi.WgradDesc))
                 arr.append(j)
             table, bstart, nblocks = _job_table(capi.WgradJob, arr, [call.pn2_conv_wgrad_blocks(C.byref(j.d), j.nsplit) for j in arr])

@@ -268,7 +268,8 @@ def test_trainer_mutation_step_matches_module_surface_and_adamw():
     for (n, _), pa, pb in zip([(n, p) for n, p in mb.named_parameters() if any(p is q for q in hot_b)], g_a, hot_b):
         gb = tr._grad_view(pb)
         scale = float(pa.abs().max())
-        assert float((gb - pa).abs().max()) <= 1e-5 * max(scale, 1e-3), n          # same kernels; only the launch grouping differs
+        # same kernels; the launch grouping differs, and the table-driven wgrads run fewer pixel splits (GradQueue.table_splits): another fp32 summation order
+        assert float((gb - pa).abs().max()) <= 1e-5 * max(scale, 1e-3) + 2e-7, n
     tr.optimizer_step()
     l2 = tr.step(x, (label, bg))
     torch.cuda.synchronize()

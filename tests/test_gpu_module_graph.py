@@ -68,8 +68,11 @@ def test_training_loop_with_graph_replayed_call_site_matches_eager():
         assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (l0, l1)
     for k in sd0:
         if sd0[k].numel() > 1:
-            d = float((sd0[k] - sd1[k]).abs().max())
-            assert d <= 2e-4 * max(1e-3, float(sd0[k].abs().max())) + 1e-6, (k, d)       # 7 Adam steps of lr 1e-4: a step is +-1e-4, equal up to the sign of ~zero gradients
+            # Adam moves a weight by ~lr per step whatever the size of its gradient: where a gradient is ~0 the two runs (another fp32 summation order in the
+            # table-driven wgrads) may step in opposite directions - a few steps of 1e-4 on single elements, nothing on the bulk
+            d = (sd0[k] - sd1[k]).abs()
+            assert float(d.max()) <= 3e-4 + 1e-6 * float(sd0[k].abs().max()), (k, float(d.max()))
+            assert float(d.norm()) <= 2e-3 * float(sd0[k].norm()) + 1e-6, (k, float(d.norm()), float(sd0[k].norm()))
 
 
 def test_outputs_and_gradients_of_a_replayed_call_match_the_plain_pass():

@@ -824,8 +824,10 @@ def test_lr_schedule_reaches_captured_graph():
 @pytest.mark.parametrize("fp32", [False, True])
 def test_table_driven_launches_match_single_launches(fp32, monkeypatch):
     """pn2_conv_wgrad_multi / pn2_wgrad_reduce_multi over the step arena == one pn2_conv_wgrad + pn2_wgrad_reduce per conv, bit for bit."""
+    from pn2 import core
     from pn2.trainer import Trainer
     from oracle import weights as W
+    monkeypatch.setattr(core, "WGRAD_SLAB_CAP", 0.0)       # same pixel splits in both forms (the table form otherwise runs fewer: GradQueue.table_splits, tests/test_gpu_switches.py)
     x, mask = W.synthetic_batch(2, 96, seed=5)
     xg, mg = x.to(dev), mask.to(dev)
     res = []
