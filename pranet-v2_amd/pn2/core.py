@@ -349,7 +349,7 @@ class StepArena:
 TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the tuners time every candidate behind a cache-evicting fill (tests/conftest.py switches it off)
 WGRAD_WGS = 640               # pixel splits: workgroups a single wgrad aims at ...
 WGRAD_SLAB_MB = 24            # ... within this many MB of fp32 slabs
-WGRAD_SLAB_CAP = float(os.environ.get("PN2_WGRAD_SLAB_CAP", "0.25"))   # table-driven wgrad: fp32 slab bytes of a job <= this x its operand bytes (GradQueue.table_splits; 0: off)
+WGRAD_SLAB_CAP = float(os.environ.get("PN2_WGRAD_SLAB_CAP", "0.35"))   # table-driven wgrad: fp32 slab bytes of a job <= this x its operand bytes (GradQueue.table_splits; 0: off)
 WGRAD_ROTATE = os.environ.get("PN2_WGRAD_ROTATE", "1") == "1"      # table-driven wgrad: a job's pixel splits start on the XCD after the previous job's last one
 _THRASH = {}
 
@@ -414,7 +414,7 @@ class GradQueue:
     def table_splits(self, nsplit, M, chans, wd):
         """Pixel splits of a wgrad that runs inside a table-driven launch.  The tuner times a conv ALONE, where splits are what fills the chip; inside a table the
         other jobs do that, and every split costs a fp32 slab (Rp x Kp x 4 B written, then re-read by the reduce: 3.9 GB of the step's 46 GB with the tuned counts).
-        The slabs of a job are therefore capped at WGRAD_SLAB_CAP x the bytes of its own operands (dy + x): the long-contraction / few-pixel layers go from
+        The slabs of a job are therefore capped at WGRAD_SLAB_CAP (0.35) x the bytes of its own operands (dy + x): the long-contraction / few-pixel layers go from
         3..16 splits to 1..2, the many-pixel layers keep theirs.  Sweep at bs = 32 (ms per step): no cap 14.51, 1: 14.27, 0.5: 14.22, 0.35: 14.19, 0.25: 14.19, 0.18: 14.18,
         0.125: 14.53 (the greedy XCD rotation of _build is what makes few splits pay: without it they pile onto the first XCDs)."""
         cap = self.slab_cap if self.slab_cap is not None else WGRAD_SLAB_CAP
