@@ -10,12 +10,13 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, gflat, spans, bucket_bytes=64 << 20, process_group=None, wire_dtype=None, head_bytes=None):
+    def __init__(self, gflat, spans, bucket_bytes=100 << 20, process_group=None, wire_dtype=None, head_bytes=None):
         """spans: ordered list of (key, offset, length) of the parameters inside `gflat` (elements).
         Buckets are cut FROM THE TAIL of the arena - the order backward completes gradients in: full buckets of `bucket_bytes`, whose all-reduce overlaps
         the backward kernels that follow, and the bucket that leaves last (the head of the arena: nothing is left to overlap its all-reduce with) holds at
-        most `head_bytes` (default bucket_bytes / 5).  Every cut costs a flush of the deferred weight-gradient tables (~0.09 ms on an MI355X), every byte of
-        the last bucket is exposed wire time: 64 MB + a 12 MB head gives 3 buckets for PraNet-V2's 122 MB of gradients.
+        most `head_bytes` (default bucket_bytes / 5).  Every cut costs a flush of the deferred weight-gradient tables (0.25 ms on an MI355X: two sets of smaller, less balanced
+        tables instead of one), every byte of the last bucket is exposed wire time: 100 MB gives PraNet-V2's 122 MB of gradients ONE cut - a 101 MB bucket that leaves with a fifth of
+        the backward pass still to run, and a 16 MB head (one-rank RCCL, ms per step: local 14.22, no cut 14.22, one cut 14.47, two cuts 14.71).
         wire_dtype: None = the buckets travel as they are (fp32, what the reference's DDP does); torch.bfloat16 = each bucket is rounded to bf16
         for the exchange (half the bytes on xGMI) and widened back into the fp32 arena after it - the sum itself is then a bf16 sum, so this is
         a bandwidth / precision trade the caller has to ask for (PN2_DP_WIRE=bf16)."""

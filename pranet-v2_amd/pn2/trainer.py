@@ -34,7 +34,7 @@ DP_CAPTURE = os.environ.get("PN2_DP_CAPTURE", "1") == "1"
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8, dtype=None, process_group=None, bucket_bytes=64 << 20,
+    def __init__(self, model, lr=1e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8, dtype=None, process_group=None, bucket_bytes=100 << 20,
                  loss="structure", loss_weights=(0.5, 0.7, 0.3), weight_decay=0.0, hot=None, force_dp=False):
         """loss: "structure" - the 4-pair structure loss of MyTrain_med.py:78-82 on (images, masks), Adam + clip_gradient (binary_seg);
                  "mutation"  - the 15-subset CE + Dice + BCE loss of EMCAD/trainer.py:106-140 on (images, (label, bg_mask)) with the 8 maps of a
