@@ -192,6 +192,10 @@ int pn2_affine_act(int dt_in, const void* x, int ld_x, int dt_out, void* y, int 
  * written by the pass that produces sp.  16-byte aligned rows only (-2 otherwise). */
 int pn2_affine_act_sum(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* scale, const float* shift, int relu,
                        const void* add, int ld_add, void* y2, int ld_y2, void* stream);
+/* pn2_affine_act (same dtype, no residual) whose channels >= c_lo are ALSO written to y3[m][c - c_lo]: conv1 + bn1 + ReLU of a Bottle2neck writes its last
+ * slice spx[3] straight into the concat buffer (Res2Net_v1b.py:78-79: `out = torch.cat((out, spx[self.nums]), 1)`), no copy launch.  16-byte aligned rows / c_lo only. */
+int pn2_affine_act_tee(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* scale, const float* shift, int relu,
+                       void* y3, int ld_y3, int c_lo, void* stream);
 /* backward pass 1: per-channel partials of sum(dz) and sum(dz*xhat), dz = dy*(relu mask) ; dy has Cdy valid channels.
  * ReLU mask: y>0 when y is given; else recomputed as fmaf(x,mask_scale,mask_shift)>0 when mask_scale is given (saves reading y). */
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,

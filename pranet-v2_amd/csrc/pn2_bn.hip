@@ -397,9 +397,11 @@ template <typename T>
 __device__ __forceinline__ void affine_rows_body(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int M, int C,
                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                  const T* __restrict__ res, int ld_res, int relu, int rows_per_blk, int CVP,
-                                                 const T* __restrict__ add, int ld_add, T* __restrict__ y2, int ld_y2, int bid) {
+                                                 const T* __restrict__ add, int ld_add, T* __restrict__ y2, int ld_y2, int bid,
+                                                 T* __restrict__ y3 = nullptr, int ld_y3 = 0, int c_lo = 0) {
     // add / y2 (optional): second output y2 = y + add - the "sp + spx[i+1]" of Bottle2neck.forward (Res2Net_v1b.py:68) written by the pass
     // that produces sp instead of by a separate element-wise launch
+    // y3 (optional): the channels >= c_lo are ALSO written to y3[m][c - c_lo] - Bottle2neck's pass-through slice spx[3] lands in the concat buffer (Res2Net_v1b.py:78-79) without a copy launch
     constexpr int V = TT<T>::VEC;
     const int CV = C / V, R = 256 / CVP;
     const int cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
@@ -437,6 +439,7 @@ __device__ __forceinline__ void affine_rows_body(const T* __restrict__ x, int ld
                     }
                     const uint4 pk = TT<T>::pack(v);
                     *reinterpret_cast<uint4*>(y + (size_t)mm * ld_y + c) = pk;
+                    if (y3 && c >= c_lo) *reinterpret_cast<uint4*>(y3 + (size_t)mm * ld_y3 + (c - c_lo)) = pk;
                     if (y2) {                     // sum of the STORED (rounded) y and the other operand, as a separate add of the two tensors gives
                         float a[V];
                         TT<T>::unpack(pk, v);
@@ -455,8 +458,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void affine_rows_k(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y, int M, int C,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      const T* __restrict__ res, int ld_res, int relu, int rows_per_blk, int CVP,
-                                                     const T* __restrict__ add = nullptr, int ld_add = 0, T* __restrict__ y2 = nullptr, int ld_y2 = 0) {
-    affine_rows_body<T>(x, ld_x, y, ld_y, M, C, scale, shift, res, ld_res, relu, rows_per_blk, CVP, add, ld_add, y2, ld_y2, blockIdx.x);
+                                                     const T* __restrict__ add = nullptr, int ld_add = 0, T* __restrict__ y2 = nullptr, int ld_y2 = 0,
+                                                     T* __restrict__ y3 = nullptr, int ld_y3 = 0, int c_lo = 0) {
+    affine_rows_body<T>(x, ld_x, y, ld_y, M, C, scale, shift, res, ld_res, relu, rows_per_blk, CVP, add, ld_add, y2, ld_y2, blockIdx.x, y3, ld_y3, c_lo);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void affine_rows_tab(const pn2_affine_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
@@ -740,6 +744,22 @@ int pn2_affine_act_sum(int dt, const void* x, int ld_x, void* y, int ld_y, int M
     return 0;
 }
 
+int pn2_affine_act_tee(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* scale, const float* shift, int relu,
+                       void* y3, int ld_y3, int c_lo, void* stream) {
+    if (!x || !y || !y3) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (C % V || ld_x % V || ld_y % V || ld_y3 % V || c_lo % V || c_lo < 0 || c_lo >= C) return -2;
+    int cvp, rpb, nblk;
+    rows_geometry(M, C / V, cvp, rpb, nblk);
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((affine_rows_k<bf16_t>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, ld_x, (bf16_t*)y, ld_y, M, C, scale, shift, (const bf16_t*)nullptr, 0, relu, rpb, cvp,
+                                           (const bf16_t*)nullptr, 0, (bf16_t*)nullptr, 0, (bf16_t*)y3, ld_y3, c_lo);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((affine_rows_k<float>), dim3(nblk), dim3(256), 0, st, (const float*)x, ld_x, (float*)y, ld_y, M, C, scale, shift, (const float*)nullptr, 0, relu, rpb, cvp,
+                                               (const float*)nullptr, 0, (float*)nullptr, 0, (float*)y3, ld_y3, c_lo);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
 
 /* ------------------------------------------------------------------------------------------------ table-driven launches
  * pn2_*_job_blocks fill the derived geometry of a job (host side) and return its workgroup count (< 0: this call cannot be batched - launch it on

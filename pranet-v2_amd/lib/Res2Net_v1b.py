@@ -21,6 +21,11 @@ __all__ = ['Res2Net', 'res2net50_v1b', 'res2net101_v1b', 'res2net50_v1b_26w_4s']
 ALIAS_CAT_GRAD = os.environ.get("PN2_ALIAS_CAT_GRAD", "1") == "1"
 
 
+def TEE_CONCAT():
+    from pn2 import core
+    return core.TEE_CONCAT
+
+
 class Bottle2neck(nn.Module):
     expansion = 4
 
@@ -51,11 +56,14 @@ class Bottle2neck(nn.Module):
         stride = self.convs[0].stride[0]
         # x_last: conv1 is the first consumer of the block input, so its data gradient is the last contribution to that gradient - the dgrad
         # GEMM takes the BatchNorm-backward statistics of the previous block's bn3 in its epilogue (engine.conv_bn_act)
-        out1 = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True, out_map=(w, wp), x_last=True)
+        OH = (x.H + 2 - 3) // stride + 1              # (conv1 is 1x1, stride 1: out1 has x's extent)
+        OW = (x.W + 2 - 3) // stride + 1
+        cat = eng.new_act(x.N, OH, OW, w * sc, w, wp)
+        last = cat.slice(self.nums * wp, sc * wp, w, w, wp)
+        # a normal block passes spx[3] through unchanged (Res2Net_v1b.py:78-79): in a training pass the launch that writes out1 writes that slice into the concat buffer as well
+        tee = (last, self.nums * wp) if (not stage and eng.training and TEE_CONCAT()) else None
+        out1 = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True, out_map=(w, wp), x_last=True, tee=tee)
         spx = [out1.slice(i * wp, (i + 1) * wp, w, w, wp) for i in range(sc)]
-        OH = (out1.H + 2 - 3) // stride + 1
-        OW = (out1.W + 2 - 3) // stride + 1
-        cat = eng.new_act(out1.N, OH, OW, w * sc, w, wp)
         # the branch convs leave their raw outputs and BatchNorm rows in channel slices of two shared buffers, so that conv3's dgrad can take
         # the backward statistics of bns[0..2] (and of bn1's last slice, which the concat buffer copies) in one epilogue
         rawcat = eng.empty(out1.N, OH, OW, sc * wp)
@@ -63,7 +71,6 @@ class Bottle2neck(nn.Module):
         def branch(i, s_in, nxt):
             return eng.conv_bn_act(s_in, self.convs[i], self.bns[i], relu=True, out=cat.slice(i * wp, (i + 1) * wp, w, w, wp), out_map=(w, wp), sum_with=nxt,
                                    raw_out=rawcat[..., i * wp:(i + 1) * wp], par_out=pcat[:, i * wp:(i + 1) * wp], x_last=True)
-        last = cat.slice(self.nums * wp, sc * wp, w, w, wp)
         if stage:
             # the branches of a stage block are independent (sp = spx[i], Res2Net_v1b.py:66-69): they advance in lock step, one table-driven
             # launch per kernel kind (conv, finalize, BN-apply; and their backward) for all three, next to the pooled pass-through slice
@@ -78,7 +85,7 @@ class Bottle2neck(nn.Module):
                 r = branch(i, s_in, nxt)
                 if nxt is not None:
                     s_in = r[1]
-            eng.copy_into(spx[self.nums], last)
+            eng.copy_into(spx[self.nums], last, forward=tee is None)
             eng.concat_bnb(cat, rawcat, pcat, split=self.nums * wp, tail=spx[self.nums])
             if ALIAS_CAT_GRAD and cat.t.shape == out1.t.shape:
                 # d(cat) and d(out1) share ONE buffer: slice i of d(cat) (the gradient of sp_i) is dead once bns[i]'s backward has formed dz_i, which is

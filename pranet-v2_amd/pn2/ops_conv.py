@@ -187,7 +187,7 @@ class ConvOps:
 
     # ------------------------------------------------------------------ conv (+BN +ReLU +residual)
     def conv_bn_act(self, x, conv, bn=None, relu=False, residual=None, out=None, out_map=None, y_dt=None, y_C=None, bias=None, sum_with=None,
-                    raw_out=None, par_out=None, x_last=False, gate=None):
+                    raw_out=None, par_out=None, x_last=False, gate=None, tee=None):
         """y = act(BN(conv(x)) + residual)   — BasicConv2d / Bottle2neck pieces.
 
         conv: nn.Conv2d (bias-free unless `bias` given), bn: nn.BatchNorm2d or None.
@@ -205,6 +205,7 @@ class ConvOps:
                   order).  If x is the output of a train-mode BatchNorm, the dgrad GEMM then takes that BatchNorm's backward statistics in its
                   epilogue (pn2_conv_gemm_ep) and x's producer skips its pn2_bn_bwd_reduce pass.
         """
+        assert tee is None or (self.training and bn is not None and bias is None and gate is None and sum_with is None), "tee: train-mode conv + BatchNorm outputs only"
         w = conv.weight
         Cout, Cin, KH, KW = _w4(w)
         sh, sw = conv.stride
@@ -346,8 +347,16 @@ class ConvOps:
                 y2.galias = sum_with            # d(y + s)/ds = 1 and s has no other consumer: the sum's gradient lives in s's gradient storage
                 y2.sum_of = (out, sum_with)
         elif not fuse_bias:
-            call.pn2_affine_act(self.dt, _p(raw), raw_ld, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
-                                residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
+            # tee = (Act, c_lo): the output channels >= c_lo also go to that activation (Bottle2neck: spx[3] lands in the concat buffer, no copy launch)
+            if tee is not None and residual is None and y_dt == self.dt and ncopy == Cout_p and core.TEE_CONCAT and tee[0].dt == self.dt and not (tee[1] % V or tee[0].ld % V or out.ld % V or raw_ld % V or Cout_p % V):
+                call.pn2_affine_act_tee(self.dt, _p(raw), raw_ld, out.ptr, out.ld, M, Cout_p, _p(scale), _p(shift), (2 if relu == 2 else 1) if relu else 0,
+                                        tee[0].ptr, tee[0].ld, tee[1], st)
+                tee = None
+            else:
+                call.pn2_affine_act(self.dt, _p(raw), raw_ld, y_dt, out.ptr, out.ld, M, ncopy, _p(scale), _p(shift),
+                                    residual.ptr if residual is not None else C.c_void_p(0), residual.ld if residual is not None else 0, (2 if relu == 2 else 1) if relu else 0, st)
+        if tee is not None:          # (a path without the second output: the slice is copied)
+            call.pn2_copy(out.dt, _p(out.t[..., tee[1]:tee[1] + tee[0].Cp]), out.ld, tee[0].dt, tee[0].ptr, tee[0].ld, M, tee[0].Cp, 0, st)
 
         if not self.need_grad:
             return out if y2 is None else (out, y2)

@@ -134,8 +134,11 @@ class SpatialOps:
     def mul(self, a, b, out=None):
         return self.binary(1, a, b, out)
 
-    def copy_into(self, src, dst):
-        call.pn2_copy(src.dt, src.ptr, src.ld, dst.dt, dst.ptr, dst.ld, src.M, src.Cp, 0, _stream())
+    def copy_into(self, src, dst, forward=True):
+        """dst = src (a channel slice of a concat buffer); forward=False: the producer of src has already written dst as well (conv_bn_act(tee=)), only the
+        backward of the copy is recorded."""
+        if forward:
+            call.pn2_copy(src.dt, src.ptr, src.ld, dst.dt, dst.ptr, dst.ld, src.M, src.Cp, 0, _stream())
 
         def bwd():
             if not src.requires_grad:

@@ -340,6 +340,13 @@ class Trainer:
         import torch.distributed as dist
         if not DP_CAPTURE or self._expected is None or dist.get_backend(self.pg) != "nccl":
             return False
+        # c10d's watchdog thread polls the events of the EAGER collectives of the warm-up steps (every 100 ms) until it has seen them complete.  Once the capture
+        # pulls RCCL's stream in, HIP refuses hipEventQuery on events of that stream ("operation not permitted on an event last recorded in a capturing
+        # stream") and the watchdog takes the process down - a race that fires when the capture starts within a poll interval of the last eager collective.
+        # All eager work is complete here; give the watchdog a few poll intervals to retire it before RCCL's stream starts capturing.
+        import time
+        torch.cuda.synchronize()
+        time.sleep(0.5)
         g = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):

@@ -221,7 +221,14 @@ def test_rccl_one_rank_dp_path_is_bit_identical_to_local(wire, captured):
     port = 31600 + (os.getpid() + (3 if wire == "bf16" else 0) + (7 if captured else 0)) % 2000
     p = ctx.Process(target=_rccl_worker, args=(port, q, wire, captured))
     p.start()
-    res = q.get(timeout=900)
+    import queue as _queue, time as _time
+    res, t_end = None, _time.monotonic() + 900
+    while res is None:                       # a worker that dies (e.g. c10d's watchdog terminating the process) must fail the test at once, not after the time-out
+        try:
+            res = q.get(timeout=2)
+        except _queue.Empty:
+            assert p.is_alive() or not q.empty(), f"the RCCL worker exited with code {p.exitcode} without a result"
+            assert _time.monotonic() < t_end, "the RCCL worker timed out"
     p.join(60)
     assert res[0] == "OK", res[1]
     _, same, same3, info, nseg, nb, backend = res
