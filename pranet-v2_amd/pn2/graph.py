@@ -280,12 +280,12 @@ def _site(build, inputs, params, training, dtype, pc):
     st = sites.get(key)
     if st is not None and st.pc is not pc:            # the pack cache was rebuilt (a weight was re-allocated): the graphs hold the old pointers
         st = None
+    sites.pop(key, None)
     if st is None:
-        sites.pop(key, None)
         while len(sites) >= MAX_SITES:
-            sites.pop(next(iter(sites)))
+            sites.pop(next(iter(sites)))          # the least recently used input shape
         st = _Site(params, pc)
-    sites[key] = st
+    sites[key] = st                               # (re-inserted: most recently used last)
     return st
 
 
