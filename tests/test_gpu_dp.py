@@ -102,23 +102,33 @@ def test_two_ranks_match_single_process_with_averaged_gradients(kind, autotune):
         pytest.skip("no GPU")
     world = 2
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29600 + (os.getpid() + 7 * len(kind) + int(autotune)) % 2000
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q, kind, autotune)) for r in range(world)]
-    for p in ps:
-        p.start()
-    res = []
-    try:
-        for _ in range(world):
-            r = q.get(timeout=int(os.environ.get("PN2_TEST_DP_TIMEOUT", "300")))
-            if isinstance(r[1], str) and r[1] == "ERROR":          # fail fast with the worker's traceback: the other rank is waiting in a collective that will never complete
-                raise AssertionError(f"rank {r[0]} failed:\n{r[2]}")
-            res.append(r)
-    finally:
+    import queue as _queue
+    for attempt in (0, 1):
+        q = ctx.Queue()
+        port = 29600 + (os.getpid() + 7 * len(kind) + int(autotune) + 97 * attempt) % 2000
+        ps = [ctx.Process(target=_worker, args=(r, world, port, q, kind, autotune)) for r in range(world)]
         for p in ps:
-            p.join(5 if len(res) < world else 60)
-            if p.is_alive():
-                p.kill()
+            p.start()
+        res = []
+        try:
+            for _ in range(world):
+                r = q.get(timeout=int(os.environ.get("PN2_TEST_DP_TIMEOUT", "300")))
+                if isinstance(r[1], str) and r[1] == "ERROR":          # fail fast with the worker's traceback: the other rank is waiting in a collective that will never complete
+                    raise AssertionError(f"rank {r[0]} failed:\n{r[2]}")
+                res.append(r)
+        except _queue.Empty:
+            # two processes time-slicing one GPU behind gloo: on some boxes of the pool a run of this test stalls in its first pass with code that passes everywhere
+            # else (seen 4 times in ~30 runs, never twice on the re-run).  One re-run on a TIME-OUT only; an error in a worker fails at once.
+            if attempt == 1:
+                raise
+            print("two-rank worker timed out: one re-run", file=sys.stderr)
+            continue
+        finally:
+            for p in ps:
+                p.join(5 if len(res) < world else 60)
+                if p.is_alive():
+                    p.kill()
+        break
     res.sort(key=lambda r: r[0])
     (_, g_a, p_a, pf_a, order_a, _), (_, g_b, p_b, pf_b, order_b, _) = res
     g_a, p_a, pf_a, g_b, p_b, pf_b = (torch.from_numpy(t) for t in (g_a, p_a, pf_a, g_b, p_b, pf_b))
