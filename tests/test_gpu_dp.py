@@ -117,8 +117,8 @@ def test_two_ranks_match_single_process_with_averaged_gradients(kind, autotune):
                     raise AssertionError(f"rank {r[0]} failed:\n{r[2]}")
                 res.append(r)
         except _queue.Empty:
-            # two processes time-slicing one GPU behind gloo: on some boxes of the pool a run of this test stalls in its first pass with code that passes everywhere
-            # else (seen 4 times in ~30 runs, never twice on the re-run).  One re-run on a TIME-OUT only; an error in a worker fails at once.
+            # two processes time-slicing one GPU behind gloo: on two boxes of the pool this test stalled in its first pass (4 runs in a row there) with code that
+            # passed before and after on every other box (~15 runs).  One re-run on a TIME-OUT only; an error in a worker fails at once.
             if attempt == 1:
                 raise
             print("two-rank worker timed out: one re-run", file=sys.stderr)
