@@ -196,6 +196,11 @@ int pn2_affine_act_sum(int dt, const void* x, int ld_x, void* y, int ld_y, int M
  * slice spx[3] straight into the concat buffer (Res2Net_v1b.py:78-79: `out = torch.cat((out, spx[self.nums]), 1)`), no copy launch.  16-byte aligned rows / c_lo only. */
 int pn2_affine_act_tee(int dt, const void* x, int ld_x, void* y, int ld_y, int M, int C, const float* scale, const float* shift, int relu,
                        void* y3, int ld_y3, int c_lo, void* stream);
+/* BatchNorm + ReLU + MaxPool2d(3, 2, 1) forward as ONE pass (the stem of Res2Net_v1b.py:137-139: self.bn1 -> self.relu -> self.maxpool): the normalised full-resolution activation feeds
+ * the pool alone, so it is never written.  pooled[n][oy][ox][c] = max over the window of T(relu(raw*scale + shift)), idx = argmax tap (0..8), exactly as pn2_affine_act followed by
+ * pn2_maxpool3x3s2_fwd give them.  The backward is pn2_maxpool3x3s2_bwd + the BatchNorm passes with the ReLU mask recomputed from raw. */
+int pn2_bn_relu_maxpool_fwd(int dt, const void* raw, int ld_raw, const float* scale, const float* shift, void* y, int ld_y, unsigned char* idx,
+                            int N, int H, int W, int C, int OH, int OW, void* stream);
 /* backward pass 1: per-channel partials of sum(dz) and sum(dz*xhat), dz = dy*(relu mask) ; dy has Cdy valid channels.
  * ReLU mask: y>0 when y is given; else recomputed as fmaf(x,mask_scale,mask_shift)>0 when mask_scale is given (saves reading y). */
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,

@@ -209,6 +209,52 @@ __device__ __forceinline__ void ldpar(const float* __restrict__ p, float (&v)[V]
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// BatchNorm + ReLU + MaxPool(3, 2, 1) forward as ONE pass (the stem of Res2Net_v1b.py:137-139: bn1 -> relu -> maxpool): the normalised 176 x 176 x 64 activation is
+// consumed by the pool alone, so it is never written - the pass pools T(relu(raw*scale + shift)) on the fly: values and argmax bytes exactly as the normalise pass
+// followed by maxpool3x3s2_fwd give them.  (The backward keeps its three passes: gathering the pooled gradient inside the two BatchNorm passes was 4x slower)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int W>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(const T* __restrict__ x, int ld_x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             T* __restrict__ y, int ld_y, unsigned char* __restrict__ arg, int N, int H, int Wd, int C, int OH, int OW) {
+    const int CV = C / W;
+    const size_t total = (size_t)N * OH * OW * CV;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int cv = (int)(idx % CV); unsigned p = (unsigned)(idx / CV);
+        const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const int n = (int)(p / OH);
+        float sc[W], sh[W], best[W]; int bi[W];
+        ldpar<W>(scale + cv * W, sc); ldpar<W>(shift + cv * W, sh);
+#pragma unroll
+        for (int e = 0; e < W; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy * 2 - 1 + r; if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const int ix = ox * 2 - 1 + s_; if ((unsigned)ix >= (unsigned)Wd) continue;
+                float v[W];
+                VL<T, W>::load(x + ((size_t)(n * H + iy) * Wd + ix) * ld_x + cv * W, v);
+#pragma unroll
+                for (int e = 0; e < W; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+                if constexpr (sizeof(T) == 2 && W == 8) { const uint4 pk = TT<T>::pack(v); TT<T>::unpack(pk, v); }      // the value the normalise pass would have stored
+#pragma unroll
+                for (int e = 0; e < W; ++e) if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = r * 3 + s_; }
+            }
+        }
+        const size_t o = (size_t)(n * OH + oy) * OW + ox;
+        VL<T, W>::store(y + o * ld_y + cv * W, best);
+        if constexpr (W == 8) {
+            uint2 a;
+            a.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+            a.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+            *reinterpret_cast<uint2*>(arg + o * C + cv * W) = a;
+        } else {
+#pragma unroll
+            for (int e = 0; e < W; ++e) arg[o * C + cv * W + e] = (unsigned char)bi[e];
+        }
+    }
+}
+
 template <typename T, typename Tdy, int W, bool LEAN = false>       // LEAN: no stored-activation mask (y) - its staging registers disappear
 __device__ __forceinline__ void bn_bwd_reduce_body(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y_, int ld_y,
                                                    const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
@@ -724,6 +770,22 @@ int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, cons
     return -3;
 }
 
+
+/* BatchNorm + ReLU + MaxPool(3, 2, 1) forward as one pass (stem of Res2Net_v1b.py:137-139).  Vector rows only (C, ld multiples of the 16-byte vector). */
+int pn2_bn_relu_maxpool_fwd(int dt, const void* raw, int ld_raw, const float* scale, const float* shift, void* y, int ld_y, unsigned char* idx,
+                            int N, int H, int W, int C, int OH, int OW, void* stream) {
+    if (!raw || !scale || !shift || !y || !idx) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if (C % V || ld_raw % V || ld_y % V || OH != (H - 1) / 2 + 1 || OW != (W - 1) / 2 + 1) return -2;
+    if ((size_t)N * OH * OW * (C / V) >= ((size_t)1 << 32) - ((size_t)8192 << 8)) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for((size_t)N * OH * OW * (C / V));
+    if (dt == PN2_BF16) hipLaunchKernelGGL((bn_relu_maxpool_fwd_k<bf16_t, 8>), dim3(grid), dim3(256), 0, st, (const bf16_t*)raw, ld_raw, scale, shift, (bf16_t*)y, ld_y, idx, N, H, W, C, OH, OW);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((bn_relu_maxpool_fwd_k<float, 4>), dim3(grid), dim3(256), 0, st, (const float*)raw, ld_raw, scale, shift, (float*)y, ld_y, idx, N, H, W, C, OH, OW);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
 
 /* pn2_affine_act (same dtype in / out, no residual) with a second output y2 = y + add: the branch sum of Bottle2neck.forward
  * (Res2Net_v1b.py:66-68, sp = sp + spx[i]) produced by the pass that writes sp.  16-byte aligned rows only (-2 otherwise). */

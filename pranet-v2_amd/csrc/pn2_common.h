@@ -27,6 +27,7 @@ template <> struct TT<float> {
     static constexpr int DT = PN2_F32;
     __device__ static __forceinline__ float ld(const float* p) { return *p; }
     __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float round(float v) { return v; }          // the value as the storage type holds it
     __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
         f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
     }
@@ -39,6 +40,7 @@ template <> struct TT<bf16_t> {
     static constexpr int DT = PN2_BF16;
     __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
     __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
         f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
         f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);

@@ -26,6 +26,11 @@ def TEE_CONCAT():
     return core.TEE_CONCAT
 
 
+def POOL_FUSE():
+    from pn2 import core
+    return core.POOL_FUSE
+
+
 class Bottle2neck(nn.Module):
     expansion = 4
 
@@ -148,8 +153,12 @@ class Res2Net(nn.Module):
         c = self.conv1
         x = eng.conv_bn_act(x, c[0], c[1], relu=True)
         x = eng.conv_bn_act(x, c[3], c[4], relu=True, x_last=True)          # single-consumer chain: see Bottle2neck._build
-        x = eng.conv_bn_act(x, c[6], self.bn1, relu=True, x_last=True)
-        x = eng.maxpool3x3s2(x)
+        if eng.training and POOL_FUSE() and rup(c[6].out_channels, 8) == c[6].out_channels:
+            # bn1 -> relu -> maxpool (Res2Net_v1b.py:137-139) as one op: the 176 x 176 x 64 BatchNorm output is consumed by the pool alone and never written
+            x = eng.conv_bn_act(x, c[6], self.bn1, relu=True, x_last=True, pool=True)
+        else:
+            x = eng.conv_bn_act(x, c[6], self.bn1, relu=True, x_last=True)
+            x = eng.maxpool3x3s2(x)
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:

@@ -157,6 +157,7 @@ SIGNATURES = {
     "pn2_bn_eval_prepare_multi": [P, P, I, I, P],
     "pn2_affine_act_sum": [I, P, I, P, I, I, I, P, P, I, P, I, P, I, P],
     "pn2_affine_act_tee": [I, P, I, P, I, I, I, P, P, I, P, I, I, P],
+    "pn2_bn_relu_maxpool_fwd": [I, P, I, P, P, P, I, P, I, I, I, I, I, I, P],
     "pn2_affine_act": [I, P, I, I, P, I, I, I, P, P, P, I, I, P],
     "pn2_bn_bwd_reduce": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, P, I, P],
     "pn2_bn_bwd_blocks": [I, I, I],

@@ -187,7 +187,7 @@ class ConvOps:
 
     # ------------------------------------------------------------------ conv (+BN +ReLU +residual)
     def conv_bn_act(self, x, conv, bn=None, relu=False, residual=None, out=None, out_map=None, y_dt=None, y_C=None, bias=None, sum_with=None,
-                    raw_out=None, par_out=None, x_last=False, gate=None, tee=None):
+                    raw_out=None, par_out=None, x_last=False, gate=None, tee=None, pool=False):
         """y = act(BN(conv(x)) + residual)   — BasicConv2d / Bottle2neck pieces.
 
         conv: nn.Conv2d (bias-free unless `bias` given), bn: nn.BatchNorm2d or None.
@@ -206,6 +206,10 @@ class ConvOps:
                   epilogue (pn2_conv_gemm_ep) and x's producer skips its pn2_bn_bwd_reduce pass.
         """
         assert tee is None or (self.training and bn is not None and bias is None and gate is None and sum_with is None), "tee: train-mode conv + BatchNorm outputs only"
+        # pool: the op is conv -> BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) and returns the POOLED activation; the full-resolution BatchNorm output is never written
+        # (pn2_bn_relu_maxpool_fwd; backward: pn2_maxpool3x3s2_bwd, then the BatchNorm passes with the mask recomputed from raw).  Train-mode BatchNorm with a plain ReLU only.
+        assert not pool or (self.training and bn is not None and relu is True and bias is None and gate is None and sum_with is None and residual is None and out is None
+                            and tee is None and y_C is None and y_dt in (None, self.dt)), "pool: train-mode conv + BatchNorm + ReLU only"
         w = conv.weight
         Cout, Cin, KH, KW = _w4(w)
         sh, sw = conv.stride
@@ -327,6 +331,12 @@ class ConvOps:
                 shift[:Cout] = bias.detach()
 
         y_dt = self.dt if y_dt is None else y_dt
+        pidx = None
+        if pool:
+            PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+            out = Act(self, self.empty(N, PH, PW, Cout_p), Cout, gw_o, gwp_o, self.dt)
+            pidx = self.alloc((N, PH, PW, Cout_p), torch.uint8)
+            call.pn2_bn_relu_maxpool_fwd(self.dt, _p(raw), raw_ld, _p(scale), _p(shift), out.ptr, out.ld, _p(pidx), N, OH, OW, Cout_p, PH, PW, st)
         if out is None:
             if y_C is not None:
                 out = Act(self, self.empty(N, OH, OW, y_C, y_dt), y_C, y_C, y_C, y_dt)
@@ -346,6 +356,8 @@ class ConvOps:
             if self.need_grad and sum_with.requires_grad:
                 y2.galias = sum_with            # d(y + s)/ds = 1 and s has no other consumer: the sum's gradient lives in s's gradient storage
                 y2.sum_of = (out, sum_with)
+        elif pool:
+            pass                      # (written above, pooled)
         elif not fuse_bias:
             # tee = (Act, c_lo): the output channels >= c_lo also go to that activation (Bottle2neck: spx[3] lands in the concat buffer, no copy launch)
             if tee is not None and residual is None and y_dt == self.dt and ncopy == Cout_p and core.TEE_CONCAT and tee[0].dt == self.dt and not (tee[1] % V or tee[0].ld % V or out.ld % V or raw_ld % V or Cout_p % V):
@@ -361,7 +373,7 @@ class ConvOps:
         if not self.need_grad:
             return out if y2 is None else (out, y2)
         # the BatchNorm-backward statistics of this output's gradient can be taken by the dgrad GEMM that completes it (x_last of the consumer)
-        bnb_ok = core.BNB_EPILOGUE and train_bn and not fuse_bias and y_C is None and y_dt == self.dt and relu in (False, True) and out.ld % V == 0 and Cout_p % V == 0
+        bnb_ok = core.BNB_EPILOGUE and train_bn and not fuse_bias and y_C is None and y_dt == self.dt and relu in (False, True) and out.ld % V == 0 and Cout_p % V == 0 and not pool
         if bnb_ok:
             out.bnb = Bnb(raw, par, bool(relu), out.t if residual is not None else None)
 
@@ -379,12 +391,16 @@ class ConvOps:
                     call.pn2_copy(self.dt, _p(g2), g2.stride(2), self.dt, _p(gs), gs.stride(2), M, Cout_p, sacc, st)
             dy = out.grad_buf()
             assert out.grad_written or out.child_written, "conv output never received a gradient"
+            if pool:          # the gradient of the (never stored) full-resolution BatchNorm output, as MaxPool2d's backward leaves it
+                dyf = self.empty(N, OH, OW, Cout_p)
+                call.pn2_maxpool3x3s2_bwd(self.dt, _p(dy), dy.stride(2), _p(pidx), _p(dyf), Cout_p, N, OH, OW, Cout_p, out.H, out.W, st)
+                dy = dyf
             draw = self.empty(N, OH, OW, Cout_p)
             Cdy = ncopy
             ymask = out if relu else None
             r6 = 1 if relu == 2 else 0          # relu: False / True (ReLU) / 2 (ReLU6: the mask also drops the saturated y == 6)
             msc = msh = None
-            if bnb_ok and relu and residual is None and dy.stride(2) % V == 0:
+            if (bnb_ok or pool) and relu and residual is None and dy.stride(2) % V == 0:
                 # ReLU mask recomputed from the raw conv output (fmaf(x, scale, shift) > 0, bit-identical to the forward):
                 # the backward passes then do not read y at all
                 ymask, msc, msh = None, scale, shift

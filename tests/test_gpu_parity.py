@@ -1083,3 +1083,25 @@ def test_inference_predictor_graph_matches_module_eval():
         pred.postprocess(x, (500, 574))
     torch.cuda.synchronize()
     print(f"\\ninference 1x3x352x352 + tail (hipGraph replay): {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms/image")
+
+
+@pytest.mark.parametrize("fp32", [False, True])
+def test_stem_bn_relu_maxpool_as_one_op_is_bit_identical(fp32, monkeypatch):
+    """conv_bn_act(pool=True): the stem's bn1 -> ReLU -> MaxPool2d(3, 2, 1) (Res2Net_v1b.py:137-139) without the full-resolution BatchNorm output - the pooled
+    activation and the argmax bytes come straight from the raw conv output (pn2_bn_relu_maxpool_fwd) - against the separate normalise and pool passes: every value is
+    formed the same way, so loss, maps and every gradient of a training step agree bit for bit."""
+    from pn2 import core
+    from pn2.trainer import Trainer
+    from oracle import weights as W
+    for size in (96, 224):          # 48 -> 24 and 112 -> 56 stem maps
+        x, mask = W.synthetic_batch(2, size, seed=9)
+        xg, mg = x.to(dev), mask.to(dev)
+        res = []
+        for on in (True, False):
+            monkeypatch.setattr(core, "POOL_FUSE", on)
+            tr = Trainer(_fixture_model(fp32=fp32))
+            loss = tr.forward_backward(xg, mg)
+            torch.cuda.synchronize()
+            res.append((loss.clone(), tr.gflat.clone(), tr.last_outs.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+        assert torch.equal(res[0][1], res[1][1]), float((res[0][1] - res[1][1]).abs().max())
