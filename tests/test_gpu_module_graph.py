@@ -167,3 +167,64 @@ def test_clip_gradient_multi_tensor_form_is_the_per_tensor_clamp():
     clip_gradient(torch.optim.SGD(ps, 0.1), 0.5)
     for p, w in zip(ps, want):
         assert (p.grad is None and w is None) or torch.equal(p.grad, w)
+
+
+@pytest.mark.parametrize("kind", ["pvt", "emcad"])
+def test_pvt_and_emcad_call_sites_replay_from_graphs(kind):
+    """The PVTv2 / EMCAD mirrors go through the same call-site machinery (attention, LayerNorm, depth-wise ops, CAB's shared weights).  Seven calls on constant weights: the
+    plain pass (calls 1, 2), the arena passes (3, 4) and the replays (5, 6, 7) must give the same outputs and - up to the fp32 summation order of the table-driven
+    weight gradients - the same gradients.  (A training trajectory is no yardstick here: on these random-init nets with train-mode BatchNorm over 2 x 2 maps a 1e-8 gradient
+    difference grows to 1e-3 in the loss within two SGD steps.)"""
+    import pn2, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from pn2 import graph as G
+    pn2.set_compute_dtype("fp32")
+    G.set_module_graph(True)
+    g = torch.Generator().manual_seed(11)
+    if kind == "pvt":
+        from test_gpu_pvt import _pvt_model as mk
+        x = torch.randn(2, 3, 96, 96, generator=g).to(dev)
+        fwd = lambda m, t: m(t)
+    else:
+        from test_gpu_emcad import _model as mk
+        x = torch.randn(2, 1, 64, 64, generator=g).to(dev)
+        fwd = lambda m, t: m(t, mode="train")
+    model = mk(True)
+    gs, res = None, []
+    for _ in range(7):
+        model.zero_grad()
+        outs = fwd(model, x)
+        outs = list(outs) if isinstance(outs, (tuple, list)) else [outs]
+        if gs is None:
+            gs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(50 + k)).to(dev) for k, o in enumerate(outs)]
+        torch.autograd.backward(outs, gs)
+        res.append(([o.detach().clone() for o in outs], torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]).clone()))
+    sites = [st for p in model.parameters() if "_pn2_sites" in p.__dict__ for st in p.__dict__["_pn2_sites"].values()]
+    assert sites and any(st.graph_f is not None and st.gen >= 3 for st in sites), "no call site reached graph replay"
+    for i in range(1, 7):
+        for a, b in zip(res[0][0], res[i][0]):
+            assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), i
+        assert float((res[0][1] - res[i][1]).norm() / res[0][1].norm()) <= 1e-6, i
+
+
+def test_droppath_draws_fresh_masks_under_graph_replay():
+    """DropPath (pvtv2.py:125) keeps drawing new per-sample masks when the call site is replayed: torch's graph-safe generator advances with every replay."""
+    import pn2, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_pvt import _pvt_model
+    from pn2 import graph as G
+    pn2.set_compute_dtype("fp32")
+    G.set_module_graph(True)
+    model = _pvt_model(True)
+    model.backbone.reset_drop_path(0.5)
+    x = torch.randn(4, 3, 96, 96, generator=torch.Generator().manual_seed(3)).to(dev)
+    outs = []
+    for _ in range(8):
+        model.zero_grad()
+        o = model(x)
+        sum(t.sum() for t in o).backward()
+        outs.append(o[0].detach().clone())
+    st = [st for p in model.parameters() if "_pn2_sites" in p.__dict__ for st in p.__dict__["_pn2_sites"].values()]
+    assert st and st[0].graph_f is not None
+    # calls 6, 7, 8 are replays of one graph on the same input and (nearly) the same weights: different DropPath masks -> different outputs
+    assert not torch.equal(outs[5], outs[6]) and not torch.equal(outs[6], outs[7])
