@@ -343,10 +343,10 @@ class Trainer:
         # c10d's watchdog thread polls the events of the EAGER collectives of the warm-up steps (every 100 ms) until it has seen them complete.  Once the capture
         # pulls RCCL's stream in, HIP refuses hipEventQuery on events of that stream ("operation not permitted on an event last recorded in a capturing
         # stream") and the watchdog takes the process down - a race that fires when the capture starts within a poll interval of the last eager collective.
-        # All eager work is complete here; give the watchdog a few poll intervals to retire it before RCCL's stream starts capturing.
+        # All eager work is complete here; give the watchdog ten poll intervals to retire it before RCCL's stream starts capturing.
         import time
         torch.cuda.synchronize()
-        time.sleep(0.5)
+        time.sleep(1.0)
         g = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
