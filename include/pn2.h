@@ -201,6 +201,13 @@ int pn2_affine_act_tee(int dt, const void* x, int ld_x, void* y, int ld_y, int M
  * pn2_maxpool3x3s2_fwd give them.  The backward is pn2_maxpool3x3s2_bwd + the BatchNorm passes with the ReLU mask recomputed from raw. */
 int pn2_bn_relu_maxpool_fwd(int dt, const void* raw, int ld_raw, const float* scale, const float* shift, void* y, int ld_y, unsigned char* idx,
                             int N, int H, int W, int C, int OH, int OW, void* stream);
+/* The backward of that op without the full-resolution gradient tensor (even H, W; C / vector a power of two <= 256): the two BatchNorm passes with the incoming gradient formed per
+ * 2 x 2 input quad from the pooled gradient dpool [N][OH][OW][C] and idx - each pixel's value is the sum pn2_maxpool3x3s2_bwd forms, in its tap order, rounded to T.  p1 / p2: nblk
+ * partial rows for pn2_bn_bwd_finalize (any nblk >= 1: the launch has nblk workgroups); dz as pn2_bn_bwd_apply writes it.  mask_scale / mask_shift: the forward's scale / shift. */
+int pn2_pool_bn_bwd_reduce(int dt, const void* dpool, int ld_dp, const unsigned char* idx, const void* raw, int ld_raw, int N, int H, int W, int C, int OH, int OW,
+                           const float* mean, const float* invstd, const float* mask_scale, const float* mask_shift, float* p1, float* p2, int nblk, void* stream);
+int pn2_pool_bn_bwd_apply(int dt, const void* dpool, int ld_dp, const unsigned char* idx, const void* raw, int ld_raw, int N, int H, int W, int C, int OH, int OW,
+                          const float* mean, const float* invstd, const float* coef, const float* mask_scale, const float* mask_shift, void* dz, int ld_dz, void* stream);
 /* backward pass 1: per-channel partials of sum(dz) and sum(dz*xhat), dz = dy*(relu mask) ; dy has Cdy valid channels.
  * ReLU mask: y>0 when y is given; else recomputed as fmaf(x,mask_scale,mask_shift)>0 when mask_scale is given (saves reading y). */
 int pn2_bn_bwd_reduce(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, const void* y, int ld_y, int dt_y, const void* x, int ld_x,

@@ -255,6 +255,131 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(const T* __restrict
     }
 }
 
+// quotient / remainder of a < 2^24 by d (quotient < 2^20): float reciprocal + one correction step instead of a ~35-instruction integer division
+__device__ __forceinline__ unsigned fdivmod(unsigned a, unsigned d, float rcp_d, unsigned& rem) {
+    unsigned q = (unsigned)((float)a * rcp_d);
+    int r = (int)a - (int)(q * d);
+    if (r < 0) { --q; r += (int)d; } else if (r >= (int)d) { ++q; r -= (int)d; }
+    rem = (unsigned)r;
+    return q;
+}
+
+// Backward of that op in QUAD form (even H, W).  MaxPool(3, 2, 1): input pixel (iy, ix) belongs to the windows oy = (iy + 1 - r) / 2, r in {0, 1, 2} where integral - so
+// the 2 x 2 input quad rows {2k, 2k+1} x cols {2j, 2j+1} is served by exactly the four windows (k, k+1) x (j, j+1).  A thread takes one quad and one channel vector:
+// 4 pooled-gradient vectors + 4 argmax vectors + 4 raw vectors give it the gradient of all four pixels (each the sum maxpool3x3s2_bwd forms, in its tap order, rounded to T),
+// without the materialised 176 x 176 gradient tensor: no pool-backward launch, and the two BatchNorm passes read 3/8 of the bytes.  (The same gather per ROW inside the generic
+// BatchNorm passes was 4x slower: up to four dependent look-ups per row and a pixel decode each; here the decode is per quad and every load is issued up front.)
+template <typename T, int W> struct QuadGrad {
+    float dy[4][W], xr[4][W];            // pixel order: (2k,2j) (2k,2j+1) (2k+1,2j) (2k+1,2j+1)
+    __device__ __forceinline__ void load(const T* __restrict__ dp, int ld_dp, const unsigned char* __restrict__ arg, const T* __restrict__ x, int ld_x,
+                                         int n, int k, int j, int H, int Wd, int OH, int OW, int C, int c) {
+        float g[4][W]; unsigned char a[4][W];          // windows (k,j) (k,j+1) (k+1,j) (k+1,j+1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = k + (q >> 1), ox = j + (q & 1);
+            const bool ok = oy < OH && ox < OW;
+            const size_t o = ((size_t)n * OH + (ok ? oy : k)) * OW + (ok ? ox : j);
+            VL<T, W>::load(dp + o * ld_dp + c, g[q]);
+            if constexpr (W == 8) { const uint2 t = *reinterpret_cast<const uint2*>(arg + o * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[q][e] = (unsigned char)(t.x >> (8 * e)); a[q][4 + e] = (unsigned char)(t.y >> (8 * e)); } }
+            else { const unsigned t = *reinterpret_cast<const unsigned*>(arg + o * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[q][e] = (unsigned char)(t >> (8 * e)); }
+            if (!ok) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) a[q][e] = 255;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) VL<T, W>::load(x + ((size_t)(n * H + 2 * k + (p >> 1)) * Wd + 2 * j + (p & 1)) * ld_x + c, xr[p]);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            // taps in maxpool3x3s2_bwd's order (r ascending, then s ascending); tap = r*3 + s of the window that holds the pixel at (r, s)
+            dy[0][e] = a[0][e] == 4 ? g[0][e] : 0.f;                                                                  // (2k, 2j): window (k, j), r = 1, s = 1
+            dy[1][e] = (a[1][e] == 3 ? g[1][e] : 0.f) + (a[0][e] == 5 ? g[0][e] : 0.f);                               // (2k, 2j+1): s = 0 -> (k, j+1); s = 2 -> (k, j)
+            dy[2][e] = (a[2][e] == 1 ? g[2][e] : 0.f) + (a[0][e] == 7 ? g[0][e] : 0.f);                               // (2k+1, 2j): r = 0 -> (k+1, j); r = 2 -> (k, j)
+            dy[3][e] = (((a[3][e] == 0 ? g[3][e] : 0.f) + (a[2][e] == 2 ? g[2][e] : 0.f)) + (a[1][e] == 6 ? g[1][e] : 0.f)) + (a[0][e] == 8 ? g[0][e] : 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int e = 0; e < W; ++e) dy[p][e] = TT<T>::round(dy[p][e]);          // what maxpool3x3s2_bwd stores
+    }
+};
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) void pool_bn_bwd_reduce_k(const T* __restrict__ dp, int ld_dp, const unsigned char* __restrict__ arg, const T* __restrict__ x, int ld_x,
+                                                            int N, int H, int Wd, int OH, int OW, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ msc, const float* __restrict__ msh, float* __restrict__ p1, float* __restrict__ p2) {
+    // block = CV channel vectors x (256 / CV) quad lanes; quads dealt round-robin to (block, lane): fixed order -> deterministic partial rows [gridDim.x][C]
+    __shared__ float sh[2][256][W];
+    const int CV = C / W, QL = 256 / CV, cv = threadIdx.x % CV, ql = threadIdx.x / CV, c = cv * W;
+    const int QH = H >> 1, QW = Wd >> 1;
+    const unsigned nq = (unsigned)N * QH * QW;
+    const float rqw = __builtin_amdgcn_rcpf((float)QW), rqh = __builtin_amdgcn_rcpf((float)QH);
+    float mu[W], is[W], ks[W], kh[W], a1[W], a2[W];
+    ldpar<W>(mean + c, mu); ldpar<W>(invstd + c, is); ldpar<W>(msc + c, ks); ldpar<W>(msh + c, kh);
+#pragma unroll
+    for (int e = 0; e < W; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (ql < QL) {
+        for (unsigned q = blockIdx.x * QL + ql; q < nq; q += gridDim.x * QL) {
+            unsigned j, k; const unsigned t = fdivmod(q, (unsigned)QW, rqw, j), n = fdivmod(t, (unsigned)QH, rqh, k);
+            QuadGrad<T, W> G;
+            G.load(dp, ld_dp, arg, x, ld_x, (int)n, (int)k, (int)j, H, Wd, OH, OW, C, c);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    const float dz = (fmaf(G.xr[p][e], ks[e], kh[e]) > 0.f) ? G.dy[p][e] : 0.f;
+                    a1[e] += dz; a2[e] += dz * (G.xr[p][e] - mu[e]) * is[e];
+                }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < W; ++e) { sh[0][threadIdx.x][e] = a1[e]; sh[1][threadIdx.x][e] = a2[e]; }
+    __syncthreads();
+    if (ql == 0) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int r = 0; r < QL; ++r) { s1 += sh[0][r * CV + cv][e]; s2 += sh[1][r * CV + cv][e]; }
+            p1[(size_t)blockIdx.x * C + c + e] = s1; p2[(size_t)blockIdx.x * C + c + e] = s2;
+        }
+    }
+}
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply_k(const T* __restrict__ dp, int ld_dp, const unsigned char* __restrict__ arg, const T* __restrict__ x, int ld_x,
+                                                           int N, int H, int Wd, int OH, int OW, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, const float* __restrict__ msc, const float* __restrict__ msh, T* __restrict__ dz_, int ld_dz) {
+    const int CV = C / W, QL = 256 / CV, cv = threadIdx.x % CV, ql = threadIdx.x / CV, c = cv * W;
+    const int QH = H >> 1, QW = Wd >> 1;
+    const unsigned nq = (unsigned)N * QH * QW;
+    const float rqw = __builtin_amdgcn_rcpf((float)QW), rqh = __builtin_amdgcn_rcpf((float)QH);
+    if (ql >= QL) return;
+    float ka[W], kb[W], kd[W], kmu[W], ks[W], kh[W], c1[W], c2[W], is[W];
+    ldpar<W>(msc + c, ks); ldpar<W>(msh + c, kh);
+    ldpar<W>(coef + c, ka); ldpar<W>(coef + C + c, c1); ldpar<W>(coef + 2 * C + c, c2); ldpar<W>(invstd + c, is); ldpar<W>(mean + c, kmu);
+#pragma unroll
+    for (int e = 0; e < W; ++e) { kb[e] = __fmul_rn(__fmul_rn(-ka[e], c2[e]), is[e]); kd[e] = __fmul_rn(-ka[e], c1[e]); }        // as bn_bwd_apply_rows_body
+    for (unsigned q = blockIdx.x * QL + ql; q < nq; q += gridDim.x * QL) {
+        unsigned j, k; const unsigned t = fdivmod(q, (unsigned)QW, rqw, j), n = fdivmod(t, (unsigned)QH, rqh, k);
+        QuadGrad<T, W> G;
+        G.load(dp, ld_dp, arg, x, ld_x, (int)n, (int)k, (int)j, H, Wd, OH, OW, C, c);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float o[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const float dz = (fmaf(G.xr[p][e], ks[e], kh[e]) > 0.f) ? G.dy[p][e] : 0.f;
+                o[e] = __fmaf_rn(ka[e], dz, __fmaf_rn(kb[e], G.xr[p][e] - kmu[e], kd[e]));
+            }
+            VL<T, W>::store(dz_ + ((size_t)((int)n * H + 2 * (int)k + (p >> 1)) * Wd + 2 * (int)j + (p & 1)) * ld_dz + c, o);
+        }
+    }
+}
+
 template <typename T, typename Tdy, int W, bool LEAN = false>       // LEAN: no stored-activation mask (y) - its staging registers disappear
 __device__ __forceinline__ void bn_bwd_reduce_body(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y_, int ld_y,
                                                    const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
@@ -782,6 +907,38 @@ int pn2_bn_relu_maxpool_fwd(int dt, const void* raw, int ld_raw, const float* sc
     const int grid = grid_for((size_t)N * OH * OW * (C / V));
     if (dt == PN2_BF16) hipLaunchKernelGGL((bn_relu_maxpool_fwd_k<bf16_t, 8>), dim3(grid), dim3(256), 0, st, (const bf16_t*)raw, ld_raw, scale, shift, (bf16_t*)y, ld_y, idx, N, H, W, C, OH, OW);
     else if (dt == PN2_F32) hipLaunchKernelGGL((bn_relu_maxpool_fwd_k<float, 4>), dim3(grid), dim3(256), 0, st, (const float*)raw, ld_raw, scale, shift, (float*)y, ld_y, idx, N, H, W, C, OH, OW);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+/* Backward of pn2_bn_relu_maxpool_fwd without the full-resolution gradient tensor (even H, W; C / V a power of two <= 256): pn2_bn_bwd_reduce / pn2_bn_bwd_apply with the
+ * incoming gradient formed per 2 x 2 input quad from the pooled gradient and the argmax bytes.  p1 / p2: nblk partial rows (any nblk >= 1; pn2_bn_bwd_finalize follows). */
+int pn2_pool_bn_bwd_reduce(int dt, const void* dpool, int ld_dp, const unsigned char* idx, const void* raw, int ld_raw, int N, int H, int W, int C, int OH, int OW,
+                           const float* mean, const float* invstd, const float* mask_scale, const float* mask_shift, float* p1, float* p2, int nblk, void* stream) {
+    if (!dpool || !idx || !raw || !mean || !invstd || !mask_scale || !mask_shift || !p1 || !p2 || nblk < 1) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8, CV = C / V;
+    if (C % V || ld_dp % V || ld_raw % V || (H & 1) || (W & 1) || OH != H / 2 || OW != W / 2 || CV < 1 || CV > 256 || (CV & (CV - 1))) return -2;
+    if ((size_t)N * (H / 2) * (W / 2) >= ((size_t)1 << 24) - 65536 * 32) return -2;          // (quad indices decoded through a float reciprocal)
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((pool_bn_bwd_reduce_k<bf16_t, 8>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)dpool, ld_dp, idx, (const bf16_t*)raw, ld_raw, N, H, W, OH, OW, C, mean, invstd, mask_scale, mask_shift, p1, p2);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((pool_bn_bwd_reduce_k<float, 4>), dim3(nblk), dim3(256), 0, st, (const float*)dpool, ld_dp, idx, (const float*)raw, ld_raw, N, H, W, OH, OW, C, mean, invstd, mask_scale, mask_shift, p1, p2);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+int pn2_pool_bn_bwd_apply(int dt, const void* dpool, int ld_dp, const unsigned char* idx, const void* raw, int ld_raw, int N, int H, int W, int C, int OH, int OW,
+                          const float* mean, const float* invstd, const float* coef, const float* mask_scale, const float* mask_shift, void* dz, int ld_dz, void* stream) {
+    if (!dpool || !idx || !raw || !mean || !invstd || !coef || !mask_scale || !mask_shift || !dz) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8, CV = C / V;
+    if (C % V || ld_dp % V || ld_raw % V || ld_dz % V || (H & 1) || (W & 1) || OH != H / 2 || OW != W / 2 || CV < 1 || CV > 256 || (CV & (CV - 1))) return -2;
+    const size_t nq = (size_t)N * (H / 2) * (W / 2);
+    if (nq >= ((size_t)1 << 24) - 65536 * 32) return -2;
+    const int QL = 256 / CV;
+    int grid = (int)((nq + QL - 1) / QL); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == PN2_BF16) hipLaunchKernelGGL((pool_bn_bwd_apply_k<bf16_t, 8>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dpool, ld_dp, idx, (const bf16_t*)raw, ld_raw, N, H, W, OH, OW, C, mean, invstd, coef, mask_scale, mask_shift, (bf16_t*)dz, ld_dz);
+    else if (dt == PN2_F32) hipLaunchKernelGGL((pool_bn_bwd_apply_k<float, 4>), dim3(grid), dim3(256), 0, st, (const float*)dpool, ld_dp, idx, (const float*)raw, ld_raw, N, H, W, OH, OW, C, mean, invstd, coef, mask_scale, mask_shift, (float*)dz, ld_dz);
     else return -3;
     PN2_CHECK_LAUNCH();
     return 0;

@@ -158,6 +158,8 @@ SIGNATURES = {
     "pn2_affine_act_sum": [I, P, I, P, I, I, I, P, P, I, P, I, P, I, P],
     "pn2_affine_act_tee": [I, P, I, P, I, I, I, P, P, I, P, I, I, P],
     "pn2_bn_relu_maxpool_fwd": [I, P, I, P, P, P, I, P, I, I, I, I, I, I, P],
+    "pn2_pool_bn_bwd_reduce": [I, P, I, P, P, I, I, I, I, I, I, I, P, P, P, P, P, P, I, P],
+    "pn2_pool_bn_bwd_apply": [I, P, I, P, P, I, I, I, I, I, I, I, P, P, P, P, P, P, I, P],
     "pn2_affine_act": [I, P, I, I, P, I, I, I, P, P, P, I, I, P],
     "pn2_bn_bwd_reduce": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, P, I, P],
     "pn2_bn_bwd_blocks": [I, I, I],

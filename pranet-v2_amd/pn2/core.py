@@ -373,6 +373,7 @@ FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN
 BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
 LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
+POOL_BWD_QUAD = os.environ.get("PN2_POOL_BWD_QUAD", "1") == "1"  # ... and its backward without the full-resolution gradient tensor (pn2_pool_bn_bwd_reduce / _apply); 0: pool-backward launch + the generic BatchNorm passes
 POOL_FUSE = os.environ.get("PN2_POOL_FUSE", "1") == "1"          # the stem's bn1 -> ReLU -> MaxPool as one op: the 176 x 176 BatchNorm output is never written (conv_bn_act(pool=True))
 TEE_CONCAT = os.environ.get("PN2_TEE_CONCAT", "1") == "1"         # Bottle2neck: conv1 + bn1 + ReLU writes its pass-through slice into the concat buffer as well (pn2_affine_act_tee); False: a copy launch
 EVAL_FUSE = True          # eval mode: conv + BatchNorm (+ ReLU) (+ residual) in ONE launch (pn2_conv_gemm_affine); tests switch it off to compare with the two-launch path

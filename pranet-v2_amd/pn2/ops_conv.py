@@ -391,7 +391,10 @@ class ConvOps:
                     call.pn2_copy(self.dt, _p(g2), g2.stride(2), self.dt, _p(gs), gs.stride(2), M, Cout_p, sacc, st)
             dy = out.grad_buf()
             assert out.grad_written or out.child_written, "conv output never received a gradient"
-            if pool:          # the gradient of the (never stored) full-resolution BatchNorm output, as MaxPool2d's backward leaves it
+            cvq = Cout_p // V
+            quad = (pool and core.POOL_BWD_QUAD and OH % 2 == 0 and OW % 2 == 0 and cvq <= 256 and cvq & (cvq - 1) == 0 and dy.stride(2) % V == 0
+                    and N * (OH // 2) * (OW // 2) < (1 << 24) - (1 << 21))
+            if pool and not quad:          # the gradient of the (never stored) full-resolution BatchNorm output, as MaxPool2d's backward leaves it
                 dyf = self.empty(N, OH, OW, Cout_p)
                 call.pn2_maxpool3x3s2_bwd(self.dt, _p(dy), dy.stride(2), _p(pidx), _p(dyf), Cout_p, N, OH, OW, Cout_p, out.H, out.W, st)
                 dy = dyf
@@ -411,7 +414,14 @@ class ConvOps:
                 gb, gba = self.pgrads.sink(bn.bias)
                 assert ga == gba
                 segs = out.find_bstats() if (bnb_ok and dy.stride(2) % V == 0) else None
-                if segs is not None and len(segs) <= 4 and any(s_[2] is not None for s_ in segs):
+                if quad:
+                    # both BatchNorm passes form the incoming gradient per 2 x 2 input quad from the pooled gradient + argmax bytes: no pool-backward launch, no 176 x 176 gradient tensor
+                    nb = 512          # workgroups = partial rows of the reduce (flat from 512 to 4096)
+                    p1, p2 = self.fbuf(nb, Cout_p), self.fbuf(nb, Cout_p)
+                    call.pn2_pool_bn_bwd_reduce(self.dt, _p(dy), dy.stride(2), _p(pidx), _p(raw), raw_ld, N, OH, OW, Cout_p, out.H, out.W,
+                                                _p(mean), _p(invstd), _p(msc), _p(msh), _p(p1), _p(p2), nb, st)
+                    call.pn2_bn_bwd_finalize(_p(p1), _p(p2), nb, C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
+                elif segs is not None and len(segs) <= 4 and any(s_[2] is not None for s_ in segs):
                     # (part of) the statistics were left by dgrad epilogues; channel ranges nobody covered get a reduce pass of their own
                     sg = capi.BnSegs()
                     sg.nseg = len(segs)
@@ -454,7 +464,10 @@ class ConvOps:
                     residual.grad_written = True
                 else:
                     rg, racc = residual.grad_sink()
-            if coef is None and ymask is None and rg is None and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) == Cout_p and dy.is_contiguous():
+            if quad:
+                call.pn2_pool_bn_bwd_apply(self.dt, _p(dy), dy.stride(2), _p(pidx), _p(raw), raw_ld, N, OH, OW, Cout_p, out.H, out.W,
+                                           _p(mean), _p(invstd), _p(coef), _p(msc), _p(msh), _p(draw), Cout_p, st)
+            elif coef is None and ymask is None and rg is None and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) == Cout_p and dy.is_contiguous():
                 draw = dy               # no BN, no activation, no residual (nn.Linear / biased conv): dz IS dy - no copy pass
             else:
                 call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,

@@ -1086,22 +1086,28 @@ def test_inference_predictor_graph_matches_module_eval():
 
 
 @pytest.mark.parametrize("fp32", [False, True])
-def test_stem_bn_relu_maxpool_as_one_op_is_bit_identical(fp32, monkeypatch):
-    """conv_bn_act(pool=True): the stem's bn1 -> ReLU -> MaxPool2d(3, 2, 1) (Res2Net_v1b.py:137-139) without the full-resolution BatchNorm output - the pooled
-    activation and the argmax bytes come straight from the raw conv output (pn2_bn_relu_maxpool_fwd) - against the separate normalise and pool passes: every value is
-    formed the same way, so loss, maps and every gradient of a training step agree bit for bit."""
+def test_stem_bn_relu_maxpool_as_one_op(fp32, monkeypatch):
+    """conv_bn_act(pool=True): the stem's bn1 -> ReLU -> MaxPool2d(3, 2, 1) (Res2Net_v1b.py:137-139) without the full-resolution BatchNorm output.  Forward
+    (pn2_bn_relu_maxpool_fwd): pooled activation and argmax bytes straight from the raw conv output - every value formed as the separate normalise and pool passes form
+    it, so with the generic backward (pool-backward launch + BatchNorm passes) a training step agrees BIT FOR BIT with the three separate ops.  Quad backward
+    (pn2_pool_bn_bwd_reduce / _apply, the default): no full-resolution gradient tensor either; each pixel's gradient is the same rounded sum, the BatchNorm sums are taken
+    in another order - loss and maps identical, gradients equal up to that fp32 order (bf16: plus the roundings of dz that flip with the last bit of the coefficients)."""
     from pn2 import core
     from pn2.trainer import Trainer
     from oracle import weights as W
     for size in (96, 224):          # 48 -> 24 and 112 -> 56 stem maps
         x, mask = W.synthetic_batch(2, size, seed=9)
         xg, mg = x.to(dev), mask.to(dev)
-        res = []
-        for on in (True, False):
-            monkeypatch.setattr(core, "POOL_FUSE", on)
+        res = {}
+        for name, fuse, quad in (("sep", False, False), ("fwd", True, False), ("quad", True, True)):
+            monkeypatch.setattr(core, "POOL_FUSE", fuse)
+            monkeypatch.setattr(core, "POOL_BWD_QUAD", quad)
             tr = Trainer(_fixture_model(fp32=fp32))
             loss = tr.forward_backward(xg, mg)
             torch.cuda.synchronize()
-            res.append((loss.clone(), tr.gflat.clone(), tr.last_outs.clone()))
-        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
-        assert torch.equal(res[0][1], res[1][1]), float((res[0][1] - res[1][1]).abs().max())
+            res[name] = (loss.clone(), tr.gflat.clone(), tr.last_outs.clone())
+        for name in ("fwd", "quad"):
+            assert torch.equal(res["sep"][0], res[name][0]) and torch.equal(res["sep"][2], res[name][2]), name
+        assert torch.equal(res["sep"][1], res["fwd"][1]), float((res["sep"][1] - res["fwd"][1]).abs().max())
+        rel = float((res["sep"][1] - res["quad"][1]).norm() / res["sep"][1].norm())
+        assert rel <= (2e-7 if fp32 else 5e-5), rel
