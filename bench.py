@@ -362,6 +362,11 @@ def main():
                                      round(ips / world * (TRAIN_GFLOP_PER_IMG if args.model == "res2net" else 72.3) / 1e3 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4)),
             "roofline": roof["roofline"], "kernels": roof["kernels"],
         }
+        hb = out["roofline"].get("step_hbm_bytes_pmc")
+        if hb:          # the whole step against the HBM roofline: bytes of the committed PMC passes / this run's step time (the step is traffic-bound first)
+            gbs = hb / (1e-3 * out["ms_per_step"]) / 1e9
+            out["roofline"]["step_hbm"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "bytes_per_step": hb,
+                                          "source": out["roofline"].get("traffic_source")}
         if dp is not None:
             out["dp"] = dp
         if world == 1 and not args.no_fp32_line and args.model == "res2net" and args.dtype == "bf16":
