@@ -2,7 +2,8 @@
 """bench.py — images/sec of the full PraNet-V2 (Res2Net-50) training step at 352x352, bs=32 per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus 8 ...          # starts 8 ranks itself (one per GPU, torch.distributed.run as a CHILD process) and exits with their status
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...   # the same ranks, launched by the caller
 
 A step = forward + 4x structure loss + backward + clamp(0.5) + Adam(1e-4) [+ RCCL gradient all-reduce], i.e. everything the
 reference runs between optimizer.zero_grad() and optimizer.step() (MyTrain_med.py:59-86), on synthetic data (images N(0,1),
@@ -232,7 +233,104 @@ def dp1_line(dev, x, m, steps=10):
     return res
 
 
-def main():
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, backend="nccl", timeout=3600.0, out=None):
+    """`bench.py --gpus N` without a launcher around it: start N ranks (one per GPU) with torch.distributed.run as a CHILD process, pass its stdout through (rank 0's JSON
+    line), return its exit status.  The reference's counterpart is the one-line nn.DataParallel wrap (multiclass_seg/EMCAD/trainer.py:75-77): as easy to start.
+    Runs BEFORE anything in this process touches the GPU (torch.cuda.device_count() only counts devices on this image) and never replaces this process: a child, not an exec.
+    A rank that hangs: the whole process group of the child is killed after `timeout` seconds and the status is 124.  Fewer than N devices: status 2, nothing started."""
+    import signal, subprocess, threading
+    out = sys.stdout if out is None else out
+    if backend == "nccl":
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} GPUs, this node shows {have} (torch.cuda.device_count()); nothing was started", file=sys.stderr, flush=True)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+
+    def pump():
+        for line in child.stdout:
+            out.write(line); out.flush()
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    try:
+        rc = child.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {n}-rank run did not finish within {timeout:.0f} s; killing its process group", file=sys.stderr, flush=True)
+        try:
+            os.killpg(child.pid, signal.SIGKILL)          # the exact group this function started (start_new_session), never a pattern
+        except ProcessLookupError:
+            pass
+        child.wait()
+        rc = 124
+    except KeyboardInterrupt:
+        os.killpg(child.pid, signal.SIGKILL)
+        child.wait()
+        raise
+    t.join(5)
+    return rc
+
+
+def wire_only(args, world, rank, local):
+    """--dry-run: everything of an N-rank run except the model - rendezvous, the gradient buckets of pn2/dp.py over an arena of PraNet-V2's gradient size (122 MB; 4 MB on gloo),
+    the barrier + max-over-ranks timing protocol, rank 0's JSON line.  With nccl on GPUs this is the exposed-wire bound of the step's all-reduce; with `--backend gloo` it runs on
+    CPUs, which is how tests/test_bench_launcher_cpu.py drives the launcher without a GPU.  `value` is null: no images were processed."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "pranet-v2_amd"))
+    from pn2.dp import GradBuckets
+    if args.backend == "nccl":
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        dist.init_process_group("nccl", device_id=dev)
+        n = 30_499_908
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group(args.backend)
+        n = 1 << 20
+    g = torch.full((n,), float(rank + 1), dtype=torch.float32, device=dev)
+    bk = GradBuckets(g, [(0, 0, n // 8), (1, n // 8, n - n // 8)], process_group=dist.group.WORLD)
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+    def step():
+        bk.reduce_all()
+    for _ in range(args.warmup):
+        step()
+    sync(); dist.barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync(); dist.barrier(); sync()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t)
+    g.fill_(float(rank + 1))
+    bk.reduce_all(); sync()
+    ok = bool((g == world * (world + 1) / 2).all())
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec (train fwd+bwd) at 352x352 bs=32/GPU", "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * el / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "dry_run": True, "config": {"workload": f"dry run: bucketed gradient all-reduce only ({4 * n / 2 ** 20:.0f} MB fp32 arena, no model)", "parallelism": f"dp{world}"},
+                          "dp": {"backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "nccl_ranks": world, "buckets": len(bk.buckets), "allreduce_bytes_per_step": 4 * n,
+                                 "sum_correct": ok, "bus_GBps": round(2 * (world - 1) / world * 4 * n / (el / max(args.steps, 1)) / 1e9, 2)}}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=150, help="timed steps (default: ~2 s of hipGraph replay)")
@@ -249,11 +347,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-line", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra records of the default single-GPU run (configs 4 / 5, module surface, inference, one-rank DP)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of a multi-rank run (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous + bucketed gradient all-reduce + the timing protocol, no model (see wire_only)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="seconds after which a self-launched multi-rank run is killed (status 124)")
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = ap.parse_args(argv)
+    if args.backend != "nccl" and not args.dry_run:
+        ap.error("--backend gloo is only meaningful with --dry-run (the step itself has no CPU path)")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become the launcher (before any GPU call; the ranks are children, this process never initialises the GPU)
+        return launch_ranks(args.gpus, argv, backend=args.backend, timeout=args.launch_timeout)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" in os.environ and args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus = {world}", file=sys.stderr, flush=True)
+    if args.dry_run:
+        return wire_only(args, world, rank, local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
@@ -367,8 +478,8 @@ def main():
             gbs = hb / (1e-3 * out["ms_per_step"]) / 1e9
             out["roofline"]["step_hbm"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "bytes_per_step": hb,
                                           "source": out["roofline"].get("traffic_source")}
-        if dp is not None:
-            out["dp"] = dp
+        # always present: how many ranks exchanged gradients (1 = a single process, no collective on the data path)
+        out["dp"] = dp if dp is not None else {"backend": None, "nccl_ranks": 1, "mode": "single process, no collective on the data path"}
         if world == 1 and not args.no_fp32_line and args.model == "res2net" and args.dtype == "bf16":
             tr = None
             torch.cuda.empty_cache()
@@ -394,4 +505,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -8,7 +8,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; the library never frees);
  *   - activations are NHWC views: base pointer at the view's first channel, `ld` = elements between pixels;
- *   - dtype: PN2_F32 (exact fp32 parity path, v_mfma_f32_16x16x4_f32) or PN2_BF16 (bf16 storage, f32 accumulate);
+ *   - dtype: PN2_F32 (fp32 parity path: fp32 storage, conv products and sums in double on v_mfma_f64_16x16x4_f64, one rounding per output)
+ *     or PN2_BF16 (bf16 storage, v_mfma_f32_16x16x32_bf16, f32 accumulate);
  *   - every call is asynchronous on `stream` (a hipStream_t); returns 0 on success, <0 for argument
  *     errors (-1 null pointer, -2 unsupported geometry/alignment, -3 unknown dtype), >0 = hipError_t;
  *   - no global state; safe to call from any thread / any stream; graph-capture safe (no sync, no malloc).

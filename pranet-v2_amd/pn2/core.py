@@ -240,6 +240,8 @@ class PackCache:
         self.jobs = []             # capi.PackJob (host copies)
         self.keep = []             # weights referenced by the table (pointers must stay valid)
         self.table = None
+        self.retired = []          # tables replaced by add(): a hipGraph captured earlier still launches them (their jobs, panels and weights all stay alive) - never freed
+        self.version = 0           # bumped by add(): holders of captured graphs can tell that the job set has grown since their capture
         self.dt = None
 
     # a cache hangs off a module parameter on the nn.Module surface: pickling / deep-copying the module must not drag device job tables along
@@ -256,7 +258,10 @@ class PackCache:
         C.memmove(C.byref(j.d), C.byref(d), C.sizeof(capi.PackDesc))
         self.jobs.append(j)
         self.keep.append(w)
+        if self.table is not None:
+            self.retired.append((self.table, self.bstart))
         self.table = None
+        self.version += 1
         self.dt = key[4]
 
     def refresh(self):
@@ -275,6 +280,7 @@ class BnFoldCache:
     def __init__(self):
         self.entries = {}          # (id(bn), Cp, gw, gwp) -> [2][Cp] fp32 rows scale, shift
         self.jobs, self.keep, self.table = [], [], None
+        self.retired, self.version = [], 0          # as in PackCache: replaced tables stay allocated for the graphs that captured them
 
     def __reduce__(self):
         return (BnFoldCache, ())
@@ -294,7 +300,10 @@ class BnFoldCache:
         C.memmove(C.byref(j.d), C.byref(bd), C.sizeof(capi.BnDesc))
         self.jobs.append(j)
         self.keep.append(bn)
+        if self.table is not None:
+            self.retired.append((self.table, self.bstart))
         self.table = None
+        self.version += 1
 
     def refresh(self):
         if not self.jobs:

@@ -29,8 +29,18 @@ DP_SEGMENTS = os.environ.get("PN2_DP_SEGMENTS", "1") == "1"          # data-para
 # data-parallel replay on RCCL: the bucket all-reduces are captured INTO the step's hipGraph (forked onto RCCL's stream by the events c10d records, joined before
 # the optimizer) - a replay is ONE hipGraphLaunch.  Measured on a one-rank communicator (tools/dp_probe.py): 14.85 ms local, 15.31 ms with c10d's asynchronous
 # collectives between graph segments (the cross-stream event traffic costs 0.37 ms per step plus ~0.09 ms per cut), back to local speed when captured.  A backend
-# that cannot be captured (gloo) or a failing capture falls back to the chain of graph segments.
-DP_CAPTURE = os.environ.get("PN2_DP_CAPTURE", "1") == "1"
+# that cannot be captured (gloo) or a failing capture falls back to the chain of graph segments - on EVERY rank: the outcome is agreed with a MIN all-reduce
+# (Trainer._agree), a rank never replays captured collectives while another issues eager ones.
+# PN2_DP_CAPTURE: "1" always try, "0" never, unset = only on a one-rank communicator (verified on hardware, bench.py --dp1).  Multi-rank runs default to the
+# segment chain - c10d's ordinary asynchronous collectives, the path every DDP job takes - until captured multi-rank RCCL has run on an 8-GPU node.
+_DP_CAPTURE_ENV = os.environ.get("PN2_DP_CAPTURE", "")
+
+
+def dp_capture_wanted(world):
+    return _DP_CAPTURE_ENV == "1" or (_DP_CAPTURE_ENV == "" and world == 1)
+
+
+_CAP_GROUPS = {}          # main process group -> (communicator for captured collectives, time of its one eager collective): shared by the trainers of a process
 
 
 class Trainer:
@@ -79,6 +89,21 @@ class Trainer:
         bucket_bytes = int(os.environ.get("PN2_DP_BUCKET_MB", "0")) << 20 or bucket_bytes
         self.buckets = GradBuckets(self.gflat, [(id(p), self.off[id(p)][0], _r4(self.off[id(p)][1])) for p in hot], bucket_bytes, process_group,
                                    wire_dtype=torch.bfloat16 if os.environ.get("PN2_DP_WIRE", "fp32") == "bf16" else None)
+        # The collectives that are captured INTO a step graph run on a communicator of their own (see _capture_with_collectives): its stream has carried exactly one
+        # eager collective - the warm-up below, retired by c10d's watchdog long before any capture() - so no watchdog ever polls an event of a capturing stream.
+        self.pg_cap, self._cap_warm_t = None, 0.0
+        if self.dp and dp_capture_wanted(self.world):
+            import time
+            import torch.distributed as dist
+            ranks = dist.get_process_group_ranks(process_group)
+            if dist.get_backend(process_group) == "nccl" and len(ranks) == dist.get_world_size():      # new_group is a collective over the default group
+                if process_group not in _CAP_GROUPS:
+                    cap = dist.new_group(ranks=ranks, backend="nccl")
+                    warm = torch.zeros(4, dtype=torch.float32, device=dev)
+                    dist.all_reduce(warm, group=cap)          # creates the communicator and its stream outside any capture
+                    torch.cuda.synchronize()
+                    _CAP_GROUPS[process_group] = (cap, time.monotonic())
+                self.pg_cap, self._cap_warm_t = _CAP_GROUPS[process_group]
         self._seg = None                # capture of a data-parallel step in progress (see _capture_segments)
         self._expected = None           # id(p) -> gradient contributions per step, learned from the first backward pass (see _backward)
         self.last_outs = None
@@ -286,8 +311,9 @@ class Trainer:
     # ------------------------------------------------------------------ hipGraph replay of the whole step
     def capture(self, images, gts, warmup=3, size=None):
         """Capture forward+loss+backward(+Adam) into hipGraphs and replay them with `replay(images, gts)`.
-        With data parallelism the gradient all-reduce stays outside the graphs (between backward and Adam).
-        One set of graphs per (batch shape, train size): call once per scale of a multi-scale schedule."""
+        With data parallelism the bucket all-reduces are either captured into the step graph as forked branches (_capture_with_collectives; default on a one-rank
+        communicator, PN2_DP_CAPTURE=1 elsewhere) or issued by c10d between a chain of graph segments cut where buckets leave (_capture_segments); all ranks take the
+        same form (_agree).  One set of graphs per (batch shape, train size): call once per scale of a multi-scale schedule."""
         st = self._state(images, size)
         if st.steps_run + warmup < 2:
             # step 1 measures the arena, step 2 builds the deferred-launch tables on the arena addresses the graph will replay
@@ -313,7 +339,7 @@ class Trainer:
                 with torch.cuda.graph(st.graph, capture_error_mode=CAPTURE_MODE):
                     st.s_loss = self.step(st.s_images, st.s_gts, size=size)
                 st.graph_opt = None
-            elif self._capture_with_collectives(st, size):
+            elif self._agree(self._capture_with_collectives(st, size)):
                 st.graph_opt, st.segments = None, None
             else:
                 st.graph = torch.cuda.CUDAGraph()
@@ -337,17 +363,21 @@ class Trainer:
         the optimizer - as ONE hipGraph.  c10d runs a collective on its own stream behind an event of the capturing stream and joins it back in Work.wait():
         inside a capture those become a forked branch of the graph, so the all-reduce of a bucket overlaps the backward kernels that follow it exactly as in
         the eager step, without any host-side stream traffic at replay.  Returns False (nothing captured) when the backend cannot be captured."""
-        import torch.distributed as dist
-        if not DP_CAPTURE or self._expected is None or dist.get_backend(self.pg) != "nccl":
+        if self.pg_cap is None or self._expected is None:
             return False
-        # c10d's watchdog thread polls the events of the EAGER collectives of the warm-up steps (every 100 ms) until it has seen them complete.  Once the capture
-        # pulls RCCL's stream in, HIP refuses hipEventQuery on events of that stream ("operation not permitted on an event last recorded in a capturing
-        # stream") and the watchdog takes the process down - a race that fires when the capture starts within a poll interval of the last eager collective.
-        # All eager work is complete here; give the watchdog ten poll intervals to retire it before RCCL's stream starts capturing.
+        # c10d's watchdog thread polls the events of EAGER collectives (every 100 ms) until it has seen them complete.  Once a capture pulls a communicator's
+        # stream in, HIP refuses hipEventQuery on events of that stream ("operation not permitted on an event last recorded in a capturing stream") and the
+        # watchdog takes the process down - round 4 hit that when a capture started within a poll interval of the last eager collective of the warm-up steps and
+        # papered over it with a sleep.  Now the captured collectives have their own communicator (self.pg_cap): the eager steps - warm-up, fall-back, the
+        # agreement all-reduce - run on self.pg, whose stream is never captured, and pg_cap's single eager collective dates from the constructor, at least two
+        # eager training steps ago (capture() insists on them).  The guard below only ever waits in a test that builds and captures within the same 0.5 s.
         import time
         torch.cuda.synchronize()
-        time.sleep(1.0)
+        dt = 0.5 - (time.monotonic() - self._cap_warm_t)
+        if dt > 0:
+            time.sleep(dt)
         g = torch.cuda.CUDAGraph()
+        main_pg, self.buckets.pg = self.buckets.pg, self.pg_cap
         try:
             with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 st.s_loss = self.step(st.s_images, st.s_gts, size=size)
@@ -357,8 +387,26 @@ class Trainer:
             self.buckets.works = []
             torch.cuda.synchronize()
             return False
+        finally:
+            self.buckets.pg = main_pg
         st.graph = g
         return True
+
+    def _agree(self, ok):
+        """Every rank must replay the same form of the step: a rank whose capture of the collectives failed would issue eager all-reduces between graph segments
+        while the others replay captured ones - different collective sequences on the wire, a hang.  MIN over the ranks of the local outcome, eagerly, on the main
+        communicator (nothing is capturing here).  One rank: nothing to agree."""
+        if self.world > 1:
+            import torch.distributed as dist
+            torch.cuda.synchronize()
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.flat.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            agreed = bool(int(flag.item()))
+            if ok and not agreed:
+                import warnings
+                warnings.warn("another rank could not capture the RCCL collectives into its step graph; every rank falls back to graph segments")
+            return agreed
+        return ok
 
     def _cut_segment(self):
         """Capture of a data-parallel step: one or more gradient buckets just became complete - close the hipGraph segment that produced them

@@ -126,5 +126,9 @@ def test_buckets_are_cut_from_the_tail_with_a_small_head_bucket():
     assert b[0][0] == 0 and b[-1][1] == off and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
     assert [sorted(k[2]) for k in b] == [[0, 1], [2, 3], [4, 5], [6, 7, 8]], [sorted(k[2]) for k in b]      # tail: 6000 >= 5000; 5000; rest 4000 -> head 1000 <= 1200 + 3000
     assert (b[0][1] - b[0][0]) * 4 <= 4 * 1200
-    one = GradBuckets(torch.zeros(off), spans, bucket_bytes=4 * 100000)                                     # everything below one bucket: head + rest
-    assert [len(k[2]) for k in one.buckets] == [len(sizes)] or sum(len(k[2]) for k in one.buckets) == len(sizes)
+    # everything below one bucket (15000 elements < 100000): the head bucket (spans that fit bucket_bytes / 5 = 20000 elements ... all of them) - i.e. ONE bucket
+    one = GradBuckets(torch.zeros(off), spans, bucket_bytes=4 * 100000)
+    assert [sorted(k[2]) for k in one.buckets] == [list(range(len(sizes)))]
+    # below one bucket but above the head allowance: a head of <= head_bytes plus ONE rest bucket, in arena order
+    two = GradBuckets(torch.zeros(off), spans, bucket_bytes=4 * 100000, head_bytes=4 * 1200)
+    assert [sorted(k[2]) for k in two.buckets] == [[0, 1], list(range(2, len(sizes)))] and (two.buckets[0][1] - two.buckets[0][0]) * 4 <= 4 * 1200

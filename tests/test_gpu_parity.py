@@ -1085,6 +1085,32 @@ def test_inference_predictor_graph_matches_module_eval():
     print(f"\\ninference 1x3x352x352 + tail (hipGraph replay): {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms/image")
 
 
+def test_predictor_graphs_survive_a_growing_job_table():
+    """a captured inference graph bakes in the device job tables of PackCache / BnFoldCache.  A later input shape that takes another kernel
+    path registers new jobs (bs >= 34 at 352^2: the ra4 5x5 convs leave the split-K path, M = 121 * bs > 4096, and add BatchNorm fold entries), which replaces
+    the tables.  The replaced tables must stay allocated: the first graph still launches them.  Replay the first shape after the second was captured (with
+    allocator churn in between, so a freed table would have been reused) and require the bit-identical maps."""
+    from pn2.infer import Predictor
+    model = _fixture_model(fp32=False).eval()
+    pred = Predictor(model)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    xa = torch.randn(2, 3, 352, 352, generator=g).to(dev)
+    xb = torch.randn(34, 3, 352, 352, generator=g).to(dev)
+    first = [o.clone() for o in pred(xa)]
+    v0 = (pred.pack_cache.version, pred.bn_fold.version)
+    pred(xb)
+    grew = (pred.pack_cache.version, pred.bn_fold.version) != v0
+    junk = [torch.full((1 << 12,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(256)]      # lands in any small block the allocator got back
+    torch.cuda.synchronize()
+    again = pred(xa)
+    torch.cuda.synchronize()
+    for a, b in zip(first, again):
+        assert torch.equal(a, b)
+    assert grew, "the second shape was meant to register new jobs (otherwise this test does not exercise the retired tables)"
+    assert len(pred.pack_cache.retired) + len(pred.bn_fold.retired) >= 1
+    del junk
+
+
 @pytest.mark.parametrize("fp32", [False, True])
 def test_stem_bn_relu_maxpool_as_one_op(fp32, monkeypatch):
     """conv_bn_act(pool=True): the stem's bn1 -> ReLU -> MaxPool2d(3, 2, 1) (Res2Net_v1b.py:137-139) without the full-resolution BatchNorm output.  Forward
