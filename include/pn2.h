@@ -326,6 +326,17 @@ int pn2_dsra_tail_scratch(const pn2_tail_desc* d);
 /* scratch may be NULL / short: the backward then runs one block per low-res row (slower, same result up to summation order) */
 int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* weit, const float* wsum, const float* sums,
                       float gscale, float* scratch, long long scratch_floats, void* stream);
+/* Forward + backward of the tail in ONE pass over the pixels (pranet.py:354,371,393,415 + MyTrain_med.py:19-38,78-84): the gradient of the structure
+ * loss is linear in three per-logit quantities whose coefficients alone need the image-wide sums, so the forward walk also pushes them through the
+ * bilinear adjoint and leaves band partials; a second small kernel combines them with the coefficients it forms from the loss partials, a third
+ * finishes loss[P+1].  No backward walk, no single-workgroup finalize between two big kernels.  Served geometry (pn2_dsra_tail_fused_ok() == 1, else -2:
+ * use _fwd + _bwd): align_corners = 0, every map magnified by a power of two >= 8 in both directions (all scales of MyTrain_med.py:55,70-73), pair p's
+ * fg and bg map of one geometry, OW <= 512.  per: [P][N] floats of caller-owned scratch; sums / wsum / loss as pn2_dsra_tail_fwd (valid when the call has
+ * run); scratch: pn2_dsra_tail_fused_scratch() floats.  PN2_TAIL_BAND=0|1 (row / band kernels of the two-call path) also switches this path off. */
+int pn2_dsra_tail_fused_ok(const pn2_tail_desc* d);
+int pn2_dsra_tail_fused_scratch(const pn2_tail_desc* d);
+int pn2_dsra_tail_fwd_bwd(const pn2_tail_desc* d, float* lat, const float* mask, const float* weit, float* partial, float* sums, float* wsum,
+                          float* per, float* loss, float gscale, float* scratch, long long scratch_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- PVTv2 encoder (lib/pvtv2.py)
  * Tokens [B, N, C] of the reference are NHWC pixels here.  The nn.Linear layers run as 1x1 pn2_conv_gemm / pn2_conv_wgrad.      */

@@ -747,6 +747,369 @@ __global__ __launch_bounds__(256) void tail_band_fin_k(pn2_tail_desc d, tail_ban
     *dst = mp.accumulate ? *dst + s : s;
 }
 
+// ------------------------------------------------------------------------------------------ fused DSRA tail in ONE pass (round 5)
+// PMC on the band kernels above (profiles/r05_tail_*): they issue 25-30 vector instructions per logit, forward and backward each, and both walk every
+// pixel - stage the low-res rows, fetch mask / weit, interpolate, take the sigmoid.  Two rewrites that kept the two-pass structure (one block per (band,
+// image) over all 2P maps; per-logit arithmetic on packed pairs, ~11 instructions) measured 105-123 us against 108: with the walk halved, what is left is
+// the per-block fixed cost and the second pass itself.  This kernel removes the second pass.  The gradient of the structure loss is LINEAR in three
+// per-logit quantities whose coefficients are the only thing that needs the image-wide sums:
+//     dL/dz_fg = gw*(w*p - m*w) + cA*(w*p(1-p)) - (cA + cB)*(m*w*p(1-p)),     dL/dz_bg = 0.8*gw*(w*p - (w - m*w)),
+//     gw = g/(N*sum w), cA = g*(I + 1)/(N*D^2), cB = g/(N*D), D = U - I + 1      (I = sum p*m*w, U = sum (p + m)*w per image; MyTrain_med.py:19-38)
+// so the forward walk also pushes those quantities through the bilinear adjoint (vertical: two slot accumulators per thread; horizontal: a thread-local
+// dot with its four tap weights, then a short gather over the threads of a low-res column) and leaves band partials; tail_one_fin_k sums the <= 3 bands of
+// a low-res row and applies gw / cA / cB, which it forms from the forward's loss partials.  With p = 1/2 + gs, hw = w/2, c1 = w/2 - m*w (per pixel, shared
+// by the 2P maps) the walk accumulates  X1 = hw*gs, X2 = hw*gs^2, X3 = c1*gs^2 (fg), Y1 = hw*gs (bg)  and, once per pair geometry, Shw = hw, Sc1 = c1:
+//     fg: gw*(2 X1 + Sc1) + cA*(Shw/2 - 2 X2) - (cA + cB)*((Shw - Sc1)/4 - X2 + X3)          bg: 0.8*gw*(2 Y1 - Sc1)
+// Served geometry: align_corners = 0 and every map magnified by a power of two >= 8 in both directions (all training scales of MyTrain_med.py:55,70-73:
+// 256 / 352 / 448 px -> x8, x16, x32): then a pixel quad has one left tap column, a row lane's rows one upper tap row, and the run of quads behind a
+// low-res column is (i*mag + mag/2)/4 exactly.  Everything else takes pn2_dsra_tail_fwd + _bwd.  No atomics, fixed summation orders.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 f2s(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 f2fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+constexpr float T_LOG2E = 1.44269504f, T_2LN2 = 1.38629436f;
+// u = 1 + e^-|z|
+__device__ __forceinline__ f2 tail_u(f2 z) {
+    return f2{__builtin_amdgcn_exp2f(-fabsf(z.x) * T_LOG2E), __builtin_amdgcn_exp2f(-fabsf(z.y) * T_LOG2E)} + f2s(1.f);
+}
+// |z| + 2 ln2 log2(u)  (= 2 softplus(z) - z):   w*bce(z, m) = hw*t + z*c1,   w*bce(z, 1 - m) = hw*t - z*c1
+__device__ __forceinline__ f2 tail_t(f2 z, f2 u) {
+    return f2{fmaf(__builtin_amdgcn_logf(u.x), T_2LN2, fabsf(z.x)), fmaf(__builtin_amdgcn_logf(u.y), T_2LN2, fabsf(z.y))};
+}
+// sigmoid(z) - 1/2 = copysign(1/u - 1/2, z)      (e/(1 + e) = 1 - 1/(1 + e))
+__device__ __forceinline__ f2 tail_gs(f2 z, f2 u) {
+    const f2 g = f2{__builtin_amdgcn_rcpf(u.x), __builtin_amdgcn_rcpf(u.y)} - f2s(0.5f);
+    return f2{copysignf(g.x, z.x), copysignf(g.y, z.y)};
+}
+
+constexpr int TNK = 12;          // gradient rows of a pair in cc: (X1, X2, X3, Y1, Shw, Sc1) x 2 slots
+struct tail_one_aux {
+    int voff[PN2_TAIL_MAX_MAPS];            // float offset of map j's staged source rows ([3][w + 1]) in LDS
+    int poff[PN2_TAIL_MAX_MAPS];            // pair p's block of the band partials: [6][3][w] floats
+    int mag[PN2_TAIL_MAX_MAPS];             // pair p's magnification
+    unsigned wmagic[PN2_TAIL_MAX_MAPS];     // ceil(2^32 / w_p)
+    int ptot, vtot, R, nb;
+};
+
+// the thread's 4 logits on output row r of one map: z[h] = columns (2h, 2h + 1); raw: the map's staged source rows, rt = {dy0*(w+1), dy1*(w+1), ly0, ly1}
+__device__ __forceinline__ void tail_z4(const float* raw, const float4 rt, int x0, const f2* la, const f2* lb, f2* z) {
+    const float* r0 = raw + __float_as_int(rt.x) + x0; const float* r1 = raw + __float_as_int(rt.y) + x0;
+    const f2 tv = f2fma(f2s(rt.w), f2{r1[0], r1[1]}, f2s(rt.z) * f2{r0[0], r0[1]});          // (v[x0], v[x0 + 1]), v = ly0*s[y0] + ly1*s[y1] as bilinear_fwd_k
+    z[0] = f2fma(lb[0], f2s(tv.y), la[0] * f2s(tv.x)); z[1] = f2fma(lb[1], f2s(tv.y), la[1] * f2s(tv.x));
+}
+// thread-local horizontal adjoint of a slot accumulator (4 columns): (sum lx0*a, sum lx1*a) -> the quad's left / right tap column
+__device__ __forceinline__ void tail_cc(float* cc, int k, const f2* acc, const f2* la, const f2* lb, bool rightmost) {
+    const f2 s0 = f2fma(la[1], acc[1], la[0] * acc[0]), s1 = f2fma(lb[1], acc[1], lb[0] * acc[0]);
+    float c0 = s0.x + s0.y, c1 = s1.x + s1.y;
+    if (rightmost) { c0 += c1; c1 = 0.f; }          // x0 = w - 1: the right tap is the same column
+    *reinterpret_cast<float2*>(cc + (size_t)k * 2) = make_float2(c0, c1);
+}
+
+template <int P>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void tail_one_k(pn2_tail_desc d, tail_one_aux A, float* __restrict__ lat, const float* __restrict__ mask,
+                                                                                            const float* __restrict__ weit, float* __restrict__ partial, float* __restrict__ pbuf) {
+    extern __shared__ float lds[];          // raw[2P][3][w + 1] | cc[R][TNK][LV][2]
+    __shared__ __attribute__((aligned(16))) float tab[P * TRB * 4];
+    __shared__ float wst[P * TRB * 2];          // slot weights of a row: towards its upper / lower tap row
+    __shared__ int sbt[P * TRB];                // upper tap row of a row, relative to the band's first
+    __shared__ float red[4 * P + 2][16];
+    const int nb = A.nb, R = A.R;
+    const int n = blockIdx.x / nb, band = blockIdx.x - n * nb;
+    const int OW = d.OW, LV = OW >> 2;
+    const int oyA = band * TRB, rows = min(TRB, d.OH - oyA), RPT = TRB / R;          // RPT <= 4 (host)
+    const int rl0 = threadIdx.x / LV, jv0 = threadIdx.x - rl0 * LV;
+    const bool live = rl0 < R;
+    const int rl = live ? rl0 : 0, jv = live ? jv0 : 0;          // padding lanes of the last wave shadow lane 0's pixels and contribute nothing
+    const int rA = rl * RPT;                                     // the thread's rows rA .. rA + RPT - 1 (contiguous: one upper tap row)
+    const size_t img = (size_t)d.OH * OW, base = (size_t)n * img + (size_t)oyA * OW;
+    float* cc = lds + A.vtot;
+    // ---- every global load of the block is requested before the first one is used: mask / weit rows, then the low-res source rows
+    f2 qh[4][2], qc[4][2];          // hw = w/2, c1 = w/2 - m*w of the thread's pixels (rows x column pairs)
+    {
+        float4 mq[4], wq[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = rA + t, rc = (t < RPT && r < rows) ? r : 0;
+            const size_t px = base + (size_t)rc * OW + jv * 4;
+            mq[t] = *reinterpret_cast<const float4*>(mask + px); wq[t] = *reinterpret_cast<const float4*>(weit + px);
+        }
+        float a0[2 * P];
+#pragma unroll
+        for (int j = 0; j < 2 * P; ++j) {
+            const pn2_tail_map& mp = d.maps[j];
+            const int w = mp.w, wp = w + 1, cnt = 3 * wp, h = mp.h;
+            const float* src = mp.src + (size_t)n * h * w;
+            int ylo, t1; float t2, t3;
+            bl_src(oyA, mp.rh, 0, h, ylo, t1, t2, t3);
+            auto fetch = [&](int e) {
+                const int rr = (e >= wp ? 1 : 0) + (e >= 2 * wp ? 1 : 0), x = e - rr * wp, xs = x < w ? x : w - 1;
+                const int y = ylo + rr < h ? ylo + rr : h - 1;
+                return src[y * w + xs];
+            };
+            a0[j] = (int)threadIdx.x < cnt ? fetch(threadIdx.x) : 0.f;
+            if (cnt > (int)blockDim.x) for (int e = threadIdx.x + blockDim.x; e < cnt; e += blockDim.x) lds[A.voff[j] + e] = fetch(e);          // (w > 63 only)
+        }
+        if ((int)threadIdx.x < P * TRB) {
+            const int p = threadIdx.x / TRB, r = threadIdx.x - p * TRB;
+            const pn2_tail_map& mp = d.maps[p];
+            int y0, y1, ylo, t1; float l0, l1, t2, t3;
+            bl_src(oyA, mp.rh, 0, mp.h, ylo, t1, t2, t3);
+            bl_src(oyA + (r < rows ? r : 0), mp.rh, 0, mp.h, y0, y1, l0, l1);
+            float* t = tab + (p * TRB + r) * 4;
+            t[0] = __int_as_float((y0 - ylo) * (mp.w + 1)); t[1] = __int_as_float((y1 - ylo) * (mp.w + 1)); t[2] = l0; t[3] = l1;
+            wst[(p * TRB + r) * 2] = y1 == y0 ? l0 + l1 : l0; wst[(p * TRB + r) * 2 + 1] = y1 == y0 ? 0.f : l1;          // (bottom border: both taps are row h - 1)
+            sbt[p * TRB + r] = y0 - ylo;
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * P; ++j)
+            if ((int)threadIdx.x < 3 * (d.maps[j].w + 1)) lds[A.voff[j] + threadIdx.x] = a0[j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f2 w0 = f2{wq[t].x, wq[t].y}, w1 = f2{wq[t].z, wq[t].w};
+            qh[t][0] = w0 * f2s(0.5f); qh[t][1] = w1 * f2s(0.5f);
+            qc[t][0] = f2fma(-f2{mq[t].x, mq[t].y}, w0, qh[t][0]); qc[t][1] = f2fma(-f2{mq[t].z, mq[t].w}, w1, qh[t][1]);
+        }
+    }
+    __syncthreads();
+    bool rowok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rowok[t] = live && t < RPT && rA + t < rows;
+    const int rrow = threadIdx.x >> 4, nrow = blockDim.x >> 4;
+    const bool rlead = (threadIdx.x & 15) == 0;
+    {       // sum w/2, sum (w/2 - m*w) over the block's pixels
+        f2 hs = f2s(0.f), cs = f2s(0.f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (rowok[t]) { hs += qh[t][0] + qh[t][1]; cs += qc[t][0] + qc[t][1]; }
+        const float s0 = row16_sum(hs.x + hs.y), s1 = row16_sum(cs.x + cs.y);
+        if (rlead) { red[4 * P][rrow] = s0; red[4 * P + 1][rrow] = s1; }
+    }
+    float* ccme = cc + ((size_t)rl * TNK * LV + jv) * 2;          // cc[rl][k][jv][2]
+    float* pb = pbuf + ((size_t)n * nb + band) * A.ptot;
+#pragma unroll 1
+    for (int p = 0; p < P; ++p) {
+        const pn2_tail_map& mf = d.maps[p];
+        const int w = mf.w;
+        int x0; f2 la[2], lb[2];
+        {
+            int xo[4]; float l0[4], l1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { int x1; bl_src(jv * 4 + e, mf.rw, 0, w, xo[e], x1, l0[e], l1[e]); }
+            x0 = xo[0];          // (= xo[1..3]: power-of-two magnification)
+            la[0] = f2{l0[0], l0[1]}; la[1] = f2{l0[2], l0[3]}; lb[0] = f2{l1[0], l1[1]}; lb[1] = f2{l1[2], l1[3]};
+        }
+        const bool rightmost = x0 == w - 1;
+        const float* vf = lds + A.voff[p]; const float* vb = lds + A.voff[P + p];
+        float* latf = lat + (size_t)p * d.N * img + base + jv * 4; float* latb = lat + (size_t)(P + p) * d.N * img + base + jv * 4;
+        const float* tp = tab + p * TRB * 4; const float* wp_ = wst + p * TRB * 2;
+        if (live) {       // ---- the pair's map-independent rows: Shw, Sc1
+            f2 sh[2][2], sc[2][2];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) { sh[s_][0] = f2s(0.f); sh[s_][1] = f2s(0.f); sc[s_][0] = f2s(0.f); sc[s_][1] = f2s(0.f); }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (rowok[t]) {
+                    const f2 ws0 = f2s(wp_[(rA + t) * 2]), ws1 = f2s(wp_[(rA + t) * 2 + 1]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        sh[0][h] = f2fma(ws0, qh[t][h], sh[0][h]); sh[1][h] = f2fma(ws1, qh[t][h], sh[1][h]);
+                        sc[0][h] = f2fma(ws0, qc[t][h], sc[0][h]); sc[1][h] = f2fma(ws1, qc[t][h], sc[1][h]);
+                    }
+                }
+            tail_cc(ccme, 8 * LV, sh[0], la, lb, rightmost); tail_cc(ccme, 9 * LV, sh[1], la, lb, rightmost);
+            tail_cc(ccme, 10 * LV, sc[0], la, lb, rightmost); tail_cc(ccme, 11 * LV, sc[1], la, lb, rightmost);
+        }
+        {       // ---- fg map: logits, loss sums, X1 / X2 / X3
+            f2 A0 = f2s(0.f), B1 = f2s(0.f), B2 = f2s(0.f);
+            f2 x1[2][2], x2[2][2], x3[2][2];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { x1[s_][h] = f2s(0.f); x2[s_][h] = f2s(0.f); x3[s_][h] = f2s(0.f); }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (rowok[t]) {
+                    const int r = rA + t;
+                    const f2 ws0 = f2s(wp_[r * 2]), ws1 = f2s(wp_[r * 2 + 1]);
+                    f2 z[2];
+                    tail_z4(vf, *reinterpret_cast<const float4*>(tp + r * 4), x0, la, lb, z);
+                    *reinterpret_cast<float4*>(latf + (size_t)r * OW) = make_float4(z[0].x, z[0].y, z[1].x, z[1].y);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f2 hw = qh[t][h], c1 = qc[t][h];
+                        const f2 u = tail_u(z[h]), gs = tail_gs(z[h], u);
+                        A0 = f2fma(z[h], c1, f2fma(hw, tail_t(z[h], u), A0));
+                        const f2 a = hw * gs, v = c1 * gs, b = a * gs, g = v * gs;
+                        B1 += a; B2 += v;
+                        x1[0][h] = f2fma(ws0, a, x1[0][h]); x1[1][h] = f2fma(ws1, a, x1[1][h]);
+                        x2[0][h] = f2fma(ws0, b, x2[0][h]); x2[1][h] = f2fma(ws1, b, x2[1][h]);
+                        x3[0][h] = f2fma(ws0, g, x3[0][h]); x3[1][h] = f2fma(ws1, g, x3[1][h]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);          // one row body at a time
+            }
+            if (live) {
+                tail_cc(ccme, 0, x1[0], la, lb, rightmost); tail_cc(ccme, LV, x1[1], la, lb, rightmost);
+                tail_cc(ccme, 2 * LV, x2[0], la, lb, rightmost); tail_cc(ccme, 3 * LV, x2[1], la, lb, rightmost);
+                tail_cc(ccme, 4 * LV, x3[0], la, lb, rightmost); tail_cc(ccme, 5 * LV, x3[1], la, lb, rightmost);
+            }
+            const float a0 = row16_sum(A0.x + A0.y), b1 = row16_sum(B1.x + B1.y), b2 = row16_sum(B2.x + B2.y);
+            if (rlead) { red[p * 4][rrow] = a0; red[p * 4 + 1][rrow] = b1; red[p * 4 + 2][rrow] = b2; }
+        }
+        {       // ---- bg map: logits, loss sum, Y1
+            f2 A3 = f2s(0.f);
+            f2 y1[2][2];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) { y1[s_][0] = f2s(0.f); y1[s_][1] = f2s(0.f); }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (rowok[t]) {
+                    const int r = rA + t;
+                    const f2 ws0 = f2s(wp_[r * 2]), ws1 = f2s(wp_[r * 2 + 1]);
+                    f2 z[2];
+                    tail_z4(vb, *reinterpret_cast<const float4*>(tp + r * 4), x0, la, lb, z);
+                    *reinterpret_cast<float4*>(latb + (size_t)r * OW) = make_float4(z[0].x, z[0].y, z[1].x, z[1].y);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f2 hw = qh[t][h];
+                        const f2 u = tail_u(z[h]);
+                        A3 = f2fma(-z[h], qc[t][h], f2fma(hw, tail_t(z[h], u), A3));
+                        const f2 a = hw * tail_gs(z[h], u);
+                        y1[0][h] = f2fma(ws0, a, y1[0][h]); y1[1][h] = f2fma(ws1, a, y1[1][h]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (live) { tail_cc(ccme, 6 * LV, y1[0], la, lb, rightmost); tail_cc(ccme, 7 * LV, y1[1], la, lb, rightmost); }
+            const float a3 = row16_sum(A3.x + A3.y);
+            if (rlead) red[p * 4 + 3][rrow] = a3;
+        }
+        __syncthreads();
+        // ---- the quads behind low-res column ix: left taps from quads [J(ix), J(ix+1)), right taps from [J(ix-1), J(ix)), J(i) = (i*mag + mag/2)/4;
+        //      row lane rl's slot s belongs to the band's low-res row sbt[first row of rl] + s.  One thread per (comp, band row, column), fixed order.
+        {
+            const int mag = A.mag[p], total = 18 * w;
+            for (int o = threadIdx.x; o < total; o += blockDim.x) {
+                const int cS = (int)__umulhi((unsigned)o, A.wmagic[p]), ix = o - cS * w, c = cS / 3, S = cS - c * 3;
+                auto J = [&](int i) { return i <= 0 ? 0 : min(LV, (i * mag + (mag >> 1)) >> 2); };
+                const int jB = J(ix), jC = J(ix + 1), jA = ix >= 1 ? J(ix - 1) : jB;
+                float acc = 0.f;
+                for (int rr = 0; rr < R; ++rr) {
+                    const int s_ = S - sbt[p * TRB + rr * RPT];
+                    if (s_ == 0 || s_ == 1) {
+                        const float* row = cc + ((size_t)(rr * TNK + c * 2 + s_) * LV) * 2;
+                        for (int j = jB; j < jC; ++j) acc += row[j * 2];
+                        for (int j = jA; j < jB; ++j) acc += row[j * 2 + 1];
+                    }
+                }
+                pb[A.poff[p] + cS * w + ix] = acc;
+            }
+        }
+        __syncthreads();          // cc is rewritten by the next pair
+    }
+    if (threadIdx.x < 5 * P) {          // partial[p][n][band][5] = {w*bce_fg, w*bce_bg, p*m*w, (p+m)*w, w}
+        const int p = threadIdx.x / 5, k = threadIdx.x - p * 5;
+        auto tot = [&](int row) { float s_ = red[row][0]; for (int i = 1; i < nrow; ++i) s_ += red[row][i]; return s_; };
+        const float HW_ = tot(4 * P), C1_ = tot(4 * P + 1), MW_ = HW_ - C1_;          // sum w/2, sum (w/2 - m*w), sum m*w
+        float val;
+        if (k == 0) val = tot(p * 4);
+        else if (k == 1) val = tot(p * 4 + 3);
+        else if (k == 2) val = 0.5f * MW_ + (tot(p * 4 + 1) - tot(p * 4 + 2));                 // sum p*m*w = sum (1/2 + gs)*(hw - c1)
+        else if (k == 3) val = (HW_ + 2.f * tot(p * 4 + 1)) + MW_;                              // sum p*w + sum m*w
+        else val = 2.f * HW_;
+        partial[(((size_t)p * d.N + n) * nb + band) * 5 + k] = val;
+    }
+}
+
+// dsrc[j][n][y][x] from the band partials of tail_one_k: sum over the <= 3 bands that touch low-res row y (ascending), combined with gw / cA / cB of the
+// pixel's image, which the block forms from the forward's loss partials (16 lanes per sum, double, fixed order - what loss_finalize_k does in one workgroup
+// for the whole batch).  The block of fg map p that holds an image's first pixel also leaves sums / wsum / the image's loss term per[p][n].
+constexpr int TFI = 64;         // images a 256-pixel block can span (h*w >= 5: host)
+__global__ __launch_bounds__(256) void tail_one_fin_k(pn2_tail_desc d, tail_one_aux A, const float* __restrict__ pbuf, const float* __restrict__ partial,
+                                                      float gscale, float* __restrict__ sums_out, float* __restrict__ wsum_out, float* __restrict__ per) {
+    __shared__ double s_d[TFI * 5];
+    const int j = blockIdx.y, P = d.P, p = j >= P ? j - P : j, nb = A.nb;
+    const pn2_tail_map& mp = d.maps[j];
+    const int h = mp.h, w = mp.w, hw_ = h * w, total = d.N * hw_;
+    const int first = blockIdx.x * 256;
+    if (first >= total) return;
+    const int last = min(first + 255, total - 1), n0 = first / hw_, n1 = last / hw_, ni = n1 - n0 + 1;
+    {
+        const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+        for (int c = grp; c < 5 * ni; c += 16) {
+            const int i = c / 5, k = c - i * 5;
+            const float* src = partial + ((size_t)p * d.N + (n0 + i)) * nb * 5 + k;
+            double a = 0.0;
+            for (int b0 = l; b0 < nb; b0 += 128) {
+                float vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int b = b0 + 16 * u; vv[u] = b < nb ? src[(size_t)b * 5] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (double)vv[u];
+            }
+            a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+            if (l == 0) s_d[c] = a;
+        }
+    }
+    __syncthreads();
+    if (j < P && (int)threadIdx.x < ni) {          // the image's first pixel lies in this block: its sums, wsum and loss term (as loss_finalize_k)
+        const int n = n0 + threadIdx.x;
+        if (n * hw_ >= first) {
+            const double* a = s_d + threadIdx.x * 5;
+            float* so = sums_out + ((size_t)p * d.N + n) * 4;
+            so[0] = (float)a[0]; so[1] = (float)a[1]; so[2] = (float)a[2]; so[3] = (float)a[3];
+            if (p == 0) wsum_out[n] = (float)a[4];
+            const float wbce = (float)(a[0] / a[4]), wbce2 = (float)(a[1] / a[4]);
+            const float wiou = 1.f - ((float)a[2] + 1.f) / ((float)a[3] - (float)a[2] + 1.f);
+            per[(size_t)p * d.N + n] = wbce + wiou + 0.8f * wbce2;
+        }
+    }
+    const int local = first + threadIdx.x;
+    if (local >= total) return;
+    const int n = local / hw_, rem = local - n * hw_, y = rem / w, x = rem - y * w;
+    const double* a = s_d + (n - n0) * 5;
+    const float gs_ = gscale / (float)d.N, I = (float)a[2], U = (float)a[3], D = U - I + 1.f;
+    const float gw = gs_ / (float)a[4], cA = gs_ * (I + 1.f) / (D * D), cB = gs_ / D;
+    int oy0, oy1;
+    bl_range(y, mp.rh, 0, d.OH, oy0, oy1);
+    float t1 = 0.f, t2 = 0.f, t3 = 0.f, th = 0.f, tc = 0.f;
+    for (int b = oy0 / TRB; b <= oy1 / TRB; ++b) {
+        const int oyA = b * TRB, oyB = min(oyA + TRB - 1, d.OH - 1);
+        int ylo, yhi, t; float u0, u1;
+        bl_src(oyA, mp.rh, 0, h, ylo, t, u0, u1);
+        bl_src(oyB, mp.rh, 0, h, t, yhi, u0, u1);
+        if (y >= ylo && y <= yhi) {
+            const float* q = pbuf + ((size_t)n * nb + b) * A.ptot + A.poff[p] + (y - ylo) * w + x;          // [comp][3][w]
+            const int cs = 3 * w;
+            if (j < P) { t1 += q[0]; t2 += q[cs]; t3 += q[2 * cs]; th += q[4 * cs]; } else t1 += q[3 * cs];
+            tc += q[5 * cs];
+        }
+    }
+    const float g = j < P ? gw * (2.f * t1 + tc) + cA * (0.5f * th - 2.f * t2) - (cA + cB) * (0.25f * (th - tc) - t2 + t3)
+                          : 0.8f * gw * (2.f * t1 - tc);
+    float* dst = mp.dsrc + local;
+    *dst = mp.accumulate ? *dst + g : g;
+}
+
+// loss[p] = mean over the images of per[p][n], loss[P] = their sum (the order of loss_finalize_k)
+__global__ void loss_total_k(const float* __restrict__ per, int P, int N, float* __restrict__ loss) {
+    __shared__ float lp[8];
+    const int p = threadIdx.x;
+    if (p < P) {
+        float s = 0.f;
+        int i = 0;
+        for (; i + 8 <= N; i += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = per[(size_t)p * N + i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < N; ++i) s += per[(size_t)p * N + i];
+        lp[p] = s / (float)N; loss[p] = lp[p];
+    }
+    __syncthreads();
+    if (p == 0) { float tot = 0.f; for (int k = 0; k < P; ++k) tot += lp[k]; loss[P] = tot; }
+}
+
 // ------------------------------------------------------------------------------------------ clamp + Adam
 __global__ void adam_tick_k(float* bc, float b1, float b2) {
     // bc = {1-b1^t, 1-b2^t, b1^t, b2^t}; host initialises {0,0,1,1}
@@ -975,10 +1338,15 @@ static size_t tail_make_groups(const pn2_tail_desc* d, tail_groups& G, int cap =
     return lds;
 }
 
+// 0 = row kernels, 1 = band kernels (one block per geometry group of <= 2 maps), 2 = all maps per block (default where the geometry allows)
+static int tail_mode() {
+    const char* e = getenv("PN2_TAIL_BAND");
+    return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 2;
+}
+
 // band kernels apply when a band of TRB output rows touches <= 3 low-res rows of every map; PN2_TAIL_BAND=0 keeps the row kernels
 static bool tail_band_ok(const pn2_tail_desc* d) {
-    const char* e = getenv("PN2_TAIL_BAND");
-    if ((e && e[0] == '0') || d->N > 65535) return false;
+    if (tail_mode() == 0 || d->N > 65535) return false;
     for (int j = 0; j < 2 * d->P; ++j) {
         const pn2_tail_map& m = d->maps[j];
         if (m.rh * (float)(TRB - 1) >= 0.999f || m.rw * 4.f >= 0.999f) return false;
@@ -1003,6 +1371,31 @@ static void tail_band_geometry(const pn2_tail_desc* d, const tail_groups& G, tai
     }
 }
 
+// the one-pass kernel: align_corners = 0, every map magnified by the same power of two >= 8 in both directions, pair p = (maps[p], maps[P + p]) of one
+// geometry, <= 4 rows per thread, maps of >= 5 pixels (tail_one_fin_k's image window)
+static bool tail_one_geometry(const pn2_tail_desc* d, tail_one_aux& A, int& threads, size_t& lds) {
+    if (tail_mode() != 2 || d->align_corners || d->OW > 512 || (long long)d->N * pn2_dsra_tail_blocks(d->OH) > 0x7fffffffLL) return false;
+    const int LV = d->OW >> 2;
+    int R = 1; while (R * 2 * LV <= 256 && R * 2 <= TRB) R <<= 1;
+    if (TRB / R > 4) return false;
+    A.R = R; threads = (R * LV + 63) & ~63;
+    A.nb = pn2_dsra_tail_blocks(d->OH);
+    A.ptot = 0; A.vtot = 0;
+    for (int p = 0; p < d->P; ++p) {
+        const pn2_tail_map& a = d->maps[p]; const pn2_tail_map& b = d->maps[d->P + p];
+        if (a.h != b.h || a.w != b.w || a.rh != b.rh || a.rw != b.rw || a.h * a.w < 5 || a.w > 63) return false;
+        const int mag = d->OW / a.w;
+        if (mag < 8 || (mag & (mag - 1)) || mag * a.w != d->OW || mag * a.h != d->OH || a.rw != 1.f / (float)mag || a.rh != 1.f / (float)mag) return false;
+        A.mag[p] = mag;
+        A.poff[p] = A.ptot; A.ptot += 18 * a.w;
+        A.wmagic[p] = (unsigned)((0x100000000ULL + (unsigned long long)a.w - 1) / (unsigned long long)a.w);
+    }
+    for (int j = 0; j < 2 * d->P; ++j) { A.voff[j] = A.vtot; A.vtot += 3 * (d->maps[j].w + 1); }
+    A.vtot = (A.vtot + 3) & ~3;
+    lds = ((size_t)A.vtot + (size_t)R * TNK * LV * 2) * 4;
+    return lds <= 60 * 1024;
+}
+
 int pn2_dsra_tail_scratch(const pn2_tail_desc* d) {
     if (tail_check(d) || !tail_band_ok(d)) return 0;
     long long ptot = 0;
@@ -1017,7 +1410,7 @@ int pn2_dsra_tail_fwd(const pn2_tail_desc* d, float* lat, const float* mask, con
     if (int rc = tail_check(d)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int nb = pn2_dsra_tail_blocks(d->OH);
-    bool band = tail_band_ok(d);
+    bool band = tail_mode() >= 1 && tail_band_ok(d);
     if (band) {
         tail_groups G; tail_band_aux A; int threads, blocks; size_t lds_f, lds_b;
         tail_make_groups(d, G, TBM);
@@ -1067,6 +1460,44 @@ int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* we
     const size_t lds = tail_make_groups(d, G);
     if (lds > 60 * 1024) return -2;
     hipLaunchKernelGGL(tail_bwd_k, dim3(G.start[G.ng]), dim3(256), lds, st, *d, G, mask, weit, wsum, sums, gscale);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_dsra_tail_fused_ok(const pn2_tail_desc* d) {
+    if (tail_check(d)) return 0;
+    tail_one_aux A; int threads; size_t lds;
+    return tail_one_geometry(d, A, threads, lds) && (long long)d->N * A.nb * A.ptot <= 0x7fffffffLL ? 1 : 0;
+}
+
+int pn2_dsra_tail_fused_scratch(const pn2_tail_desc* d) {
+    if (tail_check(d)) return 0;
+    tail_one_aux A; int threads; size_t lds;
+    if (!tail_one_geometry(d, A, threads, lds)) return 0;
+    const long long need = (long long)d->N * A.nb * A.ptot;
+    return need > 0x7fffffffLL ? 0 : (int)need;
+}
+
+int pn2_dsra_tail_fwd_bwd(const pn2_tail_desc* d, float* lat, const float* mask, const float* weit, float* partial, float* sums, float* wsum,
+                          float* per, float* loss, float gscale, float* scratch, long long scratch_floats, void* stream) {
+    if (!lat || !mask || !weit || !partial || !sums || !wsum || !per || !loss || !scratch) return -1;
+    if (int rc = tail_check(d)) return rc;
+    for (int j = 0; j < 2 * d->P; ++j) if (!d->maps[j].dsrc) return -1;
+    tail_one_aux A; int threads; size_t lds;
+    if (!tail_one_geometry(d, A, threads, lds)) return -2;
+    if (scratch_floats < (long long)d->N * A.nb * A.ptot) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(A.nb * d->N), blk(threads);
+    switch (d->P) {
+        case 1: hipLaunchKernelGGL(tail_one_k<1>, grid, blk, lds, st, *d, A, lat, mask, weit, partial, scratch); break;
+        case 2: hipLaunchKernelGGL(tail_one_k<2>, grid, blk, lds, st, *d, A, lat, mask, weit, partial, scratch); break;
+        case 3: hipLaunchKernelGGL(tail_one_k<3>, grid, blk, lds, st, *d, A, lat, mask, weit, partial, scratch); break;
+        default: hipLaunchKernelGGL(tail_one_k<4>, grid, blk, lds, st, *d, A, lat, mask, weit, partial, scratch); break;
+    }
+    int emax = 0;
+    for (int j = 0; j < 2 * d->P; ++j) emax = std::max(emax, d->N * d->maps[j].h * d->maps[j].w);
+    hipLaunchKernelGGL(tail_one_fin_k, dim3((emax + 255) / 256, 2 * d->P), dim3(256), 0, st, *d, A, scratch, partial, gscale, sums, wsum, per);
+    hipLaunchKernelGGL(loss_total_k, dim3(1), dim3(64), 0, st, per, d->P, d->N, loss);
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -62,6 +62,31 @@ def tail_forward(eng, tail, lat, P, mask, N, H, W):
     return loss, (weit, sums, wsum, d)
 
 
+def tail_forward_backward(eng, tail, lat, P, mask, N, H, W, gscale=1.0):
+    """Up-sampling + dual structure loss + their backward in ONE pass over the pixels (pn2_dsra_tail_fwd_bwd: the forward walk also leaves the gradient's
+    linear components, a small kernel applies the image-wide coefficients).  Returns loss[P+1], or None when the geometry is not served (the caller then
+    runs tail_forward + tail_backward)."""
+    d = tail_desc(eng, tail, P, N, H, W)
+    if not int(call.pn2_dsra_tail_fused_ok(C.byref(d))):
+        return None
+    for j in range(2 * P):
+        g, acc = tail[j][0].grad_sink()
+        d.maps[j].dsrc, d.maps[j].accumulate = g.data_ptr(), acc
+    HW = H * W
+    weit = eng.alloc((N, HW), torch.float32)
+    call.pn2_loss_weights(_p(mask), _p(weit), N, H, W, 31, _stream())
+    nb = call.pn2_dsra_tail_blocks(H)
+    partial = eng.alloc((P, N, nb, 5), torch.float32)
+    sums = eng.alloc((P, N, 4), torch.float32)
+    wsum = eng.alloc((N,), torch.float32)
+    per = eng.alloc((P, N), torch.float32)
+    loss = torch.empty((P + 1,), dtype=torch.float32, device=lat.device)
+    need = int(call.pn2_dsra_tail_fused_scratch(C.byref(d)))
+    scratch = eng.alloc((need,), torch.float32)
+    call.pn2_dsra_tail_fwd_bwd(C.byref(d), _p(lat), _p(mask), _p(weit), _p(partial), _p(sums), _p(wsum), _p(per), _p(loss), float(gscale), _p(scratch), need, _stream())
+    return loss
+
+
 def tail_backward(eng, tail, P, mask, saved, gscale=1.0):
     """Loss gradient + bilinear adjoint straight into the low-res maps' gradients (pn2_dsra_tail_bwd)."""
     weit, sums, wsum, d = saved

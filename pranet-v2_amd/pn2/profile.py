@@ -44,6 +44,11 @@ def _bytes(name, a):
             S = d.N * d.OH * d.OW * 4
             ACTUAL["tail"] = ACTUAL.get("tail", 0) + (S * (2 * d.P + 2) if name.endswith("fwd") else S * 2)   # what the kernels really move: fwd writes 2P maps +
             return S * (2 * d.P + 1) if name.endswith("fwd") else S * 2 * d.P                                  # reads mask, weit; bwd reads mask, weit only
+        if name == "pn2_dsra_tail_fwd_bwd":          # the two above in one call: 17*S per image at P = 4
+            d = a[0]._obj
+            S = d.N * d.OH * d.OW * 4
+            ACTUAL["tail"] = ACTUAL.get("tail", 0) + S * (2 * d.P + 4)
+            return S * (4 * d.P + 1)
         if name == "pn2_structure_loss_fwd":
             P, N, HW = a[2], a[9], a[10]
             return N * HW * 4 * (2 * P + 2)
@@ -293,7 +298,8 @@ def measure_step(trainer, x, m, dtype, config=None):
         roofline["wgrad"] = {"kernel": "pn2_conv_wgrad_multi (symbols conv_wgrad_tab<*>, conv_wgrad_dma_tab<*>)", "bound": "mfma",
                              "achieved": round(wfl / (wms * 1e-3) / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
                              "frac": round(wfl / (wms * 1e-3) / 1e12 / peak_tf, 4), "launches": wnl, "avg_launch_us": round(1e3 * wms / wnl, 2)}
-    names = ("pn2_dsra_tail_fwd", "pn2_dsra_tail_bwd") if "pn2_dsra_tail_fwd" in agg else ("pn2_structure_loss_fwd", "pn2_structure_loss_bwd")
+    names = (("pn2_dsra_tail_fwd_bwd",) if "pn2_dsra_tail_fwd_bwd" in agg else
+             ("pn2_dsra_tail_fwd", "pn2_dsra_tail_bwd") if "pn2_dsra_tail_fwd" in agg else ("pn2_structure_loss_fwd", "pn2_structure_loss_bwd"))
     tail = [agg[k] for k in names if k in agg]
     if tail:
         by = sum(t["bytes"] for t in tail); ms = sum(t["ms"] for t in tail)

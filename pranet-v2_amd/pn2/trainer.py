@@ -203,8 +203,10 @@ class Trainer:
         if eng.tail and not fused:
             raise RuntimeError("only some lateral maps were deferred to the fused DSRA tail")
         if fused:       # up-sampling + loss in one pass; the backward goes straight to the low-res maps
-            loss, saved = L.tail_forward(eng, eng.tail, lat, P, mask, N, H, W)
-            L.tail_backward(eng, eng.tail, P, mask, saved, 1.0)
+            loss = L.tail_forward_backward(eng, eng.tail, lat, P, mask, N, H, W) if os.environ.get("PN2_TAIL_FUSED_ENTRY", "1") == "1" else None
+            if loss is None:
+                loss, saved = L.tail_forward(eng, eng.tail, lat, P, mask, N, H, W)
+                L.tail_backward(eng, eng.tail, P, mask, saved, 1.0)
         else:
             loss, saved = L.loss_forward(lat, P, mask, N, HW, H, W)
             dlat = eng.alloc(lat.shape, lat.dtype)

@@ -902,6 +902,8 @@ def test_fused_dsra_tail_matches_unfused_path(monkeypatch):
 
 TAIL_GEOMS = [  # N, S, align_corners: the three training scales of a 96-pixel fixture, the 1.25x headline scale with align_corners, ragged last band
     (3, 96, 0), (2, 64, 1), (2, 128, 0), (2, 448, 1), (1, 352, 0), (2, 100, 0),
+    (1, 640, 0),        # OW > 512: not served by the one-pass kernel
+    (2, 256, 0), (2, 448, 0), (3, 352, 0),        # the 0.75x / 1.25x / 1x training scales: 4 / 2 / 2 row lanes, several images per finishing block
 ]
 
 
@@ -931,8 +933,9 @@ def test_dsra_tail_band_kernels_vs_oracle_and_row_kernels(cfg, monkeypatch):
     # the maps themselves are held to the reference's own fp32 index math (float64 source coordinates differ by ~55 * 2^-24 at 448 px, align_corners)
     ups32 = [F.interpolate(t[:, None], size=(S, S), mode="bilinear", align_corners=bool(ac)).reshape(N, S, S) for t in src_cpu]
     res = {}
-    for band in ("1", "0"):
-        monkeypatch.setenv("PN2_TAIL_BAND", band)
+    pow2 = ac == 0 and S % 32 == 0 and S <= 512 and S // 32 >= 1 and all(S // h in (8, 16, 32) for h in sizes)      # what the one-pass kernel serves
+    for band in ("F", "1", "0"):          # the one-pass entry (default in the trainer) / band kernels / row kernels of the two-call path
+        monkeypatch.setenv("PN2_TAIL_BAND", "2" if band == "F" else band)
         srcs = [t.to(dev) for t in src_cpu]
         base = [torch.randn_like(t) * float(ref_grads[j].abs().max()) for j, t in enumerate(srcs)]      # pre-existing gradient of the sinks that accumulate
         dsrcs = [base[j].clone() if j % 3 == 0 else torch.empty_like(t) for j, t in enumerate(srcs)]
@@ -950,21 +953,33 @@ def test_dsra_tail_band_kernels_vs_oracle_and_row_kernels(cfg, monkeypatch):
         lat = torch.empty(8, N, S, S, device=dev)
         partial = torch.empty(4, N, nb, 5, device=dev)
         sums, wsum, loss = torch.empty(4, N, 4, device=dev), torch.empty(N, device=dev), torch.empty(5, device=dev)
-        need = int(call.pn2_dsra_tail_scratch(C.byref(d)))
-        assert (need > 0) == (band == "1")
-        scratch = torch.empty(max(need, 1), device=dev)
-        call.pn2_dsra_tail_fwd(C.byref(d), P(lat), P(mask), P(weit), P(partial), P(sums), P(wsum), P(loss), st)
-        call.pn2_dsra_tail_bwd(C.byref(d), P(mask), P(weit), P(wsum), P(sums), 1.0, P(scratch) if need else None, need, st)
+        fused = int(call.pn2_dsra_tail_fused_ok(C.byref(d)))
+        assert fused == (1 if band == "F" and pow2 else 0), (band, fused, pow2)
+        if band == "F":
+            if not fused:
+                continue
+            need = int(call.pn2_dsra_tail_fused_scratch(C.byref(d)))
+            scratch, per = torch.empty(need, device=dev), torch.empty(4, N, device=dev)
+            call.pn2_dsra_tail_fwd_bwd(C.byref(d), P(lat), P(mask), P(weit), P(partial), P(sums), P(wsum), P(per), P(loss), 1.0, P(scratch), need, st)
+        else:
+            need = int(call.pn2_dsra_tail_scratch(C.byref(d)))
+            assert (need > 0) == (band == "1")
+            scratch = torch.empty(max(need, 1), device=dev)
+            call.pn2_dsra_tail_fwd(C.byref(d), P(lat), P(mask), P(weit), P(partial), P(sums), P(wsum), P(loss), st)
+            call.pn2_dsra_tail_bwd(C.byref(d), P(mask), P(weit), P(wsum), P(sums), 1.0, P(scratch) if need else None, need, st)
         torch.cuda.synchronize()
         for j in range(8):
             assert relmax(lat[j], ups32[j]) < 2e-6, (band, j)
         for j in range(4):
             assert abs(float(loss[j]) - float(ref_losses[j].detach())) < 5e-6 * abs(float(ref_losses[j].detach())), (band, j)
+        assert abs(float(loss[4]) - float(sum(ref_losses).detach())) < 5e-6 * abs(float(sum(ref_losses).detach()))
         for j in range(8):
             got = dsrcs[j] - base[j] if j % 3 == 0 else dsrcs[j]
-            assert relmax(got, ref_grads[j]) < 2e-4 and rell2(got, ref_grads[j]) < 2e-5, (band, j, relmax(got, ref_grads[j]))
-        res[band] = (lat.clone(),)
+            assert relmax(got, ref_grads[j]) < 2e-4 and rell2(got, ref_grads[j]) < 2e-5, (band, j, relmax(got, ref_grads[j]), rell2(got, ref_grads[j]))
+        res[band] = (lat.clone(), sums.clone(), wsum.clone())
     assert relmax(res["1"][0], res["0"][0]) < 1e-6
+    if "F" in res:      # the same maps and per-image sums as the two-call path (another summation order)
+        assert relmax(res["F"][0], res["1"][0]) < 1e-6 and relmax(res["F"][1], res["1"][1]) < 2e-6 and relmax(res["F"][2], res["1"][2]) < 2e-6
     # short / missing scratch: the backward falls back to the row kernels instead of failing
     monkeypatch.setenv("PN2_TAIL_BAND", "1")
     call.pn2_dsra_tail_bwd(C.byref(d), P(mask), P(weit), P(wsum), P(sums), 1.0, None, 0, st)

@@ -28,7 +28,8 @@ def timeit(fn, reps=50, cold=None):
 
 
 def run(N, S, ac, band):
-    os.environ["PN2_TAIL_BAND"] = "1" if band else "0"
+    """band: 0 row kernels, 1 band kernels (one block per group of <= 2 maps), 3 = the one-pass entry pn2_dsra_tail_fwd_bwd"""
+    os.environ["PN2_TAIL_BAND"] = str(band) if band < 2 else "2"
     dev = "cuda"
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -55,16 +56,30 @@ def run(N, S, ac, band):
     scratch = torch.empty(max(need, 1), device=dev)
     fwd = lambda: call.pn2_dsra_tail_fwd(C.byref(d), P(lat), P(mask), P(weit), P(partial), P(sums), P(wsum), P(loss), st)
     bwd = lambda: call.pn2_dsra_tail_bwd(C.byref(d), P(mask), P(weit), P(wsum), P(sums), 1.0, P(scratch) if need else None, need, st)
+    per = torch.empty(Pn, N, device=dev)
+    both = lambda: call.pn2_dsra_tail_fwd_bwd(C.byref(d), P(lat), P(mask), P(weit), P(partial), P(sums), P(wsum), P(per), P(loss), 1.0, P(scratch), need, st)
+    alg = 17 * N * S * S * 4
+    cold = torch.zeros(256 << 20, device=dev)
+    if band == 3:
+        assert int(call.pn2_dsra_tail_fused_ok(C.byref(d))) == 1
+        need = int(call.pn2_dsra_tail_fused_scratch(C.byref(d)))
+        scratch = torch.empty(need, device=dev)
+        for ds in dsrcs:
+            ds.fill_(0.25)
+        both()
+        torch.cuda.synchronize()
+        out = (lat.clone(), sums.clone(), loss.clone(), [x.clone() for x in dsrcs])
+        t, tc = timeit(both), timeit(both, cold=cold)
+        print(f"N={N} S={S} ac={ac} one-pass entry (3 launches): fwd+bwd {t:7.1f} us (cold {tc:7.1f})  -> {alg / t / 1e6:6.2f} TB/s algorithmic, cold {alg / tc / 1e6:6.2f} TB/s")
+        return out
     fwd()
     for ds in dsrcs:
         ds.fill_(0.25)
     bwd()
     torch.cuda.synchronize()
     out = (lat.clone(), sums.clone(), loss.clone(), [x.clone() for x in dsrcs])
-    cold = torch.zeros(256 << 20, device=dev)
     tf, tb = timeit(fwd), timeit(bwd)
     tfc, tbc = timeit(fwd, cold=cold), timeit(bwd, cold=cold)
-    alg = 17 * N * S * S * 4
     print(f"N={N} S={S} ac={ac} band={int(band)} scratch={need}: fwd {tf:7.1f} us  bwd {tb:7.1f} us (cold {tfc:7.1f} / {tbc:7.1f})  "
           f"-> {alg / (tf + tb) / 1e6:6.2f} TB/s algorithmic (17*S per image), cold {alg / (tfc + tbc) / 1e6:6.2f} TB/s")
     return out
@@ -78,8 +93,8 @@ if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 352
     ac = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    a = run(N, S, ac, False)
-    b = run(N, S, ac, True)
-    print("maps relmax", relmax(b[0], a[0]), "sums relmax", relmax(b[1], a[1]), "loss", a[2].tolist(), b[2].tolist())
-    for j, (x, y) in enumerate(zip(b[3], a[3])):
-        print(f"  dsrc[{j}] relmax {relmax(x, y):.3e}")
+    a = run(N, S, ac, 0)
+    for mode in (1, 3):
+        b = run(N, S, ac, mode)
+        print(f"mode {mode} vs row kernels: maps relmax", relmax(b[0], a[0]), "sums relmax", relmax(b[1], a[1]), "loss", a[2].tolist(), b[2].tolist(),
+              " dsrc relmax", max(relmax(x, y) for x, y in zip(b[3], a[3])))
