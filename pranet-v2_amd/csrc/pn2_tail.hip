@@ -786,7 +786,7 @@ struct tail_one_aux {
     int voff[PN2_TAIL_MAX_MAPS];            // float offset of map j's staged source rows ([3][w + 1]) in LDS
     int poff[PN2_TAIL_MAX_MAPS];            // pair p's block of the band partials: [6][3][w] floats
     int mag[PN2_TAIL_MAX_MAPS];             // pair p's magnification
-    unsigned wmagic[PN2_TAIL_MAX_MAPS];     // ceil(2^32 / w_p)
+    int shp[PN2_TAIL_MAX_MAPS];             // first pair of pair p's geometry: its Shw / Sc1 rows serve pair p too
     int ptot, vtot, R, nb;
 };
 
@@ -797,15 +797,46 @@ __device__ __forceinline__ void tail_z4(const float* raw, const float4 rt, int x
     z[0] = f2fma(lb[0], f2s(tv.y), la[0] * f2s(tv.x)); z[1] = f2fma(lb[1], f2s(tv.y), la[1] * f2s(tv.x));
 }
 // thread-local horizontal adjoint of a slot accumulator (4 columns): (sum lx0*a, sum lx1*a) -> the quad's left / right tap column
-__device__ __forceinline__ void tail_cc(float* cc, int k, const f2* acc, const f2* la, const f2* lb, bool rightmost) {
+__device__ __forceinline__ void tail_cc(float* cc, int k, const f2* acc, const f2* la, const f2* lb) {
     const f2 s0 = f2fma(la[1], acc[1], la[0] * acc[0]), s1 = f2fma(lb[1], acc[1], lb[0] * acc[0]);
-    float c0 = s0.x + s0.y, c1 = s1.x + s1.y;
-    if (rightmost) { c0 += c1; c1 = 0.f; }          // x0 = w - 1: the right tap is the same column
-    *reinterpret_cast<float2*>(cc + (size_t)k * 2) = make_float2(c0, c1);
+    *reinterpret_cast<float2*>(cc + (size_t)k * 2) = make_float2(s0.x + s0.y, s1.x + s1.y);
+}
+
+// horizontal gather of one pair (see tail_one_k): NQ = mag/4 quads per low-res column (3 NQ / 2 at column 0, which also owns the clamped left border), every
+// LDS read of a (row, row lane) requested before the first add - with run-time trip counts the loads and adds alternated, one LDS latency each
+template <int NQ>
+__device__ __forceinline__ void tail_gather(const float* cc, const int* sbt_p, int R, int RPT, int LV, int w, int mag, int nrows_, float* pbp) {
+    constexpr int NL = (3 * NQ) / 2;
+    int sh = 4; while ((1 << sh) < w) ++sh;          // lanes per row: power of two >= w (w <= 63)
+    const int ix = threadIdx.x & ((1 << sh) - 1), g0 = threadIdx.x >> sh, ng = blockDim.x >> sh;
+    if (ix >= w) return;
+    auto J = [&](int i) { return i <= 0 ? 0 : min(LV, (i * mag + (mag >> 1)) >> 2); };
+    const int jB = J(ix), jC = J(ix + 1), jA = ix >= 1 ? J(ix - 1) : jB;
+    const float rsel = ix == w - 1 ? 1.f : 0.f;          // column w - 1 also takes the right taps of its own quads (their x1 is clamped)
+    for (int cS = g0; cS < nrows_; cS += ng) {
+        const int c = (cS * 11) >> 5, S = cS - c * 3;
+        float acc = 0.f;
+        for (int rr = 0; rr < R; ++rr) {
+            const int s_ = S - sbt_p[rr * RPT];
+            if (s_ == 0 || s_ == 1) {
+                const float2* row = reinterpret_cast<const float2*>(cc + ((size_t)(rr * TNK + c * 2 + s_) * LV) * 2);
+                float2 eL[NL]; float eR[NL];
+#pragma unroll
+                for (int k = 0; k < NL; ++k) { const int j = jB + k; eL[k] = row[j < jC ? j : jB]; }
+#pragma unroll
+                for (int k = 0; k < NL; ++k) { const int j = jA + k; eR[k] = row[j < jB ? j : jA].y; }
+#pragma unroll
+                for (int k = 0; k < NL; ++k) acc += jB + k < jC ? fmaf(rsel, eL[k].y, eL[k].x) : 0.f;
+#pragma unroll
+                for (int k = 0; k < NL; ++k) acc += jA + k < jB ? eR[k] : 0.f;
+            }
+        }
+        pbp[cS * w + ix] = acc;
+    }
 }
 
 template <int P>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void tail_one_k(pn2_tail_desc d, tail_one_aux A, float* __restrict__ lat, const float* __restrict__ mask,
+__global__ __launch_bounds__(256) void tail_one_k(pn2_tail_desc d, tail_one_aux A, float* __restrict__ lat, const float* __restrict__ mask,
                                                                                             const float* __restrict__ weit, float* __restrict__ partial, float* __restrict__ pbuf) {
     extern __shared__ float lds[];          // raw[2P][3][w + 1] | cc[R][TNK][LV][2]
     __shared__ __attribute__((aligned(16))) float tab[P * TRB * 4];
@@ -896,11 +927,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void t
             x0 = xo[0];          // (= xo[1..3]: power-of-two magnification)
             la[0] = f2{l0[0], l0[1]}; la[1] = f2{l0[2], l0[3]}; lb[0] = f2{l1[0], l1[1]}; lb[1] = f2{l1[2], l1[3]};
         }
-        const bool rightmost = x0 == w - 1;
         const float* vf = lds + A.voff[p]; const float* vb = lds + A.voff[P + p];
         float* latf = lat + (size_t)p * d.N * img + base + jv * 4; float* latb = lat + (size_t)(P + p) * d.N * img + base + jv * 4;
         const float* tp = tab + p * TRB * 4; const float* wp_ = wst + p * TRB * 2;
-        if (live) {       // ---- the pair's map-independent rows: Shw, Sc1
+        if (live && A.shp[p] == p) {       // ---- the geometry's map-independent rows: Shw, Sc1 (once per geometry)
             f2 sh[2][2], sc[2][2];
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_) { sh[s_][0] = f2s(0.f); sh[s_][1] = f2s(0.f); sc[s_][0] = f2s(0.f); sc[s_][1] = f2s(0.f); }
@@ -914,8 +944,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void t
                         sc[0][h] = f2fma(ws0, qc[t][h], sc[0][h]); sc[1][h] = f2fma(ws1, qc[t][h], sc[1][h]);
                     }
                 }
-            tail_cc(ccme, 8 * LV, sh[0], la, lb, rightmost); tail_cc(ccme, 9 * LV, sh[1], la, lb, rightmost);
-            tail_cc(ccme, 10 * LV, sc[0], la, lb, rightmost); tail_cc(ccme, 11 * LV, sc[1], la, lb, rightmost);
+            tail_cc(ccme, 8 * LV, sh[0], la, lb); tail_cc(ccme, 9 * LV, sh[1], la, lb);
+            tail_cc(ccme, 10 * LV, sc[0], la, lb); tail_cc(ccme, 11 * LV, sc[1], la, lb);
         }
         {       // ---- fg map: logits, loss sums, X1 / X2 / X3
             f2 A0 = f2s(0.f), B1 = f2s(0.f), B2 = f2s(0.f);
@@ -947,9 +977,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void t
                 __builtin_amdgcn_sched_barrier(0);          // one row body at a time
             }
             if (live) {
-                tail_cc(ccme, 0, x1[0], la, lb, rightmost); tail_cc(ccme, LV, x1[1], la, lb, rightmost);
-                tail_cc(ccme, 2 * LV, x2[0], la, lb, rightmost); tail_cc(ccme, 3 * LV, x2[1], la, lb, rightmost);
-                tail_cc(ccme, 4 * LV, x3[0], la, lb, rightmost); tail_cc(ccme, 5 * LV, x3[1], la, lb, rightmost);
+                tail_cc(ccme, 0, x1[0], la, lb); tail_cc(ccme, LV, x1[1], la, lb);
+                tail_cc(ccme, 2 * LV, x2[0], la, lb); tail_cc(ccme, 3 * LV, x2[1], la, lb);
+                tail_cc(ccme, 4 * LV, x3[0], la, lb); tail_cc(ccme, 5 * LV, x3[1], la, lb);
             }
             const float a0 = row16_sum(A0.x + A0.y), b1 = row16_sum(B1.x + B1.y), b2 = row16_sum(B2.x + B2.y);
             if (rlead) { red[p * 4][rrow] = a0; red[p * 4 + 1][rrow] = b1; red[p * 4 + 2][rrow] = b2; }
@@ -978,30 +1008,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void t
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (live) { tail_cc(ccme, 6 * LV, y1[0], la, lb, rightmost); tail_cc(ccme, 7 * LV, y1[1], la, lb, rightmost); }
+            if (live) { tail_cc(ccme, 6 * LV, y1[0], la, lb); tail_cc(ccme, 7 * LV, y1[1], la, lb); }
             const float a3 = row16_sum(A3.x + A3.y);
             if (rlead) red[p * 4 + 3][rrow] = a3;
         }
         __syncthreads();
-        // ---- the quads behind low-res column ix: left taps from quads [J(ix), J(ix+1)), right taps from [J(ix-1), J(ix)), J(i) = (i*mag + mag/2)/4;
-        //      row lane rl's slot s belongs to the band's low-res row sbt[first row of rl] + s.  One thread per (comp, band row, column), fixed order.
+        // ---- the quads behind low-res column ix: left taps from quads [J(ix), J(ix+1)), right taps from [J(ix-1), J(ix)) (column w - 1 also takes the right
+        //      taps of its own quads: their x1 is clamped), J(i) = (i*mag + mag/2)/4; row lane rl's slot s belongs to the band's low-res row
+        //      sbt[first row of rl] + s.  A thread keeps its column and walks rows (comp, band row) of the 18 (12: Shw / Sc1 come from an earlier pair); fixed order.
         {
-            const int mag = A.mag[p], total = 18 * w;
-            for (int o = threadIdx.x; o < total; o += blockDim.x) {
-                const int cS = (int)__umulhi((unsigned)o, A.wmagic[p]), ix = o - cS * w, c = cS / 3, S = cS - c * 3;
-                auto J = [&](int i) { return i <= 0 ? 0 : min(LV, (i * mag + (mag >> 1)) >> 2); };
-                const int jB = J(ix), jC = J(ix + 1), jA = ix >= 1 ? J(ix - 1) : jB;
-                float acc = 0.f;
-                for (int rr = 0; rr < R; ++rr) {
-                    const int s_ = S - sbt[p * TRB + rr * RPT];
-                    if (s_ == 0 || s_ == 1) {
-                        const float* row = cc + ((size_t)(rr * TNK + c * 2 + s_) * LV) * 2;
-                        for (int j = jB; j < jC; ++j) acc += row[j * 2];
-                        for (int j = jA; j < jB; ++j) acc += row[j * 2 + 1];
-                    }
-                }
-                pb[A.poff[p] + cS * w + ix] = acc;
-            }
+            const int mag = A.mag[p], nrows_ = A.shp[p] == p ? 18 : 12;
+            if (mag == 8) tail_gather<2>(cc, sbt + p * TRB, R, RPT, LV, w, mag, nrows_, pb + A.poff[p]);
+            else if (mag == 16) tail_gather<4>(cc, sbt + p * TRB, R, RPT, LV, w, mag, nrows_, pb + A.poff[p]);
+            else tail_gather<8>(cc, sbt + p * TRB, R, RPT, LV, w, mag, nrows_, pb + A.poff[p]);
         }
         __syncthreads();          // cc is rewritten by the next pair
     }
@@ -1032,6 +1051,27 @@ __global__ __launch_bounds__(256) void tail_one_fin_k(pn2_tail_desc d, tail_one_
     const int first = blockIdx.x * 256;
     if (first >= total) return;
     const int last = min(first + 255, total - 1), n0 = first / hw_, n1 = last / hw_, ni = n1 - n0 + 1;
+    // the pixel's band partials first: their loads are in flight while the image sums below are formed (one memory latency instead of two in a row)
+    const int local = min(first + (int)threadIdx.x, total - 1);
+    const int n = local / hw_, rem = local - n * hw_, y = rem / w, x = rem - y * w;
+    float t1 = 0.f, t2 = 0.f, t3 = 0.f, th = 0.f, tc = 0.f;
+    {
+        int oy0, oy1;
+        bl_range(y, mp.rh, 0, d.OH, oy0, oy1);
+        for (int b = oy0 / TRB; b <= oy1 / TRB; ++b) {
+            const int oyA = b * TRB, oyB = min(oyA + TRB - 1, d.OH - 1);
+            int ylo, yhi, t; float u0, u1;
+            bl_src(oyA, mp.rh, 0, h, ylo, t, u0, u1);
+            bl_src(oyB, mp.rh, 0, h, t, yhi, u0, u1);
+            if (y >= ylo && y <= yhi) {
+                const float* bq = pbuf + ((size_t)n * nb + b) * A.ptot + (y - ylo) * w + x;
+                const float* q = bq + A.poff[p]; const float* qs = bq + A.poff[A.shp[p]];          // [comp][3][w]; Shw / Sc1 of the geometry's first pair
+                const int cs = 3 * w;
+                if (j < P) { t1 += q[0]; t2 += q[cs]; t3 += q[2 * cs]; th += qs[4 * cs]; } else t1 += q[3 * cs];
+                tc += qs[5 * cs];
+            }
+        }
+    }
     {
         const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
         for (int c = grp; c < 5 * ni; c += 16) {
@@ -1051,38 +1091,21 @@ __global__ __launch_bounds__(256) void tail_one_fin_k(pn2_tail_desc d, tail_one_
     }
     __syncthreads();
     if (j < P && (int)threadIdx.x < ni) {          // the image's first pixel lies in this block: its sums, wsum and loss term (as loss_finalize_k)
-        const int n = n0 + threadIdx.x;
-        if (n * hw_ >= first) {
+        const int ni_ = n0 + threadIdx.x;
+        if (ni_ * hw_ >= first) {
             const double* a = s_d + threadIdx.x * 5;
-            float* so = sums_out + ((size_t)p * d.N + n) * 4;
+            float* so = sums_out + ((size_t)p * d.N + ni_) * 4;
             so[0] = (float)a[0]; so[1] = (float)a[1]; so[2] = (float)a[2]; so[3] = (float)a[3];
-            if (p == 0) wsum_out[n] = (float)a[4];
+            if (p == 0) wsum_out[ni_] = (float)a[4];
             const float wbce = (float)(a[0] / a[4]), wbce2 = (float)(a[1] / a[4]);
             const float wiou = 1.f - ((float)a[2] + 1.f) / ((float)a[3] - (float)a[2] + 1.f);
-            per[(size_t)p * d.N + n] = wbce + wiou + 0.8f * wbce2;
+            per[(size_t)p * d.N + ni_] = wbce + wiou + 0.8f * wbce2;
         }
     }
-    const int local = first + threadIdx.x;
-    if (local >= total) return;
-    const int n = local / hw_, rem = local - n * hw_, y = rem / w, x = rem - y * w;
+    if (first + (int)threadIdx.x >= total) return;
     const double* a = s_d + (n - n0) * 5;
     const float gs_ = gscale / (float)d.N, I = (float)a[2], U = (float)a[3], D = U - I + 1.f;
     const float gw = gs_ / (float)a[4], cA = gs_ * (I + 1.f) / (D * D), cB = gs_ / D;
-    int oy0, oy1;
-    bl_range(y, mp.rh, 0, d.OH, oy0, oy1);
-    float t1 = 0.f, t2 = 0.f, t3 = 0.f, th = 0.f, tc = 0.f;
-    for (int b = oy0 / TRB; b <= oy1 / TRB; ++b) {
-        const int oyA = b * TRB, oyB = min(oyA + TRB - 1, d.OH - 1);
-        int ylo, yhi, t; float u0, u1;
-        bl_src(oyA, mp.rh, 0, h, ylo, t, u0, u1);
-        bl_src(oyB, mp.rh, 0, h, t, yhi, u0, u1);
-        if (y >= ylo && y <= yhi) {
-            const float* q = pbuf + ((size_t)n * nb + b) * A.ptot + A.poff[p] + (y - ylo) * w + x;          // [comp][3][w]
-            const int cs = 3 * w;
-            if (j < P) { t1 += q[0]; t2 += q[cs]; t3 += q[2 * cs]; th += q[4 * cs]; } else t1 += q[3 * cs];
-            tc += q[5 * cs];
-        }
-    }
     const float g = j < P ? gw * (2.f * t1 + tc) + cA * (0.5f * th - 2.f * t2) - (cA + cB) * (0.25f * (th - tc) - t2 + t3)
                           : 0.8f * gw * (2.f * t1 - tc);
     float* dst = mp.dsrc + local;
@@ -1385,10 +1408,11 @@ static bool tail_one_geometry(const pn2_tail_desc* d, tail_one_aux& A, int& thre
         const pn2_tail_map& a = d->maps[p]; const pn2_tail_map& b = d->maps[d->P + p];
         if (a.h != b.h || a.w != b.w || a.rh != b.rh || a.rw != b.rw || a.h * a.w < 5 || a.w > 63) return false;
         const int mag = d->OW / a.w;
-        if (mag < 8 || (mag & (mag - 1)) || mag * a.w != d->OW || mag * a.h != d->OH || a.rw != 1.f / (float)mag || a.rh != 1.f / (float)mag) return false;
+        if (mag < 8 || mag > 32 || (mag & (mag - 1)) || mag * a.w != d->OW || mag * a.h != d->OH || a.rw != 1.f / (float)mag || a.rh != 1.f / (float)mag) return false;
         A.mag[p] = mag;
+        A.shp[p] = p;
+        for (int q = p - 1; q >= 0; --q) if (d->maps[q].w == a.w && d->maps[q].h == a.h) A.shp[p] = q;
         A.poff[p] = A.ptot; A.ptot += 18 * a.w;
-        A.wmagic[p] = (unsigned)((0x100000000ULL + (unsigned long long)a.w - 1) / (unsigned long long)a.w);
     }
     for (int j = 0; j < 2 * d->P; ++j) { A.voff[j] = A.vtot; A.vtot += 3 * (d->maps[j].w + 1); }
     A.vtot = (A.vtot + 3) & ~3;
