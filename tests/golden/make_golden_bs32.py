@@ -10,7 +10,7 @@ Two weight sets (oracle.weights.make_state_dict, seed 0): "cond" = bn3 gamma x 0
 checkpoint: the carrier of north_star's literal 1e-4, see make_golden_cond.py) and "rand" = the plain default init bench.py runs on (chaotic: relative
 gates only).  Three runs of the SAME reference classes per set: fp32, float64, and fp32 modules under torch.autocast("cpu", bfloat16) - the bf16 yardstick.
 
-Stored per set: the 8 logit maps at stride 16 (fp32 run: every image; float64 run: rounded to fp32, every image for cond / every second image for rand),
+Stored per set: the 8 logit maps at stride 16 (fp32 run, and the float64 run rounded to fp32: every image for cond / every second image for rand),
 the reference's own max |fp32 - float64| per map over the FULL maps, the 4 pair losses of every run, the 38 gradient probes (first 256 elements; fp32 and
 float64), torch-autocast's rel-L2 per map / per probe / losses against float64 (full tensors), and the heads of every BatchNorm running_mean /
 running_var after the step (fp32 run).
@@ -93,13 +93,13 @@ def assemble():
             print(f"{which}: fp32 / float64 runs missing, set skipped")
             continue
         r32, r64 = run(which, "f32"), run(which, "f64")
-        step = 1 if which == "cond" else 2                      # images of the float64 maps that are stored
-        out[f"{which}.f64_image_step"] = np.array(step)
+        step = 1 if which == "cond" else 2                      # images of the maps that are stored (fp32 and float64 runs alike)
+        out[f"{which}.image_step"] = np.array(step)
         out[f"{which}.losses"] = np.array(r32["losses"]); out[f"{which}.f64.losses"] = np.array(r64["losses"])
         out[f"{which}.nograd"] = np.array(r32["nograd"])
         own = []
         for i in range(8):
-            out[f"{which}.out{i}"] = npy(r32["outs"][i][:, :, ::STRIDE, ::STRIDE])
+            out[f"{which}.out{i}"] = npy(r32["outs"][i][::step, :, ::STRIDE, ::STRIDE])
             out[f"{which}.f64.out{i}"] = npy(r64["outs"][i][::step, :, ::STRIDE, ::STRIDE]).astype(np.float32)
             own.append(float((r32["outs"][i].double() - r64["outs"][i]).abs().max()))
         out[f"{which}.own_abs"] = np.array(own)

@@ -1,0 +1,148 @@
+"""The BENCHMARKED object against the reference itself: `Trainer.capture()` / `replay()` at 32 x 3 x 352 x 352 - exactly what bench.py times - compared with
+the imported reference's train step at that batch (tests/golden/pranet_v2_bs32.npz, written by tests/golden/make_golden_bs32.py from /root/reference:
+MyTrain_med.py:59-86 in fp32, float64 and under torch.autocast(bfloat16)).
+
+  cond (bn3 gamma x 0.05, the regime of a trained checkpoint; the reference agrees with its own float64 run to 3.4e-5 at this batch):
+      fp32 path: north_star's literal |logit - reference fp32 logit| <= 1e-4 (and <= 1e-4 against the float64 run), losses 1e-5, BatchNorm running statistics
+                 after the first step 1e-5, gradient probes no worse than the reference's own fp32 gradients in the median;
+      bf16 path (the headline precision): every map within 1.3 x torch-autocast's own distance to float64, losses / probes within 1.25 x.
+  rand (the default init bench.py runs on; chaotic - the reference's own fp32 logits sit 2.5e-3 from its float64 logits): relative gates as in test_gpu_parity.py.
+
+lr = 0 keeps the weights at the fixture's through the eager warm-up steps capture() needs, so the REPLAYED step is the reference's step; clip=None leaves
+the raw gradients in the arena (clamp + Adam are pinned by test_trainer_two_steps_and_eval_tail_vs_reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("PN2_NO_PRETRAINED", "1")
+dev = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pn2
+    pn2.load_library()      # fails loudly if the HIP extension is missing
+    yield
+    pn2.set_compute_dtype("bf16")
+
+
+@pytest.fixture(scope="module")
+def z():
+    return np.load(os.path.join(G, "pranet_v2_bs32.npz"))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rell2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _replayed_step(z, which, fp32):
+    """-> (trainer, maps [8][N][H][W] on the CPU, losses[4], BatchNorm buffers after the FIRST step): one eager step, capture, one replay."""
+    import pn2
+    from pn2.trainer import Trainer
+    from lib.pranet import PraNet_V2
+    from oracle import weights as W
+    pn2.set_compute_dtype("fp32" if fp32 else "bf16")
+    n, size = int(z["n"]), int(z["size"])
+    sd = W.make_state_dict(W.manifest_pranet_v2(1), seed=0, bn3_gamma=float(z["bn3_gamma"]) if which == "cond" else None)
+    model = PraNet_V2(num_class=1)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    x, mask = W.synthetic_batch(n, size, seed=int(z["seed"]))
+    x, mask = x.to(dev), mask.to(dev)
+    tr = Trainer(model, lr=0.0, clip=None)
+    tr.step(x, mask)
+    torch.cuda.synchronize()
+    bufs = {k: v.detach().float().cpu().reshape(-1)[:32].clone() for k, v in model.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    tr.capture(x, mask, warmup=1)
+    loss = tr.replay()
+    torch.cuda.synchronize()
+    maps = tr.last_outs.reshape(8, n, size, size).float().cpu()
+    return tr, model, maps, [float(v) for v in loss[:4].cpu()], bufs
+
+
+def _probes(z, which, tr, model):
+    named = dict(model.named_parameters())
+    keys = [f[len(which) + 6:] for f in z.files if f.startswith(f"{which}.graw.")]
+    ours = np.array([rell2(tr._grad_view(named[k]).reshape(-1)[:256], T(z[f"{which}.f64.graw." + k])) for k in keys])
+    own = np.array([rell2(T(z[f"{which}.graw." + k]), T(z[f"{which}.f64.graw." + k])) for k in keys])
+    return keys, ours, own
+
+
+def test_bs32_replayed_step_fp32_literal_tolerance(z):
+    which = "cond"
+    tr, model, maps, losses, bufs = _replayed_step(z, which, True)
+    st, step = int(z["stride"]), int(z[f"{which}.image_step"])
+    e32 = [float((maps[i][::step, ::st, ::st] - T(z[f"{which}.out{i}"])[:, 0]).abs().max()) for i in range(8)]
+    e64 = [float((maps[i][::step, ::st, ::st] - T(z[f"{which}.f64.out{i}"])[:, 0]).abs().max()) for i in range(8)]
+    print(f"[bs32 cond fp32, hipGraph replay] max |logit - ref fp32| {max(e32):.2e}   max |logit - ref f64| {max(e64):.2e}   (reference fp32 vs its f64: {float(z[which + '.own_abs'].max()):.2e})")
+    assert max(e32) <= 1e-4, e32
+    assert max(e64) <= 1e-4, e64
+    assert np.abs(np.array(losses) - z[f"{which}.losses"]).max() < 1e-5, (losses, z[f"{which}.losses"])
+    worst = max(float((bufs[k] - T(z[f"{which}.buf." + k])).abs().max()) for k in bufs)
+    assert worst <= 1e-5, worst          # running statistics after ONE step of the reference (momentum 0.1)
+    keys, ours, own = _probes(z, which, tr, model)
+    print(f"[bs32 cond fp32] gradient probes rel-L2 vs f64: median {np.median(ours):.2e} (reference fp32: {np.median(own):.2e}), worst {ours.max():.2e} at {keys[int(ours.argmax())]} "
+          f"(reference's worst {own.max():.2e})")
+    assert float(np.median(ours)) <= max(2e-6, float(np.median(own)))
+    assert float(ours.max()) <= 2e-2, keys[int(ours.argmax())]
+
+
+def test_bs32_replayed_step_bf16_vs_torch_bf16_yardstick(z):
+    which = "cond"
+    tr, model, maps, losses, _ = _replayed_step(z, which, False)
+    st, step = int(z["stride"]), int(z[f"{which}.image_step"])
+    ours = [rell2(maps[i][::step, ::st, ::st], T(z[f"{which}.f64.out{i}"])[:, 0]) for i in range(8)]
+    tb = [float(v) for v in z[f"{which}.bf16.rel"]]
+    print(f"[bs32 cond bf16, hipGraph replay] rel-L2 per map: ours {[f'{e:.3f}' for e in ours]}   torch-autocast {[f'{e:.3f}' for e in tb]}")
+    for e, t in zip(ours, tb):
+        assert e <= 1.3 * t, (ours, tb)
+    l64 = z[f"{which}.f64.losses"]
+    lerr, terr = np.abs(np.array(losses) - l64) / l64, np.abs(z[f"{which}.bf16.losses"] - l64) / l64
+    print(f"[bs32 cond bf16] rel loss error: ours {[f'{e:.1e}' for e in lerr]}   torch-autocast {[f'{e:.1e}' for e in terr]}")
+    assert float(lerr.max()) <= max(3e-3, 1.25 * float(terr.max())), (lerr, terr)
+    keys, g_ours, _ = _probes(z, which, tr, model)
+    g_tb = z[f"{which}.bf16.grel"]
+    print(f"[bs32 cond bf16] gradient probes rel-L2 vs f64: ours median {np.median(g_ours):.3f} max {g_ours.max():.3f}   torch-autocast median {np.median(g_tb):.3f} max {g_tb.max():.3f}")
+    assert float(np.median(g_ours)) <= 1.25 * float(np.median(g_tb))
+    assert float(g_ours.max()) <= 1.25 * float(g_tb.max())
+
+
+@pytest.mark.parametrize("fp32", [True, False])
+def test_bs32_replayed_step_random_init(z, fp32):
+    """The weights bench.py runs on.  fp32: closer to the float64 run than 0.6 x the reference's own fp32 run (floor 1e-4), as test_gpu_parity.py; bf16: every map
+    within 1.5 x torch-autocast's distance (0.18 .. 1.0 relative L2: both are noise on the deeper maps, the gate only catches a broken kernel)."""
+    which = "rand"
+    tr, model, maps, losses, _ = _replayed_step(z, which, fp32)
+    st, step = int(z["stride"]), int(z[f"{which}.image_step"])
+    if fp32:
+        own = z[f"{which}.own_abs"]
+        e64 = [float((maps[i][::step, ::st, ::st] - T(z[f"{which}.f64.out{i}"])[:, 0]).abs().max()) for i in range(8)]
+        print(f"[bs32 rand fp32] max |logit - ref f64| per map {[f'{e:.1e}' for e in e64]}   reference fp32 vs its f64 {[f'{e:.1e}' for e in own]}")
+        for e, o in zip(e64, own):
+            assert e <= max(1e-4, 0.6 * float(o)), (e64, own)
+        l64 = z[f"{which}.f64.losses"]
+        assert np.abs(np.array(losses) - l64).max() <= max(1e-4, 0.6 * float(np.abs(z[f"{which}.losses"] - l64).max()))
+        keys, ours, own_g = _probes(z, which, tr, model)
+        print(f"[bs32 rand fp32] gradient probes: median ratio to the reference's own fp32 error {np.median(ours / np.maximum(own_g, 1e-12)):.2f}, worst ratio {np.max(ours / np.maximum(own_g, 2e-6)):.2f}")
+        assert float(np.median(ours)) <= 0.8 * float(np.median(own_g)) or float(np.median(ours)) <= 2e-6
+    else:
+        ours = [rell2(maps[i][::step, ::st, ::st], T(z[f"{which}.f64.out{i}"])[:, 0]) for i in range(8)]
+        tb = [float(v) for v in z[f"{which}.bf16.rel"]]
+        print(f"[bs32 rand bf16] rel-L2 per map: ours {[f'{e:.3f}' for e in ours]}   torch-autocast {[f'{e:.3f}' for e in tb]}")
+        for e, t in zip(ours, tb):
+            assert e <= 1.5 * t, (ours, tb)
+        l64 = z[f"{which}.f64.losses"]
+        lerr, terr = np.abs(np.array(losses) - l64) / l64, np.abs(z[f"{which}.bf16.losses"] - l64) / l64
+        assert float(lerr.max()) <= max(1e-2, 2.0 * float(terr.max())), (lerr, terr)
