@@ -457,6 +457,17 @@ int pn2_eval_tail(const float* res, unsigned char* out, float* minmax /* scratch
  * uint8 prediction value, hist[256..511] = the same restricted to gt > 0.5 (integer atomics: deterministic).  All 256-threshold
  * metrics of Fmeasure_calu (eval_functions.py:131-166) and the MAE follow from these counts (pn2/evaltail.py).                    */
 int pn2_eval_hist(const unsigned char* pred_u8, const float* gt, long long n, unsigned* hist, void* stream);
+/* The remaining metrics of eval_for_testAllInOne (binary_seg/eval.py:18-66), finished on the host in float64 with the reference's expressions (pn2/evaltail.py):
+ * Sm (StructureMeasure, utils/eval_functions.py:5-94): out25[0..2] = sum of rows, sum of columns, count of the foreground (gt > 0.5) pixels; out25[3 + q*5 ..] =
+ *   {pixels, sum k, sum k^2, sum g, sum k*g} of centroid quadrant q = (row >= X) + 2*(col >= Y) (k = prediction byte, g in {0,1}); out25[23], [24] = X, Y.
+ *   All integers: exact.  S_Object comes from the pn2_eval_hist histograms.
+ * wFm (original_WFb, :96-129): exact Euclidean feature transform with scipy.ndimage.distance_transform_edt's order of preference among equidistant pixels,
+ *   7x7 Gaussian (K49, row-major, computed by the caller as fspecial_gauss(7, 5)) of the propagated error with edge replication, c5 = log(0.5)/5;
+ *   part[pn2_eval_wfm_blocks(H, W)][2] = per-block sums of Ew over the foreground / background (fixed order).  work_i: H*W ints, work_d: 2*H*W doubles.
+ * meanEm (EnhancedMeasure, :168-192) needs no kernel: per threshold it is a function of the pn2_eval_hist histograms. */
+int pn2_eval_region_sums(const unsigned char* pred_u8, const float* gt, int H, int W, unsigned long long* out25, void* stream);
+int pn2_eval_wfm_blocks(int H, int W);
+int pn2_eval_wfm(const unsigned char* pred_u8, const float* gt, int H, int W, const double* K49, double c5, int* work_i, double* work_d, double* part, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- input transform
  * binary_seg/utils/dataloader.py:104-111 (PolypDataset) / :176-181 (test_dataset): transforms.Resize((S, S)) on the decoded PIL image

@@ -391,3 +391,136 @@ def threshold_metrics(pred_u8, gt):
 
 def clone_sd(sd):
     return OrderedDict((k, v.clone()) for k, v in sd.items())
+
+
+# ---------------------------------------------------------------------------------------------- the remaining metrics of eval_for_testAllInOne
+# (binary_seg/eval.py:18-66: Sm = StructureMeasure, wFm = original_WFb, meanEm = mean over the 256 thresholds of EnhancedMeasure;
+#  utils/eval_functions.py:5-129,168-192).  numpy restatement; the only third-party arithmetic the reference uses here is scipy.ndimage's exact Euclidean
+#  feature transform (distance_transform_edt(return_indices=True)) and its `convolve(mode='nearest')`: both are restated below (edt_nearest / conv_nearest)
+#  and pinned against scipy itself in tests/test_oracle_golden.py, tie-breaking included.
+def edt_nearest(fg):
+    """For every pixel the nearest pixel with fg != 0 (Euclidean), as scipy.ndimage.distance_transform_edt(1 - fg, return_indices=True) returns it - ties
+    included: scipy runs Maurer's Voronoi sweep along axis 0 and then along axis 1 and keeps the EARLIER site while the next one is not strictly closer, i.e.
+    (1) in a column the nearest fg row, the smaller row on a tie; (2) over the columns' candidates (r(i, j'), j') the smallest squared distance, the smaller
+    column on a tie.  Returns (dist float64 [H, W], ri int [H, W], rj int [H, W]); a map without any fg pixel gives dist = inf... scipy's answer for that case
+    is never used by the reference (StructureMeasure / original_WFb are only meaningful with a non-empty gt; eval.py calls them anyway: see full_metrics)."""
+    import numpy as np
+    fg = np.asarray(fg) != 0
+    H, W = fg.shape
+    big = 1 << 40
+    rows = np.arange(H)
+    rcol = np.full((H, W), -1, dtype=np.int64)          # nearest fg row of every (i, j) within column j
+    for j in range(W):
+        sites = rows[fg[:, j]]
+        if sites.size:
+            d = np.abs(rows[:, None] - sites[None, :])
+            rcol[:, j] = sites[np.argmin(d, axis=1)]     # argmin takes the first (= smaller row) of equal distances
+    dist2 = np.full((H, W), big, dtype=np.int64)
+    ri = np.zeros((H, W), dtype=np.int64); rj = np.zeros((H, W), dtype=np.int64)
+    cols = np.arange(W)
+    for i in range(H):
+        r = rcol[i]                                      # candidate row per column
+        ok = r >= 0
+        if not ok.any():
+            continue
+        dv = np.where(ok, (r - i) ** 2, big)             # [W]
+        d = dv[None, :] + (cols[None, :] - cols[:, None]) ** 2          # [j, j']
+        k = np.argmin(d, axis=1)                         # first (= smaller column) of equal distances
+        dist2[i] = d[cols, k]; ri[i] = r[k]; rj[i] = k
+    return np.sqrt(dist2.astype(np.float64)), ri, rj
+
+
+def conv_nearest(x, k):
+    """scipy.ndimage.convolve(x, k, mode='nearest') for an odd square kernel: out[i, j] = sum_{a, b} k[a, b] * x[clamp(i + c - a), clamp(j + c - b)]
+    (convolution = correlation with the flipped kernel; borders replicate the edge pixel), accumulated in float64 in scipy's order (footprint row-major)."""
+    import numpy as np
+    K = k.shape[0]; c = K // 2
+    xp = np.pad(x, c, mode="edge")
+    H, W = x.shape
+    out = np.zeros((H, W), dtype=np.float64)
+    kf = k[::-1, ::-1]
+    for a in range(K):
+        for b in range(K):
+            out += kf[a, b] * xp[a:a + H, b:b + W]
+    return out
+
+
+def full_metrics(pred_u8, gt):
+    """eval_for_testAllInOne(opt, pred, gt) for opt["metrics"] = every name eval.py:52-60 defines that is not commented out:
+    -> dict(meanDic, meanIoU, meanEm, mae, Sm, wFm) + the threshold curve of EnhancedMeasure ("E")."""
+    import numpy as np
+    eps = np.finfo(np.float64).eps
+    pred = pred_u8.astype(np.float64) / 255                       # eval.py:28
+    g = (np.asarray(gt) > 0.5).astype(np.float64)                 # :26
+    cols, mae = threshold_metrics(pred_u8, gt)
+    # ---- EnhancedMeasure per threshold (eval_functions.py:168-192)
+    E = np.zeros(256)
+    for i, t in enumerate(np.linspace(1, 0, 256)):
+        b = (pred >= t).astype(np.float64)
+        if g.sum() == 0:
+            em = 1 - b
+        elif (1 - g).sum() == 0:
+            em = b.copy()
+        else:
+            ap, ag = b - b.mean(), g - g.mean()
+            al = 2 * (ag * ap) / (ag ** 2 + ap ** 2 + eps)
+            em = ((al + 1) ** 2) / 4
+        E[i] = em.sum() / (g.size - 1 + eps)
+    # ---- StructureMeasure (eval_functions.py:5-94)
+    y = g.mean()
+    if y == 0:
+        sm = 1 - pred.mean()
+    elif y == 1:
+        sm = pred.mean()
+    else:
+        def obj(p, m):
+            x = p[m == 1].mean(); s = p[m == 1].std()
+            return 2.0 * x / (x ** 2 + 1 + s + eps)
+        pf = pred.copy(); pf[g != 1] = 0.0
+        pb = 1 - pred; pb[g == 1] = 0.0
+        u = g.mean()
+        s_obj = u * obj(pf, g) + (1 - u) * obj(pb, 1 - g)
+        if g.sum() == 0:
+            cx, cy = g.shape[0] // 2, g.shape[1] // 2
+        else:
+            xs, ys = np.where(g == 1)
+            cx, cy = int(xs.mean().round()), int(ys.mean().round())
+
+        def ssim(p, m):
+            if p.size == 0:                                       # an empty quadrant: numpy's mean of an empty slice is nan -> the reference returns nan * 0-weight
+                return np.nan
+            x, yy, n = p.mean(), m.mean(), p.size
+            sx = ((p - x) ** 2 / (n - 1 + eps)).sum(); sy = ((m - yy) ** 2 / (n - 1 + eps)).sum()
+            sxy = ((p - x) * (m - yy) / (n - 1 + eps)).sum()
+            al, be = 4 * x * yy * sxy, (x ** 2 + yy ** 2) * (sx + sy)
+            return al / (be + eps) if al != 0 else (1 if be == 0 else 0)
+        quads = [(slice(None, cx), slice(None, cy)), (slice(cx, None), slice(None, cy)), (slice(None, cx), slice(cy, None)), (slice(cx, None), slice(cy, None))]
+        s_reg = 0.0
+        for a, b_ in quads:
+            wq = g[a, b_].size / g.size
+            s_reg = s_reg + ssim(pred[a, b_], g[a, b_]) * wq
+        sm = 0.5 * s_obj + 0.5 * s_reg
+        if sm < 0:
+            sm = 0
+    # ---- original_WFb (eval_functions.py:96-129)
+    Eabs = np.abs(pred - g)
+    if g.sum() == 0:
+        wfm = float("nan")          # scipy's feature transform of an all-background map returns out-of-range indices; the reference's value is undefined there
+    else:
+        dst, ri, rj = edt_nearest(g)
+        xk, yk = np.mgrid[-7 // 2 + 1:7 // 2 + 1, -7 // 2 + 1:7 // 2 + 1]
+        K = np.exp(-((xk ** 2 + yk ** 2) / (2.0 * 5 ** 2))); K = K / K.sum()
+        Et = Eabs.copy()
+        Et[g != 1] = Eabs[ri[g != 1], rj[g != 1]]
+        EA = conv_nearest(Et, K)
+        mn = Eabs.copy()
+        sel = (g == 1) & (EA < Eabs)
+        mn[sel] = EA[sel]
+        B = np.ones_like(g)
+        B[g != 1] = 2.0 - 1 * np.exp(np.log(1 - 0.5) / 5 * dst[g != 1])
+        Ew = mn * B
+        TPw = g.sum() - Ew[g == 1].sum(); FPw = Ew[g != 1].sum()
+        R = 1 - Ew[g == 1].mean(); Pq = TPw / (TPw + FPw + eps)
+        wfm = 2 * R * Pq / (R + Pq + eps)
+    m = cols.mean(axis=0)
+    return {"meanDic": float(m[3]), "meanIoU": float(m[5]), "meanEm": float(E.mean()), "mae": mae, "Sm": float(sm), "wFm": float(wfm), "E": E}

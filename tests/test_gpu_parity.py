@@ -738,6 +738,53 @@ def test_threshold_metrics_vs_reference_and_oracle():
     assert abs(r["meanDic"] - O.mean_dice(pred, gt)) < 1e-12
 
 
+def test_full_eval_metrics_vs_reference_eval_for_testAllInOne():
+    """Sm, wFm and meanEm on the device (pn2_eval_region_sums, pn2_eval_wfm + the histograms) against the imported reference's eval_for_testAllInOne
+    (eval.py:18-66; tests/golden/make_golden_evalfull.py): every metric of opt["metrics"] within 1e-9 (the reference sums pixels pairwise in float64, the device
+    path uses exact integer moments / fixed-order sums), the EnhancedMeasure threshold curve within 1e-12, and - through the C ABI - the exact Euclidean feature
+    transform: distances and the error propagated from the nearest foreground pixel IDENTICAL to scipy's on a map full of equidistant sites."""
+    import ctypes as C
+    import warnings
+    from pn2.evaltail import threshold_metrics, eval_for_testAllInOne
+    from pn2.capi import call
+    from oracle import pranet_oracle as O
+    z = np.load(os.path.join(G, "eval_full.npz"))
+    names = ["meanDic", "meanIoU", "wFm", "Sm", "meanEm", "mae"]
+    for tag in ("blob", "zero_pred", "exact", "full", "two", "rand352"):
+        pred, gt = torch.from_numpy(z[tag + "_pred"]).to(dev), torch.from_numpy(z[tag + "_gt"]).to(dev)
+        r = threshold_metrics(pred, gt, full=True)
+        for k, ref in zip(names, z[tag + "_vals"]):
+            assert abs(r[k] - float(ref)) <= 1e-9 * max(1.0, abs(float(ref))), (tag, k, r[k], float(ref))
+        assert np.abs(r["E"] - z[tag + "_E"]).max() <= 1e-12, tag
+        assert eval_for_testAllInOne({"metrics": ["Sm", "mae", "wFm"]}, pred, gt) == [r["Sm"], r["mae"], r["wFm"]]
+    # no foreground at all: Sm = 1 - mean(pred) (eval_functions.py:79-81), meanEm from 1 - pred; wFm is undefined in the reference (scipy has no site to return)
+    pred = torch.from_numpy(z["blob_pred"]).to(dev)
+    r = threshold_metrics(pred, torch.zeros_like(pred, dtype=torch.float32), full=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o = O.full_metrics(z["blob_pred"], np.zeros_like(z["blob_gt"]))
+    assert abs(r["Sm"] - o["Sm"]) < 1e-12 and abs(r["meanEm"] - o["meanEm"]) < 1e-12 and np.isnan(r["wFm"])
+    # ---- the feature transform itself, through the C ABI
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    K = torch.full((49,), 1.0 / 49, dtype=torch.float64, device=dev)
+    for gt_np, pred_np in ((z["tie_gt"], None), (z["blob_gt"], z["blob_pred"])):
+        H, W = gt_np.shape
+        gt = torch.from_numpy(gt_np).to(dev)
+        pred = torch.from_numpy(pred_np).to(dev) if pred_np is not None else torch.zeros(H, W, dtype=torch.uint8, device=dev)
+        wi = torch.empty(H * W, dtype=torch.int32, device=dev); wd = torch.empty(2 * H * W, dtype=torch.float64, device=dev)
+        part = torch.empty(int(call.pn2_eval_wfm_blocks(H, W)), 2, dtype=torch.float64, device=dev)
+        call.pn2_eval_wfm(P(pred), P(gt), H, W, P(K), -0.1, P(wi), P(wd), P(part), st)
+        torch.cuda.synchronize()
+        et, dst = wd[:H * W].reshape(H, W).cpu().numpy(), wd[H * W:].reshape(H, W).cpu().numpy()
+        if pred_np is None:
+            assert np.array_equal(dst, z["tie_dst"])
+            # with pred = 0 the propagated error is 1 everywhere (|0 - 1| at a foreground pixel): use the distances only here, the indices via the blob case below
+            assert np.array_equal(et, np.ones_like(et))
+        else:
+            assert np.array_equal(et, z["blob_Et"])
+
+
 @pytest.mark.parametrize("which", ["res2net", "pvt"])
 def test_v1_forward_vs_reference(which):
     """PraNet / PVT_PraNet (V1 reverse attention, PraNet_Res2Net.py:101-273; the two V1 models MyTest_med.py:58-66 loads strict) in fp32

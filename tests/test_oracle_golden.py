@@ -353,3 +353,30 @@ def test_constructor_variants_oracle_matches_reference(tag):
             k = f[len(f"{tag}.buf."):]
             assert float((P[k].detach().reshape(-1)[:256] - T(z[f])).abs().max()) < 1e-5, k
     assert sorted(k for k in keys if P[k].grad is None) == sorted(str(s_) for s_ in z[f"{tag}.nograd"])
+
+
+def test_full_metrics_oracle_matches_reference_eval_for_testAllInOne():
+    """oracle.full_metrics (Sm, wFm, meanEm next to meanDic / meanIoU / mae) == the imported reference's eval_for_testAllInOne (eval.py:18-66; vectors from
+    tests/golden/make_golden_evalfull.py), and the oracle's restatement of scipy's exact Euclidean feature transform == scipy's own output INDEX BY INDEX on a
+    map full of equidistant sites (the tie-breaking decides which error value original_WFb propagates to a background pixel)."""
+    import warnings
+    z = np.load(os.path.join(G, "eval_full.npz"))
+    names = ["meanDic", "meanIoU", "wFm", "Sm", "meanEm", "mae"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag in ("blob", "zero_pred", "exact", "full", "two", "rand352"):
+            m = O.full_metrics(z[tag + "_pred"], z[tag + "_gt"])
+            for k, ref in zip(names, z[tag + "_vals"]):
+                assert abs(m[k] - float(ref)) <= 1e-12 * max(1.0, abs(float(ref))), (tag, k, m[k], float(ref))
+            assert np.abs(m["E"] - z[tag + "_E"]).max() <= 1e-12, tag
+    dst, ri, rj = O.edt_nearest(z["tie_gt"])
+    assert np.array_equal(ri, z["tie_ri"]) and np.array_equal(rj, z["tie_rj"]) and np.array_equal(dst, z["tie_dst"])
+    # ... and against scipy in this process, on random maps of several densities (scipy is a dependency of the reference, present in the image)
+    from scipy.ndimage import distance_transform_edt
+    rng = np.random.default_rng(3)
+    for dens in (0.002, 0.05, 0.5):
+        g = (rng.random((37, 61)) < dens).astype(np.float64)
+        g[rng.integers(0, 37), rng.integers(0, 61)] = 1
+        d_s, i_s = distance_transform_edt(1 - g, return_indices=True)
+        d_o, ri, rj = O.edt_nearest(g)
+        assert np.array_equal(d_o, d_s) and np.array_equal(ri, i_s[0]) and np.array_equal(rj, i_s[1]), dens
