@@ -109,6 +109,24 @@ def _timed_replay(tr, steps):
     return (time.perf_counter() - t0) / steps
 
 
+def _config_roofline(tr, x, m):
+    """The `roofline` object of a secondary configuration, measured like the headline's (pn2.profile.measure_step: HIP events around every launch of an
+    instrumented eager step): the MFMA family (conv / Linear GEMMs forward + dgrad), the weight-gradient GEMMs and the six heaviest kernels."""
+    from pn2 import profile as prof
+    r = prof.measure_step(tr, x, m, "bf16")
+    ro = r["roofline"]
+    out = {k: ro[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us") if k in ro}
+    out["traffic"] = None
+    if "wgrad" in ro:
+        out["wgrad"] = {k: ro["wgrad"][k] for k in ("achieved", "frac", "launches")}
+    if "per_launch_roofline" in ro:
+        out["per_launch_roofline_frac"] = ro["per_launch_roofline"]["frac"]
+    tot = sum(k["ms"] for k in r["kernels"].values())
+    out["kernel_ms_total"] = round(tot, 3)
+    out["top_kernels"] = {n: k for n, k in list(r["kernels"].items())[:6]}
+    return out
+
+
 def other_configs(dev, steps=10):
     """BASELINE configs 4 and 5 on this GPU (their single-GPU workloads), through the same fused Trainer + hipGraph replay as the headline."""
     import pn2
@@ -124,7 +142,12 @@ def other_configs(dev, steps=10):
     tr.capture(x, m, warmup=2)
     el = _timed_replay(tr, steps)
     out["pvt_bs16_352"] = {"workload": "PVT-PraNet-V2 (pvt_v2_b2, DropPath 0.1) training step, bs=16 352x352 bf16 (config 4, one GPU)", "value": round(16 / el, 1),
-                           "unit": "images/sec", "ms_per_step": round(1e3 * el, 3), "steps": steps}
+                           "unit": "images/sec", "ms_per_step": round(1e3 * el, 3), "steps": steps,
+                           "mfma_frac_whole_step": round(16 / el * 72.3 / 1e3 / PEAK_BF16_TFLOPS, 4)}       # 72.3 GFLOP per image and train step
+    try:
+        out["pvt_bs16_352"]["roofline"] = _config_roofline(tr, x, m)
+    except Exception as e:          # noqa: BLE001
+        out["pvt_bs16_352"]["roofline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     del tr, model
     torch.cuda.empty_cache()
     torch.manual_seed(0)
@@ -139,6 +162,10 @@ def other_configs(dev, steps=10):
     el = _timed_replay(tr, steps)
     out["emcad_k9_bs16_512"] = {"workload": "EMCADNet dual K=9 (pvt_v2_b2 + EMCAD decoder) fwd + 15-subset CE/Dice/BCE loss + bwd + AdamW, bs=16 512x512 bf16 (config 5, one GPU)",
                                 "value": round(16 / el, 1), "unit": "images/sec", "ms_per_step": round(1e3 * el, 3), "steps": steps}
+    try:
+        out["emcad_k9_bs16_512"]["roofline"] = _config_roofline(tr, x, m)
+    except Exception as e:          # noqa: BLE001
+        out["emcad_k9_bs16_512"]["roofline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     del tr, model
     torch.cuda.empty_cache()
     return out
@@ -477,7 +504,9 @@ def main(argv=None):
         if hb:          # the whole step against the HBM roofline: bytes of the committed PMC passes / this run's step time (the step is traffic-bound first)
             gbs = hb / (1e-3 * out["ms_per_step"]) / 1e9
             out["roofline"]["step_hbm"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "bytes_per_step": hb,
-                                          "source": out["roofline"].get("traffic_source")}
+                                          "source": out["roofline"].get("traffic_source"), "source_commit": out["roofline"].get("traffic_commit"),
+                                          "note": "bytes: PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, eager launches) recorded at source_commit - a derived figure, stale "
+                                                  "if kernels that move data changed after that commit; time: this run"}
         # always present: how many ranks exchanged gradients (1 = a single process, no collective on the data path)
         out["dp"] = dp if dp is not None else {"backend": None, "nccl_ranks": 1, "mode": "single process, no collective on the data path"}
         if world == 1 and not args.no_fp32_line and args.model == "res2net" and args.dtype == "bf16":
