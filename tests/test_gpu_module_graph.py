@@ -228,3 +228,74 @@ def test_droppath_draws_fresh_masks_under_graph_replay():
     assert st and st[0].graph_f is not None
     # calls 6, 7, 8 are replays of one graph on the same input and (nearly) the same weights: different DropPath masks -> different outputs
     assert not torch.equal(outs[5], outs[6]) and not torch.equal(outs[6], outs[7])
+
+
+def test_bf16_replayed_call_matches_the_plain_pass():
+    """The default (benchmarked) precision through the call-site graphs (the tests above run fp32 only): a replayed bf16 call against the plain bf16 pass
+    of a fresh model on the same weights and batch - the same kernels on the same operands, so the maps agree to the last bit and the gradients up to the fp32
+    summation order of the table-driven weight gradients."""
+    import pn2
+    from pn2 import graph as G
+    from oracle import weights as W
+    pn2.set_compute_dtype("bf16")
+    x, _ = W.synthetic_batch(2, 96, seed=7)
+    x = x.to(dev)
+    gs = [torch.randn(2, 1, 96, 96, device=dev, generator=torch.Generator(device=dev).manual_seed(i)) for i in range(8)]
+
+    def one(model):
+        model.zero_grad()
+        outs = model(x)
+        torch.autograd.backward([o for o in outs], gs)
+        return [o.detach().clone() for o in outs], {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    G.set_module_graph(True)
+    model = _model()
+    for _ in range(4):
+        one(model)
+    o1, g1 = one(model)
+    st = next(iter(next(iter(model.hot_parameters())).__dict__["_pn2_sites"].values()))
+    assert st.graph_f is not None and st.graph_b is not None
+    G.set_module_graph(False)
+    o0, g0 = one(_model())
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    num = sum(float((g0[k].double() - g1[k].double()).pow(2).sum()) for k in g0) ** 0.5
+    den = sum(float(g0[k].double().pow(2).sum()) for k in g0) ** 0.5
+    assert set(g0) == set(g1) and num / den < 2e-4, num / den
+
+
+def test_gradients_accumulate_across_replayed_calls_without_zero_grad():
+    """Two forward / backward pairs WITHOUT zero_grad in between (gradient accumulation): the second replayed backward hands out views of a NEW flat copy, and
+    autograd must add them to the .grad tensors adopted from the first one - p.grad == g(batch a) + g(batch b), not the second gradient alone."""
+    import pn2
+    from pn2 import graph as G
+    from oracle import weights as W
+    pn2.set_compute_dtype("fp32")
+    G.set_module_graph(True)
+    model = _model()
+    xa, _ = W.synthetic_batch(2, 96, seed=21)
+    xb, _ = W.synthetic_batch(2, 96, seed=22)
+    xa, xb = xa.to(dev), xb.to(dev)
+    for _ in range(5):                         # warm the site up to replay
+        model.zero_grad()
+        sum(o.sum() for o in model(xa)).backward()
+    st = next(iter(next(iter(model.hot_parameters())).__dict__["_pn2_sites"].values()))
+    assert st.graph_f is not None
+
+    def grads():
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    sum(o.sum() for o in model(xa)).backward()
+    ga = grads()
+    model.zero_grad()
+    sum(o.sum() for o in model(xb)).backward()
+    gb = grads()
+    model.zero_grad()
+    sum(o.sum() for o in model(xa)).backward()
+    held = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}          # the tensors adopted as .grad by the first backward
+    sum(o.sum() for o in model(xb)).backward()                                               # no zero_grad: accumulates
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        assert p.grad is held[n], n                                                          # accumulated in place
+        want = ga[n] + gb[n]
+        assert float((p.grad - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), n
