@@ -1042,7 +1042,12 @@ __global__ __launch_bounds__(256) void conv_gather_gemm_tab(const pn2_conv_job* 
 
 // NS = 3: two K-steps of loads in flight; NS = 2: one step ahead and a third less LDS, so that three (64x128) instead of two workgroups share
 // a CU - the per-shape tuner picks (the K loop runs at ~27 % of the MFMA rate with two resident workgroups: barrier / wait stalls).
-template <int BM, int BN, int WM, int WN, bool PW, int NS, bool EP>
+// KS = 2 / 4 (conv_dma_gemm_ks, 512 / 1024 threads): INTRA-workgroup split-K for launches that are one partial wave of tiles with a long K loop (the 3x3 Res2Net
+// branch convs of layer3 / layer4: 121-242 tiles, 15-30 K-steps, one wave per SIMD - nothing hides the DMA round trip of a K-step, 13-15 us whatever the
+// tile, tools/gemm_codes_micro.py).  Every further group of four waves runs its share of the K-steps on a ring of its own, next to waves 0-3 on the same SIMDs;
+// the accumulators meet in LDS (fp32, lane-linear) and waves 0-3 alone run the unchanged epilogue (the others have ended: a barrier only counts live waves).
+// Same tile, half the serial chain, no partial tiles in memory and no reduce launch (the global split-K of PN2_CONV_SPLITK needs both).
+template <int BM, int BN, int WM, int WN, bool PW, int NS, bool EP, int KS = 1>
 __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
                                               float* __restrict__ psum, float* __restrict__ psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, int lbid, int lgrid, int by) {
     using T = bf16_t;
@@ -1055,11 +1060,13 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     typedef __attribute__((address_space(3))) void* lptr_t;
 
     PN2_STAMP_AT(0);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int kg = KS > 1 ? (int)(threadIdx.x >> 8) : 0;           // K group of this wave: group k takes the k-th share of the K-steps
+    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN, l15 = lane & 15, g = lane >> 4;
     const int M = d.N * d.OH * d.OW;
     const int nbn = (d.Cout + BN - 1) / BN;
     const int bid = xcd_remap(lbid, lgrid);
+    if (KS > 1) by = kg;
     // (tile -> (row block, column block): a scalar division costs ~25 dependent instructions with two VALU round trips at the very top of the kernel;
     //  one column tile - every narrow conv - or a power-of-two count need none)
     int bn, bm;
@@ -1071,10 +1078,12 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     const int ktot = taps * d.Cin_p;
     const int ksteps_all = (ktot + BK - 1) / BK;
     // split-K (PN2_CONV_SPLITK, small-M long-K convs): blockIdx.y owns the K-steps [kt0, kt0 + ksteps) and leaves an fp32 partial tile
-    const int ksplit = (d.flags >> 16) & 15;
+    const int ksplit = KS > 1 ? KS : (d.flags >> 16) & 15;
     const int kper = ksplit > 1 ? (ksteps_all + ksplit - 1) / ksplit : ksteps_all;
     const int kt0 = ksplit > 1 ? by * kper : 0;
     const int ksteps = max(0, min(ksteps_all - kt0, kper));
+    const int kloop = KS > 1 ? kper : ksteps;           // (KS > 1: every group passes the same barriers; a shorter one idles through its last steps)
+    char* const ring = smem + (KS > 1 ? kg * NS * STAGE : 0);
 
     GatherGeom gg;
     gg.H = d.H; gg.W = d.W; gg.OH = d.OH; gg.OW = d.OW; gg.KH = d.KH; gg.KW = d.KW; gg.stride = d.stride;
@@ -1138,7 +1147,7 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
 // (a non-temporal policy on the activation operand's DMA wins 14-24 % on cold operands and loses inside the step, where the operand still sits in L2 / MALL: DESIGN 6)
 #define PN2_ISSUE(step_, buf_)                                                                                         \
     do {                                                                                                               \
-        char* sb_ = smem + (buf_) * STAGE;                                                                             \
+        char* sb_ = ring + (buf_) * STAGE;                                                                             \
         if (PW) {                                                                                                      \
             const int k_ = (step_) * BK + cg * VEC;                                                                    \
             const bool kok_ = k_ < d.Cin_p;                                                                            \
@@ -1177,13 +1186,13 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     const int key = (l15 >> 1) & 7;
     const unsigned so0 = ((g) ^ key) * 16, so1 = ((4 + g) ^ key) * 16;
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;     // LDS byte address of the dynamic segment
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)ring;     // LDS byte address of this K group's ring
 
     PN2_STAMP_AT(1);
     if (ksteps > 0) PN2_ISSUE(kt0, 0);
     if (NS == 3 && ksteps > 1) PN2_ISSUE(kt0 + 1, 1);
     PN2_STAMP_AT(2);
-    for (int t = 0; t < ksteps; ++t) {
+    for (int t = 0; t < kloop; ++t) {
         if constexpr (NS == 3) {
             // my own DMA of step t has landed once at most one later step (LPS loads) is still outstanding
             if (t + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
@@ -1207,6 +1216,7 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
                 PN2_ISSUE(kt0 + t + 1, nb_);
             }
         }
+        if (KS > 1 && t >= ksteps) continue;           // (a shorter K group: nothing left to multiply, the barrier above is all it owes)
         // Fragment reads are inline asm: for a compiler-visible LDS load hipcc drains ALL outstanding LDS-DMA (vmcnt(0)) first,
         // which would collapse the pipeline to depth 1.  DS operations return in order, so counted lgkmcnt waits are exact.
         const unsigned As = lds0 + (t % NS) * STAGE + (wm * WTM + l15) * ROW;
@@ -1237,7 +1247,30 @@ __device__ __forceinline__ void conv_dma_body(const bf16_t* __restrict__ in, con
     __syncthreads();
     PN2_STAMP_AT(4);
 
-    if (ksplit > 1) {            // fp32 partial tile -> workspace [ksplit][M][Cout] (psum); pn2_conv_splitk_reduce finishes (sum, stats, bias, store)
+    if constexpr (KS > 1) {      // the K groups' accumulators meet in LDS (lane-linear fp32: conflict-free); groups 1.. end here
+        float* xs = reinterpret_cast<float*>(smem);
+        constexpr int XG = MT * NT * 4 * 256;          // floats per group
+        if (kg > 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xs[(kg - 1) * XG + ((i * NT + j) * 4 + r) * 256 + tid] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k)          // fixed order: group 1, 2, 3
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += xs[k * XG + ((i * NT + j) * 4 + r) * 256 + tid];
+        __syncthreads();          // (4 live waves from here on) the exchange area is the epilogue's staging area next
+    }
+    if (KS == 1 && ksplit > 1) { // fp32 partial tile -> workspace [ksplit][M][Cout] (psum); pn2_conv_splitk_reduce finishes (sum, stats, bias, store)
         float* ws = psum + (size_t)by * M * d.Cout;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -1263,6 +1296,11 @@ template <int BM, int BN, int WM, int WN, bool PW, int NS = 3, bool EP = false>
 __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
                                                      float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
     conv_dma_body<BM, BN, WM, WN, PW, NS, EP>(in, wp, out, psum, psq, d, ep, blockIdx.x, gridDim.x, blockIdx.y);
+}
+template <int BM, int BN, int WM, int WN, bool PW, int NS, bool EP, int KS>
+__global__ __launch_bounds__(256 * KS) void conv_dma_gemm_ks(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
+                                                             float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
+    conv_dma_body<BM, BN, WM, WN, PW, NS, EP, KS>(in, wp, out, psum, psq, d, ep, blockIdx.x, gridDim.x, 0);
 }
 template <int BM, int BN, int WM, int WN, bool PW, int NS, bool EP>
 __global__ __launch_bounds__(256) void conv_dma_gemm_tab(const pn2_conv_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
@@ -1890,6 +1928,34 @@ int launch_dma(const void* in, const void* wp, void* out, float* psum, float* ps
     return 0;
 }
 
+// intra-workgroup split-K launch (conv_dma_gemm_ks): KS rings, 256 * KS threads; -4 when the rings / the exchange area / the epilogue do not fit 160 KB
+template <bool EP, int BM, int BN, int WM, int WN, int NS, int KS>
+int launch_dma_ks(const void* in, const void* wp, void* out, float* psum, float* psq, const pn2_conv_desc& d, const pn2_conv_ep& ep, hipStream_t st) {
+    const int M = d.N * d.OH * d.OW;
+    const int grid = ((M + BM - 1) / BM) * ((d.Cout + BN - 1) / BN);
+    constexpr int stage_b = (BM + BN) * 128, main_b = KS * NS * stage_b, epi_b = BM * (BN * 2 + 16) + 3 * WM * BN * 4, xch_b = (KS - 1) * BM * BN * 4;
+    static_assert(main_b <= 160 * 1024 && xch_b <= 160 * 1024, "tile does not fit");
+    int lds = main_b > epi_b ? main_b : epi_b;
+    if (xch_b > lds) lds = xch_b;
+    constexpr bool E2 = EP && ep2_tile(BM, BN);
+    if (E2) { const int e2 = ep2_lds_for<BM, BN>(d, ep); if (e2 > lds) lds = e2; }
+    else if (EP && lds < ep_lds_bytes(8)) lds = ep_lds_bytes(8);
+    if (lds > 160 * 1024 || ((d.flags >> 16) & 15) > 1) return -4;
+    const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0;
+    {
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_ks<BM, BN, WM, WN, true, NS, EP, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_ks<BM, BN, WM, WN, false, NS, EP, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+    }
+    if (pw) hipLaunchKernelGGL((conv_dma_gemm_ks<BM, BN, WM, WN, true, NS, EP, KS>), dim3(grid), dim3(256 * KS), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d, ep);
+    else hipLaunchKernelGGL((conv_dma_gemm_ks<BM, BN, WM, WN, false, NS, EP, KS>), dim3(grid), dim3(256 * KS), lds, st, (const bf16_t*)in, (const bf16_t*)wp, (bf16_t*)out, psum, psq, d, ep);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
 // the LDS-DMA kernel addresses the activation operand with 32-bit byte offsets behind a buffer descriptor (conv_dma_body): its extent must stay below 2 GB
 inline bool dma_extent_ok(const pn2_conv_desc& d) {
     return ((size_t)d.N * d.H * d.W - 1) * (size_t)d.ld_in * 2 + (size_t)d.Cin_p * 2 < 0x80000000ull;
@@ -1936,6 +2002,17 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
     int kern, bm, bn;
     gemm_select<T>(d, kern, bm, bn);
     if constexpr (sizeof(T) == 2) {
+        if (((d.flags >> 8) & 0x80) && kern >= 2 && bm == 64 && bn == 64) {          // tuning-code bit 7: intra-workgroup split-K over FOUR K groups (64 x 64 tiles)
+            return launch_dma_ks<EP, 64, 64, 2, 2, 2, 4>(in, wp, out, psum, psq, d, ep, st);          // (four 3-stage rings of a 64 x 64 tile would take 192 KB: 2 stages)
+        }
+        if (((d.flags >> 8) & 0x40) && kern >= 2 && bn >= 64) {          // tuning-code bit 6: intra-workgroup split-K over two K groups of four waves
+            if (kern == 3) {
+                if (bm == 128) return bn == 128 ? launch_dma_ks<EP, 128, 128, 2, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st) : launch_dma_ks<EP, 128, 64, 2, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+                return bn == 128 ? launch_dma_ks<EP, 64, 128, 2, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st) : launch_dma_ks<EP, 64, 64, 2, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st);
+            }
+            if (bm == 128) return bn == 128 ? -4 : launch_dma_ks<EP, 128, 64, 2, 2, 3, 2>(in, wp, out, psum, psq, d, ep, st);
+            return bn == 128 ? launch_dma_ks<EP, 64, 128, 2, 2, 3, 2>(in, wp, out, psum, psq, d, ep, st) : launch_dma_ks<EP, 64, 64, 2, 2, 3, 2>(in, wp, out, psum, psq, d, ep, st);
+        }
         if (kern == 3) {              // LDS-DMA, 2-stage ring (more workgroups per CU)
             if (bm == 128) {
                 if (bn == 128) return launch_dma<EP, 128, 128, 2, 2, 2>(in, wp, out, psum, psq, d, ep, st);

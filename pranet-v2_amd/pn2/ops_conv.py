@@ -97,6 +97,13 @@ class ConvOps:
                     if (bn == 2 and Cout <= 32) or (bn == 3 and Cout <= 64):
                         continue
                     cands.append(kern | (bm << 2) | (bn << 4))
+                    # bit 6: intra-workgroup split-K (two K groups of four waves, conv_dma_gemm_ks2) - for launches that are about one wave of tiles with a long K loop
+                    tiles = -(-M // (64 << (bm - 1))) * -(-Cout // (16 << bn))
+                    ksteps = -(-(cd.KH * cd.KW * cd.Cin_p) // 64)
+                    if core.KS2 and kern >= 2 and bn >= 2 and tiles <= 640 and ksteps >= 6 and not (cd.flags >> 16) & 15:
+                        cands.append(kern | (bm << 2) | (bn << 4) | 0x40)
+                        if bm == 1 and bn == 2 and tiles <= 320 and ksteps >= 12:          # bit 7: four K groups (64 x 64 tiles only)
+                            cands.append(kern | (bm << 2) | (bn << 4) | 0x80)
         evs = []
         feasible = []
         for code in cands:
@@ -281,6 +288,8 @@ class ConvOps:
         shape = f"{Cin}->{Cout} k{KH}x{KW} s{sh} d{dh} {N}x{OH}x{OW}"
         capi.WORK.update(flops=flops, tag=":fwd", shape=shape)
         ksplit = self._ksplit(M, KH * KW * x.Cp, Cout_p)
+        if tune & 0xC0:
+            ksplit = 1          # the tuner found the intra-workgroup split-K kernel faster than every plain tile: it also replaces the global split-K + reduce pair
         if gate is not None:
             assert (KH, KW, sh) == (1, 1, 1) and gate.dt == F32 and gate.C == 1 and gate.M == M and bias is None, "the fused gate sits in front of a bias-free 1x1 conv"
             ksplit = 1
@@ -552,6 +561,8 @@ class ConvOps:
                 dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = KH, KW, sh, ph, pw, dh, dw
                 dd.transposed, dd.Kp, dd.flags = 1, ptd.Kp, (capi.CONV_ACCUM if gxa else 0)
                 ks = self._ksplit(Mx, KH * KW * Cout_p, x.Cp) if gx.stride(2) == x.Cp else 1
+                if ks > 1 and self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp) & 0xC0:
+                    ks = 1          # (as in the forward: intra-workgroup split-K instead of partial tiles + reduce; the launch may then carry the BatchNorm-backward epilogue)
                 capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
                 dual = x.sum_of is not None and x.galias is x.sum_of[1] and x.sum_of[0].requires_grad
                 if ks > 1:

@@ -227,3 +227,98 @@ def test_table_driven_conv_launch_matches_single_launches_bitwise():
         for i, (a, b) in enumerate(zip(single, multi)):
             assert torch.equal(a[0], b[0]), (bm, i, "output")
             assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (bm, i, "statistics")
+
+
+KS_GEOMS = [  # long contractions (>= 6 K-steps of 64) where the intra-workgroup split-K kernels apply; few tiles, ragged last tile, uneven K shares
+    (2, 11, 13, 104, 104, 3, 3, 1, 1, 1, 1),
+    (1, 9, 9, 40, 48, 5, 5, 1, 2, 2, 1),            # 1000-long contraction: 16 K-steps, 4 groups x 4
+    (2, 11, 11, 208, 208, 3, 3, 1, 1, 1, 1),        # 30 K-steps: 15 + 15 / 8 + 8 + 8 + 6
+    (1, 5, 7, 456, 136, 1, 1, 1, 0, 0, 1),          # 1x1, 8 K-steps (the last one half empty)
+    (3, 20, 18, 56, 72, 3, 3, 1, 1, 1, 1),          # a K-step straddles two taps at a group boundary
+    (2, 16, 18, 56, 56, 3, 3, 2, 1, 1, 1),          # stride 2 and its transposed gather
+]
+
+
+@pytest.mark.parametrize("geom", KS_GEOMS)
+@pytest.mark.parametrize("transposed", [0, 1])
+def test_intra_workgroup_split_k_kernels_match_float64_and_the_plain_kernel(geom, transposed):
+    """conv_dma_gemm_ks (tuning-code bits 6 / 7: two / four K groups of four waves share a tile's K loop, accumulators meet in LDS): the convolution of the
+    same bf16 operands in float64 up to one rounding of the output, BatchNorm partials consistent with the STORED tile, and - another fp32 summation order, not
+    another result - the plain kernel's tensor up to single bf16 roundings on a few elements."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pn2 import capi
+    from pn2.capi import call, BF16
+    N, H, W, Cin, Cout, KH, KW, s, ph, pw, dil = geom
+    OH = (H + 2 * ph - dil * (KH - 1) - 1) // s + 1
+    OW = (W + 2 * pw - dil * (KW - 1) - 1) // s + 1
+    g = torch.Generator(device="cpu").manual_seed(N * 1000 + H * 10 + KH + transposed + 7)
+    w = (torch.randn(Cout, Cin, KH, KW, generator=g) * 0.2).bfloat16()
+    taps = KH * KW
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = capi.ConvDesc()
+    d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.dil_h, d.dil_w = KH, KW, s, ph, pw, dil, dil
+    if not transposed:
+        x = torch.randn(N, H, W, Cin, generator=g).bfloat16()
+        ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), None, s, (ph, pw), dil).permute(0, 2, 3, 1)
+        Kp = _rup(taps * Cin, 128)
+        wp = torch.zeros(_rup(Cout, 128), Kp, dtype=torch.bfloat16)
+        wp[:Cout, :taps * Cin] = w.permute(0, 2, 3, 1).reshape(Cout, taps * Cin)
+        d.N, d.H, d.W, d.OH, d.OW = N, H, W, OH, OW
+        d.Cin_p, d.ld_in, d.Cout, d.ld_out = Cin, Cin, Cout, Cout
+        src, n_out, M = x, Cout, N * OH * OW
+    else:
+        dy = torch.randn(N, OH, OW, Cout, generator=g).bfloat16()
+        ref = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double(), None, s, (ph, pw),
+                                 (H - ((OH - 1) * s - 2 * ph + dil * (KH - 1) + 1), W - ((OW - 1) * s - 2 * pw + dil * (KW - 1) + 1)), 1, dil).permute(0, 2, 3, 1)
+        Kp = _rup(taps * Cout, 128)
+        wp = torch.zeros(_rup(Cin, 128), Kp, dtype=torch.bfloat16)
+        wp[:Cin, :taps * Cout] = w.permute(1, 2, 3, 0).reshape(Cin, taps * Cout)
+        d.N, d.H, d.W, d.OH, d.OW = N, OH, OW, H, W
+        d.Cin_p, d.ld_in, d.Cout, d.ld_out = Cout, Cout, Cin, Cin
+        src, n_out, M = dy, Cin, N * H * W
+    d.transposed, d.Kp = transposed, Kp
+    src_g, wp_g = src.to(dev), wp.to(dev)
+    tol = ref.abs() * 2.0 ** -8 + 1e-3 * float(ref.abs().max())
+
+    def run(code):
+        d.flags = (code << 8) | (0 if transposed else capi.CONV_STATS)
+        tm = 64 * ((code >> 2) & 3)
+        out = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device=dev)
+        nblk = (M + tm - 1) // tm
+        ps = torch.full((nblk, n_out), float("nan"), device=dev); pq = torch.full((nblk, n_out), float("nan"), device=dev)
+        call.pn2_conv_gemm(BF16, P(src_g), P(wp_g), P(out), C.c_void_p(0) if transposed else P(ps), C.c_void_p(0) if transposed else P(pq), C.byref(d), st)
+        torch.cuda.synchronize()
+        return out, ps, pq, tm
+    ran = 0
+    for kern in (2, 3):
+        for bm in (1, 2):
+            for bn in (2, 3):
+                if bn == 3 and n_out <= 64:
+                    continue
+                base = kern | (bm << 2) | (bn << 4)
+                plain = run(base)[0]
+                for bit in (0x40, 0x80):
+                    if bit == 0x80 and not (bm == 1 and bn == 2):
+                        continue
+                    try:
+                        out, ps, pq, tm = run(base | bit)
+                    except RuntimeError as e:          # a tile whose rings do not fit 160 KB of LDS (128 x 128 with three stages)
+                        assert "status -4" in str(e), e
+                        continue
+                    ran += 1
+                    got = out.double().cpu().reshape(ref.shape)
+                    assert bool(((got - ref).abs() <= tol).all()), (hex(base | bit), float(((got - ref).abs() - tol).max()))
+                    dd = (out.float() - plain.float()).abs()
+                    assert float((dd > 0).float().mean()) < 0.02 and bool((dd <= plain.float().abs() * 2.0 ** -7 + 1e-6).all()), hex(base | bit)
+                    if not transposed:          # partials = mean / M2 of the stored tile rows
+                        o64 = out.double().cpu()
+                        nblk = ps.shape[0]
+                        n_t = torch.full((nblk,), float(tm), dtype=torch.float64); n_t[-1] = M - (nblk - 1) * tm
+                        mean_t, m2_t = ps.double().cpu(), pq.double().cpu()
+                        mean = (mean_t * n_t[:, None]).sum(0) / M
+                        var = (m2_t.sum(0) + (n_t[:, None] * (mean_t - mean) ** 2).sum(0)) / M
+                        smean, svar = o64.mean(0), o64.var(0, unbiased=False)
+                        assert float(((mean - smean).abs() / svar.sqrt()).max()) < 2e-5 and float(((var - svar).abs() / svar).max()) < 5e-5
+    assert ran >= 6
