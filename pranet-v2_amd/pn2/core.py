@@ -56,8 +56,9 @@ TUNE_REPS = int(os.environ.get("PN2_TUNE_REPS", "3"))            # timed repetit
 # entry only ever applies to exactly the launch it was timed for; shapes not in the table are tuned at first use as before.  PN2_TUNE_TABLE=0 ignores it.
 if os.environ.get("PN2_TUNE_CACHE"):
     load_tuner(os.environ["PN2_TUNE_CACHE"])          # (first entry wins: an explicit cache overrides the shipped table)
-if os.environ.get("PN2_TUNE_TABLE", "1") == "1":
-    load_tuner(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json"))
+if os.environ.get("PN2_TUNE_TABLE", "1") != "0":          # "0": no table; "1" (default): the shipped one; anything else: path of another table (A/B of tuning runs)
+    _tt = os.environ.get("PN2_TUNE_TABLE", "1")
+    load_tuner(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json") if _tt == "1" else _tt)
 
 
 def rup(v, m):
