@@ -1297,6 +1297,12 @@ __global__ __launch_bounds__(256) void conv_dma_gemm(const bf16_t* __restrict__ 
                                                      float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
     conv_dma_body<BM, BN, WM, WN, PW, NS, EP>(in, wp, out, psum, psq, d, ep, blockIdx.x, gridDim.x, blockIdx.y);
 }
+template <int BM, int BN, int WM, int WN, bool EP>
+__global__ __launch_bounds__(512) void conv_dma_gemm_tab_ks2(const pn2_conv_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_conv_job j = jobs[jb];
+    conv_dma_body<BM, BN, WM, WN, false, 3, EP, 2>((const bf16_t*)j.in, (const bf16_t*)j.wp, (bf16_t*)j.out, j.psum, j.psq, j.d, j.ep, blockIdx.x - bstart[jb], bstart[jb + 1] - bstart[jb], 0);
+}
 template <int BM, int BN, int WM, int WN, bool PW, int NS, bool EP, int KS>
 __global__ __launch_bounds__(256 * KS) void conv_dma_gemm_ks(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wp, bf16_t* __restrict__ out,
                                                              float* __restrict__ psum, float* __restrict__ psq, pn2_conv_desc d, pn2_conv_ep ep) {
@@ -2065,6 +2071,25 @@ int launch_dma_tab(const pn2_conv_job* jobs, const int* bstart, int njobs, int t
     PN2_CHECK_LAUNCH();
     return 0;
 }
+// table-driven launch of the intra-workgroup split-K kernel (two K groups, 3-stage rings): jobs whose shape rule asks for it share tables among themselves
+template <bool EP, int BM, int BN, int WM, int WN>
+int launch_dma_tab_ks2(const pn2_conv_job* jobs, const int* bstart, int njobs, int total, int bits, hipStream_t st) {
+    constexpr int stage_b = (BM + BN) * 128, max_b = 2 * 3 * stage_b, epi_b = BM * (BN * 2 + 16) + 3 * WM * BN * 4, xch_b = BM * BN * 4;
+    static_assert(max_b <= 160 * 1024, "tile does not fit");
+    int lds = max_b > epi_b ? max_b : epi_b;
+    if (xch_b > lds) lds = xch_b;
+    if (EP && ep2_tile(BM, BN)) { const int e2 = ep2_lds_bits<BM, BN>(bits); if (e2 > lds) lds = e2; }
+    else if (EP && lds < ep_lds_bytes(8)) lds = ep_lds_bytes(8);
+    if (lds > 160 * 1024) return -4;
+    static bool done = false;
+    if (!done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_tab_ks2<BM, BN, WM, WN, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+    hipLaunchKernelGGL((conv_dma_gemm_tab_ks2<BM, BN, WM, WN, EP>), dim3(total), dim3(512), lds, st, jobs, bstart, njobs);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
 template <bool EP, int BM, int BN, int WM, int WN>
 int launch_gather_tab_f32(const pn2_conv_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
     constexpr int main_b = 2 * (BM + BN) * RS, epi_b = BM * (BN * 4 + 16) + 3 * WM * BN * 4, ep_b = EP ? ep_lds_bytes(4) : 0;
@@ -2080,6 +2105,13 @@ int launch_gather_tab_f32(const pn2_conv_job* jobs, const int* bstart, int njobs
 }
 template <bool EP>
 int gemm_multi_dispatch(int dtype, int bm, int bn, int bits, const pn2_conv_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
+    if (dtype == PN2_BF16 && (bm & 0x100)) {          // tile code of pn2_conv_gemm_tile with the split-K bit: the two-K-group table kernel
+        bm &= 0xff;
+        if (bm == 128 && bn == 64) return launch_dma_tab_ks2<EP, 128, 64, 2, 2>(jobs, bstart, njobs, total, bits, st);
+        if (bm == 64 && bn == 128) return launch_dma_tab_ks2<EP, 64, 128, 2, 2>(jobs, bstart, njobs, total, bits, st);
+        if (bm == 64 && bn == 64) return launch_dma_tab_ks2<EP, 64, 64, 2, 2>(jobs, bstart, njobs, total, bits, st);
+        return -2;
+    }
     if (dtype == PN2_BF16) {
         if (bm == 128) {
             if (bn == 128) return launch_dma_tab<EP, 128, 128, 2, 2>(jobs, bstart, njobs, total, bits, st);
@@ -2478,14 +2510,21 @@ int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d) {
     if (!d) return -1;
     if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
     if (((d->flags >> 16) & 15) > 1) return -2;
+    const int ksb = (d->flags >> 8) & 0xC0;          // intra-workgroup split-K (another fp32 summation order): such jobs only share tables among themselves
+    if (ksb & 0x80) return -2;
     int kern, bm, bn;
     if (dtype == PN2_BF16) { gemm_select<bf16_t>(*d, kern, bm, bn); if (!dma_extent_ok(*d)) return -2; }      // (a register-staged choice joins the table on the LDS-DMA kernel: same bits)
     else if (dtype == PN2_F32) gemm_select<float>(*d, kern, bm, bn);
     else return -3;
+    if (ksb) {
+        if (dtype != PN2_BF16 || bn < 64 || (bm == 128 && bn == 128)) return -2;
+        return ((bm | 0x100) << 8) | bn;          // bm carries the split-K bit through pn2_conv_gemm_job_blocks / pn2_conv_gemm_multi
+    }
     return (bm << 8) | bn;
 }
 
 int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn) {
+    bm &= 0xff;          // (bit 8: the split-K table kernel, same tile)
     if (!j || !j->in || !j->wp || !j->out || bm < 1 || bn < 1) return -1;
     const pn2_conv_desc& d = j->d;
     if ((d.flags & PN2_CONV_STATS) && (!j->psum || !j->psq)) return -1;

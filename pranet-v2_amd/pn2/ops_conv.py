@@ -88,7 +88,13 @@ class ConvOps:
             def launch(code):
                 d2.flags = code << 8
                 call.pn2_conv_gemm(self.dt, in_ptr, _p(wp), _p(scratch), nul, nul, C.byref(d2), st)
-        cands = []
+        # Intra-workgroup split-K (conv_dma_gemm_ks, tuning-code bit 6: two K groups of four waves) sums a tile's K loop in another fp32 order than the plain
+        # kernels, which all agree bit for bit.  Whether a shape takes it is therefore a RULE of the shape, not of a timing: about one wave of tiles and a long
+        # K loop (what the free tuning run of round 5 picked it for) - every call site that computes the same conv gets the same bits, and the tuner chooses
+        # kernel / tile inside the class.
+        ksteps = -(-(cd.KH * cd.KW * cd.Cin_p) // 64)
+        ks2 = core.KS2 and Cout > 32 and ksteps >= 9 and -(-M // 64) * -(-Cout // 64) <= 484 and not (cd.flags >> 16) & 15
+        cands, plain = [], []
         for kern in (1, 2, 3):             # 1 register-staged, 2 LDS-DMA with a 3-stage ring, 3 LDS-DMA with a 2-stage ring (more workgroups per CU)
             for bm in (1, 2):
                 if bm == 2 and M <= 64:
@@ -96,17 +102,14 @@ class ConvOps:
                 for bn in (1, 2, 3):
                     if (bn == 2 and Cout <= 32) or (bn == 3 and Cout <= 64):
                         continue
-                    cands.append(kern | (bm << 2) | (bn << 4))
-                    # bit 6: intra-workgroup split-K (two K groups of four waves, conv_dma_gemm_ks2) - for launches that are about one wave of tiles with a long K loop
-                    tiles = -(-M // (64 << (bm - 1))) * -(-Cout // (16 << bn))
-                    ksteps = -(-(cd.KH * cd.KW * cd.Cin_p) // 64)
-                    if core.KS2 and kern >= 2 and bn >= 2 and tiles <= 640 and ksteps >= 6 and not (cd.flags >> 16) & 15:
+                    plain.append(kern | (bm << 2) | (bn << 4))
+                    if ks2 and kern >= 2 and bn >= 2 and not (kern == 2 and bm == 2 and bn == 3):          # (128 x 128 with two 3-stage rings: 192 KB)
                         cands.append(kern | (bm << 2) | (bn << 4) | 0x40)
-                        if bm == 1 and bn == 2 and tiles <= 320 and ksteps >= 12:          # bit 7: four K groups (64 x 64 tiles only)
-                            cands.append(kern | (bm << 2) | (bn << 4) | 0x80)
         evs = []
         feasible = []
-        for code in cands:
+        for code in (cands + plain if ks2 else plain):
+            if ks2 and feasible and not code & 0x40:
+                break          # (the plain kernels only stand in when no split-K tile fits the LDS next to this launch's epilogue operands)
             try:
                 launch(code)
             except RuntimeError as err:       # status -4 only: the epilogue's operand tiles of this tile shape do not fit the LDS; anything else is a real failure

@@ -1,0 +1,37 @@
+import ctypes as C, os, sys
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/pranet-v2_amd")
+import torch
+from pn2 import capi
+from pn2.capi import call, BF16
+dev = "cuda"
+P = lambda t: C.c_void_p(t.data_ptr())
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def rup(v, m): return (v + m - 1) // m * m
+for (N, H, W, Cin, Cout, K, pad) in ((1, 3, 3, 256, 256, 5, 2), (1, 6, 6, 64, 64, 3, 1), (1, 3, 3, 2048, 832, 1, 0), (2, 11, 11, 208, 208, 3, 1)):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, H, W, Cin, generator=g).bfloat16().to(dev)
+    w = (torch.randn(Cout, Cin, K, K, generator=g) * 0.1).bfloat16()
+    taps = K * K
+    Kp = rup(taps * Cin, 128)
+    wp = torch.zeros(rup(Cout, 128), Kp, dtype=torch.bfloat16); wp[:Cout, :taps * Cin] = w.permute(0, 2, 3, 1).reshape(Cout, taps * Cin)
+    wp = wp.to(dev)
+    d = capi.ConvDesc()
+    d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.dil_h, d.dil_w = K, K, 1, pad, pad, 1, 1
+    d.N, d.H, d.W, d.OH, d.OW = N, H, W, H, W
+    d.Cin_p, d.ld_in, d.Cout, d.ld_out, d.transposed, d.Kp = Cin, Cin, Cout, Cout, 0, Kp
+    M = N * H * W
+    for code in (38, 102, 166, 54, 118, 39, 103, 167):
+        res = []
+        for rep in range(6):
+            out = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+            d.flags = code << 8
+            try:
+                call.pn2_conv_gemm(BF16, P(x), P(wp), P(out), C.c_void_p(0), C.c_void_p(0), C.byref(d), st)
+            except RuntimeError as e:
+                res = None; break
+            torch.cuda.synchronize()
+            res.append(out)
+        if res is None: continue
+        same = all(torch.equal(res[0].view(torch.int16), r.view(torch.int16)) for r in res)
+        nan = bool(torch.isnan(res[0].float()).any())
+        print((N, H, W, Cin, Cout, K), "code", code, "deterministic" if same else "NONDETERMINISTIC", "nan!" if nan else "")
