@@ -178,7 +178,7 @@ def _conv_bytes(shape, es):
         return 0
 
 
-PMC_FILE = "r04_pmc_hbm_traffic.json"       # the current round's summary (tools/prof_pmc.sh)
+PMC_FILE = "r05_pmc_hbm_traffic.json"       # the current round's summary (tools/prof_pmc.sh)
 
 
 def _pmc_traffic(symbols, config):
@@ -246,7 +246,7 @@ def measure_step(trainer, x, m, dtype, config=None):
     fam = [d for n, d in agg.items() if n.startswith("pn2_conv_gemm")]
     fl, ms, nl = sum(d["flops"] for d in fam), sum(d["ms"] for d in fam), sum(d["launches"] for d in fam)
     ach = fl / (ms * 1e-3) / 1e12
-    roofline = {"kernel": "pn2_conv_gemm + pn2_conv_gemm_multi (fwd+dgrad incl. the BatchNorm-backward statistics epilogues; symbols conv_dma_gemm[_tab]<*>, conv_gather_gemm[_tab]<*>)", "bound": "mfma", "achieved": round(ach, 2),
+    roofline = {"kernel": "pn2_conv_gemm + pn2_conv_gemm_multi (fwd+dgrad incl. the BatchNorm-backward statistics epilogues; symbols conv_dma_gemm[_tab|_ks|_tab_ks2]<*>, conv_gather_gemm[_tab]<*>)", "bound": "mfma", "achieved": round(ach, 2),
                 "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": None, "launches": nl,
                 "avg_launch_us": round(1e3 * ms / nl, 2), "algorithmic_gflop_per_launch": round(fl / nl / 1e9, 3)}
     # the same family against the roofline of EACH launch: a launch cannot finish before max(flops / MFMA peak, algorithmic bytes / HBM peak) - the
@@ -270,7 +270,7 @@ def measure_step(trainer, x, m, dtype, config=None):
             roofline["forward" if tag_ == ":fwd" else "dgrad_with_bn_statistics"] = {
                 "achieved": round(fl_ / (ms_ * 1e-3) / 1e12, 2), "frac": round(fl_ / (ms_ * 1e-3) / 1e12 / peak_tf, 4), "ms": round(ms_, 3),
                 "launches": sum(d_["launches"] for d_ in sel)}
-    traffic = _pmc_traffic(("conv_dma_gemm", "conv_gather_gemm", "conv_dma_gemm_tab", "conv_gather_gemm_tab"), config or {})
+    traffic = _pmc_traffic(("conv_dma_gemm", "conv_gather_gemm", "conv_dma_gemm_tab", "conv_gather_gemm_tab", "conv_dma_gemm_ks", "conv_dma_gemm_tab_ks2"), config or {})
     if traffic is not None:
         roofline["traffic"] = traffic["bytes_per_launch"]
         roofline["traffic_source"] = traffic["source"]
