@@ -377,6 +377,7 @@ DEFER_COLSUM = os.environ.get("PN2_DEFER_COLSUM", "1") == "1"
 SMALL_CIN_DGRAD = os.environ.get("PN2_SMALL_CIN_DGRAD", "1") == "1"  # strided convs with <= 4 input channels: per-pixel data gradient
 GRAD_ALIAS = os.environ.get("PN2_GRAD_ALIAS", "1") == "1"             # sums whose second operand has no other consumer share its gradient storage
 SPLITK = os.environ.get("PN2_SPLITK", "1") == "1"                     # split-K for few-row / long-contraction convs
+TUNE_LOG = None          # debugging: a list that receives (key, code, source) of every conv-tile lookup
 KS2 = os.environ.get("PN2_KS2", "1") == "1"                           # tuner candidates with intra-workgroup split-K (conv_dma_gemm_ks2): one wave of tiles, long K loop
 KSPLIT_MINK = 4096            # shortest contraction that is split (M <= 4096 rows; shorter ones lose to the partial-tile traffic)
 PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == stride convs: data gradient as GEMM + depth-to-space

@@ -9,6 +9,8 @@ from . import core
 from .capi import call, F32, BF16
 from .core import (Act, Bnb, KSPLIT_MINK, TUNE_REPS, WGRAD_SLAB_MB, WGRAD_WGS, _LinearAsConv, _job_table, _p, _stream, _thrash, _w4, rup)
 
+KS_UNTUNED = 3 | (1 << 2) | (2 << 4) | 0x40          # tuning code: LDS-DMA 2-stage ring, 64 x 128 tile, two K groups (see ConvOps._untuned)
+
 
 class ConvOps:
     # ------------------------------------------------------------------ weights
@@ -47,19 +49,38 @@ class ConvOps:
         self.tuner and reused under hipGraph capture).  Returns the code for pn2_conv_desc.flags bits 8..15 (0 = library heuristic).
         ep: the launch carries a BatchNorm-backward epilogue (pn2_conv_gemm_ep): the candidates are timed WITH it (its extra operand reads and
         per-tile work favour other tiles than the plain kernel), writing to scratch destinations."""
-        t = self.tuner
-        if t is None or self.dt != BF16:
+        if self.dt != BF16:
             return 0
+        t = self.tuner
+        if t is None:                    # PN2_AUTOTUNE=0: the library's heuristic tile, inside the class the shape rule names
+            return self._untuned(cd, M, Cout, ep)
         key = ("g", cd.N, cd.H, cd.W, cd.OH, cd.OW, cd.Cin_p, cd.ld_in, Cout, cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w, cd.transposed)
         if ep is not None:
             key = key + ("ep", ep.a.mode, ep.b.mode, 1 if ep.b.out else 0, cd.flags & capi.CONV_ACCUM)
         if key in t:
+            if core.TUNE_LOG is not None:
+                core.TUNE_LOG.append((key, t[key], "hit"))
             return t[key]
         if torch.cuda.is_current_stream_capturing():
-            return 0
+            return self._untuned(cd, M, Cout, ep)
         from . import lockstep as LS
         with LS.pause():                 # the candidates are timed with real launches even inside a lock-step region
             return self._tune_gemm_run(t, key, cd, in_ptr, wp, M, Cout, ep)
+
+    @staticmethod
+    def _ks_class(cd, M, Cout):
+        """The shape rule of the intra-workgroup split-K kernels (see _tune_gemm_run): about one wave of tiles and a long K loop, no global split-K."""
+        ksteps = -(-(cd.KH * cd.KW * cd.Cin_p) // 64)
+        return bool(core.KS2 and Cout > 32 and ksteps >= 9 and -(-M // 64) * -(-Cout // 64) <= 484 and not (cd.flags >> 16) & 15)
+
+    def _untuned(self, cd, M, Cout, ep):
+        """Tuning code without a timing run (PN2_AUTOTUNE=0, or a shape first met under capture).  The split-K class sums in its own fp32 order, so the
+        rule has to hold here too: module eval without the tuner and a tuned Predictor must return the same bits.  2-stage ring, 64 x 128 tile: fits
+        the LDS for every shape of the class.  Launches with a BatchNorm-backward epilogue (training only) keep the heuristic: whether a split-K tile
+        fits next to their operand tiles is only known by trying, which is the tuner's job."""
+        if ep is None and self._ks_class(cd, M, Cout):
+            return KS_UNTUNED
+        return 0
 
     def _tune_gemm_run(self, t, key, cd, in_ptr, wp, M, Cout, ep):
         st = _stream()
@@ -92,8 +113,7 @@ class ConvOps:
         # kernels, which all agree bit for bit.  Whether a shape takes it is therefore a RULE of the shape, not of a timing: about one wave of tiles and a long
         # K loop (what the free tuning run of round 5 picked it for) - every call site that computes the same conv gets the same bits, and the tuner chooses
         # kernel / tile inside the class.
-        ksteps = -(-(cd.KH * cd.KW * cd.Cin_p) // 64)
-        ks2 = core.KS2 and Cout > 32 and ksteps >= 9 and -(-M // 64) * -(-Cout // 64) <= 484 and not (cd.flags >> 16) & 15
+        ks2 = self._ks_class(cd, M, Cout)
         cands, plain = [], []
         for kern in (1, 2, 3):             # 1 register-staged, 2 LDS-DMA with a 3-stage ring, 3 LDS-DMA with a 2-stage ring (more workgroups per CU)
             for bm in (1, 2):

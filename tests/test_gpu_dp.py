@@ -144,8 +144,13 @@ def test_two_ranks_match_single_process_with_averaged_gradients(kind, autotune):
     assert torch.equal(g_a, g_b), "both ranks must hold the same summed gradient"
     assert torch.equal(p_a, p_b) and torch.equal(pf_a, pf_b), "replicas must stay bit-identical (eager steps, then 2 eager + 2 replayed steps)"
     # single process: the two shards one after the other, gradients averaged by hand, same clamp+Adam
-    model, W = _setup(kind, autotune)
-    tr = _trainer(kind, model, None)
+    saved = {k: os.environ.get(k) for k in ("PN2_AUTOTUNE", "PN2_NO_PRETRAINED")}
+    try:
+        model, W = _setup(kind, autotune)
+        tr = _trainer(kind, model, None)
+    finally:                      # _setup's switches are for the worker processes; this process runs the rest of the suite
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     gs = []
     for rank in range(world):
         x, m = _batch(kind, W, rank)

@@ -1147,6 +1147,26 @@ def test_inference_predictor_graph_matches_module_eval():
     print(f"\\ninference 1x3x352x352 + tail (hipGraph replay): {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms/image")
 
 
+def test_untuned_module_eval_returns_the_tuned_predictors_bits(monkeypatch):
+    """The intra-workgroup split-K conv kernels sum a tile's K loop in another fp32 order than the plain kernels, so which shapes take them is a rule of the
+    shape - and the rule has to hold without the tuner too.  PN2_AUTOTUNE=0 (the nn.Module surface then runs the library heuristics; this is the state an
+    earlier test of the suite once leaked into the process) against the Predictor, which always runs tuned tiles: the same bits."""
+    from pn2.infer import Predictor
+    model = _fixture_model(fp32=False).eval()
+    pred = Predictor(model)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(2, 3, 96, 96, generator=g).to(dev)
+    monkeypatch.setenv("PN2_AUTOTUNE", "0")
+    with torch.no_grad():
+        untuned = model(x)
+    monkeypatch.setenv("PN2_AUTOTUNE", "1")
+    with torch.no_grad():
+        tuned = model(x)
+    outs = pred(x)
+    for a, b, c in zip(outs, untuned, tuned):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_predictor_graphs_survive_a_growing_job_table():
     """a captured inference graph bakes in the device job tables of PackCache / BnFoldCache.  A later input shape that takes another kernel
     path registers new jobs (bs >= 34 at 352^2: the ra4 5x5 convs leave the split-K path, M = 121 * bs > 4096, and add BatchNorm fold entries), which replaces
