@@ -245,10 +245,44 @@ __global__ __launch_bounds__(256) void colsum_multi_k(const pn2_colsum_in_job* _
 }
 
 // ------------------------------------------------------------------------------------------ depth-wise 3x3 (+bias, +GELU)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad(float x) {       // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+// erf without branches, on channel PAIRS (v_pk_fma_f32 / v_pk_mul_f32: one instruction per two channels).  The device library's erff is ~150 instructions
+// with data-dependent branches; two of them per element made the depth-wise conv + GELU walks (and the weight-gradient walk that forms dz = dy * gelu'(z))
+// instruction-bound.  Two polynomial pieces, both evaluated, one selected:
+//   |a| <= 0.921875: erf(a) = a + a * p(a^2)                       (degree 5 in a^2)
+//   |a| >  0.921875: erf(a) = sign(a) * (1 - exp(-(t + t * q(t)))), t = min(|a|, 4)   (degree 7: -log(erfc(t)) / t - 1 on [0.921875, 4])
+// Chebyshev fits (coefficients rounded to fp32); max |error| 7.2e-8, max relative error 8.4e-8 against float64 erf over [-6, 6] - the last bit of fp32,
+// as the library function.  NaN propagates through the first piece, +-inf saturates through the second.  Every operation is written out (no contraction
+// left to the compiler), so the scalar wrappers below return the bits of the packed form.
+typedef float dwf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dwf2 dw2(float v) { return dwf2{v, v}; }
+__device__ __forceinline__ dwf2 dwfma(dwf2 a, dwf2 b, dwf2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ dwf2 dw_exp2(dwf2 v) { return dwf2{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
+__device__ __forceinline__ dwf2 erf_nb2(dwf2 a) {
+#pragma clang fp contract(off)
+    const dwf2 t = dwf2{fabsf(a.x), fabsf(a.y)}, s = a * a;
+    dwf2 p = dw2(-0x1.3b07e8p-11f);
+    p = dwfma(p, s, dw2(0x1.477bf2p-8f)); p = dwfma(p, s, dw2(-0x1.b69768p-6f)); p = dwfma(p, s, dw2(0x1.ce1b58p-4f));
+    p = dwfma(p, s, dw2(-0x1.8126ecp-2f)); p = dwfma(p, s, dw2(0x1.06eba6p-3f));
+    const dwf2 ra = dwfma(p, a, a);
+    const dwf2 tc = dwf2{fminf(t.x, 4.f), fminf(t.y, 4.f)};
+    dwf2 q = dw2(-0x1.020fbcp-20f);
+    q = dwfma(q, tc, dw2(0x1.142290p-15f)); q = dwfma(q, tc, dw2(-0x1.fff3bcp-12f)); q = dwfma(q, tc, dw2(0x1.176048p-8f)); q = dwfma(q, tc, dw2(-0x1.9a65fcp-6f));
+    q = dwfma(q, tc, dw2(0x1.b94d44p-4f)); q = dwfma(q, tc, dw2(0x1.44b95ap-1f)); q = dwfma(q, tc, dw2(0x1.07f2d6p-3f));
+    q = dwfma(q, tc, tc);
+    const dwf2 e = dw2(1.f) - dw_exp2(q * dw2(-1.4426950408889634f));          // 1 - exp(-q)
+    return dwf2{t.x > 0.921875f ? copysignf(e.x, a.x) : ra.x, t.y > 0.921875f ? copysignf(e.y, a.y) : ra.y};
 }
+__device__ __forceinline__ dwf2 gelu_f2(dwf2 x) {           // x * Phi(x)
+#pragma clang fp contract(off)
+    return (dw2(0.5f) * x) * (dw2(1.f) + erf_nb2(x * dw2(0.70710678118654752f)));
+}
+__device__ __forceinline__ dwf2 gelu_grad2(dwf2 x) {        // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+#pragma clang fp contract(off)
+    const dwf2 ph = (x * dw2(0.3989422804014327f)) * dw_exp2(((dw2(-0.5f) * x) * x) * dw2(1.4426950408889634f));
+    return dwfma(dw2(0.5f), dw2(1.f) + erf_nb2(x * dw2(0.70710678118654752f)), ph);
+}
+__device__ __forceinline__ float gelu_f(float x) { return gelu_f2(dw2(x)).x; }
+__device__ __forceinline__ float gelu_grad(float x) { return gelu_grad2(dw2(x)).x; }
 
 // z = sum_taps w[c][tap] * x[pixel + tap][c] (+ b[c]) ; y = gelu(z) (optional).  flip: correlate with the mirrored kernel (data gradient).
 template <typename T>
@@ -359,6 +393,247 @@ __global__ __launch_bounds__(256) void dwconv3x3_row_k(const T* __restrict__ x, 
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; c2[r] = n1[r]; n1[r] = n2[r]; }
+    }
+}
+
+// ---- the 3x3 walks again, built for instruction count (round 5; bf16).  What the counters and three ablations said about dwconv3x3_row_k on the PVTv2 Mlp
+// shapes (tools/dw_micro.py, tools/prof_dw_pmc.sh, tools/dw_dbg.py): it fetches 1.13x the algorithmic bytes (the halo rows hit the L2), keeping more loads
+// in flight makes it slower, and with two of the three rows and all stores switched off it still takes 77 of 84 us - while a plain copy of the same tensors
+// streams at 7 TB/s.  It is bound by vector instructions: every step re-unpacks the whole 3x3 window (72 shift / and per 8 channels), multiplies channel
+// by channel, rotates the window through register moves (which also forces a vmcnt wait per step) and guards every load with a branch.  Here:
+//   * the window lives UNPACKED in registers as channel pairs (3 columns x 3 rows x VT/2 float2): only the new column is unpacked per step;
+//   * all arithmetic is packed (v_pk_fma_f32: two channels per instruction), GELU and its derivative too (erf_nb2);
+//   * window slots and the ring of D = 3 prefetched (packed) columns are addressed by compile-time indices (the step loop is unrolled by 3 = a full
+//     rotation of both), so nothing is moved and a column is fetched three steps before it is unpacked;
+//   * halo rows, image border and segment end are buffer-descriptor range checks (offset with bit 31 set: loads return zeros, stores are dropped) - plain
+//     integer arithmetic on byte offsets, no branches in the walk.  Tensors below 2 GB (host).
+// Same order of the nine products per channel as dwconv3x3_row_k (row-major taps on top of the bias), every one a fused multiply-add; the compiler had left
+// a few of the old walk's products unfused (v_pk_mul + v_pk_add), so the two agree to the last fp32 bit or two - 1-ulp flips of the bf16 outputs
+// (tools/dw_check.py: both sit at the bf16 rounding error against a float64 conv).
+// Measured (tools/dw_micro.py, 16 x 88 x 88 x 512): conv + GELU 130 -> 108 us, data gradient 84 -> 62, weight gradient 100 -> 71, with dz = dy * gelu'(z) 155 -> 122;
+// PVT_PraNet_V2 bs 16: 10.93 -> 10.69 ms per step.  The instruction count fell 2.5-3x, the time by a quarter: with loads and stores switched off the walk still
+// takes 52 of 55 us (tools/dw_dbg.py) - what is left is issue-bound at roughly twice the ideal 4 cycles per wave instruction.
+typedef unsigned dw_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned dw_u2 __attribute__((ext_vector_type(2)));
+template <typename T, int VT>
+__device__ __forceinline__ void dw_bload(DwVec<T, VT>& v, __amdgpu_buffer_rsrc_t rs, unsigned off) {
+    constexpr int NW = DwVec<T, VT>::NW;
+    if constexpr (NW == 4) { const dw_u4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); v.w[0] = q.x; v.w[1] = q.y; v.w[2] = q.z; v.w[3] = q.w; }
+    else if constexpr (NW == 2) { const dw_u2 q = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0); v.w[0] = q.x; v.w[1] = q.y; }
+    else v.w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+}
+template <typename T, int VT>
+__device__ __forceinline__ void dw_bstore(const DwVec<T, VT>& v, __amdgpu_buffer_rsrc_t rs, unsigned off) {
+    constexpr int NW = DwVec<T, VT>::NW;
+    if constexpr (NW == 4) { dw_u4 q; q.x = v.w[0]; q.y = v.w[1]; q.z = v.w[2]; q.w = v.w[3]; __builtin_amdgcn_raw_buffer_store_b128(q, rs, off, 0, 0); }
+    else if constexpr (NW == 2) { dw_u2 q; q.x = v.w[0]; q.y = v.w[1]; __builtin_amdgcn_raw_buffer_store_b64(q, rs, off, 0, 0); }
+    else __builtin_amdgcn_raw_buffer_store_b32(v.w[0], rs, off, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dw_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)p >> 32)) << 32) |
+                                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)p)), 0, (int)0x80000000u, 0x00020000);
+}
+constexpr unsigned DW_INV = 0x80000000u;
+// -DPN2_DW_ABLATE (tools/dw_dbg.py): bit 1 of `flip` switches the two halo rows off, bit 2 the stores - what the walk costs without its memory traffic
+#ifdef PN2_DW_ABLATE
+#define DW_ABL_ROW(f, r) (((f) & 2) && (r) != 1)
+#define DW_ABL_ST(f) ((f) & 4)
+#else
+#define DW_ABL_ROW(f, r) false
+#define DW_ABL_ST(f) false
+#endif
+constexpr int DW_D = 3;          // packed columns in flight ahead of the window (= the unroll of the step loop)
+__device__ __forceinline__ unsigned dw_mask(bool ok) { unsigned m = ok ? 0u : DW_INV; asm volatile("" : "+v"(m)); return m; }      // (opaque: see above)
+// bf16 pair -> two floats / back
+__device__ __forceinline__ dwf2 dw_unpk(unsigned w) { return dwf2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+template <int VT>
+__device__ __forceinline__ void dw_unpack_col(const DwVec<bf16_t, VT> (&c)[3], dwf2 (&o)[3][VT / 2]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < VT / 2; ++i) o[r][i] = dw_unpk(c[r].w[i]);
+}
+// the VT weights of tap t as channel pairs, from the [c][9] fp32 master
+template <int VT>
+__device__ __forceinline__ void dw_weights(const float* __restrict__ w, int cv, int flip, int walign, dwf2 (&wr)[9][VT / 2]) {
+    float wf[9 * VT];
+    const float* wp = w + (size_t)cv * VT * 9;
+    if (VT % 4 == 0 && walign) {
+#pragma unroll
+        for (int i = 0; i < 9 * VT / 4; ++i) {
+            const float4 q = reinterpret_cast<const float4*>(wp)[i];
+            wf[4 * i] = q.x; wf[4 * i + 1] = q.y; wf[4 * i + 2] = q.z; wf[4 * i + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9 * VT; ++i) wf[i] = wp[i];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < VT / 2; ++i) wr[t][i] = flip ? dwf2{wf[(2 * i) * 9 + 8 - t], wf[(2 * i + 1) * 9 + 8 - t]} : dwf2{wf[(2 * i) * 9 + t], wf[(2 * i + 1) * 9 + t]};
+}
+
+template <int VT, bool GELU>
+__global__ __launch_bounds__(256) void dwconv3x3_win_k(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, bf16_t* __restrict__ z,
+                                                       bf16_t* __restrict__ y, int N, int H, int W, int C, int flip, int SEG, int SPR, int CVP, int walign) {
+    typedef DwVec<bf16_t, VT> Vec;
+    constexpr int NP = VT / 2;
+    const int CV = C / VT, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);          // consecutive segments (and their halo rows) share an XCD's L2
+    const int s = bid * R + rl, cv = blockIdx.y * CVP + cvl;
+    if (s >= N * H * SPR || cv >= CV) return;
+    const int sx = s % SPR, row = s / SPR, oy = row % H;
+    const int x0 = sx * SEG, x1 = min(W, x0 + SEG), hi = min(x1, W - 1);          // columns x0 - 1 .. hi are read (the image's and the segment's halo)
+    dwf2 wr[9][NP], br[NP];
+    dw_weights<VT>(w, cv, flip & 1, walign, wr);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) br[i] = b ? dwf2{b[cv * VT + 2 * i], b[cv * VT + 2 * i + 1]} : dw2(0.f);
+    const __amdgpu_buffer_rsrc_t rx = dw_rsrc(x), rz = dw_rsrc(z), ry = dw_rsrc(GELU ? y : z);
+    const unsigned Cb = (unsigned)C * 2u, cvb = (unsigned)(cv * VT) * 2u;
+    unsigned rowb[3], rowm[3];          // byte offset of column 0 of the three input rows; bit 31 when the row lies outside the image
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { rowb[r] = (unsigned)((row + r - 1) * W) * Cb + cvb; rowm[r] = dw_mask((unsigned)(oy + r - 1) < (unsigned)H && !DW_ABL_ROW(flip, r)); }
+    const unsigned outb = (unsigned)(row * W) * Cb + cvb;
+    Vec ring[DW_D][3];
+    dwf2 win[3][3][NP];
+    auto fetch = [&](Vec (&c)[3], int ix) {
+        const unsigned co = (unsigned)ix * Cb, cm = dw_mask((unsigned)ix <= (unsigned)hi);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) dw_bload<bf16_t, VT>(c[r], rx, (rowb[r] + co) | rowm[r] | cm);          // (the masks are OR-ed in: an add of two set bits 31 would carry out)
+    };
+    {
+        Vec p0[3], p1[3];
+        fetch(p0, x0 - 1); fetch(p1, x0);
+#pragma unroll
+        for (int k = 0; k < DW_D; ++k) fetch(ring[k], x0 + 1 + k);
+        dw_unpack_col<VT>(p0, win[0]); dw_unpack_col<VT>(p1, win[1]);
+    }
+    for (int xb = x0; xb < x1; xb += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int ox = xb + u;
+            dw_unpack_col<VT>(ring[u], win[(u + 2) % 3]);          // column ox + 1 takes the slot of column ox - 2
+            fetch(ring[u], ox + 1 + DW_D);
+            const unsigned o = (outb + (unsigned)ox * Cb) | dw_mask(ox < x1 && !DW_ABL_ST(flip));
+            dwf2 a[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) a[i] = br[i];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) a[i] = dwfma(wr[r * 3 + k][i], win[(u + k) % 3][r][i], a[i]);
+            Vec ov;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) ov.w[i] = TT<bf16_t>::cvt2(a[i].x, a[i].y);
+            dw_bstore<bf16_t, VT>(ov, rz, o);
+            if constexpr (GELU) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) { const dwf2 g = gelu_f2(a[i]); ov.w[i] = TT<bf16_t>::cvt2(g.x, g.y); }
+                dw_bstore<bf16_t, VT>(ov, ry, o);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // one step at a time: the scheduler otherwise gathers the waits of all three steps at the top of the loop body
+        }
+    }
+}
+
+// weight gradient on the same window: partial[chunk][C*10] as dwconv3x3_wgrad_row_k leaves it (same segments per lane, same order of the sums).
+template <int VT, bool ZP>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_win_k(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ x, float* __restrict__ partial, int N, int H, int W, int C,
+                                                             int SEG, int SPR, int SPC, int CVP, const bf16_t* __restrict__ zpre, bf16_t* __restrict__ dz_out) {
+    typedef DwVec<bf16_t, VT> Vec;
+    typedef DwVec<bf16_t, VT> Vec1;
+    constexpr int NP = VT / 2;
+    extern __shared__ float sh[];            // [R][CVP*VT] reused for each of the 10 sums
+    const int CV = C / VT, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
+    const int chunk = xcd_remap(blockIdx.x, gridDim.x), cv = blockIdx.y * CVP + cvl;
+    const int nseg = N * H * SPR;
+    dwf2 a[10][NP];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) a[t][i] = dw2(0.f);
+    if (cv < CV) {
+        const __amdgpu_buffer_rsrc_t rx = dw_rsrc(x), rd = dw_rsrc(dz), rzp = dw_rsrc(ZP ? zpre : dz), ro = dw_rsrc(ZP ? dz_out : (bf16_t*)nullptr);
+        const unsigned Cb = (unsigned)C * 2u, cvb = (unsigned)(cv * VT) * 2u;
+        const int s1 = min(nseg, (chunk + 1) * SPC);
+        for (int s = chunk * SPC + rl; s < s1; s += R) {
+            const int sx = s % SPR, row = s / SPR, oy = row % H;
+            const int x0 = sx * SEG, x1 = min(W, x0 + SEG), hi = min(x1, W - 1);
+            unsigned rowb[3], rowm[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { rowb[r] = (unsigned)((row + r - 1) * W) * Cb + cvb; rowm[r] = dw_mask((unsigned)(oy + r - 1) < (unsigned)H); }
+            const unsigned outb = (unsigned)(row * W) * Cb + cvb;
+            Vec ring[DW_D][3];
+            Vec1 dring[DW_D], zring[DW_D];
+            dwf2 win[3][3][NP];
+            auto fetch = [&](Vec (&c)[3], int ix) {
+                const unsigned co = (unsigned)ix * Cb, cm = dw_mask((unsigned)ix <= (unsigned)hi);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dw_bload<bf16_t, VT>(c[r], rx, (rowb[r] + co) | rowm[r] | cm);
+            };
+            auto fetch_d = [&](int k, int ox) {          // dz (and the GELU input) of output column ox; zeros past the segment
+                const unsigned o = (outb + (unsigned)ox * Cb) | dw_mask(ox < x1);
+                dw_bload<bf16_t, VT>(dring[k], rd, o);
+                if constexpr (ZP) dw_bload<bf16_t, VT>(zring[k], rzp, o);
+            };
+            {
+                Vec p0[3], p1[3];
+                fetch(p0, x0 - 1); fetch(p1, x0);
+#pragma unroll
+                for (int k = 0; k < DW_D; ++k) { fetch(ring[k], x0 + 1 + k); fetch_d(k, x0 + k); }
+                dw_unpack_col<VT>(p0, win[0]); dw_unpack_col<VT>(p1, win[1]);
+            }
+            for (int xb = x0; xb < x1; xb += 3) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int ox = xb + u;
+                    dw_unpack_col<VT>(ring[u], win[(u + 2) % 3]);
+                    fetch(ring[u], ox + 1 + DW_D);
+                    dwf2 d[NP];
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) d[i] = dw_unpk(dring[u].w[i]);
+                    if constexpr (ZP) {
+                        Vec1 pk;
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) {
+                            const dwf2 g = d[i] * gelu_grad2(dw_unpk(zring[u].w[i]));
+                            pk.w[i] = TT<bf16_t>::cvt2(g.x, g.y);
+                            d[i] = dw_unpk(pk.w[i]);                  // accumulate what the data-gradient pass will read (the rounded value)
+                        }
+                        dw_bstore<bf16_t, VT>(pk, ro, (outb + (unsigned)ox * Cb) | dw_mask(ox < x1));
+                    }
+                    fetch_d(u, ox + DW_D);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) a[9][i] += d[i];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+#pragma unroll
+                            for (int i = 0; i < NP; ++i) a[r * 3 + k][i] = dwfma(d[i], win[(u + k) % 3][r][i], a[r * 3 + k][i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { sh[(rl * CVP + cvl) * VT + 2 * i] = a[t][i].x; sh[(rl * CVP + cvl) * VT + 2 * i + 1] = a[t][i].y; }
+        __syncthreads();
+        if (rl == 0 && cv < CV) {
+#pragma unroll
+            for (int e = 0; e < VT; ++e) {
+                float s_ = 0.f;
+                for (int r = 0; r < R; ++r) s_ += sh[(r * CVP + cvl) * VT + e];
+                const int c = cv * VT + e;
+                partial[(size_t)chunk * C * 10 + (t < 9 ? c * 9 + t : C * 9 + c)] = s_;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1015,9 +1290,15 @@ int pn2_colsum_unit(int dt, int C) { const int V = dt == PN2_F32 ? 4 : 8; int cv
 // channels per thread (VT) and segment length of the depth-wise walks, from a sweep on MI355X (tools/dw_micro.py):
 // kind 0 = conv + GELU (ALU-heavier: 8-byte vectors, more waves), 1 = plain conv / data gradient (16-byte vectors while there are threads to
 // spare), 2 = weight gradient (80 accumulators per 8 channels: 2 channels per thread keeps 8 waves per SIMD).  Short segments for small tensors.
+// PN2_DW_WIN=0: the round-3 walks (dwconv3x3_row_k / dwconv3x3_wgrad_row_k) instead of the window kernels (A/B; bf16 only - fp32 always takes them)
+static int dw_win() { static const int v = [] { const char* e = getenv("PN2_DW_WIN"); return e ? atoi(e) : 1; }(); return v; }
+
 static void dw_row_geometry(int dt, int kind, int N, int H, int W, int C, int& VT, int& SEG, int& SPR) {
     const int vmax = dt == PN2_F32 ? 4 : 8;
     auto threads = [&](int vt, int target) { return (long long)N * H * ((W + target - 1) / target) * (C / vt); };
+    // window kernels: a segment costs ~150 instructions and two memory latencies before its first output (weights, the first five columns); 32-pixel segments
+    // where the tensor still gives 4 resident waves per SIMD twice over (stage 1 of PVTv2-B2 at 352^2: 117 -> 108 us conv + GELU, 71 -> 62 us data gradient)
+    static const int seg_env = [] { const char* e = getenv("PN2_DW_SEG"); return e ? atoi(e) : 32; }();
     int target = 16;
     if (kind == 2) VT = 2;
     else {
@@ -1025,6 +1306,7 @@ static void dw_row_geometry(int dt, int kind, int N, int H, int W, int C, int& V
         while (VT > 2 && ((C % VT) || (VT == vmax && kind == 1 && threads(VT, 16) < 2LL * 256 * 8 * 64))) VT >>= 1;
         if (threads(VT, 16) < 200000) target = 8;
     }
+    if (seg_env > 0 && dt == PN2_BF16 && dw_win() && threads(4, seg_env) >= 2LL * 256 * 4 * 64 * 4) target = seg_env;
     SPR = (W + target - 1) / target; SEG = (W + SPR - 1) / SPR;
 }
 
@@ -1038,6 +1320,17 @@ int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z
     const int cvp = CV >= lanes ? lanes : pow2ceil(CV), R = 256 / cvp, nseg = N * H * SPR;
     const int walign = ((uintptr_t)w & 15) == 0;
     const dim3 grid((nseg + R - 1) / R, (CV + cvp - 1) / cvp);
+    if (dt == PN2_BF16 && dw_win() && !accumulate && (long long)N * H * W * C * 2 < 0x7fff0000LL) {          // the window walk (4 or 2 channels per thread)
+        const int vt = C % 4 == 0 ? 4 : 2, cv4 = C / vt, ln = 512 / vt;
+        const int cvp4 = cv4 >= ln ? ln : pow2ceil(cv4), R4 = 256 / cvp4;
+        const dim3 g4((nseg + R4 - 1) / R4, (cv4 + cvp4 - 1) / cvp4);
+#define PN2_DW_WIN(VT_, G_) hipLaunchKernelGGL((dwconv3x3_win_k<VT_, G_>), g4, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, b, (bf16_t*)z, (bf16_t*)y_gelu, N, H, W, C, flip, SEG, SPR, cvp4, walign)
+        if (vt == 4) { if (y_gelu) PN2_DW_WIN(4, true); else PN2_DW_WIN(4, false); }
+        else { if (y_gelu) PN2_DW_WIN(2, true); else PN2_DW_WIN(2, false); }
+#undef PN2_DW_WIN
+        PN2_CHECK_LAUNCH();
+        return 0;
+    }
     if (dt == PN2_BF16) { DW_VT(VT, { hipLaunchKernelGGL((dwconv3x3_row_k<bf16_t, VT_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, b, (bf16_t*)z, (bf16_t*)y_gelu,
                                                       N, H, W, C, flip, accumulate, SEG, SPR, cvp, walign); }) }
     else if (dt == PN2_F32) {
@@ -1059,6 +1352,8 @@ int pn2_gelu_bwd(int dt, const void* dy, const void* z, void* dz, long long n, v
 
 static void dw_wgrad_geometry(int dt, int N, int H, int W, int C, int& VT, int& SEG, int& SPR, int& SPC, int& cvp, int& nchunk) {
     dw_row_geometry(dt, 2, N, H, W, C, VT, SEG, SPR);
+    const bool win = dt == PN2_BF16 && dw_win() && (long long)N * H * W * C * 2 < 0x7fff0000LL;
+    if (win) VT = C % 4 == 0 ? 4 : 2;          // window kernel: 4 channels per thread (20 packed accumulators), still 256 contiguous bytes of a pixel per block
     const int CV = C / VT, lanes = (dt == PN2_F32 ? 32 : 64) / VT * 2;          // 256 contiguous bytes of one pixel per block
     cvp = CV >= lanes ? lanes : pow2ceil(CV);
     const int R = 256 / cvp, gy = (CV + cvp - 1) / cvp, nseg = N * H * SPR;
@@ -1082,6 +1377,14 @@ int pn2_dwconv3x3_wgrad(int dt, const void* dz, const void* x, float* partial, i
     const int CV = C / VT;
     const dim3 grid(nchunk, (CV + cvp - 1) / cvp);
     const size_t lds = (size_t)256 * VT * 4;
+    if (dt == PN2_BF16 && dw_win() && (long long)N * H * W * C * 2 < 0x7fff0000LL) {
+#define PN2_DW_WG(VT_, Z_) hipLaunchKernelGGL((dwconv3x3_wgrad_win_k<VT_, Z_>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)x, partial, N, H, W, C, SEG, SPR, SPC, cvp, (const bf16_t*)zpre, (bf16_t*)dz_out)
+        if (VT == 4) { if (zpre) PN2_DW_WG(4, true); else PN2_DW_WG(4, false); }
+        else { if (zpre) PN2_DW_WG(2, true); else PN2_DW_WG(2, false); }
+#undef PN2_DW_WG
+        PN2_CHECK_LAUNCH();
+        return 0;
+    }
     if (dt == PN2_BF16) { DW_VT(VT, { hipLaunchKernelGGL((dwconv3x3_wgrad_row_k<bf16_t, VT_>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)x, partial,
                                                       N, H, W, C, SEG, SPR, SPC, cvp, (const bf16_t*)zpre, (bf16_t*)dz_out); }) }
     else if (dt == PN2_F32) {
