@@ -180,6 +180,8 @@ class PyramidVisionTransformerImpr(nn.Module):
     def _build_features(self, eng, x):
         """forward_features :307-341: four NHWC feature maps (64, 128, 320, 512 channels for b2)."""
         outs = []
+        if eng.training:          # all DropPath draws of the forward at once (two per block with a non-zero rate, in block order)
+            eng.drop_path_plan([p for i in range(4) for blk in getattr(self, f"block{i + 1}") for p in 2 * (getattr(blk.drop_path, "drop_prob", 0.0),)], x.N)
         for i in range(4):
             x = getattr(self, f"patch_embed{i + 1}")._build(eng, x)
             for blk in getattr(self, f"block{i + 1}"):

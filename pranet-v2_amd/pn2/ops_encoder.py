@@ -10,6 +10,9 @@ from .capi import call, F32, BF16
 from .core import (Act, _PERMS, _p, _stream, rup)
 
 
+_DP_KEEP = {}          # (drop probabilities, batch, device) -> [K][N] table of keep probabilities (drop_path_plan)
+
+
 class EncoderOps:
     def layernorm(self, x, ln):
         """nn.LayerNorm over the channel axis (tokens = pixels)."""
@@ -64,12 +67,35 @@ class EncoderOps:
         self.record(bwd)
         return y
 
+    def drop_path_plan(self, drop_probs, N):
+        """The DropPath draws of a whole forward in TWO launches (one bernoulli over a [K][N] table of keep probabilities, one divide) instead of two per
+        residual branch (60 tiny launches per PVTv2-B2 step): `drop_probs` = the non-zero drop probabilities in the order drop_path / drop_path_add will ask
+        for them.  A request that does not match the plan (other probability, other batch) falls back to its own draw."""
+        ps = [float(p) for p in drop_probs if p > 0.0]
+        self._dp_rows, self._dp_next = None, 0
+        if not ps or not self.training:
+            return
+        key = (tuple(ps), N, str(self.dev))
+        keep = _DP_KEEP.get(key)
+        if keep is None:
+            keep = _DP_KEEP[key] = (1.0 - torch.tensor(ps, dtype=torch.float32, device=self.dev)).reshape(-1, 1).expand(len(ps), N).contiguous()
+        self._dp_rows = (torch.bernoulli(keep).div_(keep), ps)
+
+    def _dp_scale(self, N, drop_prob):
+        """[N] fp32: keep mask / keep probability of the next DropPath (from the plan's table when it matches)."""
+        rows = getattr(self, "_dp_rows", None)
+        if rows is not None and self._dp_next < len(rows[1]) and rows[1][self._dp_next] == float(drop_prob) and rows[0].shape[1] == N:
+            sc = rows[0][self._dp_next]
+            self._dp_next += 1
+            return sc
+        keep = 1.0 - drop_prob
+        return torch.empty(N, dtype=torch.float32, device=self.dev).bernoulli_(keep).div_(keep)
+
     def drop_path(self, x, drop_prob):
         """timm DropPath in train mode: every sample is kept with probability 1 - drop_prob and rescaled by 1 / keep."""
         if drop_prob == 0.0 or not self.training:
             return x
-        keep = 1.0 - drop_prob
-        sc = torch.empty(x.N, dtype=torch.float32, device=self.dev).bernoulli_(keep).div_(keep)
+        sc = self._dp_scale(x.N, drop_prob)
         assert x.ld == x.Cp
         y = Act(self, self.empty(x.N, x.H, x.W, x.Cp), x.C, x.gw, x.gwp, self.dt)
         per = x.H * x.W * x.Cp
@@ -87,8 +113,7 @@ class EncoderOps:
         """res + DropPath(x) in one pass (Block.forward pvtv2.py:148-149 in train mode); plain add when nothing is dropped."""
         if drop_prob == 0.0 or not self.training:
             return self.add(res, x)
-        keep = 1.0 - drop_prob
-        sc = torch.empty(x.N, dtype=torch.float32, device=self.dev).bernoulli_(keep).div_(keep)
+        sc = self._dp_scale(x.N, drop_prob)
         assert x.ld == x.Cp and res.ld == res.Cp and (res.N, res.H, res.W, res.Cp) == (x.N, x.H, x.W, x.Cp) and res.dt == x.dt == self.dt
         y = Act(self, self.empty(x.N, x.H, x.W, x.Cp), x.C, x.gw, x.gwp, self.dt)
         per = x.H * x.W * x.Cp
@@ -101,8 +126,15 @@ class EncoderOps:
             gx, _ = x.grad_sink()
             call.pn2_scale_samples(self.dt, _p(dy), _p(gx), _p(sc), C.c_void_p(0), x.N, per, st)
             if res.requires_grad:
-                gr, acc = res.grad_sink()
-                call.pn2_copy(self.dt, _p(dy), dy.stride(2), self.dt, _p(gr), gr.stride(2), x.M, x.Cp, acc, st)
+                if (res.grad is None and res.galias is None and res.parent is None and not res.grad_written and tuple(dy.shape) == tuple(res.t.shape)
+                        and dy.dtype == res.t.dtype and dy.is_contiguous()):
+                    # d(y)/d(res) = 1: dy IS the residual stream's gradient - share the buffer (it is dead here: gx has been formed; the LayerNorm backward of
+                    # the branch accumulates into it in place) instead of copying it per residual add
+                    res.grad = dy
+                    res.grad_written = True
+                else:
+                    gr, acc = res.grad_sink()
+                    call.pn2_copy(self.dt, _p(dy), dy.stride(2), self.dt, _p(gr), gr.stride(2), x.M, x.Cp, acc, st)
         self.record(bwd)
         return y
 

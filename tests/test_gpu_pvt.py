@@ -257,6 +257,44 @@ def test_pvt_trainer_step_and_graph_replay():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+def test_drop_path_plan_draws_and_residual_gradient_alias():
+    """Engine.drop_path_plan: the DropPath draws of a forward from ONE bernoulli over a [K][N] table of keep probabilities (pvtv2.py:125,148-149 asks for two
+    per block); drop_path_add takes its rows in order, a request that does not match draws for itself; the residual's gradient shares dy's buffer."""
+    from pn2 import BF16
+    from pn2.engine import Engine
+    from pn2.graph import _seed_grad
+    torch.manual_seed(3)
+    N = 4096
+    eng = Engine(BF16, True, need_grad=True)
+    eng.drop_path_plan([0.0, 0.1, 0.1, 0.3, 0.3], N)
+    table, ps = eng._dp_rows
+    assert ps == [0.1, 0.1, 0.3, 0.3] and tuple(table.shape) == (4, N)
+    for k, p in enumerate(ps):
+        vals = torch.unique(table[k]).tolist()
+        assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / (1.0 - p)) < 1e-6
+        assert abs(float((table[k] > 0).float().mean()) - (1.0 - p)) < 4 * (p * (1 - p) / N) ** 0.5          # keep rate within 4 sigma
+    assert not torch.equal(table[0] > 0, table[1] > 0)
+    res = torch.randn(N, 16, 2, 2, device=dev); x = torch.randn(N, 16, 2, 2, device=dev)
+    ra, xa = eng.from_nchw(res, requires_grad=True), eng.from_nchw(x, requires_grad=True)
+    y = eng.drop_path_add(ra, xa, 0.1)
+    assert eng._dp_next == 1
+    sc = table[0].view(N, 1, 1, 1)
+    want = torch.addcmul(res.bfloat16().double(), x.bfloat16().double(), sc.double())
+    assert float((eng.to_nchw(y).double() - want).abs().max()) <= 2 ** -8 * float(want.abs().max())          # one bf16 rounding of the result
+    xb = eng.from_nchw(torch.randn(N, 16, 2, 2, device=dev), requires_grad=True)
+    z = eng.drop_path_add(y, xb, 0.2)          # not in the plan at this position: own draw, the plan's cursor stays
+    assert eng._dp_next == 1
+    gy = torch.randn(N, 16, 2, 2, device=dev)
+    _seed_grad(z, gy)
+    eng.backward()
+    gz = gy.bfloat16()
+    assert y.grad.data_ptr() == z.grad.data_ptr() and ra.grad.data_ptr() == z.grad.data_ptr(), "the residual stream's gradient is one buffer"
+    assert torch.equal(ra.grad[..., :16].permute(0, 3, 1, 2), gz)
+    eng2 = Engine(BF16, False, need_grad=False)
+    eng2.drop_path_plan([0.1, 0.1], N)
+    assert eng2._dp_rows is None          # eval: nothing is drawn
+
+
 @pytest.mark.parametrize("dtn", ["fp32", "bf16"])
 def test_sliding_window_depthwise_edge_geometries(dtn):
     """The row-segment walks of the depth-wise 3x3 (+GELU) kernels at awkward sizes: one-pixel and one-row images, widths that are not a
