@@ -528,6 +528,11 @@ def main(argv=None):
                 out["dp1"]["overhead_frac"] = round(out["dp1"]["ms_per_step"] / out["ms_per_step"] - 1.0, 4)
         if world == 1 and not args.no_cpu_baseline and args.model != "emcad":
             out["cpu_baseline"] = cpu_baseline(args.size)
+        try:          # libraries that printf to the C stdout of a pipe (RCCL's version banner) are flushed first: the JSON line stays the last line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

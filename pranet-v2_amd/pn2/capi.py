@@ -180,6 +180,7 @@ SIGNATURES = {
     "pn2_conv_gemm_gated": [I, P, P, P, P, P, P, P, P],
     "pn2_conv_gemm_affine": [I, P, P, P, P, P, P, I, P, P],
     "pn2_loss_weights": [P, P, I, I, I, I, P],
+    "pn2_loss_weights_clear": [P, P, I, I, I, I, P, I, P],
     "pn2_loss_blocks": [I],
     "pn2_structure_loss_fwd": [P, LL, I, P, P, P, P, P, P, I, I, P],
     "pn2_structure_loss_bwd": [P, P, LL, I, P, P, P, P, FL, I, I, P],
@@ -189,7 +190,7 @@ SIGNATURES = {
     "pn2_dsra_tail_bwd": [C.POINTER(TailDesc), P, P, P, P, FL, P, LL, P],
     "pn2_dsra_tail_fused_ok": [C.POINTER(TailDesc)],
     "pn2_dsra_tail_fused_scratch": [C.POINTER(TailDesc)],
-    "pn2_dsra_tail_fwd_bwd": [C.POINTER(TailDesc), P, P, P, P, P, P, P, P, FL, P, LL, P],
+    "pn2_dsra_tail_fwd_bwd": [C.POINTER(TailDesc), P, P, P, P, P, P, P, P, FL, P, LL, P, P],
     "pn2_layernorm_fwd": [I, P, I, P, I, I, I, P, P, FL, P, P, P],
     "pn2_ln_slots": [I, I],
     "pn2_rows_blocks": [I, I],

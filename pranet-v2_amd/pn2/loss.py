@@ -8,8 +8,12 @@ import ctypes as C
 
 import torch
 
+import os
+
 from .capi import F32, call
 from .engine import _p, _stream
+
+TAIL_ISUM = os.environ.get("PN2_TAIL_ISUM", "1") == "1"          # 0: the one-pass tail without the fp64 image-sum accumulators (three launches; A/B)
 
 
 def loss_forward(buf, P, mask, N, HW, H, W):
@@ -74,7 +78,12 @@ def tail_forward_backward(eng, tail, lat, P, mask, N, H, W, gscale=1.0):
         d.maps[j].dsrc, d.maps[j].accumulate = g.data_ptr(), acc
     HW = H * W
     weit = eng.alloc((N, HW), torch.float32)
-    call.pn2_loss_weights(_p(mask), _p(weit), N, H, W, 31, _stream())
+    # the image sums are accumulated by the walk itself (fp64 atomics into isum, zeroed by the weights launch in front of it): two launches instead of three
+    isum = eng.alloc((P * N * 5,), torch.float64) if (TAIL_ISUM and P * N <= 1024) else None
+    if isum is not None:
+        call.pn2_loss_weights_clear(_p(mask), _p(weit), N, H, W, 31, _p(isum), P * N * 5, _stream())
+    else:
+        call.pn2_loss_weights(_p(mask), _p(weit), N, H, W, 31, _stream())
     nb = call.pn2_dsra_tail_blocks(H)
     partial = eng.alloc((P, N, nb, 5), torch.float32)
     sums = eng.alloc((P, N, 4), torch.float32)
@@ -83,7 +92,8 @@ def tail_forward_backward(eng, tail, lat, P, mask, N, H, W, gscale=1.0):
     loss = torch.empty((P + 1,), dtype=torch.float32, device=lat.device)
     need = int(call.pn2_dsra_tail_fused_scratch(C.byref(d)))
     scratch = eng.alloc((need,), torch.float32)
-    call.pn2_dsra_tail_fwd_bwd(C.byref(d), _p(lat), _p(mask), _p(weit), _p(partial), _p(sums), _p(wsum), _p(per), _p(loss), float(gscale), _p(scratch), need, _stream())
+    call.pn2_dsra_tail_fwd_bwd(C.byref(d), _p(lat), _p(mask), _p(weit), _p(partial), _p(sums), _p(wsum), _p(per), _p(loss), float(gscale), _p(scratch), need,
+                               _p(isum), _stream())
     return loss
 
 

@@ -981,14 +981,19 @@ def test_dsra_tail_band_kernels_vs_oracle_and_row_kernels(cfg, monkeypatch):
     ups32 = [F.interpolate(t[:, None], size=(S, S), mode="bilinear", align_corners=bool(ac)).reshape(N, S, S) for t in src_cpu]
     res = {}
     pow2 = ac == 0 and S % 32 == 0 and S <= 512 and S // 32 >= 1 and all(S // h in (8, 16, 32) for h in sizes)      # what the one-pass kernel serves
-    for band in ("F", "1", "0"):          # the one-pass entry (default in the trainer) / band kernels / row kernels of the two-call path
-        monkeypatch.setenv("PN2_TAIL_BAND", "2" if band == "F" else band)
+    # the one-pass entry with the fp64 image-sum accumulators (default in the trainer: two launches) / without (three launches) / band kernels / row kernels
+    for band in ("Fi", "F", "1", "0"):
+        monkeypatch.setenv("PN2_TAIL_BAND", "2" if band[0] == "F" else band)
         srcs = [t.to(dev) for t in src_cpu]
         base = [torch.randn_like(t) * float(ref_grads[j].abs().max()) for j, t in enumerate(srcs)]      # pre-existing gradient of the sinks that accumulate
         dsrcs = [base[j].clone() if j % 3 == 0 else torch.empty_like(t) for j, t in enumerate(srcs)]
         mask = mask_cpu.reshape(N, S, S).to(dev).contiguous()
         weit = torch.empty_like(mask)
-        call.pn2_loss_weights(P(mask), P(weit), N, S, S, 31, st)
+        isum = torch.full((4 * N * 5,), 7.0, dtype=torch.float64, device=dev) if band == "Fi" else None          # (pn2_loss_weights_clear zeroes it)
+        if isum is not None:
+            call.pn2_loss_weights_clear(P(mask), P(weit), N, S, S, 31, P(isum), isum.numel(), st)
+        else:
+            call.pn2_loss_weights(P(mask), P(weit), N, S, S, 31, st)
         d = capi.TailDesc()
         d.N, d.OH, d.OW, d.P, d.align_corners = N, S, S, 4, ac
         for j, (s_, ds) in enumerate(zip(srcs, dsrcs)):
@@ -1001,13 +1006,13 @@ def test_dsra_tail_band_kernels_vs_oracle_and_row_kernels(cfg, monkeypatch):
         partial = torch.empty(4, N, nb, 5, device=dev)
         sums, wsum, loss = torch.empty(4, N, 4, device=dev), torch.empty(N, device=dev), torch.empty(5, device=dev)
         fused = int(call.pn2_dsra_tail_fused_ok(C.byref(d)))
-        assert fused == (1 if band == "F" and pow2 else 0), (band, fused, pow2)
-        if band == "F":
+        assert fused == (1 if band[0] == "F" and pow2 else 0), (band, fused, pow2)
+        if band[0] == "F":
             if not fused:
                 continue
             need = int(call.pn2_dsra_tail_fused_scratch(C.byref(d)))
             scratch, per = torch.empty(need, device=dev), torch.empty(4, N, device=dev)
-            call.pn2_dsra_tail_fwd_bwd(C.byref(d), P(lat), P(mask), P(weit), P(partial), P(sums), P(wsum), P(per), P(loss), 1.0, P(scratch), need, st)
+            call.pn2_dsra_tail_fwd_bwd(C.byref(d), P(lat), P(mask), P(weit), P(partial), P(sums), P(wsum), P(per), P(loss), 1.0, P(scratch), need, P(isum), st)
         else:
             need = int(call.pn2_dsra_tail_scratch(C.byref(d)))
             assert (need > 0) == (band == "1")
@@ -1023,8 +1028,11 @@ def test_dsra_tail_band_kernels_vs_oracle_and_row_kernels(cfg, monkeypatch):
         for j in range(8):
             got = dsrcs[j] - base[j] if j % 3 == 0 else dsrcs[j]
             assert relmax(got, ref_grads[j]) < 2e-4 and rell2(got, ref_grads[j]) < 2e-5, (band, j, relmax(got, ref_grads[j]), rell2(got, ref_grads[j]))
-        res[band] = (lat.clone(), sums.clone(), wsum.clone())
+        res[band] = (lat.clone(), sums.clone(), wsum.clone(), loss.clone(), [t.clone() for j, t in enumerate(dsrcs) if j % 3])          # (the accumulating sinks start from another random base)
     assert relmax(res["1"][0], res["0"][0]) < 1e-6
+    if "Fi" in res:     # sums of <= a few thousand fp32 terms are exact in double: the atomically accumulated image sums give the bits of the reduced partial rows
+        a, b = res["Fi"], res["F"]
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and all(torch.equal(x, y) for x, y in zip(a[4], b[4]))
     if "F" in res:      # the same maps and per-image sums as the two-call path (another summation order)
         assert relmax(res["F"][0], res["1"][0]) < 1e-6 and relmax(res["F"][1], res["1"][1]) < 2e-6 and relmax(res["F"][2], res["1"][2]) < 2e-6
     # short / missing scratch: the backward falls back to the row kernels instead of failing
