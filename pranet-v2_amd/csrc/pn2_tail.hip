@@ -1037,8 +1037,10 @@ __global__ __launch_bounds__(256) void tail_one_k(pn2_tail_desc d, tail_one_aux 
         else if (k == 3) val = (HW_ + 2.f * tot(p * 4 + 1)) + MW_;                              // sum p*w + sum m*w
         else val = 2.f * HW_;
         partial[(((size_t)p * d.N + n) * nb + band) * 5 + k] = val;
-        // the image's sums, formed on the way (isum[pair][5], zero on entry): fp64 hardware atomics.  A sum of a few thousand fp32 terms is exact in double, so
-        // the order in which the bands arrive changes no bit: tail_one_fin_k reads five doubles per image instead of reducing nb partial rows per workgroup
+        // the image's sums, formed on the way (isum[pair][5], zero on entry): fp64 hardware atomics.  Adding n fp32 values in double is exact while their
+        // magnitudes span less than 2^(29 - log2 n) - here n = nb <= 64 band sums of one image, each over 8 rows of pixels (positive weights: within a few
+        // binades of each other) - so the order in which the bands arrive changes no bit (beyond that span an order dependence would sit at the 2^-53 level,
+        // below the conversion to fp32 except on rounding ties).  tail_one_fin_k reads five doubles per image instead of reducing nb partial rows per workgroup
         if (isum) unsafeAtomicAdd(isum + ((size_t)p * d.N + n) * 5 + k, (double)val);
     }
 }
