@@ -229,11 +229,12 @@ int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn
 typedef struct pn2_bn_segs { int nseg; int c0[4]; int nblk[4]; int ldp[4]; const float* p1[4]; const float* p2[4]; } pn2_bn_segs;
 int pn2_bn_bwd_finalize_seg(const pn2_bn_segs* segs, const pn2_bn_desc* d, const float* gamma, const float* invstd,
                             float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);
-/* pn2_bn_bwd_finalize_seg + pn2_bn_bwd_apply in ONE launch, for segments that are all PN2_BNB_ACC accumulators (nblk = -1): every workgroup forms the
- * coefficient rows of its channels from the accumulators in its prologue (LDS), workgroup 0 also leaves dgamma / dbeta.  Same arithmetic as the two launches.
+/* pn2_bn_bwd_finalize_seg + pn2_bn_bwd_apply in ONE launch, for segments that are all PN2_BNB_ACC accumulators (nblk = -1): the first ceil(Cp / 64) workgroups
+ * form the coefficient rows of 64 channels each, publish them through `pub` ([3][Cp] floats + one counter word, ZERO on entry) and leave dgamma / dbeta; every
+ * workgroup waits for them and takes the rows into LDS.  Same arithmetic as the two launches.
  * 16-byte rows of one dtype only (the row-streaming kernels), Cp <= 2048; -2 otherwise (use the two launches). */
 int pn2_bn_bwd_apply_acc(int dt, const void* dy, int ld_dy, const void* y, int ld_y, const void* x, int ld_x, int M, int Cp, const float* mean, const float* invstd,
-                         const pn2_bn_segs* segs, const pn2_bn_desc* d, const float* gamma, float* dgamma, float* dbeta, int accumulate,
+                         const pn2_bn_segs* segs, const pn2_bn_desc* d, const float* gamma, float* dgamma, float* dbeta, int accumulate, float* pub,
                          void* dx, int ld_dx, void* dres, int ld_dres, int dres_accum, const float* mask_scale, const float* mask_shift, int relu6, void* stream);
 /* ---- table-driven launches of the BatchNorm family.  Independent chains of a model (the three RFB modules and their three branches each, pranet.py:46-83;
  * the three parallel 3x3 convs of a Res2Net stage block, Res2Net_v1b.py:66-69) advance in LOCK STEP: one launch per kernel kind and position in the

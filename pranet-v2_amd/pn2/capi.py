@@ -167,7 +167,7 @@ SIGNATURES = {
     "pn2_bn_bwd_finalize": [P, P, I, C.POINTER(BnDesc), P, P, P, P, I, P, P],
     "pn2_bn_bwd_finalize_seg": [C.POINTER(BnSegs), C.POINTER(BnDesc), P, P, P, P, I, P, P],
     "pn2_bn_bwd_apply": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, I, I, P, P, I, P],
-    "pn2_bn_bwd_apply_acc": [I, P, I, P, I, P, I, I, I, P, P, C.POINTER(BnSegs), C.POINTER(BnDesc), P, P, P, I, P, I, P, I, I, P, P, I, P],
+    "pn2_bn_bwd_apply_acc": [I, P, I, P, I, P, I, I, I, P, P, C.POINTER(BnSegs), C.POINTER(BnDesc), P, P, P, I, P, P, I, P, I, I, P, P, I, P],
     "pn2_maxpool3x3s2_fwd": [I, P, I, P, I, P, I, I, I, I, I, I, P],
     "pn2_maxpool3x3s2_bwd": [I, P, I, P, P, I, I, I, I, I, I, I, P],
     "pn2_avgpool_fwd": [I, P, I, P, I, I, I, I, I, I, I, I, I, I, I, P],

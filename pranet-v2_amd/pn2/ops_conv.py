@@ -513,7 +513,7 @@ class ConvOps:
             elif acc_apply is not None:
                 sg_, gg_, gb_, ga_ = acc_apply
                 call.pn2_bn_bwd_apply_acc(self.dt, _p(dy), dy.stride(2), ymask.ptr if ymask else nul, ymask.ld if ymask else 0, _p(raw), raw_ld, M, Cout_p, _p(mean), _p(invstd),
-                                          C.byref(sg_), C.byref(bd), _p(bn.weight), _p(gg_), _p(gb_), ga_, _p(draw), Cout_p,
+                                          C.byref(sg_), C.byref(bd), _p(bn.weight), _p(gg_), _p(gb_), ga_, _p(self.zbuf((3 * Cout_p + 4,), torch.float32)), _p(draw), Cout_p,
                                           _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), r6, st)
             else:
                 call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
