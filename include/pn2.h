@@ -383,6 +383,11 @@ int pn2_colsum_finalize_multi(const pn2_colsum_job* jobs_dev, const int* block_s
 /* DWConv (pvtv2.py:363-374, groups = C, 3x3, pad 1) [+ bias] [+ nn.GELU of Mlp.forward :45]: z = dw(x) + b (kept for the backward),
  * y_gelu = gelu(z) when non-null.  flip=1 correlates with the mirrored kernel = data gradient of the same conv.  w [C][9] fp32. */
 int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z, void* y_gelu, int N, int H, int W, int C, int flip, int accumulate, void* stream);
+/* The data-gradient form (no GELU, no accumulate; bf16 window kernels only) that also leaves cpart[nblk][C]: per-workgroup column sums of the stored result - the
+ * bias gradient of the nn.Linear whose output gradient this is (Mlp.fc1, pvtv2.py:49-56) without a second read of that tensor.  nblk = pn2_dwconv3x3_colsum_blocks()
+ * (< 0: geometry not served).  Finish with pn2_colsum_finalize. */
+int pn2_dwconv3x3_colsum_blocks(int dt, int N, int H, int W, int C);
+int pn2_dwconv3x3_colsum(int dt, const void* x, const float* w, const float* b, void* z, int N, int H, int W, int C, int flip, float* cpart, int nblk, void* stream);
 int pn2_gelu_bwd(int dt, const void* dy, const void* z, void* dz, long long n, void* stream);      /* dz = dy * gelu'(z), exact erf form */
 /* partial[nblk][C*10]: columns c*9+tap = dW, C*9+c = dbias ; nblk = pn2_dwconv3x3_wgrad_blocks(dt, N, H, W, C) ; finish with pn2_colsum_finalize.
  * zpre non-null: `dz` holds dy (the gradient of the GELU output), dz = dy * gelu'(zpre) is formed in the same pass and written to dz_out

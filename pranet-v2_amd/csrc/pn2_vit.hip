@@ -474,29 +474,41 @@ __device__ __forceinline__ void dw_weights(const float* __restrict__ w, int cv, 
         for (int i = 0; i < VT / 2; ++i) wr[t][i] = flip ? dwf2{wf[(2 * i) * 9 + 8 - t], wf[(2 * i + 1) * 9 + 8 - t]} : dwf2{wf[(2 * i) * 9 + t], wf[(2 * i + 1) * 9 + t]};
 }
 
-template <int VT, bool GELU>
+// CS: the kernel also leaves the column sums of what it stores (as stored: the rounded values) per workgroup, cpart[gridDim.x][C] - the bias gradient of the
+// nn.Linear in front (Mlp.fc1, whose dY this data gradient IS) without the second read of the largest gradient tensor of the block by the column-sum pass.
+template <int VT, bool GELU, bool CS = false>
 __global__ __launch_bounds__(256) void dwconv3x3_win_k(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, bf16_t* __restrict__ z,
-                                                       bf16_t* __restrict__ y, int N, int H, int W, int C, int flip, int SEG, int SPR, int CVP, int walign) {
+                                                       bf16_t* __restrict__ y, int N, int H, int W, int C, int flip, int SEG, int SPR, int CVP, int walign,
+                                                       float* __restrict__ cpart = nullptr) {
     typedef DwVec<bf16_t, VT> Vec;
     constexpr int NP = VT / 2;
     const int CV = C / VT, R = 256 / CVP, cvl = threadIdx.x % CVP, rl = threadIdx.x / CVP;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);          // consecutive segments (and their halo rows) share an XCD's L2
-    const int s = bid * R + rl, cv = blockIdx.y * CVP + cvl;
-    if (s >= N * H * SPR || cv >= CV) return;
+    int s = bid * R + rl;
+    const int cv = blockIdx.y * CVP + cvl;
+    bool live = true;
+    if (s >= N * H * SPR || cv >= CV) {
+        if constexpr (!CS) return;
+        live = false; s = 0;          // (CS: every thread reaches the workgroup's column-sum exchange; a dead one walks no step)
+    }
+    const int cvx = live ? cv : 0;
     const int sx = s % SPR, row = s / SPR, oy = row % H;
-    const int x0 = sx * SEG, x1 = min(W, x0 + SEG), hi = min(x1, W - 1);          // columns x0 - 1 .. hi are read (the image's and the segment's halo)
+    const int x0 = sx * SEG, x1 = live ? min(W, x0 + SEG) : x0, hi = min(x1, W - 1);          // columns x0 - 1 .. hi are read (the image's and the segment's halo)
     dwf2 wr[9][NP], br[NP];
-    dw_weights<VT>(w, cv, flip & 1, walign, wr);
+    dw_weights<VT>(w, cvx, flip & 1, walign, wr);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) br[i] = b ? dwf2{b[cv * VT + 2 * i], b[cv * VT + 2 * i + 1]} : dw2(0.f);
+    for (int i = 0; i < NP; ++i) br[i] = b ? dwf2{b[cvx * VT + 2 * i], b[cvx * VT + 2 * i + 1]} : dw2(0.f);
     const __amdgpu_buffer_rsrc_t rx = dw_rsrc(x), rz = dw_rsrc(z), ry = dw_rsrc(GELU ? y : z);
-    const unsigned Cb = (unsigned)C * 2u, cvb = (unsigned)(cv * VT) * 2u;
+    const unsigned Cb = (unsigned)C * 2u, cvb = (unsigned)(cvx * VT) * 2u;
     unsigned rowb[3], rowm[3];          // byte offset of column 0 of the three input rows; bit 31 when the row lies outside the image
 #pragma unroll
     for (int r = 0; r < 3; ++r) { rowb[r] = (unsigned)((row + r - 1) * W) * Cb + cvb; rowm[r] = dw_mask((unsigned)(oy + r - 1) < (unsigned)H && !DW_ABL_ROW(flip, r)); }
     const unsigned outb = (unsigned)(row * W) * Cb + cvb;
     Vec ring[DW_D][3];
     dwf2 win[3][3][NP];
+    dwf2 csum[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) csum[i] = dw2(0.f);
     auto fetch = [&](Vec (&c)[3], int ix) {
         const unsigned co = (unsigned)ix * Cb, cm = dw_mask((unsigned)ix <= (unsigned)hi);
 #pragma unroll
@@ -529,12 +541,32 @@ __global__ __launch_bounds__(256) void dwconv3x3_win_k(const bf16_t* __restrict_
 #pragma unroll
             for (int i = 0; i < NP; ++i) ov.w[i] = TT<bf16_t>::cvt2(a[i].x, a[i].y);
             dw_bstore<bf16_t, VT>(ov, rz, o);
+            if constexpr (CS) {
+                if (ox < x1) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) csum[i] += dw_unpk(ov.w[i]);
+                }
+            }
             if constexpr (GELU) {
 #pragma unroll
                 for (int i = 0; i < NP; ++i) { const dwf2 g = gelu_f2(a[i]); ov.w[i] = TT<bf16_t>::cvt2(g.x, g.y); }
                 dw_bstore<bf16_t, VT>(ov, ry, o);
             }
             __builtin_amdgcn_sched_barrier(0);          // one step at a time: the scheduler otherwise gathers the waits of all three steps at the top of the loop body
+        }
+    }
+    if constexpr (CS) {          // the R segment lanes of a channel group meet in LDS (fixed order); one partial row per workgroup
+        __shared__ float cs_sh[256 * VT];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { cs_sh[(rl * CVP + cvl) * VT + 2 * i] = csum[i].x; cs_sh[(rl * CVP + cvl) * VT + 2 * i + 1] = csum[i].y; }
+        __syncthreads();
+        if (rl == 0 && cv < CV) {
+#pragma unroll
+            for (int e = 0; e < VT; ++e) {
+                float t = 0.f;
+                for (int r = 0; r < R; ++r) t += cs_sh[(r * CVP + cvl) * VT + e];
+                cpart[(size_t)blockIdx.x * C + cv * VT + e] = t;
+            }
         }
     }
 }
@@ -1312,7 +1344,8 @@ static void dw_row_geometry(int dt, int kind, int N, int H, int W, int C, int& V
 
 #define DW_VT(VT, BODY) switch (VT) { case 8: { constexpr int VT_ = 8; BODY } break; case 4: { constexpr int VT_ = 4; BODY } break; default: { constexpr int VT_ = 2; BODY } }
 
-int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z, void* y_gelu, int N, int H, int W, int C, int flip, int accumulate, void* stream) {
+static int dwconv3x3_impl(int dt, const void* x, const float* w, const float* b, void* z, void* y_gelu, int N, int H, int W, int C, int flip, int accumulate, float* cpart, int cblk,
+                          void* stream) {
     if (!x || !w || !z) return -1;
     if (C % 2 || (dt == PN2_BF16 && C % 2) || N < 1 || H < 1 || W < 1) return -2;
     int VT, SEG, SPR; dw_row_geometry(dt, y_gelu ? 0 : 1, N, H, W, C, VT, SEG, SPR);
@@ -1324,13 +1357,18 @@ int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z
         const int vt = C % 4 == 0 ? 4 : 2, cv4 = C / vt, ln = 512 / vt;
         const int cvp4 = cv4 >= ln ? ln : pow2ceil(cv4), R4 = 256 / cvp4;
         const dim3 g4((nseg + R4 - 1) / R4, (cv4 + cvp4 - 1) / cvp4);
-#define PN2_DW_WIN(VT_, G_) hipLaunchKernelGGL((dwconv3x3_win_k<VT_, G_>), g4, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, b, (bf16_t*)z, (bf16_t*)y_gelu, N, H, W, C, flip, SEG, SPR, cvp4, walign)
-        if (vt == 4) { if (y_gelu) PN2_DW_WIN(4, true); else PN2_DW_WIN(4, false); }
-        else { if (y_gelu) PN2_DW_WIN(2, true); else PN2_DW_WIN(2, false); }
+#define PN2_DW_WIN(VT_, G_, CS_) hipLaunchKernelGGL((dwconv3x3_win_k<VT_, G_, CS_>), g4, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, b, (bf16_t*)z, (bf16_t*)y_gelu, N, H, W, C, flip, SEG, SPR, cvp4, walign, cpart)
+        if (cblk == -1) return (int)g4.x;          // (pn2_dwconv3x3_colsum_blocks: rows of cpart)
+        if (cpart) {
+            if (y_gelu || cblk != (int)g4.x) return -2;
+            if (vt == 4) PN2_DW_WIN(4, false, true); else PN2_DW_WIN(2, false, true);
+        } else if (vt == 4) { if (y_gelu) PN2_DW_WIN(4, true, false); else PN2_DW_WIN(4, false, false); }
+        else { if (y_gelu) PN2_DW_WIN(2, true, false); else PN2_DW_WIN(2, false, false); }
 #undef PN2_DW_WIN
         PN2_CHECK_LAUNCH();
         return 0;
     }
+    if (cpart || cblk == -1) return -2;          // column sums only ride on the window kernels
     if (dt == PN2_BF16) { DW_VT(VT, { hipLaunchKernelGGL((dwconv3x3_row_k<bf16_t, VT_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, b, (bf16_t*)z, (bf16_t*)y_gelu,
                                                       N, H, W, C, flip, accumulate, SEG, SPR, cvp, walign); }) }
     else if (dt == PN2_F32) {
@@ -1339,6 +1377,22 @@ int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z
     } else return -3;
     PN2_CHECK_LAUNCH();
     return 0;
+}
+
+int pn2_dwconv3x3(int dt, const void* x, const float* w, const float* b, void* z, void* y_gelu, int N, int H, int W, int C, int flip, int accumulate, void* stream) {
+    return dwconv3x3_impl(dt, x, w, b, z, y_gelu, N, H, W, C, flip, accumulate, nullptr, 0, stream);
+}
+/* rows of `cpart` for pn2_dwconv3x3_colsum at this geometry (< 0: that entry does not serve it - run pn2_dwconv3x3 and a column-sum pass) */
+int pn2_dwconv3x3_colsum_blocks(int dt, int N, int H, int W, int C) {
+    if (dt != PN2_BF16 || C % 2 || N < 1 || H < 1 || W < 1) return -1;
+    static const float dummy = 0.f;
+    const int r = dwconv3x3_impl(dt, &dummy, &dummy, nullptr, (void*)&dummy, nullptr, N, H, W, C, 0, 0, nullptr, -1, nullptr);
+    return r > 0 ? r : -1;
+}
+/* pn2_dwconv3x3 (no GELU, no accumulate) that also leaves cpart[nblk][C]: per-workgroup column sums of the stored result */
+int pn2_dwconv3x3_colsum(int dt, const void* x, const float* w, const float* b, void* z, int N, int H, int W, int C, int flip, float* cpart, int nblk, void* stream) {
+    if (!cpart || nblk < 1) return -1;
+    return dwconv3x3_impl(dt, x, w, b, z, nullptr, N, H, W, C, flip, 0, cpart, nblk, stream);
 }
 
 int pn2_gelu_bwd(int dt, const void* dy, const void* z, void* dz, long long n, void* stream) {

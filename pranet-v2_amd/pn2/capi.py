@@ -205,6 +205,8 @@ SIGNATURES = {
     "pn2_colsum_finalize_blocks": [I],
     "pn2_colsum_finalize_multi": [P, P, I, I, P],
     "pn2_dwconv3x3": [I, P, P, P, P, P, I, I, I, I, I, I, P],
+    "pn2_dwconv3x3_colsum_blocks": [I, I, I, I, I],
+    "pn2_dwconv3x3_colsum": [I, P, P, P, P, I, I, I, I, I, P, I, P],
     "pn2_gelu_bwd": [I, P, P, P, LL, P],
     "pn2_dwconv3x3_wgrad_blocks": [I, I, I, I, I],
     "pn2_dwconv3x3_wgrad": [I, P, P, P, I, I, I, I, I, P, P, P],
@@ -253,7 +255,7 @@ SIGNATURES = {
 }
 # entry points that return a value rather than a status
 _VALUE_FUNCS = {"pn2_conv_gemm_tile", "pn2_conv_gemm_job_blocks", "pn2_bn_finalize_job_blocks", "pn2_affine_job_blocks", "pn2_bn_bwd_finalize_job_blocks",
-                "pn2_bn_bwd_apply_job_blocks", "pn2_bn_bwd_reduce_job_blocks", "pn2_resize_ksize", "pn2_colsum_job_blocks", "pn2_colsum_finalize_blocks", "pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
+                "pn2_bn_bwd_apply_job_blocks", "pn2_bn_bwd_reduce_job_blocks", "pn2_dwconv3x3_colsum_blocks", "pn2_resize_ksize", "pn2_colsum_job_blocks", "pn2_colsum_finalize_blocks", "pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
                 "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
                 "pn2_dsra_tail_blocks", "pn2_dsra_tail_scratch", "pn2_dsra_tail_fused_ok", "pn2_dsra_tail_fused_scratch", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks", "pn2_mutation_loss_blocks", "pn2_mutation_loss_width",
                 "pn2_dwconv_blocks", "pn2_pairconv_blocks", "pn2_gate_blocks", "pn2_eval_wfm_blocks"}

@@ -89,7 +89,7 @@ class _LinearAsConv:
 class Act:
     """NHWC activation view.  t: torch tensor (N,H,W,Cp) whose last dim is contiguous; ld = pixel stride."""
     __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0", "lat", "galias",
-                 "bnb", "bstats", "sum_of", "dual_done", "_sealed", "grad_masked")
+                 "bnb", "bstats", "sum_of", "dual_done", "_sealed", "grad_masked", "colparts")
 
     def __init__(self, eng, t, C_, gw=None, gwp=None, dt=None, requires_grad=True):
         self.eng, self.t = eng, t
@@ -108,6 +108,7 @@ class Act:
         self.dual_done = False          # the sum's consumer wrote the gradient of BOTH operands (dual-target dgrad epilogue)
         self._sealed = False            # a dgrad that declared itself the last contribution has written this gradient
         self.grad_masked = False        # that dgrad stored dz = dy * [y > 0] (PN2_BNB_STORE_MASKED): the gradient buffer already carries the ReLU mask
+        self.colparts = None            # (partial rows, nblk, gradient tensor): column sums of this Act's gradient left by the kernel that wrote it (EncoderOps.dwconv_gelu)
 
     @property
     def grad_written(self):
@@ -407,6 +408,7 @@ FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN
 BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
 LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
 BNB_ACC = os.environ.get("PN2_BNB_ACC", "0") == "1"                 # ... leaving its sums in exact int64 accumulators instead of partial rows: pn2_bn_bwd_apply_acc needs no finalize launch
+DW_COLSUM = os.environ.get("PN2_DW_COLSUM", "1") == "1"             # PVTv2 Mlp: fc1's bias gradient from the depth-wise conv's data-gradient walk (no second read of that gradient)
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
 POOL_BWD_QUAD = os.environ.get("PN2_POOL_BWD_QUAD", "1") == "1"  # ... and its backward without the full-resolution gradient tensor (pn2_pool_bn_bwd_reduce / _apply); 0: pool-backward launch + the generic BatchNorm passes
 POOL_FUSE = os.environ.get("PN2_POOL_FUSE", "1") == "1"          # the stem's bn1 -> ReLU -> MaxPool as one op: the 176 x 176 BatchNorm output is never written (conv_bn_act(pool=True))

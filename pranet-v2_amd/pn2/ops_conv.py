@@ -532,7 +532,11 @@ class ConvOps:
                 bias_done = bias is None
             if not bias_done:                                  # biased conv / nn.Linear: db = column sums of dz (~0 under a train-mode BN)
                 gb, gba = self.pgrads.sink(bias)
-                self.colsum(draw, M, Cout_p, Cout, gb, gba)
+                cp = getattr(out, "colparts", None)
+                if cp is not None and draw is dy and cp[2].data_ptr() == dy.data_ptr() and tuple(cp[0].shape) == (cp[1], Cout_p):
+                    self.colsum_finalize(cp[0], cp[1], Cout, Cout_p, gb, gba)          # (the consumer's data-gradient kernel left the column sums of this very buffer)
+                else:
+                    self.colsum(draw, M, Cout_p, Cout, gb, gba)
             # ---- weight gradient
             wd = capi.WgradDesc()
             wd.N, wd.H, wd.W, wd.OH, wd.OW = N, H, W, OH, OW

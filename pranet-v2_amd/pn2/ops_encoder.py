@@ -63,7 +63,15 @@ class EncoderOps:
             if x.requires_grad:
                 gx, acc = x.grad_sink()
                 assert gx.stride(2) == Cc
-                call.pn2_dwconv3x3(self.dt, _p(dz), _p(conv.weight), C.c_void_p(0), _p(gx), C.c_void_p(0), N, H, W, Cc, 1, acc, st)
+                nbc = int(call.pn2_dwconv3x3_colsum_blocks(self.dt, N, H, W, Cc)) if (core.DW_COLSUM and not acc and gx.is_contiguous()) else -1
+                if nbc >= 1:
+                    # this data gradient IS the output gradient of the Linear in front (Mlp.fc1): its column sums - fc1's bias gradient - are left by the
+                    # same walk (per-workgroup partial rows), so the deferred column-sum pass does not read the block's largest gradient tensor again
+                    cpart = self.fbuf(nbc, Cc)
+                    call.pn2_dwconv3x3_colsum(self.dt, _p(dz), _p(conv.weight), C.c_void_p(0), _p(gx), N, H, W, Cc, 1, _p(cpart), nbc, st)
+                    x.colparts = (cpart, nbc, gx)
+                else:
+                    call.pn2_dwconv3x3(self.dt, _p(dz), _p(conv.weight), C.c_void_p(0), _p(gx), C.c_void_p(0), N, H, W, Cc, 1, acc, st)
         self.record(bwd)
         return y
 

@@ -257,6 +257,39 @@ def test_pvt_trainer_step_and_graph_replay():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+def test_fc1_bias_gradient_from_the_depthwise_data_gradient_walk(monkeypatch):
+    """PN2_DW_COLSUM (default): the depth-wise conv's data-gradient kernel IS the producer of Mlp.fc1's output gradient (pvtv2.py:49-56), so it also leaves that
+    tensor's column sums - fc1's bias gradient - as per-workgroup partial rows (pn2_dwconv3x3_colsum) and the deferred column-sum pass does not read the block's
+    largest gradient tensor again.  One backward with the switch on and off: every gradient identical except fc1.bias up to the fp32 order of the sums."""
+    from pn2 import core
+    from pn2.capi import call
+    from pn2.trainer import Trainer
+    from oracle import weights as W
+    x, mask = W.synthetic_batch(2, 96, seed=99)
+    xg, mg = x.to(dev), mask.to(dev)
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(core, "DW_COLSUM", on)
+        n = {"c": 0}
+        real = call.pn2_dwconv3x3_colsum
+        monkeypatch.setattr(call, "pn2_dwconv3x3_colsum", lambda *a: (n.__setitem__("c", n["c"] + 1), real(*a))[1], raising=False)
+        model = _pvt_model(fp32=False)
+        tr = Trainer(model, lr=1e-4, clip=0.5)
+        tr.forward_backward(xg, mg)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(call, "pn2_dwconv3x3_colsum", real, raising=False)
+        fc1b = torch.zeros_like(tr.gflat, dtype=torch.bool)
+        for k, p in model.named_parameters():
+            if k.endswith("mlp.fc1.bias") and id(p) in tr.off:
+                off, cnt = tr.off[id(p)]
+                fc1b[off:off + cnt] = True
+        res.append((tr.gflat.clone(), fc1b, n["c"]))
+    (g0, m0, n0), (g1, m1, n1) = res
+    assert n0 == 0 and n1 == 16 and int(m0.sum()) > 0 and torch.equal(m0, m1), (n0, n1)          # one launch per block of PVTv2-B2
+    assert torch.equal(g0[~m0], g1[~m0]), "only fc1's bias gradients may differ"
+    assert float((g0[m0] - g1[m0]).abs().max()) <= 2e-6 * float(g0[m0].abs().max()) + 1e-12
+
+
 def test_drop_path_plan_draws_and_residual_gradient_alias():
     """Engine.drop_path_plan: the DropPath draws of a forward from ONE bernoulli over a [K][N] table of keep probabilities (pvtv2.py:125,148-149 asks for two
     per block); drop_path_add takes its rows in order, a request that does not match draws for itself; the residual's gradient shares dy's buffer."""
