@@ -302,8 +302,8 @@ int pn2_ra_gate_post_bwd(int dt, const void* raw, int ld_raw, const float* crop,
  * MyTrain_med.py:19-38 applied to the P (fg,bg) pairs of :78-82 in one pass.  preds = P fg maps then P bg maps,
  * each [N][HW] fp32 ; mask [N][HW].  weit/wsum are `weit` is produced once per batch by pn2_loss_weights.   */
 int pn2_loss_weights(const float* mask, float* weit, int N, int H, int W, int ksize, void* stream);
-/* the same launch also zeroes `nclear` doubles at `clear` (the image-sum accumulators `isum` of pn2_dsra_tail_fwd_bwd, which runs right behind it) */
-int pn2_loss_weights_clear(const float* mask, float* weit, int N, int H, int W, int ksize, double* clear, int nclear, void* stream);
+/* the same launch also zeroes `nclear` 64-bit words at `clear` (the image-sum accumulators `isum` of pn2_dsra_tail_fwd_bwd, which runs right behind it) */
+int pn2_loss_weights_clear(const float* mask, float* weit, int N, int H, int W, int ksize, long long* clear, int nclear, void* stream);
 int pn2_loss_blocks(int HW);            /* row-chunks per image of the `partial` scratch: [P][N][blocks][5] floats */
 /* preds: 2P maps laid out at preds + j*map_stride (j<P: fg of pair j, j>=P: bg of pair j-P), each [N][HW] fp32.
  * Outputs: sums [P][N][4] and wsum [N] (kept for the backward), loss [P+1] = per-pair losses then their total. */
@@ -347,13 +347,15 @@ int pn2_dsra_tail_bwd(const pn2_tail_desc* d, const float* mask, const float* we
  * use _fwd + _bwd): align_corners = 0, every map magnified by a power of two >= 8 in both directions (all scales of MyTrain_med.py:55,70-73), pair p's
  * fg and bg map of one geometry, OW <= 512.  per: [P][N] floats of caller-owned scratch; sums / wsum / loss as pn2_dsra_tail_fwd (valid when the call has
  * run); scratch: pn2_dsra_tail_fused_scratch() floats.  PN2_TAIL_BAND=0|1 (row / band kernels of the two-call path) also switches this path off.
- * isum (optional): P*N*5 doubles, ZERO on entry (pn2_loss_weights_clear) - the walk adds every image's five loss sums into them with fp64 atomics (exact for
- * these term counts, hence order-independent), the second kernel reads them instead of reducing the partial rows, and one of its workgroups finishes
- * loss[P+1]: two launches instead of three (P*N <= 1024).  NULL: the second kernel reduces `partial` itself and a third launch forms the loss. */
+ * isum (optional): P*N*5 sums of TWO 64-bit words each (P*N*10 words), ZERO on entry (pn2_loss_weights_clear) - the walk adds every image's five loss sums into
+ * them as two-word fixed point (value * 2^30: integer part, 50 fractional bits) with integer atomics: integer addition is associative, so the result does not
+ * depend on the order in which the workgroups arrive - the step is bit-reproducible across replays and ranks (tests/test_gpu_determinism.py).  The second kernel
+ * reads them instead of reducing the partial rows, and one of its workgroups finishes loss[P+1]: two launches instead of three (P*N <= 1024).
+ * NULL: the second kernel reduces `partial` itself and a third launch forms the loss. */
 int pn2_dsra_tail_fused_ok(const pn2_tail_desc* d);
 int pn2_dsra_tail_fused_scratch(const pn2_tail_desc* d);
 int pn2_dsra_tail_fwd_bwd(const pn2_tail_desc* d, float* lat, const float* mask, const float* weit, float* partial, float* sums, float* wsum,
-                          float* per, float* loss, float gscale, float* scratch, long long scratch_floats, double* isum, void* stream);
+                          float* per, float* loss, float gscale, float* scratch, long long scratch_floats, long long* isum, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- PVTv2 encoder (lib/pvtv2.py)
  * Tokens [B, N, C] of the reference are NHWC pixels here.  The nn.Linear layers run as 1x1 pn2_conv_gemm / pn2_conv_wgrad.      */

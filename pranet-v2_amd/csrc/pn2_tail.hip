@@ -111,10 +111,10 @@ __global__ __launch_bounds__(256) void ra_gate_bwd_k(const T* __restrict__ x, in
 // subtracts the leaving sample (2 LDS reads per output instead of ks); same for (column, 8-row segment) lanes on the row sums.  {0,1} masks
 // sum exactly.  Odd LDS row strides keep both walks bank-conflict free.  (The 32x32-tile / full-window version took 55 us at 32x352x352.)
 constexpr int LTY = 32, LTX = 64, LSX = 16, LSY = 8;
-__global__ __launch_bounds__(256) void loss_weights_k(const float* __restrict__ mask, float* __restrict__ weit, int H, int W, int ks, double* __restrict__ clr = nullptr, int nclr = 0) {
+__global__ __launch_bounds__(256) void loss_weights_k(const float* __restrict__ mask, float* __restrict__ weit, int H, int W, int ks, long long* __restrict__ clr = nullptr, int nclr = 0) {
     extern __shared__ float sh[];                  // tile TSY x TSX, then row sums TSY x HSX
     if (clr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)          // pn2_loss_weights_clear: the image-sum accumulators of the one-pass tail, zeroed by the launch in front of it
-        for (int i = threadIdx.x; i < nclr; i += 256) clr[i] = 0.0;
+        for (int i = threadIdx.x; i < nclr; i += 256) clr[i] = 0;
     const int R = ks / 2, TSY = LTY + ks - 1, TSXr = LTX + ks - 1, TSX = TSXr | 1, HSX = LTX + 1;
     float* tile = sh; float* hs = sh + TSY * TSX;
     const int n = blockIdx.z, ty0 = blockIdx.y * LTY, tx0 = blockIdx.x * LTX;
@@ -837,9 +837,21 @@ __device__ __forceinline__ void tail_gather(const float* cc, const int* sbt_p, i
     }
 }
 
+// Order-independent image sums: v * 2^30 split into its integer part and 50 fractional bits (|v| < 2^31; everything below 2^-80 is dropped - per VALUE, so the
+// result still does not depend on the order), added with 64-bit integer atomics (no return value); tail_isum_get puts the two words together again.
+__device__ __forceinline__ void tail_isum_add(long long* a, float v) {
+    double s_ = (double)v * 0x1p30;
+    s_ = fmin(fmax(s_, -0x1p61), 0x1p61);
+    const double f = floor(s_);
+    const long long hi = (long long)f, lo = (long long)((s_ - f) * 0x1p50);
+    atomicAdd(reinterpret_cast<unsigned long long*>(a), (unsigned long long)hi);
+    if (lo) atomicAdd(reinterpret_cast<unsigned long long*>(a) + 1, (unsigned long long)lo);
+}
+__device__ __forceinline__ double tail_isum_get(const long long* a) { return (double)a[0] * 0x1p-30 + (double)a[1] * 0x1p-80; }
+
 template <int P>
 __global__ __launch_bounds__(256) void tail_one_k(pn2_tail_desc d, tail_one_aux A, float* __restrict__ lat, const float* __restrict__ mask,
-                                                                                            const float* __restrict__ weit, float* __restrict__ partial, float* __restrict__ pbuf, double* __restrict__ isum) {
+                                                                                            const float* __restrict__ weit, float* __restrict__ partial, float* __restrict__ pbuf, long long* __restrict__ isum) {
     extern __shared__ float lds[];          // raw[2P][3][w + 1] | cc[R][TNK][LV][2]
     __shared__ __attribute__((aligned(16))) float tab[P * TRB * 4];
     __shared__ float wst[P * TRB * 2];          // slot weights of a row: towards its upper / lower tap row
@@ -1037,11 +1049,11 @@ __global__ __launch_bounds__(256) void tail_one_k(pn2_tail_desc d, tail_one_aux 
         else if (k == 3) val = (HW_ + 2.f * tot(p * 4 + 1)) + MW_;                              // sum p*w + sum m*w
         else val = 2.f * HW_;
         partial[(((size_t)p * d.N + n) * nb + band) * 5 + k] = val;
-        // the image's sums, formed on the way (isum[pair][5], zero on entry): fp64 hardware atomics.  Adding n fp32 values in double is exact while their
-        // magnitudes span less than 2^(29 - log2 n) - here n = nb <= 64 band sums of one image, each over 8 rows of pixels (positive weights: within a few
-        // binades of each other) - so the order in which the bands arrive changes no bit (beyond that span an order dependence would sit at the 2^-53 level,
-        // below the conversion to fp32 except on rounding ties).  tail_one_fin_k reads five doubles per image instead of reducing nb partial rows per workgroup
-        if (isum) unsafeAtomicAdd(isum + ((size_t)p * d.N + n) * 5 + k, (double)val);
+        // the image's sums, formed on the way (isum[pair][5][2], zero on entry): two-word FIXED-POINT integer atomics (tail_isum_add) - integer addition is
+        // associative, so the order in which the bands of an image arrive cannot change a bit of the loss or of the gradient coefficients, whatever the
+        // spread of the band sums (round 5 used fp64 atomics, exact only while the sums span < 2^(29 - log2 nb)).  tail_one_fin_k reads five sums per image
+        // instead of reducing nb partial rows per workgroup
+        if (isum) tail_isum_add(isum + (((size_t)p * d.N + n) * 5 + k) * 2, val);
     }
 }
 
@@ -1049,12 +1061,12 @@ __global__ __launch_bounds__(256) void tail_one_k(pn2_tail_desc d, tail_one_aux 
 // image sums isum[pair][5] that tail_one_k accumulated, then loss[p] = mean over the images in the order of loss_total_k.  (Two versions that reduced the forward's
 // partial rows inside this workgroup - 110 KB through one CU - took 16-25 us, longer than the rest of the launch.)
 constexpr int TLB_MAXPN = 1024;          // P * N the loss block serves (host: more -> loss_total_k)
-__device__ __forceinline__ void tail_loss_block(const pn2_tail_desc& d, const double* __restrict__ isum, float* __restrict__ loss) {
+__device__ __forceinline__ void tail_loss_block(const pn2_tail_desc& d, const long long* __restrict__ isum, float* __restrict__ loss) {
     __shared__ float s_per[TLB_MAXPN], s_lp[8];
     const int P = d.P, N = d.N, PN = P * N;
     for (int pair = threadIdx.x; pair < PN; pair += 256) {
-        const double* a = isum + (size_t)pair * 5;
-        const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4];
+        const long long* a = isum + (size_t)pair * 10;
+        const double a0 = tail_isum_get(a), a1 = tail_isum_get(a + 2), a2 = tail_isum_get(a + 4), a3 = tail_isum_get(a + 6), a4 = tail_isum_get(a + 8);
         const float wbce = (float)(a0 / a4), wbce2 = (float)(a1 / a4);
         const float wiou = 1.f - ((float)a2 + 1.f) / ((float)a3 - (float)a2 + 1.f);
         s_per[pair] = wbce + wiou + 0.8f * wbce2;
@@ -1076,7 +1088,7 @@ __device__ __forceinline__ void tail_loss_block(const pn2_tail_desc& d, const do
 constexpr int TFI = 64;         // images a 256-pixel block can span (h*w >= 5: host)
 __global__ __launch_bounds__(256) void tail_one_fin_k(pn2_tail_desc d, tail_one_aux A, const float* __restrict__ pbuf, const float* __restrict__ partial,
                                                       float gscale, float* __restrict__ sums_out, float* __restrict__ wsum_out, float* __restrict__ per, float* __restrict__ loss,
-                                                      const double* __restrict__ isum) {
+                                                      const long long* __restrict__ isum) {
     const int lossrow = (int)gridDim.y == 2 * d.P + 1 ? 1 : 0;          // the host asked for the loss (isum given): row 0 of the grid (dispatched first), one workgroup
     if (lossrow && blockIdx.y == 0) {
         if (blockIdx.x == 0) tail_loss_block(d, isum, loss);
@@ -1111,7 +1123,7 @@ __global__ __launch_bounds__(256) void tail_one_fin_k(pn2_tail_desc d, tail_one_
         }
     }
     if (isum) {          // the image sums as tail_one_k accumulated them
-        for (int c = threadIdx.x; c < 5 * ni; c += 256) s_d[c] = isum[((size_t)p * d.N + n0) * 5 + c];
+        for (int c = threadIdx.x; c < 5 * ni; c += 256) s_d[c] = tail_isum_get(isum + (((size_t)p * d.N + n0) * 5 + c) * 2);
     } else {
         const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
         for (int c = grp; c < 5 * ni; c += 16) {
@@ -1317,7 +1329,7 @@ int pn2_loss_weights(const float* mask, float* weit, int N, int H, int W, int ks
     return 0;
 }
 
-int pn2_loss_weights_clear(const float* mask, float* weit, int N, int H, int W, int ksize, double* clear, int nclear, void* stream) {
+int pn2_loss_weights_clear(const float* mask, float* weit, int N, int H, int W, int ksize, long long* clear, int nclear, void* stream) {
     if (!mask || !weit || (nclear > 0 && !clear) || nclear < 0) return -1;
     if (ksize < 1 || !(ksize & 1) || ksize > 63) return -2;
     const int TSY = LTY + ksize - 1, TSX = (LTX + ksize - 1) | 1;
@@ -1553,14 +1565,14 @@ int pn2_dsra_tail_fused_scratch(const pn2_tail_desc* d) {
 }
 
 int pn2_dsra_tail_fwd_bwd(const pn2_tail_desc* d, float* lat, const float* mask, const float* weit, float* partial, float* sums, float* wsum,
-                          float* per, float* loss, float gscale, float* scratch, long long scratch_floats, double* isum, void* stream) {
+                          float* per, float* loss, float gscale, float* scratch, long long scratch_floats, long long* isum, void* stream) {
     if (!lat || !mask || !weit || !partial || !sums || !wsum || !per || !loss || !scratch) return -1;
     if (int rc = tail_check(d)) return rc;
     for (int j = 0; j < 2 * d->P; ++j) if (!d->maps[j].dsrc) return -1;
     tail_one_aux A; int threads; size_t lds;
     if (!tail_one_geometry(d, A, threads, lds)) return -2;
     if (scratch_floats < (long long)d->N * A.nb * A.ptot) return -2;
-    if (isum && (d->P * d->N > TLB_MAXPN || d->P > 8)) return -2;          // (P * N * 5 doubles, ZERO on entry: pn2_loss_weights_clear; NULL: two more passes, see pn2.h)
+    if (isum && (d->P * d->N > TLB_MAXPN || d->P > 8)) return -2;          // (P * N * 5 two-word fixed-point sums, ZERO on entry: pn2_loss_weights_clear; NULL: two more passes, see pn2.h)
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(A.nb * d->N), blk(threads);
     switch (d->P) {
@@ -1571,7 +1583,7 @@ int pn2_dsra_tail_fwd_bwd(const pn2_tail_desc* d, float* lat, const float* mask,
     }
     int emax = 0;
     for (int j = 0; j < 2 * d->P; ++j) emax = std::max(emax, d->N * d->maps[j].h * d->maps[j].w);
-    hipLaunchKernelGGL(tail_one_fin_k, dim3((emax + 255) / 256, 2 * d->P + (isum ? 1 : 0)), dim3(256), 0, st, *d, A, scratch, partial, gscale, sums, wsum, per, loss, (const double*)isum);
+    hipLaunchKernelGGL(tail_one_fin_k, dim3((emax + 255) / 256, 2 * d->P + (isum ? 1 : 0)), dim3(256), 0, st, *d, A, scratch, partial, gscale, sums, wsum, per, loss, (const long long*)isum);
     if (!isum) hipLaunchKernelGGL(loss_total_k, dim3(1), dim3(64), 0, st, per, d->P, d->N, loss);
     PN2_CHECK_LAUNCH();
     return 0;

@@ -13,7 +13,7 @@ import os
 from .capi import F32, call
 from .engine import _p, _stream
 
-TAIL_ISUM = os.environ.get("PN2_TAIL_ISUM", "1") == "1"          # 0: the one-pass tail without the fp64 image-sum accumulators (three launches; A/B)
+TAIL_ISUM = os.environ.get("PN2_TAIL_ISUM", "1") == "1"          # 0: the one-pass tail without the fixed-point image-sum accumulators (three launches; A/B)
 
 
 def loss_forward(buf, P, mask, N, HW, H, W):
@@ -78,10 +78,11 @@ def tail_forward_backward(eng, tail, lat, P, mask, N, H, W, gscale=1.0):
         d.maps[j].dsrc, d.maps[j].accumulate = g.data_ptr(), acc
     HW = H * W
     weit = eng.alloc((N, HW), torch.float32)
-    # the image sums are accumulated by the walk itself (fp64 atomics into isum, zeroed by the weights launch in front of it): two launches instead of three
-    isum = eng.alloc((P * N * 5,), torch.float64) if (TAIL_ISUM and P * N <= 1024) else None
+    # the image sums are accumulated by the walk itself (two-word fixed-point integer atomics into isum - order-independent, so replays agree bit for bit -
+    # zeroed by the weights launch in front of it): two launches instead of three
+    isum = eng.alloc((P * N * 10,), torch.int64) if (TAIL_ISUM and P * N <= 1024) else None
     if isum is not None:
-        call.pn2_loss_weights_clear(_p(mask), _p(weit), N, H, W, 31, _p(isum), P * N * 5, _stream())
+        call.pn2_loss_weights_clear(_p(mask), _p(weit), N, H, W, 31, _p(isum), P * N * 10, _stream())
     else:
         call.pn2_loss_weights(_p(mask), _p(weit), N, H, W, 31, _stream())
     nb = call.pn2_dsra_tail_blocks(H)

@@ -1013,7 +1013,7 @@ def test_dsra_tail_band_kernels_vs_oracle_and_row_kernels(cfg, monkeypatch):
     ups32 = [F.interpolate(t[:, None], size=(S, S), mode="bilinear", align_corners=bool(ac)).reshape(N, S, S) for t in src_cpu]
     res = {}
     pow2 = ac == 0 and S % 32 == 0 and S <= 512 and S // 32 >= 1 and all(S // h in (8, 16, 32) for h in sizes)      # what the one-pass kernel serves
-    # the one-pass entry with the fp64 image-sum accumulators (default in the trainer: two launches) / without (three launches) / band kernels / row kernels
+    # the one-pass entry with the fixed-point image-sum accumulators (default in the trainer: two launches) / without (three launches) / band kernels / row kernels
     for band in ("Fi", "F", "1", "0"):
         monkeypatch.setenv("PN2_TAIL_BAND", "2" if band[0] == "F" else band)
         srcs = [t.to(dev) for t in src_cpu]
@@ -1021,7 +1021,7 @@ def test_dsra_tail_band_kernels_vs_oracle_and_row_kernels(cfg, monkeypatch):
         dsrcs = [base[j].clone() if j % 3 == 0 else torch.empty_like(t) for j, t in enumerate(srcs)]
         mask = mask_cpu.reshape(N, S, S).to(dev).contiguous()
         weit = torch.empty_like(mask)
-        isum = torch.full((4 * N * 5,), 7.0, dtype=torch.float64, device=dev) if band == "Fi" else None          # (pn2_loss_weights_clear zeroes it)
+        isum = torch.full((4 * N * 10,), 7, dtype=torch.int64, device=dev) if band == "Fi" else None          # (pn2_loss_weights_clear zeroes it)
         if isum is not None:
             call.pn2_loss_weights_clear(P(mask), P(weit), N, S, S, 31, P(isum), isum.numel(), st)
         else:

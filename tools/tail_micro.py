@@ -57,7 +57,7 @@ def run(N, S, ac, band):
     fwd = lambda: call.pn2_dsra_tail_fwd(C.byref(d), P(lat), P(mask), P(weit), P(partial), P(sums), P(wsum), P(loss), st)
     bwd = lambda: call.pn2_dsra_tail_bwd(C.byref(d), P(mask), P(weit), P(wsum), P(sums), 1.0, P(scratch) if need else None, need, st)
     per = torch.empty(Pn, N, device=dev)
-    isum = torch.zeros(Pn * N * 5, dtype=torch.float64, device=dev) if os.environ.get("PN2_TAIL_ISUM", "1") == "1" else None
+    isum = torch.zeros(Pn * N * 10, dtype=torch.int64, device=dev) if os.environ.get("PN2_TAIL_ISUM", "1") == "1" else None
     def both():          # (in the trainer the clear rides on the weights launch; here it is a fill in front of the timed region's kernels)
         if isum is not None:
             isum.zero_()
