@@ -56,3 +56,67 @@ def test_hung_ranks_are_killed_after_the_launch_timeout():
     with um.patch("subprocess.Popen", sleeper):
         rc = bench.launch_ranks(2, [], backend="gloo", timeout=1.0, out=io.StringIO())
     assert rc == 124
+
+
+def test_refuses_to_launch_ranks_under_a_profiler():
+    # rocprofv3 -- python3 bench.py --gpus 8: the profiler's preloaded library has initialised the GPU in the would-be launcher: status 2, nothing started
+    for var, val in (("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so"), ("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/librocprofiler-sdk-tool.so"), ("ROCPROFILER_LOG_LEVEL", "1")):
+        e = _env()
+        import bench
+        assert not bench.profiler_attached(e)
+        e[var] = val
+        assert bench.profiler_attached(e)
+    e = _env()
+    e["ROCPROF_OUTPUT_PATH"] = "/tmp/x"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "1"], capture_output=True, text=True, timeout=120, env=e)
+    assert r.returncode == 2 and "profiled process" in r.stderr and r.stdout.strip() == ""
+
+
+def test_gpu_count_comes_from_sysfs_not_from_hip(tmp_path):
+    import bench
+    for i, simd in enumerate((0, 256, 256, 0)):          # two CPU nodes, two GPU nodes
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    assert bench.count_gpus_sysfs(str(tmp_path)) == 2
+    assert bench.count_gpus_sysfs(str(tmp_path / "missing")) in (0, None)
+
+
+def test_sigterm_to_the_launcher_takes_the_rank_group_down(tmp_path):
+    # a harness that SIGTERMs bench.py must not leave torchrun + ranks behind in their own session
+    import signal, time
+    marker = tmp_path / "pids"
+    code = (
+        "import sys, os, io, subprocess, unittest.mock as um\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "real = subprocess.Popen\n"
+        "def sleeper(cmd, **kw):\n"
+        "    p = real([sys.executable, '-c', 'import time; time.sleep(120)'], **kw)\n"
+        f"    open({str(marker)!r}, 'w').write(str(p.pid))\n"
+        "    return p\n"
+        "with um.patch('subprocess.Popen', sleeper):\n"
+        "    sys.exit(bench.launch_ranks(2, [], backend='gloo', timeout=100.0, out=io.StringIO()))\n")
+    p = subprocess.Popen([sys.executable, "-c", code], env=_env())
+    for _ in range(200):
+        if marker.exists() and marker.read_text().strip():
+            break
+        time.sleep(0.1)
+    child = int(marker.read_text())
+    os.kill(child, 0)                      # alive
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    for _ in range(100):
+        try:
+            os.kill(child, 0)
+        except ProcessLookupError:
+            break
+        # (a zombie still answers kill 0 until it is reaped by init: look at its state)
+        try:
+            if open(f"/proc/{child}/stat").read().split()[2] == "Z":
+                break
+        except OSError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the launcher's child group survived SIGTERM")

@@ -3,6 +3,8 @@
 # The shipped tile table (pn2/tuned_gfx950.json) covers every conv shape of the benchmark configurations, so the trace holds no tuner launches and no
 # cache-evicting fills: the per-kernel averages are those of the steady-state step.
 out=$1; shift
+# one rank only: `bench.py --gpus N` would start torchrun from a process the profiler has already initialised the GPU in (bench.py refuses that too)
+prev=""; for a in "$@"; do if [ "$prev" = "--gpus" ] && [ "$a" != "1" ]; then echo "prof_bench.sh: profile ONE rank (--gpus $a refused); run multi-rank jobs with the launcher outside the profiler" >&2; exit 2; fi; case "$a" in --gpus=1) ;; --gpus=*) echo "prof_bench.sh: profile ONE rank ($a refused)" >&2; exit 2;; esac; prev="$a"; done
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_bench
 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > /tmp/pb.log 2>&1
