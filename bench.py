@@ -171,13 +171,33 @@ def other_configs(dev, steps=10):
     return out
 
 
-def module_surface(dev, x, m, steps=20):
-    """The drop-in path: the literal loop of MyTrain_med.py:59-86 on the mirror classes - model(images) -> 4 x structure_loss -> loss.backward() -> clip_gradient ->
-    torch.optim.Adam.step(); torch autograd around one engine pass, which the call site replays from two hipGraphs (forward, backward) after its first calls."""
+def torch_structure_loss(pred, pred_bg, mask_fg, mask_bg):
+    """What an UNEDITED MyTrain_med.py runs (its own structure_loss, :19-38): plain torch ops on the GPU, the 31 x 31 average pool recomputed in each of the four
+    calls.  Restated from the formula (as oracle/pranet_oracle.py does), not imported: the reference cannot travel to the GPU box."""
+    import torch.nn.functional as F
+    weit = 1 + 5 * torch.abs(F.avg_pool2d(mask_fg, kernel_size=31, stride=1, padding=15) - mask_fg)
+    wsum = weit.sum(dim=(2, 3))
+    wbce = (weit * F.binary_cross_entropy_with_logits(pred, mask_fg, reduction="none")).sum(dim=(2, 3)) / wsum
+    wbce_bg = (weit * F.binary_cross_entropy_with_logits(pred_bg, mask_bg, reduction="none")).sum(dim=(2, 3)) / wsum
+    p = torch.sigmoid(pred)
+    inter = ((p * mask_fg) * weit).sum(dim=(2, 3))
+    union = ((p + mask_fg) * weit).sum(dim=(2, 3))
+    wiou = 1 - (inter + 1) / (union - inter + 1)
+    return (wbce + wiou + 0.8 * wbce_bg).mean()
+
+
+def module_surface(dev, x, m, steps=20, verbatim=False):
+    """The drop-in path: the loop of MyTrain_med.py:59-86 on the mirror classes - model(images) -> 4 x structure_loss -> loss.backward() -> clip_gradient ->
+    torch.optim.Adam.step(); torch autograd around one engine pass, which the call site replays from two hipGraphs (forward, backward) after its first calls.
+    verbatim=True: the loss is the script's OWN torch-op structure_loss (torch_structure_loss above) - what an unedited MyTrain_med.py executes;
+    verbatim=False: the one edit a user can make, `from pn2.loss import structure_loss` (the fused loss kernels, same signature)."""
     import pn2
     from lib.pranet import PraNet_V2
-    from pn2.loss import structure_loss
     from utils.utils import clip_gradient
+    if verbatim:
+        structure_loss = torch_structure_loss
+    else:
+        from pn2.loss import structure_loss
     pn2.set_compute_dtype("bf16")
     torch.manual_seed(0)
     model = PraNet_V2(num_class=1).to(dev).train()
@@ -200,9 +220,14 @@ def module_surface(dev, x, m, steps=20):
         loss = step()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
+    fused_opt = bool(getattr(opt, "_pn2_fused", None))
     del model, opt
     torch.cuda.empty_cache()
-    return {"what": "nn.Module surface + torch autograd + utils.clip_gradient + torch.optim.Adam (MyTrain_med.py:59-86 verbatim); the model call replays two hipGraphs, loss / clip / Adam are eager torch", "value": round(x.shape[0] / el, 1),
+    what = ("nn.Module surface + torch autograd + utils.clip_gradient + torch.optim.Adam, loop of MyTrain_med.py:59-86 with the script's OWN torch-op structure_loss (:19-38, "
+            "4 calls, 31x31 avg_pool2d each) - what an unedited script runs" if verbatim else
+            "the same loop with ONE edit: structure_loss imported from pn2.loss (fused loss kernels) instead of the script's torch-op version")
+    return {"what": what + "; the model call replays two hipGraphs" + ("; clip_gradient + Adam.step run as one clamp launch + pn2_clamp_adam over the flat arenas" if fused_opt else "; clip / Adam are eager torch"),
+            "loss_impl": "torch ops (script verbatim)" if verbatim else "pn2.loss.structure_loss (swapped in)", "value": round(x.shape[0] / el, 1),
             "unit": "images/sec", "ms_per_step": round(1e3 * el, 3), "steps": steps, "loss": round(float(loss), 4)}
 
 
@@ -580,7 +605,8 @@ def main(argv=None):
             # the other numbers of the repository, in the driver's record (each bounded to a few seconds of GPU time; a failure is reported, not fatal)
             tr = None
             torch.cuda.empty_cache()
-            for key, fn in (("configs", lambda: other_configs(dev)), ("module_surface", lambda: module_surface(dev, x, m)), ("inference", lambda: inference(dev)),
+            for key, fn in (("configs", lambda: other_configs(dev)), ("module_surface_verbatim", lambda: module_surface(dev, x, m, verbatim=True)),
+                            ("module_surface", lambda: module_surface(dev, x, m)), ("inference", lambda: inference(dev)),
                             ("dp1", lambda: dp1_line(dev, x, m))):
                 try:
                     out[key] = fn()

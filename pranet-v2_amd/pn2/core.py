@@ -189,6 +189,8 @@ class Act:
             raise RuntimeError("a gradient contribution arrived after the dgrad that was declared the last one (x_last=True)")
         g = self.grad_buf()
         acc = 1 if self.grad_written else 0
+        if acc:
+            self.colparts = None          # column sums a kernel left for an earlier, complete state of this gradient are stale once another consumer accumulates into it
         self.grad_written = True
         return g, acc
 

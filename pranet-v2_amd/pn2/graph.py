@@ -295,6 +295,8 @@ def run_module(build, inputs, params, training, dtype=None):
     params = [p for p in params]
     need = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(x.requires_grad for x in inputs))
     if need and training and MODULE_GRAPH and params and not any(x.requires_grad for x in inputs) and os.environ.get("PN2_MODULE_PACK_CACHE", "1") == "1":
+        from .optim import flat_params
+        flat_params(params)          # the trained parameters in ONE flat arena, laid out like the site's flat gradient buffer (pn2/optim.py: one-launch clip + Adam)
         pc = _pack_cache(dtype, params, refresh=False)
         site = _site(build, inputs, params, training, dtype, pc)
         if site.calls >= PLAIN_CALLS and not site.busy():

@@ -16,11 +16,13 @@ from .engine import _p, _stream
 TAIL_ISUM = os.environ.get("PN2_TAIL_ISUM", "1") == "1"          # 0: the one-pass tail without the fixed-point image-sum accumulators (three launches; A/B)
 
 
-def loss_forward(buf, P, mask, N, HW, H, W):
-    """buf: [2P][N][HW] fp32 contiguous logits.  Returns (loss[P+1], saved) — raw kernel driver, no autograd."""
+def loss_forward(buf, P, mask, N, HW, H, W, weit=None):
+    """buf: [2P][N][HW] fp32 contiguous logits.  Returns (loss[P+1], saved) — raw kernel driver, no autograd.  weit: the boundary weights of `mask` when the
+    caller has them already."""
     dev = buf.device
-    weit = torch.empty((N, HW), dtype=torch.float32, device=dev)
-    call.pn2_loss_weights(_p(mask), _p(weit), N, H, W, 31, _stream())
+    if weit is None:
+        weit = torch.empty((N, HW), dtype=torch.float32, device=dev)
+        call.pn2_loss_weights(_p(mask), _p(weit), N, H, W, 31, _stream())
     nb = call.pn2_loss_blocks(HW)
     partial = torch.empty((P, N, nb, 5), dtype=torch.float32, device=dev)
     sums = torch.empty((P, N, 4), dtype=torch.float32, device=dev)
@@ -111,6 +113,24 @@ def tail_backward(eng, tail, P, mask, saved, gscale=1.0):
                            _p(scratch) if scratch is not None else None, need, _stream())
 
 
+# The four structure_loss calls of a step (MyTrain_med.py:78-81) pass the SAME mask tensor: its 31 x 31 boundary weights are computed by the first call and reused
+# by the other three.  The entry holds the mask object itself (identity + version counter decide a hit; holding it keeps its address from being recycled for
+# another mask while the entry is alive) - one entry, replaced by the next new mask.
+_WEIT = [None]
+
+
+def _mask_weights(mask, N, H, W):
+    e = _WEIT[0]
+    if e is not None and e[0] is mask and e[1] == mask._version:
+        return e[2], e[3]
+    HW = H * W
+    m = mask.reshape(N, HW).float().contiguous()
+    weit = torch.empty((N, HW), dtype=torch.float32, device=mask.device)
+    call.pn2_loss_weights(_p(m), _p(weit), N, H, W, 31, _stream())
+    _WEIT[0] = (mask, mask._version, m, weit)
+    return m, weit
+
+
 class _StructureLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mask, P, *preds):
@@ -119,8 +139,8 @@ class _StructureLoss(torch.autograd.Function):
         N, _, H, W = mask.shape
         HW = H * W
         buf = torch.stack([p.reshape(N, HW) for p in preds]).float().contiguous()
-        m = mask.reshape(N, HW).float().contiguous()
-        loss, saved = loss_forward(buf, P, m, N, HW, H, W)
+        m, weit = _mask_weights(mask, N, H, W)
+        loss, saved = loss_forward(buf, P, m, N, HW, H, W, weit)
         ctx.save_for_backward(buf, m, *saved)
         ctx.dims = (P, N, HW, preds[0].shape)
         return loss[P], loss[:P]

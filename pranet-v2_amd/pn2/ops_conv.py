@@ -602,16 +602,32 @@ class ConvOps:
                 dd.KH, dd.KW, dd.stride, dd.pad_h, dd.pad_w, dd.dil_h, dd.dil_w = KH, KW, sh, ph, pw, dh, dw
                 dd.transposed, dd.Kp, dd.flags = 1, ptd.Kp, (capi.CONV_ACCUM if gxa else 0)
                 ks = self._ksplit(Mx, KH * KW * Cout_p, x.Cp) if gx.stride(2) == x.Cp else 1
-                if ks > 1 and self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp) & 0xC0:
-                    ks = 1          # (as in the forward: intra-workgroup split-K instead of partial tiles + reduce; the launch may then carry the BatchNorm-backward epilogue)
-                capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
                 dual = x.sum_of is not None and x.galias is x.sum_of[1] and x.sum_of[0].requires_grad
+                want_ep = bool(core.BNB_EPILOGUE and x_last and x.Cp % V == 0 and gx.stride(2) % V == 0 and (x.bnb is not None or dual))
+                if ks > 1:
+                    # as in the forward: intra-workgroup split-K instead of partial tiles + reduce.  The probe asks the tuner with THE KEY THE LAUNCH WILL USE (a launch
+                    # with a BatchNorm-backward epilogue is tuned with it: other LDS budget, other key); if that code is not of the split-K class (no tile of it fits
+                    # next to the epilogue's operand tiles, or no tuner) the global split-K + reduce pair stays - never a long-K launch with neither
+                    probe = None
+                    if want_ep:
+                        probe = capi.ConvEp()
+                        for t_, a_ in ((probe.a, x.sum_of[0] if dual else x), (probe.b, x.sum_of[1] if dual else None)):
+                            if a_ is not None and a_.bnb is not None:
+                                self._fill_bnb(t_, a_, 0)
+                        if dual:
+                            probe.b.out = 1
+                        if dual and x.sum_of[0].grad_written:
+                            dd.flags |= capi.CONV_ACCUM
+                    if self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, probe) & 0xC0:
+                        ks = 1
+                    dd.flags = capi.CONV_ACCUM if gxa else 0
+                capi.WORK.update(flops=flops, tag=":dgrad", shape=shape)
                 if ks > 1:
                     ws = self.fbuf(ks, Mx, x.Cp)
                     dd.flags = ((2 | (1 << 2) | ((3 if x.Cp > 64 else 2) << 4)) << 8) | (ks << 16)
                     call.pn2_conv_gemm(self.dt, _p(draw), _p(wt), _p(gx), _p(ws), C.c_void_p(0), C.byref(dd), st)
                     call.pn2_conv_splitk_reduce(self.dt, _p(ws), ks, Mx, x.Cp, _p(gx), x.Cp, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), gxa, st)
-                elif core.BNB_EPILOGUE and x_last and x.Cp % V == 0 and gx.stride(2) % V == 0 and (x.bnb is not None or dual):
+                elif want_ep:
                     ep = capi.ConvEp()
                     if dual and x.sum_of[0].grad_written:
                         dd.flags |= capi.CONV_ACCUM

@@ -4,6 +4,13 @@ import torch
 
 def clip_gradient(optimizer, grad_clip):
     """Per-element clamp of every gradient to [-grad_clip, grad_clip] (reference utils/utils.py:7-17)."""
+    try:          # gradients handed out by the module surface are views of ONE flat buffer: one clamp launch, and Adam.step as one kernel (pn2/optim.py)
+        from pn2 import optim as _po
+        if _po.clip_flat(optimizer, grad_clip):
+            _po.fuse_adam(optimizer)
+            return
+    except ImportError:
+        pass
     grads = [param.grad.data for group in optimizer.param_groups for param in group['params'] if param.grad is not None]
     dense = [g for g in grads if g.is_cuda and not g.is_sparse]
     if len(dense) == len(grads) and grads:

@@ -299,3 +299,91 @@ def test_gradients_accumulate_across_replayed_calls_without_zero_grad():
         assert p.grad is held[n], n                                                          # accumulated in place
         want = ga[n] + gb[n]
         assert float((p.grad - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), n
+
+
+def test_clip_and_adam_as_one_launch_each_match_the_stock_optimizer(monkeypatch):
+    """utils.clip_gradient on the module surface: the gradients handed out by a call site are views of one flat buffer and its parameters live in one flat arena
+    (pn2/optim.py), so clip = one clamp launch and torch.optim.Adam.step = pn2_clamp_adam (same update formula).  The training run must be the stock run:
+    same losses, same weights, a usable optimizer.state_dict(), lr changes (utils.adjust_lr) followed, and the stock step back in charge when the layout breaks."""
+    from pn2 import optim as PO
+    from utils.utils import adjust_lr
+    monkeypatch.setattr(PO, "FUSED_OPT", False)
+    l0, sd0, _ = _run(7, True)
+    monkeypatch.setattr(PO, "FUSED_OPT", True)
+    l1, sd1, model = _run(7, True)
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (l0, l1)
+    for k in sd0:
+        if sd0[k].numel() > 1:
+            d = (sd0[k] - sd1[k]).abs()
+            assert float(d.max()) <= 3e-4 + 1e-6 * float(sd0[k].abs().max()), (k, float(d.max()))
+            assert float(d.norm()) <= 2e-3 * float(sd0[k].norm()) + 1e-6, (k, float(d.norm()), float(sd0[k].norm()))
+    # ---- one more run, looking inside
+    import pn2
+    from pn2.loss import structure_loss
+    from utils.utils import clip_gradient
+    from oracle import weights as W
+    pn2.set_compute_dtype("fp32")
+    model = _model()
+    ref = _model()
+    opt, opt_ref = torch.optim.Adam(model.parameters(), 1e-4), torch.optim.Adam(ref.parameters(), 1e-4)
+    x, m = W.synthetic_batch(2, 96, seed=3)
+    x, m = x.to(dev), m.to(dev)
+
+    def step(model, opt, fused):
+        monkeypatch.setattr(PO, "FUSED_OPT", fused)
+        opt.zero_grad()
+        o = model(x)
+        loss = sum(structure_loss(o[i], o[i + 4], m, 1 - m) for i in range(4))
+        loss.backward()
+        clip_gradient(opt, 0.5)
+        gmax = max(float(p.grad.abs().max()) for p in model.parameters() if p.grad is not None)
+        opt.step()
+        return gmax
+    for i in range(5):
+        if i == 4:
+            adjust_lr(opt, 1e-4, 30, 0.1, 30); adjust_lr(opt_ref, 1e-4, 30, 0.1, 30)          # lr *= 0.1 on both
+        assert step(model, opt, True) <= 0.5 and step(ref, opt_ref, False) <= 0.5
+    f = opt._pn2_fused
+    assert f is not None and f.used == 3 and getattr(opt_ref, "_pn2_fused", None) is None          # (calls 1-2 are plain passes: separate gradient tensors, stock step)
+    hot = list(model.hot_parameters())
+    assert all(f.fp.holds(p) for p in hot)
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert float((p - q).abs().max()) <= 2.2e-5 + 1e-6 * float(q.abs().max()), n           # (lr 1e-5 in the last step; a ~zero gradient may step the other way)
+    s, s_ref = opt.state_dict()["state"], opt_ref.state_dict()["state"]
+    assert set(s) == set(s_ref)
+    for k in s:
+        assert float(s[k]["step"]) == float(s_ref[k]["step"]) == 5.0
+        assert float((s[k]["exp_avg"] - s_ref[k]["exp_avg"]).abs().max()) <= 1e-6 + 1e-4 * float(s_ref[k]["exp_avg"].abs().max())
+    # the layout breaks (a parameter is re-allocated): the stock step takes over again, the state stays usable
+    with torch.no_grad():
+        hot[3].data = hot[3].data.clone()
+    step(model, opt, True)
+    step(model, opt, True)
+    st7 = opt.state_dict()["state"]
+    assert getattr(opt, "_pn2_fused", None) is None and all(float(v["step"]) == 7.0 for v in st7.values()) and len({id(v["step"]) for v in opt.state.values()}) == len(opt.state)
+
+
+def test_verbatim_torch_op_structure_loss_on_the_module_surface():
+    """What an unedited MyTrain_med.py runs: its own torch-op structure_loss (restated in bench.torch_structure_loss) on the outputs of the mirror model - same loss
+    and same parameter gradients as the fused loss kernels."""
+    import sys
+    import pn2
+    from pn2.loss import structure_loss
+    from oracle import weights as W
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    pn2.set_compute_dtype("fp32")
+    x, m = W.synthetic_batch(2, 96, seed=11)
+    x, m = x.to(dev), m.to(dev)
+    res = []
+    for fn in (bench.torch_structure_loss, structure_loss):
+        model = _model()
+        o = model(x)
+        loss = sum(fn(o[i], o[i + 4], m, 1 - m) for i in range(4))
+        loss.backward()
+        res.append((float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
+    num = sum(float((res[0][1][k].double() - res[1][1][k].double()).pow(2).sum()) for k in res[1][1]) ** 0.5
+    den = sum(float(res[1][1][k].double().pow(2).sum()) for k in res[1][1]) ** 0.5
+    assert num / den < 1e-4, num / den
