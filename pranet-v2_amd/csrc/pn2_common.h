@@ -13,6 +13,10 @@ typedef __attribute__((ext_vector_type(4))) double f64x4_t;
 
 #define PN2_F32 0
 #define PN2_BF16 1
+#define PN2_F32F 2          // fp32 storage like PN2_F32, contractions on the f32 matrix pipe (v_mfma_f32_16x16x4_f32, 157 TF/s) instead of the f64 one - conv GEMM / wgrad entry points only
+
+// storage type of PN2_F32F: a float under another name, so that the conv kernels (templated on the storage type) pick another MFMA form for it
+struct f32f_t { float v; };
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {           // round-to-nearest-even, gfx950 hardware convert
@@ -34,6 +38,11 @@ template <> struct TT<float> {
     __device__ static __forceinline__ uint4 pack(const float* f) {
         return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
     }
+};
+template <> struct TT<f32f_t> : TT<float> {
+    static constexpr int DT = PN2_F32F;
+    __device__ static __forceinline__ float ld(const f32f_t* p) { return p->v; }
+    __device__ static __forceinline__ void st(f32f_t* p, float v) { p->v = v; }
 };
 template <> struct TT<bf16_t> {
     static constexpr int VEC = 8;

@@ -46,10 +46,17 @@ __device__ __forceinline__ void pn2_stamp_hw() {
 template <typename T> struct MMA;
 template <> struct MMA<bf16_t> {
     static constexpr int BK = 32 * KSUB;
+    static constexpr bool F64ROWS = false, DEEP = false;
     typedef f32x4_t acc_t;
     __device__ static __forceinline__ int arow(int l15) { return l15; }
     __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+    template <int MT, int NT> __device__ static __forceinline__ void run_block(acc_t (&acc)[MT][NT], const uint4 (&a)[MT], const uint4 (&b)[NT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) run(acc[i][j], a[i], b[j]);
     }
 };
 // PN2_F32 (the parity path): fp32 storage, products and sums in DOUBLE on v_mfma_f64_16x16x4_f64, one rounding to fp32 per output - every conv
@@ -59,6 +66,7 @@ template <> struct MMA<bf16_t> {
 // transpose arow() so that the accumulators land in the common layout and the shared epilogue applies unchanged.
 template <> struct MMA<float> {
     static constexpr int BK = 16 * KSUB;
+    static constexpr bool F64ROWS = true, DEEP = false;
     typedef f64x4_t acc_t;
     __device__ static __forceinline__ int arow(int l15) { return ((l15 & 3) << 2) | (l15 >> 2); }
     // lane (g = lane>>4) holds k = 4g..4g+3 of this 16-deep sub-step; MFMA j contracts {j, 4+j, 8+j, 12+j}
@@ -67,6 +75,55 @@ template <> struct MMA<float> {
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)__uint_as_float(a.y), (double)__uint_as_float(b.y), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)__uint_as_float(a.z), (double)__uint_as_float(b.z), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)__uint_as_float(a.w), (double)__uint_as_float(b.w), acc, 0, 0, 0);
+    }
+    template <int MT, int NT> __device__ static __forceinline__ void run_block(acc_t (&acc)[MT][NT], const uint4 (&a)[MT], const uint4 (&b)[NT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) run(acc[i][j], a[i], b[j]);
+    }
+};
+// PN2_F32F ("fp32fast"): the reference's own arithmetic - fp32 operands, fp32 products and sums - on the f32 matrix pipe (v_mfma_f32_16x16x4_f32: twice the rate of
+// the f64 form).  Round 1 ran ONE k-ordered MFMA chain per output and sat 2.5-3 x further from float64 than the reference's blocked fp32 sums: the matrix
+// core's internal adds do not round to nearest, so a long chain drifts.  Here a chain is 4 MFMAs long (the 16 k-values of a sub-step, started from C = 0);
+// the chunk sums meet in a round-to-nearest VALU add (K / 16 adds per output, unbiased), which costs 4 v_add_f32 per 4 MFMAs (128 matrix-pipe cycles).
+// C/D layout is the common one (row = (lane>>4)*4 + reg): no A-row transpose.
+template <> struct MMA<f32f_t> {
+    static constexpr int BK = 16 * KSUB;
+    static constexpr bool F64ROWS = false, DEEP = true;          // DEEP: the gather kernel prefetches two K-steps ahead (conv_gather_body)
+    typedef f32x4_t acc_t;
+    __device__ static __forceinline__ int arow(int l15) { return l15; }
+    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), t, 0, 0, 0);
+        acc += t;
+    }
+    // a wave's MT x NT blocks of one sub-step, k-major: the MT * NT chains are independent, so consecutive MFMAs never wait for each other's result (issued
+    // block by block as run() would, every MFMA of a chain waited for the one before it and every add for its chain: s_nop 9 per block in the ISA)
+    template <int MT, int NT> __device__ static __forceinline__ void run_block(acc_t (&acc)[MT][NT], const uint4 (&a)[MT], const uint4 (&b)[NT]) {
+        f32x4_t t[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].x), __uint_as_float(b[j].x), f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].y), __uint_as_float(b[j].y), t[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].z), __uint_as_float(b[j].z), t[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].w), __uint_as_float(b[j].w), t[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] += t[i][j];
     }
 };
 
@@ -947,27 +1004,29 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
     // Loads are UNCONDITIONAL (out-of-range vectors read a clamped, valid address) and the zero fill is applied when the
     // registers are written to LDS: a branch around a load makes hipcc wait for it at the join, which would serialise the
     // global->register prefetch of step t+1 with the MFMAs of step t.
-    uint4 ra[NA], rb[NB];
-    unsigned amask = 0;
-    // (macros, not lambdas: arrays captured by reference in a lambda ended up in scratch memory)
-#define PN2_GLOAD(step_)                                                                                               \
+    // (macros, not lambdas: arrays captured by reference in a lambda ended up in scratch memory).  RA_ / RB_ / AM_: the register set a load batch lands in
+    // the weight-panel vectors by literal index: with two register sets (DEEP) hipcc left an `unroll`-ed loop over RB_[i] as a loop and the arrays in scratch
+#define PN2_U4(N_, M_, X_, Y_) do { if constexpr ((N_) > 0) { M_(0, X_, Y_); } if constexpr ((N_) > 1) { M_(1, X_, Y_); } if constexpr ((N_) > 2) { M_(2, X_, Y_); } if constexpr ((N_) > 3) { M_(3, X_, Y_); } } while (0)
+#define PN2_GLOAD_B(i_, RB_, step_) RB_[i_] = *reinterpret_cast<const u32x4_t_*>(bptr + (size_t)(32 * (i_)) * d.Kp + (size_t)(step_) * BK)
+#define PN2_LSTORE_B(i_, RB_, Bs_) *reinterpret_cast<u32x4_t_*>(Bs_ + ((tid >> 3) + 32 * (i_)) * RS + kv * 16) = RB_[i_]
+#define PN2_GLOAD(step_, RA_, RB_, AM_)                                                                                \
     do {                                                                                                               \
-        amask = 0;                                                                                                     \
+        AM_ = 0;                                                                                                       \
         if (PW) {                                                                                                      \
             const int k_ = (step_) * BK + kv * VEC;                                                                    \
             const bool kok_ = k_ < d.Cin_p;                                                                            \
             const int kc_ = kok_ ? k_ : 0;                                                                             \
             _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
-                if (rok[i] && kok_) amask |= 1u << i;                                                                  \
-                ra[i] = *reinterpret_cast<const uint4*>(in + (size_t)rbase[i] * d.ld_in + kc_);                        \
+                if (rok[i] && kok_) AM_ |= 1u << i;                                                                    \
+                RA_[i] = *reinterpret_cast<const u32x4_t_*>(in + (size_t)rbase[i] * d.ld_in + kc_);                    \
             }                                                                                                          \
         } else {                                                                                                       \
             _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
                 int iy_, ix_;                                                                                          \
                 const bool ok_ = rok[i] && tap < taps && tap_pixel_off(gg, riy0[i], rix0[i], tdr, tdc, iy_, ix_);      \
                 const size_t off_ = ok_ ? (size_t)(rbase[i] + iy_ * d.W + ix_) * d.ld_in + ci : 0;                     \
-                if (ok_) amask |= 1u << i;                                                                             \
-                ra[i] = *reinterpret_cast<const uint4*>(in + off_);                                                    \
+                if (ok_) AM_ |= 1u << i;                                                                               \
+                RA_[i] = *reinterpret_cast<const u32x4_t_*>(in + off_);                                                \
             }                                                                                                          \
             ci += BK;                                                                                                  \
             while (ci >= d.Cin_p) {                                                                                    \
@@ -975,19 +1034,28 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
                 if (tcol == d.KW) { tcol = 0; tdc = 0; tdr += d.dil_h; }                                               \
             }                                                                                                          \
         }                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                 \
-            rb[i] = *reinterpret_cast<const uint4*>(bptr + (size_t)(32 * i) * d.Kp + (size_t)(step_) * BK);            \
+        PN2_U4(NB, PN2_GLOAD_B, RB_, step_);                                                                           \
     } while (0)
-#define PN2_LSTORE(stage_)                                                                                             \
+#define PN2_LSTORE(stage_, RA_, RB_, AM_)                                                                              \
     do {                                                                                                               \
         char* As_ = smem + (stage_) * STAGE;                                                                           \
         char* Bs_ = As_ + BM * RS;                                                                                     \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                               \
-            const uint4 v_ = (amask >> i) & 1u ? ra[i] : make_uint4(0, 0, 0, 0);                                       \
-            *reinterpret_cast<uint4*>(As_ + ((tid >> 3) + 32 * i) * RS + kv * 16) = v_;                                \
+            const u32x4_t_ v_ = (AM_ >> i) & 1u ? RA_[i] : u32x4_t_{0u, 0u, 0u, 0u};                                   \
+            *reinterpret_cast<u32x4_t_*>(As_ + ((tid >> 3) + 32 * i) * RS + kv * 16) = v_;                             \
         }                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                 \
-            *reinterpret_cast<uint4*>(Bs_ + ((tid >> 3) + 32 * i) * RS + kv * 16) = rb[i];                            \
+        PN2_U4(NB, PN2_LSTORE_B, RB_, Bs_);                                                                            \
+    } while (0)
+#define PN2_MFMAS(stage_)                                                                                              \
+    do {                                                                                                               \
+        const char* As = smem + (stage_) * STAGE;                                                                      \
+        const char* Bs = As + BM * RS;                                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < KSUB; ++ks) {                                                          \
+            uint4 a[MT], b[NT];                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(As + (wm * WTM + i * 16 + l15a) * RS + ks * 64 + g * 16); \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WTN + j * 16 + l15) * RS + ks * 64 + g * 16);  \
+            MMA<T>::template run_block<MT, NT>(acc, a, b);                                                             \
+        }                                                                                                              \
     } while (0)
 
     BnbPre<T, BM, BN> pre;
@@ -998,33 +1066,53 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
         for (int j = 0; j < NT; ++j) acc[i][j] = typename MMA<T>::acc_t{0, 0, 0, 0};
     const int l15a = MMA<T>::arow(l15);
 
-    PN2_GLOAD(0);
-    PN2_LSTORE(0);
-    __syncthreads();
-    for (int step = 0; step < ksteps; ++step) {
-        const int cur = step & 1;
-        // branch-free prefetch: the last iteration re-loads the final tile into the idle stage (never read)
-        const int nxt = step + 1 < ksteps ? step + 1 : step;
-        PN2_GLOAD(nxt);
-        const char* As = smem + cur * STAGE;
-        const char* Bs = As + BM * RS;
-#pragma unroll
-        for (int ks = 0; ks < KSUB; ++ks) {
-            uint4 a[MT], b[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(As + (wm * WTM + i * 16 + l15a) * RS + ks * 64 + g * 16);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WTN + j * 16 + l15) * RS + ks * 64 + g * 16);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) MMA<T>::run(acc[i][j], a[i], b[j]);
-        }
-        PN2_LSTORE(cur ^ 1);
+    u32x4_t_ ra[NA], rb[NB], ra1[NA], rb1[NB];          // (plain vector types, not HIP's uint4 struct: with two register sets the uint4 arrays stayed in scratch memory; the second set: DEEP only)
+    unsigned amask = 0, amask1 = 0;
+    // Loads are UNCONDITIONAL (out-of-range vectors read a clamped, valid address) and the zero fill is applied when the
+    // registers are written to LDS: a branch around a load makes hipcc wait for it at the join, which would serialise the
+    // global->register prefetch of step t+1 with the MFMAs of step t.
+    if constexpr (!MMA<T>::DEEP) {
+        PN2_GLOAD(0, ra, rb, amask);
+        PN2_LSTORE(0, ra, rb, amask);
         __syncthreads();
+        for (int step = 0; step < ksteps; ++step) {
+            const int cur = step & 1;
+            // branch-free prefetch: the last iteration re-loads the final tile into the idle stage (never read)
+            const int nxt = step + 1 < ksteps ? step + 1 : step;
+            PN2_GLOAD(nxt, ra, rb, amask);
+            PN2_MFMAS(cur);
+            PN2_LSTORE(cur ^ 1, ra, rb, amask);
+            __syncthreads();
+        }
+    } else {
+        // fp32 on the f32 matrix pipe: a K-step is 0.4-0.9 us of MFMAs per wave, shorter than a global-load round trip under load - with the prefetch one step
+        // ahead the LDS store at the end of every step waited for its loads (62 TF/s).  Two register sets: the batch of step t+2 is requested before the MFMAs
+        // of step t, the batch stored to LDS at the end of step t was requested a whole step earlier (loads return in order: the compiler's vmcnt leaves the
+        // younger batch in flight).  Unrolled by two so that both sets are addressed statically.
+        const int last = ksteps - 1;
+        PN2_GLOAD(0, ra, rb, amask);
+        PN2_GLOAD(last < 1 ? last : 1, ra1, rb1, amask1);
+        PN2_LSTORE(0, ra, rb, amask);
+        __syncthreads();
+        for (int step = 0; step < ksteps; step += 2) {
+            PN2_GLOAD(step + 2 < last ? step + 2 : last, ra, rb, amask);
+            PN2_MFMAS(0);
+            PN2_LSTORE(1, ra1, rb1, amask1);
+            __syncthreads();
+            if (step + 1 < ksteps) {
+                PN2_GLOAD(step + 3 < last ? step + 3 : last, ra1, rb1, amask1);
+                PN2_MFMAS(1);
+                PN2_LSTORE(0, ra, rb, amask);
+                __syncthreads();
+            }
+        }
     }
 #undef PN2_GLOAD
 #undef PN2_LSTORE
+#undef PN2_MFMAS
+#undef PN2_U4
+#undef PN2_GLOAD_B
+#undef PN2_LSTORE_B
 
     if constexpr (sizeof(T) == 4) {
         f32x4_t accf[MT][NT];
@@ -1355,6 +1443,7 @@ template <> struct WG<float> {
     static constexpr int PAD = 64;
     static constexpr int NFRAG = 2;  // two uint4 = 8 pixels-slots per lane per 32-pixel step
 };
+template <> struct WG<f32f_t> : WG<float> {};
 
 template <typename T, int BMC, int BNK, int WM, int WN, bool PW>
 __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ slab, const pn2_wgrad_desc& d, int nsplit, int bloc) {
@@ -1479,8 +1568,9 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
 #pragma unroll
                     for (int j = 0; j < NT; ++j) MMA<bf16_t>::run(acc[i][j], a[i], b[j]);
             } else {
+                f32x4_t part[MMA<T>::F64ROWS ? 1 : MT][MMA<T>::F64ROWS ? 1 : NT];
 #pragma unroll
-                for (int q = 0; q < WGP / 4; ++q) {       // 4 pixels per v_mfma_f32_16x16x4_f32
+                for (int q = 0; q < WGP / 4; ++q) {       // 4 pixels per 16x16x4 MFMA
                     float a[MT], b[NT];
 #pragma unroll
                     for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float*>(Ys + (q * 4 + g) * RSY + (wm * WTM + i * 16 + l15) * 4);
@@ -1489,7 +1579,14 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[i], (double)b[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j) {
+                            if constexpr (MMA<T>::F64ROWS) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[i], (double)b[j], acc[i][j], 0, 0, 0);
+                            else {          // PN2_F32F: chains of 4 MFMAs (16 pixels) from C = 0, met by round-to-nearest adds (see MMA<f32f_t>)
+                                if ((q & 3) == 0) part[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                                else part[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], part[i][j], 0, 0, 0);
+                                if ((q & 3) == 3) acc[i][j] += part[i][j];
+                            }
+                        }
                 }
             }
             lstore(cur ^ 1);
@@ -1504,7 +1601,7 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // f64 MFMA (fp32 path): C/D row = (lane>>4) + 4*reg; every other form: (lane>>4)*4 + reg
-                const int row = sizeof(T) == 4 ? g + 4 * r : g * 4 + r;
+                const int row = MMA<T>::F64ROWS ? g + 4 * r : g * 4 + r;
                 dst[(size_t)(wm * WTM + i * 16 + row) * d.Kp + wn * WTN + j * 16 + l15] = (float)acc[i][j][r];
             }
 }
@@ -2110,16 +2207,16 @@ int launch_dma_tab_ks2(const pn2_conv_job* jobs, const int* bstart, int njobs, i
     PN2_CHECK_LAUNCH();
     return 0;
 }
-template <bool EP, int BM, int BN, int WM, int WN>
+template <typename T, bool EP, int BM, int BN, int WM, int WN>
 int launch_gather_tab_f32(const pn2_conv_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
     constexpr int main_b = 2 * (BM + BN) * RS, epi_b = BM * (BN * 4 + 16) + 3 * WM * BN * 4, ep_b = EP ? ep_lds_bytes(4) : 0;
     constexpr int lds = (main_b > epi_b ? main_b : epi_b) > ep_b ? (main_b > epi_b ? main_b : epi_b) : ep_b;
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm_tab<float, BM, BN, WM, WN, false, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm_tab<T, BM, BN, WM, WN, false, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    hipLaunchKernelGGL((conv_gather_gemm_tab<float, BM, BN, WM, WN, false, EP>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
+    hipLaunchKernelGGL((conv_gather_gemm_tab<T, BM, BN, WM, WN, false, EP>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
     PN2_CHECK_LAUNCH();
     return 0;
 }
@@ -2146,11 +2243,21 @@ int gemm_multi_dispatch(int dtype, int bm, int bn, int bits, const pn2_conv_job*
     }
     if (dtype == PN2_F32) {
         if (bm == 128) {
-            if (bn == 64) return launch_gather_tab_f32<EP, 128, 64, 2, 2>(jobs, bstart, njobs, total, st);
-            if (bn == 32) return launch_gather_tab_f32<EP, 128, 32, 4, 1>(jobs, bstart, njobs, total, st);
+            if (bn == 64) return launch_gather_tab_f32<float, EP, 128, 64, 2, 2>(jobs, bstart, njobs, total, st);
+            if (bn == 32) return launch_gather_tab_f32<float, EP, 128, 32, 4, 1>(jobs, bstart, njobs, total, st);
         } else if (bm == 64) {
-            if (bn == 64) return launch_gather_tab_f32<EP, 64, 64, 2, 2>(jobs, bstart, njobs, total, st);
-            if (bn == 32) return launch_gather_tab_f32<EP, 64, 32, 4, 1>(jobs, bstart, njobs, total, st);
+            if (bn == 64) return launch_gather_tab_f32<float, EP, 64, 64, 2, 2>(jobs, bstart, njobs, total, st);
+            if (bn == 32) return launch_gather_tab_f32<float, EP, 64, 32, 4, 1>(jobs, bstart, njobs, total, st);
+        }
+        return -2;
+    }
+    if (dtype == PN2_F32F) {
+        if (bm == 128) {
+            if (bn == 64) return launch_gather_tab_f32<f32f_t, EP, 128, 64, 2, 2>(jobs, bstart, njobs, total, st);
+            if (bn == 32) return launch_gather_tab_f32<f32f_t, EP, 128, 32, 4, 1>(jobs, bstart, njobs, total, st);
+        } else if (bm == 64) {
+            if (bn == 64) return launch_gather_tab_f32<f32f_t, EP, 64, 64, 2, 2>(jobs, bstart, njobs, total, st);
+            if (bn == 32) return launch_gather_tab_f32<f32f_t, EP, 64, 32, 4, 1>(jobs, bstart, njobs, total, st);
         }
         return -2;
     }
@@ -2445,11 +2552,12 @@ static int conv_gemm_impl(int dtype, const void* in, const void* wp, void* out, 
     if (((d->flags >> 16) & 15) > 1 && (dtype != PN2_BF16 || !psum || (d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS | PN2_CONV_ACCUM)) || ((d->flags >> 8) & 3) < 2)) return -2;
     if (d->flags & PN2_CONV_AFFINE) return -2;                 // (pn2_conv_gemm_affine owns that flag)
     const bool gated = d->flags & PN2_CONV_ROWGATE;
-    const int vec_ = dtype == PN2_F32 ? 4 : 8;
+    const int vec_ = dtype == PN2_BF16 ? 8 : 4;
     if (gated && (!ep.a.par || (ep.a.mode | ep.b.mode) != 0 || ep.b.out || (d->flags & PN2_CONV_BIAS) || ((d->flags >> 16) & 15) > 1 || d->Cout % vec_ || d->ld_out % vec_)) return -2;
     const bool use_ep = (ep.a.mode | ep.b.mode) != 0 || ep.b.out != nullptr || gated;      // the gate lives in the epilogue-statistics instantiations
     if (dtype == PN2_BF16) return use_ep ? gemm_dispatch<bf16_t, true>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream) : gemm_dispatch<bf16_t, false>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream);
     if (dtype == PN2_F32) return use_ep ? gemm_dispatch<float, true>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream) : gemm_dispatch<float, false>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream);
+    if (dtype == PN2_F32F) return use_ep ? gemm_dispatch<f32f_t, true>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream) : gemm_dispatch<f32f_t, false>(in, wp, out, psum, psq, *d, ep, (hipStream_t)stream);
     return -3;
 }
 
@@ -2477,7 +2585,7 @@ int pn2_conv_tile_n(int cout) {
 
 int pn2_wgrad_tile_co(int cout_p) { return cout_p > 64 ? 128 : (cout_p > 32 ? 64 : 32); }
 
-int pn2_conv_tile_m(int m, int cout, int dtype) { int bm, bn; pick_tiles(m, cout, dtype == PN2_F32, bm, bn); return bm; }
+int pn2_conv_tile_m(int m, int cout, int dtype) { int bm, bn; pick_tiles(m, cout, dtype != PN2_BF16, bm, bn); return bm; }
 
 int pn2_conv_stat_blocks(int m, int cout, int dtype) { const int bm = pn2_conv_tile_m(m, cout, dtype); return (m + bm - 1) / bm; }
 
@@ -2491,7 +2599,7 @@ int pn2_conv_gemm_affine(int dtype, const void* in, const void* wp, void* out, c
                          void* stream) {
     if (!d || !scale || !shift) return -1;
     if (!(d->flags & PN2_CONV_AFFINE) || (d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS | PN2_CONV_ACCUM | PN2_CONV_ROWGATE)) || ((d->flags >> 16) & 15) > 1) return -2;
-    const int vec_ = dtype == PN2_F32 ? 4 : 8;
+    const int vec_ = dtype == PN2_BF16 ? 8 : 4;
     if (res && (d->Cout % vec_ || d->ld_out % vec_ || ld_res % vec_)) return -2;
     pn2_conv_ep ep;
     memset(&ep, 0, sizeof(ep));
@@ -2500,6 +2608,7 @@ int pn2_conv_gemm_affine(int dtype, const void* in, const void* wp, void* out, c
     if (d->Cin_p % 8 || d->ld_in % 8 || d->Kp % 128 || (d->stride != 1 && d->stride != 2 && d->stride != 4 && d->stride != 8)) return -2;
     if (dtype == PN2_BF16) return gemm_dispatch<bf16_t, false>(in, wp, out, const_cast<float*>(scale), const_cast<float*>(shift), *d, ep, (hipStream_t)stream);
     if (dtype == PN2_F32) return gemm_dispatch<float, false>(in, wp, out, const_cast<float*>(scale), const_cast<float*>(shift), *d, ep, (hipStream_t)stream);
+    if (dtype == PN2_F32F) return gemm_dispatch<f32f_t, false>(in, wp, out, const_cast<float*>(scale), const_cast<float*>(shift), *d, ep, (hipStream_t)stream);
     return -3;
 }
 
@@ -2515,7 +2624,7 @@ int pn2_conv_gemm_gated(int dtype, const void* in, const void* wp, void* out, fl
 
 int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const pn2_conv_desc* d, const pn2_conv_ep* ep, void* stream) {
     if (!d || !ep) return -1;
-    const int vec = dtype == PN2_F32 ? 4 : 8;
+    const int vec = dtype == PN2_BF16 ? 8 : 4;
     if ((d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS)) || ((d->flags >> 16) & 15) > 1) return -2;
     if (d->Cout % vec || d->ld_out % vec) return -2;                      // the statistics live in the 16-byte store path
     int rc = bnb_check(ep->a, vec, false);
@@ -2534,7 +2643,7 @@ int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d) {
     if (ksb & 0x80) return -2;
     int kern, bm, bn;
     if (dtype == PN2_BF16) { gemm_select<bf16_t>(*d, kern, bm, bn); if (!dma_extent_ok(*d)) return -2; }      // (a register-staged choice joins the table on the LDS-DMA kernel: same bits)
-    else if (dtype == PN2_F32) gemm_select<float>(*d, kern, bm, bn);
+    else if (dtype == PN2_F32 || dtype == PN2_F32F) gemm_select<float>(*d, kern, bm, bn);
     else return -3;
     if (ksb) {
         if (dtype != PN2_BF16 || bn < 64 || (bm == 128 && bn == 128)) return -2;
@@ -2550,12 +2659,12 @@ int pn2_conv_gemm_job_blocks(int dtype, const pn2_conv_job* j, int bm, int bn) {
     if ((d.flags & PN2_CONV_STATS) && (!j->psum || !j->psq)) return -1;
     if ((d.flags & PN2_CONV_BIAS) && !j->psum) return -1;
     if (d.flags & PN2_CONV_AFFINE) {
-        const int v_ = dtype == PN2_F32 ? 4 : 8;
+        const int v_ = dtype == PN2_BF16 ? 8 : 4;
         if (!j->psum || !j->psq || (d.flags & (PN2_CONV_STATS | PN2_CONV_BIAS | PN2_CONV_ACCUM | PN2_CONV_ROWGATE)) || j->ep.a.mode || j->ep.b.mode || j->ep.b.out) return -1;
         if (j->ep.a.y && (d.Cout % v_ || d.ld_out % v_ || j->ep.a.ld_y % v_)) return -2;
     }
     const bool use_ep = (j->ep.a.mode | j->ep.b.mode) != 0 || j->ep.b.out != nullptr;
-    const int vec = dtype == PN2_F32 ? 4 : 8;
+    const int vec = dtype == PN2_BF16 ? 8 : 4;
     if (use_ep && (d.Cout % vec || d.ld_out % vec || (d.flags & (PN2_CONV_STATS | PN2_CONV_BIAS)))) return -2;
     return ((d.N * d.OH * d.OW + bm - 1) / bm) * ((d.Cout + bn - 1) / bn);
 }
@@ -2569,15 +2678,16 @@ int pn2_conv_gemm_multi(int dtype, int bm, int bn, int ep, const pn2_conv_job* j
 int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const pn2_wgrad_desc* d, int nsplit, void* stream) {
     if (!dy || !x || !slab || !d || nsplit < 1) return -1;
     if (d->Cin_p % 8 || d->ld_x % 8 || d->ld_dy % 8 || d->Cout_p % 8) return -2;
-    if (dtype == PN2_F32 && d->tune >= 2) return -2;           // the LDS-DMA kernels (and pn2_conv_wgrad_blocks' tile for them) are bf16 only
+    if (dtype != PN2_BF16 && d->tune >= 2) return -2;           // the LDS-DMA kernels (and pn2_conv_wgrad_blocks' tile for them) are bf16 only
     if (dtype == PN2_BF16) return wgrad_dispatch<bf16_t>(dy, x, slab, *d, nsplit, (hipStream_t)stream);
     if (dtype == PN2_F32) return wgrad_dispatch<float>(dy, x, slab, *d, nsplit, (hipStream_t)stream);
+    if (dtype == PN2_F32F) return wgrad_dispatch<f32f_t>(dy, x, slab, *d, nsplit, (hipStream_t)stream);
     return -3;
 }
 
 int pn2_conv_wgrad_variant(int dtype, const pn2_wgrad_desc* d) {
     if (!d) return -1;
-    return dtype == PN2_BF16 ? wgrad_variant<bf16_t>(*d) : (dtype == PN2_F32 ? wgrad_variant<float>(*d) : -3);
+    return dtype == PN2_BF16 ? wgrad_variant<bf16_t>(*d) : ((dtype == PN2_F32 || dtype == PN2_F32F) ? wgrad_variant<float>(*d) : -3);
 }
 
 int pn2_conv_wgrad_blocks(const pn2_wgrad_desc* d, int nsplit) {
@@ -2591,6 +2701,7 @@ int pn2_conv_wgrad_multi(int dtype, int variant, const pn2_wgrad_job* jobs_dev, 
     if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1 || variant < 0 || variant >= 14) return -1;
     if (dtype == PN2_BF16) return wgrad_multi_dispatch<bf16_t>(variant, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
     if (dtype == PN2_F32) return wgrad_multi_dispatch<float>(variant, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
+    if (dtype == PN2_F32F) return wgrad_multi_dispatch<f32f_t>(variant, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
     return -3;
 }
 

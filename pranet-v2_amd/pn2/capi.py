@@ -11,6 +11,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PN2_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libpn2_hip.so")      # PN2_LIB: another build of the same library (A/B of build flags)
 
 F32, BF16 = 0, 1
+F32F = 2          # PN2_F32F: fp32 storage like F32, conv contractions on the f32 matrix pipe (v_mfma_f32_16x16x4_f32) instead of the f64 one
+# "fp32fast" (pn2.set_compute_dtype): the engine keeps working in F32 - same buffers, same element-wise kernels - and the conv GEMM / wgrad entry points below
+# receive F32F instead of F32 at this boundary (the only place where the two differ)
+F32_MMA = F32
+_MMA_FUNCS = {"pn2_conv_gemm", "pn2_conv_gemm_ep", "pn2_conv_gemm_gated", "pn2_conv_gemm_affine", "pn2_conv_gemm_multi", "pn2_conv_gemm_tile", "pn2_conv_gemm_job_blocks",
+              "pn2_conv_wgrad", "pn2_conv_wgrad_multi", "pn2_conv_wgrad_variant"}
+
+
+def set_f32_mma(fast):
+    global F32_MMA
+    F32_MMA = F32F if fast else F32
 CONV_STATS, CONV_ACCUM, CONV_BIAS = 1, 2, 4
 CONV_AFFINE, CONV_RELU, CONV_RELU6 = 16, 32, 64
 
@@ -286,6 +297,11 @@ class _Caller:
 
     def __getattr__(self, name):
         fn = getattr(load(), name)
+        if name in _MMA_FUNCS:
+            raw = fn
+
+            def fn(dt, *a):          # noqa: F811   (fp32fast: F32 -> F32F for the entry points that run MFMA contractions)
+                return raw(F32_MMA if dt == F32 else dt, *a)
         if name in _VALUE_FUNCS:
             return fn
 

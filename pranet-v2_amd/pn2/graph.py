@@ -18,9 +18,20 @@ _compute_dtype = _DT[os.environ.get("PN2_DTYPE", "bf16").lower()]
 
 
 def set_compute_dtype(name):
-    """'bf16' (default: bf16 storage + MFMA, fp32 accumulate) or 'fp32' (exact-fp32 MFMA, parity runs)."""
+    """'bf16' (default: bf16 storage + MFMA, fp32 accumulate), 'fp32' (fp32 storage, conv contractions in DOUBLE on the f64 matrix pipe: the parity path) or
+    'fp32fast' (fp32 storage, fp32 products and sums on the f32 matrix pipe - the reference's own arithmetic, MyTrain_med.py runs without autocast - at twice
+    the pipe rate; everything except the conv GEMM / wgrad kernels is the 'fp32' path)."""
     global _compute_dtype
-    _compute_dtype = _DT[name.lower()] if isinstance(name, str) else name
+    from . import capi
+    fast = isinstance(name, str) and name.lower() in ("fp32fast", "f32fast", "fp32_fast")
+    capi.set_f32_mma(fast)
+    _compute_dtype = F32 if fast else (_DT[name.lower()] if isinstance(name, str) else name)
+
+
+def get_compute_mode():
+    """'bf16' | 'fp32' | 'fp32fast'"""
+    from . import capi
+    return "bf16" if _compute_dtype == BF16 else ("fp32fast" if capi.F32_MMA == capi.F32F else "fp32")
 
 
 def get_compute_dtype():

@@ -135,6 +135,8 @@ class Recorder:
                     fl, tag, shape = 0, "", _shape(_name, a)
                     by_ = capi.WORK.pop("bytes", 0) if _name.endswith("_multi") else _bytes(_name, a)      # lock-step launches: summed over their jobs
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                if _name in capi._MMA_FUNCS and int(a[0]) == capi.F32:          # fp32fast: the translation capi.call applies at the ABI boundary
+                    a = (capi.F32_MMA,) + tuple(a[1:])
                 e0.record()
                 rc = _fn(*a)
                 e1.record()
