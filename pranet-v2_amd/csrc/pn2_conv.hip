@@ -1569,6 +1569,10 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
                     for (int j = 0; j < NT; ++j) MMA<bf16_t>::run(acc[i][j], a[i], b[j]);
             } else {
                 f32x4_t part[MMA<T>::F64ROWS ? 1 : MT][MMA<T>::F64ROWS ? 1 : NT];
+#ifndef PN2_WCH
+#define PN2_WCH 4
+#endif
+                constexpr int WCH = PN2_WCH;          // MFMAs per chain (x 4 pixels)
 #pragma unroll
                 for (int q = 0; q < WGP / 4; ++q) {       // 4 pixels per 16x16x4 MFMA
                     float a[MT], b[NT];
@@ -1582,9 +1586,9 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
                         for (int j = 0; j < NT; ++j) {
                             if constexpr (MMA<T>::F64ROWS) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[i], (double)b[j], acc[i][j], 0, 0, 0);
                             else {          // PN2_F32F: chains of 4 MFMAs (16 pixels) from C = 0, met by round-to-nearest adds (see MMA<f32f_t>)
-                                if ((q & 3) == 0) part[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                                if ((q & (WCH - 1)) == 0) part[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                                 else part[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], part[i][j], 0, 0, 0);
-                                if ((q & 3) == 3) acc[i][j] += part[i][j];
+                                if ((q & (WCH - 1)) == WCH - 1) acc[i][j] += part[i][j];
                             }
                         }
                 }
@@ -2111,13 +2115,13 @@ int launch_wgrad(const void* dy, const void* x, float* slab, const pn2_wgrad_des
 template <typename T>
 void gemm_select(const pn2_conv_desc& d, int& kern, int& bm, int& bn) {
     pick_tiles(d.N * d.OH * d.OW, d.Cout, sizeof(T) == 4, bm, bn);
-    const int tune = sizeof(T) == 2 ? (d.flags >> 8) & 0xff : 0;
+    const int tune = (sizeof(T) == 2 || !MMA<T>::F64ROWS) ? (d.flags >> 8) & 0xff : 0;          // (fp32fast takes the tile bits of a tuning code; its kernel is always the register-staged one)
     const int tk_ = dma_extent_ok(d) ? (tune & 3) : 1, tbm = (tune >> 2) & 3, tbn = (tune >> 4) & 3;     // > 2 GB operand: register-staged kernel (64-bit addresses)
     if (tbm) bm = tbm == 1 ? 64 : 128;
     if (tbn) bn = tbn == 1 ? 32 : (tbn == 2 ? 64 : 128);
     kern = 0;
     if (sizeof(T) == 2) kern = tk_ == 3 ? 3 : ((tk_ ? tk_ == 2 : true) ? 2 : 0);
-    if (sizeof(T) == 4 && bn == 128) bn = 64;
+    if (sizeof(T) == 4 && bn == 128) bn = 64;          // (fp32: 64-wide tiles at most - f64 accumulators of a 128-wide wave tile would take 128 registers; fp32fast measured slower on them: 82 -> 76 TF/s on the wide 1x1 convs, fewer workgroups per CU)
 }
 
 template <typename T, bool EP>
@@ -2159,13 +2163,13 @@ int gemm_dispatch(const void* in, const void* wp, void* out, float* psum, float*
     }
     if (bm == 128) {
         if (bn == 128) {
-            if constexpr (sizeof(T) == 2) return launch_gemm<T, 128, 128, 2, 2, EP>(in, wp, out, psum, psq, d, ep, st);
+            if constexpr (!MMA<T>::F64ROWS) return launch_gemm<T, 128, 128, 2, 2, EP>(in, wp, out, psum, psq, d, ep, st);
         }
         if (bn == 64) return launch_gemm<T, 128, 64, 2, 2, EP>(in, wp, out, psum, psq, d, ep, st);
         return launch_gemm<T, 128, 32, 4, 1, EP>(in, wp, out, psum, psq, d, ep, st);
     }
     if (bn == 128) {
-        if constexpr (sizeof(T) == 2) return launch_gemm<T, 64, 128, 2, 2, EP>(in, wp, out, psum, psq, d, ep, st);
+        if constexpr (!MMA<T>::F64ROWS) return launch_gemm<T, 64, 128, 2, 2, EP>(in, wp, out, psum, psq, d, ep, st);
     }
     if (bn == 64) return launch_gemm<T, 64, 64, 2, 2, EP>(in, wp, out, psum, psq, d, ep, st);
     return launch_gemm<T, 64, 32, 4, 1, EP>(in, wp, out, psum, psq, d, ep, st);
@@ -2253,9 +2257,11 @@ int gemm_multi_dispatch(int dtype, int bm, int bn, int bits, const pn2_conv_job*
     }
     if (dtype == PN2_F32F) {
         if (bm == 128) {
+            if (bn == 128) return launch_gather_tab_f32<f32f_t, EP, 128, 128, 2, 2>(jobs, bstart, njobs, total, st);
             if (bn == 64) return launch_gather_tab_f32<f32f_t, EP, 128, 64, 2, 2>(jobs, bstart, njobs, total, st);
             if (bn == 32) return launch_gather_tab_f32<f32f_t, EP, 128, 32, 4, 1>(jobs, bstart, njobs, total, st);
         } else if (bm == 64) {
+            if (bn == 128) return launch_gather_tab_f32<f32f_t, EP, 64, 128, 2, 2>(jobs, bstart, njobs, total, st);
             if (bn == 64) return launch_gather_tab_f32<f32f_t, EP, 64, 64, 2, 2>(jobs, bstart, njobs, total, st);
             if (bn == 32) return launch_gather_tab_f32<f32f_t, EP, 64, 32, 4, 1>(jobs, bstart, njobs, total, st);
         }
@@ -2643,7 +2649,8 @@ int pn2_conv_gemm_tile(int dtype, const pn2_conv_desc* d) {
     if (ksb & 0x80) return -2;
     int kern, bm, bn;
     if (dtype == PN2_BF16) { gemm_select<bf16_t>(*d, kern, bm, bn); if (!dma_extent_ok(*d)) return -2; }      // (a register-staged choice joins the table on the LDS-DMA kernel: same bits)
-    else if (dtype == PN2_F32 || dtype == PN2_F32F) gemm_select<float>(*d, kern, bm, bn);
+    else if (dtype == PN2_F32) gemm_select<float>(*d, kern, bm, bn);
+    else if (dtype == PN2_F32F) gemm_select<f32f_t>(*d, kern, bm, bn);
     else return -3;
     if (ksb) {
         if (dtype != PN2_BF16 || bn < 64 || (bm == 128 && bn == 128)) return -2;

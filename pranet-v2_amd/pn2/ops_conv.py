@@ -49,7 +49,8 @@ class ConvOps:
         self.tuner and reused under hipGraph capture).  Returns the code for pn2_conv_desc.flags bits 8..15 (0 = library heuristic).
         ep: the launch carries a BatchNorm-backward epilogue (pn2_conv_gemm_ep): the candidates are timed WITH it (its extra operand reads and
         per-tile work favour other tiles than the plain kernel), writing to scratch destinations."""
-        if self.dt != BF16:
+        fast = self.dt == F32 and capi.F32_MMA == capi.F32F          # fp32fast: tiles of the register-staged kernel are tuned per shape too (64-row tiles win where
+        if self.dt != BF16 and not fast:                             # the heuristic takes 128: more workgroups per CU; 716 -> 748 images/s with 64 rows everywhere)
             return 0
         t = self.tuner
         if t is None:                    # PN2_AUTOTUNE=0: the library's heuristic tile, inside the class the shape rule names
@@ -57,6 +58,8 @@ class ConvOps:
         key = ("g", cd.N, cd.H, cd.W, cd.OH, cd.OW, cd.Cin_p, cd.ld_in, Cout, cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w, cd.transposed)
         if ep is not None:
             key = key + ("ep", ep.a.mode, ep.b.mode, 1 if ep.b.out else 0, cd.flags & capi.CONV_ACCUM)
+        if fast:
+            key = key + ("f32f",)
         if key in t:
             if core.TUNE_LOG is not None:
                 core.TUNE_LOG.append((key, t[key], "hit"))
@@ -78,14 +81,14 @@ class ConvOps:
         rule has to hold here too: module eval without the tuner and a tuned Predictor must return the same bits.  2-stage ring, 64 x 128 tile: fits
         the LDS for every shape of the class.  Launches with a BatchNorm-backward epilogue (training only) keep the heuristic: whether a split-K tile
         fits next to their operand tiles is only known by trying, which is the tuner's job."""
-        if ep is None and self._ks_class(cd, M, Cout):
+        if ep is None and self.dt == BF16 and self._ks_class(cd, M, Cout):
             return KS_UNTUNED
         return 0
 
     def _tune_gemm_run(self, t, key, cd, in_ptr, wp, M, Cout, ep):
         st = _stream()
         nul = C.c_void_p(0)
-        scratch = torch.empty((M, Cout), dtype=torch.bfloat16, device=self.dev)
+        scratch = torch.empty((M, Cout), dtype=self.tdt, device=self.dev)
         d2 = capi.ConvDesc()
         C.memmove(C.byref(d2), C.byref(cd), C.sizeof(capi.ConvDesc))
         d2.ld_out, d2.Cout = Cout, Cout
@@ -97,7 +100,7 @@ class ConvOps:
             tp = torch.empty((4, nb64, Cout), dtype=torch.float32, device=self.dev)
             e2.a.p1, e2.a.p2, e2.a.ldp = tp[0].data_ptr(), tp[1].data_ptr(), Cout
             if ep.b.out:
-                scratch_b = torch.empty((M, Cout), dtype=torch.bfloat16, device=self.dev)
+                scratch_b = torch.empty((M, Cout), dtype=self.tdt, device=self.dev)
                 e2.b.out, e2.b.ld_out = scratch_b.data_ptr(), Cout
                 e2.b.p1, e2.b.p2, e2.b.ldp = tp[2].data_ptr(), tp[3].data_ptr(), Cout
             base = d2.flags
@@ -113,13 +116,13 @@ class ConvOps:
         # kernels, which all agree bit for bit.  Whether a shape takes it is therefore a RULE of the shape, not of a timing: about one wave of tiles and a long
         # K loop (what the free tuning run of round 5 picked it for) - every call site that computes the same conv gets the same bits, and the tuner chooses
         # kernel / tile inside the class.
-        ks2 = self._ks_class(cd, M, Cout)
+        ks2 = self.dt == BF16 and self._ks_class(cd, M, Cout)
         cands, plain = [], []
-        for kern in (1, 2, 3):             # 1 register-staged, 2 LDS-DMA with a 3-stage ring, 3 LDS-DMA with a 2-stage ring (more workgroups per CU)
+        for kern in ((1, 2, 3) if self.dt == BF16 else (1,)):             # 1 register-staged, 2 LDS-DMA with a 3-stage ring, 3 LDS-DMA with a 2-stage ring (more workgroups per CU); fp32fast: 1
             for bm in (1, 2):
                 if bm == 2 and M <= 64:
                     continue
-                for bn in (1, 2, 3):
+                for bn in ((1, 2, 3) if self.dt == BF16 else (1, 2)):
                     if (bn == 2 and Cout <= 32) or (bn == 3 and Cout <= 64):
                         continue
                     plain.append(kern | (bm << 2) | (bn << 4))
@@ -168,15 +171,18 @@ class ConvOps:
         if bm:
             b = 64 if bm == 1 else 128
             return (M + b - 1) // b
-        return call.pn2_conv_stat_blocks(M, Cout, self.dt)
+        return call.pn2_conv_stat_blocks(M, Cout, capi.F32_MMA if self.dt == F32 else self.dt)          # (fp32fast picks its own tiles)
 
     def _tune_wgrad(self, wd, dy_ptr, x_ptr, rd, nsplit, wshape):
         """-> (kernel code, pixel splits) for this wgrad shape.  Candidates: register-staged / LDS-DMA / LDS-DMA with 128 x 256 tiles x
         {1, 1/2, 1/4, 1/8} of the heuristic split count; each is timed together with the slab reduction its split count implies."""
         t = self.tuner
-        if t is None or self.dt != BF16:
+        fast = self.dt == F32 and capi.F32_MMA == capi.F32F          # fp32fast: one kernel, but the pixel-split count is worth timing
+        if t is None or (self.dt != BF16 and not fast):
             return 0, nsplit
         key = ("w", wd.N, wd.H, wd.W, wd.OH, wd.OW, wd.Cin_p, wd.ld_x, wd.Cout_p, wd.ld_dy, wd.KH, wd.KW, wd.stride, wd.pad_h, wd.pad_w, wd.dil_h, wd.dil_w, nsplit)
+        if fast:
+            key = key + ("f32f",)
         if key in t:
             return t[key]
         if torch.cuda.is_current_stream_capturing():
@@ -190,6 +196,8 @@ class ConvOps:
         slab = torch.empty((nsplit, wd.Rp, wd.Kp), dtype=torch.float32, device=self.dev)
         gw = torch.empty(tuple(wshape), dtype=torch.float32, device=self.dev)
         codes = (1, 2, 3) if (call.pn2_wgrad_tile_co(wd.Cout_p) == 128 and wd.Kp >= 256) else (1, 2)      # 3: LDS-DMA kernel with 128 x 256 tiles
+        if self.dt != BF16:
+            codes = (1,)
         cands = [(code, ns) for ns in sorted({max(1, nsplit >> k) for k in range(4)}, reverse=True) for code in codes]
         evs = []
 
@@ -687,7 +695,7 @@ class ConvOps:
 
     def _tile_m(self, M, Cout, tune):
         bm = (tune >> 2) & 3
-        return (64 if bm == 1 else 128) if bm else call.pn2_conv_tile_m(M, Cout, self.dt)
+        return (64 if bm == 1 else 128) if bm else call.pn2_conv_tile_m(M, Cout, capi.F32_MMA if self.dt == F32 else self.dt)
 
     def _fill_bnb(self, t, act, nblk):
         """Describe `act`'s BatchNorm to a dgrad epilogue target and register the partial rows it will leave."""
