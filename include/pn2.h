@@ -116,7 +116,11 @@ typedef struct pn2_bnb_target {
     const void* raw2; const float* par2;   /* par2 == NULL: no statistics for those columns (zeros are written) */
     float* p1; float* p2; int ldp;  /* partial rows [pn2_conv_stat_blocks or ceil(M / tile_m)][ldp] */
 } pn2_bnb_target;
-typedef struct pn2_conv_ep { pn2_bnb_target a, b; } pn2_conv_ep;
+/* pool (optional, with PN2_CONV_ACCUM, target a with statistics, no target b, even OH / OW): the prior content of the += destination is NOT read from `out`; it is
+ * 1/4 of row (n, y/2, x/2) of this quarter-resolution tensor [N][OH/2][OW/2][ld_pool] for output row (n, y, x) - the backward of AvgPool2d(2, 2) in front of the
+ * downsample conv of a Res2Net stage block (Res2Net_v1b.py:127-136,80) folded into the dgrad that completes the block input's gradient: out = dgrad + pool/4 (the bits a
+ * separate pn2_avgpool_bwd + += would leave: 1/4 is exact), no pool-backward launch, no full-resolution write + re-read of that gradient. */
+typedef struct pn2_conv_ep { pn2_bnb_target a, b; const void* pool; int ld_pool; int pad_; } pn2_conv_ep;
 int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const pn2_conv_desc* d, const pn2_conv_ep* ep, void* stream);
 /* Many conv GEMMs (forward / dgrad, with or without the epilogue above) of ONE tile shape in one launch, from a DEVICE job table: the convs at the same
  * position of independent chains (the RFB branches of the three RFB modules, pranet.py:46-83; the parallel 3x3 convs of a Res2Net stage block,

@@ -190,6 +190,13 @@ __device__ __forceinline__ void bnb_select(const pn2_bnb_target& t, int col, con
     if (t.split > 0 && col >= t.split) { raw = t.raw2; par = t.par2; if (!par) stat = false; }
 }
 
+// pn2_conv_ep.pool: the prior content of a += destination comes from a QUARTER-resolution tensor (row (n, y/2, x/2) for output row (n, y, x)), scaled by 1/4 -
+// the backward of AvgPool2d(2, 2) (Res2Net_v1b.py:127-136: the downsample branch of a stage block) folded into the dgrad epilogue that completes the gradient
+__device__ __forceinline__ int pool_row(const pn2_conv_desc& d, int m) {
+    const int hw = d.OH * d.OW, n = m / hw, rem = m - n * hw, y = rem / d.OW, x = rem - y * d.OW;
+    return (n * (d.OH >> 1) + (y >> 1)) * (d.OW >> 1) + (x >> 1);
+}
+
 template <typename T, int BM, int BN>
 __device__ __forceinline__ void bnb_prefetch(const pn2_conv_desc& d, const pn2_conv_ep& ep, const T* out, int M, int m0, int n0, BnbPre<T, BM, BN>& P) {
     constexpr int VEC = TT<T>::VEC, VPR = BN / VEC, RPT = BnbPre<T, BM, BN>::RPT;
@@ -207,7 +214,10 @@ __device__ __forceinline__ void bnb_prefetch(const pn2_conv_desc& d, const pn2_c
         if (stA) P.ra[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(rawA) + mc * ep.a.ld_raw + colc);
         if (yA) P.ma[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(ep.a.y) + mc * ep.a.ld_y + colc);
         if (stB) P.rb[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(rawB) + mc * ep.b.ld_raw + colc);
-        if (acc) P.vd[u] = *reinterpret_cast<const uint4*>(out + mc * d.ld_out + colc);
+        if (acc) {
+            if (ep.pool) P.vd[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(ep.pool) + (size_t)pool_row(d, (int)mc) * ep.ld_pool + colc);
+            else P.vd[u] = *reinterpret_cast<const uint4*>(out + mc * d.ld_out + colc);
+        }
     }
 }
 
@@ -232,7 +242,7 @@ __device__ __forceinline__ void bnb_params(const pn2_bnb_target& t, const float*
 // One target: walk this thread's rows of the staged C tile, store them to dst (+= vd when ACC) and accumulate t1 = sum dz, t2 = sum dz * raw
 template <typename T, int BM, int BN, bool ACC, bool FULL>
 __device__ __forceinline__ void bnb_rows(T* __restrict__ dst, int ld_dst, const char* Cs, int M, int m0, int col, int cv, bool cok, bool stat, bool usey, bool smask,
-                                         const uint4* vr, const uint4* vm, const uint4* vd, const float* msc, const float* msh, float* t1, float* t2) {
+                                         const uint4* vr, const uint4* vm, const uint4* vd, const float* msc, const float* msh, float* t1, float* t2, float ps) {
     constexpr int VEC = TT<T>::VEC, VPR = BN / VEC, CRS = BN * (int)sizeof(T) + 16, RPT = BnbPre<T, BM, BN>::RPT;
     const int r0 = threadIdx.x / VPR;
 #pragma unroll
@@ -247,7 +257,7 @@ __device__ __forceinline__ void bnb_rows(T* __restrict__ dst, int ld_dst, const 
             float y[VEC];
             TT<T>::unpack(vd[u], y);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) x[e] += y[e];
+            for (int e = 0; e < VEC; ++e) x[e] = __fmaf_rn(y[e], ps, x[e]);          // ps = 1 (fmaf(y, 1, x) == x + y) or 1/4 (pooled prior)
             o = TT<T>::pack(x);
             TT<T>::unpack(o, x);                  // the statistics see the STORED (rounded) gradient, as a separate reduce pass would
         }
@@ -269,7 +279,7 @@ __device__ __forceinline__ void bnb_rows(T* __restrict__ dst, int ld_dst, const 
 
 template <typename T, int BM, int BN>
 __device__ __forceinline__ void bnb_target(const pn2_bnb_target& t, T* __restrict__ dst, int ld_dst, bool accum, const char* Cs, int M, int m0, int n0, int Cout,
-                                           const uint4* vr, const uint4* vm, const uint4* vd, float* s1, float* s2) {
+                                           const uint4* vr, const uint4* vm, const uint4* vd, float* s1, float* s2, float ps = 1.f) {
     constexpr int VEC = TT<T>::VEC, VPR = BN / VEC;
     const int cv = threadIdx.x % VPR, col = n0 + cv * VEC;
     const bool cok = col < Cout;
@@ -284,11 +294,11 @@ __device__ __forceinline__ void bnb_target(const pn2_bnb_target& t, T* __restric
     const bool smask = stat && (t.mode & PN2_BNB_STORE_MASKED) != 0;
     const bool full = m0 + BM <= M && n0 + BN <= Cout;
     if (full) {
-        if (accum) bnb_rows<T, BM, BN, true, true>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2);
-        else bnb_rows<T, BM, BN, false, true>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2);
+        if (accum) bnb_rows<T, BM, BN, true, true>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2, ps);
+        else bnb_rows<T, BM, BN, false, true>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2, ps);
     } else {
-        if (accum) bnb_rows<T, BM, BN, true, false>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2);
-        else bnb_rows<T, BM, BN, false, false>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2);
+        if (accum) bnb_rows<T, BM, BN, true, false>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2, ps);
+        else bnb_rows<T, BM, BN, false, false>(dst, ld_dst, Cs, M, m0, col, cv, cok, stat, usey, smask, vr, vm, vd, msc, msh, t1, t2, ps);
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s1[e] = t1[e]; s2[e] = is[e] * (t2[e] - mu[e] * t1[e]); }
@@ -382,6 +392,23 @@ __device__ __forceinline__ void ep2_dma_tile(char* region, const bf16_t* base, i
     }
 }
 
+// the prior tile of a += destination from the quarter-resolution tensor of pn2_conv_ep.pool (see pool_row): flat addresses, one source row per tile row
+template <int BM, int BN>
+__device__ __forceinline__ void ep2_dma_pool(char* region, const bf16_t* pool, int ld, const pn2_conv_desc& d, int M, int m0, int n0) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int CPR = BN / 8, NCH = BM * CPR, RPK = 256 / CPR;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = wid * 64 + lane, row0 = p0 / CPR, ch = p0 - row0 * CPR;
+    int col = n0 + ch * 8;
+    if (col >= d.Cout) col = n0;
+#pragma unroll
+    for (int k = 0; k < NCH / 256; ++k) {
+        const int m = min(m0 + row0 + k * RPK, M - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pool + (size_t)pool_row(d, m) * ld + col), (lptr_t)(region + (k * 4 + wid) * 1024), 16, 0, 0);
+    }
+}
+
 template <int BM, int BN>
 __device__ __forceinline__ void ep2_issue(char* smem, const pn2_conv_desc& d, const pn2_conv_ep& ep, const bf16_t* out, int M, int m0, int n0) {
     bool stat_a, y_a, acc, stat_b;
@@ -389,7 +416,10 @@ __device__ __forceinline__ void ep2_issue(char* smem, const pn2_conv_desc& d, co
     const Ep2Layout L = ep2_layout<BM, BN>(stat_a, y_a, acc, stat_b);
     if (stat_a) ep2_dma_tile<BM, BN>(smem + L.raw_a, (const bf16_t*)ep.a.raw, ep.a.ld_raw, (const bf16_t*)ep.a.raw2, ep.a.split, M, m0, n0, d.Cout);
     if (y_a) ep2_dma_tile<BM, BN>(smem + L.y_a, (const bf16_t*)ep.a.y, ep.a.ld_y, nullptr, 0, M, m0, n0, d.Cout);
-    if (acc) ep2_dma_tile<BM, BN>(smem + L.prior, out, d.ld_out, nullptr, 0, M, m0, n0, d.Cout);
+    if (acc) {
+        if (ep.pool) ep2_dma_pool<BM, BN>(smem + L.prior, (const bf16_t*)ep.pool, ep.ld_pool, d, M, m0, n0);
+        else ep2_dma_tile<BM, BN>(smem + L.prior, out, d.ld_out, nullptr, 0, M, m0, n0, d.Cout);
+    }
     if (stat_b) ep2_dma_tile<BM, BN>(smem + L.raw_b, (const bf16_t*)ep.b.raw, ep.b.ld_raw, (const bf16_t*)ep.b.raw2, ep.b.split, M, m0, n0, d.Cout);
 }
 
@@ -446,6 +476,7 @@ __device__ __forceinline__ void ep2_apply(char* smem, const pn2_conv_desc& d, co
     ep2_mask_params(ep.a, parA, colc, stA, kindA, scA, shA);
     ep2_mask_params(ep.b, parB, colc, stB, kindB, scB, shB);          // (stB is false without a second target)
     const bool smA = stA && (ep.a.mode & PN2_BNB_STORE_MASKED), smB = stB && (ep.b.mode & PN2_BNB_STORE_MASKED);
+    const float ps = ep.pool ? 0.25f : 1.f;
     const unsigned base = lds_addr(smem);
     u32x4_t_ c[RPT], pr[RPT], ma[RPT], mb[RPT];
 #pragma unroll
@@ -471,7 +502,7 @@ __device__ __forceinline__ void ep2_apply(char* smem, const pn2_conv_desc& d, co
             TT<T>::unpack(cc, x);
             TT<T>::unpack(__builtin_bit_cast(uint4, pr[u]), y);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] += y[e];
+            for (int e = 0; e < 8; ++e) x[e] = __fmaf_rn(y[e], ps, x[e]);          // ps = 1 (== x + y) or 1/4 (pooled prior, pn2_conv_ep.pool)
             o = TT<T>::pack(x);                      // the statistics see the STORED (rounded) gradient, as a separate reduce pass would
         }
         uint4 dz = o;
@@ -911,7 +942,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
     float sums[4][VEC];
     const bool dual = ep.b.out != nullptr;
     if (dual) bnb_target<T, BM, BN>(ep.b, reinterpret_cast<T*>(ep.b.out), ep.b.ld_out, false, Cs, M, m0, n0, d.Cout, pre.rb, pre.rb, pre.vd, sums[2], sums[3]);
-    bnb_target<T, BM, BN>(ep.a, out, d.ld_out, accum, Cs, M, m0, n0, d.Cout, pre.ra, pre.ma, pre.vd, sums[0], sums[1]);
+    bnb_target<T, BM, BN>(ep.a, out, d.ld_out, accum, Cs, M, m0, n0, d.Cout, pre.ra, pre.ma, pre.vd, sums[0], sums[1], ep.pool ? 0.25f : 1.f);
     PN2_STAMP_AT(14);
     __syncthreads();                                   // everyone has drained the C tile
     // the 256 / VPR row lanes of a channel vector meet in LDS: rs[sum][row lane][BN], then column-parallel adds in a fixed order
@@ -2633,6 +2664,7 @@ int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const
     const int vec = dtype == PN2_BF16 ? 8 : 4;
     if ((d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS)) || ((d->flags >> 16) & 15) > 1) return -2;
     if (d->Cout % vec || d->ld_out % vec) return -2;                      // the statistics live in the 16-byte store path
+    if (ep->pool && (!(d->flags & PN2_CONV_ACCUM) || !(ep->a.mode & PN2_BNB_STATS) || ep->b.out || (d->OH & 1) || (d->OW & 1) || ep->ld_pool % vec || ep->ld_pool < d->Cout)) return -2;
     int rc = bnb_check(ep->a, vec, false);
     if (rc) return rc;
     rc = bnb_check(ep->b, vec, true);

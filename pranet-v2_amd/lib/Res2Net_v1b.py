@@ -99,7 +99,8 @@ class Bottle2neck(nn.Module):
         if self.downsample is not None:
             pool, dconv, dbn = self.downsample[0], self.downsample[1], self.downsample[2]
             k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
-            r = x if k == 1 else eng.avgpool(x, k, k, 0, ceil_mode=True, count_include_pad=False)
+            # (fold_bwd: conv1 above is x's first consumer - its dgrad runs last in the backward pass and adds this pool's gradient in its epilogue)
+            r = x if k == 1 else eng.avgpool(x, k, k, 0, ceil_mode=True, count_include_pad=False, fold_bwd=True)
             res = eng.conv_bn_act(r, dconv, dbn, relu=False)
         else:
             res = x

@@ -87,7 +87,7 @@ class BnbTarget(C.Structure):
 
 
 class ConvEp(C.Structure):
-    _fields_ = [("a", BnbTarget), ("b", BnbTarget)]
+    _fields_ = [("a", BnbTarget), ("b", BnbTarget), ("pool", C.c_void_p), ("ld_pool", C.c_int), ("pad_", C.c_int)]
 
 
 class BnSegs(C.Structure):

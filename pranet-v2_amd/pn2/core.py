@@ -89,7 +89,7 @@ class _LinearAsConv:
 class Act:
     """NHWC activation view.  t: torch tensor (N,H,W,Cp) whose last dim is contiguous; ld = pixel stride."""
     __slots__ = ("eng", "t", "N", "H", "W", "C", "gw", "gwp", "dt", "grad", "_written", "child_written", "requires_grad", "parent", "c0", "lat", "galias",
-                 "bnb", "bstats", "sum_of", "dual_done", "_sealed", "grad_masked", "colparts")
+                 "bnb", "bstats", "sum_of", "dual_done", "_sealed", "grad_masked", "colparts", "pool_prior")
 
     def __init__(self, eng, t, C_, gw=None, gwp=None, dt=None, requires_grad=True):
         self.eng, self.t = eng, t
@@ -109,6 +109,7 @@ class Act:
         self._sealed = False            # a dgrad that declared itself the last contribution has written this gradient
         self.grad_masked = False        # that dgrad stored dz = dy * [y > 0] (PN2_BNB_STORE_MASKED): the gradient buffer already carries the ReLU mask
         self.colparts = None            # (partial rows, nblk, gradient tensor): column sums of this Act's gradient left by the kernel that wrote it (EncoderOps.dwconv_gelu)
+        self.pool_prior = None          # gradient of AvgPool2d(2, 2)(this Act), not yet applied: the dgrad that completes this Act's gradient adds 1/4 of it in its epilogue (SpatialOps.avgpool(fold_bwd=True))
 
     @property
     def grad_written(self):
@@ -413,6 +414,7 @@ BNB_ACC = os.environ.get("PN2_BNB_ACC", "0") == "1"                 # ... leavin
 DW_COLSUM = os.environ.get("PN2_DW_COLSUM", "1") == "1"             # PVTv2 Mlp: fc1's bias gradient from the depth-wise conv's data-gradient walk (no second read of that gradient)
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
 POOL_BWD_QUAD = os.environ.get("PN2_POOL_BWD_QUAD", "1") == "1"  # ... and its backward without the full-resolution gradient tensor (pn2_pool_bn_bwd_reduce / _apply); 0: pool-backward launch + the generic BatchNorm passes
+POOL_FOLD = os.environ.get("PN2_POOL_FOLD", "1") == "1"          # Bottle2neck stage blocks: the backward of the downsample branch's AvgPool2d(2, 2) rides in conv1's dgrad epilogue (pn2_conv_ep.pool) - no pool-backward launch
 POOL_FUSE = os.environ.get("PN2_POOL_FUSE", "1") == "1"          # the stem's bn1 -> ReLU -> MaxPool as one op: the 176 x 176 BatchNorm output is never written (conv_bn_act(pool=True))
 TEE_CONCAT = os.environ.get("PN2_TEE_CONCAT", "1") == "1"         # Bottle2neck: conv1 + bn1 + ReLU writes its pass-through slice into the concat buffer as well (pn2_affine_act_tee); False: a copy launch
 EVAL_FUSE = True          # eval mode: conv + BatchNorm (+ ReLU) (+ residual) in ONE launch (pn2_conv_gemm_affine); tests switch it off to compare with the two-launch path

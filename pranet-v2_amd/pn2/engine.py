@@ -46,6 +46,7 @@ class Engine(ConvOps, EncoderOps, SpatialOps):
         self.fuse_tail = False          # trainer: leave the lateral up-sampling to the fused DSRA tail kernels (K = 1)
         self.tail = {}                  # lateral slot -> (low-res source Act, align_corners, rh, rw) when fuse_tail
         self._keep = []
+        self._pending_pool = []          # activations with a deferred AvgPool2d(2, 2) backward (Act.pool_prior)
 
     # ------------------------------------------------------------------ allocation / layout
     def alloc(self, shape, dtype):
@@ -125,6 +126,8 @@ class Engine(ConvOps, EncoderOps, SpatialOps):
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        if self._pending_pool:
+            raise RuntimeError("a deferred AvgPool2d backward (avgpool(fold_bwd=True)) was never applied: its activation has no conv consumer that runs later in the backward pass")
         self.flush_colsum()
         self._keep = []
 

@@ -57,7 +57,7 @@ class ConvOps:
             return self._untuned(cd, M, Cout, ep)
         key = ("g", cd.N, cd.H, cd.W, cd.OH, cd.OW, cd.Cin_p, cd.ld_in, Cout, cd.KH, cd.KW, cd.stride, cd.pad_h, cd.pad_w, cd.dil_h, cd.dil_w, cd.transposed)
         if ep is not None:
-            key = key + ("ep", ep.a.mode, ep.b.mode, 1 if ep.b.out else 0, cd.flags & capi.CONV_ACCUM)
+            key = key + ("ep", ep.a.mode, ep.b.mode, 1 if ep.b.out else 0, cd.flags & capi.CONV_ACCUM) + (("pool",) if ep.pool else ())
         if fast:
             key = key + ("f32f",)
         if key in t:
@@ -419,6 +419,8 @@ class ConvOps:
 
         def bwd():
             st = _stream()
+            if out.pool_prior is not None:
+                self.flush_pool_prior(out)          # (no dgrad epilogue took the deferred pool backward of this output: apply it before the gradient is consumed)
             if y2 is not None and y2.grad_written and not y2.dual_done:          # the sum's gradient also flows into y (the other operand holds it already)
                 if y2.galias is not None:
                     assert not sum_with._written, "sum_with: the aliased operand received another gradient"
@@ -602,6 +604,13 @@ class ConvOps:
                 call.pn2_conv_dgrad_small_cin(self.dt, _p(draw), Cout_p, _p(w), _p(gx), gx.stride(2), N, H, W, OH, OW, Cout, Cin, KH, KW, sh, ph, gxa, st)
             elif x.requires_grad:
                 wt, ptd = self.pack(w, x_map, o_map, True)
+                # a deferred AvgPool2d(2, 2) backward on x (SpatialOps.avgpool(fold_bwd=True)): this dgrad completes x's gradient with a BatchNorm-backward epilogue and
+                # nothing has been written to it yet -> the epilogue adds 1/4 of the pooled gradient itself (pn2_conv_ep.pool); anything else: the plain pool-backward launch
+                pool_ok = (x.pool_prior is not None and core.BNB_EPILOGUE and x_last and not x.grad_written and x.bnb is not None and x.sum_of is None
+                           and x.Cp % V == 0 and x.pool_prior[0].shape[3] == x.Cp and self.dt == x.dt and x.grad_buf().stride(2) % V == 0
+                           and self._ksplit(N * H * W, KH * KW * Cout_p, x.Cp) == 1)
+                if x.pool_prior is not None and not pool_ok:
+                    self.flush_pool_prior(x)
                 gx, gxa = x.grad_sink()
                 Mx = N * H * W
                 dd = capi.ConvDesc()
@@ -644,10 +653,16 @@ class ConvOps:
                             self._fill_bnb(t_, a_, 0)
                     if dual:
                         ep.b.out = 1
+                    if pool_ok:
+                        assert not gxa and not dual
+                        dd.flags |= capi.CONV_ACCUM
+                        ep.pool, ep.ld_pool = x.pool_prior[0].data_ptr(), x.pool_prior[0].stride(2)
                     tcode = self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp, ep)
                     dd.flags |= tcode << 8
                     nbx = self._stat_blocks(Mx, x.Cp, tcode)
                     ep = capi.ConvEp()
+                    if pool_ok:
+                        ep.pool, ep.ld_pool = x.pool_prior[0].data_ptr(), x.pool_prior[0].stride(2)
                     if dual:
                         # x = u + v (Bottle2neck's sp + spx[i]): the gradient goes to BOTH operands - accumulated into u's (the concat buffer slice
                         # conv3's dgrad wrote), stored as v's (aliased by x) - each with the statistics of its own BatchNorm
@@ -665,6 +680,9 @@ class ConvOps:
                     else:
                         self._fill_bnb(ep.a, x, nbx)
                         call.pn2_conv_gemm_ep(self.dt, _p(draw), _p(wt), _p(gx), C.byref(dd), C.byref(ep), st)
+                    if pool_ok and x.pool_prior is not None:
+                        x.pool_prior = None
+                        self._pending_pool.remove(x)
                     x._sealed = True
                 else:
                     dd.flags |= self._tune_gemm(dd, _p(draw), wt, Mx, x.Cp) << 8

@@ -27,7 +27,9 @@ class SpatialOps:
         self.record(bwd)
         return y
 
-    def avgpool(self, x, k, stride, pad, ceil_mode=False, count_include_pad=True, out=None):
+    def avgpool(self, x, k, stride, pad, ceil_mode=False, count_include_pad=True, out=None, fold_bwd=False):
+        """fold_bwd: (2, 2, 0) pools of an activation whose gradient a later-running conv dgrad completes (x_last): the backward launches nothing and leaves the pooled
+        gradient on x (Act.pool_prior) - that dgrad's epilogue adds 1/4 of it (ConvOps.conv_bn_act; flush_pool_prior() is the fall-back)."""
         N, H, W = x.N, x.H, x.W
 
         def osz(i):
@@ -45,10 +47,25 @@ class SpatialOps:
             if not x.requires_grad:
                 return
             gy = y.grad_buf()
+            if (fold_bwd and core.POOL_FOLD and (k, stride, pad) == (2, 2, 0) and H % 2 == 0 and W % 2 == 0 and not x.grad_written and x.pool_prior is None
+                    and x.dt == self.dt and gy.stride(2) % (4 if x.dt == F32 else 8) == 0):
+                x.pool_prior = (gy, (N, H, W, x.Cp, OH, OW, k, stride, pad, inc))
+                self._pending_pool.append(x)
+                return
             gx, acc = x.grad_sink()
             call.pn2_avgpool_bwd(x.dt, _p(gy), gy.stride(2), _p(gx), gx.stride(2), N, H, W, x.Cp, OH, OW, k, stride, pad, inc, acc, _stream())
         self.record(bwd)
         return y
+
+    def flush_pool_prior(self, x):
+        """A deferred AvgPool2d(2, 2) backward that no dgrad epilogue took: the plain launch, now."""
+        if x.pool_prior is None:
+            return
+        gy, (N, H, W, Cp, OH, OW, k, stride, pad, inc) = x.pool_prior
+        x.pool_prior = None
+        self._pending_pool.remove(x)
+        gx, acc = x.grad_sink()
+        call.pn2_avgpool_bwd(x.dt, _p(gy), gy.stride(2), _p(gx), gx.stride(2), N, H, W, Cp, OH, OW, k, stride, pad, inc, acc, _stream())
 
     # ------------------------------------------------------------------ bilinear
     def bilinear(self, x, scale=None, align_corners=False, out=None):

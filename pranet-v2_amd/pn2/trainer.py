@@ -251,6 +251,8 @@ class Trainer:
                 if self._seg is not None and self.buckets.record:
                     self._cut_segment()
         eng.tape = []
+        if eng._pending_pool:
+            raise RuntimeError("a deferred AvgPool2d backward was never applied (see Engine.backward)")
         eng.pgrads.on_sink = None
         if len(eng.pgrads.written) != len(self.hot):
             # torch.optim skips parameters whose grad is None; the fused kernel steps the whole arena, so a trained parameter without a gradient

@@ -14,7 +14,7 @@ dev = "cuda"
 SWITCHES = [
     ("engine", "BNB_EPILOGUE", False), ("engine", "MASKED_STORE", False), ("engine", "LOCKSTEP", False), ("engine", "GRAD_ALIAS", False),
     ("engine", "SPLITK", False), ("engine", "FUSE_BIAS", False), ("engine", "DEFER_COLSUM", False), ("engine", "ZERO_CROP_SKIP", False),
-    ("engine", "PATCH_DGRAD", False), ("engine", "SMALL_CIN_DGRAD", False), ("engine", "WGRAD_SLAB_CAP", 0.0), ("engine", "WGRAD_ROTATE", False), ("engine", "TEE_CONCAT", False), ("engine", "POOL_FUSE", False), ("engine", "POOL_BWD_QUAD", False),
+    ("engine", "PATCH_DGRAD", False), ("engine", "SMALL_CIN_DGRAD", False), ("engine", "WGRAD_SLAB_CAP", 0.0), ("engine", "WGRAD_ROTATE", False), ("engine", "TEE_CONCAT", False), ("engine", "POOL_FUSE", False), ("engine", "POOL_BWD_QUAD", False), ("engine", "POOL_FOLD", False),
     ("res2net", "ALIAS_CAT_GRAD", False),
     ("env", "PN2_FUSED_TAIL", "0"), ("env", "PN2_DEFER_WGRAD", "1"), ("env", "PN2_DEFER_WGRAD", "0"), ("env", "PN2_STEP_ARENA", "0"), ("env", "PN2_AUTOTUNE", "0"),
 ]
@@ -66,3 +66,34 @@ def test_step_under_switch_matches_default(where, name, value, monkeypatch):
     assert float((o1 - o0).abs().max()) < 2e-5                      # forward maps
     rel = float((g1 - g0).norm() / g0.norm())
     assert rel < 2e-4, (name, rel)                                   # same gradients up to another fp32 summation order (conditioned weights: no chaos)
+
+
+def test_pool_backward_folded_into_the_dgrad_epilogue_is_bit_identical_bf16(monkeypatch):
+    """PN2_POOL_FOLD (bf16, the benchmarked precision): AvgPool2d(2, 2)'s backward inside conv1's dgrad epilogue (pn2_conv_ep.pool; layer2.0 of the Res2Net encoder, where nothing
+    else has written the block input's gradient) leaves the bits the separate pool-backward launch + `+=` leave: 1/4 is exact, the sum is rounded once either way."""
+    import pn2
+    from pn2 import core
+    from pn2.trainer import Trainer
+    from lib.pranet import PraNet_V2
+    from oracle import weights as W
+
+    def step(fold):
+        monkeypatch.setattr(core, "POOL_FOLD", fold)
+        pn2.set_compute_dtype("bf16")
+        model = PraNet_V2(num_class=1)
+        model.load_state_dict(W.make_state_dict(W.manifest_pranet_v2(1), seed=0, bn3_gamma=0.05), strict=True)
+        model = model.to(dev).train()
+        x, m = W.synthetic_batch(2, 96, seed=1234)
+        tr = Trainer(model, lr=1e-4, clip=0.5)
+        calls = []
+        from pn2.capi import call
+        real = call.pn2_avgpool_bwd
+        monkeypatch.setattr(call, "pn2_avgpool_bwd", lambda *a: (calls.append(a[5:10]), real(*a))[1])
+        loss = tr.forward_backward(x.to(dev), m.to(dev))
+        torch.cuda.synchronize()
+        monkeypatch.setattr(call, "pn2_avgpool_bwd", real)
+        return loss.clone(), tr.gflat.clone(), len(calls)
+    l0, g0, n0 = step(False)
+    l1, g1, n1 = step(True)
+    assert n1 == n0 - 1, (n0, n1)          # one pool-backward launch fewer (layer3.0 / layer4.0: their block inputs x2 / x3 already carry the heads' gradient -> plain launch)
+    assert torch.equal(l0, l1) and torch.equal(g0, g1)
