@@ -1752,84 +1752,7 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const bf16_t* __restrict__ d
         }                                                                                                              \
     } while (0)
 
-#ifndef PN2_WG_MFMA32
-#define PN2_WG_MFMA32 0
-#endif
-#if PN2_WG_MFMA32
-    // v_mfma_f32_32x32x16_bf16 form (tools/probes/mfma_shape_micro.hip: 15-28 % more MFMA throughput than 16x16x32 in an LDS-fed loop).  A lane
-    // (g, l15) holds channel (g&1)*16 + l15 of a 32-channel block and the 8 pixels (g>>1)*8 + 0..7 of a 16-pixel sub-step: two transposing reads, rows +0..3 / +4..7
-    // (their swizzle keys differ: row & 7); the same pixel <-> k-slot map on both operands.  C/D: row (r>>2)*8 + (lane>>5)*4 + (r&3), column lane & 31.
-    typedef __attribute__((ext_vector_type(16))) float f32x16_t_;
-    constexpr int MT2 = MT / 2, NT2 = NT / 2;
-    static_assert(MT % 2 == 0 && NT % 2 == 0, "32 x 32 blocks");
-    f32x16_t_ acc[MT2][NT2];
-#pragma unroll
-    for (int i = 0; i < MT2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-    const int prow = (g >> 1) * 8 + (l15 >> 2);
-    unsigned offA[MT2][2], offB[NT2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int row = prow + 4 * h, keyy = (row & KMY) << 1, keyx = (row & KMX) << 1;
-#pragma unroll
-        for (int i = 0; i < MT2; ++i) offA[i][h] = row * RBY + ((((wm * WTM) >> 3) + i * 4 + (g & 1) * 2 + ((l15 & 3) >> 1)) ^ keyy) * 16 + (l15 & 1) * 8;
-#pragma unroll
-        for (int j = 0; j < NT2; ++j) offB[j][h] = PX * RBY + row * RBX + ((((wn * WTN) >> 3) + j * 4 + (g & 1) * 2 + ((l15 & 3) >> 1)) ^ keyx) * 16 + (l15 & 1) * 8;
-    }
-    if (nsteps > 0) {
-        PN2_WISSUE(s_begin, 0);
-        if (nsteps > 1) PN2_WISSUE(s_begin + 1, 1);
-        for (int t = 0; t < nsteps; ++t) {
-            if (t + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 2 < nsteps) {
-                const int nb_ = (t + 2) % NS;
-                PN2_WISSUE(s_begin + t + 2, nb_);
-            }
-            const unsigned sb = lds0 + (t % NS) * STAGE;
-#pragma unroll
-            for (int ks = 0; ks < PX / 16; ++ks) {
-                u32x2_t a0[MT2], a1[MT2], b0[NT2], b1[NT2];
-#pragma unroll
-                for (int i = 0; i < MT2; ++i) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0[i]) : "v"(sb + offA[i][0] + ks * 16 * RBY));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a1[i]) : "v"(sb + offA[i][1] + ks * 16 * RBY));
-                }
-#pragma unroll
-                for (int j = 0; j < NT2; ++j) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0[j]) : "v"(sb + offB[j][0] + ks * 16 * RBX));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1[j]) : "v"(sb + offB[j][1] + ks * 16 * RBX));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < MT2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, make_uint4(a0[i].x, a0[i].y, a1[i].x, a1[i].y)),
-                                                                            __builtin_bit_cast(bf16x8_t, make_uint4(b0[j].x, b0[j].y, b1[j].x, b1[j].y)), acc[i][j], 0, 0, 0);
-            }
-        }
-    }
-#undef PN2_WISSUE
-    float* dst = slab + ((size_t)split * d.Rp + co0) * d.Kp + k0;
-    const int l31 = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < MT2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT2; ++j) {
-            if (BNK > 128 && k0 + wn * WTN + j * 32 >= d.Kp) continue;          // Kp is a multiple of 128 (and the wave tiles of 32-column blocks): the last 256-wide tile may be half empty
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dst[(size_t)(wm * WTM + i * 32 + (r >> 2) * 8 + hh * 4 + (r & 3)) * d.Kp + wn * WTN + j * 32 + l31] = acc[i][j][r];
-        }
-}
-#else
+    // (a v_mfma_f32_32x32x16_bf16 form of this loop was built and measured in round 6: correct, 0.6 % slower in the step - profiles/r06_mfma_shape_micro.txt)
     f32x4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -1893,7 +1816,6 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const bf16_t* __restrict__ d
                 dst[(size_t)(wm * WTM + i * 16 + g * 4 + r) * d.Kp + wn * WTN + j * 16 + l15] = acc[i][j][r];
         }
 }
-#endif
 
 // single-conv and table-driven (many convs, one launch) entry points of the two wgrad kernels
 template <typename T, int BMC, int BNK, int WM, int WN, bool PW>
