@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void mloss_fwd_k(ml_maps m, const long long* _
         t = row16_sum(t);
         if (rlead) red[rrow][ML_NS * W + k] = t;
     }
-#pragma unroll
+#pragma unroll          // (measured in round 6: rolled, with 0 / 1 map weights, the kernel drops from 205 to 126 registers and gets SLOWER - 0.88 -> 1.07 ms: twice the adds per subset)
     for (int s = 1; s <= ML_NS; ++s) {
         float z[K], zb[K], v[W];
 #pragma unroll
@@ -751,59 +751,86 @@ __global__ void mloss_finalize_k(const double* __restrict__ grp, int ngrp, float
     }
 }
 
+// Round 6: the kernel was register-bound, not memory-bound (256 VGPRs + 256 AGPRs + 708 bytes of scratch, ONE wave per SIMD: nothing hid its transcendental chains;
+// staging the 36-byte pixel rows through LDS as coalesced float4s made it slower still - profiles/r06_emcad_notes.txt).  The foreground part (softmax over the K classes
+// couples them: CE + Dice) and the background part (BCE: every class on its own) share nothing but the subset loop, so they run one after the other, the background
+// part class by class with four logits and four gradient sums live: ~130 registers, three to four waves per SIMD.
 template <int K>
 __global__ __launch_bounds__(256) void mloss_bwd_k(ml_maps m, const long long* __restrict__ label, const float* __restrict__ bgm, size_t NP, size_t HW,
                                                    const float* __restrict__ sums, float gscale, float lc1, float lc2, float lc3) {
     constexpr int W = MLW<K>::W;
+    // the Dice coefficients of every (subset, class) - uniform over the pixels - once per block in LDS: as 270 global loads per thread the compiler hoisted them
+    // all to the top of the fully unrolled subset loop (256 + 256 registers and scratch)
+    __shared__ float tA[ML_NS * K], tB[ML_NS * K];
+    const float wdice = gscale * lc2 / K;
+    for (int j = threadIdx.x; j < ML_NS * K; j += 256) {
+        const int s0 = j / K, k = j - s0 * K;
+        const float* S = sums + s0 * W;
+        // d dice_k / d p_k = -(2 t / D - (2 I + eps) 2 p / D^2),  D = Z + T + eps
+        const float D = S[2 + K + k] + sums[ML_NS * W + k] + 1e-5f;
+        tA[j] = wdice * 2.f / D; tB[j] = wdice * (2.f * S[2 + k] + 1e-5f) * 2.f / (D * D);
+    }
+    __syncthreads();
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= NP) return;
     const int lab = (int)label[p];
     const size_t n = p / HW, hw = p % HW;
-    float f[4][K], b[4][K], mk[K], gf[4][K], gb[4][K];
+    const float wce = gscale * lc1 / (float)NP, wbce = gscale * lc3 / ((float)NP * K);
+    {       // ---- foreground maps: d(CE + Dice) / d logits
+        float f[4][K], gf[4][K];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < K; ++k) { f[i][k] = m.fg[i][p * K + k]; b[i][k] = m.bg[i][p * K + k]; gf[i][k] = 0.f; gb[i][k] = 0.f; }
+            for (int k = 0; k < K; ++k) { f[i][k] = m.fg[i][p * K + k]; gf[i][k] = 0.f; }
+#pragma unroll 1
+        for (int s = 1; s <= ML_NS; ++s) {
+            const float w0 = s & 1 ? 1.f : 0.f, w1 = s & 2 ? 1.f : 0.f, w2 = s & 4 ? 1.f : 0.f, w3 = s & 8 ? 1.f : 0.f;          // (x * 1 and + 0 are exact: the subset sums keep their order)
+            float z[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) mk[k] = bgm[(n * K + k) * HW + hw];
-    const float wce = gscale * lc1 / (float)NP, wbce = gscale * lc3 / ((float)NP * K), wdice = gscale * lc2 / K;
+            for (int k = 0; k < K; ++k) z[k] = ((w0 * f[0][k] + w1 * f[1][k]) + w2 * f[2][k]) + w3 * f[3][k];
+            float mx = z[0];
 #pragma unroll
-    for (int s = 1; s <= ML_NS; ++s) {
-        float z[K], zb[K];
+            for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+            float se = 0.f, pr[K], g[K], dot = 0.f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            z[k] = 0.f; zb[k] = 0.f;
+            for (int k = 0; k < K; ++k) { pr[k] = __expf(z[k] - mx); se += pr[k]; }
+            const float inv = __builtin_amdgcn_rcpf(se);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (s >> i & 1) { z[k] += f[i][k]; zb[k] += b[i][k]; }
+            for (int k = 0; k < K; ++k) {
+                pr[k] *= inv;
+                g[k] = -((lab == k ? tA[(s - 1) * K + k] : 0.f) - tB[(s - 1) * K + k] * pr[k]);
+                dot += g[k] * pr[k];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float dz = wce * (pr[k] - (lab == k ? 1.f : 0.f)) + pr[k] * (g[k] - dot);
+                gf[0][k] += w0 * dz; gf[1][k] += w1 * dz; gf[2][k] += w2 * dz; gf[3][k] += w3 * dz;
+            }
         }
-        float mx = z[0];
 #pragma unroll
-        for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
-        float se = 0.f, pr[K], g[K], dot = 0.f;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < K; ++k) { pr[k] = __expf(z[k] - mx); se += pr[k]; }
-        const float inv = __builtin_amdgcn_rcpf(se);
-        const float* S = sums + (s - 1) * W;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            pr[k] *= inv;
-            // d dice_k / d p_k = -(2 t / D - (2 I + eps) 2 p / D^2),  D = Z + T + eps
-            const float D = S[2 + K + k] + sums[ML_NS * W + k] + 1e-5f, t = lab == k ? 1.f : 0.f;
-            g[k] = -wdice * (2.f * t / D - (2.f * S[2 + k] + 1e-5f) * 2.f * pr[k] / (D * D));
-            dot += g[k] * pr[k];
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float dz = wce * (pr[k] - (lab == k ? 1.f : 0.f)) + pr[k] * (g[k] - dot);
-            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-zb[k])), dzb = wbce * (sg - mk[k]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) if (s >> i & 1) { gf[i][k] += dz; gb[i][k] += dzb; }
-        }
+            for (int k = 0; k < K; ++k) m.dfg[i][p * K + k] = gf[i][k];
     }
+    // ---- background maps: d BCE / d logits, class by class (same subset order, same sums per (map, class) as before)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int k = 0; k < K; ++k) {
+        float b[4], gb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < K; ++k) { m.dfg[i][p * K + k] = gf[i][k]; m.dbg[i][p * K + k] = gb[i][k]; }
+        for (int i = 0; i < 4; ++i) b[i] = m.bg[i][p * K + k];
+        const float mk = bgm[(n * K + k) * HW + hw];
+#pragma unroll
+        for (int s = 1; s <= ML_NS; ++s) {
+            float zb = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (s >> i & 1) zb += b[i];
+            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-zb)), dzb = wbce * (sg - mk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (s >> i & 1) gb[i] += dzb;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m.dbg[i][p * K + k] = gb[i];
+    }
 }
 
 }  // namespace
