@@ -315,6 +315,11 @@ int pn2_structure_loss_fwd(const float* preds, long long map_stride, int P, cons
                            float* sums, float* wsum, float* loss, int N, int HW, void* stream);
 int pn2_structure_loss_bwd(const float* preds, float* dpreds, long long map_stride, int P, const float* mask, const float* weit,
                            const float* wsum, const float* sums, float gscale, int N, int HW, void* stream);
+/* The same backward for logits that live where the caller's framework put them (the nn.Module surface: autograd hands the loss the maps the model returned):
+ * dpreds has its own map stride (dmap_stride, elements), and the upstream gradient of pair p is read from the DEVICE (gscale_dev[p], may be NULL) times gscale -
+ * no host synchronisation, no separate scaling pass over the gradient maps (MyTrain_med.py:78-84: loss = loss5 + loss3 + loss2 + loss1; loss.backward()). */
+int pn2_structure_loss_bwd_dev(const float* preds, float* dpreds, long long map_stride, long long dmap_stride, int P, const float* mask, const float* weit,
+                               const float* wsum, const float* sums, const float* gscale_dev, float gscale, int N, int HW, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- fused DSRA tail (K = 1)
  * The memory-bound end of the training step as two kernels: lateral = bilinear(low-res fg|bg map, x8/x16/x32) for all 2P maps

@@ -250,19 +250,21 @@ __global__ void loss_finalize_k(const float* __restrict__ partial, int P, int N,
 
 __global__ __launch_bounds__(256) void loss_bwd_k(const float* __restrict__ preds, float* __restrict__ dpreds, long long map_stride, int P,
                                                   const float* __restrict__ mask, const float* __restrict__ weit, const float* __restrict__ wsum,
-                                                  const float* __restrict__ sums, float gscale, int N, int HW) {
+                                                  const float* __restrict__ sums, float gscale, int N, int HW, long long dmap_stride = -1, const float* __restrict__ gdev = nullptr) {
     const int p = blockIdx.z, n = blockIdx.y;
+    if (dmap_stride < 0) dmap_stride = map_stride;
     const size_t of = (size_t)p * map_stride + (size_t)n * HW, ob = (size_t)(P + p) * map_stride + (size_t)n * HW;
+    const size_t df = (size_t)p * dmap_stride + (size_t)n * HW, db = (size_t)(P + p) * dmap_stride + (size_t)n * HW;
     const float* s = sums + ((size_t)p * N + n) * 4;
     const float Wn = wsum[n], I = s[2], U = s[3], D = U - I + 1.f;
-    const float gs = gscale / (float)N, invW = 1.f / Wn, invD2 = 1.f / (D * D);
+    const float gs = (gdev ? gscale * gdev[p] : gscale) / (float)N, invW = 1.f / Wn, invD2 = 1.f / (D * D);          // gdev: the pair's upstream gradient on the DEVICE (autograd's)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
         const float m = mask[(size_t)n * HW + i], w = weit[(size_t)n * HW + i];
         const float f = preds[of + i], b = preds[ob + i];
         const float pr = 1.f / (1.f + expf(-f)), pb = 1.f / (1.f + expf(-b));
         const float dwiou = -(m * w * D - (I + 1.f) * (w - m * w)) * invD2;
-        dpreds[of + i] = gs * (w * (pr - m) * invW + dwiou * pr * (1.f - pr));
-        dpreds[ob + i] = gs * 0.8f * w * (pb - (1.f - m)) * invW;
+        dpreds[df + i] = gs * (w * (pr - m) * invW + dwiou * pr * (1.f - pr));
+        dpreds[db + i] = gs * 0.8f * w * (pb - (1.f - m)) * invW;
     }
 }
 
@@ -1357,6 +1359,16 @@ int pn2_structure_loss_bwd(const float* preds, float* dpreds, long long map_stri
     if (!preds || !dpreds || !mask || !weit || !wsum || !sums) return -1;
     int nb = (HW + 1023) / 1024; if (nb > 256) nb = 256;
     hipLaunchKernelGGL(loss_bwd_k, dim3(nb, N, P), dim3(256), 0, (hipStream_t)stream, preds, dpreds, map_stride, P, mask, weit, wsum, sums, gscale, N, HW);
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_structure_loss_bwd_dev(const float* preds, float* dpreds, long long map_stride, long long dmap_stride, int P, const float* mask, const float* weit, const float* wsum,
+                               const float* sums, const float* gscale_dev, float gscale, int N, int HW, void* stream) {
+    if (!preds || !dpreds || !mask || !weit || !wsum || !sums) return -1;
+    if (map_stride < 0 || dmap_stride < 0) return -2;
+    int nb = (HW + 1023) / 1024; if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(loss_bwd_k, dim3(nb, N, P), dim3(256), 0, (hipStream_t)stream, preds, dpreds, map_stride, P, mask, weit, wsum, sums, gscale, N, HW, dmap_stride, gscale_dev);
     PN2_CHECK_LAUNCH();
     return 0;
 }

@@ -197,6 +197,7 @@ SIGNATURES = {
     "pn2_loss_blocks": [I],
     "pn2_structure_loss_fwd": [P, LL, I, P, P, P, P, P, P, I, I, P],
     "pn2_structure_loss_bwd": [P, P, LL, I, P, P, P, P, FL, I, I, P],
+    "pn2_structure_loss_bwd_dev": [P, P, LL, LL, I, P, P, P, P, P, FL, I, I, P],
     "pn2_dsra_tail_blocks": [I],
     "pn2_dsra_tail_fwd": [C.POINTER(TailDesc), P, P, P, P, P, P, P, P],
     "pn2_dsra_tail_scratch": [C.POINTER(TailDesc)],

@@ -237,6 +237,21 @@ class _Site:
         self.graph_f, self.graph_b = gf, gb
 
 
+def _hand_out(outs):
+    """Private copies of a call site's outputs (its arena / static buffers are rewritten by the next call).  Outputs that are slices of ONE storage - the eight
+    full-resolution maps of PraNet-V2 are views of one block - are copied by ONE launch and handed out as the same views of the copy: a loss that takes two of them
+    (MyTrain_med.py:78-81) finds them at a fixed stride and reads them in place (pn2.loss)."""
+    if len(outs) > 1 and all(o.dtype == torch.float32 and o.is_cuda for o in outs):
+        sp = outs[0].untyped_storage().data_ptr()
+        if all(o.untyped_storage().data_ptr() == sp for o in outs):
+            lo = min(o.storage_offset() for o in outs)
+            hi = max(o.storage_offset() + (sum((n - 1) * st for n, st in zip(o.shape, o.stride())) + 1 if o.numel() else 0) for o in outs)
+            if hi - lo <= 2 * sum(o.numel() for o in outs):
+                flat = torch.empty(0, dtype=torch.float32, device=outs[0].device).set_(outs[0].untyped_storage(), lo, (hi - lo,)).clone()
+                return tuple(flat.as_strided(o.shape, o.stride(), o.storage_offset() - lo) for o in outs)
+    return tuple(o.clone() for o in outs)
+
+
 class _SiteFn(torch.autograd.Function):
     """One eager pass of a call site on its arena / tables (the two passes before the capture)."""
 
@@ -245,7 +260,7 @@ class _SiteFn(torch.autograd.Function):
         eng, outs, nchw = site.forward(build, training, dtype, tensors[:n_in])
         site.begin(ctx)
         ctx.eng, ctx.outs, ctx.params, ctx.n_in = eng, outs, tensors[n_in:], n_in
-        return tuple(o.clone() for o in nchw)         # the arena is reused by the next call: hand out copies
+        return _hand_out(nchw)         # the arena is reused by the next call: hand out copies
 
     @staticmethod
     def backward(ctx, *gouts):
@@ -268,7 +283,7 @@ class _ReplayFn(torch.autograd.Function):
         site.graph_f.replay()
         site.begin(ctx)
         ctx.n_in = n_in
-        return tuple(o.clone() for o in site.s_out)
+        return _hand_out(site.s_out)
 
     @staticmethod
     def backward(ctx, *gouts):

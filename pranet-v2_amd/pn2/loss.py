@@ -131,6 +131,20 @@ def _mask_weights(mask, N, H, W):
     return m, weit
 
 
+def _in_place_maps(preds, P, N, HW):
+    """-> (base tensor, map stride in elements) when the 2P logit maps are fp32, contiguous and sit at base + j * stride (stride > 0) - the maps a call site of the
+    mirror model hands out are views of ONE block, slots i and i + 4 - so the loss kernels read them where they are; None: they are gathered into one buffer."""
+    if any(p.dtype != torch.float32 or not p.is_contiguous() or p.numel() != N * HW for p in preds):
+        return None
+    a0 = preds[0].data_ptr()
+    if len(preds) < 2:
+        return None
+    d = preds[1].data_ptr() - a0
+    if d <= 0 or d % 4 or any(p.data_ptr() - a0 != j * d for j, p in enumerate(preds)):
+        return None
+    return preds[0], d // 4
+
+
 class _StructureLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mask, P, *preds):
@@ -138,27 +152,39 @@ class _StructureLoss(torch.autograd.Function):
             raise RuntimeError("pn2.structure_loss needs GPU tensors (no CPU fallback)")
         N, _, H, W = mask.shape
         HW = H * W
-        buf = torch.stack([p.reshape(N, HW) for p in preds]).float().contiguous()
         m, weit = _mask_weights(mask, N, H, W)
-        loss, saved = loss_forward(buf, P, m, N, HW, H, W, weit)
-        ctx.save_for_backward(buf, m, *saved)
-        ctx.dims = (P, N, HW, preds[0].shape)
+        inp = _in_place_maps(preds, P, N, HW)
+        if inp is None:
+            buf = torch.stack([p.reshape(N, HW) for p in preds]).float().contiguous()
+            stride = N * HW
+            loss, saved = loss_forward(buf, P, m, N, HW, H, W, weit)
+            ctx.save_for_backward(buf, m, *saved)
+        else:
+            base, stride = inp
+            dev = base.device
+            nb = call.pn2_loss_blocks(HW)
+            partial = torch.empty((P, N, nb, 5), dtype=torch.float32, device=dev)
+            sums = torch.empty((P, N, 4), dtype=torch.float32, device=dev)
+            wsum = torch.empty((N,), dtype=torch.float32, device=dev)
+            loss = torch.empty((P + 1,), dtype=torch.float32, device=dev)
+            call.pn2_structure_loss_fwd(_p(base), stride, P, _p(m), _p(weit), _p(partial), _p(sums), _p(wsum), _p(loss), N, HW, _stream())
+            ctx.save_for_backward(base, m, weit, sums, wsum, *preds)          # (the maps themselves: nothing is copied)
+        ctx.dims = (P, N, HW, preds[0].shape, stride, inp is not None)
         return loss[P], loss[:P]
 
     @staticmethod
     def backward(ctx, gtotal, gpairs):
-        buf, m, weit, sums, wsum = ctx.saved_tensors
-        P, N, HW, shape = ctx.dims
-        dbuf = torch.empty_like(buf)
-        loss_backward(buf, dbuf, P, m, (weit, sums, wsum), N, HW, 1.0)
-        g = dbuf.view(2, P, N, HW)
+        buf, m, weit, sums, wsum = ctx.saved_tensors[:5]
+        P, N, HW, shape, stride, in_place = ctx.dims
+        dbuf = torch.empty((2 * P, N, HW), dtype=torch.float32, device=buf.device)
         scale = torch.zeros(P, device=buf.device)
         if gtotal is not None:
             scale = scale + gtotal
         if gpairs is not None:
             scale = scale + gpairs
-        g = g * scale.view(1, P, 1, 1)
-        return (None, None, *[g[j // P, j % P].reshape(shape) for j in range(2 * P)])
+        # the upstream gradient of every pair goes to the kernel on the device: no scaling pass over the gradient maps
+        call.pn2_structure_loss_bwd_dev(_p(buf), _p(dbuf), stride, N * HW, P, _p(m), _p(weit), _p(wsum), _p(sums), _p(scale), 1.0, N, HW, _stream())
+        return (None, None, *[dbuf[j].reshape(shape) for j in range(2 * P)])
 
 
 def structure_loss_multi(preds_fg, preds_bg, mask, return_pairs=False):
