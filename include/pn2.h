@@ -89,11 +89,6 @@ int pn2_conv_gemm(int dtype, const void* in, const void* wp, void* out, float* p
 #define PN2_BNB_MASK_Y 4     /* ReLU mask from the stored activation y > 0 (BN + residual + ReLU) */
 #define PN2_BNB_STORE_MASKED 8   /* store dz (the masked gradient) instead of the plain one: it IS the gradient of the residual branch, so the caller
                                     can alias that buffer and pn2_bn_bwd_apply neither re-reads y nor writes dres */
-#define PN2_BNB_ACC 16       /* p1 / p2 are EXACT accumulators instead of partial rows: int64 [PN2_BNB_REPS][2][ldp], zero on entry.  A tile adds its column sums as
-                                two 64-bit integers (v * 2^30 split into integer part and 50 fractional bits: exact for |v| < 2^21, truncated below 2^-80), so the
-                                total does not depend on the order in which the tiles arrive; tile row bm goes to replica bm % PN2_BNB_REPS.  pn2_bn_bwd_finalize_seg
-                                takes such a segment with nblk = -1; pn2_bn_bwd_apply_acc forms the coefficients itself (no finalize launch). */
-#define PN2_BNB_REPS 16
 /* V1 reverse attention fused into the 1x1 conv behind it (PraNet_Res2Net.py:153-155,166-168,177-179:  x = -1*sigmoid(crop)+1 ; x = x.expand(-1, C, -1, -1).mul(x_l) ;
  * x = ra*_conv1(x)).  The gate is one number per pixel and ra*_conv1 is 1x1, so conv(gate * x_l) = gate * conv(x_l): out[m][:] = (1 - sigmoid(gate[m])) * conv(in)[m][:],
  * applied to the accumulator rows in the GEMM epilogue; PN2_CONV_STATS statistics are those of the gated result.  The gated copy of x_l (512..2048 channels)
@@ -233,13 +228,6 @@ int pn2_bn_bwd_finalize(const float* p1, const float* p2, int nblk, const pn2_bn
 typedef struct pn2_bn_segs { int nseg; int c0[4]; int nblk[4]; int ldp[4]; const float* p1[4]; const float* p2[4]; } pn2_bn_segs;
 int pn2_bn_bwd_finalize_seg(const pn2_bn_segs* segs, const pn2_bn_desc* d, const float* gamma, const float* invstd,
                             float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);
-/* pn2_bn_bwd_finalize_seg + pn2_bn_bwd_apply in ONE launch, for segments that are all PN2_BNB_ACC accumulators (nblk = -1): the first ceil(Cp / 64) workgroups
- * form the coefficient rows of 64 channels each, publish them through `pub` ([3][Cp] floats + one counter word, ZERO on entry) and leave dgamma / dbeta; every
- * workgroup waits for them and takes the rows into LDS.  Same arithmetic as the two launches.
- * 16-byte rows of one dtype only (the row-streaming kernels), Cp <= 2048; -2 otherwise (use the two launches). */
-int pn2_bn_bwd_apply_acc(int dt, const void* dy, int ld_dy, const void* y, int ld_y, const void* x, int ld_x, int M, int Cp, const float* mean, const float* invstd,
-                         const pn2_bn_segs* segs, const pn2_bn_desc* d, const float* gamma, float* dgamma, float* dbeta, int accumulate, float* pub,
-                         void* dx, int ld_dx, void* dres, int ld_dres, int dres_accum, const float* mask_scale, const float* mask_shift, int relu6, void* stream);
 /* ---- table-driven launches of the BatchNorm family.  Independent chains of a model (the three RFB modules and their three branches each, pranet.py:46-83;
  * the three parallel 3x3 convs of a Res2Net stage block, Res2Net_v1b.py:66-69) advance in LOCK STEP: one launch per kernel kind and position in the
  * chain instead of one per chain.  pn2_*_job_blocks (host) fills the derived geometry of a job and returns its workgroup count (< 0: not batchable,

@@ -28,24 +28,6 @@ template <typename T, int W> struct VL {   // W == VEC: 16-byte vector ; W == 1:
 // reduce [nblk][Cp] partial rows: CPB channels x (256 / CPB) row-lanes per block, accumulate in double.  CPB = 8 for short partial buffers;
 // tall ones (the stem / layer1 convs leave thousands of rows) take fewer channels per block so that every thread walks <= ~8 rows.
 // ---------------------------------------------------------------------------------------------
-// PN2_BNB_ACC accumulators (pn2.h): int64 [PN2_BNB_REPS][2][ldp]; the replicas are added as integers (exact), then hi * 2^-30 + lo * 2^-80
-__device__ __forceinline__ double acc_value(const float* acc_, int ldp, int c) {
-#ifdef PN2_BNB_F64
-    {
-        const double* a = reinterpret_cast<const double*>(acc_) + c;
-        double t = 0.0;
-#pragma unroll
-        for (int r = 0; r < PN2_BNB_REPS; ++r) t += a[(size_t)r * ldp];
-        return t;
-    }
-#endif
-    const long long* a = reinterpret_cast<const long long*>(acc_) + c;
-    long long hi = 0, lo = 0;
-#pragma unroll
-    for (int r = 0; r < PN2_BNB_REPS; ++r) { hi += a[(size_t)(2 * r) * ldp]; lo += a[(size_t)(2 * r + 1) * ldp]; }
-    return ((double)hi + (double)lo * 0x1p-50) * 0x1p-30;
-}
-
 __device__ __forceinline__ void reduce_partials(const float* p1, const float* p2, int nblk, int Cn, int Cp, int c, int rl, int RL, double& s1, double& s2) {
     // Cn = channels of this BN, Cp = row stride of the partial buffers, RL = row lanes
     s1 = 0.0; s2 = 0.0;
@@ -522,10 +504,7 @@ __device__ __forceinline__ void bn_bwd_finalize_seg_body(const pn2_bn_segs& sg, 
     float pg = 0.f, pis = 0.f, pdb = 0.f, pdg = 0.f;
     if (lc0 >= 0) { pg = gamma[lc0]; pis = invstd[c]; if (accumulate) { pdb = dbeta[lc0]; pdg = dgamma[lc0]; } }
     double s1, s2;
-    if (sg.nblk[si] < 0) {          // exact accumulators: one row lane reads them, the others add zeros
-        s1 = 0.0; s2 = 0.0;
-        if (rl == 0 && c < d.Cp) { s1 = acc_value(sg.p1[si], sg.ldp[si], cc); s2 = acc_value(sg.p2[si], sg.ldp[si], cc); }
-    } else reduce_partials(sg.p1[si], sg.p2[si], sg.nblk[si], c < d.Cp ? cc + 1 : 0, sg.ldp[si], cc, rl, 256 / CPB, s1, s2);
+    reduce_partials(sg.p1[si], sg.p2[si], sg.nblk[si], c < d.Cp ? cc + 1 : 0, sg.ldp[si], cc, rl, 256 / CPB, s1, s2);
     const int cs = d.ldp ? d.ldp : d.Cp;     // plane stride of coef
     block_reduce_rows(sh, CPB, s1, s2);
     if (rl == 0 && c < d.Cp) {
@@ -743,76 +722,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_tab(const pn2_bnapply_j
                               (T*)j.dres, j.ld_dres, j.dres_accum, j.rows_per_blk, j.cvp, j.msc, j.msh, j.r6, blockIdx.x - bstart[jb]);
 }
 
-// pn2_bn_bwd_apply_acc: pn2_bn_bwd_finalize_seg folded into the apply launch.  The first B = ceil(Cp / 64) workgroups each form the coefficient rows of 64 channels
-// from the PN2_BNB_ACC accumulators (16 loads per thread), publish them in global memory (`pub`: [3][Cp] floats + a counter, zero on entry) and leave dgamma / dbeta;
-// every workgroup then waits for the counter to reach B (workgroups are dispatched in index order, so the publishers are resident before anyone can wait for them;
-// a waiter that gives up after ~50 ms forms all rows itself) and copies the rows to LDS.  (Forming all rows in EVERY workgroup - ~1000 of them - cost more than the
-// finalize launches it replaced: DESIGN 6.)
-constexpr int ACC_SLICE = 64;
-__device__ __forceinline__ void acc_coef(const pn2_bn_segs& sg, const pn2_bn_desc& d, const float* __restrict__ gamma, const float* __restrict__ invstd, int c,
-                                         float& g, float& c1, float& c2, double& s1, double& s2, int& lc) {
-    int si = 0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k) if (k < sg.nseg && c >= sg.c0[k]) si = k;
-    const int cc = c - sg.c0[si];
-    lc = phys2log(c, d.gw, d.gwp, d.C);
-    g = 0.f; c1 = 0.f; c2 = 0.f; s1 = 0.0; s2 = 0.0;
-    if (lc >= 0) {
-        s1 = acc_value(sg.p1[si], sg.ldp[si], cc); s2 = acc_value(sg.p2[si], sg.ldp[si], cc);
-        g = gamma[lc] * invstd[c]; c1 = (float)(s1 / d.M); c2 = (float)(s2 / d.M);
-    }
-}
-
-template <typename T, bool LEAN>
-__global__ __launch_bounds__(256) void bn_bwd_apply_rows_acc_k(const T* __restrict__ dy, int ld_dy, const T* __restrict__ y, int ld_y, const T* __restrict__ x, int ld_x, int M, int Cp,
-                                                               const float* __restrict__ mean, const float* __restrict__ invstd, pn2_bn_segs sg, pn2_bn_desc d,
-                                                               const float* __restrict__ gamma, float* dgamma, float* dbeta, int accumulate, float* pub,
-                                                               T* __restrict__ dx, int ld_dx, T* __restrict__ dres, int ld_dres, int dres_accum, int rows_per_blk, int CVP,
-                                                               const float* __restrict__ msc, const float* __restrict__ msh, int r6) {
-    extern __shared__ float coefS[];          // [3][Cp]: g = gamma * invstd, c1 = sum dz / M, c2 = sum dz xhat / M
-    __shared__ int s_ok;
-    const int B = min((Cp + ACC_SLICE - 1) / ACC_SLICE, (int)gridDim.x);
-    unsigned* cnt = reinterpret_cast<unsigned*>(pub + 3 * (size_t)Cp);
-    if ((int)blockIdx.x < B) {
-        const int per = (Cp + B - 1) / B, c_lo = blockIdx.x * per, c_hi = min(Cp, c_lo + per);
-        for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
-            float g, c1, c2; double s1, s2; int lc;
-            acc_coef(sg, d, gamma, invstd, c, g, c1, c2, s1, s2, lc);
-            if (lc >= 0) {
-                const float pdb = accumulate ? dbeta[lc] : 0.f, pdg = accumulate ? dgamma[lc] : 0.f;
-                dbeta[lc] = pdb + (float)s1; dgamma[lc] = pdg + (float)s2;
-            }
-            __hip_atomic_store(pub + c, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pub + Cp + c, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pub + 2 * Cp + c, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // no fences: a release / acquire pair at agent scope writes back and invalidates the L2 of every participating workgroup (measured: 70 us per launch).  Every
-        // word that crosses workgroups here is written and read with agent-scope atomics (coherent at the device level by themselves); the rows are complete when
-        // this workgroup's stores have been acknowledged (vmcnt 0), only then does the counter move
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x == 0) {
-        int it = 0;
-        unsigned v;
-        // relaxed polls (an acquire load per poll invalidates caches every time; ~1000 workgroups poll one word), one fence after the last
-        while ((v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)B && ++it < (1 << 17)) __builtin_amdgcn_s_sleep(16);
-        s_ok = v >= (unsigned)B;
-    }
-    __syncthreads();
-    if (s_ok) {
-        for (int c = threadIdx.x; c < 3 * Cp; c += 256) coefS[c] = __hip_atomic_load(pub + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {          // (never seen: a publisher that did not arrive in ~50 ms) every row formed here
-        for (int c = threadIdx.x; c < Cp; c += 256) {
-            float g, c1, c2; double s1, s2; int lc;
-            acc_coef(sg, d, gamma, invstd, c, g, c1, c2, s1, s2, lc);
-            coefS[c] = g; coefS[Cp + c] = c1; coefS[2 * Cp + c] = c2;
-        }
-    }
-    __syncthreads();
-    bn_bwd_apply_rows_body<T, LEAN>(dy, ld_dy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coefS, dx, ld_dx, dres, ld_dres, dres_accum, rows_per_blk, CVP, msc, msh, r6, blockIdx.x);
-}
 
 inline void rows_geometry(int M, int CV, int& cvp, int& rows_per_blk, int& nblk) {
     cvp = 1; while (cvp < CV && cvp < 256) cvp <<= 1;
@@ -987,31 +896,6 @@ int pn2_bn_bwd_apply(int dt, int dt_dy, const void* dy, int ld_dy, int Cdy, cons
     return -3;
 }
 
-
-int pn2_bn_bwd_apply_acc(int dt, const void* dy, int ld_dy, const void* y, int ld_y, const void* x, int ld_x, int M, int Cp, const float* mean, const float* invstd,
-                         const pn2_bn_segs* segs, const pn2_bn_desc* d, const float* gamma, float* dgamma, float* dbeta, int accumulate, float* pub,
-                         void* dx, int ld_dx, void* dres, int ld_dres, int dres_accum, const float* mask_scale, const float* mask_shift, int relu6, void* stream) {
-    if (!dy || !dx || !x || !mean || !invstd || !segs || !d || !gamma || !dgamma || !dbeta || !pub) return -1;
-    if (segs->nseg < 1 || segs->nseg > 4 || segs->c0[0] != 0 || Cp > 2048 || d->Cp != Cp) return -2;
-    for (int k = 0; k < segs->nseg; ++k) {
-        if (!segs->p1[k] || !segs->p2[k] || segs->ldp[k] < 1) return -1;
-        if (segs->nblk[k] != -1 || (k && segs->c0[k] <= segs->c0[k - 1])) return -2;
-    }
-    const int V = dt == PN2_F32 ? 4 : 8;
-    if ((dt != PN2_F32 && dt != PN2_BF16) || Cp % V || ld_dy % V || ld_dx % V || ld_x % V || (y && ld_y % V) || (dres && ld_dres % V)) return -2;
-    int cvp, rpb, nblk;
-    rows_geometry(M, Cp / V, cvp, rpb, nblk);
-    const size_t lds = (size_t)3 * Cp * sizeof(float);
-    hipStream_t st = (hipStream_t)stream;
-    const bool lean = !y && !dres;
-#define PN2_APPLY_ACC(T, L) hipLaunchKernelGGL((bn_bwd_apply_rows_acc_k<T, L>), dim3(nblk), dim3(256), lds, st, (const T*)dy, ld_dy, (const T*)y, ld_y, (const T*)x, ld_x, M, Cp, mean, invstd, \
-        *segs, *d, gamma, dgamma, dbeta, accumulate, pub, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accum, rpb, cvp, mask_scale, mask_shift, relu6)
-    if (dt == PN2_BF16) { if (lean) PN2_APPLY_ACC(bf16_t, true); else PN2_APPLY_ACC(bf16_t, false); }
-    else { if (lean) PN2_APPLY_ACC(float, true); else PN2_APPLY_ACC(float, false); }
-#undef PN2_APPLY_ACC
-    PN2_CHECK_LAUNCH();
-    return 0;
-}
 
 /* BatchNorm + ReLU + MaxPool(3, 2, 1) forward as one pass (stem of Res2Net_v1b.py:137-139).  Vector rows only (C, ld multiples of the 16-byte vector). */
 int pn2_bn_relu_maxpool_fwd(int dt, const void* raw, int ld_raw, const float* scale, const float* shift, void* y, int ld_y, unsigned char* idx,

@@ -579,21 +579,6 @@ __device__ __forceinline__ void mfma_stats(const char* Cs, int crs, int nrow, in
 }
 
 // p1 = sum dz, p2 = invstd * (sum dz * raw - mean * sum dz) per channel of the tile, on the matrix cores; wave w takes the 16-channel blocks w, w + 4, ...
-// PN2_BNB_ACC: a tile's column sum into the exact accumulators of its replica (see pn2.h) - two 64-bit integer atomics, no return value
-__device__ __forceinline__ void bnb_acc_add(float* acc_, int ldp, int bm, int col, float v) {
-#ifdef PN2_BNB_F64
-    unsafeAtomicAdd(reinterpret_cast<double*>(acc_) + (size_t)(bm & (PN2_BNB_REPS - 1)) * ldp + col, (double)v);
-    return;
-#endif
-    double s_ = (double)v * 0x1p30;
-    s_ = fmin(fmax(s_, -0x1p61), 0x1p61);          // (|v| >= 2^31: saturates instead of wrapping; such a step is lost anyway)
-    const double f = floor(s_);
-    const long long hi = (long long)f, lo = (long long)((s_ - f) * 0x1p50);
-    unsigned long long* a = reinterpret_cast<unsigned long long*>(acc_) + (size_t)((bm & (PN2_BNB_REPS - 1)) * 2) * ldp + col;
-    atomicAdd(a, (unsigned long long)hi);
-    if (lo) atomicAdd(a + ldp, (unsigned long long)lo);
-}
-
 template <int BM, int BN>
 __device__ __forceinline__ void ep2_sums(const char* dz, const char* raw, const pn2_bnb_target& t, int Cout, int n0, int bm) {
     constexpr int CRS = BN * 2 + 16, NCB = (BN / 16 + 3) / 4, KC = BM / 32;
@@ -644,11 +629,8 @@ __device__ __forceinline__ void ep2_sums(const char* dz, const char* raw, const 
         if (cb < BN / 16 && holder && col < Cout) {
             float s1 = 0.f, s2 = 0.f;
             if (ST[c]) { s1 = a1[c][0]; s2 = IS[c] * (q - MU[c] * s1); }
-            if (t.mode & PN2_BNB_ACC) { if (ST[c]) { bnb_acc_add(t.p1, t.ldp, bm, col, s1); bnb_acc_add(t.p2, t.ldp, bm, col, s2); } }
-            else {
-                t.p1[(size_t)bm * t.ldp + col] = s1;
-                t.p2[(size_t)bm * t.ldp + col] = s2;
-            }
+            t.p1[(size_t)bm * t.ldp + col] = s1;
+            t.p2[(size_t)bm * t.ldp + col] = s2;
         }
     }
 }
@@ -973,8 +955,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
             float* pp = isb ? pb : pa;
             const int ldp = isb ? ep.b.ldp : ep.a.ldp;
             const int md = isb ? ep.b.mode : ep.a.mode;
-            if (md & PN2_BNB_ACC) bnb_acc_add(pp, ldp, bm, n0 + c, v);
-            else if (md & PN2_BNB_STATS) pp[(size_t)bm * ldp + n0 + c] = v;
+            if (md & PN2_BNB_STATS) pp[(size_t)bm * ldp + n0 + c] = v;
         }
     }
     }

@@ -76,8 +76,7 @@ class BnDesc(C.Structure):
                 ("eps", C.c_float), ("momentum", C.c_float), ("ldp", C.c_int), ("tile_rows", C.c_int)]
 
 
-BNB_STATS, BNB_MASK_RAW, BNB_MASK_Y, BNB_STORE_MASKED, BNB_ACC = 1, 2, 4, 8, 16
-BNB_REPS = 16
+BNB_STATS, BNB_MASK_RAW, BNB_MASK_Y, BNB_STORE_MASKED = 1, 2, 4, 8
 
 
 class BnbTarget(C.Structure):
@@ -178,7 +177,6 @@ SIGNATURES = {
     "pn2_bn_bwd_finalize": [P, P, I, C.POINTER(BnDesc), P, P, P, P, I, P, P],
     "pn2_bn_bwd_finalize_seg": [C.POINTER(BnSegs), C.POINTER(BnDesc), P, P, P, P, I, P, P],
     "pn2_bn_bwd_apply": [I, I, P, I, I, P, I, I, P, I, I, I, P, P, P, P, I, P, I, I, P, P, I, P],
-    "pn2_bn_bwd_apply_acc": [I, P, I, P, I, P, I, I, I, P, P, C.POINTER(BnSegs), C.POINTER(BnDesc), P, P, P, I, P, P, I, P, I, I, P, P, I, P],
     "pn2_maxpool3x3s2_fwd": [I, P, I, P, I, P, I, I, I, I, I, I, P],
     "pn2_maxpool3x3s2_bwd": [I, P, I, P, P, I, I, I, I, I, I, I, P],
     "pn2_avgpool_fwd": [I, P, I, P, I, I, I, I, I, I, I, I, I, I, I, P],

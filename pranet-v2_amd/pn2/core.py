@@ -360,28 +360,6 @@ class StepArena:
         return torch.empty(shape, dtype=dtype, device=dev)
 
 
-class ZeroArena(StepArena):
-    """A StepArena whose buffers are ZERO when handed out: the block is cleared by ONE fill at the top of the step (begin_step), so the exact accumulators of
-    every BatchNorm-backward epilogue of the step (PN2_BNB_ACC) cost one launch together.  The measuring first step hands out torch.zeros."""
-
-    def begin_step(self, dev):
-        super().begin_step(dev)
-        if self.buf is not None:
-            self.buf.zero_()
-
-    def alloc(self, shape, dtype, dev):
-        n = dtype.itemsize
-        for d in shape:
-            n *= d
-        na = (n + 255) // 256 * 256
-        self.need += na
-        if self.buf is not None and self.off + na <= self.buf.numel():
-            t = self.buf[self.off:self.off + n].view(dtype).view(shape)
-            self.off += na
-            return t
-        return torch.zeros(shape, dtype=dtype, device=dev)
-
-
 TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the tuners time every candidate behind a cache-evicting fill (tests/conftest.py switches it off)
 WGRAD_WGS = 640               # pixel splits: workgroups a single wgrad aims at ...
 WGRAD_SLAB_MB = 24            # ... within this many MB of fp32 slabs
@@ -410,7 +388,6 @@ PATCH_DGRAD = os.environ.get("PN2_PATCH_DGRAD", "1") == "1"         # kernel == 
 FUSE_BIAS = os.environ.get("PN2_FUSE_BIAS", "1") == "1"             # bias of BN-less convs / nn.Linear in the GEMM epilogue (PN2_CONV_BIAS)
 BNB_EPILOGUE = os.environ.get("PN2_BNB_EPILOGUE", "1") == "1"       # BatchNorm-backward statistics in the epilogue of the dgrad GEMM that completes dy
 LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independent chains (RFB branches, stage-block branches) share table-driven launches
-BNB_ACC = os.environ.get("PN2_BNB_ACC", "0") == "1"                 # ... leaving its sums in exact int64 accumulators instead of partial rows: pn2_bn_bwd_apply_acc needs no finalize launch
 DW_COLSUM = os.environ.get("PN2_DW_COLSUM", "1") == "1"             # PVTv2 Mlp: fc1's bias gradient from the depth-wise conv's data-gradient walk (no second read of that gradient)
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
 POOL_BWD_QUAD = os.environ.get("PN2_POOL_BWD_QUAD", "1") == "1"  # ... and its backward without the full-resolution gradient tensor (pn2_pool_bn_bwd_reduce / _apply); 0: pool-backward launch + the generic BatchNorm passes

@@ -22,8 +22,7 @@ from .ops_spatial import SpatialOps
 
 class Engine(ConvOps, EncoderOps, SpatialOps):
     def __init__(self, dtype=BF16, training=True, grad_provider=None, need_grad=True, pack_cache=None, tuner=None, grad_queue=None, arena=None, lock_cache=None,
-                 bn_fold=None, zarena=None):
-        self.zarena = zarena            # ZeroArena: buffers that must be zero when first used (the exact accumulators of PN2_BNB_ACC), cleared by one fill per step
+                 bn_fold=None):
         self.bn_fold = bn_fold          # BnFoldCache: eval-mode BatchNorm rows kept across forwards (the caller refreshes it once per forward); None = one prepare launch per layer
         self.lock_cache = lock_cache    # dict shared across steps: device job tables of the lock-step regions (Engine.lockstep); None = no lock-step batching
         self.pack_cache = pack_cache
@@ -80,12 +79,6 @@ class Engine(ConvOps, EncoderOps, SpatialOps):
 
     def fbuf(self, *shape):
         return self.alloc(shape, torch.float32)
-
-    def zbuf(self, shape, dtype):
-        """A zero-filled buffer (from the step's ZeroArena when there is one: no launch of its own)."""
-        if self.zarena is not None:
-            return self.zarena.alloc(tuple(shape), dtype, self.dev)
-        return torch.zeros(tuple(shape), dtype=dtype, device=self.dev)
 
     def from_nchw(self, x, requires_grad=False, dt=None):
         """fp32 NCHW module input -> NHWC compute dtype (or `dt`), channels zero-padded to a multiple of 8."""

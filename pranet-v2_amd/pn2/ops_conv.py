@@ -450,7 +450,6 @@ class ConvOps:
                 # the backward passes then do not read y at all
                 ymask, msc, msh = None, scale, shift
             nul = C.c_void_p(0)
-            acc_apply = None
             if train_bn:
                 coef = self.fbuf(3 * Cout_p)
                 gg, ga = self.pgrads.sink(bn.weight)
@@ -468,11 +467,6 @@ class ConvOps:
                     # (part of) the statistics were left by dgrad epilogues; channel ranges nobody covered get a reduce pass of their own
                     sg = capi.BnSegs()
                     sg.nseg = len(segs)
-                    # all of them exact accumulators: pn2_bn_bwd_apply_acc forms the coefficients itself - no finalize launch (not inside a lock-step region,
-                    # whose finalize / apply launches are table-driven already)
-                    from . import lockstep as LS
-                    fold_acc = (all(s_[4] == -1 for s_ in segs) and Cout_p <= 2048 and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) % V == 0
-                                and gate is None and not LS._ACTIVE)
                     for k_, (c0, nc, p1, p2, nb_, ldp) in enumerate(segs):
                         if p1 is None:
                             nb_ = call.pn2_bn_bwd_blocks(M, nc, self.dt)
@@ -483,10 +477,7 @@ class ConvOps:
                                                    _p(msc[c0:]) if msc is not None else nul, _p(msh[c0:]) if msc is not None else nul, r6, st)
                         sg.c0[k_], sg.nblk[k_], sg.ldp[k_], sg.p1[k_], sg.p2[k_] = c0, nb_, ldp, p1.data_ptr(), p2.data_ptr()
                         self._keep.append((p1, p2))
-                    if fold_acc:
-                        acc_apply = (sg, gg, gb, ga)
-                    else:
-                        call.pn2_bn_bwd_finalize_seg(C.byref(sg), C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
+                    call.pn2_bn_bwd_finalize_seg(C.byref(sg), C.byref(bd), _p(bn.weight), _p(invstd), _p(gg), _p(gb), ga, _p(coef), st)
                 else:
                     nb = call.pn2_bn_bwd_blocks(M, Cout_p, self.dt)
                     p1, p2 = self.fbuf(nb, Cout_p), self.fbuf(nb, Cout_p)
@@ -520,11 +511,6 @@ class ConvOps:
                                            _p(mean), _p(invstd), _p(coef), _p(msc), _p(msh), _p(draw), Cout_p, st)
             elif coef is None and ymask is None and rg is None and out.dt == self.dt and Cdy == Cout_p and dy.stride(2) == Cout_p and dy.is_contiguous():
                 draw = dy               # no BN, no activation, no residual (nn.Linear / biased conv): dz IS dy - no copy pass
-            elif acc_apply is not None:
-                sg_, gg_, gb_, ga_ = acc_apply
-                call.pn2_bn_bwd_apply_acc(self.dt, _p(dy), dy.stride(2), ymask.ptr if ymask else nul, ymask.ld if ymask else 0, _p(raw), raw_ld, M, Cout_p, _p(mean), _p(invstd),
-                                          C.byref(sg_), C.byref(bd), _p(bn.weight), _p(gg_), _p(gb_), ga_, _p(self.zbuf((3 * Cout_p + 4,), torch.float32)), _p(draw), Cout_p,
-                                          _p(rg), rg.stride(2) if rg is not None else 0, racc, _p(msc), _p(msh), r6, st)
             else:
                 call.pn2_bn_bwd_apply(self.dt, out.dt, _p(dy), dy.stride(2), Cdy, ymask.ptr if ymask else nul, ymask.ld if ymask else 0, self.dt,
                                       _p(raw), raw_ld, M, Cout_p, _p(mean), _p(invstd), _p(coef), _p(draw), Cout_p,
@@ -737,13 +723,7 @@ class ConvOps:
                 t.raw2, t.par2 = b.raw2.data_ptr(), b.par2.data_ptr()
         if nblk == 0:               # description only (the tuner supplies its own partial rows)
             return
-        if core.BNB_ACC and self.dt == BF16:
-            # exact int64 accumulators [REPS][2][Cp] (zero: the step's ZeroArena) instead of nblk partial rows; registered with nblk = -1
-            p1, p2 = self.zbuf((2 * capi.BNB_REPS, Cp), torch.int64), self.zbuf((2 * capi.BNB_REPS, Cp), torch.int64)
-            t.mode |= capi.BNB_ACC
-            nblk = -1
-        else:
-            p1, p2 = self.fbuf(nblk, Cp), self.fbuf(nblk, Cp)
+        p1, p2 = self.fbuf(nblk, Cp), self.fbuf(nblk, Cp)
         t.p1, t.p2, t.ldp = p1.data_ptr(), p2.data_ptr(), Cp
         if b.split:
             t.split = b.split

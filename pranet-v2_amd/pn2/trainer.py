@@ -13,7 +13,7 @@ import os
 import torch
 
 from .capi import call, F32
-from .engine import Engine, Act, PackCache, GradQueue, StepArena, ZeroArena, TUNER, _p, _stream
+from .engine import Engine, Act, PackCache, GradQueue, StepArena, TUNER, _p, _stream
 from .graph import get_compute_dtype
 from .dp import GradBuckets
 from . import loss as L
@@ -157,8 +157,7 @@ class Trainer:
                 key=key, steps_run=0, graph=None, graph_opt=None, segments=None, s_images=None, s_gts=None, s_loss=None,
                 lock_cache={},
                 grad_queue=GradQueue(defer_wgrad=mode == "2") if mode in ("1", "2") else None,
-                arena=StepArena() if os.environ.get("PN2_STEP_ARENA", "1") == "1" else None,
-                zarena=ZeroArena() if os.environ.get("PN2_STEP_ARENA", "1") == "1" else None)
+                arena=StepArena() if os.environ.get("PN2_STEP_ARENA", "1") == "1" else None)
         self._cur = st
         return st
 
@@ -175,9 +174,8 @@ class Trainer:
         self.pack_cache.refresh()
         if st.arena is not None:
             st.arena.begin_step(self.flat.device)
-            st.zarena.begin_step(self.flat.device)
         st.steps_run += 1
-        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, grad_queue=st.grad_queue, arena=st.arena, zarena=st.zarena,
+        eng = Engine(self.dtype, True, grad_provider=self._grad_view, need_grad=True, pack_cache=self.pack_cache, tuner=self.tuner, grad_queue=st.grad_queue, arena=st.arena,
                      lock_cache=st.lock_cache if (st.arena is not None and st.arena.buf is not None) else None)    # recorded launches hold raw pointers:
         # only with the bump arena (nothing is recycled inside a step) do the buffers of a lane outlive the deferred emission
         eng.fuse_tail = self.fuse_tail and self.loss_kind == "structure"
@@ -270,7 +268,7 @@ class Trainer:
         eng.tail.clear()
         eng._lat = None
         eng.pgrads.provider = None
-        eng.lock_cache = eng.grad_queue = eng.arena = eng.zarena = eng.pack_cache = None
+        eng.lock_cache = eng.grad_queue = eng.arena = eng.pack_cache = None
         if self.tuner is not None and len(self.tuner) != self._tuned and os.environ.get("PN2_TUNE_CACHE"):
             from .engine import save_tuner
             save_tuner(os.environ["PN2_TUNE_CACHE"])

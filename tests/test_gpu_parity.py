@@ -281,38 +281,6 @@ def test_bn_backward_statistics_in_dgrad_epilogue(dtn, case, monkeypatch):
                 assert rell2(g_, r_) < 3e-2
 
 
-@pytest.mark.parametrize("arena", ["1", "0"])
-def test_bnb_exact_accumulators_match_partial_rows(arena, monkeypatch):
-    """PN2_BNB_ACC (opt-in, measured slower in its exact form: DESIGN 6): the dgrad epilogues add their BatchNorm-backward sums into int64 fixed-point accumulators
-    (two words per sum, zero from the step's ZeroArena or torch.zeros) with atomics, pn2_bn_bwd_apply_acc forms the coefficients in its prologue (no finalize
-    launch) and the lock-step regions hand the accumulators to the table-driven finalize.  Integer sums do not depend on the order: two steps give the loss of the
-    partial-row path and the same gradients up to the rare last-bit difference of the old path's own double sums (amplified by the random-init net)."""
-    from pn2 import core
-    from pn2.trainer import Trainer
-    from pn2.capi import call
-    from oracle import weights as W
-    monkeypatch.setenv("PN2_STEP_ARENA", arena)
-    x, mask = W.synthetic_batch(2, 96, seed=77)
-    xg, mg = x.to(dev), mask.to(dev)
-    res = []
-    for acc in (False, True):
-        monkeypatch.setattr(core, "BNB_ACC", acc)
-        counts = {"pn2_bn_bwd_apply_acc": 0, "pn2_bn_bwd_finalize_seg": 0}
-        real = {n: getattr(call, n) for n in counts}
-        for n in counts:
-            monkeypatch.setattr(call, n, (lambda *a, _n=n: (counts.__setitem__(_n, counts[_n] + 1), real[_n](*a))[1]), raising=False)
-        tr = Trainer(_fixture_model(fp32=False), lr=1e-4, clip=0.5)
-        tr.step(xg, mg)
-        loss = tr.forward_backward(xg, mg)
-        torch.cuda.synchronize()
-        for n in counts:
-            monkeypatch.setattr(call, n, real[n], raising=False)
-        res.append((loss.clone(), tr.gflat.clone(), dict(counts)))
-    (l0, g0, c0), (l1, g1, c1) = res
-    assert c0["pn2_bn_bwd_apply_acc"] == 0 and c1["pn2_bn_bwd_apply_acc"] >= 20 and c1["pn2_bn_bwd_finalize_seg"] < c0["pn2_bn_bwd_finalize_seg"], (c0, c1)
-    assert relmax(l1, l0) < 1e-5 and rell2(g1, g0) < 5e-3, (relmax(l1, l0), rell2(g1, g0))
-
-
 @pytest.mark.parametrize("dtn", ["fp32", "bf16"])
 def test_pool_and_bilinear_ops(dtn):
     from pn2 import F32, BF16
