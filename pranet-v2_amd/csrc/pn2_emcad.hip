@@ -650,17 +650,17 @@ __global__ __launch_bounds__(256) void mloss_fwd_k(ml_maps m, const long long* _
     const bool rlead = (lane & 15) == 0;
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool ok = p < NP;
-    float f[4][K], b[4][K], mk[K];
+    // Round 6: foreground (softmax-coupled: CE, Dice sums) and background (BCE: every class on its own) parts apart, as in the backward - the background part runs
+    // class by class with four logits and fifteen running sums live (205 -> ~110 registers, two -> four waves per SIMD); same sums, same order, bit for bit
+    float f[4][K];
     int lab = -1;
+    const size_t n = ok ? p / HW : 0, hw = ok ? p % HW : 0;
     if (ok) {
         lab = (int)label[p];
-        const size_t n = p / HW, hw = p % HW;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int k = 0; k < K; ++k) { f[i][k] = m.fg[i][p * K + k]; b[i][k] = m.bg[i][p * K + k]; }
-#pragma unroll
-        for (int k = 0; k < K; ++k) mk[k] = bgm[(n * K + k) * HW + hw];
+            for (int k = 0; k < K; ++k) f[i][k] = m.fg[i][p * K + k];
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {          // label histogram (sum of target^2 per class), once
@@ -668,14 +668,14 @@ __global__ __launch_bounds__(256) void mloss_fwd_k(ml_maps m, const long long* _
         t = row16_sum(t);
         if (rlead) red[rrow][ML_NS * W + k] = t;
     }
-#pragma unroll          // (measured in round 6: rolled, with 0 / 1 map weights, the kernel drops from 205 to 126 registers and gets SLOWER - 0.88 -> 1.07 ms: twice the adds per subset)
+#pragma unroll
     for (int s = 1; s <= ML_NS; ++s) {
-        float z[K], zb[K], v[W];
+        float z[K], v[W];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            z[k] = 0.f; zb[k] = 0.f;
+            z[k] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (s >> i & 1) { z[k] += f[i][k]; zb[k] += b[i][k]; }
+            for (int i = 0; i < 4; ++i) if (s >> i & 1) z[k] += f[i][k];
         }
         float mx = z[0];
 #pragma unroll
@@ -684,21 +684,46 @@ __global__ __launch_bounds__(256) void mloss_fwd_k(ml_maps m, const long long* _
 #pragma unroll
         for (int k = 0; k < K; ++k) { e[k] = __expf(z[k] - mx); se += e[k]; }
         const float inv = __builtin_amdgcn_rcpf(se), lse = mx + __logf(se);
-        float ce = 0.f, bce = 0.f;
+        float ce = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float pk = e[k] * inv;
             if (lab == k) ce = lse - z[k];
             v[2 + k] = (lab == k) ? pk : 0.f;
             v[2 + K + k] = pk * pk;
-            bce += fmaxf(zb[k], 0.f) - zb[k] * mk[k] + __logf(1.f + __expf(-fabsf(zb[k])));
         }
-        v[0] = ce; v[1] = bce;
+        v[0] = ce; v[1] = 0.f;
 #pragma unroll
-        for (int j = 0; j < W; ++j) v[j] = row16_sum(ok ? v[j] : 0.f);
+        for (int j = 0; j < W; ++j) if (j != 1) v[j] = row16_sum(ok ? v[j] : 0.f);
         if (rlead) {
 #pragma unroll
-            for (int j = 0; j < W; ++j) red[rrow][(s - 1) * W + j] = v[j];
+            for (int j = 0; j < W; ++j) if (j != 1) red[rrow][(s - 1) * W + j] = v[j];
+        }
+    }
+    {
+        float bce[ML_NS];
+#pragma unroll
+        for (int s = 0; s < ML_NS; ++s) bce[s] = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float b[4] = {0.f, 0.f, 0.f, 0.f}, mk = 0.f;
+            if (ok) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = m.bg[i][p * K + k];
+                mk = bgm[(n * K + k) * HW + hw];
+            }
+#pragma unroll
+            for (int s = 1; s <= ML_NS; ++s) {
+                float zb = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (s >> i & 1) zb += b[i];
+                bce[s - 1] += fmaxf(zb, 0.f) - zb * mk + __logf(1.f + __expf(-fabsf(zb)));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < ML_NS; ++s) {
+            const float t = row16_sum(ok ? bce[s] : 0.f);
+            if (rlead) red[rrow][s * W + 1] = t;
         }
     }
     __syncthreads();
