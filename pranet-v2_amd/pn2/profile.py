@@ -180,7 +180,7 @@ def _conv_bytes(shape, es):
         return 0
 
 
-PMC_FILE = "r05_pmc_hbm_traffic.json"       # the current round's summary (tools/prof_pmc.sh)
+PMC_FILE = "r06_pmc_hbm_traffic.json"       # the current round's summary (tools/prof_pmc.sh)
 
 
 def _pmc_traffic(symbols, config):
