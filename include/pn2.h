@@ -115,7 +115,11 @@ typedef struct pn2_bnb_target {
  * 1/4 of row (n, y/2, x/2) of this quarter-resolution tensor [N][OH/2][OW/2][ld_pool] for output row (n, y, x) - the backward of AvgPool2d(2, 2) in front of the
  * downsample conv of a Res2Net stage block (Res2Net_v1b.py:127-136,80) folded into the dgrad that completes the block input's gradient: out = dgrad + pool/4 (the bits a
  * separate pn2_avgpool_bwd + += would leave: 1/4 is exact), no pool-backward launch, no full-resolution write + re-read of that gradient. */
-typedef struct pn2_conv_ep { pn2_bnb_target a, b; const void* pool; int ld_pool; int pad_; } pn2_conv_ep;
+/* c (optional; mode == PN2_BNB_STATS, bf16 launches whose tile has at most 4096 elements, no target b): a SECOND BatchNorm whose output gradient is target a's masked
+ * gradient dz - the BatchNorm of a residual branch without activation (Bottle2neck's downsample: out = relu(bn3(..) + dbn(dconv(pool(x)))), Res2Net_v1b.py:80-89,127-136).
+ * The epilogue that forms dz for bn3 leaves p1 = sum dz, p2 = invstd_c * (sum dz * raw_c - mean_c * sum dz) for it as well (fields raw / ld_raw / par / ps / p1 / p2 / ldp):
+ * the pn2_bn_bwd_reduce pass of that BatchNorm (two full-tensor reads) disappears. */
+typedef struct pn2_conv_ep { pn2_bnb_target a, b; const void* pool; int ld_pool; int pad_; pn2_bnb_target c; } pn2_conv_ep;
 int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const pn2_conv_desc* d, const pn2_conv_ep* ep, void* stream);
 /* Many conv GEMMs (forward / dgrad, with or without the epilogue above) of ONE tile shape in one launch, from a DEVICE job table: the convs at the same
  * position of independent chains (the RFB branches of the three RFB modules, pranet.py:46-83; the parallel 3x3 convs of a Res2Net stage block,

@@ -336,9 +336,9 @@ __device__ __forceinline__ void tr_frag_issue(unsigned tile, int rs, int chan0, 
 // with += (64 x 128: 142 -> 154 us, 90.8 -> 100.3 us: three operand tiles cost ~1 us of LDS-DMA issue per workgroup and the sums + stores tail
 // 2.3 us against 1.3 us of the register form).  Tiles of at most 4096 elements use it, the others keep the register form.
 constexpr bool ep2_tile(int bm, int bn) { return bm * bn <= 4096; }
-struct Ep2Layout { int raw_a, y_a, prior, raw_b, dz_b, total; };
+struct Ep2Layout { int raw_a, y_a, prior, raw_b, dz_b, raw_c, total; };
 template <int BM, int BN>
-__host__ __device__ inline Ep2Layout ep2_layout(bool stat_a, bool y_a, bool acc, bool stat_b) {
+__host__ __device__ inline Ep2Layout ep2_layout(bool stat_a, bool y_a, bool acc, bool stat_b, bool stat_c = false) {
     constexpr int CT = BM * (BN * 2 + 16), TB = BM * BN * 2;
     Ep2Layout L; int off = CT;
     L.raw_a = off; if (stat_a) off += TB;
@@ -346,6 +346,7 @@ __host__ __device__ inline Ep2Layout ep2_layout(bool stat_a, bool y_a, bool acc,
     L.prior = off; if (acc) off += TB;
     L.raw_b = off; if (stat_b) off += TB;
     L.dz_b = off; if (stat_b) off += CT;
+    L.raw_c = off; if (stat_c) off += TB;
     L.total = off;
     return L;
 }
@@ -355,6 +356,9 @@ __host__ __device__ inline void ep2_needs(const pn2_conv_desc& d, const pn2_conv
     acc = (d.flags & PN2_CONV_ACCUM) != 0;
     stat_b = ep.b.out != nullptr && (ep.b.mode & PN2_BNB_STATS) != 0;
 }
+// pn2_conv_ep.c: a second BatchNorm behind target a's MASKED gradient (the BatchNorm of a residual branch without activation: Bottle2neck's downsample,
+// Res2Net_v1b.py:80,127-136 - its output gradient IS dz of bn3): sum dz and sum dz * raw_c from the dz tile this epilogue has in LDS anyway
+__host__ __device__ inline bool ep2_stat_c(const pn2_conv_ep& ep) { return (ep.a.mode & PN2_BNB_STATS) && (ep.c.mode & PN2_BNB_STATS); }
 
 // one [BM][BN] bf16 operand tile -> LDS, dense rows, by LDS-DMA.  Tensors below 2 GB without a column split go through a buffer descriptor: one
 // 32-bit offset per lane, stepped by a constant per request, rows past M read as zeros (out of range); otherwise flat 64-bit addresses, rows clamped.
@@ -413,7 +417,8 @@ template <int BM, int BN>
 __device__ __forceinline__ void ep2_issue(char* smem, const pn2_conv_desc& d, const pn2_conv_ep& ep, const bf16_t* out, int M, int m0, int n0) {
     bool stat_a, y_a, acc, stat_b;
     ep2_needs(d, ep, stat_a, y_a, acc, stat_b);
-    const Ep2Layout L = ep2_layout<BM, BN>(stat_a, y_a, acc, stat_b);
+    const Ep2Layout L = ep2_layout<BM, BN>(stat_a, y_a, acc, stat_b, ep2_stat_c(ep));
+    if (ep2_stat_c(ep)) ep2_dma_tile<BM, BN>(smem + L.raw_c, (const bf16_t*)ep.c.raw, ep.c.ld_raw, nullptr, 0, M, m0, n0, d.Cout);
     if (stat_a) ep2_dma_tile<BM, BN>(smem + L.raw_a, (const bf16_t*)ep.a.raw, ep.a.ld_raw, (const bf16_t*)ep.a.raw2, ep.a.split, M, m0, n0, d.Cout);
     if (y_a) ep2_dma_tile<BM, BN>(smem + L.y_a, (const bf16_t*)ep.a.y, ep.a.ld_y, nullptr, 0, M, m0, n0, d.Cout);
     if (acc) {
@@ -464,7 +469,7 @@ __device__ __forceinline__ void ep2_apply(char* smem, const pn2_conv_desc& d, co
     constexpr int VPR = BN / 8, CRS = BN * 2 + 16, RPT = BM * VPR / 256, RSTEP = 256 / VPR;
     bool stat_a, y_a, acc, stat_b;
     ep2_needs(d, ep, stat_a, y_a, acc, stat_b);
-    const Ep2Layout L = ep2_layout<BM, BN>(stat_a, y_a, acc, stat_b);
+    const Ep2Layout L = ep2_layout<BM, BN>(stat_a, y_a, acc, stat_b, ep2_stat_c(ep));
     const int tid = threadIdx.x, cv = tid % VPR, r0 = tid / VPR, col = n0 + cv * 8;
     const bool cok = col < d.Cout, dual = ep.b.out != nullptr;
     const int colc = cok ? col : n0;
@@ -915,8 +920,9 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[MT][NT], char* smem
         PN2_STAMP_AT(15);
         bool stat_a, y_a, acc_, stat_b;
         ep2_needs(d, ep, stat_a, y_a, acc_, stat_b);
-        const Ep2Layout L = ep2_layout<BM, BN>(stat_a, y_a, acc_, stat_b);
+        const Ep2Layout L = ep2_layout<BM, BN>(stat_a, y_a, acc_, stat_b, ep2_stat_c(ep));
         if (stat_a) ep2_sums<BM, BN>(smem, smem + L.raw_a, ep.a, d.Cout, n0, bm);
+        if (ep2_stat_c(ep)) ep2_sums<BM, BN>(smem, smem + L.raw_c, ep.c, d.Cout, n0, bm);          // the same dz tile against the second BatchNorm's raw tile
         if (stat_b) ep2_sums<BM, BN>(smem + L.dz_b, smem + L.raw_b, ep.b, d.Cout, n0, bm);
         ep2_store<BM, BN>(d, ep, reinterpret_cast<bf16_t*>(out), M, m0, n0, O);      // global stores last
     } else {
@@ -2001,7 +2007,7 @@ template <int BM, int BN>
 inline int ep2_lds_for(const pn2_conv_desc& d, const pn2_conv_ep& ep) {
     bool stat_a, y_a, acc, stat_b;
     ep2_needs(d, ep, stat_a, y_a, acc, stat_b);
-    return ep2_layout<BM, BN>(stat_a, y_a, acc, stat_b).total;
+    return ep2_layout<BM, BN>(stat_a, y_a, acc, stat_b, ep2_stat_c(ep)).total;
 }
 // table launches: the caller says what the jobs need (bits 1..4 of `ep`: statistics a, mask-from-activation a, +=, statistics b); no bits = everything
 template <int BM, int BN>
@@ -2646,6 +2652,13 @@ int pn2_conv_gemm_ep(int dtype, const void* in, const void* wp, void* out, const
     const int vec = dtype == PN2_BF16 ? 8 : 4;
     if ((d->flags & (PN2_CONV_STATS | PN2_CONV_BIAS)) || ((d->flags >> 16) & 15) > 1) return -2;
     if (d->Cout % vec || d->ld_out % vec) return -2;                      // the statistics live in the 16-byte store path
+    if (ep->c.mode) {          // second BatchNorm behind target a's masked gradient: LDS-DMA / matrix-core epilogue form only (tiles of <= 4096 elements, bf16, single launches)
+        if (dtype != PN2_BF16 || ep->c.mode != PN2_BNB_STATS || !(ep->a.mode & PN2_BNB_STATS) || ep->b.out || ep->c.split) return -2;
+        if (!ep->c.raw || !ep->c.par || !ep->c.p1 || !ep->c.p2 || ep->c.ldp < 1 || ep->c.ld_raw % vec || ep->c.ps < 1) return -1;
+        int kern_, bm_, bn_;
+        gemm_select<bf16_t>(*d, kern_, bm_, bn_);
+        if (!ep2_tile(bm_, bn_)) return -2;
+    }
     if (ep->pool && (!(d->flags & PN2_CONV_ACCUM) || !(ep->a.mode & PN2_BNB_STATS) || ep->b.out || (d->OH & 1) || (d->OW & 1) || ep->ld_pool % vec || ep->ld_pool < d->Cout)) return -2;
     int rc = bnb_check(ep->a, vec, false);
     if (rc) return rc;

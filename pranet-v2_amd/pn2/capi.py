@@ -86,7 +86,7 @@ class BnbTarget(C.Structure):
 
 
 class ConvEp(C.Structure):
-    _fields_ = [("a", BnbTarget), ("b", BnbTarget), ("pool", C.c_void_p), ("ld_pool", C.c_int), ("pad_", C.c_int)]
+    _fields_ = [("a", BnbTarget), ("b", BnbTarget), ("pool", C.c_void_p), ("ld_pool", C.c_int), ("pad_", C.c_int), ("c", BnbTarget)]
 
 
 class BnSegs(C.Structure):

@@ -202,10 +202,11 @@ class Bnb:
     relu: the activation behind the BN; ymask: the stored output (tensor view) when the ReLU mask cannot be recomputed from raw (BN + residual + ReLU).
     split / raw2 / par2 / tail: a concat buffer whose columns >= split are (a copy of) another BatchNorm's output `tail` (raw2 / par2 indexed by the
     same local column; par2 None = those columns carry no BatchNorm)."""
-    __slots__ = ("raw", "par", "relu", "ymask", "split", "raw2", "par2", "tail")
+    __slots__ = ("raw", "par", "relu", "ymask", "split", "raw2", "par2", "tail", "res")
 
     def __init__(self, raw, par, relu, ymask=None, split=0, raw2=None, par2=None, tail=None):
         self.raw, self.par, self.relu, self.ymask, self.split, self.raw2, self.par2, self.tail = raw, par, relu, ymask, split, raw2, par2, tail
+        self.res = None          # Act: the residual operand when it is itself a train-mode BatchNorm output without activation (Bottle2neck's downsample): its gradient is this BN's masked dz
 
     def cols(self, c0, c1):
         return Bnb(self.raw[..., c0:c1], self.par[:, c0:c1], self.relu, self.ymask[..., c0:c1] if self.ymask is not None else None)
@@ -391,6 +392,7 @@ LOCKSTEP = os.environ.get("PN2_LOCKSTEP", "1") == "1"               # independen
 DW_COLSUM = os.environ.get("PN2_DW_COLSUM", "1") == "1"             # PVTv2 Mlp: fc1's bias gradient from the depth-wise conv's data-gradient walk (no second read of that gradient)
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
 POOL_BWD_QUAD = os.environ.get("PN2_POOL_BWD_QUAD", "1") == "1"  # ... and its backward without the full-resolution gradient tensor (pn2_pool_bn_bwd_reduce / _apply); 0: pool-backward launch + the generic BatchNorm passes
+RES_STATS = os.environ.get("PN2_RES_STATS", "1") == "1"          # the downsample BatchNorm's backward sums from the dgrad epilogue that forms bn3's masked gradient (pn2_conv_ep.c): no reduce pass
 POOL_FOLD = os.environ.get("PN2_POOL_FOLD", "1") == "1"          # Bottle2neck stage blocks: the backward of the downsample branch's AvgPool2d(2, 2) rides in conv1's dgrad epilogue (pn2_conv_ep.pool) - no pool-backward launch
 POOL_FUSE = os.environ.get("PN2_POOL_FUSE", "1") == "1"          # the stem's bn1 -> ReLU -> MaxPool as one op: the 176 x 176 BatchNorm output is never written (conv_bn_act(pool=True))
 TEE_CONCAT = os.environ.get("PN2_TEE_CONCAT", "1") == "1"         # Bottle2neck: conv1 + bn1 + ReLU writes its pass-through slice into the concat buffer as well (pn2_affine_act_tee); False: a copy launch

@@ -416,6 +416,9 @@ class ConvOps:
         bnb_ok = core.BNB_EPILOGUE and train_bn and not fuse_bias and y_C is None and y_dt == self.dt and relu in (False, True) and out.ld % V == 0 and Cout_p % V == 0 and not pool
         if bnb_ok:
             out.bnb = Bnb(raw, par, bool(relu), out.t if residual is not None else None)
+            if (residual is not None and relu and residual.bnb is not None and not residual.bnb.relu and residual.bnb.ymask is None and residual.bnb.split == 0
+                    and residual.parent is None and residual.Cp == Cout_p):
+                out.bnb.res = residual          # (only as this op's residual operand: Bottle2neck's downsample branch)
 
         def bwd():
             st = _stream()
@@ -664,7 +667,7 @@ class ConvOps:
                         u._sealed = v._sealed = True
                         call.pn2_conv_gemm_ep(self.dt, _p(draw), _p(wt), _p(gu), C.byref(dd), C.byref(ep), st)
                     else:
-                        self._fill_bnb(ep.a, x, nbx)
+                        self._fill_bnb(ep.a, x, nbx, ep, tcode)
                         call.pn2_conv_gemm_ep(self.dt, _p(draw), _p(wt), _p(gx), C.byref(dd), C.byref(ep), st)
                     if pool_ok and x.pool_prior is not None:
                         x.pool_prior = None
@@ -701,7 +704,7 @@ class ConvOps:
         bm = (tune >> 2) & 3
         return (64 if bm == 1 else 128) if bm else call.pn2_conv_tile_m(M, Cout, capi.F32_MMA if self.dt == F32 else self.dt)
 
-    def _fill_bnb(self, t, act, nblk):
+    def _fill_bnb(self, t, act, nblk, ep=None, tcode=0):
         """Describe `act`'s BatchNorm to a dgrad epilogue target and register the partial rows it will leave."""
         b = act.bnb
         if b is None:
@@ -725,6 +728,17 @@ class ConvOps:
             return
         p1, p2 = self.fbuf(nblk, Cp), self.fbuf(nblk, Cp)
         t.p1, t.p2, t.ldp = p1.data_ptr(), p2.data_ptr(), Cp
+        bm_, bn_ = (tcode >> 2) & 3, (tcode >> 4) & 3
+        if (ep is not None and core.RES_STATS and b.res is not None and (t.mode & capi.BNB_STORE_MASKED) and self.dt == BF16 and bm_ and bn_
+                and (64 << (bm_ - 1)) * (16 << bn_) <= 4096 and not b.res.grad_written and b.res.galias is None and b.res.grad is None):
+            # the residual operand is a BatchNorm output without activation whose gradient will BE the masked dz stored here: its backward sums ride in this
+            # epilogue too (LDS-DMA / matrix-core form: tiles of <= 4096 elements); its producer then finds them like any other epilogue statistics
+            rb = b.res.bnb
+            c = ep.c
+            c.mode, c.raw, c.ld_raw, c.par, c.ps = capi.BNB_STATS, rb.raw.data_ptr(), rb.raw.stride(2), rb.par.data_ptr(), rb.par.stride(0)
+            q1, q2 = self.fbuf(nblk, Cp), self.fbuf(nblk, Cp)
+            c.p1, c.p2, c.ldp = q1.data_ptr(), q2.data_ptr(), Cp
+            b.res.add_bstats(0, Cp, q1, q2, nblk, Cp)
         if b.split:
             t.split = b.split
             if b.par2 is not None:
