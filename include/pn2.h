@@ -464,6 +464,11 @@ int pn2_mutation_loss_bwd(const float* const* fg, const float* const* bg, float*
 /* ---------------------------------------------------------------------------------------------- element-wise / layout */
 int pn2_binary(int dt, int op /*0 add,1 mul*/, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream);
 int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld_d, int M, int C, int accumulate, void* stream);
+/* Many same-dtype copies (16-byte aligned rows) in ONE launch from a DEVICE job table - the pass-through slices of independent chains at one lock-step position
+ * (pranet.py:77-79: branch0 of the three RFB modules into their concat buffers; the same slices of the gradient in the backward pass).  Bit-identical to pn2_copy per job. */
+typedef struct pn2_copy_job { const void* src; void* dst; int ld_s, ld_d, M, C, accumulate, pad_; } pn2_copy_job;
+int pn2_copy_job_blocks(int dt, const pn2_copy_job* j);
+int pn2_copy_multi(int dt, const pn2_copy_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
 int pn2_nchw_to_nhwc(int dt_out, const float* x, void* y, int ld_y, int N, int C, int HW, int Cp, void* stream);   /* pad channels zeroed */
 int pn2_bias_grad(const float* dy, int M, int K, float* db, int accumulate, void* stream);   /* db[k] = sum_m dy[m][k] (fp32 head maps) */
 

@@ -1019,7 +1019,7 @@ int pn2_bn_bwd_finalize_job_blocks(pn2_bnbfin_job* j) {
     if (j->sg.nseg < 1 || j->sg.nseg > 4 || j->sg.c0[0] != 0) return -2;
     int nmax = 1;
     for (int k = 0; k < j->sg.nseg; ++k) {
-        if (!j->sg.p1[k] || !j->sg.p2[k] || (j->sg.nblk[k] < 1 && j->sg.nblk[k] != -1) || j->sg.ldp[k] < 1) return -1;
+        if (!j->sg.p1[k] || !j->sg.p2[k] || j->sg.nblk[k] < 1 || j->sg.ldp[k] < 1) return -1;
         if (j->sg.nblk[k] > nmax) nmax = j->sg.nblk[k];
     }
     j->cpb = finalize_cpb(nmax);

@@ -360,6 +360,28 @@ __global__ __launch_bounds__(256) void copy_k(const Ti* __restrict__ s, int ld_s
     }
 }
 
+// table-driven copies of one dtype (16-byte vectors): the pass-through slices of independent chains at one lock-step position (the branch0 outputs of the three RFB
+// modules into their concat buffers, pranet.py:77-79, and the same slices of the gradient on the way back) as ONE launch
+template <typename T>
+__global__ __launch_bounds__(256) void copy_tab_k(const pn2_copy_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    constexpr int W = TT<T>::VEC;
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_copy_job j = jobs[jb];
+    const unsigned b = blockIdx.x - bstart[jb], nb = bstart[jb + 1] - bstart[jb];
+    const T* __restrict__ s = (const T*)j.src; T* __restrict__ d = (T*)j.dst;
+    const int CV = j.C / W;
+    const size_t total = (size_t)j.M * CV;
+    for (size_t idx = (size_t)b * 256u + threadIdx.x; idx < total; idx += (size_t)nb * 256u) {
+        const int m = (int)(idx / CV), c = (int)(idx % CV) * W;
+        float x[W];
+        VL<T, W>::load(s + (size_t)m * j.ld_s + c, x);
+        if (j.accumulate) { float o[W]; VL<T, W>::load(d + (size_t)m * j.ld_d + c, o);
+#pragma unroll
+            for (int e = 0; e < W; ++e) x[e] += o[e]; }
+        VL<T, W>::store(d + (size_t)m * j.ld_d + c, x);
+    }
+}
+
 template <typename To>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_k(const float* __restrict__ x, To* __restrict__ y, int ld_y, int N, int C, int HW, int Cp) {
     const size_t total = (size_t)N * HW;
@@ -527,6 +549,23 @@ int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld
         hipLaunchKernelGGL((copy_k<float, bf16_t, 1>), dim3(grid_for((size_t)M * C)), dim3(256), 0, st, (const float*)src, ld_s, (bf16_t*)dst, ld_d, M, C, accumulate);
     else if (dt_in == PN2_BF16 && dt_out == PN2_F32)
         hipLaunchKernelGGL((copy_k<bf16_t, float, 1>), dim3(grid_for((size_t)M * C)), dim3(256), 0, st, (const bf16_t*)src, ld_s, (float*)dst, ld_d, M, C, accumulate);
+    else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_copy_job_blocks(int dt, const pn2_copy_job* j) {
+    if (!j || !j->src || !j->dst || j->M < 1 || j->C < 1) return -1;
+    const int V = dt == PN2_F32 ? 4 : 8;
+    if ((dt != PN2_F32 && dt != PN2_BF16) || j->C % V || j->ld_s % V || j->ld_d % V) return -2;
+    const size_t vecs = (size_t)j->M * (j->C / V);
+    const size_t nb = (vecs + 1023) / 1024;          // four 16-byte vectors per thread
+    return (int)(nb > 4096 ? 4096 : nb);
+}
+int pn2_copy_multi(int dt, const pn2_copy_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    if (dt == PN2_BF16) hipLaunchKernelGGL(copy_tab_k<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    else if (dt == PN2_F32) hipLaunchKernelGGL(copy_tab_k<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
     else return -3;
     PN2_CHECK_LAUNCH();
     return 0;

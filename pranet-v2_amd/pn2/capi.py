@@ -93,6 +93,10 @@ class BnSegs(C.Structure):
     _fields_ = [("nseg", C.c_int), ("c0", C.c_int * 4), ("nblk", C.c_int * 4), ("ldp", C.c_int * 4), ("p1", C.c_void_p * 4), ("p2", C.c_void_p * 4)]
 
 
+class CopyJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ld_s", C.c_int), ("ld_d", C.c_int), ("M", C.c_int), ("C", C.c_int), ("accumulate", C.c_int), ("pad_", C.c_int)]
+
+
 class ConvJob(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("wp", C.c_void_p), ("out", C.c_void_p), ("psum", C.c_void_p), ("psq", C.c_void_p), ("d", ConvDesc), ("pad_", C.c_int), ("ep", ConvEp)]
 
@@ -249,6 +253,8 @@ SIGNATURES = {
     "pn2_mutation_loss_bwd": [P, P, P, P, P, P, I, LL, I, FL, FL, FL, P, FL, P],
     "pn2_binary": [I, I, P, I, P, I, P, I, I, I, I, P],
     "pn2_copy": [I, P, I, I, P, I, I, I, I, P],
+    "pn2_copy_job_blocks": [I, C.POINTER(CopyJob)],
+    "pn2_copy_multi": [I, P, P, I, I, P],
     "pn2_nchw_to_nhwc": [I, P, P, I, I, I, I, I, P],
     "pn2_bias_grad": [P, I, I, P, I, P],
     "pn2_resize_ksize": [I, I],
@@ -264,7 +270,7 @@ SIGNATURES = {
     "pn2_eval_wfm": [P, P, I, I, P, C.c_double, P, P, P, P],
 }
 # entry points that return a value rather than a status
-_VALUE_FUNCS = {"pn2_conv_gemm_tile", "pn2_conv_gemm_job_blocks", "pn2_bn_finalize_job_blocks", "pn2_affine_job_blocks", "pn2_bn_bwd_finalize_job_blocks",
+_VALUE_FUNCS = {"pn2_copy_job_blocks", "pn2_conv_gemm_tile", "pn2_conv_gemm_job_blocks", "pn2_bn_finalize_job_blocks", "pn2_affine_job_blocks", "pn2_bn_bwd_finalize_job_blocks",
                 "pn2_bn_bwd_apply_job_blocks", "pn2_bn_bwd_reduce_job_blocks", "pn2_dwconv3x3_colsum_blocks", "pn2_resize_ksize", "pn2_colsum_job_blocks", "pn2_colsum_finalize_blocks", "pn2_dwconv3x3_wgrad_blocks", "pn2_conv_tile_n", "pn2_wgrad_tile_co", "pn2_conv_stat_blocks", "pn2_conv_tile_m", "pn2_bn_bwd_blocks", "pn2_loss_blocks",
                 "pn2_pack_blocks", "pn2_wgrad_reduce_blocks", "pn2_conv_wgrad_variant", "pn2_conv_wgrad_blocks",
                 "pn2_dsra_tail_blocks", "pn2_dsra_tail_scratch", "pn2_dsra_tail_fused_ok", "pn2_dsra_tail_fused_scratch", "pn2_ln_slots", "pn2_rows_blocks", "pn2_colsum_unit", "pn2_attn_bwd_blocks", "pn2_mutation_loss_blocks", "pn2_mutation_loss_width",

@@ -124,7 +124,18 @@ def _bnreduce_job(a):
     return (("bnreduce", dt), j, nb) if nb >= 1 else None
 
 
+def _copy_job(a):
+    dt_in, src, ld_s, dt_out, dst, ld_d, M, Cc, acc, _st = a
+    if dt_in != dt_out:
+        return None
+    j = capi.CopyJob()
+    j.src, j.dst, j.ld_s, j.ld_d, j.M, j.C, j.accumulate = _v(src), _v(dst), ld_s, ld_d, M, Cc, acc
+    nb = call.pn2_copy_job_blocks(dt_in, C.byref(j))
+    return (("copy", dt_in), j, nb) if nb >= 1 else None
+
+
 CONVERT = {
+    "pn2_copy": _copy_job,
     "pn2_conv_gemm": lambda a: _conv_job(a, False),
     "pn2_conv_gemm_ep": lambda a: _conv_job(a, True),
     "pn2_conv_gemm_affine": lambda a: _conv_job(a, 2),
@@ -269,6 +280,8 @@ class Lockstep:
                     call.pn2_bn_bwd_apply_multi(kind[1], _p(table), _p(bstart), n, total, st)
                 elif kind[0] == "bnreduce":
                     call.pn2_bn_bwd_reduce_multi(kind[1], _p(table), _p(bstart), n, total, st)
+                elif kind[0] == "copy":
+                    call.pn2_copy_multi(kind[1], _p(table), _p(bstart), n, total, st)
         self.lanes = []
 
     _RUN_OUT = {"pn2_bn_finalize": 8, "pn2_bn_bwd_finalize": 9, "pn2_bn_bwd_finalize_seg": 7}          # index of the launch's private output row (scale / coef)

@@ -275,11 +275,7 @@ class ConvOps:
         if fuse_bias:
             out = Act(self, self.empty(N, OH, OW, Cout_p), Cout, gw_o, gwp_o, self.dt)
             raw = out.t
-            if Cout_p == Cout:
-                bvec = bias.detach()
-            else:
-                bvec = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
-                bvec[:Cout] = bias.detach()
+            bvec = self._padded_bias(bias, Cout, Cout_p)
         elif raw_out is not None:
             assert tuple(raw_out.shape) == (N, OH, OW, Cout_p) and raw_out.dtype == self.tdt and raw_out.stride(2) % V == 0
             raw = raw_out
@@ -364,11 +360,7 @@ class ConvOps:
                 if bias is not None:
                     shift[:Cout] += bias.detach() * scale[:Cout]
         elif bias is not None:
-            if Cout_p == Cout:
-                shift = bias.detach()
-            else:
-                shift = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
-                shift[:Cout] = bias.detach()
+            shift = self._padded_bias(bias, Cout, Cout_p)
 
         y_dt = self.dt if y_dt is None else y_dt
         pidx = None
@@ -679,6 +671,25 @@ class ConvOps:
 
         self.record(bwd)
         return out if y2 is None else (out, y2)
+
+    def _padded_bias(self, bias, Cout, Cout_p):
+        """[Cout_p] fp32 row: the bias in its first Cout slots, zeros behind.  With a persistent pack cache the row persists (its pad slots are written once) and a step
+        refreshes it with ONE copy instead of a fill + a copy (the K-channel head convs of pranet.py:104-105,303-325: 4 launches per step fewer)."""
+        if Cout_p == Cout:
+            return bias.detach()
+        cache = self.pack_cache
+        if cache is None:
+            row = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
+        else:
+            rows = cache.__dict__.setdefault("bias_rows", {})
+            row = rows.get((id(bias), Cout_p))
+            if row is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("run an eager step before capturing (the padded bias rows are created then)")
+                row = rows[(id(bias), Cout_p)] = torch.zeros(Cout_p, dtype=torch.float32, device=self.dev)
+                cache.__dict__.setdefault("bias_keep", []).append(bias)          # (id(bias) stays unique while the row exists)
+        row[:Cout].copy_(bias.detach())
+        return row
 
     def _bn_eval_rows(self, bn, M, Cout_p, Cout, gw_o, gwp_o, bias=None):
         """-> (scale, shift) fp32 [Cout_p] rows of an eval-mode BatchNorm (bias of the conv in front folded into shift).  With a BnFoldCache the rows persist and
