@@ -179,13 +179,21 @@ def _dsra_tail(m, eng, t1, ra5_fg, ra5_bg):
         t = getattr(m, f"ra{s}_conv3")._build(eng, t, relu=True, x_last=True)
         return getattr(m, f"ra{s}_conv4_fg")._build(eng, t, head=True, x_last=True), getattr(m, f"ra{s}_conv4_bg")._build(eng, t, head=True)
     (f4, b4), (f3, b3), (f2, b2) = eng.lockstep("dsra.stacks", [lambda: stack(4), lambda: stack(3), lambda: stack(2)])
+    # K = 1 with the softmax gate (every model the binary scripts build): softmax over ONE channel is identically 1 whatever the crop maps hold, the fusion is fg + fg
+    # and no gradient reaches the crops - so they are not resampled at all (six bilinear launches per step; the fusion kernel gets fg itself as a stand-in operand and
+    # computes softmax(fg - fg) = 1: the same bits).  PN2_ZERO_CROP_SKIP=0 keeps the reference's data flow.
+    from pn2 import core as _core
+    if f4.C == 1 and m.use_softmax and _core.ZERO_CROP_SKIP:
+        crop = lambda a, s, stand_in: stand_in
+    else:
+        crop = lambda a, s, stand_in: up(a, s)
     # ---- DSRA3
-    f = eng.dsra_fuse(f4, up(ra5_fg, 0.25), up(ra5_bg, 0.25), m.use_softmax)
+    f = eng.dsra_fuse(f4, crop(ra5_fg, 0.25, f4), crop(ra5_bg, 0.25, f4), m.use_softmax)
     b = b4
     l4_fg, l4_bg = final(f, 32 / sd, 2), final(b, 32 / sd, 6)
     lat = {}
     for s, u, fs, bs in ((3, 16, f3, b3), (2, 8, f2, b2)):
-        f = eng.dsra_fuse(fs, up(f, 2), up(b, 2), m.use_softmax)
+        f = eng.dsra_fuse(fs, crop(f, 2, fs), crop(b, 2, fs), m.use_softmax)
         b = bs
         lat[s] = (final(f, u / sd, s - 2), final(b, u / sd, s + 2))     # slot = position in the returned 8-tuple
     return [lat[2][0], lat[3][0], l4_fg, l5_fg, lat[2][1], lat[3][1], l4_bg, l5_bg]
