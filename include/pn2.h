@@ -251,6 +251,8 @@ int pn2_bn_bwd_finalize_multi(const pn2_bnbfin_job* jobs_dev, const int* block_s
 typedef struct pn2_bnapply_job { const void* dy; const void* y; const void* x; const float* mean; const float* invstd; const float* coef; void* dx; void* dres;
                                  const float* msc; const float* msh; int ld_dy, ld_y, ld_x, ld_dx, ld_dres, M, Cp, dres_accum, r6, rows_per_blk, cvp, pad_; } pn2_bnapply_job;
 int pn2_bn_bwd_apply_job_blocks(int dt, pn2_bnapply_job* j);
+#define PN2_MULTI_F32DY 0x200  /* OR into the dt (PN2_BF16) of pn2_bn_bwd_apply / _reduce job_blocks + _multi: the jobs' dy is fp32 with job.pad_ channels (the K-channel head maps of bf16 layers: element-wise / scalar kernels, as pn2_bn_bwd_apply / _reduce launch for that dtype pair) */
+#define PN2_MULTI_F32OUT 0x200 /* ... and of pn2_affine_job_blocks / pn2_affine_multi: bf16 in, fp32 out (element-wise kernel) */
 #define PN2_MULTI_LEAN 0x100   /* OR into pn2_bn_bwd_apply_multi's dt when NO job of the table has y or dres: the launch runs the register-lean instantiation */
 int pn2_bn_bwd_apply_multi(int dt, const pn2_bnapply_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream);
 typedef struct pn2_bnreduce_job { const void* dy; const void* y; const void* x; const float* mean; const float* invstd; float* p1; float* p2;

@@ -169,12 +169,12 @@ __global__ __launch_bounds__(256) void bn_eval_prepare_tab(const pn2_bnprep_job*
 // y = act(x*scale + shift + res)
 // ---------------------------------------------------------------------------------------------
 template <typename Ti, typename To, int W>
-__global__ __launch_bounds__(256) void affine_act_k(const Ti* __restrict__ x, int ld_x, To* __restrict__ y, int ld_y, int M, int C,
-                                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    const Ti* __restrict__ res, int ld_res, int relu) {
+__device__ __forceinline__ void affine_act_body(const Ti* __restrict__ x, int ld_x, To* __restrict__ y, int ld_y, int M, int C,
+                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                const Ti* __restrict__ res, int ld_res, int relu, unsigned bid, unsigned nb) {
     const int CV = C / W;
     const size_t total = (size_t)M * CV;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    for (size_t idx = (size_t)bid * 256 + threadIdx.x; idx < total; idx += (size_t)nb * 256) {
         int c; const int m = (int)divmod_idx(idx, CV, c); c *= W;
         float v[W], r[W];
         VL<Ti, W>::load(x + (size_t)m * ld_x + c, v);
@@ -193,6 +193,19 @@ __global__ __launch_bounds__(256) void affine_act_k(const Ti* __restrict__ x, in
             for (int e = 0; e < W; ++e) TT<To>::st(y + (size_t)m * ld_y + c + e, v[e]);
         }
     }
+}
+template <typename Ti, typename To, int W>
+__global__ __launch_bounds__(256) void affine_act_k(const Ti* __restrict__ x, int ld_x, To* __restrict__ y, int ld_y, int M, int C,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    const Ti* __restrict__ res, int ld_res, int relu) {
+    affine_act_body<Ti, To, W>(x, ld_x, y, ld_y, M, C, scale, shift, res, ld_res, relu, blockIdx.x, gridDim.x);
+}
+// table form of the element-wise kernel for bf16 -> fp32 outputs (the K-channel head maps: W = 1): the head convs of independent chains at one lock-step position
+__global__ __launch_bounds__(256) void affine_act_tab_f32out(const pn2_affine_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_affine_job j = jobs[jb];
+    affine_act_body<bf16_t, float, 1>((const bf16_t*)j.x, j.ld_x, (float*)j.y, j.ld_y, j.M, j.C, j.scale, j.shift, (const bf16_t*)j.res, j.ld_res, j.relu,
+                                      blockIdx.x - bstart[jb], bstart[jb + 1] - bstart[jb]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -470,6 +483,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_tab(const pn2_bnreduce_job*
                                          j.rows_per_blk, j.cvp, j.msc, j.msh, j.r6, blockIdx.x - bstart[jb]);
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_reduce_tab_f32dy(const pn2_bnreduce_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_bnreduce_job j = jobs[jb];
+    bn_bwd_reduce_body<bf16_t, float, 1>((const float*)j.dy, j.ld_dy, j.pad_, (const bf16_t*)j.y, j.ld_y, (const bf16_t*)j.x, j.ld_x, j.M, j.Cp, j.mean, j.invstd, j.p1, j.p2,
+                                         j.rows_per_blk, j.cvp, j.msc, j.msh, j.r6, blockIdx.x - bstart[jb]);
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ p1, const float* __restrict__ p2, int nblk, pn2_bn_desc d,
                                                          const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                          float* dgamma, float* dbeta, int accumulate, float* coef, int CPB) {
@@ -530,13 +550,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_tab(const pn2_bnbfin_job*
 }
 
 template <typename T, typename Tdy, int W>
-__global__ __launch_bounds__(256) void bn_bwd_apply_k(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
-                                                      const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
-                                                      const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
-                                                      T* __restrict__ dres, int ld_dres, int dres_accum, int r6) {
+__device__ __forceinline__ void bn_bwd_apply_body(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
+                                                  const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
+                                                  const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
+                                                  T* __restrict__ dres, int ld_dres, int dres_accum, int r6, unsigned bid, unsigned nb) {
     const int CV = Cp / W;
     const size_t total = (size_t)M * CV;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    for (size_t idx = (size_t)bid * 256 + threadIdx.x; idx < total; idx += (size_t)nb * 256) {
         int c; const int m = (int)divmod_idx(idx, CV, c); c *= W;
         float g[W], xv[W], yv[W], o[W], rr[W];
         if (W > 1 || c < Cdy) VL<Tdy, W>::load(dy + (size_t)m * ld_dy + c, g); else g[0] = 0.f;
@@ -555,6 +575,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const Tdy* __restrict__ dy
         VL<T, W>::store(dx + (size_t)m * ld_dx + c, o);
         if (dres) VL<T, W>::store(dres + (size_t)m * ld_dres + c, rr);
     }
+}
+template <typename T, typename Tdy, int W>
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const Tdy* __restrict__ dy, int ld_dy, int Cdy, const T* __restrict__ y, int ld_y,
+                                                      const T* __restrict__ x, int ld_x, int M, int Cp, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, const float* __restrict__ coef, T* __restrict__ dx, int ld_dx,
+                                                      T* __restrict__ dres, int ld_dres, int dres_accum, int r6) {
+    bn_bwd_apply_body<T, Tdy, W>(dy, ld_dy, Cdy, y, ld_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, r6, blockIdx.x, gridDim.x);
+}
+// table forms for fp32 gradients of bf16 layers (PN2_MULTI_F32DY: the K-channel head maps; job.pad_ = Cdy, the gradient's channel count): element-wise apply, scalar reduce
+__global__ __launch_bounds__(256) void bn_bwd_apply_tab_f32dy(const pn2_bnapply_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int jb = find_job(bstart, njobs, blockIdx.x);
+    const pn2_bnapply_job j = jobs[jb];
+    bn_bwd_apply_body<bf16_t, float, 1>((const float*)j.dy, j.ld_dy, j.pad_, (const bf16_t*)j.y, j.ld_y, (const bf16_t*)j.x, j.ld_x, j.M, j.Cp, j.mean, j.invstd, j.coef,
+                                        (bf16_t*)j.dx, j.ld_dx, (bf16_t*)j.dres, j.ld_dres, j.dres_accum, j.r6, blockIdx.x - bstart[jb], bstart[jb + 1] - bstart[jb]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -873,7 +907,7 @@ int pn2_bn_bwd_finalize_seg(const pn2_bn_segs* segs, const pn2_bn_desc* d, const
     if (segs->nseg < 1 || segs->nseg > 4 || segs->c0[0] != 0) return -2;
     int nmax = 1;
     for (int k = 0; k < segs->nseg; ++k) {
-        if (!segs->p1[k] || !segs->p2[k] || (segs->nblk[k] < 1 && segs->nblk[k] != -1) || segs->ldp[k] < 1) return -1;
+        if (!segs->p1[k] || !segs->p2[k] || segs->nblk[k] < 1 || segs->ldp[k] < 1) return -1;
         if (k && segs->c0[k] <= segs->c0[k - 1]) return -2;
         if (segs->nblk[k] > nmax) nmax = segs->nblk[k];
     }
@@ -999,6 +1033,10 @@ int pn2_bn_finalize_multi(const pn2_bnfin_job* jobs_dev, const int* block_start_
 
 int pn2_affine_job_blocks(int dt, pn2_affine_job* j) {
     if (!j || !j->x || !j->y) return -1;
+    if (dt == (PN2_BF16 | PN2_MULTI_F32OUT)) {          // bf16 in, fp32 out, element-wise (pn2_affine_act's own grid)
+        if (j->y2 || j->add || j->M < 1 || j->C < 1) return -2;
+        return grid_for((size_t)j->M * j->C);
+    }
     const int V = dt == PN2_F32 ? 4 : 8;
     if (j->C % V || j->ld_x % V || j->ld_y % V || (j->res && j->ld_res % V) || (j->y2 && (!j->add || j->ld_add % V || j->ld_y2 % V))) return -2;
     int nblk;
@@ -1007,7 +1045,8 @@ int pn2_affine_job_blocks(int dt, pn2_affine_job* j) {
 }
 int pn2_affine_multi(int dt, const pn2_affine_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
     if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
-    if (dt == PN2_BF16) hipLaunchKernelGGL((affine_rows_tab<bf16_t>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    if (dt == (PN2_BF16 | PN2_MULTI_F32OUT)) hipLaunchKernelGGL(affine_act_tab_f32out, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    else if (dt == PN2_BF16) hipLaunchKernelGGL((affine_rows_tab<bf16_t>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
     else if (dt == PN2_F32) hipLaunchKernelGGL((affine_rows_tab<float>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
     else return -3;
     PN2_CHECK_LAUNCH();
@@ -1035,6 +1074,7 @@ int pn2_bn_bwd_finalize_multi(const pn2_bnbfin_job* jobs_dev, const int* block_s
 int pn2_bn_bwd_apply_job_blocks(int dt, pn2_bnapply_job* j) {
     if (!j || !j->dy || !j->dx) return -1;
     if (j->coef && (!j->x || !j->mean || !j->invstd)) return -1;
+    if (dt == (PN2_BF16 | PN2_MULTI_F32DY)) return (j->M < 1 || j->Cp < 1 || j->pad_ < 1) ? -2 : grid_for((size_t)j->M * j->Cp);
     const int V = dt == PN2_F32 ? 4 : 8;
     if (j->Cp % V || j->ld_dy % V || j->ld_dx % V || (j->coef && j->ld_x % V) || (j->y && j->ld_y % V) || (j->dres && j->ld_dres % V)) return -2;
     int nblk;
@@ -1043,9 +1083,14 @@ int pn2_bn_bwd_apply_job_blocks(int dt, pn2_bnapply_job* j) {
 }
 int pn2_bn_bwd_apply_multi(int dt, const pn2_bnapply_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
     if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == (PN2_BF16 | PN2_MULTI_F32DY)) {
+        hipLaunchKernelGGL(bn_bwd_apply_tab_f32dy, dim3(total_blocks), dim3(256), 0, st, jobs_dev, block_start_dev, njobs);
+        PN2_CHECK_LAUNCH();
+        return 0;
+    }
     const bool lean = dt & PN2_MULTI_LEAN;
     dt &= ~PN2_MULTI_LEAN;
-    hipStream_t st = (hipStream_t)stream;
     if (dt == PN2_BF16 && lean) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<bf16_t, true>), dim3(total_blocks), dim3(256), 0, st, jobs_dev, block_start_dev, njobs);
     else if (dt == PN2_BF16) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<bf16_t, false>), dim3(total_blocks), dim3(256), 0, st, jobs_dev, block_start_dev, njobs);
     else if (dt == PN2_F32 && lean) hipLaunchKernelGGL((bn_bwd_apply_rows_tab<float, true>), dim3(total_blocks), dim3(256), 0, st, jobs_dev, block_start_dev, njobs);
@@ -1057,6 +1102,12 @@ int pn2_bn_bwd_apply_multi(int dt, const pn2_bnapply_job* jobs_dev, const int* b
 
 int pn2_bn_bwd_reduce_job_blocks(int dt, pn2_bnreduce_job* j) {
     if (!j || !j->dy || !j->x || !j->mean || !j->invstd || !j->p1 || !j->p2 || j->nblk < 1) return -1;
+    if (dt == (PN2_BF16 | PN2_MULTI_F32DY)) {          // the scalar form of bwd_reduce_dispatch<bf16_t, float>
+        if (j->pad_ < 1) return -2;
+        int cvp = pow2ceil(j->Cp); if (cvp > 256) cvp = 256;
+        j->cvp = cvp; j->rows_per_blk = (j->M + j->nblk - 1) / j->nblk;
+        return j->nblk;
+    }
     const int V = dt == PN2_F32 ? 4 : 8;
     if (j->Cp % V || j->ld_dy % V || j->ld_x % V || (j->y && j->ld_y % V)) return -2;
     int cvp = pow2ceil(j->Cp / V); if (cvp > 256) cvp = 256;
@@ -1065,7 +1116,8 @@ int pn2_bn_bwd_reduce_job_blocks(int dt, pn2_bnreduce_job* j) {
 }
 int pn2_bn_bwd_reduce_multi(int dt, const pn2_bnreduce_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
     if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1) return -1;
-    if (dt == PN2_BF16) hipLaunchKernelGGL((bn_bwd_reduce_tab<bf16_t>), dim3(total_blocks), dim3(256), 2 * 256 * 8 * 4, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    if (dt == (PN2_BF16 | PN2_MULTI_F32DY)) hipLaunchKernelGGL(bn_bwd_reduce_tab_f32dy, dim3(total_blocks), dim3(256), 2 * 256 * 4, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
+    else if (dt == PN2_BF16) hipLaunchKernelGGL((bn_bwd_reduce_tab<bf16_t>), dim3(total_blocks), dim3(256), 2 * 256 * 8 * 4, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
     else if (dt == PN2_F32) hipLaunchKernelGGL((bn_bwd_reduce_tab<float>), dim3(total_blocks), dim3(256), 2 * 256 * 4 * 4, (hipStream_t)stream, jobs_dev, block_start_dev, njobs);
     else return -3;
     PN2_CHECK_LAUNCH();

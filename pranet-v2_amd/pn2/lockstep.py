@@ -77,6 +77,10 @@ def _affine_job(a, with_sum):
         res, ld_res = None, 0
     else:
         dt, x, ld_x, dt_out, y, ld_y, M, Cc, scale, shift, res, ld_res, relu, _st = a
+        if dt == capi.BF16 and dt_out == capi.F32 and MIXED:          # K-channel head maps: the element-wise kernel in table form
+            j.x, j.ld_x, j.y, j.ld_y, j.M, j.C, j.scale, j.shift, j.res, j.ld_res, j.relu = _v(x), ld_x, _v(y), ld_y, M, Cc, _v(scale), _v(shift), _v(res), ld_res, relu
+            nb = call.pn2_affine_job_blocks(dt | MULTI_F32, C.byref(j))
+            return (("affine", dt | MULTI_F32), j, nb) if nb >= 1 else None
         if dt_out != dt or _v(scale) is None or _v(shift) is None:
             return None
     j.x, j.ld_x, j.y, j.ld_y, j.M, j.C, j.scale, j.shift, j.res, j.ld_res, j.relu = _v(x), ld_x, _v(y), ld_y, M, Cc, _v(scale), _v(shift), _v(res), ld_res, relu
@@ -102,6 +106,12 @@ def _bnbfin_job(a, seg):
 
 def _bnapply_job(a):
     dt, dt_dy, dy, ld_dy, Cdy, y, ld_y, dt_y, x, ld_x, M, Cp, mean, invstd, coef, dx, ld_dx, dres, ld_dres, dres_accum, msc, msh, r6, _st = a
+    if dt == capi.BF16 and dt_dy == capi.F32 and MIXED and _v(msc) is None and (_v(y) is None or dt_y == dt):          # fp32 gradient of a bf16 layer (K-channel heads)
+        j = capi.BnApplyJob()
+        j.dy, j.ld_dy, j.y, j.ld_y, j.x, j.ld_x, j.M, j.Cp, j.pad_ = _v(dy), ld_dy, _v(y), ld_y, _v(x), ld_x, M, Cp, Cdy
+        j.mean, j.invstd, j.coef, j.dx, j.ld_dx, j.dres, j.ld_dres, j.dres_accum, j.r6 = _v(mean), _v(invstd), _v(coef), _v(dx), ld_dx, _v(dres), ld_dres, dres_accum, r6
+        nb = call.pn2_bn_bwd_apply_job_blocks(dt | MULTI_F32, C.byref(j))
+        return (("bnapply", dt | MULTI_F32), j, nb) if nb >= 1 else None
     if dt != dt_dy or Cdy != Cp or (_v(y) is not None and dt_y != dt):
         return None
     j = capi.BnApplyJob()
@@ -115,6 +125,12 @@ def _bnapply_job(a):
 
 def _bnreduce_job(a):
     dt, dt_dy, dy, ld_dy, Cdy, y, ld_y, dt_y, x, ld_x, M, Cp, mean, invstd, p1, p2, nblk, msc, msh, r6, _st = a
+    if dt == capi.BF16 and dt_dy == capi.F32 and MIXED and (_v(y) is None or dt_y == dt):
+        j = capi.BnReduceJob()
+        j.dy, j.ld_dy, j.y, j.ld_y, j.x, j.ld_x, j.M, j.Cp, j.pad_ = _v(dy), ld_dy, _v(y), ld_y, _v(x), ld_x, M, Cp, Cdy
+        j.mean, j.invstd, j.p1, j.p2, j.nblk, j.msc, j.msh, j.r6 = _v(mean), _v(invstd), _v(p1), _v(p2), nblk, _v(msc), _v(msh), r6
+        nb = call.pn2_bn_bwd_reduce_job_blocks(dt | MULTI_F32, C.byref(j))
+        return (("bnreduce", dt | MULTI_F32), j, nb) if nb >= 1 else None
     if dt != dt_dy or Cdy != Cp or (_v(y) is not None and dt_y != dt):
         return None
     j = capi.BnReduceJob()
@@ -153,6 +169,8 @@ SINGLE = tuple(n for n in capi.SIGNATURES if n not in CONVERT and n not in capi.
 _ACTIVE = []        # stack of recording Lockstep objects (innermost last)
 import os
 _NOBATCH = set(os.environ.get("PN2_LOCKSTEP_NOBATCH", "").split(","))      # debugging: launch names that are never batched
+MULTI_F32 = 0x200                                                             # PN2_MULTI_F32DY / PN2_MULTI_F32OUT (pn2.h)
+MIXED = os.environ.get("PN2_LOCKSTEP_MIXED", "1") == "1"                    # bf16 layers with fp32 K-channel maps (the head convs of the DSRA stages) join table-driven launches too
 COALESCE = os.environ.get("PN2_LOCKSTEP_COALESCE", "1") == "1"              # runs of BatchNorm finalize launches of one lane share a position (see Lockstep.emit)
 
 
