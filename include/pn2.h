@@ -465,6 +465,9 @@ int pn2_mutation_loss_bwd(const float* const* fg, const float* const* bg, float*
 
 /* ---------------------------------------------------------------------------------------------- element-wise / layout */
 int pn2_binary(int dt, int op /*0 add,1 mul*/, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream);
+/* backward of out = a * b in one pass: ga (+)= g * b, gb (+)= g * a (the bits two pn2_binary launches leave; ga != gb) */
+int pn2_mul_bwd(int dt, const void* g, int ld_g, const void* a, int ld_a, const void* b, int ld_b, void* ga, int ld_ga, int acc_a, void* gb, int ld_gb, int acc_b,
+                int M, int C, void* stream);
 int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld_d, int M, int C, int accumulate, void* stream);
 /* Many same-dtype copies (16-byte aligned rows) in ONE launch from a DEVICE job table - the pass-through slices of independent chains at one lock-step position
  * (pranet.py:77-79: branch0 of the three RFB modules into their concat buffers; the same slices of the gradient in the backward pass).  Bit-identical to pn2_copy per job. */

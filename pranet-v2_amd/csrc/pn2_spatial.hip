@@ -340,6 +340,27 @@ __global__ __launch_bounds__(256) void binary_k(int op, const T* __restrict__ a,
     }
 }
 
+// backward of out = a * b in ONE pass over the gradient: ga (+)= g * b, gb (+)= g * a (two pn2_binary launches otherwise; the aggregation's products, pranet.py:111-119)
+template <typename T, int W>
+__global__ __launch_bounds__(256) void mul_bwd_k(const T* __restrict__ g, int ld_g, const T* __restrict__ a, int ld_a, const T* __restrict__ b, int ld_b,
+                                                 T* __restrict__ ga, int ld_ga, int acc_a, T* __restrict__ gb, int ld_gb, int acc_b, int M, int C) {
+    const int CV = C / W;
+    const size_t total = (size_t)M * CV;
+    PIX_LOOP(total) {
+        const int m = (int)(idx / CV), c = (int)(idx % CV) * W;
+        float gv[W], x[W], y[W], oa[W], ob[W];
+        VL<T, W>::load(g + (size_t)m * ld_g + c, gv); VL<T, W>::load(a + (size_t)m * ld_a + c, x); VL<T, W>::load(b + (size_t)m * ld_b + c, y);
+        if (acc_a) VL<T, W>::load(ga + (size_t)m * ld_ga + c, oa);
+        if (acc_b) VL<T, W>::load(gb + (size_t)m * ld_gb + c, ob);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const float ra = gv[e] * y[e], rb = gv[e] * x[e];
+            oa[e] = acc_a ? oa[e] + ra : ra; ob[e] = acc_b ? ob[e] + rb : rb;
+        }
+        VL<T, W>::store(ga + (size_t)m * ld_ga + c, oa); VL<T, W>::store(gb + (size_t)m * ld_gb + c, ob);
+    }
+}
+
 template <typename Ti, typename To, int W>
 __global__ __launch_bounds__(256) void copy_k(const Ti* __restrict__ s, int ld_s, To* __restrict__ d, int ld_d, int M, int C, int accumulate) {
     const int CV = C / W;
@@ -550,6 +571,20 @@ int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld
     else if (dt_in == PN2_BF16 && dt_out == PN2_F32)
         hipLaunchKernelGGL((copy_k<bf16_t, float, 1>), dim3(grid_for((size_t)M * C)), dim3(256), 0, st, (const bf16_t*)src, ld_s, (float*)dst, ld_d, M, C, accumulate);
     else return -3;
+    PN2_CHECK_LAUNCH();
+    return 0;
+}
+
+int pn2_mul_bwd(int dt, const void* g, int ld_g, const void* a, int ld_a, const void* b, int ld_b, void* ga, int ld_ga, int acc_a, void* gb, int ld_gb, int acc_b,
+                int M, int C, void* stream) {
+    if (!g || !a || !b || !ga || !gb || ga == gb) return -1;
+    PN2_TOO_MANY((size_t)M * C);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dt, {
+        if (vec_ok<T>(C, ld_g, ld_a, ld_b) && vec_ok<T>(C, ld_ga, ld_gb))
+            hipLaunchKernelGGL((mul_bwd_k<T, TT<T>::VEC>), dim3(grid_for((size_t)M * C / TT<T>::VEC)), dim3(256), 0, st, (const T*)g, ld_g, (const T*)a, ld_a, (const T*)b, ld_b, (T*)ga, ld_ga, acc_a, (T*)gb, ld_gb, acc_b, M, C);
+        else hipLaunchKernelGGL((mul_bwd_k<T, 1>), dim3(grid_for((size_t)M * C)), dim3(256), 0, st, (const T*)g, ld_g, (const T*)a, ld_a, (const T*)b, ld_b, (T*)ga, ld_ga, acc_a, (T*)gb, ld_gb, acc_b, M, C);
+    })
     PN2_CHECK_LAUNCH();
     return 0;
 }

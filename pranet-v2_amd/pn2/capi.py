@@ -252,6 +252,7 @@ SIGNATURES = {
     "pn2_mutation_loss_fwd": [P, P, P, P, I, LL, I, FL, FL, FL, P, P, P, P],
     "pn2_mutation_loss_bwd": [P, P, P, P, P, P, I, LL, I, FL, FL, FL, P, FL, P],
     "pn2_binary": [I, I, P, I, P, I, P, I, I, I, I, P],
+    "pn2_mul_bwd": [I, P, I, P, I, P, I, P, I, I, P, I, I, I, I, P],
     "pn2_copy": [I, P, I, I, P, I, I, I, I, P],
     "pn2_copy_job_blocks": [I, C.POINTER(CopyJob)],
     "pn2_copy_multi": [I, P, P, I, I, P],

@@ -393,6 +393,7 @@ DW_COLSUM = os.environ.get("PN2_DW_COLSUM", "1") == "1"             # PVTv2 Mlp:
 MASKED_STORE = os.environ.get("PN2_MASKED_STORE", "1") == "1"       # ... which then stores dy * [y > 0] for BN + residual + ReLU outputs (residual gradient aliases it)
 POOL_BWD_QUAD = os.environ.get("PN2_POOL_BWD_QUAD", "1") == "1"  # ... and its backward without the full-resolution gradient tensor (pn2_pool_bn_bwd_reduce / _apply); 0: pool-backward launch + the generic BatchNorm passes
 RES_STATS = os.environ.get("PN2_RES_STATS", "1") == "1"          # the downsample BatchNorm's backward sums from the dgrad epilogue that forms bn3's masked gradient (pn2_conv_ep.c): no reduce pass
+MUL_BWD = os.environ.get("PN2_MUL_BWD", "1") == "1"              # backward of a product (the aggregation's): both operand gradients from one pass (pn2_mul_bwd); 0: two pn2_binary launches
 POOL_FOLD = os.environ.get("PN2_POOL_FOLD", "1") == "1"          # Bottle2neck stage blocks: the backward of the downsample branch's AvgPool2d(2, 2) rides in conv1's dgrad epilogue (pn2_conv_ep.pool) - no pool-backward launch
 POOL_FUSE = os.environ.get("PN2_POOL_FUSE", "1") == "1"          # the stem's bn1 -> ReLU -> MaxPool as one op: the 176 x 176 BatchNorm output is never written (conv_bn_act(pool=True))
 TEE_CONCAT = os.environ.get("PN2_TEE_CONCAT", "1") == "1"         # Bottle2neck: conv1 + bn1 + ReLU writes its pass-through slice into the concat buffer as well (pn2_affine_act_tee); False: a copy launch

@@ -138,6 +138,11 @@ class SpatialOps:
             if alias:
                 assert not b._written, "grad_alias: the aliased operand received another gradient"
                 b.grad_written = True
+            if core.MUL_BWD and op == 1 and a.requires_grad and b.requires_grad and a.grad_buf().data_ptr() != b.grad_buf().data_ptr():
+                ga, acc_a = a.grad_sink()          # both gradients of the product from ONE pass over gy
+                gb, acc_b = b.grad_sink()
+                call.pn2_mul_bwd(a.dt, _p(gy), gy.stride(2), a.ptr, a.ld, b.ptr, b.ld, _p(ga), ga.stride(2), acc_a, _p(gb), gb.stride(2), acc_b, a.M, a.Cp, st)
+                return
             for u, v in ((a, b), (b, a)):
                 if not u.requires_grad or (alias and u is b):
                     continue

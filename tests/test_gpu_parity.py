@@ -306,6 +306,31 @@ def test_pool_and_bilinear_ops(dtn):
         run(lambda e, a: e.bilinear(a, scale, ac), lambda t: F.interpolate(t, scale_factor=scale, mode="bilinear", align_corners=ac), torch.randn(2, C, H, H, device=dev))
 
 
+@pytest.mark.parametrize("dtn", ["fp32", "bf16"])
+def test_product_backward_one_pass_matches_two_launches_and_torch(dtn, monkeypatch):
+    """eng.mul's backward (pn2_mul_bwd: both operand gradients from one pass over dy) = the two pn2_binary launches, bit for bit, fresh and accumulating."""
+    from pn2 import F32, BF16, core
+    from pn2.engine import Engine
+    from pn2.graph import _seed_grad
+    dt = F32 if dtn == "fp32" else BF16
+    torch.manual_seed(5)
+    xa, xb = torch.randn(2, 24, 9, 11, device=dev), torch.randn(2, 24, 9, 11, device=dev)
+    g = torch.randn(2, 24, 9, 11, device=dev)
+
+    def run(one_pass):
+        monkeypatch.setattr(core, "MUL_BWD", one_pass)
+        eng = Engine(dt, True, need_grad=True)
+        a, b = eng.from_nchw(xa, True), eng.from_nchw(xb, True)
+        y = eng.add(eng.mul(a, b), eng.mul(b, a))          # the second product accumulates into both gradients
+        _seed_grad(y, g); eng.backward()
+        return a.grad.clone(), b.grad.clone()
+    (a1, b1), (a2, b2) = run(True), run(False)
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    q = (lambda t: t.bfloat16().float()) if dt == BF16 else (lambda t: t)
+    tol = 1e-5 if dt == F32 else 2e-2
+    assert relmax(a1.float().permute(0, 3, 1, 2), 2 * q(g) * q(xb)) < tol and relmax(b1.float().permute(0, 3, 1, 2), 2 * q(g) * q(xa)) < tol
+
+
 def test_dsra_fusion_k9_golden():
     from pn2 import F32
     from pn2.engine import Engine, Act
