@@ -97,7 +97,7 @@ def fp32_line(model_ctor, x, m, steps=5, mode="fp32"):
     peak = PEAK_F32_TFLOPS if mode == "fp32fast" else PEAK_F64_TFLOPS
     out = {"value": round(x.shape[0] / el, 2), "unit": "images/sec", "ms_per_step": round(1e3 * el, 3), "steps": steps, "peak_tf": peak,
            "mfma_frac_whole_step": round(x.shape[0] / el * TRAIN_GFLOP_PER_IMG / 1e3 / peak, 4),
-           "note": ("fp32 storage; fp32 products and sums on v_mfma_f32_16x16x4_f32 (157.3 TF/s dense peak), chains of 4 MFMAs met by round-to-nearest adds" if mode == "fp32fast" else
+           "note": ("fp32 storage; fp32 products and sums on v_mfma_f32_16x16x4_f32 (157.3 TF/s dense peak), chains of 4 (forward / data gradient) or 8 (weight gradient) MFMAs met by round-to-nearest adds" if mode == "fp32fast" else
                     "fp32 storage; conv products / sums in double on v_mfma_f64_16x16x4_f64 (78.6 TF/s dense peak), one rounding per output")}
     try:          # the conv GEMM family of this mode against ITS matrix pipe (event-timed instrumented step, as the headline's roofline)
         r = prof.measure_step(tr, x, m, "fp32")["roofline"]

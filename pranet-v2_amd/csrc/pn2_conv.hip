@@ -22,7 +22,9 @@ namespace {
 
 constexpr int ROWB = 128;      // bytes of K per LDS row per step (64 bf16 or 32 f32): two 64-byte MFMA sub-steps
 constexpr int KSUB = ROWB / 64;
-constexpr int RS = ROWB + 16;  // padded LDS row stride (bytes): 36 banks -> the 16 rows of a fragment read hit 16 distinct 16-B slots
+constexpr int RS = ROWB;       // LDS row stride of the gather kernels (bytes): no padding - the eight 16-byte slots of a row are XOR-swizzled with (row & 7).  ds_read_b128 is served in
+                               // lane groups {0-3, 12-15, 20-27}, ... (not 16 consecutive lanes): with the 144-byte padded rows used before, a group's g = 0 and g = 1 lanes met on 7 of 8
+                               // slots (SQ_LDS_BANK_CONFLICT = 30 % of SQ_LDS_IDX_ACTIVE on the fp32fast GEMMs); the swizzle is conflict-free for the reads and the stores, and 11 % smaller
 
 // Phase stamps of the conv kernels (debug build only: make stamp -> libpn2_stamp.so, read by tools/stamp_micro.py): thread 0 of every workgroup
 // leaves s_memtime at the phase boundaries, so that a launch can be taken apart into prologue / first DMA landing / K loop / C staging / stores.
@@ -997,6 +999,7 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
 
     // ---- per-thread A rows
     const int kv = tid & 7;
+    const int wslot = (kv ^ ((tid >> 3) & 7)) << 4;          // this thread's (swizzled) 16-byte slot in its LDS rows: row = (tid >> 3) + 32 i
     int rbase[NA], riy0[NA], rix0[NA]; bool rok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -1026,7 +1029,7 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
     // the weight-panel vectors by literal index: with two register sets (DEEP) hipcc left an `unroll`-ed loop over RB_[i] as a loop and the arrays in scratch
 #define PN2_U4(N_, M_, X_, Y_) do { if constexpr ((N_) > 0) { M_(0, X_, Y_); } if constexpr ((N_) > 1) { M_(1, X_, Y_); } if constexpr ((N_) > 2) { M_(2, X_, Y_); } if constexpr ((N_) > 3) { M_(3, X_, Y_); } } while (0)
 #define PN2_GLOAD_B(i_, RB_, step_) RB_[i_] = *reinterpret_cast<const u32x4_t_*>(bptr + (size_t)(32 * (i_)) * d.Kp + (size_t)(step_) * BK)
-#define PN2_LSTORE_B(i_, RB_, Bs_) *reinterpret_cast<u32x4_t_*>(Bs_ + ((tid >> 3) + 32 * (i_)) * RS + kv * 16) = RB_[i_]
+#define PN2_LSTORE_B(i_, RB_, Bs_) *reinterpret_cast<u32x4_t_*>(Bs_ + ((tid >> 3) + 32 * (i_)) * RS + wslot) = RB_[i_]
 #define PN2_GLOAD(step_, RA_, RB_, AM_)                                                                                \
     do {                                                                                                               \
         AM_ = 0;                                                                                                       \
@@ -1060,7 +1063,7 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
         char* Bs_ = As_ + BM * RS;                                                                                     \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                               \
             const u32x4_t_ v_ = (AM_ >> i) & 1u ? RA_[i] : u32x4_t_{0u, 0u, 0u, 0u};                                   \
-            *reinterpret_cast<u32x4_t_*>(As_ + ((tid >> 3) + 32 * i) * RS + kv * 16) = v_;                             \
+            *reinterpret_cast<u32x4_t_*>(As_ + ((tid >> 3) + 32 * i) * RS + wslot) = v_;                               \
         }                                                                                                              \
         PN2_U4(NB, PN2_LSTORE_B, RB_, Bs_);                                                                            \
     } while (0)
@@ -1070,8 +1073,8 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
         const char* Bs = As + BM * RS;                                                                                 \
         _Pragma("unroll") for (int ks = 0; ks < KSUB; ++ks) {                                                          \
             uint4 a[MT], b[NT];                                                                                        \
-            _Pragma("unroll") for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(As + (wm * WTM + i * 16 + l15a) * RS + ks * 64 + g * 16); \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WTN + j * 16 + l15) * RS + ks * 64 + g * 16);  \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(As + (wm * WTM + i * 16 + l15a) * RS + (((ks * 4 + g) ^ (l15a & 7)) << 4)); \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WTN + j * 16 + l15) * RS + (((ks * 4 + g) ^ (l15 & 7)) << 4));  \
             MMA<T>::template run_block<MT, NT>(acc, a, b);                                                             \
         }                                                                                                              \
     } while (0)
@@ -1112,17 +1115,27 @@ __device__ __forceinline__ void conv_gather_body(const T* __restrict__ in, const
         PN2_GLOAD(last < 1 ? last : 1, ra1, rb1, amask1);
         PN2_LSTORE(0, ra, rb, amask);
         __syncthreads();
-        for (int step = 0; step < ksteps; step += 2) {
+        // Both halves of a pair run unconditionally (an odd last step is peeled): with the second half under `if (step + 1 < ksteps)` hipcc SANK the first half's
+        // requests into that branch (their only use), next to the second batch - one step of lead lost - and hoisted the zero-fill selects, and the wait with
+        // them, to the top of the MFMA block.  The scheduling fences pin request | MFMAs | zero-fill + LDS store inside a half.
+        int step = 0;
+        for (; step + 1 < ksteps; step += 2) {
             PN2_GLOAD(step + 2 < last ? step + 2 : last, ra, rb, amask);
+            __builtin_amdgcn_sched_barrier(0);
             PN2_MFMAS(0);
+            __builtin_amdgcn_sched_barrier(0);
             PN2_LSTORE(1, ra1, rb1, amask1);
             __syncthreads();
-            if (step + 1 < ksteps) {
-                PN2_GLOAD(step + 3 < last ? step + 3 : last, ra1, rb1, amask1);
-                PN2_MFMAS(1);
-                PN2_LSTORE(0, ra, rb, amask);
-                __syncthreads();
-            }
+            PN2_GLOAD(step + 3 < last ? step + 3 : last, ra1, rb1, amask1);
+            __builtin_amdgcn_sched_barrier(0);
+            PN2_MFMAS(1);
+            __builtin_amdgcn_sched_barrier(0);
+            PN2_LSTORE(0, ra, rb, amask);
+            __syncthreads();
+        }
+        if (step < ksteps) {
+            PN2_MFMAS(0);
+            __syncthreads();          // (the epilogue re-uses the stages)
         }
     }
 #undef PN2_GLOAD
@@ -1588,9 +1601,9 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
             } else {
                 f32x4_t part[MMA<T>::F64ROWS ? 1 : MT][MMA<T>::F64ROWS ? 1 : NT];
 #ifndef PN2_WCH
-#define PN2_WCH 4
+#define PN2_WCH 8
 #endif
-                constexpr int WCH = PN2_WCH;          // MFMAs per chain (x 4 pixels)
+                constexpr int WCH = PN2_WCH;          // MFMAs per chain (x 4 pixels): 8 = the 32 pixels of a stage (4: +1.4 % step time for gradients no closer to float64 - bs32 probes: median rel-L2 1.7e-6 / 1.9e-6, reference fp32 3.3e-6)
 #pragma unroll
                 for (int q = 0; q < WGP / 4; ++q) {       // 4 pixels per 16x16x4 MFMA
                     float a[MT], b[NT];
@@ -1603,7 +1616,7 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
                             if constexpr (MMA<T>::F64ROWS) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[i], (double)b[j], acc[i][j], 0, 0, 0);
-                            else {          // PN2_F32F: chains of 4 MFMAs (16 pixels) from C = 0, met by round-to-nearest adds (see MMA<f32f_t>)
+                            else {          // PN2_F32F: chains of WCH MFMAs (4 WCH pixels) from C = 0, met by round-to-nearest adds (see MMA<f32f_t>)
                                 if ((q & (WCH - 1)) == 0) part[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                                 else part[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], part[i][j], 0, 0, 0);
                                 if ((q & (WCH - 1)) == WCH - 1) acc[i][j] += part[i][j];
