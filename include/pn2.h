@@ -465,7 +465,8 @@ int pn2_mutation_loss_bwd(const float* const* fg, const float* const* bg, float*
 
 /* ---------------------------------------------------------------------------------------------- element-wise / layout */
 int pn2_binary(int dt, int op /*0 add,1 mul*/, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int M, int C, int accumulate, void* stream);
-/* backward of out = a * b in one pass: ga (+)= g * b, gb (+)= g * a (the bits two pn2_binary launches leave; ga != gb) */
+/* backward of out = a * b in one pass (autograd of the aggregation's products x2_1 = conv_upsample1(up(x1)) * x2 ..., pranet.py:111-119): ga (+)= g * b, gb (+)= g * a -
+ * the bits two pn2_binary launches leave; ga != gb */
 int pn2_mul_bwd(int dt, const void* g, int ld_g, const void* a, int ld_a, const void* b, int ld_b, void* ga, int ld_ga, int acc_a, void* gb, int ld_gb, int acc_b,
                 int M, int C, void* stream);
 int pn2_copy(int dt_in, const void* src, int ld_s, int dt_out, void* dst, int ld_d, int M, int C, int accumulate, void* stream);
