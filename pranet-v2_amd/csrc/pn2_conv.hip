@@ -2045,8 +2045,8 @@ int launch_gemm(const void* in, const void* wp, void* out, float* psum, float* p
         static bool done = false;
         if (!done) {
             const int cap = E2 ? 160 * 1024 : lds0;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, true, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, false, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, true, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm<T, BM, BN, WM, WN, false, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
             done = true;
         }
     }
@@ -2074,8 +2074,8 @@ int launch_dma(const void* in, const void* wp, void* out, float* psum, float* ps
         static bool done = false;
         if (!done) {
             const int cap = E2 ? 160 * 1024 : (max_b > epi_b ? max_b : epi_b);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, true, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, false, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, true, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm<BM, BN, WM, WN, false, NS, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
             done = true;
         }
     }
@@ -2104,8 +2104,8 @@ int launch_dma_ks(const void* in, const void* wp, void* out, float* psum, float*
     {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_ks<BM, BN, WM, WN, true, NS, EP, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_ks<BM, BN, WM, WN, false, NS, EP, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_ks<BM, BN, WM, WN, true, NS, EP, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_ks<BM, BN, WM, WN, false, NS, EP, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             done = true;
         }
     }
@@ -2217,7 +2217,7 @@ int launch_dma_tab(const pn2_conv_job* jobs, const int* bstart, int njobs, int t
     if (lds > 160 * 1024) return -4;
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_tab<BM, BN, WM, WN, false, 3, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, EP ? 160 * 1024 : lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_tab<BM, BN, WM, WN, false, 3, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, EP ? 160 * 1024 : lds);
         done = true;
     }
     hipLaunchKernelGGL((conv_dma_gemm_tab<BM, BN, WM, WN, false, 3, EP>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
@@ -2236,7 +2236,7 @@ int launch_dma_tab_ks2(const pn2_conv_job* jobs, const int* bstart, int njobs, i
     if (lds > 160 * 1024) return -4;
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_tab_ks2<BM, BN, WM, WN, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_gemm_tab_ks2<BM, BN, WM, WN, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         done = true;
     }
     hipLaunchKernelGGL((conv_dma_gemm_tab_ks2<BM, BN, WM, WN, EP>), dim3(total), dim3(512), lds, st, jobs, bstart, njobs);
@@ -2249,7 +2249,7 @@ int launch_gather_tab_f32(const pn2_conv_job* jobs, const int* bstart, int njobs
     constexpr int lds = (main_b > epi_b ? main_b : epi_b) > ep_b ? (main_b > epi_b ? main_b : epi_b) : ep_b;
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm_tab<T, BM, BN, WM, WN, false, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gather_gemm_tab<T, BM, BN, WM, WN, false, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
     hipLaunchKernelGGL((conv_gather_gemm_tab<T, BM, BN, WM, WN, false, EP>), dim3(total), dim3(256), lds, st, jobs, bstart, njobs);
@@ -2313,8 +2313,8 @@ int launch_wgrad_dma(const void* dy, const void* x, float* slab, const pn2_wgrad
     if (max_b > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma<BMC, WM, WN, true, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma<BMC, WM, WN, false, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma<BMC, WM, WN, true, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma<BMC, WM, WN, false, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
             done = true;
         }
     }
@@ -2383,8 +2383,8 @@ int launch_wgrad_dma_tab(bool pw, const pn2_wgrad_job* jobs, const int* bstart, 
     if (max_b > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab<BMC, WM, WN, true, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab<BMC, WM, WN, false, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab<BMC, WM, WN, true, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab<BMC, WM, WN, false, BNK>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b);
             done = true;
         }
     }

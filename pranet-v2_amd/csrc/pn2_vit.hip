@@ -1469,7 +1469,7 @@ int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, voi
     const int qpb = 64;
     const dim3 grid((Nq + qpb - 1) / qpb, heads, B);
     hipStream_t st = (hipStream_t)stream;
-#define PN2_ATTN_FWD(NKV) { if (lds > 64 * 1024) { static bool done = false; if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_k<T, NKV>), \
+#define PN2_ATTN_FWD(NKV) { if (lds > 64 * 1024) { static bool done = false; if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_k<T, NKV>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; } } \
         hipLaunchKernelGGL((attn_fwd_k<T, NKV>), grid, dim3(256), lds, st, (const T*)q, ld_q, (const T*)kv, ld_kv, (T*)out, ld_o, lse, Nq, Nkv, heads, scale, qpb); }
     constexpr bool use_mfma = true;
@@ -1479,7 +1479,7 @@ int pn2_attn_fwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, voi
         const int ntile = (Nq + 127) / 128;
         int gx = (attn_target_blocks() + B * heads - 1) / (B * heads); if (gx > ntile) gx = ntile; if (gx < 1) gx = 1;
         const dim3 gm(gx, heads, B);
-#define PN2_ATTN_FWD_M(NKV) { if (lm > 64 * 1024) { static bool done = false; if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_k<NKV>), \
+#define PN2_ATTN_FWD_M(NKV) { if (lm > 64 * 1024) { static bool done = false; if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_k<NKV>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); done = true; } } \
         hipLaunchKernelGGL((attn_fwd_mfma_k<NKV>), gm, dim3(512), lm, st, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, (bf16_t*)out, ld_o, lse, Nq, Nkv, heads, scale); }
         if (NK == 1) PN2_ATTN_FWD_M(1) else if (NK == 2) PN2_ATTN_FWD_M(2) else PN2_ATTN_FWD_M(4)
@@ -1519,12 +1519,12 @@ int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, con
             const size_t lm = ((size_t)np * ATR + (size_t)np * 72 + 2 * 64 * ATR + 64 * (np + 8) + 2 * (size_t)np * 72) * 2;
             if (nkb == 2) {
                 static bool done = false;
-                if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); done = true; }
+                if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); done = true; }
                 hipLaunchKernelGGL(attn_bwd_mfma_k<2>, grid, dim3(256), lm, st, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, (const bf16_t*)dout, ld_do, lse, delta, (bf16_t*)dq, ld_dq,
                                    partial, Nq, Nkv, heads, scale, key0, NP, key0 > 0 ? 1 : 0);
             } else {
                 static bool done1 = false;
-                if (!done1) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); done1 = true; }
+                if (!done1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); done1 = true; }
                 hipLaunchKernelGGL(attn_bwd_mfma_k<1>, grid, dim3(256), lm, st, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, (const bf16_t*)dout, ld_do, lse, delta, (bf16_t*)dq, ld_dq,
                                    partial, Nq, Nkv, heads, scale, key0, NP, key0 > 0 ? 1 : 0);
             }
@@ -1537,7 +1537,7 @@ int pn2_attn_bwd(int dt, const void* q, int ld_q, const void* kv, int ld_kv, con
     const int QB = NK == 4 ? 2 : AT_QB;                 // 256 keys: smaller query groups so that K, V and the tiles fit the 160 KiB of LDS
     const size_t lds = ((size_t)2 * 64 * (NP + 1) + 2 * 4 * QB * NP + 2 * 4 * QB * 64) * 4;
     const dim3 grid(nqb, heads, B);
-#define PN2_ATTN_BWD(NKV, QBV) { if (lds > 64 * 1024) { static bool done = false; if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_k<T, NKV, QBV>), \
+#define PN2_ATTN_BWD(NKV, QBV) { if (lds > 64 * 1024) { static bool done = false; if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_k<T, NKV, QBV>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; } } \
         hipLaunchKernelGGL((attn_bwd_k<T, NKV, QBV>), grid, dim3(256), lds, st, (const T*)q, ld_q, (const T*)kv, ld_kv, (const T*)dout, ld_do, lse, (T*)dq, ld_dq, \
                            partial, Nq, Nkv, heads, scale); }
