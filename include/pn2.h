@@ -139,7 +139,8 @@ int pn2_conv_wgrad(int dtype, const void* dy, const void* x, float* slab, const 
 /* Many weight gradients in ONE launch.  A wgrad only feeds the optimizer, so a training step may defer them (keeping dy / x alive)
  * and run all convs that share a kernel instantiation (pn2_conv_wgrad_variant) together, from a DEVICE job table.
  * block_start_dev: njobs + 1 prefix sums of pn2_conv_wgrad_blocks(&job.d, job.nsplit).  Same arithmetic, bit for bit, as
- * pn2_conv_wgrad on each job. */
+ * pn2_conv_wgrad on each job.  variant 14 (bf16): jobs of variants 12 AND 13 (the 128 x 256 LDS-DMA tile, k x k and pointwise) in one table - the k x k chains leave the
+ * memory system idle, the pointwise jobs stream; the caller interleaves the job ranges (pn2/core.py GradQueue._build). */
 typedef struct pn2_wgrad_job { const void* dy; const void* x; float* slab; pn2_wgrad_desc d; int nsplit;
     int rot;      /* 0..7: XCD rotation of this job's pixel splits (split s runs on XCD (s + rot) % 8): the caller advances it by nsplit % 8 from job to job, so the
                    * partial split groups of a table (nsplit = 3, 6, 12 ... on the long-contraction layers) spread over the 8 XCDs instead of piling onto the first ones */

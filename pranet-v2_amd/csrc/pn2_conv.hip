@@ -1850,6 +1850,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_tab(const pn2_wgrad_job* _
     }
 }
 
+// One table for the pointwise AND the k x k jobs of the 128 x 256 tile (variant 14): the k x k jobs are chains of ~121 32-pixel stages that leave the memory system idle
+// (1.2 TB/s over 330 us), the pointwise table streams at the HBM rate (4.7 TB/s over 670 us) - in ONE launch, job ranges interleaved by the host, a CU holds a
+// workgroup of each kind at a time.  Same per-job arithmetic as the two tables: bit-identical gradients.
+template <int BMC, int WM, int WN, int BNK>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_tab_mix(const pn2_wgrad_job* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+    const int total = bstart[njobs];
+    for (int b = blockIdx.x; b < total; b += gridDim.x) {
+        const int jb = find_job(bstart, njobs, b);
+        const pn2_wgrad_job j = jobs[jb];
+        const int bl = b - bstart[jb];
+        const int lb = (bl & ~7) | ((bl - j.rot) & 7);
+        if (j.d.KH == 1 && j.d.KW == 1 && j.d.stride == 1 && j.d.pad_h == 0 && j.d.pad_w == 0)
+            conv_wgrad_dma_body<BMC, WM, WN, true, BNK>((const bf16_t*)j.dy, (const bf16_t*)j.x, j.slab, j.d, j.nsplit, lb);
+        else
+            conv_wgrad_dma_body<BMC, WM, WN, false, BNK>((const bf16_t*)j.dy, (const bf16_t*)j.x, j.slab, j.d, j.nsplit, lb);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight packing (OIHW fp32 master -> K-contiguous panels in the compute dtype) and grad unpacking
 // ------------------------------------------------------------------------------------------------
@@ -2398,6 +2417,17 @@ template <typename T>
 int wgrad_multi_dispatch(int v, const pn2_wgrad_job* jobs, const int* bstart, int njobs, int total, hipStream_t st) {
     const bool pw = v & 1;
     const int bi = (v % 6) >> 1;
+    if (v == 14) {          // variants 12 + 13 in one table (conv_wgrad_dma_tab_mix)
+        if constexpr (sizeof(T) == 2) {
+            constexpr int max_b = 3 * wg_px(128) * (128 * 2 + 256 * 2);
+            static bool done = false;
+            if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_tab_mix<128, 2, 2, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, max_b); done = true; }
+            hipLaunchKernelGGL((conv_wgrad_dma_tab_mix<128, 2, 2, 256>), dim3(total), dim3(256), max_b, st, jobs, bstart, njobs);
+            PN2_CHECK_LAUNCH();
+            return 0;
+        }
+        return -3;
+    }
     if (v >= 12) {
         if constexpr (sizeof(T) == 2) return launch_wgrad_dma_tab<128, 2, 2, 256>(pw, jobs, bstart, njobs, total, st);
         return -3;
@@ -2745,7 +2775,7 @@ int pn2_conv_wgrad_blocks(const pn2_wgrad_desc* d, int nsplit) {
 }
 
 int pn2_conv_wgrad_multi(int dtype, int variant, const pn2_wgrad_job* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, void* stream) {
-    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1 || variant < 0 || variant >= 14) return -1;
+    if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1 || variant < 0 || variant >= 15) return -1;
     if (dtype == PN2_BF16) return wgrad_multi_dispatch<bf16_t>(variant, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
     if (dtype == PN2_F32) return wgrad_multi_dispatch<float>(variant, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);
     if (dtype == PN2_F32F) return wgrad_multi_dispatch<f32f_t>(variant, jobs_dev, block_start_dev, njobs, total_blocks, (hipStream_t)stream);

@@ -364,6 +364,7 @@ class StepArena:
 TUNE_COLD = os.environ.get("PN2_TUNE_COLD", "1") == "1"             # the tuners time every candidate behind a cache-evicting fill (tests/conftest.py switches it off)
 WGRAD_WGS = 640               # pixel splits: workgroups a single wgrad aims at ...
 WGRAD_SLAB_MB = 24            # ... within this many MB of fp32 slabs
+WGRAD_MIX = float(os.environ.get("PN2_WGRAD_MIX", "2"))          # > 0: the pointwise and the k x k weight-gradient jobs of the 128 x 256 tile share ONE table-driven launch (GradQueue._build; the value = how much faster the k x k list is consumed); 0: two launches
 WGRAD_SLAB_CAP = float(os.environ.get("PN2_WGRAD_SLAB_CAP", "0.35"))   # table-driven wgrad: fp32 slab bytes of a job <= this x its operand bytes (GradQueue.table_splits; 0: off)
 WGRAD_ROTATE = os.environ.get("PN2_WGRAD_ROTATE", "1") == "1"      # table-driven wgrad: a job's pixel splits start on the XCD after the previous job's last one
 _THRASH = {}
@@ -469,10 +470,32 @@ class GradQueue:
             if v < 0:
                 raise RuntimeError("unsupported wgrad geometry")
             groups.setdefault((dt, v), []).append((dy, x, slab, wd, ns, fl))
+        order = lambda js: sorted(js, key=lambda j: -((j[3].N * j[3].OH * j[3].OW + j[4] - 1) // j[4]) * j[3].KH * j[3].KW)
+        mixed = {}
+        if WGRAD_MIX > 0:
+            # the k x k (variant 12) and pointwise (13) jobs of the 128 x 256 tile in ONE table (14): chains of ~121 stages that leave the memory system idle next to jobs that stream
+            # at the HBM rate.  Job ranges interleaved so that a CU holds a workgroup of each kind: the k x k list is consumed WGRAD_MIX times as fast as the pointwise list
+            # (its chains must not start late), both in their longest-first order.
+            for dt in {k[0] for k in groups}:
+                a, b = groups.get((dt, 12)), groups.get((dt, 13))
+                if a and b:
+                    a, b = order(a), order(b)
+                    real = lambda j: j[4] * call.pn2_conv_wgrad_blocks(C.byref(j[3]), j[4]) // (8 * ((j[4] + 7) // 8))          # workgroups that do work (the rest of a tile's 8 XCD slots exit)
+                    ta, tb = sum(real(j) for j in a) or 1, sum(real(j) for j in b) or 1
+                    out, ia, ib, ca, cb = [], 0, 0, 0, 0
+                    while ia < len(a) or ib < len(b):
+                        if ib >= len(b) or (ia < len(a) and ca / (ta / WGRAD_MIX) <= cb / tb):
+                            out.append(a[ia]); ca += real(a[ia]); ia += 1
+                        else:
+                            out.append(b[ib]); cb += real(b[ib]); ib += 1
+                    del groups[(dt, 12)], groups[(dt, 13)]
+                    groups[(dt, 14)] = out
+                    mixed[(dt, 14)] = True
         for (dt, v), js in sorted(groups.items()):
             # longest workgroups first (pixels per split x taps): the hardware hands out workgroups in index order, so the short jobs fill the
             # tail of the launch instead of the long ones stretching it
-            js = sorted(js, key=lambda j: -((j[3].N * j[3].OH * j[3].OW + j[4] - 1) // j[4]) * j[3].KH * j[3].KW)
+            if (dt, v) not in mixed:
+                js = order(js)
             arr, load = [], [0] * 8
             for dy, x, slab, wd, ns, fl in js:
                 j = capi.WgradJob()

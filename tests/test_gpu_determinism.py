@@ -114,3 +114,33 @@ def test_one_pass_tail_is_order_independent_on_confident_logits():
     assert float((plain[0] - ref[0]).abs().max()) <= 2e-6 * float(ref[0].abs().max())
     for a, b in zip(plain[3], ref[3]):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max() + 1e-30)
+
+
+def test_mixed_weight_gradient_table_is_bit_identical_to_the_two_tables_bs32_bf16(monkeypatch):
+    """GradQueue._build with WGRAD_MIX (default): the k x k and the pointwise jobs of the 128 x 256 weight-gradient tile run from ONE table (conv_wgrad_dma_tab_mix, job ranges
+    interleaved) instead of two launches - same per-job arithmetic: loss, gradient arena and parameters after three steps bit for bit, at the benchmarked size (the
+    small fixtures have no job on that tile)."""
+    import pn2
+    from pn2 import core
+    from pn2.trainer import Trainer
+    from lib.pranet import PraNet_V2
+    from oracle import weights as W
+    pn2.set_compute_dtype("bf16")
+    x, m = W.synthetic_batch(32, 352, seed=1234)
+    x, m = x.to(dev), m.to(dev)
+    res, variants = [], []
+    real = core.call.pn2_conv_wgrad_multi
+    for mix in (0.0, 2.0):
+        monkeypatch.setattr(core, "WGRAD_MIX", mix)
+        seen = set()
+        monkeypatch.setattr(core.call, "pn2_conv_wgrad_multi", lambda dt, v, *a, _s=seen: (_s.add(v), real(dt, v, *a))[1], raising=False)
+        torch.manual_seed(0)
+        tr = Trainer(PraNet_V2(num_class=1).to(dev).train(), lr=1e-4, clip=0.5)
+        for _ in range(3):
+            loss = tr.step(x, m)
+        torch.cuda.synchronize()
+        res.append((loss.clone(), tr.gflat.clone(), tr.flat.clone()))
+        variants.append(seen)
+        monkeypatch.setattr(core.call, "pn2_conv_wgrad_multi", real, raising=False)
+    assert {12, 13} <= variants[0] and 14 not in variants[0] and 14 in variants[1] and not ({12, 13} & variants[1])
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

@@ -14,7 +14,7 @@ dev = "cuda"
 SWITCHES = [
     ("engine", "BNB_EPILOGUE", False), ("engine", "MASKED_STORE", False), ("engine", "LOCKSTEP", False), ("engine", "GRAD_ALIAS", False),
     ("engine", "SPLITK", False), ("engine", "FUSE_BIAS", False), ("engine", "DEFER_COLSUM", False), ("engine", "ZERO_CROP_SKIP", False),
-    ("engine", "PATCH_DGRAD", False), ("engine", "SMALL_CIN_DGRAD", False), ("engine", "WGRAD_SLAB_CAP", 0.0), ("engine", "WGRAD_ROTATE", False), ("engine", "TEE_CONCAT", False), ("engine", "POOL_FUSE", False), ("engine", "POOL_BWD_QUAD", False), ("engine", "POOL_FOLD", False), ("engine", "RES_STATS", False), ("engine", "MUL_BWD", False),
+    ("engine", "PATCH_DGRAD", False), ("engine", "SMALL_CIN_DGRAD", False), ("engine", "WGRAD_SLAB_CAP", 0.0), ("engine", "WGRAD_ROTATE", False), ("engine", "TEE_CONCAT", False), ("engine", "POOL_FUSE", False), ("engine", "POOL_BWD_QUAD", False), ("engine", "POOL_FOLD", False), ("engine", "RES_STATS", False), ("engine", "MUL_BWD", False), ("engine", "WGRAD_MIX", 0.0),
     ("res2net", "ALIAS_CAT_GRAD", False), ("lockstep", "COALESCE", False), ("lockstep", "MIXED", False),
     ("env", "PN2_FUSED_TAIL", "0"), ("env", "PN2_DEFER_WGRAD", "1"), ("env", "PN2_DEFER_WGRAD", "0"), ("env", "PN2_STEP_ARENA", "0"), ("env", "PN2_AUTOTUNE", "0"),
 ]
