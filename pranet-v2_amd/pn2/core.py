@@ -436,7 +436,7 @@ class GradQueue:
             t = self.slabs[key] = torch.empty(shape, dtype=torch.float32, device=dev)
         return t
 
-    def table_splits(self, nsplit, M, chans, wd):
+    def table_splits(self, nsplit, M, chans, wd, esize=2):
         """Pixel splits of a wgrad that runs inside a table-driven launch.  The tuner times a conv ALONE, where splits are what fills the chip; inside a table the
         other jobs do that, and every split costs a fp32 slab (Rp x Kp x 4 B written, then re-read by the reduce: 3.9 GB of the step's 46 GB with the tuned counts).
         The slabs of a job are therefore capped at WGRAD_SLAB_CAP (0.35) x the bytes of its own operands (dy + x): the long-contraction / few-pixel layers go from
@@ -445,7 +445,8 @@ class GradQueue:
         cap = self.slab_cap if self.slab_cap is not None else WGRAD_SLAB_CAP
         if cap <= 0:
             return nsplit
-        return min(nsplit, max(1, int(cap * M * chans * 2 // (wd.Rp * wd.Kp * 4))))
+        # esize: bytes per operand element (round 6: the fp32 paths passed through here with bf16's 2 - half the cap they were meant to have; fp32fast 42.3 -> 41.7 ms)
+        return min(nsplit, max(1, int(cap * M * chans * esize // (wd.Rp * wd.Kp * 4))))
 
     def add_wgrad(self, dt, dy, x_ptr, x_keep, slab, wd, nsplit, flops=0):
         self.wjobs.append((dt, dy.data_ptr(), x_ptr.value, slab.data_ptr(), wd, nsplit, flops))

@@ -544,7 +544,7 @@ class ConvOps:
             wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd, nsplit, w.shape)
             rq = self.grad_queue
             if rq is not None and rq.defer_wgrad:
-                nsplit = rq.table_splits(nsplit, M, x.Cp + Cout_p, wd)
+                nsplit = rq.table_splits(nsplit, M, x.Cp + Cout_p, wd, 4 if self.dt == F32 else 2)
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab((id(w), x.M), (nsplit, wd.Rp, wd.Kp), self.dev)
             gwt, gwa = self.pgrads.sink(w)
             # wgrad (+ slab reduce) only feeds the parameter gradient: with a gradient queue both are deferred into the table-driven launches of its flush
@@ -916,7 +916,7 @@ class ConvOps:
             wd.tune, nsplit = self._tune_wgrad(wd, _p(draw), x.ptr, rd0, nsplit, convs[0].weight.shape)
             rq = self.grad_queue
             if rq is not None and rq.defer_wgrad:
-                nsplit = rq.table_splits(nsplit, M, x.Cp + Ct, wd)
+                nsplit = rq.table_splits(nsplit, M, x.Cp + Ct, wd, 4 if self.dt == F32 else 2)
             slab = self.fbuf(nsplit, wd.Rp, wd.Kp) if rq is None else rq.slab(tuple(id(c.weight) for c in convs), (nsplit, wd.Rp, wd.Kp), self.dev)
             if rq is not None and rq.defer_wgrad:
                 rq.add_wgrad(self.dt, draw, x.ptr, x.t, slab, wd, nsplit, flops)
